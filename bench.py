@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py - MPC QP solves/sec on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+A step = one pass of the hot path (K1 assembly + K2 ADMM/polish) over one batch of B synthetic
+controller instances whose inputs are already resident in HBM.  N=1 workload: config 2 of
+BASELINE.json (B=1024 independent initial poses, reference tracking, horizon 30).  With --gpus N
+every rank solves its own batch of the same size (weak scaling, no data-path collective; the
+instances are independent) and `value` is the whole-job rate.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4] [--batch B]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, "multi-purpose-mpc_amd")]
+
+import mpmpc  # noqa: E402
+import scenarios  # noqa: E402
+
+HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
+FP64_VALU_PEAK = 78.6e12   # FLOP/s vector FP64 (spec)
+
+
+def algorithmic_bytes_per_solve(N, materialised=True):
+    """compulsory inputs + outputs per solve, plus the stage-blocked QP written by
+    K1 and read by K2 when the two-kernel split materialises it."""
+    inp = 8 * (7 * N + 3)
+    out = 8 * (5 * N + 3 + 2) + 8
+    qp = 2 * 8 * mpmpc.NUM_FIELDS * (N + 1) if materialised else 0
+    return inp + out + qp
+
+
+def k1_bytes_per_solve(N):
+    return 8 * (7 * N + 3) + 8 * mpmpc.NUM_FIELDS * (N + 1)
+
+
+def k2_bytes_per_solve(N):
+    return 8 * mpmpc.NUM_FIELDS * (N + 1) + 8 * (5 * N + 3 + 2 + 2) + 12
+
+
+def cpu_baseline(sc, qp, seconds=15.0):
+    """The oracle (own restatement of OSQP + certified polish) on the host cores of this box."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import oracle_c  # C port, all cores (oracle/osqp_port.c)
+        return oracle_c.timed_baseline(sc, qp, seconds)
+    except Exception:
+        pass
+    import osqp_np as O
+    import mpmpc_testlib as T
+    t0 = time.perf_counter()
+    done = 0
+    uref = []
+    while done < sc.B and time.perf_counter() - t0 < seconds:
+        Pd, q, A, l, u = T.qp_to_dense(qp[:, done, :], sc.N)
+        r = O.solve(np.diag(Pd), q, A, l, u, O.Settings(polish=2))
+        uref.append((r.status, r.x[3 * (sc.N + 1)], np.arctan(r.x[3 * (sc.N + 1) + 1] * scenarios.CAR_LENGTH)))
+        done += 1
+    dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="solves/s", cores=1, kind="port",
+                sample="first %d instances of the workload, dense numpy restatement (oracle/osqp_np.py), "
+                       "OSQP defaults + certified polish" % done), uref
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    tr = scenarios.sim_track()
+    spec = scenarios.CONFIGS[args.config]
+    B = args.batch or spec["B"]
+    # every rank gets its own slice of a world*B batch drawn from the config's seed
+    sc_all = scenarios.make(args.config, tr, B=B * world)
+    sl = slice(rank * B, (rank + 1) * B)
+    wp, x0, cc, lb, ub = sc_all.wp_id[sl], sc_all.x0[sl], sc_all.cc_prev[sl], sc_all.lb[sl], sc_all.ub[sl]
+    N = sc_all.N
+    Q, R, QN = scenarios.WEIGHTS[sc_all.weights]
+    cfg = mpmpc.make_config(N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX,
+                            scenarios.AY_MAX, scenarios.CAR_LENGTH, circular=True, max_batch=B, device=local_rank)
+    h = mpmpc.Handle(cfg, mpmpc.default_settings())
+    h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+    h.upload(wp, x0, cc, lb, ub)          # inputs resident in HBM before the timed region
+
+    def barrier():
+        h.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        h.solve_resident(B)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        h.solve_resident(B)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel durations, HIP events on the library's own stream
+    reps = max(5, min(args.steps, 20))
+    ka, ks = [], []
+    for _ in range(reps):
+        a, s = h.solve_resident_timed(B)
+        ka.append(a)
+        ks.append(s)
+    ms_k1, ms_k2 = float(np.mean(ka)), float(np.mean(ks))
+    sol = h.download(B, want_y=False)
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        out = {
+            "metric": "MPC QP solves/sec (batch, horizon N=%d)" % N,
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "config%d: batch=%d independent poses per GPU, %s weights, N=%d, %s corridor, "
+                                   "OSQP-default ADMM + certified polish" %
+                                   (args.config, B, sc_all.weights, N, "obstacle" if sc_all.obstacles else "free"),
+                       "batch_per_gpu": B, "horizon": N, "parallelism": "batch-shard x%d" % world},
+        }
+        bytes_k2 = k2_bytes_per_solve(N) * B
+        out["roofline"] = {"bound": "hbm", "kernel": "mpmpc_solve_kernel", "achieved": bytes_k2 / (ms_k2 * 1e-3) / 1e9,
+                           "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bytes_k2 / (ms_k2 * 1e-3) / HBM_PEAK,
+                           "traffic": None, "avg_ms": ms_k2,
+                           "note": "K2 is FP64-VALU / dependency-chain bound, not HBM bound (DESIGN.md section 5)"}
+        bytes_k1 = k1_bytes_per_solve(N) * B
+        out["roofline_assembly"] = {"bound": "hbm", "kernel": "mpmpc_assemble_kernel",
+                                    "achieved": bytes_k1 / (ms_k1 * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
+                                    "unit": "GB/s", "frac": bytes_k1 / (ms_k1 * 1e-3) / HBM_PEAK, "avg_ms": ms_k1}
+        st, cnt = np.unique(sol.status, return_counts=True)
+        out["status_counts"] = {int(s): int(c) for s, c in zip(st, cnt)}
+        out["iters"] = {"admm_mean": float(sol.iters[:, 0].mean()), "admm_max": int(sol.iters[:, 0].max()),
+                        "ipm_mean": float(sol.iters[:, 1].mean()), "ipm_max": int(sol.iters[:, 1].max())}
+        if not args.no_cpu:
+            qp = h.assemble(wp, x0, cc, lb, ub)
+            base, uref = cpu_baseline(scenarios.Scenario(sc_all.name, N, sc_all.weights, sc_all.obstacles, wp, x0, cc,
+                                                         lb, ub), qp)
+            out["cpu_baseline"] = base
+            err = 0.0
+            agree = 0
+            for i, (s, v, d) in enumerate(uref):
+                agree += int(s == sol.status[i])
+                if s == 1 and sol.status[i] == 1:
+                    err = max(err, abs(sol.u0[i, 0] - v), abs(sol.u0[i, 1] - d))
+            out["max_abs_u_minus_uref"] = err
+            out["status_agreement"] = agree / max(len(uref), 1)
+            out["host_cores"] = os.cpu_count()
+        print(json.dumps(out))
+    h.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

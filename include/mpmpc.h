@@ -1,0 +1,139 @@
+/* mpmpc -- C ABI of the MI355X-native batched LTV-MPC QP path.
+ *
+ * The reference (matssteinweg/Multi-Purpose-MPC) has no FFI layer: its hot path is the Python
+ * method MPC.get_control() (src/MPC.py:161-222), which rebuilds the horizon-stacked QP in
+ * MPC._init_problem() (src/MPC.py:61-159) and hands it to the third-party OSQP solver
+ * (src/MPC.py:158-159,183).  This header is the boundary a maintainer binds with ctypes to move
+ * that path onto the GPU for B independent controller instances per call.
+ *
+ * Conventions
+ *   - every array is caller-owned, C-contiguous HOST memory (numpy); the library owns all device
+ *     memory behind the opaque handle; one handle = one device = one stream; calls on one handle
+ *     are not re-entrant; every call that returns data is synchronous.
+ *   - functions return 0 on success, <0 on error; mpmpc_last_error() gives the thread-local text.
+ *   - all arithmetic is IEEE float64; nx = 3 states (e_y, e_psi, t), nu = 2 inputs (v, kappa).
+ *   - decision vector z = [x_0..x_N (3 each), u_0..u_{N-1} (2 each)], n = 5N+3, as in
+ *     src/MPC.py:128-147; constraint rows [3(N+1) dynamics ; 3(N+1) state boxes ; 2N input boxes].
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails.
+ */
+#ifndef MPMPC_H
+#define MPMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPMPC_NX 3
+#define MPMPC_NU 2
+#define MPMPC_MAX_HORIZON 63
+#define MPMPC_NUM_FIELDS 27 /* doubles per (instance, stage) of the stage-blocked QP, see below */
+
+/* per-instance status, OSQP's numbering (drives the fallback branch of src/MPC.py:208-216) */
+#define MPMPC_SOLVED 1
+#define MPMPC_SOLVED_INACCURATE 2
+#define MPMPC_MAX_ITER_REACHED (-2)
+#define MPMPC_PRIMAL_INFEASIBLE (-3)
+#define MPMPC_DUAL_INFEASIBLE (-4)
+#define MPMPC_UNSOLVED (-10)
+
+/* error codes */
+#define MPMPC_OK 0
+#define MPMPC_E_ARG (-1)
+#define MPMPC_E_HIP (-2)
+#define MPMPC_E_STATE (-3)
+
+typedef struct mpmpc_handle_s* mpmpc_handle;
+
+/* Controller constants: what MPC.__init__ stores (src/MPC.py:15-59) plus the model's wheelbase
+ * (src/spatial_bicycle_models.py:130) and the path's `circular` flag (src/reference_path.py:96).
+ * Q, R, QN are the DIAGONALS of the reference's weight matrices (src/simulation.py:101-103). */
+typedef struct {
+  int32_t N;          /* horizon, 3 <= N <= MPMPC_MAX_HORIZON (the kappa_pred quirk of MPC.py:86 needs N >= 3) */
+  int32_t max_batch;  /* largest B of any later call */
+  int32_t device;     /* HIP device ordinal */
+  int32_t circular;   /* ReferencePath.circular */
+  double Q[3], R[2], QN[3];
+  double xmin[3], xmax[3]; /* StateConstraints 'xmin','xmax' (may be +-inf) */
+  double umin[2], umax[2]; /* InputConstraints 'umin','umax' in (v, kappa) */
+  double ay_max;           /* MPC.ay_max */
+  double wheelbase;        /* model.length */
+} mpmpc_config;
+
+/* Solver settings: OSQP 0.6.x names and defaults for the ADMM stage (what
+ * osqp.OSQP().setup(..., verbose=False) of src/MPC.py:159 runs with), plus the certified polish. */
+typedef struct {
+  double rho, sigma, alpha;
+  double eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
+  int32_t max_iter, check_termination, scaling;
+  int32_t adaptive_rho, adaptive_rho_interval;
+  double adaptive_rho_tolerance;
+  int32_t polish;   /* 0: ADMM only (stock OSQP behaviour); 2: interior-point refine + active-set polish + certificate */
+  int32_t ipm_max_iter;
+  double ipm_tol, ipm_reg;
+  double as_delta;
+  int32_t as_refine, as_rounds;
+  double cert_tol;
+} mpmpc_settings;
+
+const char* mpmpc_version(void);
+const char* mpmpc_last_error(void);
+int mpmpc_device_count(int32_t* count);
+void mpmpc_default_settings(mpmpc_settings* s);
+
+/* replaces MPC.__init__ (src/MPC.py:15-59): allocates device buffers for max_batch instances */
+int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_handle* out);
+int mpmpc_destroy(mpmpc_handle h);
+int mpmpc_set_settings(mpmpc_handle h, const mpmpc_settings* settings);
+
+/* replaces the per-stage ReferencePath.get_waypoint() / Waypoint.__sub__ reads of
+ * src/MPC.py:93-97 (src/reference_path.py:50-57,356-371): per-waypoint kappa, v_ref and the
+ * distance to the next waypoint, uploaded once per path. */
+int mpmpc_set_path(mpmpc_handle h, int32_t n_wp, const double* kappa, const double* v_ref,
+                   const double* ds_next);
+
+/* replaces ReferencePath.update_path_constraints(wp_id+1, N, ...) of src/MPC.py:116-118 for a
+ * static map, where it depends on wp_id only (src/reference_path.py:522-648): row w of the
+ * [n_wp x n_cols] tables holds ub / lb for the n_cols waypoints after waypoint w. n_cols >= N. */
+int mpmpc_set_corridor(mpmpc_handle h, int32_t n_wp, int32_t n_cols, const double* ub,
+                       const double* lb);
+
+/* replaces MPC._init_problem (src/MPC.py:61-155) for B instances: LTV linearisation
+ * (src/spatial_bicycle_models.py:391-417) around waypoints wp_id+0..N-1, offsets, speed cap from
+ * the previous plan cc_prev (src/MPC.py:86-87,111-113), box bounds, references, cost vectors.
+ *   wp_id[B], x0[B*3] (= model.spatial_state), cc_prev[B*2N] (= MPC.current_control),
+ *   lb/ub [B*N]: per-instance corridor, or both NULL to use the table of mpmpc_set_corridor.
+ * qp_out (host, may be NULL) receives the stage-blocked QP [MPMPC_NUM_FIELDS][B][LD] with
+ * LD = mpmpc_stage_ld(N); field order: ds, a10, a20, b20, beq[3], lo[5], hi[5], q[5], p[5]
+ * (A_k = [[1,ds,0],[a10,1,0],[a20,0,1]], B_k = [[0,0],[0,ds],[b20,0]] couple stage k to k+1;
+ * beq = rhs of equality block k; lo/hi/q/p over (e_y,e_psi,t,v,kappa) of stage k). */
+int mpmpc_assemble(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x0,
+                   const double* cc_prev, const double* lb, const double* ub, double* qp_out);
+int32_t mpmpc_stage_ld(int32_t N);
+
+/* replaces _init_problem + osqp setup/solve + solution extraction (src/MPC.py:180-194) for B
+ * instances.  Outputs (any may be NULL): z[B*(5N+3)] primal solution (dec.x), u0[B*2] = (v_0,
+ * delta_0 = arctan(kappa_0 * wheelbase)) as returned by get_control, status[B], iters[B*2]
+ * (ADMM iterations, interior-point iterations), resid[B*2] (primal, dual residual, unscaled),
+ * y[B*(8N+6)] multipliers in the reference's row order. */
+int mpmpc_solve(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x0,
+                const double* cc_prev, const double* lb, const double* ub, double* z, double* u0,
+                int32_t* status, int32_t* iters, double* resid, double* y);
+
+/* Split form of mpmpc_solve for callers that keep inputs resident in HBM (benchmarks, closed
+ * loops): upload once, launch any number of times (asynchronous on the handle's stream),
+ * synchronise, download. */
+int mpmpc_upload(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x0,
+                 const double* cc_prev, const double* lb, const double* ub);
+int mpmpc_solve_resident(mpmpc_handle h, int32_t B);
+int mpmpc_sync(mpmpc_handle h);
+int mpmpc_download(mpmpc_handle h, int32_t B, double* z, double* u0, int32_t* status,
+                   int32_t* iters, double* resid, double* y);
+/* one resident pass with HIP events around each kernel on the handle's stream (ms) */
+int mpmpc_solve_resident_timed(mpmpc_handle h, int32_t B, float* ms_assemble, float* ms_solve);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPMPC_H */

@@ -1,0 +1,125 @@
+// Host-side emulation of one 64-lane wavefront, used ONLY by the CPU unit tests
+// (tests/emul/): the solver core in mpmpc_core.hpp is written against an abstract
+// "lane backend" so the very same source that hipcc compiles for gfx950 (lane = one
+// double) can be executed in lock-step on the CPU (lane value = 64 doubles) and checked
+// against the oracle without a GPU.  This file is not part of the shipped library.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+namespace mpmpc {
+
+constexpr int EMU_W = 64;
+
+struct VB { bool v[EMU_W]; };
+struct VI {
+  int v[EMU_W];
+  VI() {}
+  VI(int s) { for (int i = 0; i < EMU_W; ++i) v[i] = s; }
+};
+struct VD {
+  double v[EMU_W];
+  VD() {}
+  VD(double s) { for (int i = 0; i < EMU_W; ++i) v[i] = s; }
+};
+
+#define MPMPC_EMU_BIN(op)                                                                       \
+  inline VD operator op(const VD& a, const VD& b) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] op b.v[i]; return r; } \
+  inline VD operator op(const VD& a, double b) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] op b; return r; }       \
+  inline VD operator op(double a, const VD& b) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a op b.v[i]; return r; }
+MPMPC_EMU_BIN(+) MPMPC_EMU_BIN(-) MPMPC_EMU_BIN(*) MPMPC_EMU_BIN(/)
+#undef MPMPC_EMU_BIN
+inline VD operator-(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = -a.v[i]; return r; }
+inline VD& operator+=(VD& a, const VD& b) { for (int i = 0; i < EMU_W; ++i) a.v[i] += b.v[i]; return a; }
+inline VD& operator-=(VD& a, const VD& b) { for (int i = 0; i < EMU_W; ++i) a.v[i] -= b.v[i]; return a; }
+inline VD& operator*=(VD& a, const VD& b) { for (int i = 0; i < EMU_W; ++i) a.v[i] *= b.v[i]; return a; }
+
+#define MPMPC_EMU_CMP(op)                                                                       \
+  inline VB operator op(const VD& a, const VD& b) { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] op b.v[i]; return r; } \
+  inline VB operator op(const VD& a, double b) { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] op b; return r; }
+MPMPC_EMU_CMP(<) MPMPC_EMU_CMP(>) MPMPC_EMU_CMP(<=) MPMPC_EMU_CMP(>=)
+#undef MPMPC_EMU_CMP
+#define MPMPC_EMU_ICMP(op)                                                                      \
+  inline VB operator op(const VI& a, int b) { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] op b; return r; }
+MPMPC_EMU_ICMP(<) MPMPC_EMU_ICMP(>) MPMPC_EMU_ICMP(<=) MPMPC_EMU_ICMP(>=) MPMPC_EMU_ICMP(==) MPMPC_EMU_ICMP(!=)
+#undef MPMPC_EMU_ICMP
+inline VB operator&(const VB& a, const VB& b) { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] && b.v[i]; return r; }
+inline VB operator|(const VB& a, const VB& b) { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] || b.v[i]; return r; }
+inline VB operator!(const VB& a) { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = !a.v[i]; return r; }
+inline VI operator+(const VI& a, const VI& b) { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] + b.v[i]; return r; }
+inline VI operator+(const VI& a, int b) { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] + b; return r; }
+inline VI operator-(const VI& a, int b) { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] - b; return r; }
+inline VI modi(const VI& a, int m) { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] % m; return r; }
+inline VI mini(const VI& a, int b) { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] < b ? a.v[i] : b; return r; }
+inline VI maxi(const VI& a, int b) { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] > b ? a.v[i] : b; return r; }
+inline VI operator*(const VI& a, int b) { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] * b; return r; }
+
+inline VD fma_(const VD& a, const VD& b, const VD& c) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::fma(a.v[i], b.v[i], c.v[i]); return r; }
+inline VD sqrt_(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::sqrt(a.v[i]); return r; }
+inline VD abs_(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::fabs(a.v[i]); return r; }
+inline VD max_(const VD& a, const VD& b) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] > b.v[i] ? a.v[i] : b.v[i]; return r; }
+inline VD min_(const VD& a, const VD& b) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] < b.v[i] ? a.v[i] : b.v[i]; return r; }
+inline VD tan_(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::tan(a.v[i]); return r; }
+inline VD atan_(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::atan(a.v[i]); return r; }
+inline VD sel(const VB& m, const VD& a, const VD& b) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
+inline VI seli(const VB& m, const VI& a, const VI& b) { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
+inline VB selb(const VB& m, const VB& a, const VB& b) { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
+
+// G = lanes per instance (16, 32 or 64); one emulated wave carries 64/G instances.
+template <int G>
+struct LaneEmu {
+  using real = VD;
+  using mask = VB;
+  using ival = VI;
+  static constexpr int group = G;
+  static constexpr int per_wave = EMU_W / G;
+
+  static VI lane_id() { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = i; return r; }
+  static VI stage() { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = i % G; return r; }
+  static VI slot() { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = i / G; return r; }
+  static VB mtrue() { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = true; return r; }
+  static VB mfalse() { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = false; return r; }
+
+  // value of the previous / next stage's lane (0.0 at the ends of an instance)
+  static VD up(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (i % G == 0) ? 0.0 : a.v[i - 1]; return r; }
+  static VD down(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (i % G == G - 1) ? 0.0 : a.v[i + 1]; return r; }
+
+  // butterfly all-reduce inside an instance's lanes; same association order as the GPU backend
+  template <class F>
+  static VD bfly(VD a, F f) {
+    for (int off = 1; off < G; off <<= 1) {
+      VD t;
+      for (int i = 0; i < EMU_W; ++i) t.v[i] = a.v[i ^ off];
+      for (int i = 0; i < EMU_W; ++i) a.v[i] = f(a.v[i], t.v[i]);
+    }
+    return a;
+  }
+  static VD gmax(const VD& a) { return bfly(a, [](double x, double y) { return x > y ? x : y; }); }
+  static VD gmin(const VD& a) { return bfly(a, [](double x, double y) { return x < y ? x : y; }); }
+  static VD gsum(const VD& a) { return bfly(a, [](double x, double y) { return x + y; }); }
+  static VB gany(const VB& m) {
+    VB r;
+    for (int g = 0; g < per_wave; ++g) {
+      bool any = false;
+      for (int i = 0; i < G; ++i) any = any || m.v[g * G + i];
+      for (int i = 0; i < G; ++i) r.v[g * G + i] = any;
+    }
+    return r;
+  }
+  static bool wany(const VB& m) { for (int i = 0; i < EMU_W; ++i) if (m.v[i]) return true; return false; }
+
+  static VD load(const double* p, const VI& idx, const VB& ok, double dflt) {
+    VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = ok.v[i] ? p[idx.v[i]] : dflt; return r;
+  }
+  static VI loadi(const int* p, const VI& idx, const VB& ok, int dflt) {
+    VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = ok.v[i] ? p[idx.v[i]] : dflt; return r;
+  }
+  static void store(double* p, const VI& idx, const VB& ok, const VD& a) {
+    for (int i = 0; i < EMU_W; ++i) if (ok.v[i]) p[idx.v[i]] = a.v[i];
+  }
+  static void storei(int* p, const VI& idx, const VB& ok, const VI& a) {
+    for (int i = 0; i < EMU_W; ++i) if (ok.v[i]) p[idx.v[i]] = a.v[i];
+  }
+};
+
+}  // namespace mpmpc

@@ -1,0 +1,98 @@
+// gfx950 lane backend for mpmpc_core.hpp: one lane = one horizon stage of one QP,
+// G consecutive lanes of a 64-wide wavefront = one QP instance (64/G instances per wave).
+// Neighbour exchange along the horizon is a DPP wavefront shift (no LDS, no memory);
+// instance-wide norms are butterfly reductions over the G lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mpmpc {
+
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ double sqrt_(double a) { return __builtin_sqrt(a); }
+__device__ __forceinline__ double abs_(double a) { return __builtin_fabs(a); }
+__device__ __forceinline__ double max_(double a, double b) { return a > b ? a : b; }
+__device__ __forceinline__ double min_(double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ double tan_(double a) { return ::tan(a); }
+__device__ __forceinline__ double atan_(double a) { return ::atan(a); }
+__device__ __forceinline__ double sel(bool m, double a, double b) { return m ? a : b; }
+__device__ __forceinline__ int seli(bool m, int a, int b) { return m ? a : b; }
+__device__ __forceinline__ int modi(int a, int m) { return a % m; }
+__device__ __forceinline__ int mini(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int maxi(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ bool selb(bool m, bool a, bool b) { return m ? a : b; }
+
+// DPP controls (GFX9): whole-wavefront shift by one lane.
+constexpr int DPP_WAVE_SHL1 = 0x130;   // lane i <- lane i+1
+constexpr int DPP_WAVE_SHR1 = 0x138;   // lane i <- lane i-1
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_shift(double a) {
+  int lo = __double2loint(a), hi = __double2hiint(a);
+  // old = 0 and bound_ctrl = true: the lane with no source reads 0
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+template <int G>
+struct LaneGpu {
+  using real = double;
+  using mask = bool;
+  using ival = int;
+  static constexpr int group = G;
+  static constexpr int per_wave = 64 / G;
+
+  static __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+  static __device__ __forceinline__ int stage() { return (threadIdx.x & 63) % G; }
+  static __device__ __forceinline__ int slot() { return (threadIdx.x & 63) / G; }
+  static __device__ __forceinline__ bool mtrue() { return true; }
+  static __device__ __forceinline__ bool mfalse() { return false; }
+
+  static __device__ __forceinline__ double up(double a) {
+    double r = dpp_shift<DPP_WAVE_SHR1>(a);
+    if (G < 64) r = (stage() == 0) ? 0.0 : r;
+    return r;
+  }
+  static __device__ __forceinline__ double down(double a) {
+    double r = dpp_shift<DPP_WAVE_SHL1>(a);
+    if (G < 64) r = (stage() == G - 1) ? 0.0 : r;
+    return r;
+  }
+  static __device__ __forceinline__ double gmax(double a) {
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1) { double t = __shfl_xor(a, off, 64); a = a > t ? a : t; }
+    return a;
+  }
+  static __device__ __forceinline__ double gmin(double a) {
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1) { double t = __shfl_xor(a, off, 64); a = a < t ? a : t; }
+    return a;
+  }
+  static __device__ __forceinline__ double gsum(double a) {
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1) { double t = __shfl_xor(a, off, 64); a = a + t; }
+    return a;
+  }
+  static __device__ __forceinline__ bool gany(bool m) {
+    unsigned long long b = __ballot(m);
+    if (G == 64) return b != 0ull;
+    unsigned long long mine = (b >> (slot() * G)) & ((1ull << (G & 63)) - 1ull);
+    return mine != 0ull;
+  }
+  static __device__ __forceinline__ bool wany(bool m) { return __ballot(m) != 0ull; }
+
+  static __device__ __forceinline__ double load(const double* p, int idx, bool ok, double dflt) {
+    return ok ? p[idx] : dflt;
+  }
+  static __device__ __forceinline__ int loadi(const int* p, int idx, bool ok, int dflt) {
+    return ok ? p[idx] : dflt;
+  }
+  static __device__ __forceinline__ void store(double* p, int idx, bool ok, double a) {
+    if (ok) p[idx] = a;
+  }
+  static __device__ __forceinline__ void storei(int* p, int idx, bool ok, int a) {
+    if (ok) p[idx] = a;
+  }
+};
+
+}  // namespace mpmpc

@@ -1,0 +1,968 @@
+// Lane-generic core of the batched LTV-MPC QP path (float64).
+//
+// One lane = one horizon stage k of one QP instance; G consecutive lanes = one instance.
+// Every per-stage quantity (3x3 / 3x2 dynamics blocks, bounds, iterates, multipliers, factor
+// blocks) lives in that lane's registers; neighbouring stages talk through L::up / L::down,
+// instance-wide norms through L::gmax / L::gsum.  The backend L is lane_gpu.hpp (gfx950) in
+// the shipped library and lane_emu.hpp (lock-step CPU emulation) in the unit tests.
+//
+// What is computed (reference file:line it replaces):
+//   assemble_stage  src/MPC.py:61-155 + src/spatial_bicycle_models.py:391-417 (one stage)
+//   Solver::scale   OSQP Ruiz equilibration of the QP of src/MPC.py:159 (setup)
+//   Solver::admm    OSQP ADMM iteration, termination and infeasibility tests (src/MPC.py:183)
+//   Solver::ipm / active_set / certificate   certified polish
+//
+// QP of one instance:  min 1/2 w'Pw + q'w,  w = (x_0..x_N, u_0..u_{N-1}),  P diagonal,
+//   equality block k:  -x_k + A_{k-1} x_{k-1} + B_{k-1} u_{k-1} = beq_k   (block 0: -x_0 = -x0)
+//   boxes lo <= w <= hi.
+// A_k = [[1,ds,0],[a10,1,0],[a20,0,1]], B_k = [[0,0],[0,ds],[b20,0]] are stored sparsely.
+#pragma once
+#include "mpmpc.h"
+
+#ifndef MPMPC_HD
+#define MPMPC_HD inline
+#endif
+#define MPMPC_UNROLL _Pragma("unroll")
+
+namespace mpmpc {
+
+enum Field { F_DS = 0, F_A10 = 1, F_A20 = 2, F_B20 = 3, F_BEQ = 4, F_LO = 7, F_HI = 12, F_Q = 17, F_P = 22 };
+
+constexpr double INFTY = 1e30, MIN_SCALING = 1e-4, MAX_SCALING = 1e4;
+constexpr double RHO_MIN = 1e-6, RHO_MAX = 1e6, RHO_TOL = 1e-4, RHO_EQ_FACTOR = 1e3;
+constexpr double INF_BOUND = INFTY * MIN_SCALING;   // a scaled bound beyond this is "infinite"
+
+MPMPC_HD int stage_ld(int N) { return N + 1 <= 16 ? 16 : (N + 1 <= 32 ? 32 : 64); }
+
+// ------------------------------------------------------------------------------------------
+// K1 math: the 27 fields of stage k of one instance.
+// ------------------------------------------------------------------------------------------
+template <class L>
+struct StageIn {
+  using R = typename L::real;
+  using Mk = typename L::mask;
+  R kap, v, ds;        // waypoint wp_id+k      (only used where has_u)
+  R kap_p, v_p, ds_p;  // waypoint wp_id+k-1    (only used where !first)
+  R x0[3];             // spatial state of the instance
+  R cc_a, cc_last;     // previous plan entries cc[3+k] and cc[2N-1]  (src/MPC.py:86-87)
+  R lbk, ubk;          // corridor at horizon waypoint k (k >= 1): lb[k-1], ub[k-1]
+  Mk first, has_u, terminal;   // k == 0, k < N, k == N
+};
+
+template <class L>
+MPMPC_HD void assemble_stage(const mpmpc_config& c, const StageIn<L>& in, typename L::real out[MPMPC_NUM_FIELDS]) {
+  using R = typename L::real;
+  const R zero(0.0), one(1.0);
+  // linearize(v_ref, kappa_ref, delta_s), same operation order as the reference
+  R a10 = (-(in.kap * in.kap)) * in.ds;
+  R a20 = ((-in.kap) / in.v) * in.ds;
+  R b20 = ((-one) / (in.v * in.v)) * in.ds;
+  out[F_DS] = sel(in.has_u, in.ds, zero);
+  out[F_A10] = sel(in.has_u, a10, zero);
+  out[F_A20] = sel(in.has_u, a20, zero);
+  out[F_B20] = sel(in.has_u, b20, zero);
+  // rhs of equality block k: -x0, or uq_{k-1} = B [v, kappa] - f   (src/MPC.py:107-108)
+  R b20p = ((-one) / (in.v_p * in.v_p)) * in.ds_p;
+  R f2p = (one / in.v_p) * in.ds_p;
+  out[F_BEQ + 0] = sel(in.first, -in.x0[0], zero);
+  out[F_BEQ + 1] = sel(in.first, -in.x0[1], in.ds_p * in.kap_p);
+  out[F_BEQ + 2] = sel(in.first, -in.x0[2], b20p * in.v_p - f2p);
+  // state boxes (src/MPC.py:81-82,119-122)
+  out[F_LO + 0] = sel(in.first, in.x0[0], in.lbk);
+  out[F_HI + 0] = sel(in.first, in.x0[0], in.ubk);
+  out[F_LO + 1] = R(c.xmin[1]);
+  out[F_HI + 1] = R(c.xmax[1]);
+  out[F_LO + 2] = R(c.xmin[2]);
+  out[F_HI + 2] = R(c.xmax[2]);
+  // input boxes with the curvature-dependent speed cap (src/MPC.py:84,111-113)
+  R kp = tan_(in.cc_a + in.cc_last) / R(c.wheelbase);
+  R vmax = sqrt_(R(c.ay_max) / (abs_(kp) + R(1e-12)));
+  R umax0(c.umax[0]);
+  R hi_v = sel(vmax < umax0, vmax, umax0);
+  out[F_LO + 3] = sel(in.has_u, R(c.umin[0]), R(-INFTY));
+  out[F_HI + 3] = sel(in.has_u, hi_v, R(INFTY));
+  out[F_LO + 4] = sel(in.has_u, R(c.umin[1]), R(-INFTY));
+  out[F_HI + 4] = sel(in.has_u, R(c.umax[1]), R(INFTY));
+  // cost (src/MPC.py:125,150-155): references are the corridor centre for e_y, (v_ref, kappa_ref) for u
+  R xr0 = sel(in.first, zero, (in.lbk + in.ubk) / R(2.0));
+  MPMPC_UNROLL
+  for (int i = 0; i < 3; ++i) {
+    R xr = (i == 0) ? xr0 : zero;
+    out[F_Q + i] = sel(in.terminal, -(R(c.QN[i]) * xr), R(-c.Q[i]) * xr);
+    out[F_P + i] = sel(in.terminal, R(c.QN[i]), R(c.Q[i]));
+  }
+  out[F_Q + 3] = sel(in.has_u, R(-c.R[0]) * in.v, zero);
+  out[F_Q + 4] = sel(in.has_u, R(-c.R[1]) * in.kap, zero);
+  out[F_P + 3] = sel(in.has_u, R(c.R[0]), one);
+  out[F_P + 4] = sel(in.has_u, R(c.R[1]), one);
+}
+
+// Per-path tables uploaded once per handle (device pointers in the library, host pointers in
+// the emulation): what ReferencePath.get_waypoint / update_path_constraints provide.
+struct PathTables {
+  const double* kappa;
+  const double* v_ref;
+  const double* ds_next;
+  int n_wp;
+  const double* ub_tab;   // [n_wp x n_cols] or null
+  const double* lb_tab;
+  int n_cols;
+};
+
+// One (instance, stage) of K1: gather the waypoint data, build the fields, store them
+// stage-blocked as qp[(field * B + inst) * ld + k] (consecutive lanes -> consecutive addresses).
+template <class L>
+MPMPC_HD void assemble_lane(const mpmpc_config& c, const PathTables& t, int B, int ld, const typename L::ival& inst,
+                            const typename L::ival& k, const int* wp_id, const double* x0, const double* cc,
+                            const double* lb, const double* ub, double* qp) {
+  using R = typename L::real;
+  using Mk = typename L::mask;
+  using I = typename L::ival;
+  const int N = c.N;
+  Mk ok = (inst < B) & (k <= N);
+  StageIn<L> in;
+  in.first = (k == 0);
+  in.has_u = ok & (k < N);
+  in.terminal = (k == N);
+  I wp = L::loadi(wp_id, inst, ok, 0);
+  I ik = wp + k, ip = maxi(wp + k - 1, 0);
+  if (c.circular) { ik = modi(ik, t.n_wp); ip = modi(ip, t.n_wp); }
+  else { ik = mini(ik, t.n_wp - 1); ip = mini(ip, t.n_wp - 1); }
+  in.kap = L::load(t.kappa, ik, ok, 0.0);
+  in.v = L::load(t.v_ref, ik, ok, 1.0);
+  in.ds = L::load(t.ds_next, ik, ok, 0.0);
+  in.kap_p = L::load(t.kappa, ip, ok, 0.0);
+  in.v_p = L::load(t.v_ref, ip, ok, 1.0);
+  in.ds_p = L::load(t.ds_next, ip, ok, 0.0);
+  MPMPC_UNROLL
+  for (int i = 0; i < 3; ++i) in.x0[i] = L::load(x0, inst * 3 + i, ok, 0.0);
+  in.cc_a = L::load(cc, inst * (2 * N) + k + 3, in.has_u, 0.0);
+  in.cc_last = L::load(cc, inst * (2 * N) + (2 * N - 1), ok, 0.0);
+  Mk inner = ok & (k >= 1);
+  if (lb != nullptr) {
+    in.lbk = L::load(lb, inst * N + k - 1, inner, 0.0);
+    in.ubk = L::load(ub, inst * N + k - 1, inner, 0.0);
+  } else {
+    in.lbk = L::load(t.lb_tab, wp * t.n_cols + k - 1, inner, 0.0);
+    in.ubk = L::load(t.ub_tab, wp * t.n_cols + k - 1, inner, 0.0);
+  }
+  R out[MPMPC_NUM_FIELDS];
+  assemble_stage<L>(c, in, out);
+  I base = inst * ld + k;
+  MPMPC_UNROLL
+  for (int f = 0; f < MPMPC_NUM_FIELDS; ++f) L::store(qp, base + f * (B * ld), ok, out[f]);
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: the solver.  All state is per lane.
+// ------------------------------------------------------------------------------------------
+template <class L>
+struct Solver {
+  using R = typename L::real;
+  using Mk = typename L::mask;
+  using I = typename L::ival;
+
+  // ---- lane context
+  int N;
+  Mk vx, vu, first;      // lane holds a real stage (k <= N), a real input (k < N), k == 0
+  Mk valid[5];
+  Mk live;               // this lane's instance exists
+  // ---- unscaled bounds kept for the certificate
+  R lo0[5], hi0[5], beq0[3];
+  // ---- scaled problem
+  R mI[3], a[6], b[2], g[5], p[5], q[5], D[5], Eeq[3], Eb[5], c;
+  R leq[3], lb[5], ub[5];
+  // ---- linear algebra
+  R hinv[5], Li[6], Ls[9];
+  // ---- ADMM state
+  R x[5], zeq[3], zb[5], yeq[3], yb[5];
+  R rho, rb[5], rbinv[5], rho_eq, rinv_eq;
+  R xprev[5], dyeq[3], dyb[5];
+  // ---- results
+  I status, iters, ipm_iters, polished;
+  R pri_res, dua_res;
+
+  // ======================================================================== helpers
+  MPMPC_HD static R limit(const R& v) {
+    R r = sel(v < R(MIN_SCALING), R(1.0), v);
+    return sel(r > R(MAX_SCALING), R(MAX_SCALING), r);
+  }
+  // w = A_k x_k + B_k u_k  (contribution of this stage to equality block k+1)
+  MPMPC_HD void couple(const R v[5], R w[3]) const {
+    w[0] = fma_(a[1], v[1], a[0] * v[0]);
+    w[1] = fma_(b[0], v[4], fma_(a[3], v[1], a[2] * v[0]));
+    w[2] = fma_(b[1], v[3], fma_(a[5], v[2], a[4] * v[0]));
+  }
+  MPMPC_HD void Aeq_mul(const R v[5], R r[3]) const {
+    R w[3];
+    couple(v, w);
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) r[i] = fma_(mI[i], v[i], L::up(w[i]));
+  }
+  MPMPC_HD void AeqT_mul(const R nu[3], R t[5]) const {
+    R nd[3];
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) nd[i] = L::down(nu[i]);
+    t[0] = fma_(a[4], nd[2], fma_(a[2], nd[1], fma_(a[0], nd[0], mI[0] * nu[0])));
+    t[1] = fma_(a[3], nd[1], fma_(a[1], nd[0], mI[1] * nu[1]));
+    t[2] = fma_(a[5], nd[2], mI[2] * nu[2]);
+    t[3] = b[1] * nd[2];
+    t[4] = b[0] * nd[1];
+  }
+  MPMPC_HD R gmax5(const R v[5]) const {
+    R m(0.0);
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) m = max_(m, sel(valid[j], abs_(v[j]), R(0.0)));
+    return L::gmax(m);
+  }
+  MPMPC_HD R gmax3(const R v[3]) const {
+    R m(0.0);
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) m = max_(m, sel(vx, abs_(v[i]), R(0.0)));
+    return L::gmax(m);
+  }
+
+  // ======================================================================== setup
+  MPMPC_HD void load(const double* qp, int B, int ld, const I& inst, const I& k, int N_) {
+    N = N_;
+    live = inst < B;
+    vx = live & (k <= N);
+    vu = live & (k < N);
+    first = (k == 0);
+    valid[0] = valid[1] = valid[2] = vx;
+    valid[3] = valid[4] = vu;
+    I base = inst * ld + k;
+    auto fld = [&](int f, double dflt) { return L::load(qp, base + f * (B * ld), vx, dflt); };
+    R ds = fld(F_DS, 0.0), a10 = fld(F_A10, 0.0), a20 = fld(F_A20, 0.0), b20 = fld(F_B20, 0.0);
+    R one = sel(vu, R(1.0), R(0.0));
+    a[0] = one; a[1] = ds; a[2] = a10; a[3] = one; a[4] = a20; a[5] = one;
+    b[0] = ds; b[1] = b20;
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) { beq0[i] = fld(F_BEQ + i, 0.0); mI[i] = R(-1.0); Eeq[i] = R(1.0); }
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      lo0[j] = max_(fld(F_LO + j, -INFTY), R(-INFTY));
+      hi0[j] = min_(fld(F_HI + j, INFTY), R(INFTY));
+      q[j] = fld(F_Q + j, 0.0);
+      p[j] = fld(F_P + j, 1.0);
+      g[j] = R(1.0); D[j] = R(1.0); Eb[j] = R(1.0);
+    }
+    c = R(1.0);
+  }
+
+  // OSQP scale_data(): `passes` Ruiz sweeps with cost normalisation, then l, u <- E l, E u
+  MPMPC_HD void scale(int passes) {
+    const R n_total(double(5 * N + 3));
+    for (int it = 0; it < passes; ++it) {
+      R cn[5], rn[3], r_own[3];
+      cn[0] = max_(max_(max_(abs_(p[0]), abs_(mI[0])), max_(abs_(a[0]), abs_(a[2]))), max_(abs_(a[4]), abs_(g[0])));
+      cn[1] = max_(max_(abs_(p[1]), abs_(mI[1])), max_(max_(abs_(a[1]), abs_(a[3])), abs_(g[1])));
+      cn[2] = max_(max_(abs_(p[2]), abs_(mI[2])), max_(abs_(a[5]), abs_(g[2])));
+      cn[3] = max_(max_(abs_(p[3]), abs_(b[1])), abs_(g[3]));
+      cn[4] = max_(max_(abs_(p[4]), abs_(b[0])), abs_(g[4]));
+      r_own[0] = max_(abs_(a[0]), abs_(a[1]));
+      r_own[1] = max_(max_(abs_(a[2]), abs_(a[3])), abs_(b[0]));
+      r_own[2] = max_(max_(abs_(a[4]), abs_(a[5])), abs_(b[1]));
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) rn[i] = max_(abs_(mI[i]), L::up(r_own[i]));
+      R Dt[5], Et[3], Etb[5], Etd[3];
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) {
+        Dt[j] = R(1.0) / sqrt_(limit(cn[j]));
+        Etb[j] = R(1.0) / sqrt_(limit(abs_(g[j])));
+      }
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) { Et[i] = R(1.0) / sqrt_(limit(rn[i])); Etd[i] = L::down(Et[i]); }
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) {
+        p[j] = (Dt[j] * p[j]) * Dt[j];
+        g[j] = (Etb[j] * g[j]) * Dt[j];
+        q[j] = Dt[j] * q[j];
+        D[j] = D[j] * Dt[j];
+        Eb[j] = Eb[j] * Etb[j];
+      }
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) { mI[i] = (Et[i] * mI[i]) * Dt[i]; Eeq[i] = Eeq[i] * Et[i]; }
+      a[0] = (Etd[0] * a[0]) * Dt[0]; a[1] = (Etd[0] * a[1]) * Dt[1];
+      a[2] = (Etd[1] * a[2]) * Dt[0]; a[3] = (Etd[1] * a[3]) * Dt[1];
+      a[4] = (Etd[2] * a[4]) * Dt[0]; a[5] = (Etd[2] * a[5]) * Dt[2];
+      b[0] = (Etd[1] * b[0]) * Dt[4]; b[1] = (Etd[2] * b[1]) * Dt[3];
+      // cost normalisation
+      R s(0.0), mq(0.0);
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) {
+        s = s + sel(valid[j], abs_(p[j]), R(0.0));
+        mq = max_(mq, sel(valid[j], abs_(q[j]), R(0.0)));
+      }
+      R ct = L::gsum(s) / n_total;
+      R nq = limit(L::gmax(mq));
+      ct = R(1.0) / limit(max_(ct, nq));
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) { p[j] = p[j] * ct; q[j] = q[j] * ct; }
+      c = c * ct;
+    }
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) leq[i] = Eeq[i] * beq0[i];
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) { lb[j] = Eb[j] * lo0[j]; ub[j] = Eb[j] * hi0[j]; }
+  }
+
+  // OSQP set_rho_vec(): per-row step size by constraint type
+  MPMPC_HD void set_rho(const R& rho_new) {
+    rho = rho_new;
+    rho_eq = R(RHO_EQ_FACTOR) * rho;
+    rinv_eq = R(1.0) / rho_eq;
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      Mk freerow = (lb[j] < R(-INF_BOUND)) & (ub[j] > R(INF_BOUND));
+      Mk eqrow = (ub[j] - lb[j]) < R(RHO_TOL);
+      rb[j] = sel(freerow, R(RHO_MIN), sel(eqrow, rho_eq, rho));
+      rbinv[j] = R(1.0) / rb[j];
+    }
+  }
+
+  // Block-tridiagonal Cholesky of S = Aeq diag(h) Aeq' + r I  (3x3 blocks, one per lane).
+  // Lane k ends with Li = inv(L_kk) (lower) and Ls = L_{k,k-1}.
+  MPMPC_HD void factor(const R h[5], const R& r) {
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) hinv[j] = h[j];
+    R W[6], T[7], dk[3], M[9];
+    R a0h = a[0] * h[0], a2h = a[2] * h[0], a4h = a[4] * h[0], a1h = a[1] * h[1], a3h = a[3] * h[1];
+    W[0] = fma_(a[1], a1h, a[0] * a0h);
+    W[1] = fma_(a[3], a1h, a[2] * a0h);
+    W[2] = fma_(b[0] * b[0], h[4], fma_(a[3], a3h, a[2] * a2h));
+    W[3] = a[4] * a0h;
+    W[4] = a[4] * a2h;
+    W[5] = fma_(b[1] * b[1], h[3], fma_(a[5] * a[5], h[2], a[4] * a4h));
+    T[0] = a0h * mI[0]; T[1] = a1h * mI[1];                 // row 0: cols 0,1
+    T[2] = a2h * mI[0]; T[3] = a3h * mI[1];                 // row 1: cols 0,1
+    T[4] = a4h * mI[0]; T[5] = (a[5] * h[2]) * mI[2];       // row 2: cols 0,2
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) dk[i] = fma_(mI[i] * mI[i], h[i], r);
+    MPMPC_UNROLL
+    for (int i = 0; i < 9; ++i) M[i] = R(0.0);
+    for (int s = 0; s <= N; ++s) {
+      R Wr[6], Mr[9];
+      MPMPC_UNROLL
+      for (int i = 0; i < 6; ++i) Wr[i] = L::up(W[i]);
+      MPMPC_UNROLL
+      for (int i = 0; i < 9; ++i) Mr[i] = L::up(M[i]);
+      R S00 = dk[0] + Wr[0] - fma_(Mr[2], Mr[2], fma_(Mr[1], Mr[1], Mr[0] * Mr[0]));
+      R S10 = Wr[1] - fma_(Mr[5], Mr[2], fma_(Mr[4], Mr[1], Mr[3] * Mr[0]));
+      R S11 = dk[1] + Wr[2] - fma_(Mr[5], Mr[5], fma_(Mr[4], Mr[4], Mr[3] * Mr[3]));
+      R S20 = Wr[3] - fma_(Mr[8], Mr[2], fma_(Mr[7], Mr[1], Mr[6] * Mr[0]));
+      R S21 = Wr[4] - fma_(Mr[8], Mr[5], fma_(Mr[7], Mr[4], Mr[6] * Mr[3]));
+      R S22 = dk[2] + Wr[5] - fma_(Mr[8], Mr[8], fma_(Mr[7], Mr[7], Mr[6] * Mr[6]));
+      R l00 = sqrt_(S00);
+      R i00 = R(1.0) / l00;
+      R l10 = S10 * i00, l20 = S20 * i00;
+      R l11 = sqrt_(S11 - l10 * l10);
+      R i11 = R(1.0) / l11;
+      R l21 = (S21 - l20 * l10) * i11;
+      R l22 = sqrt_(S22 - fma_(l21, l21, l20 * l20));
+      R i22 = R(1.0) / l22;
+      R i10 = -(l10 * i00) * i11;
+      R i21 = -(l21 * i11) * i22;
+      R i20 = -(fma_(l21, i10, l20 * i00)) * i22;
+      Li[0] = i00; Li[1] = i10; Li[2] = i11; Li[3] = i20; Li[4] = i21; Li[5] = i22;
+      MPMPC_UNROLL
+      for (int i = 0; i < 9; ++i) Ls[i] = Mr[i];
+      // M = T * inv(L_kk)'  -> L_{k+1,k}, consumed by lane k+1 in the next sweep step
+      M[0] = T[0] * i00; M[1] = fma_(T[1], i11, T[0] * i10); M[2] = fma_(T[1], i21, T[0] * i20);
+      M[3] = T[2] * i00; M[4] = fma_(T[3], i11, T[2] * i10); M[5] = fma_(T[3], i21, T[2] * i20);
+      M[6] = T[4] * i00; M[7] = T[4] * i10;                  M[8] = fma_(T[5], i22, T[4] * i20);
+    }
+    // lanes beyond the horizon never receive settled neighbours: give them a benign block
+    MPMPC_UNROLL
+    for (int i = 0; i < 9; ++i) Ls[i] = sel(vx, Ls[i], R(0.0));
+    Li[0] = sel(vx, Li[0], R(1.0)); Li[2] = sel(vx, Li[2], R(1.0)); Li[5] = sel(vx, Li[5], R(1.0));
+    Li[1] = sel(vx, Li[1], R(0.0)); Li[3] = sel(vx, Li[3], R(0.0)); Li[4] = sel(vx, Li[4], R(0.0));
+  }
+
+  MPMPC_HD void s_solve(const R bv[3], R nu[3]) const {
+    R y[3] = {R(0.0), R(0.0), R(0.0)};
+    for (int s = 0; s <= N; ++s) {
+      R yp0 = L::up(y[0]), yp1 = L::up(y[1]), yp2 = L::up(y[2]);
+      R t0 = bv[0] - fma_(Ls[2], yp2, fma_(Ls[1], yp1, Ls[0] * yp0));
+      R t1 = bv[1] - fma_(Ls[5], yp2, fma_(Ls[4], yp1, Ls[3] * yp0));
+      R t2 = bv[2] - fma_(Ls[8], yp2, fma_(Ls[7], yp1, Ls[6] * yp0));
+      y[0] = Li[0] * t0;
+      y[1] = fma_(Li[2], t1, Li[1] * t0);
+      y[2] = fma_(Li[5], t2, fma_(Li[4], t1, Li[3] * t0));
+    }
+    nu[0] = nu[1] = nu[2] = R(0.0);
+    for (int s = 0; s <= N; ++s) {
+      R g0 = fma_(Ls[6], nu[2], fma_(Ls[3], nu[1], Ls[0] * nu[0]));
+      R g1 = fma_(Ls[7], nu[2], fma_(Ls[4], nu[1], Ls[1] * nu[0]));
+      R g2 = fma_(Ls[8], nu[2], fma_(Ls[5], nu[1], Ls[2] * nu[0]));
+      R t0 = y[0] - L::down(g0), t1 = y[1] - L::down(g1), t2 = y[2] - L::down(g2);
+      nu[2] = Li[5] * t2;
+      nu[1] = fma_(Li[4], t2, Li[2] * t1);
+      nu[0] = fma_(Li[3], t2, fma_(Li[1], t1, Li[0] * t0));
+    }
+  }
+
+  // [diag(1/hinv) Aeq'; Aeq -r I] [xt; nu] = [rx; req]
+  MPMPC_HD void kkt_solve(const R rx[5], const R req[3], R xt[5], R nu[3]) const {
+    R t[5], bv[3], s[5];
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) t[j] = hinv[j] * rx[j];
+    Aeq_mul(t, bv);
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) bv[i] = bv[i] - req[i];
+    s_solve(bv, nu);
+    AeqT_mul(nu, s);
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) xt[j] = hinv[j] * (rx[j] - s[j]);
+  }
+
+  MPMPC_HD void admm_factor(double sigma) {
+    R h[5];
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) h[j] = R(1.0) / (p[j] + R(sigma) + (g[j] * g[j]) * rb[j]);
+    factor(h, rinv_eq);
+  }
+
+  // ======================================================================== ADMM (OSQP)
+  struct Info {
+    R pri, dua, n_z, n_Ax, n_q, n_Aty, n_Px;       // unscaled norms for the termination test
+    R s_rp, s_rd, s_z, s_Ax, s_q, s_Aty, s_Px;     // scaled norms for the rho estimate
+  };
+  MPMPC_HD void info(Info& o) const {
+    R Axe[3], Aty[5];
+    Aeq_mul(x, Axe);
+    AeqT_mul(yeq, Aty);
+    R pri(0.0), nz(0.0), nAx(0.0), srp(0.0), sz(0.0), sAx(0.0);
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) {
+      R ei = R(1.0) / Eeq[i];
+      R rp = Axe[i] - zeq[i];
+      pri = max_(pri, sel(vx, abs_(ei * rp), R(0.0)));
+      nz = max_(nz, sel(vx, abs_(ei * zeq[i]), R(0.0)));
+      nAx = max_(nAx, sel(vx, abs_(ei * Axe[i]), R(0.0)));
+      srp = max_(srp, sel(vx, abs_(rp), R(0.0)));
+      sz = max_(sz, sel(vx, abs_(zeq[i]), R(0.0)));
+      sAx = max_(sAx, sel(vx, abs_(Axe[i]), R(0.0)));
+    }
+    R dua(0.0), nq(0.0), nAty(0.0), nPx(0.0), srd(0.0), sq(0.0), sAty(0.0), sPx(0.0);
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      R ei = R(1.0) / Eb[j], di = R(1.0) / D[j];
+      R Axb = g[j] * x[j];
+      R rp = Axb - zb[j];
+      pri = max_(pri, sel(valid[j], abs_(ei * rp), R(0.0)));
+      nz = max_(nz, sel(valid[j], abs_(ei * zb[j]), R(0.0)));
+      nAx = max_(nAx, sel(valid[j], abs_(ei * Axb), R(0.0)));
+      srp = max_(srp, sel(valid[j], abs_(rp), R(0.0)));
+      sz = max_(sz, sel(valid[j], abs_(zb[j]), R(0.0)));
+      sAx = max_(sAx, sel(valid[j], abs_(Axb), R(0.0)));
+      R aty = fma_(g[j], yb[j], Aty[j]);
+      R Px = p[j] * x[j];
+      R rd = Px + q[j] + aty;
+      dua = max_(dua, sel(valid[j], abs_(di * rd), R(0.0)));
+      nq = max_(nq, sel(valid[j], abs_(di * q[j]), R(0.0)));
+      nAty = max_(nAty, sel(valid[j], abs_(di * aty), R(0.0)));
+      nPx = max_(nPx, sel(valid[j], abs_(di * Px), R(0.0)));
+      srd = max_(srd, sel(valid[j], abs_(rd), R(0.0)));
+      sq = max_(sq, sel(valid[j], abs_(q[j]), R(0.0)));
+      sAty = max_(sAty, sel(valid[j], abs_(aty), R(0.0)));
+      sPx = max_(sPx, sel(valid[j], abs_(Px), R(0.0)));
+    }
+    R cinv = R(1.0) / c;
+    o.pri = L::gmax(pri); o.n_z = L::gmax(nz); o.n_Ax = L::gmax(nAx);
+    o.dua = cinv * L::gmax(dua); o.n_q = cinv * L::gmax(nq); o.n_Aty = cinv * L::gmax(nAty); o.n_Px = cinv * L::gmax(nPx);
+    o.s_rp = L::gmax(srp); o.s_z = L::gmax(sz); o.s_Ax = L::gmax(sAx);
+    o.s_rd = L::gmax(srd); o.s_q = L::gmax(sq); o.s_Aty = L::gmax(sAty); o.s_Px = L::gmax(sPx);
+  }
+
+  // OSQP is_primal_infeasible() on the last dual step
+  MPMPC_HD Mk primal_infeasible(double eps) const {
+    R nrm(0.0), lhs(0.0), pd[5];
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) {
+      nrm = max_(nrm, sel(vx, abs_(Eeq[i] * dyeq[i]), R(0.0)));
+      lhs = lhs + sel(vx, leq[i] * dyeq[i], R(0.0));      // u*max(dy,0) + l*min(dy,0) with l = u
+    }
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      Mk lo_inf = lb[j] < R(-INF_BOUND), up_inf = ub[j] > R(INF_BOUND);
+      R d = dyb[j];
+      d = sel(up_inf & lo_inf, R(0.0), sel(up_inf, min_(d, R(0.0)), sel(lo_inf, max_(d, R(0.0)), d)));
+      pd[j] = d;
+      nrm = max_(nrm, sel(valid[j], abs_(Eb[j] * d), R(0.0)));
+      lhs = lhs + sel(valid[j], ub[j] * max_(d, R(0.0)) + lb[j] * min_(d, R(0.0)), R(0.0));
+    }
+    nrm = L::gmax(nrm);
+    lhs = L::gsum(lhs);
+    R At[5];
+    AeqT_mul(dyeq, At);
+    R m(0.0);
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) m = max_(m, sel(valid[j], abs_(fma_(g[j], pd[j], At[j]) / D[j]), R(0.0)));
+    m = L::gmax(m);
+    return (nrm > R(eps)) & (lhs < R(-eps) * nrm) & (m < R(eps) * nrm);
+  }
+
+  // OSQP is_dual_infeasible() on the last primal step
+  MPMPC_HD Mk dual_infeasible(double eps) const {
+    R dx[5], nrm(0.0), qdx(0.0), pm(0.0);
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      dx[j] = x[j] - xprev[j];
+      nrm = max_(nrm, sel(valid[j], abs_(D[j] * dx[j]), R(0.0)));
+      qdx = qdx + sel(valid[j], q[j] * dx[j], R(0.0));
+      pm = max_(pm, sel(valid[j], abs_((p[j] * dx[j]) / D[j]), R(0.0)));
+    }
+    nrm = L::gmax(nrm); qdx = L::gsum(qdx); pm = L::gmax(pm);
+    R Adx[3];
+    Aeq_mul(dx, Adx);
+    R thr = R(eps) * nrm;
+    Mk bad = L::mfalse();
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) bad = bad | (vx & (abs_(Adx[i] / Eeq[i]) > thr));
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      R v = (g[j] * dx[j]) / Eb[j];
+      Mk lo_inf = lb[j] < R(-INF_BOUND), up_inf = ub[j] > R(INF_BOUND);
+      bad = bad | (valid[j] & ((!up_inf & (v > thr)) | (!lo_inf & (v < -thr))));
+    }
+    bad = L::gany(bad);
+    return (nrm > R(eps)) & (qdx < -(c * R(eps)) * nrm) & (pm < (c * R(eps)) * nrm) & !bad;
+  }
+
+  MPMPC_HD I check(const Info& o, const mpmpc_settings& st, bool approximate) const {
+    double k = approximate ? 10.0 : 1.0;
+    R eps_prim = R(st.eps_abs * k) + R(st.eps_rel * k) * max_(o.n_z, o.n_Ax);
+    R eps_dual = R(st.eps_abs * k) + R(st.eps_rel * k) * max_(max_(o.n_q, o.n_Aty), o.n_Px);
+    Mk prim_ok = o.pri < eps_prim, dual_ok = o.dua < eps_dual;
+    Mk pinf = !prim_ok & primal_infeasible(st.eps_prim_inf * k);
+    Mk dinf = !dual_ok & dual_infeasible(st.eps_dual_inf * k);
+    I stt(MPMPC_UNSOLVED);
+    stt = seli(dinf, I(MPMPC_DUAL_INFEASIBLE), stt);
+    stt = seli(pinf, I(MPMPC_PRIMAL_INFEASIBLE), stt);
+    stt = seli(prim_ok & dual_ok, I(approximate ? MPMPC_SOLVED_INACCURATE : MPMPC_SOLVED), stt);
+    return stt;
+  }
+
+  MPMPC_HD void admm(const mpmpc_settings& st) {
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) { x[j] = zb[j] = yb[j] = xprev[j] = dyb[j] = R(0.0); }
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) { zeq[i] = yeq[i] = dyeq[i] = R(0.0); }
+    status = I(MPMPC_UNSOLVED);
+    iters = I(0);
+    ipm_iters = I(0);
+    polished = I(0);
+    set_rho(R(st.rho));
+    admm_factor(st.sigma);
+    const R alpha(st.alpha), oma(1.0 - st.alpha), sigma(st.sigma);
+    Mk active = live;
+    Info nf;
+    info(nf);
+    for (int it = 1; it <= st.max_iter; ++it) {
+      if (!L::wany(active)) break;
+      // ---- one ADMM step (OSQP update_xz_tilde / update_x / update_z / update_y)
+      R rx[5], req[3], xt[5], nu[3];
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) rx[j] = fma_(g[j], fma_(rb[j], zb[j], -yb[j]), fma_(sigma, x[j], -q[j]));
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) req[i] = fma_(-yeq[i], rinv_eq, zeq[i]);
+      kkt_solve(rx, req, xt, nu);
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) {
+        R xn = fma_(alpha, xt[j], oma * x[j]);
+        R zr = fma_(alpha, g[j] * xt[j], oma * zb[j]);
+        R zn = min_(max_(fma_(yb[j], rbinv[j], zr), lb[j]), ub[j]);
+        R dy = rb[j] * (zr - zn);
+        xprev[j] = sel(active, x[j], xprev[j]);
+        x[j] = sel(active, xn, x[j]);
+        zb[j] = sel(active, zn, zb[j]);
+        dyb[j] = sel(active, dy, dyb[j]);
+        yb[j] = sel(active, yb[j] + dy, yb[j]);
+      }
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) {
+        R zt = fma_(nu[i] - yeq[i], rinv_eq, zeq[i]);
+        R zr = fma_(alpha, zt, oma * zeq[i]);
+        R zn = leq[i];                                   // projection onto [l, l]
+        R dy = rho_eq * (zr - zn);
+        zeq[i] = sel(active, zn, zeq[i]);
+        dyeq[i] = sel(active, dy, dyeq[i]);
+        yeq[i] = sel(active, yeq[i] + dy, yeq[i]);
+      }
+      iters = seli(active, I(it), iters);
+      // ---- termination
+      bool can_check = st.check_termination > 0 && (it % st.check_termination) == 0;
+      bool can_adapt = st.adaptive_rho && st.adaptive_rho_interval > 0 && (it % st.adaptive_rho_interval) == 0;
+      if (can_check || can_adapt) info(nf);
+      if (can_check) {
+        I stt = check(nf, st, false);
+        Mk term = active & (stt != MPMPC_UNSOLVED);
+        status = seli(term, stt, status);
+        active = active & !term;
+      }
+      // ---- rho adaptation (OSQP compute_rho_estimate / adapt_rho)
+      if (can_adapt) {
+        R pr = nf.s_rp / (max_(nf.s_z, nf.s_Ax) + R(1e-10));
+        R du = nf.s_rd / (max_(max_(nf.s_q, nf.s_Aty), nf.s_Px) + R(1e-10));
+        R est = rho * sqrt_(pr / (du + R(1e-10)));
+        est = min_(max_(est, R(RHO_MIN)), R(RHO_MAX));
+        Mk upd = active & ((est > rho * R(st.adaptive_rho_tolerance)) | (est < rho / R(st.adaptive_rho_tolerance)));
+        if (L::wany(upd)) {
+          set_rho(sel(upd, est, rho));
+          admm_factor(st.sigma);
+        }
+      }
+    }
+    // ---- ran out of iterations: OSQP's final exact, then approximate, check
+    if (L::wany(active)) {
+      info(nf);
+      I s1 = check(nf, st, false);
+      I s2 = check(nf, st, true);
+      I fin = seli(s1 != MPMPC_UNSOLVED, s1, seli(s2 != MPMPC_UNSOLVED, s2, I(MPMPC_MAX_ITER_REACHED)));
+      status = seli(active, fin, status);
+    }
+    info(nf);
+    pri_res = nf.pri;
+    dua_res = nf.dua;
+  }
+
+  // ======================================================================== certified polish
+  // Variable-space view of the box rows: g x in [lb, ub]  <=>  x in [lo, hi].
+  struct Box {
+    R lo[5], hi[5];
+    Mk Lm[5], Um[5], pin[5];
+  };
+  MPMPC_HD void make_box(Box& bx) const {
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      Mk fl = lb[j] > R(-INF_BOUND), fu = ub[j] < R(INF_BOUND);
+      Mk pn = fl & fu & ((ub[j] - lb[j]) <= R(1e-12) * max_(R(1.0), abs_(lb[j])));
+      bx.lo[j] = lb[j] / g[j];
+      bx.hi[j] = ub[j] / g[j];
+      bx.pin[j] = pn & valid[j];
+      bx.Lm[j] = fl & !pn & valid[j];
+      bx.Um[j] = fu & !pn & valid[j];
+    }
+  }
+
+  // Regularised Mehrotra predictor-corrector, warm started at (xw, nuw, ybw).  Linear systems
+  // go through the same block-tridiagonal Schur factorisation as the ADMM step.
+  struct Ipm {
+    R x[5], nu[3], sl[5], su[5], zl[5], zu[5], pi[5];
+  };
+  MPMPC_HD Mk ipm(const Box& bx, Ipm& s, const mpmpc_settings& st, double tol, const Mk& run) {
+    const R reg(st.ipm_reg), one(1.0), zero(0.0);
+    Mk active = run, conv = L::mfalse();
+    R cnt(0.0);
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) cnt = cnt + sel(bx.Lm[j], one, zero) + sel(bx.Um[j], one, zero);
+    R nb = max_(L::gsum(cnt), one);
+    I stall(0);
+    for (int it = 0; it <= st.ipm_max_iter; ++it) {
+      // ---- residuals
+      R At[5], rp[3], rd[5], rl[5], ru[5], rpin[5];
+      AeqT_mul(s.nu, At);
+      Aeq_mul(s.x, rp);
+      R res(0.0), msum(0.0);
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) { rp[i] = rp[i] - leq[i]; res = max_(res, sel(vx, abs_(rp[i]), zero)); }
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) {
+        rd[j] = fma_(p[j], s.x[j], q[j]) + At[j] - s.zl[j] + s.zu[j] + s.pi[j];
+        rl[j] = sel(bx.Lm[j], s.x[j] - bx.lo[j] - s.sl[j], zero);
+        ru[j] = sel(bx.Um[j], bx.hi[j] - s.x[j] - s.su[j], zero);
+        rpin[j] = sel(bx.pin[j], s.x[j] - bx.lo[j], zero);
+        res = max_(res, sel(valid[j], max_(max_(abs_(rd[j]), abs_(rpin[j])), max_(abs_(rl[j]), abs_(ru[j]))), zero));
+        msum = msum + sel(bx.Lm[j], s.sl[j] * s.zl[j], zero) + sel(bx.Um[j], s.su[j] * s.zu[j], zero);
+      }
+      res = L::gmax(res);
+      R mu = L::gsum(msum) / nb;
+      Mk ok = (res < R(tol)) & (mu < R(tol));
+      conv = conv | (active & ok);
+      active = active & !ok;
+      if (it == st.ipm_max_iter || !L::wany(active)) break;
+      ipm_iters = seli(active, ipm_iters + I(1), ipm_iters);
+      // ---- factor
+      R h[5];
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) {
+        R H = p[j] + reg + sel(bx.Lm[j], s.zl[j] / s.sl[j], zero) + sel(bx.Um[j], s.zu[j] / s.su[j], zero) +
+              sel(bx.pin[j], one / reg, zero);
+        h[j] = one / H;
+      }
+      factor(h, reg);
+      // ---- predictor and corrector share the factorisation
+      R dx[5], dnu[3], dsl[5], dsu[5], dzl[5], dzu[5], dpi[5];
+      R rcl[5], rcu[5];
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) { rcl[j] = s.sl[j] * s.zl[j]; rcu[j] = s.su[j] * s.zu[j]; }
+      R alpha_aff(1.0);
+      for (int pass = 0; pass < 2; ++pass) {
+        R rhs[5], nreq[3];
+        MPMPC_UNROLL
+        for (int j = 0; j < 5; ++j)
+          rhs[j] = -rd[j] - sel(bx.Lm[j], (rcl[j] + s.zl[j] * rl[j]) / s.sl[j], zero) +
+                   sel(bx.Um[j], (rcu[j] + s.zu[j] * ru[j]) / s.su[j], zero) - sel(bx.pin[j], rpin[j] / reg, zero);
+        MPMPC_UNROLL
+        for (int i = 0; i < 3; ++i) nreq[i] = -rp[i];
+        kkt_solve(rhs, nreq, dx, dnu);
+        {   // one refinement step
+          R At2[5], Ad[3], r1[5], r2[3], ddx[5], ddnu[3];
+          AeqT_mul(dnu, At2);
+          Aeq_mul(dx, Ad);
+          MPMPC_UNROLL
+          for (int j = 0; j < 5; ++j) r1[j] = rhs[j] - (dx[j] / hinv[j] + At2[j]);
+          MPMPC_UNROLL
+          for (int i = 0; i < 3; ++i) r2[i] = nreq[i] - (Ad[i] - reg * dnu[i]);
+          kkt_solve(r1, r2, ddx, ddnu);
+          MPMPC_UNROLL
+          for (int j = 0; j < 5; ++j) dx[j] = dx[j] + ddx[j];
+          MPMPC_UNROLL
+          for (int i = 0; i < 3; ++i) dnu[i] = dnu[i] + ddnu[i];
+        }
+        R ratio(1e300);
+        MPMPC_UNROLL
+        for (int j = 0; j < 5; ++j) {
+          dsl[j] = sel(bx.Lm[j], dx[j] + rl[j], zero);
+          dsu[j] = sel(bx.Um[j], -dx[j] + ru[j], zero);
+          dzl[j] = sel(bx.Lm[j], (-rcl[j] - s.zl[j] * dsl[j]) / s.sl[j], zero);
+          dzu[j] = sel(bx.Um[j], (-rcu[j] - s.zu[j] * dsu[j]) / s.su[j], zero);
+          dpi[j] = sel(bx.pin[j], (rpin[j] + dx[j]) / reg, zero);
+          ratio = min_(ratio, sel(bx.Lm[j] & (dsl[j] < zero), -s.sl[j] / dsl[j], R(1e300)));
+          ratio = min_(ratio, sel(bx.Um[j] & (dsu[j] < zero), -s.su[j] / dsu[j], R(1e300)));
+          ratio = min_(ratio, sel(bx.Lm[j] & (dzl[j] < zero), -s.zl[j] / dzl[j], R(1e300)));
+          ratio = min_(ratio, sel(bx.Um[j] & (dzu[j] < zero), -s.zu[j] / dzu[j], R(1e300)));
+        }
+        ratio = L::gmin(ratio);
+        if (pass == 0) {
+          alpha_aff = min_(one, ratio);
+          R ms(0.0);
+          MPMPC_UNROLL
+          for (int j = 0; j < 5; ++j)
+            ms = ms + sel(bx.Lm[j], (s.sl[j] + alpha_aff * dsl[j]) * (s.zl[j] + alpha_aff * dzl[j]), zero) +
+                 sel(bx.Um[j], (s.su[j] + alpha_aff * dsu[j]) * (s.zu[j] + alpha_aff * dzu[j]), zero);
+          R mu_aff = L::gsum(ms) / nb;
+          R sg = mu_aff / max_(mu, R(1e-300));
+          sg = sg * sg * sg;
+          MPMPC_UNROLL
+          for (int j = 0; j < 5; ++j) {
+            rcl[j] = s.sl[j] * s.zl[j] - sg * mu + dsl[j] * dzl[j];
+            rcu[j] = s.su[j] * s.zu[j] - sg * mu + dsu[j] * dzu[j];
+          }
+        } else {
+          R al = min_(one, R(0.995) * ratio);
+          stall = seli(active & (al < R(1e-6)), stall + I(1), I(0));
+          MPMPC_UNROLL
+          for (int j = 0; j < 5; ++j) {
+            s.x[j] = sel(active, fma_(al, dx[j], s.x[j]), s.x[j]);
+            s.sl[j] = sel(active, fma_(al, dsl[j], s.sl[j]), s.sl[j]);
+            s.su[j] = sel(active, fma_(al, dsu[j], s.su[j]), s.su[j]);
+            s.zl[j] = sel(active, fma_(al, dzl[j], s.zl[j]), s.zl[j]);
+            s.zu[j] = sel(active, fma_(al, dzu[j], s.zu[j]), s.zu[j]);
+            s.pi[j] = sel(active, fma_(al, dpi[j], s.pi[j]), s.pi[j]);
+          }
+          MPMPC_UNROLL
+          for (int i = 0; i < 3; ++i) s.nu[i] = sel(active, fma_(al, dnu[i], s.nu[i]), s.nu[i]);
+          active = active & (stall < 3);      // steps collapsed: infeasible or hopelessly degenerate
+        }
+      }
+    }
+    return conv;
+  }
+
+  // OSQP's polish solve on a given active set, iterated with primal-dual active-set updates.
+  // On success (xs, nus, lam) is a KKT point of the scaled problem.
+  MPMPC_HD Mk active_set(const Box& bx, Mk aL[5], Mk aU[5], R xs[5], R nus[3], R lam[5],
+                         const mpmpc_settings& st, const Mk& run) {
+    const R delta(st.as_delta), zero(0.0), one(1.0), tol(1e-9);
+    Mk todo = run, okm = L::mfalse();
+    for (int rnd = 0; rnd < st.as_rounds; ++rnd) {
+      if (!L::wany(todo)) break;
+      R h[5], bound[5];
+      Mk act[5];
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) {
+        act[j] = aL[j] | aU[j] | bx.pin[j];
+        bound[j] = sel(aU[j], bx.hi[j], bx.lo[j]);
+        h[j] = one / (p[j] + delta + sel(act[j], one / delta, zero));
+      }
+      factor(h, delta);
+      R xn[5], nn[3], ln[5];
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) xn[j] = ln[j] = zero;
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) nn[i] = zero;
+      for (int rf = 0; rf <= st.as_refine; ++rf) {
+        R At[5], Ax[3], rhs[5], r2[3], r3[5], dx[5], dnu[3];
+        AeqT_mul(nn, At);
+        Aeq_mul(xn, Ax);
+        MPMPC_UNROLL
+        for (int j = 0; j < 5; ++j) {
+          R r1 = -q[j] - p[j] * xn[j] - At[j] - ln[j];
+          r3[j] = sel(act[j], bound[j] - xn[j], zero);
+          rhs[j] = r1 + r3[j] / delta;
+        }
+        MPMPC_UNROLL
+        for (int i = 0; i < 3; ++i) r2[i] = leq[i] - Ax[i];
+        kkt_solve(rhs, r2, dx, dnu);
+        MPMPC_UNROLL
+        for (int j = 0; j < 5; ++j) {
+          ln[j] = ln[j] + sel(act[j], (dx[j] - r3[j]) / delta, zero);
+          xn[j] = xn[j] + dx[j];
+        }
+        MPMPC_UNROLL
+        for (int i = 0; i < 3; ++i) nn[i] = nn[i] + dnu[i];
+      }
+      Mk anybad = L::mfalse();
+      Mk vL[5], vU[5], bL[5], bU[5];
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) {
+        vL[j] = bx.Lm[j] & !aL[j] & (xn[j] < bx.lo[j] - tol);
+        vU[j] = bx.Um[j] & !aU[j] & (xn[j] > bx.hi[j] + tol);
+        bL[j] = aL[j] & (ln[j] > tol);
+        bU[j] = aU[j] & (ln[j] < -tol);
+        anybad = anybad | vL[j] | vU[j] | bL[j] | bU[j];
+      }
+      anybad = L::gany(anybad);
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) {
+        xs[j] = sel(todo, xn[j], xs[j]);
+        lam[j] = sel(todo, ln[j], lam[j]);
+        Mk nL = (aL[j] & !bL[j]) | vL[j];
+        Mk nU = ((aU[j] & !bU[j]) | vU[j]) & !nL;
+        aL[j] = selb(todo & anybad, nL, aL[j]);
+        aU[j] = selb(todo & anybad, nU, aU[j]);
+      }
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) nus[i] = sel(todo, nn[i], nus[i]);
+      okm = okm | (todo & !anybad);
+      todo = todo & anybad;
+    }
+    return okm;
+  }
+
+  // KKT certificate in the UNSCALED problem: primal violation, stationarity, complementarity
+  MPMPC_HD Mk certificate(const R xs[5], const R nus[3], const R lam[5], double tol, R& prim, R& stat) const {
+    R Ax[3], At[5];
+    Aeq_mul(xs, Ax);
+    AeqT_mul(nus, At);
+    R pv(0.0), sv(0.0), cv(0.0);
+    R cinv = R(1.0) / c;
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) pv = max_(pv, sel(vx, abs_((Ax[i] - leq[i]) / Eeq[i]), R(0.0)));
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      R xu = D[j] * xs[j];
+      R viol = max_(max_(lo0[j] - xu, xu - hi0[j]), R(0.0));
+      pv = max_(pv, sel(valid[j], viol, R(0.0)));
+      R rd = fma_(p[j], xs[j], q[j]) + At[j] + lam[j];
+      sv = max_(sv, sel(valid[j], abs_(rd / D[j]) * cinv, R(0.0)));
+      R yu = (lam[j] / D[j]) * cinv;                      // multiplier of the unscaled box row
+      Mk fu = hi0[j] < R(INF_BOUND), fl = lo0[j] > R(-INF_BOUND);
+      R cu = sel(fu, max_(yu, R(0.0)) * abs_(hi0[j] - xu), sel(yu > R(0.0), R(1e300), R(0.0)));
+      R cl = sel(fl, max_(-yu, R(0.0)) * abs_(xu - lo0[j]), sel(yu < R(0.0), R(1e300), R(0.0)));
+      cv = max_(cv, sel(valid[j], max_(cu, cl), R(0.0)));
+    }
+    prim = L::gmax(pv);
+    stat = L::gmax(sv);
+    cv = L::gmax(cv);
+    return (prim <= R(tol)) & (stat <= R(tol)) & (cv <= R(tol));
+  }
+
+  MPMPC_HD void polish(const mpmpc_settings& st) {
+    Mk run = live & ((status == MPMPC_SOLVED) | (status == MPMPC_SOLVED_INACCURATE) | (status == MPMPC_MAX_ITER_REACHED));
+    if (!L::wany(run)) return;
+    Box bx;
+    make_box(bx);
+    const R theta(1e-3), zero(0.0), one(1.0);
+    Ipm s;
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) s.nu[i] = yeq[i];
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      R yv = yb[j] * g[j];
+      s.x[j] = x[j];
+      s.sl[j] = sel(bx.Lm[j], max_(x[j] - bx.lo[j], theta), one);
+      s.su[j] = sel(bx.Um[j], max_(bx.hi[j] - x[j], theta), one);
+      s.zl[j] = sel(bx.Lm[j], max_(-yv, theta), zero);
+      s.zu[j] = sel(bx.Um[j], max_(yv, theta), zero);
+      s.pi[j] = sel(bx.pin[j], yv, zero);
+    }
+    double tol = st.ipm_tol;
+    Mk todo = run;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      Mk conv = ipm(bx, s, st, tol, todo);
+      Mk aL[5], aU[5];
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) {
+        aL[j] = bx.Lm[j] & (s.zl[j] > s.sl[j]);
+        aU[j] = bx.Um[j] & (s.zu[j] > s.su[j]) & !aL[j];
+      }
+      R xs[5], nus[3], lam[5];
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) { xs[j] = s.x[j]; lam[j] = zero; }
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) nus[i] = s.nu[i];
+      Mk okm = active_set(bx, aL, aU, xs, nus, lam, st, todo & conv);
+      R prim, stat;
+      Mk cert = certificate(xs, nus, lam, st.cert_tol, prim, stat);
+      Mk good = todo & conv & okm & cert;
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) { x[j] = sel(good, xs[j], x[j]); yb[j] = sel(good, lam[j] / g[j], yb[j]); }
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) yeq[i] = sel(good, nus[i], yeq[i]);
+      pri_res = sel(good, prim, pri_res);
+      dua_res = sel(good, stat, dua_res);
+      status = seli(good, I(MPMPC_SOLVED), status);
+      polished = seli(good, I(1), polished);
+      todo = todo & conv & !good;       // a diverged interior-point run is not retried
+      if (!L::wany(todo)) break;
+      tol *= 1e-2;
+    }
+    // whatever is left could not be certified: keep the ADMM iterate, flag it
+    Mk failed = run & (polished != 1);
+    status = seli(failed, I(MPMPC_SOLVED_INACCURATE), status);
+    polished = seli(failed, I(-1), polished);
+  }
+
+  // ======================================================================== output
+  // z in the reference's ordering, u0 = (v_0, delta_0), multipliers in the reference's row order
+  MPMPC_HD void store(const I& inst, const I& k, double wheelbase, double* z, double* u0, int* st_out,
+                      int* it_out, double* resid, double* y) const {
+    const int n = 5 * N + 3, m = 8 * N + 6;
+    R cinv = R(1.0) / c;
+    if (z) {
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) L::store(z, inst * n + k * 3 + i, vx, D[i] * x[i]);
+      L::store(z, inst * n + k * 2 + (3 * (N + 1)), vu, D[3] * x[3]);
+      L::store(z, inst * n + k * 2 + (3 * (N + 1) + 1), vu, D[4] * x[4]);
+    }
+    if (y) {
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) {
+        L::store(y, inst * m + k * 3 + i, vx, (Eeq[i] * yeq[i]) * cinv);
+        L::store(y, inst * m + k * 3 + (3 * (N + 1) + i), vx, (Eb[i] * yb[i]) * cinv);
+      }
+      L::store(y, inst * m + k * 2 + (6 * (N + 1)), vu, (Eb[3] * yb[3]) * cinv);
+      L::store(y, inst * m + k * 2 + (6 * (N + 1) + 1), vu, (Eb[4] * yb[4]) * cinv);
+    }
+    Mk lead = live & first;
+    if (u0) {
+      L::store(u0, inst * 2, lead, D[3] * x[3]);
+      L::store(u0, inst * 2 + 1, lead, atan_((D[4] * x[4]) * R(wheelbase)));   // src/MPC.py:188-189
+    }
+    if (st_out) L::storei(st_out, inst, lead, status);
+    if (it_out) { L::storei(it_out, inst * 2, lead, iters); L::storei(it_out, inst * 2 + 1, lead, ipm_iters); }
+    if (resid) { L::store(resid, inst * 2, lead, pri_res); L::store(resid, inst * 2 + 1, lead, dua_res); }
+  }
+
+  MPMPC_HD void run(const double* qp, int B, int ld, const I& inst, const I& k, int N_, const mpmpc_settings& st) {
+    load(qp, B, ld, inst, k, N_);
+    scale(st.scaling);
+    admm(st);
+    if (st.polish) polish(st);
+  }
+};
+
+}  // namespace mpmpc

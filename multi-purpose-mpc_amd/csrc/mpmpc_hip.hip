@@ -1,0 +1,392 @@
+// libmpmpc.so: HIP kernels for gfx950 (MI355X) + the C ABI of include/mpmpc.h.
+//
+//   K1  mpmpc_assemble_kernel   one thread per (instance, stage): gathers waypoint data from
+//                               LDS-staged path tables, builds the stage's dynamics blocks,
+//                               offsets, bounds and cost terms, stores them stage-blocked
+//                               ([field][instance][stage], unit-stride across lanes).  HBM bound.
+//   K2  mpmpc_solve_kernel<G>   one 64-lane wavefront per 64/G instances, lane = horizon stage;
+//                               Ruiz scaling, OSQP ADMM, certified polish, all state in VGPRs,
+//                               stage coupling by DPP shifts, norms by wavefront reductions.
+//                               FP64-VALU / dependency-chain bound; touches HBM only to read the
+//                               27 stage fields and to write the solution.
+//
+// No CPU path exists in this library: every compute entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#define MPMPC_HD __device__ __forceinline__
+#include "lane_gpu.hpp"
+#include "mpmpc_core.hpp"
+
+using namespace mpmpc;
+
+// ------------------------------------------------------------------------------------ kernels
+constexpr int K1_THREADS = 256;
+constexpr int K1_LDS_WP = 1024;   // path tables of up to this many waypoints are staged in LDS
+
+__global__ __launch_bounds__(K1_THREADS) void mpmpc_assemble_kernel(
+    mpmpc_config cfg, PathTables tab, int B, int ld, const int* __restrict__ wp_id, const double* __restrict__ x0,
+    const double* __restrict__ cc, const double* __restrict__ lb, const double* __restrict__ ub,
+    double* __restrict__ qp) {
+  __shared__ double s_kappa[K1_LDS_WP], s_vref[K1_LDS_WP], s_ds[K1_LDS_WP];
+  PathTables t = tab;
+  if (tab.n_wp <= K1_LDS_WP) {   // block-uniform
+    for (int i = threadIdx.x; i < tab.n_wp; i += K1_THREADS) {
+      s_kappa[i] = tab.kappa[i];
+      s_vref[i] = tab.v_ref[i];
+      s_ds[i] = tab.ds_next[i];
+    }
+    __syncthreads();
+    t.kappa = s_kappa;
+    t.v_ref = s_vref;
+    t.ds_next = s_ds;
+  }
+  // grid-stride over (instance, stage) pairs, stage fastest: a wavefront writes 64 consecutive
+  // doubles of one field
+  const int total = B * ld;
+  for (int g = blockIdx.x * K1_THREADS + threadIdx.x; g < total; g += gridDim.x * K1_THREADS) {
+    int inst = g / ld, k = g - inst * ld;
+    assemble_lane<LaneGpu<64>>(cfg, t, B, ld, inst, k, wp_id, x0, cc, lb, ub, qp);
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, mpmpc_settings st, int B, int ld,
+                                                         const double* __restrict__ qp, double* __restrict__ z,
+                                                         double* __restrict__ u0, int* __restrict__ status,
+                                                         int* __restrict__ iters, double* __restrict__ resid,
+                                                         double* __restrict__ y) {
+  using L = LaneGpu<G>;
+  const int inst = blockIdx.x * L::per_wave + L::slot();
+  const int k = L::stage();
+  Solver<L> s;
+  s.run(qp, B, ld, inst, k, cfg.N, st);
+  s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y);
+}
+
+// ------------------------------------------------------------------------------------ host side
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(MPMPC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+  } while (0)
+
+struct mpmpc_handle_s {
+  mpmpc_config cfg;
+  mpmpc_settings st;
+  int ld = 0, n = 0, m = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  // tables
+  double *kappa = nullptr, *v_ref = nullptr, *ds_next = nullptr, *ub_tab = nullptr, *lb_tab = nullptr;
+  int n_wp = 0, n_cols = 0;
+  // per-batch inputs
+  int* wp_id = nullptr;
+  double *x0 = nullptr, *cc = nullptr, *lb = nullptr, *ub = nullptr;
+  bool have_rows = false;     // per-instance corridor rows uploaded (else: table)
+  int uploaded = 0;
+  // stage-blocked QP and outputs
+  double *qp = nullptr, *z = nullptr, *u0 = nullptr, *resid = nullptr, *y = nullptr;
+  int *status = nullptr, *iters = nullptr;
+};
+
+static int host_stage_ld(int N) { return N + 1 <= 16 ? 16 : (N + 1 <= 32 ? 32 : 64); }
+
+static int check_settings(const mpmpc_settings* s) {
+  if (!s) return fail(MPMPC_E_ARG, "settings is NULL");
+  if (!(s->rho > 0) || !(s->sigma > 0) || !(s->alpha > 0 && s->alpha < 2))
+    return fail(MPMPC_E_ARG, "need rho > 0, sigma > 0, 0 < alpha < 2");
+  if (s->max_iter < 0 || s->check_termination < 0 || s->scaling < 0 || s->ipm_max_iter < 0 || s->as_rounds < 0 ||
+      s->as_refine < 0)
+    return fail(MPMPC_E_ARG, "iteration counts must be non-negative");
+  if (s->polish != 0 && s->polish != 2) return fail(MPMPC_E_ARG, "polish must be 0 or 2");
+  if (s->polish == 2 && (!(s->ipm_reg > 0) || !(s->as_delta > 0) || !(s->ipm_tol > 0)))
+    return fail(MPMPC_E_ARG, "polish needs ipm_reg, ipm_tol, as_delta > 0");
+  return MPMPC_OK;
+}
+
+extern "C" {
+
+const char* mpmpc_version(void) { return "mpmpc 0.1.0 (gfx950, float64)"; }
+const char* mpmpc_last_error(void) { return g_err.c_str(); }
+
+int mpmpc_device_count(int32_t* count) {
+  if (!count) return fail(MPMPC_E_ARG, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(MPMPC_E_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *count = n;
+  return MPMPC_OK;
+}
+
+void mpmpc_default_settings(mpmpc_settings* s) {
+  if (!s) return;
+  s->rho = 0.1; s->sigma = 1e-6; s->alpha = 1.6;
+  s->eps_abs = 1e-3; s->eps_rel = 1e-3; s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4;
+  s->max_iter = 4000; s->check_termination = 25; s->scaling = 10;
+  s->adaptive_rho = 1; s->adaptive_rho_interval = 50; s->adaptive_rho_tolerance = 5.0;
+  s->polish = 2; s->ipm_max_iter = 50; s->ipm_tol = 1e-9; s->ipm_reg = 1e-8;
+  s->as_delta = 1e-9; s->as_refine = 5; s->as_rounds = 10; s->cert_tol = 1e-8;
+}
+
+int32_t mpmpc_stage_ld(int32_t N) { return host_stage_ld(N); }
+
+int mpmpc_destroy(mpmpc_handle h) {
+  if (!h) return MPMPC_OK;
+  (void)hipSetDevice(h->cfg.device);
+  void* ptrs[] = {h->kappa, h->v_ref, h->ds_next, h->ub_tab, h->lb_tab, h->wp_id, h->x0, h->cc, h->lb,
+                  h->ub,    h->qp,    h->z,       h->u0,     h->resid,  h->y,     h->status, h->iters};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (auto& e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return MPMPC_OK;
+}
+
+int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_handle* out) {
+  if (!cfg || !out) return fail(MPMPC_E_ARG, "cfg/out is NULL");
+  *out = nullptr;
+  if (cfg->N < 3 || cfg->N > MPMPC_MAX_HORIZON)
+    return fail(MPMPC_E_ARG, "horizon N must satisfy 3 <= N <= 63");
+  if (cfg->max_batch < 1) return fail(MPMPC_E_ARG, "max_batch must be >= 1");
+  if (!(cfg->wheelbase > 0)) return fail(MPMPC_E_ARG, "wheelbase must be > 0");
+  for (int i = 0; i < 3; ++i)
+    if (!(cfg->Q[i] >= 0) || !(cfg->QN[i] >= 0)) return fail(MPMPC_E_ARG, "Q, QN diagonals must be >= 0");
+  for (int i = 0; i < 2; ++i) {
+    if (!(cfg->R[i] >= 0)) return fail(MPMPC_E_ARG, "R diagonal must be >= 0");
+    if (!std::isfinite(cfg->umin[i]) || !std::isfinite(cfg->umax[i]) || cfg->umin[i] > cfg->umax[i])
+      return fail(MPMPC_E_ARG, "input bounds must be finite with umin <= umax");
+  }
+  mpmpc_settings st;
+  if (settings) st = *settings; else mpmpc_default_settings(&st);
+  if (int rc = check_settings(&st)) return rc;
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (cfg->device < 0 || cfg->device >= ndev)
+    return fail(MPMPC_E_HIP, "no such HIP device (this library has no CPU fallback)");
+  HIP_TRY(hipSetDevice(cfg->device));
+  mpmpc_handle h = new (std::nothrow) mpmpc_handle_s();
+  if (!h) return fail(MPMPC_E_STATE, "out of host memory");
+  h->cfg = *cfg;
+  h->st = st;
+  h->ld = host_stage_ld(cfg->N);
+  h->n = 5 * cfg->N + 3;
+  h->m = 8 * cfg->N + 6;
+  const size_t B = (size_t)cfg->max_batch, N = (size_t)cfg->N;
+#define ALLOC(ptr, count)                                                                \
+  do {                                                                                   \
+    hipError_t e_ = hipMalloc((void**)&(ptr), (count) * sizeof(*(ptr)));                 \
+    if (e_ != hipSuccess) {                                                              \
+      mpmpc_destroy(h);                                                                  \
+      return fail(MPMPC_E_HIP, std::string("hipMalloc " #ptr ": ") + hipGetErrorString(e_)); \
+    }                                                                                    \
+  } while (0)
+  ALLOC(h->wp_id, B);
+  ALLOC(h->x0, B * 3);
+  ALLOC(h->cc, B * 2 * N);
+  ALLOC(h->lb, B * N);
+  ALLOC(h->ub, B * N);
+  ALLOC(h->qp, (size_t)MPMPC_NUM_FIELDS * B * h->ld);
+  ALLOC(h->z, B * h->n);
+  ALLOC(h->u0, B * 2);
+  ALLOC(h->resid, B * 2);
+  ALLOC(h->y, B * h->m);
+  ALLOC(h->status, B);
+  ALLOC(h->iters, B * 2);
+#undef ALLOC
+  hipError_t e = hipStreamCreate(&h->stream);
+  for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
+  if (e != hipSuccess) {
+    mpmpc_destroy(h);
+    return fail(MPMPC_E_HIP, std::string("stream/event creation: ") + hipGetErrorString(e));
+  }
+  *out = h;
+  return MPMPC_OK;
+}
+
+int mpmpc_set_settings(mpmpc_handle h, const mpmpc_settings* settings) {
+  if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  if (int rc = check_settings(settings)) return rc;
+  h->st = *settings;
+  return MPMPC_OK;
+}
+
+static int upload_table(mpmpc_handle h, double** dst, const double* src, size_t count) {
+  if (*dst) { HIP_TRY(hipFree(*dst)); *dst = nullptr; }
+  HIP_TRY(hipMalloc((void**)dst, count * sizeof(double)));
+  HIP_TRY(hipMemcpyAsync(*dst, src, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  return MPMPC_OK;
+}
+
+int mpmpc_set_path(mpmpc_handle h, int32_t n_wp, const double* kappa, const double* v_ref, const double* ds_next) {
+  if (!h || !kappa || !v_ref || !ds_next) return fail(MPMPC_E_ARG, "NULL argument");
+  if (n_wp < 2) return fail(MPMPC_E_ARG, "need at least 2 waypoints");
+  for (int i = 0; i < n_wp; ++i)
+    if (!(v_ref[i] > 0) || !std::isfinite(kappa[i]) || !(ds_next[i] >= 0))
+      return fail(MPMPC_E_ARG, "path table: need v_ref > 0, finite kappa, ds_next >= 0");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (int rc = upload_table(h, &h->kappa, kappa, n_wp)) return rc;
+  if (int rc = upload_table(h, &h->v_ref, v_ref, n_wp)) return rc;
+  if (int rc = upload_table(h, &h->ds_next, ds_next, n_wp)) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->n_wp != n_wp) { h->n_cols = 0; }   // a corridor table of another path is void
+  h->n_wp = n_wp;
+  return MPMPC_OK;
+}
+
+int mpmpc_set_corridor(mpmpc_handle h, int32_t n_wp, int32_t n_cols, const double* ub, const double* lb) {
+  if (!h || !ub || !lb) return fail(MPMPC_E_ARG, "NULL argument");
+  if (h->n_wp == 0 || n_wp != h->n_wp) return fail(MPMPC_E_STATE, "set the path first; n_wp must match it");
+  if (n_cols < h->cfg.N) return fail(MPMPC_E_ARG, "corridor table needs n_cols >= N");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (int rc = upload_table(h, &h->ub_tab, ub, (size_t)n_wp * n_cols)) return rc;
+  if (int rc = upload_table(h, &h->lb_tab, lb, (size_t)n_wp * n_cols)) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->n_cols = n_cols;
+  return MPMPC_OK;
+}
+
+int mpmpc_upload(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x0, const double* cc_prev,
+                 const double* lb, const double* ub) {
+  if (!h || !wp_id || !x0 || !cc_prev) return fail(MPMPC_E_ARG, "NULL argument");
+  if (B < 1 || B > h->cfg.max_batch) return fail(MPMPC_E_ARG, "B must be in [1, max_batch]");
+  if (h->n_wp == 0) return fail(MPMPC_E_STATE, "no path set (mpmpc_set_path)");
+  if ((lb == nullptr) != (ub == nullptr)) return fail(MPMPC_E_ARG, "lb and ub must both be given or both NULL");
+  if (!lb && h->n_cols == 0) return fail(MPMPC_E_STATE, "no corridor rows given and no corridor table set");
+  const int N = h->cfg.N;
+  for (int i = 0; i < B; ++i) {
+    if (wp_id[i] < 0 || wp_id[i] >= h->n_wp) return fail(MPMPC_E_ARG, "wp_id out of range");
+    // an open path ends the run when the horizon passes its last waypoint (src/reference_path.py:367-369)
+    if (!h->cfg.circular && wp_id[i] + N >= h->n_wp) return fail(MPMPC_E_ARG, "Reached end of path!");
+  }
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipMemcpyAsync(h->wp_id, wp_id, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->x0, x0, sizeof(double) * 3 * B, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->cc, cc_prev, sizeof(double) * 2 * N * B, hipMemcpyHostToDevice, h->stream));
+  if (lb) {
+    HIP_TRY(hipMemcpyAsync(h->lb, lb, sizeof(double) * N * B, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->ub, ub, sizeof(double) * N * B, hipMemcpyHostToDevice, h->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller
+  h->have_rows = lb != nullptr;
+  h->uploaded = B;
+  return MPMPC_OK;
+}
+
+static int launch_assemble(mpmpc_handle h, int B) {
+  PathTables t{h->kappa, h->v_ref, h->ds_next, h->n_wp, h->ub_tab, h->lb_tab, h->n_cols};
+  const int total = B * h->ld;
+  int blocks = (total + K1_THREADS - 1) / K1_THREADS;
+  if (blocks > 2048) blocks = 2048;          // 256 CUs x 8 blocks, grid-stride beyond that
+  hipLaunchKernelGGL(mpmpc_assemble_kernel, dim3(blocks), dim3(K1_THREADS), 0, h->stream, h->cfg, t, B, h->ld,
+                     h->wp_id, h->x0, h->cc, h->have_rows ? h->lb : nullptr, h->have_rows ? h->ub : nullptr, h->qp);
+  HIP_TRY(hipGetLastError());
+  return MPMPC_OK;
+}
+
+static int launch_solve(mpmpc_handle h, int B) {
+  const int N = h->cfg.N;
+  // lanes per instance: the smallest power of two holding N+1 stages once there are enough
+  // instances to fill the chip (1024 SIMDs) several times over; otherwise one instance per wave
+  int G = 64;
+  if (N + 1 <= 32 && B >= 4096) G = 32;
+  if (N + 1 <= 16 && B >= 8192) G = 16;
+  const int per = 64 / G;
+  const int blocks = (B + per - 1) / per;
+#define LAUNCH(GG)                                                                                         \
+  hipLaunchKernelGGL(mpmpc_solve_kernel<GG>, dim3(blocks), dim3(64), 0, h->stream, h->cfg, h->st, B, h->ld, \
+                     h->qp, h->z, h->u0, h->status, h->iters, h->resid, h->y)
+  if (G == 64) LAUNCH(64);
+  else if (G == 32) LAUNCH(32);
+  else LAUNCH(16);
+#undef LAUNCH
+  HIP_TRY(hipGetLastError());
+  return MPMPC_OK;
+}
+
+int mpmpc_solve_resident(mpmpc_handle h, int32_t B) {
+  if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  if (B < 1 || B > h->uploaded) return fail(MPMPC_E_STATE, "B exceeds the uploaded batch");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (int rc = launch_assemble(h, B)) return rc;
+  return launch_solve(h, B);
+}
+
+int mpmpc_solve_resident_timed(mpmpc_handle h, int32_t B, float* ms_assemble, float* ms_solve) {
+  if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  if (B < 1 || B > h->uploaded) return fail(MPMPC_E_STATE, "B exceeds the uploaded batch");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+  if (int rc = launch_assemble(h, B)) return rc;
+  HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+  if (int rc = launch_solve(h, B)) return rc;
+  HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+  HIP_TRY(hipEventSynchronize(h->ev[2]));
+  float a = 0.f, s = 0.f;
+  HIP_TRY(hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+  HIP_TRY(hipEventElapsedTime(&s, h->ev[1], h->ev[2]));
+  if (ms_assemble) *ms_assemble = a;
+  if (ms_solve) *ms_solve = s;
+  return MPMPC_OK;
+}
+
+int mpmpc_sync(mpmpc_handle h) {
+  if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return MPMPC_OK;
+}
+
+int mpmpc_download(mpmpc_handle h, int32_t B, double* z, double* u0, int32_t* status, int32_t* iters,
+                   double* resid, double* y) {
+  if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  if (B < 1 || B > h->uploaded) return fail(MPMPC_E_STATE, "B exceeds the uploaded batch");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (z) HIP_TRY(hipMemcpyAsync(z, h->z, sizeof(double) * h->n * B, hipMemcpyDeviceToHost, h->stream));
+  if (u0) HIP_TRY(hipMemcpyAsync(u0, h->u0, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, h->stream));
+  if (status) HIP_TRY(hipMemcpyAsync(status, h->status, sizeof(int) * B, hipMemcpyDeviceToHost, h->stream));
+  if (iters) HIP_TRY(hipMemcpyAsync(iters, h->iters, sizeof(int) * 2 * B, hipMemcpyDeviceToHost, h->stream));
+  if (resid) HIP_TRY(hipMemcpyAsync(resid, h->resid, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, h->stream));
+  if (y) HIP_TRY(hipMemcpyAsync(y, h->y, sizeof(double) * h->m * B, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return MPMPC_OK;
+}
+
+int mpmpc_assemble(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x0, const double* cc_prev,
+                   const double* lb, const double* ub, double* qp_out) {
+  if (int rc = mpmpc_upload(h, B, wp_id, x0, cc_prev, lb, ub)) return rc;
+  if (int rc = launch_assemble(h, B)) return rc;
+  if (qp_out) {
+    // device layout is [field][B][ld]; rows of B*ld doubles per field are contiguous
+    HIP_TRY(hipMemcpyAsync(qp_out, h->qp, sizeof(double) * MPMPC_NUM_FIELDS * (size_t)B * h->ld,
+                           hipMemcpyDeviceToHost, h->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return MPMPC_OK;
+}
+
+int mpmpc_solve(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x0, const double* cc_prev,
+                const double* lb, const double* ub, double* z, double* u0, int32_t* status, int32_t* iters,
+                double* resid, double* y) {
+  if (int rc = mpmpc_upload(h, B, wp_id, x0, cc_prev, lb, ub)) return rc;
+  if (int rc = mpmpc_solve_resident(h, B)) return rc;
+  return mpmpc_download(h, B, z, u0, status, iters, resid, y);
+}
+
+}  // extern "C"

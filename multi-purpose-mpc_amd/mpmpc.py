@@ -1,0 +1,250 @@
+"""ctypes binding of the C ABI declared in include/mpmpc.h (libmpmpc.so, HIP kernels for gfx950).
+
+This is the only place Python touches the device library.  There is no CPU fallback: if the
+shared library is missing or no HIP device is present, construction of a `Handle` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libmpmpc.so")
+
+NX, NU = 3, 2
+NUM_FIELDS = 27
+MAX_HORIZON = 63
+
+SOLVED, SOLVED_INACCURATE = 1, 2
+MAX_ITER_REACHED, PRIMAL_INFEASIBLE, DUAL_INFEASIBLE, UNSOLVED = -2, -3, -4, -10
+
+
+class Config(C.Structure):
+    """mpmpc_config"""
+    _fields_ = [("N", C.c_int32), ("max_batch", C.c_int32), ("device", C.c_int32), ("circular", C.c_int32),
+                ("Q", C.c_double * 3), ("R", C.c_double * 2), ("QN", C.c_double * 3),
+                ("xmin", C.c_double * 3), ("xmax", C.c_double * 3),
+                ("umin", C.c_double * 2), ("umax", C.c_double * 2),
+                ("ay_max", C.c_double), ("wheelbase", C.c_double)]
+
+
+class Settings(C.Structure):
+    """mpmpc_settings (OSQP 0.6.x names/defaults for the ADMM stage + certified polish)"""
+    _fields_ = [("rho", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double),
+                ("eps_abs", C.c_double), ("eps_rel", C.c_double),
+                ("eps_prim_inf", C.c_double), ("eps_dual_inf", C.c_double),
+                ("max_iter", C.c_int32), ("check_termination", C.c_int32), ("scaling", C.c_int32),
+                ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32),
+                ("adaptive_rho_tolerance", C.c_double),
+                ("polish", C.c_int32), ("ipm_max_iter", C.c_int32),
+                ("ipm_tol", C.c_double), ("ipm_reg", C.c_double), ("as_delta", C.c_double),
+                ("as_refine", C.c_int32), ("as_rounds", C.c_int32), ("cert_tol", C.c_double)]
+
+
+def default_settings(**kw) -> Settings:
+    s = Settings(rho=0.1, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, eps_prim_inf=1e-4,
+                 eps_dual_inf=1e-4, max_iter=4000, check_termination=25, scaling=10, adaptive_rho=1,
+                 adaptive_rho_interval=50, adaptive_rho_tolerance=5.0, polish=2, ipm_max_iter=50,
+                 ipm_tol=1e-9, ipm_reg=1e-8, as_delta=1e-9, as_refine=5, as_rounds=10, cert_tol=1e-8)
+    for k, v in kw.items():
+        if not hasattr(s, k):
+            raise TypeError("unknown solver setting %r" % k)
+        setattr(s, k, v)
+    return s
+
+
+def make_config(N, Q, R, QN, xmin, xmax, umin, umax, ay_max, wheelbase, circular=True, max_batch=1,
+                device=0) -> Config:
+    if not 3 <= int(N) <= MAX_HORIZON:
+        raise ValueError("horizon N must satisfy 3 <= N <= %d" % MAX_HORIZON)
+    c = Config(N=int(N), max_batch=int(max_batch), device=int(device), circular=int(bool(circular)),
+               ay_max=float(ay_max), wheelbase=float(wheelbase))
+    for name, val, n in (("Q", Q, 3), ("R", R, 2), ("QN", QN, 3), ("xmin", xmin, 3), ("xmax", xmax, 3),
+                         ("umin", umin, 2), ("umax", umax, 2)):
+        a = np.asarray(val, float).ravel()
+        if a.size != n:
+            raise ValueError("%s must have %d entries" % (name, n))
+        setattr(c, name, (C.c_double * n)(*a))
+    return c
+
+
+def stage_ld(N: int) -> int:
+    return 16 if N + 1 <= 16 else (32 if N + 1 <= 32 else 64)
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """dlopen libmpmpc.so and declare every entry point of include/mpmpc.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError("mpmpc: %s not found - build it with `python __graft_entry__.py` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % p)
+    lib = C.CDLL(p)
+    h = C.c_void_p
+    lib.mpmpc_version.restype = C.c_char_p
+    lib.mpmpc_last_error.restype = C.c_char_p
+    lib.mpmpc_device_count.argtypes = [_ip]
+    lib.mpmpc_default_settings.argtypes = [C.POINTER(Settings)]
+    lib.mpmpc_default_settings.restype = None
+    lib.mpmpc_create.argtypes = [C.POINTER(Config), C.POINTER(Settings), C.POINTER(h)]
+    lib.mpmpc_destroy.argtypes = [h]
+    lib.mpmpc_set_settings.argtypes = [h, C.POINTER(Settings)]
+    lib.mpmpc_set_path.argtypes = [h, C.c_int32, _dp, _dp, _dp]
+    lib.mpmpc_set_corridor.argtypes = [h, C.c_int32, C.c_int32, _dp, _dp]
+    lib.mpmpc_assemble.argtypes = [h, C.c_int32, _ip, _dp, _dp, _dp, _dp, _dp]
+    lib.mpmpc_stage_ld.argtypes = [C.c_int32]
+    lib.mpmpc_stage_ld.restype = C.c_int32
+    lib.mpmpc_solve.argtypes = [h, C.c_int32, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _dp]
+    lib.mpmpc_upload.argtypes = [h, C.c_int32, _ip, _dp, _dp, _dp, _dp]
+    lib.mpmpc_solve_resident.argtypes = [h, C.c_int32]
+    lib.mpmpc_sync.argtypes = [h]
+    lib.mpmpc_download.argtypes = [h, C.c_int32, _dp, _dp, _ip, _ip, _dp, _dp]
+    lib.mpmpc_solve_resident_timed.argtypes = [h, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+EXPORTS = ["mpmpc_version", "mpmpc_last_error", "mpmpc_device_count", "mpmpc_default_settings",
+           "mpmpc_create", "mpmpc_destroy", "mpmpc_set_settings", "mpmpc_set_path", "mpmpc_set_corridor",
+           "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident",
+           "mpmpc_sync", "mpmpc_download", "mpmpc_solve_resident_timed"]
+
+
+class MpmpcError(RuntimeError):
+    pass
+
+
+class Solution:
+    """Outputs of one batched solve (host arrays)."""
+    __slots__ = ("z", "u0", "status", "iters", "resid", "y")
+
+    def __init__(self, z, u0, status, iters, resid, y):
+        self.z, self.u0, self.status, self.iters, self.resid, self.y = z, u0, status, iters, resid, y
+
+
+class Handle:
+    """One device context: controller constants, path tables, device buffers for max_batch QPs."""
+
+    def __init__(self, config: Config, settings: Settings | None = None):
+        self.lib = load_library()
+        self.cfg = config
+        self.N = config.N
+        self.n = 5 * self.N + 3
+        self.m = 8 * self.N + 6
+        self.settings = settings or default_settings()
+        self._h = C.c_void_p()
+        self._check(self.lib.mpmpc_create(C.byref(self.cfg), C.byref(self.settings), C.byref(self._h)))
+        self._have_table = False
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MpmpcError("mpmpc error %d: %s" % (rc, self.lib.mpmpc_last_error().decode()))
+
+    def close(self):
+        if self._h:
+            self.lib.mpmpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_settings(self, settings: Settings):
+        self.settings = settings
+        self._check(self.lib.mpmpc_set_settings(self._h, C.byref(settings)))
+
+    def set_path(self, kappa, v_ref, ds_next):
+        k, v, d = (np.ascontiguousarray(a, dtype=np.float64) for a in (kappa, v_ref, ds_next))
+        if not (k.size == v.size == d.size):
+            raise ValueError("path tables must have equal length")
+        self._check(self.lib.mpmpc_set_path(self._h, k.size, _d(k), _d(v), _d(d)))
+
+    def set_corridor(self, ub, lb):
+        ub = np.ascontiguousarray(ub, dtype=np.float64)
+        lb = np.ascontiguousarray(lb, dtype=np.float64)
+        if ub.shape != lb.shape or ub.ndim != 2:
+            raise ValueError("corridor tables must be equal-shape [n_wp x n_cols]")
+        self._check(self.lib.mpmpc_set_corridor(self._h, ub.shape[0], ub.shape[1], _d(ub), _d(lb)))
+        self._have_table = True
+
+    def _inputs(self, wp_id, x0, cc_prev, lb, ub):
+        wp = np.ascontiguousarray(wp_id, dtype=np.int32).ravel()
+        B = wp.size
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(B, 3)
+        cc = np.ascontiguousarray(cc_prev, dtype=np.float64).reshape(B, 2 * self.N)
+        if (lb is None) != (ub is None):
+            raise ValueError("lb and ub must both be given or both be None")
+        if lb is not None:
+            lb = np.ascontiguousarray(lb, dtype=np.float64).reshape(B, self.N)
+            ub = np.ascontiguousarray(ub, dtype=np.float64).reshape(B, self.N)
+        elif not self._have_table:
+            raise ValueError("no per-instance corridor given and no corridor table set")
+        return B, wp, x0, cc, lb, ub
+
+    def assemble(self, wp_id, x0, cc_prev, lb=None, ub=None):
+        """Stage-blocked QP [NUM_FIELDS, B, LD] as K1 leaves it in HBM."""
+        B, wp, x0, cc, lb, ub = self._inputs(wp_id, x0, cc_prev, lb, ub)
+        qp = np.zeros((NUM_FIELDS, B, stage_ld(self.N)))
+        self._check(self.lib.mpmpc_assemble(self._h, B, _i(wp), _d(x0), _d(cc), _d(lb), _d(ub), _d(qp)))
+        return qp
+
+    def _outputs(self, B, want_y):
+        return (np.zeros((B, self.n)), np.zeros((B, 2)), np.zeros(B, np.int32), np.zeros((B, 2), np.int32),
+                np.zeros((B, 2)), np.zeros((B, self.m)) if want_y else None)
+
+    def solve(self, wp_id, x0, cc_prev, lb=None, ub=None, want_y=False) -> Solution:
+        B, wp, x0, cc, lb, ub = self._inputs(wp_id, x0, cc_prev, lb, ub)
+        z, u0, st, it, rs, y = self._outputs(B, want_y)
+        self._check(self.lib.mpmpc_solve(self._h, B, _i(wp), _d(x0), _d(cc), _d(lb), _d(ub), _d(z), _d(u0),
+                                         _i(st), _i(it), _d(rs), _d(y)))
+        return Solution(z, u0, st, it, rs, y)
+
+    # --- resident (benchmark / closed loop) form
+    def upload(self, wp_id, x0, cc_prev, lb=None, ub=None):
+        B, wp, x0, cc, lb, ub = self._inputs(wp_id, x0, cc_prev, lb, ub)
+        self._check(self.lib.mpmpc_upload(self._h, B, _i(wp), _d(x0), _d(cc), _d(lb), _d(ub)))
+        return B
+
+    def solve_resident(self, B):
+        self._check(self.lib.mpmpc_solve_resident(self._h, B))
+
+    def sync(self):
+        self._check(self.lib.mpmpc_sync(self._h))
+
+    def download(self, B, want_y=False) -> Solution:
+        z, u0, st, it, rs, y = self._outputs(B, want_y)
+        self._check(self.lib.mpmpc_download(self._h, B, _d(z), _d(u0), _i(st), _i(it), _d(rs), _d(y)))
+        return Solution(z, u0, st, it, rs, y)
+
+    def solve_resident_timed(self, B):
+        a, s = C.c_float(), C.c_float()
+        self._check(self.lib.mpmpc_solve_resident_timed(self._h, B, C.byref(a), C.byref(s)))
+        return a.value, s.value
+
+
+def device_count() -> int:
+    n = C.c_int32(0)
+    rc = load_library().mpmpc_device_count(C.byref(n))
+    return n.value if rc == 0 else 0

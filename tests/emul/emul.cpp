@@ -1,0 +1,51 @@
+// CPU lock-step emulation of the HIP kernels (TEST INFRASTRUCTURE ONLY).
+// Instantiates the lane-generic core of multi-purpose-mpc_amd/csrc/mpmpc_core.hpp with the
+// 64-lane emulated wavefront of lane_emu.hpp so the kernel algorithm can be checked against
+// the oracle in the GPU-less authoring container.  Never loaded by the product.
+#include "lane_emu.hpp"
+#include "mpmpc_core.hpp"
+
+using namespace mpmpc;
+
+template <int G>
+static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z,
+                    double* u0, int* status, int* iters, double* resid, double* y) {
+  using L = LaneEmu<G>;
+  const int ld = stage_ld(cfg->N);
+  const int per = L::per_wave;
+  for (int w0 = 0; w0 < B; w0 += per) {
+    VI inst = L::slot() + w0;
+    VI k = L::stage();
+    Solver<L> s;
+    s.run(qp, B, ld, inst, k, cfg->N, *st);
+    s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y);
+  }
+}
+
+extern "C" int emu_solve(const mpmpc_config* cfg, const mpmpc_settings* st, int G, const double* qp, int B,
+                         double* z, double* u0, int* status, int* iters, double* resid, double* y) {
+  if (cfg->N + 1 > G) return -1;
+  if (G == 64) solve_g<64>(cfg, st, qp, B, z, u0, status, iters, resid, y);
+  else if (G == 32) solve_g<32>(cfg, st, qp, B, z, u0, status, iters, resid, y);
+  else if (G == 16) solve_g<16>(cfg, st, qp, B, z, u0, status, iters, resid, y);
+  else return -1;
+  return 0;
+}
+
+extern "C" int emu_assemble(const mpmpc_config* cfg, int n_wp, const double* kappa, const double* v_ref,
+                            const double* ds_next, int n_cols, const double* ub_tab, const double* lb_tab, int B,
+                            const int* wp_id, const double* x0, const double* cc, const double* lb,
+                            const double* ub, double* qp) {
+  using L = LaneEmu<64>;
+  PathTables t{kappa, v_ref, ds_next, n_wp, ub_tab, lb_tab, n_cols};
+  const int ld = stage_ld(cfg->N);
+  const int total = B * ld;
+  for (int t0 = 0; t0 < total; t0 += EMU_W) {
+    VI inst, k;
+    for (int i = 0; i < EMU_W; ++i) { inst.v[i] = (t0 + i) / ld; k.v[i] = (t0 + i) % ld; }
+    assemble_lane<L>(*cfg, t, B, ld, inst, k, wp_id, x0, cc, lb, ub, qp);
+  }
+  return 0;
+}
+
+extern "C" int emu_stage_ld(int N) { return stage_ld(N); }

@@ -1,0 +1,111 @@
+"""Shared helpers for the test-suite (host side only)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "multi-purpose-mpc_amd")
+for p in (PKG, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import mpmpc  # noqa: E402
+import scenarios  # noqa: E402
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def stock_config(N, weights="stock", max_batch=1, circular=True):
+    Q, R, QN = scenarios.WEIGHTS[weights]
+    return mpmpc.make_config(N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX,
+                             scenarios.AY_MAX, scenarios.CAR_LENGTH, circular=circular, max_batch=max_batch)
+
+
+def qp_to_dense(qp_i, N):
+    """Stage-blocked fields [27, LD] of one instance -> (Pdiag, q, A, l, u) in the reference's layout."""
+    nx = 3
+    n = 5 * N + 3
+    m = 8 * N + 6
+    A = np.zeros((m, n))
+    Pd = np.zeros(n)
+    q = np.zeros(n)
+    l = np.zeros(m)
+    u = np.zeros(m)
+    ne = nx * (N + 1)
+    A[np.arange(ne), np.arange(ne)] = -1.0
+    A[ne + np.arange(n), np.arange(n)] = 1.0
+    for k in range(N + 1):
+        f = qp_i[:, k]
+        l[3 * k:3 * k + 3] = u[3 * k:3 * k + 3] = f[4:7]
+        xs = slice(3 * k, 3 * k + 3)
+        Pd[xs], q[xs] = f[22:25], f[17:20]
+        l[ne + 3 * k:ne + 3 * k + 3], u[ne + 3 * k:ne + 3 * k + 3] = f[7:10], f[12:15]
+        if k < N:
+            us = slice(ne + 2 * k, ne + 2 * k + 2)
+            Pd[us], q[us] = f[25:27], f[20:22]
+            l[2 * ne + 2 * k:2 * ne + 2 * k + 2], u[2 * ne + 2 * k:2 * ne + 2 * k + 2] = f[10:12], f[15:17]
+            ds, a10, a20, b20 = f[0:4]
+            r0, c0, cu = 3 * (k + 1), 3 * k, ne + 2 * k
+            A[r0, c0], A[r0, c0 + 1] = 1.0, ds
+            A[r0 + 1, c0], A[r0 + 1, c0 + 1] = a10, 1.0
+            A[r0 + 2, c0], A[r0 + 2, c0 + 2] = a20, 1.0
+            A[r0 + 1, cu + 1] = ds
+            A[r0 + 2, cu] = b20
+    l = np.where(l <= -1e30, -np.inf, l)
+    u = np.where(u >= 1e30, np.inf, u)
+    return Pd, q, A, l, u
+
+
+class Emul:
+    """ctypes view of tests/_build/libmpmpc_emul.so (CPU lock-step emulation of the kernels)."""
+
+    def __init__(self):
+        so = os.path.join(ROOT, "tests", "_build", "libmpmpc_emul.so")
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emul")], check=True)
+        self.lib = C.CDLL(so)
+
+    def assemble(self, cfg, track, inputs, use_table=False, obstacles=False):
+        wp, x0, cc, lb, ub = inputs
+        B = wp.size
+        N = cfg.N
+        ld = mpmpc.stage_ld(N)
+        qp = np.zeros((mpmpc.NUM_FIELDS, B, ld))
+        k, v, d = (np.ascontiguousarray(a, float) for a in (track.kappa, track.v_ref, track.ds_next))
+        ubT = np.ascontiguousarray(track.ub_obstacles if obstacles else track.ub_free)
+        lbT = np.ascontiguousarray(track.lb_obstacles if obstacles else track.lb_free)
+        wp = np.ascontiguousarray(wp, np.int32)
+        x0 = np.ascontiguousarray(x0, float)
+        cc = np.ascontiguousarray(cc, float)
+        lbp = None if use_table else np.ascontiguousarray(lb, float)
+        ubp = None if use_table else np.ascontiguousarray(ub, float)
+        rc = self.lib.emu_assemble(C.byref(cfg), C.c_int(k.size), _d(k), _d(v), _d(d), C.c_int(ubT.shape[1]),
+                                   _d(ubT), _d(lbT), C.c_int(B), _i(wp), _d(x0), _d(cc), _d(lbp), _d(ubp), _d(qp))
+        assert rc == 0
+        return qp
+
+    def solve(self, cfg, settings, qp, G=64, want_y=True):
+        B = qp.shape[1]
+        N = cfg.N
+        n, m = 5 * N + 3, 8 * N + 6
+        z, u0 = np.zeros((B, n)), np.zeros((B, 2))
+        st, it, rs = np.zeros(B, np.int32), np.zeros((B, 2), np.int32), np.zeros((B, 2))
+        y = np.zeros((B, m)) if want_y else None
+        qp = np.ascontiguousarray(qp)
+        rc = self.lib.emu_solve(C.byref(cfg), C.byref(settings), C.c_int(G), _d(qp), C.c_int(B), _d(z), _d(u0),
+                                _i(st), _i(it), _d(rs), _d(y))
+        assert rc == 0
+        return mpmpc.Solution(z, u0, st, it, rs, y)

@@ -1,0 +1,106 @@
+"""CPU lock-step emulation of the HIP kernels (same source, lane = 64-wide vector) vs the oracle.
+This is how the kernel ALGORITHM is checked without a GPU; the -m gpu tests repeat it on hardware."""
+import numpy as np
+import pytest
+
+import mpc_np as M
+import mpmpc
+import mpmpc_testlib as T
+import osqp_np as O
+import scenarios
+
+
+def _inputs(sc):
+    return (sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+
+
+@pytest.mark.parametrize("cfgid,B,N", [(2, 12, 30), (4, 12, 30), (3, 6, 50), (2, 6, 10), (4, 6, 3)])
+def test_k1_assembly_matches_oracle(cfgid, B, N, emu, track, otrack):
+    sc = scenarios.make(cfgid, track, B=B, N=N)
+    cfg = T.stock_config(N, sc.weights)
+    qp = emu.assemble(cfg, track, _inputs(sc))
+    w = M.Weights.time_optimal() if sc.weights == "time_optimal" else M.Weights.stock()
+    for i in range(B):
+        Pd, q, A, l, u = T.qp_to_dense(qp[:, i, :], N)
+        P0, q0, A0, l0, u0 = M.assemble(otrack, int(sc.wp_id[i]), sc.x0[i], sc.cc_prev[i], sc.lb[i], sc.ub[i], N,
+                                        w, M.Limits.stock())
+        assert np.array_equal(A, A0) and np.array_equal(Pd, np.diag(P0)) and np.array_equal(q, q0)
+        assert np.array_equal(l, l0)
+        fin = np.isfinite(u0)
+        assert np.array_equal(u[~fin], u0[~fin])
+        assert np.max(np.abs(u[fin] - u0[fin])) <= 4 * np.finfo(float).eps      # libm tan, see DESIGN.md
+    # table-driven corridor == per-instance corridor rows
+    qp_t = emu.assemble(cfg, track, _inputs(sc), use_table=True, obstacles=sc.obstacles)
+    assert np.array_equal(qp, qp_t)
+
+
+def test_k1_matches_reference_capture(emu, track):
+    """K1 against what the reference handed to osqp.setup (golden G4, N=30)."""
+    g = np.load(M.GOLDEN + "/g4_assembly_N30.npz")
+    N = 30
+    cfg = T.stock_config(N)
+    B = g["s"].size
+    qp = emu.assemble(cfg, track, (g["wp_id"].astype(np.int32), g["x0"], g["cc_prev"], g["lb"], g["ub"]))
+    for c in range(B):
+        Pd, q, A, l, u = T.qp_to_dense(qp[:, c, :], N)
+        assert np.array_equal(q, g["q"][c]) and np.array_equal(l, g["l"][c]) and np.array_equal(Pd, g["P_diag"][c])
+        fin = np.isfinite(g["u"][c])
+        assert np.max(np.abs(u[fin] - g["u"][c][fin])) <= 4 * np.finfo(float).eps
+
+
+@pytest.mark.parametrize("G", [64, 32])
+def test_admm_stock_matches_oracle(G, emu, track):
+    """OSQP at its defaults (what src/MPC.py:159 runs): same iterates, statuses, iteration counts."""
+    sc = scenarios.make(2, track, B=10)
+    cfg = T.stock_config(sc.N)
+    qp = emu.assemble(cfg, track, _inputs(sc))
+    sol = emu.solve(cfg, mpmpc.default_settings(polish=0), qp, G=G)
+    for i in range(sc.B):
+        Pd, q, A, l, u = T.qp_to_dense(qp[:, i, :], sc.N)
+        r = O.solve(np.diag(Pd), q, A, l, u, O.Settings())
+        assert sol.status[i] == r.status and sol.iters[i, 0] == r.iters
+        assert np.max(np.abs(sol.z[i] - r.x)) < 1e-7 and np.max(np.abs(sol.y[i] - r.y)) < 1e-7
+        assert abs(sol.resid[i, 0] - r.pri_res) < 1e-9 and abs(sol.resid[i, 1] - r.dua_res) < 1e-9
+
+
+@pytest.mark.parametrize("cfgid,B,N,G", [(2, 12, 30, 64), (4, 16, 30, 32), (3, 4, 50, 64), (2, 8, 10, 16), (4, 8, 3, 16)])
+def test_certified_matches_oracle(cfgid, B, N, G, emu, track):
+    """max |u - u_ref| <= 1e-6 (north-star tolerance); measured ~1e-15."""
+    sc = scenarios.make(cfgid, track, B=B, N=N)
+    cfg = T.stock_config(N, sc.weights)
+    qp = emu.assemble(cfg, track, _inputs(sc))
+    sol = emu.solve(cfg, mpmpc.default_settings(), qp, G=G)
+    L = scenarios.CAR_LENGTH
+    n_cert = 0
+    for i in range(B):
+        Pd, q, A, l, u = T.qp_to_dense(qp[:, i, :], N)
+        r = O.solve(np.diag(Pd), q, A, l, u, O.Settings(polish=2))
+        if r.polished != 1 and sol.status[i] == 1:
+            # the dense oracle interior point gave up where the kernel did not: the kernel's point
+            # must then carry its own certificate
+            assert O.kkt_certificate(np.diag(Pd), q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8)
+            continue
+        assert sol.status[i] == r.status
+        assert sol.iters[i, 0] == r.iters
+        if r.status == O.SOLVED:
+            n_cert += 1
+            uref = np.array([r.x[3 * (N + 1)], np.arctan(r.x[3 * (N + 1) + 1] * L)])
+            assert np.max(np.abs(sol.u0[i] - uref)) <= 1e-6
+            e = np.abs(sol.z[i] - r.x)
+            e[-1] = 0.0                 # kappa_{N-1} is cost free ...
+            e[3 * N + 1] = 0.0          # ... and so is the e_psi_N it alone drives
+            assert e.max() <= 1e-6
+            assert O.kkt_certificate(np.diag(Pd), q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8)
+    assert n_cert >= B // 2
+
+
+def test_ragged_batch_and_group_packing(emu, track):
+    """B not a multiple of the instances per wave; G=16/32/64 give the same answers."""
+    sc = scenarios.make(2, track, B=7, N=10)
+    cfg = T.stock_config(10)
+    qp = emu.assemble(cfg, track, _inputs(sc))
+    st = mpmpc.default_settings()
+    s64, s32, s16 = (emu.solve(cfg, st, qp, G=g) for g in (64, 32, 16))
+    for s in (s32, s16):
+        assert np.array_equal(s.status, s64.status) and np.array_equal(s.iters, s64.iters)
+        assert np.max(np.abs(s.z - s64.z)) < 1e-12

@@ -1,0 +1,152 @@
+"""-m gpu: the HIP path through the C ABI (libmpmpc.so) against the oracle, on a real MI355X."""
+import numpy as np
+import pytest
+
+import mpc_np as M
+import mpmpc
+import mpmpc_testlib as T
+import osqp_np as O
+import scenarios
+
+pytestmark = pytest.mark.gpu
+
+
+def _handle(track, N, weights, max_batch, settings=None, table=None):
+    cfg = T.stock_config(N, weights, max_batch=max_batch)
+    h = mpmpc.Handle(cfg, settings or mpmpc.default_settings())
+    h.set_path(track.kappa, track.v_ref, track.ds_next)
+    if table == "free":
+        h.set_corridor(track.ub_free, track.lb_free)
+    elif table == "obstacles":
+        h.set_corridor(track.ub_obstacles, track.lb_obstacles)
+    return h
+
+
+def test_device_present():
+    assert mpmpc.device_count() >= 1
+
+
+@pytest.mark.parametrize("cfgid,B,N", [(2, 40, 30), (4, 40, 30), (3, 12, 50), (2, 12, 10), (4, 12, 3)])
+def test_k1_assembly_bit_exact(cfgid, B, N, track, otrack):
+    sc = scenarios.make(cfgid, track, B=B, N=N)
+    h = _handle(track, N, sc.weights, B, table="obstacles" if sc.obstacles else "free")
+    qp = h.assemble(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    w = M.Weights.time_optimal() if sc.weights == "time_optimal" else M.Weights.stock()
+    for i in range(B):
+        Pd, q, A, l, u = T.qp_to_dense(qp[:, i, :], N)
+        P0, q0, A0, l0, u0 = M.assemble(otrack, int(sc.wp_id[i]), sc.x0[i], sc.cc_prev[i], sc.lb[i], sc.ub[i], N,
+                                        w, M.Limits.stock())
+        assert np.array_equal(A, A0) and np.array_equal(Pd, np.diag(P0)) and np.array_equal(q, q0)
+        assert np.array_equal(l, l0)
+        fin = np.isfinite(u0)
+        assert np.array_equal(u[~fin], u0[~fin])
+        # speed cap goes through tan()/sqrt(): device libm vs numpy, a few ulp
+        assert np.max(np.abs(u[fin] - u0[fin])) <= 8 * np.finfo(float).eps
+    qp_t = h.assemble(sc.wp_id, sc.x0, sc.cc_prev)          # corridor from the resident table
+    assert np.array_equal(qp, qp_t)
+    h.close()
+
+
+def test_k1_matches_reference_capture(track):
+    g = np.load(M.GOLDEN + "/g4_assembly_N30.npz")
+    N, B = 30, g["s"].size
+    h = _handle(track, N, "stock", B)
+    qp = h.assemble(g["wp_id"].astype(np.int32), g["x0"], g["cc_prev"], g["lb"], g["ub"])
+    for c in range(B):
+        Pd, q, A, l, u = T.qp_to_dense(qp[:, c, :], N)
+        assert np.array_equal(q, g["q"][c]) and np.array_equal(l, g["l"][c]) and np.array_equal(Pd, g["P_diag"][c])
+        fin = np.isfinite(g["u"][c])
+        assert np.max(np.abs(u[fin] - g["u"][c][fin])) <= 8 * np.finfo(float).eps
+    h.close()
+
+
+def test_admm_stock_matches_oracle(track):
+    """stock OSQP settings, no polish: the reference's own solver call (src/MPC.py:159,183)"""
+    sc = scenarios.make(2, track, B=24)
+    h = _handle(track, sc.N, sc.weights, sc.B, mpmpc.default_settings(polish=0))
+    qp = h.assemble(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    sol = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+    for i in range(sc.B):
+        Pd, q, A, l, u = T.qp_to_dense(qp[:, i, :], sc.N)
+        r = O.solve(np.diag(Pd), q, A, l, u, O.Settings())
+        assert sol.status[i] == r.status and sol.iters[i, 0] == r.iters
+        assert np.max(np.abs(sol.z[i] - r.x)) < 1e-7 and np.max(np.abs(sol.y[i] - r.y)) < 1e-7
+    h.close()
+
+
+@pytest.mark.parametrize("cfgid,B,N", [(2, 48, 30), (4, 48, 30), (3, 12, 50), (2, 16, 10), (4, 16, 3)])
+def test_certified_matches_oracle(cfgid, B, N, track):
+    """max |u - u_ref| <= 1e-6 with u_ref the oracle's KKT-certified optimum"""
+    sc = scenarios.make(cfgid, track, B=B, N=N)
+    h = _handle(track, N, sc.weights, B)
+    qp = h.assemble(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    sol = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+    L = scenarios.CAR_LENGTH
+    n_cert = 0
+    for i in range(B):
+        Pd, q, A, l, u = T.qp_to_dense(qp[:, i, :], N)
+        r = O.solve(np.diag(Pd), q, A, l, u, O.Settings(polish=2))
+        if r.polished != 1 and sol.status[i] == 1:
+            assert O.kkt_certificate(np.diag(Pd), q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8)
+            continue
+        assert sol.status[i] == r.status and sol.iters[i, 0] == r.iters
+        if r.status == O.SOLVED:
+            n_cert += 1
+            uref = np.array([r.x[3 * (N + 1)], np.arctan(r.x[3 * (N + 1) + 1] * L)])
+            assert np.max(np.abs(sol.u0[i] - uref)) <= 1e-6
+            e = np.abs(sol.z[i] - r.x)
+            e[-1] = 0.0
+            e[3 * N + 1] = 0.0
+            assert e.max() <= 1e-6
+            assert O.kkt_certificate(np.diag(Pd), q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8)
+    assert n_cert >= B // 2
+    h.close()
+
+
+@pytest.mark.parametrize("cfgid,B", [(2, 1024), (4, 2048)])
+def test_full_size_against_emulation_and_certificates(cfgid, B, track, emu):
+    """BASELINE sizes: GPU == lock-step CPU emulation of the same source; every solved instance
+    carries an independent KKT certificate; infeasible ones are flagged, never silently solved."""
+    sc = scenarios.make(cfgid, track, B=B)
+    h = _handle(track, sc.N, sc.weights, B)
+    qp = h.assemble(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    sol = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+    ref = emu.solve(T.stock_config(sc.N, sc.weights), h.settings, qp, G=64)
+    assert np.array_equal(sol.status, ref.status)
+    assert np.array_equal(sol.iters[:, 0], ref.iters[:, 0])
+    ok = sol.status == 1
+    assert np.max(np.abs(sol.u0[ok] - ref.u0[ok])) <= 1e-9
+    worst = 0.0
+    for i in np.flatnonzero(ok)[:256]:
+        Pd, q, A, l, u = T.qp_to_dense(qp[:, i, :], sc.N)
+        c = O.kkt_certificate(np.diag(Pd), q, A, l, u, sol.z[i], sol.y[i])
+        worst = max(worst, c["prim"], c["stat"], c["comp"])
+    assert worst <= 1e-8
+    assert ok.mean() > 0.8
+    if cfgid == 4:
+        assert (sol.status == mpmpc.PRIMAL_INFEASIBLE).sum() > 0
+    h.close()
+
+
+def test_ragged_and_single_instance(track):
+    sc = scenarios.make(2, track, B=7, N=10)
+    h = _handle(track, 10, "stock", 16)
+    full = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    one = h.solve(sc.wp_id[3:4], sc.x0[3:4], sc.cc_prev[3:4], sc.lb[3:4], sc.ub[3:4])
+    assert one.status[0] == full.status[3] and np.array_equal(one.z[0], full.z[3])
+    h.close()
+
+
+def test_errors_are_loud(track):
+    cfg = T.stock_config(30, max_batch=4)
+    h = mpmpc.Handle(cfg)
+    with pytest.raises(mpmpc.MpmpcError):          # no path yet
+        h.solve(np.zeros(1, np.int32), np.zeros((1, 3)), np.zeros((1, 60)), np.zeros((1, 30)), np.zeros((1, 30)))
+    h.set_path(track.kappa, track.v_ref, track.ds_next)
+    with pytest.raises(mpmpc.MpmpcError):          # batch larger than max_batch
+        h.solve(np.zeros(8, np.int32), np.zeros((8, 3)), np.zeros((8, 60)), np.zeros((8, 30)), np.zeros((8, 30)))
+    with pytest.raises(mpmpc.MpmpcError):          # waypoint out of range
+        h.solve(np.array([999], np.int32), np.zeros((1, 3)), np.zeros((1, 60)), np.zeros((1, 30)), np.zeros((1, 30)))
+    h.close()
+    with pytest.raises(ValueError):
+        T.stock_config(2)

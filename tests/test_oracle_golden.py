@@ -1,0 +1,85 @@
+"""The oracle's assembly half against what the REFERENCE itself produced (tests/golden/g4_*.npz,
+captured from src/MPC.py:61-159 by tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+import mpc_np as M
+import osqp_np as O
+
+
+def _ulp_close(a, b, ulps=4):
+    fin = np.isfinite(a) & np.isfinite(b)
+    ok_inf = np.array_equal(a[~fin], b[~fin])
+    return ok_inf and np.all(np.abs(a[fin] - b[fin]) <= ulps * np.spacing(np.maximum(np.abs(a[fin]), np.abs(b[fin]))))
+
+
+@pytest.mark.parametrize("N", [3, 10, 30, 50])
+def test_assembly_matches_reference_capture(N, otrack):
+    g = np.load(M.GOLDEN + "/g4_assembly_N%d.npz" % N)
+    w = M.Weights.time_optimal() if str(g["weights"][0]) == "time_optimal" else M.Weights.stock()
+    lim = M.Limits.stock()
+    assert g["s"].size >= 16
+    for c in range(g["s"].size):
+        wp = int(g["wp_id"][c])
+        # a2: waypoint localisation, a3: t2s
+        assert M.current_waypoint(otrack.segment_lengths, g["s"][c]) == wp
+        x0 = np.array(M.t2s(*g["pose"][c], otrack.x[wp], otrack.y[wp], otrack.psi[wp]))
+        assert np.array_equal(x0, g["x0"][c])
+        P, q, A, l, u = M.assemble(otrack, wp, g["x0"][c], g["cc_prev"][c], g["lb"][c], g["ub"][c], N, w, lim)
+        lo, hi = g["A_case_ptr"][c], g["A_case_ptr"][c + 1]
+        Aref = sparse.csc_matrix((g["A_data"][lo:hi], g["A_indices"][lo:hi], g["A_indptr"][c]), shape=A.shape)
+        assert np.array_equal(A, Aref.toarray())                      # bit-exact, pattern included
+        assert sparse.csc_matrix(A).nnz == Aref.nnz
+        assert np.array_equal(np.diag(P), g["P_diag"][c]) and np.count_nonzero(P) == np.count_nonzero(np.diag(P))
+        assert np.array_equal(q, g["q"][c]) and np.array_equal(np.signbit(q), np.signbit(g["q"][c]))
+        assert np.array_equal(l, g["l"][c])
+        # u: bit-exact except the speed-cap entries, which go through libm tan() (numpy 1.26 in the
+        # capture vs numpy 2.x here differ by 1 ulp on a few arguments)
+        assert _ulp_close(u, g["u"][c], 4)
+        cap = np.flatnonzero(u != g["u"][c])
+        assert all((i >= 6 * (N + 1)) and ((i - 6 * (N + 1)) % 2 == 0) for i in cap)
+
+
+def test_edge_cases_present():
+    g = np.load(M.GOLDEN + "/g4_assembly_N30.npz")
+    assert 0 in g["wp_id"] and 199 in g["wp_id"]          # int kappa at wp 0, the 199 -> 0 wrap
+    assert np.any(np.all(g["cc_prev"] == 0, axis=1)) and np.any(np.any(g["cc_prev"] != 0, axis=1))
+    nnz = np.diff(g["A_case_ptr"])
+    assert nnz.min() < nnz.max()                          # kappa == 0 stages drop entries from the pattern
+
+
+def test_kappa_pred_quirk():
+    cc = np.arange(1.0, 13.0) / 20.0                      # N = 6
+    kp = M.kappa_pred(cc, 0.12)
+    assert kp.shape == (2 * 6 - 3,)
+    assert np.array_equal(kp, np.tan(cc[3:] + cc[-1]) / 0.12)
+
+
+def test_speed_profile_qp_certified():
+    """G2: the reference's speed-profile QP (reference_path.py:289-354) and its certified optimum."""
+    g2 = np.load(M.GOLDEN + "/g2_speed_profile.npz")
+    A = sparse.coo_matrix((g2["A_val"], (g2["A_row"], g2["A_col"])), shape=tuple(g2["A_shape"])).toarray()
+    P = np.diag(g2["P_diag"])
+    c = O.kkt_certificate(P, g2["q"], A, g2["l"], g2["u"], g2["x"], g2["y"])
+    assert c["ok_tol"](1e-9)
+    r = O.solve(P, g2["q"], A, g2["l"], g2["u"], O.Settings(polish=2))
+    assert r.status == O.SOLVED and r.polished == 1
+    assert np.max(np.abs(r.x - g2["x"])) < 1e-9
+    assert np.array_equal(g2["v_ref"][:-1], g2["x"]) and g2["v_ref"][-1] == g2["v_ref"][-2]
+
+
+def test_osqp_restatement_statuses(otrack):
+    """Feasible -> solved + certificate; an impossible corridor -> primal infeasible."""
+    N = 10
+    lim, w = M.Limits.stock(), M.Weights.stock()
+    lb, ub = np.full(N, -0.1), np.full(N, 0.1)
+    P, q, A, l, u = M.assemble(otrack, 5, np.array([0.01, 0.05, 0.0]), np.zeros(2 * N), lb, ub, N, w, lim)
+    r = O.solve(P, q, A, l, u, O.Settings(polish=2))
+    assert r.status == O.SOLVED and r.polished == 1
+    assert O.kkt_certificate(P, q, A, l, u, r.x, r.y)["ok_tol"](1e-8)
+    lb2, ub2 = lb.copy(), ub.copy()
+    lb2[0], ub2[0] = 0.09, 0.1                             # unreachable from e_y = 0.01 in one step
+    P, q, A, l, u = M.assemble(otrack, 5, np.array([0.01, 0.0, 0.0]), np.zeros(2 * N), lb2, ub2, N, w, lim)
+    r = O.solve(P, q, A, l, u, O.Settings())
+    assert r.status == O.PRIMAL_INFEASIBLE
