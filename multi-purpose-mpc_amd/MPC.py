@@ -1,0 +1,173 @@
+"""Model predictive controller on the GPU QP path.
+
+`MPC` keeps the constructor, attributes and `get_control()` contract of the reference's
+src/MPC.py:14-257 so that src/simulation.py's body runs against it unchanged:
+
+    mpc = MPC(car, N, Q, R, QN, StateConstraints, InputConstraints, ay_max)
+    u = mpc.get_control()            # np.array([v, delta]); u[0], u[1]
+    mpc.show_prediction()
+
+What changed is where the work happens.  The reference rebuilds dense A/B, scipy.sparse P/A and a
+fresh OSQP workspace every step (src/MPC.py:61-159) and solves on one CPU thread
+(src/MPC.py:183).  Here the per-waypoint tables are uploaded once, and every step sends
+(waypoint id, spatial state, previous plan, corridor) through the C ABI of libmpmpc.so, where one
+HIP kernel assembles the stage-blocked QP and a second one solves it (OSQP-style ADMM + certified
+polish).  There is no CPU solver behind this class: without the library / a device it raises.
+
+`BatchMPC` is the one API extension: B independent controller instances per call (scenario
+sweeps, Monte-Carlo initial poses) on one device.
+
+Restrictions (checked, not silently ignored): Q, R, QN must be diagonal (the reference's cost
+vector only ever uses diag(Q), diag(R), src/MPC.py:153-155); 3 <= N <= 63.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+import mpmpc
+from spatial_bicycle_models import current_waypoint_batch, t2s_batch
+
+PREDICTION = '#BA4A00'
+
+
+def _diagonal(M, n, name):
+    """diag of a scipy.sparse / dense weight matrix; refuses off-diagonal weights."""
+    D = M.toarray() if hasattr(M, "toarray") else np.asarray(M, float)
+    D = np.atleast_2d(D)
+    if D.shape != (n, n):
+        raise ValueError("%s must be %dx%d" % (name, n, n))
+    if np.any(D - np.diag(np.diag(D)) != 0):
+        raise ValueError("%s must be diagonal on the GPU path" % name)
+    return np.diag(D).astype(float)
+
+
+def _make_config(model, N, Q, R, QN, StateConstraints, InputConstraints, ay_max, max_batch, device):
+    rp = model.reference_path
+    return mpmpc.make_config(N, _diagonal(Q, 3, "Q"), _diagonal(R, 2, "R"), _diagonal(QN, 3, "QN"),
+                             StateConstraints['xmin'], StateConstraints['xmax'],
+                             InputConstraints['umin'], InputConstraints['umax'], ay_max, model.length,
+                             circular=rp.circular, max_batch=max_batch, device=device)
+
+
+class MPC:
+    def __init__(self, model, N, Q, R, QN, StateConstraints, InputConstraints, ay_max,
+                 settings=None, device=0, backend=None):
+        self.N = N
+        self.Q, self.R, self.QN = Q, R, QN
+        self.model = model
+        self.nx = self.model.n_states
+        self.nu = 2
+        self.state_constraints = StateConstraints
+        self.input_constraints = InputConstraints
+        self.ay_max = ay_max
+        self.current_prediction = None
+        self.infeasibility_counter = 0
+        self.current_control = np.zeros(self.nu * self.N)
+        self.settings = settings or mpmpc.default_settings()
+        self._cfg = _make_config(model, N, Q, R, QN, StateConstraints, InputConstraints, ay_max, 1, device)
+        # `backend`: anything with set_path / solve like mpmpc.Handle (the tests inject the CPU
+        # emulation of the kernels); the product default is the HIP library and nothing else
+        self.optimizer = backend if backend is not None else mpmpc.Handle(self._cfg, self.settings)
+        self._path_version = None
+        self.last_status = None
+        self.last_solution = None
+
+    # -- path tables follow the ReferencePath (v_ref is filled by compute_speed_profile after
+    #    the controller is constructed, src/simulation.py:112-119)
+    def _sync_path(self):
+        kappa, v_ref, ds = self.model.reference_path.tables()
+        key = (kappa.tobytes(), v_ref.tobytes(), ds.tobytes())
+        if key != self._path_version:
+            if np.any(np.isnan(v_ref)):
+                raise RuntimeError("reference path has no speed profile (call compute_speed_profile first)")
+            self.optimizer.set_path(kappa, v_ref, ds)
+            self._path_version = key
+
+    def _init_problem(self):
+        """Inputs of this step's QP (the arithmetic of src/MPC.py:61-155 happens in K1 on the device)."""
+        rp, m = self.model.reference_path, self.model
+        self._sync_path()
+        ub, lb, _ = rp.update_path_constraints(m.wp_id + 1, self.N, 2 * m.safety_margin, m.safety_margin)
+        x0 = np.array(m.spatial_state[:], dtype=float)
+        return (np.array([m.wp_id], dtype=np.int32), x0[None, :], np.asarray(self.current_control, float)[None, :],
+                np.asarray(lb, float)[None, :], np.asarray(ub, float)[None, :])
+
+    def get_control(self):
+        nx, nu = self.model.n_states, 2
+        self.model.get_current_waypoint()
+        self.model.spatial_state = self.model.t2s(reference_state=self.model.temporal_state,
+                                                  reference_waypoint=self.model.current_waypoint)
+        wp, x0, cc, lb, ub = self._init_problem()
+        sol = self.optimizer.solve(wp, x0, cc, lb, ub)
+        self.last_solution = sol
+        self.last_status = int(sol.status[0])
+        # stock OSQP hands back a usable x for "solved", "solved inaccurate" and "max iter reached";
+        # only an infeasibility verdict makes the reference take its fallback branch (src/MPC.py:208)
+        if self.last_status in (mpmpc.SOLVED, mpmpc.SOLVED_INACCURATE, mpmpc.MAX_ITER_REACHED):
+            z = sol.z[0]
+            plan = np.array(z[-self.N * nu:])
+            plan[1::2] = np.arctan(plan[1::2] * self.model.length)
+            self.current_control = plan
+            self.current_prediction = self.update_prediction(np.reshape(z[:(self.N + 1) * nx], (self.N + 1, nx)))
+            u = np.array([plan[0], plan[1]])
+            self.infeasibility_counter = 0
+        else:
+            print('Infeasible problem. Previously predicted control signal used!')
+            i = nu * (self.infeasibility_counter + 1)
+            u = np.array(self.current_control[i:i + 2])
+            self.infeasibility_counter += 1
+        if self.infeasibility_counter == (self.N - 1):
+            print('No control signal computed!')
+            raise SystemExit(1)
+        return u
+
+    def update_prediction(self, spatial_state_prediction):
+        """Predicted e_y per stage -> world x, y for plotting (stages 2..N-1, src/MPC.py:224-248)."""
+        rp, wp0 = self.model.reference_path, self.model.wp_id
+        xs, ys = [], []
+        for n in range(2, self.N):
+            w = rp.get_waypoint(wp0 + n)
+            p = self.model.s2t(w, spatial_state_prediction[n, :])
+            xs.append(p.x)
+            ys.append(p.y)
+        return xs, ys
+
+    def show_prediction(self):
+        if self.current_prediction is not None:
+            import matplotlib.pyplot as plt
+            plt.scatter(self.current_prediction[0], self.current_prediction[1], c=PREDICTION, s=30)
+
+
+class BatchMPC:
+    """B independent controllers sharing one path, weights and limits; one launch per call."""
+
+    def __init__(self, model, N, Q, R, QN, StateConstraints, InputConstraints, ay_max, max_batch,
+                 settings=None, device=0, corridor=None):
+        self.N, self.model = N, model
+        self.settings = settings or mpmpc.default_settings()
+        self._cfg = _make_config(model, N, Q, R, QN, StateConstraints, InputConstraints, ay_max, max_batch, device)
+        self.handle = mpmpc.Handle(self._cfg, self.settings)
+        kappa, v_ref, ds = model.reference_path.tables()
+        if np.any(np.isnan(v_ref)):
+            raise RuntimeError("reference path has no speed profile (call compute_speed_profile first)")
+        self.handle.set_path(kappa, v_ref, ds)
+        self._path = model.reference_path
+        if corridor is not None:          # (ub, lb) tables [n_wp x >=N] of a static map
+            self.handle.set_corridor(*corridor)
+
+    def spatial_states(self, s, poses):
+        """(wp_id[B], x0[B,3]) from arc lengths and world poses, as get_control does per car."""
+        rp = self._path
+        wp = current_waypoint_batch(rp.segment_lengths, s)
+        wx = np.array([w.x for w in rp.waypoints])[wp]
+        wy = np.array([w.y for w in rp.waypoints])[wp]
+        wpsi = np.array([w.psi for w in rp.waypoints])[wp]
+        poses = np.asarray(poses, float)
+        return wp.astype(np.int32), t2s_batch(poses[:, 0], poses[:, 1], poses[:, 2], wx, wy, wpsi)
+
+    def get_control_batch(self, wp_id, x0, cc_prev, lb=None, ub=None):
+        """-> (u [B,2] = (v, delta), plan [B,2N] with delta entries, status [B], Solution)."""
+        sol = self.handle.solve(wp_id, x0, cc_prev, lb, ub)
+        plan = sol.z[:, -2 * self.N:].copy()
+        plan[:, 1::2] = np.arctan(plan[:, 1::2] * self.model.length)
+        return sol.u0, plan, sol.status, sol

@@ -87,6 +87,9 @@ def corridor_table(rp, sm):
 def stage_path():
     m, rp = build_track()
     t = path_table(rp)
+    from PIL import Image
+    raw = np.array(Image.open('maps/sim_map.png'))[:, :, 0]
+    t["grid_thresholded"] = np.packbits((raw >= m.threshold_occupied).astype(np.uint8))   # before hole removal
     grid_free = np.packbits(m.data.astype(np.uint8))
     add_obstacles(m)
     grid_obs = np.packbits(m.data.astype(np.uint8))
@@ -230,11 +233,16 @@ def stage_loop():
         rp.compute_speed_profile(dict(SPEED))
         rec = {k: [] for k in ("s", "pose", "cc_prev", "wp_id", "x0", "lb", "ub", "status", "u", "counter",
                                "z", "cc_next")}
+        exited = False
         while car.s < rp.length:
             s, pose = car.s, [car.temporal_state.x, car.temporal_state.y, car.temporal_state.psi]
             cc_prev = mpc.current_control.copy()
             osqp.CAPTURES.clear()
-            u = mpc.get_control()
+            try:
+                u = mpc.get_control()
+            except SystemExit:      # src/MPC.py:218-220: N-1 consecutive infeasible steps end the run
+                exited = True
+                break
             cap = osqp.CAPTURES[-1]
             res = cap["res"]
             ub, lb, _ = rp.update_path_constraints(car.wp_id + 1, N, 2 * car.safety_margin, car.safety_margin)
@@ -253,12 +261,34 @@ def stage_loop():
             car.drive(u)
         np.savez_compressed(os.path.join(HERE, "g6_closed_loop_N%d.npz" % N),
                             **{k: np.array(v) for k, v in rec.items()}, N=np.array([N]),
-                            final_s=np.array([car.s]))
+                            final_s=np.array([car.s]), exited=np.array([exited]))
         st = np.array(rec["status"])
-        print("G6 N=%d: %d steps, infeasible %d, final s %.4f" % (N, st.size, (st < 0).sum(), car.s))
+        print("G6 N=%d: %d steps, infeasible %d, final s %.4f, exit(1) %s" % (N, st.size, (st < 0).sum(), car.s, exited))
 
 
-STAGES = dict(path=stage_path, speed=stage_speed, corridor=stage_corridor, assembly=stage_assembly,
+def stage_raster():
+    """G7: skimage.draw.line_aa cell sequences (order matters to _compute_free_segments)."""
+    from skimage.draw import line_aa
+    rng = np.random.default_rng(7)
+    ends = rng.integers(0, 500, (300, 4))
+    ends[:20, 2:] = ends[:20, :2] + rng.integers(-3, 4, (20, 2))        # very short lines
+    ends[20] = [5, 5, 5, 5]                                             # single cell
+    ends[21] = [10, 3, 10, 40]                                          # axis aligned
+    ends[22] = [3, 10, 40, 10]
+    ends[23] = [0, 0, 30, 30]                                           # diagonal
+    ends = np.clip(ends, 0, 499)
+    rr, cc, ptr = [], [], [0]
+    for r0, c0, r1, c1 in ends:
+        a, b, _ = line_aa(int(r0), int(c0), int(r1), int(c1))
+        rr.append(a)
+        cc.append(b)
+        ptr.append(ptr[-1] + a.size)
+    np.savez_compressed(os.path.join(HERE, "g7_line_aa.npz"), ends=ends, rr=np.concatenate(rr),
+                        cc=np.concatenate(cc), ptr=np.array(ptr))
+    print("G7:", len(ends), "lines,", ptr[-1], "cells")
+
+
+STAGES = dict(raster=stage_raster, path=stage_path, speed=stage_speed, corridor=stage_corridor, assembly=stage_assembly,
               loop=stage_loop)
 
 if __name__ == "__main__":
