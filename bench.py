@@ -47,29 +47,14 @@ def k2_bytes_per_solve(N):
     return 8 * mpmpc.NUM_FIELDS * (N + 1) + 8 * (5 * N + 3 + 2 + 2) + 12
 
 
-def cpu_baseline(sc, qp, seconds=15.0):
-    """The oracle (own restatement of OSQP + certified polish) on the host cores of this box."""
+def cpu_baseline(tr, sc, seconds=15.0):
+    """The oracle's C port (oracle/osqp_port.c: own restatement of the reference's assembly + OSQP +
+    certified polish) timed on the host cores of this box, on a bounded sample of the workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    try:
-        import oracle_c  # C port, all cores (oracle/osqp_port.c)
-        return oracle_c.timed_baseline(sc, qp, seconds)
-    except Exception:
-        pass
-    import osqp_np as O
-    import mpmpc_testlib as T
-    t0 = time.perf_counter()
-    done = 0
-    uref = []
-    while done < sc.B and time.perf_counter() - t0 < seconds:
-        Pd, q, A, l, u = T.qp_to_dense(qp[:, done, :], sc.N)
-        r = O.solve(np.diag(Pd), q, A, l, u, O.Settings(polish=2))
-        uref.append((r.status, r.x[3 * (sc.N + 1)], np.arctan(r.x[3 * (sc.N + 1) + 1] * scenarios.CAR_LENGTH)))
-        done += 1
-    dt = time.perf_counter() - t0
-    return dict(value=done / dt, unit="solves/s", cores=1, kind="port",
-                sample="first %d instances of the workload, dense numpy restatement (oracle/osqp_np.py), "
-                       "OSQP defaults + certified polish" % done), uref
+    import oracle_c
+    limits = dict(umin=scenarios.UMIN, umax=scenarios.UMAX, xmin=scenarios.XMIN, xmax=scenarios.XMAX,
+                  ay_max=scenarios.AY_MAX, wheelbase=scenarios.CAR_LENGTH)
+    return oracle_c.timed_baseline(tr, sc, scenarios.WEIGHTS[sc.weights], limits, seconds)
 
 
 def main():
@@ -164,18 +149,14 @@ def main():
         out["iters"] = {"admm_mean": float(sol.iters[:, 0].mean()), "admm_max": int(sol.iters[:, 0].max()),
                         "ipm_mean": float(sol.iters[:, 1].mean()), "ipm_max": int(sol.iters[:, 1].max())}
         if not args.no_cpu:
-            qp = h.assemble(wp, x0, cc, lb, ub)
-            base, uref = cpu_baseline(scenarios.Scenario(sc_all.name, N, sc_all.weights, sc_all.obstacles, wp, x0, cc,
-                                                         lb, ub), qp)
+            sc_rank = scenarios.Scenario(sc_all.name, N, sc_all.weights, sc_all.obstacles, wp, x0, cc, lb, ub)
+            base, ref = cpu_baseline(tr, sc_rank)
             out["cpu_baseline"] = base
-            err = 0.0
-            agree = 0
-            for i, (s, v, d) in enumerate(uref):
-                agree += int(s == sol.status[i])
-                if s == 1 and sol.status[i] == 1:
-                    err = max(err, abs(sol.u0[i, 0] - v), abs(sol.u0[i, 1] - d))
-            out["max_abs_u_minus_uref"] = err
-            out["status_agreement"] = agree / max(len(uref), 1)
+            ns = ref["status"].size
+            both = (ref["status"] == 1) & (sol.status[:ns] == 1)
+            out["max_abs_u_minus_uref"] = float(np.max(np.abs(sol.u0[:ns][both] - ref["u0"][both]))) if both.any() else None
+            out["status_agreement"] = float(np.mean(ref["status"] == sol.status[:ns]))
+            out["parity_sample"] = int(ns)
             out["host_cores"] = os.cpu_count()
         print(json.dumps(out))
     h.close()

@@ -1,0 +1,158 @@
+"""ORACLE (test infrastructure): ctypes view of oracle/_build/liboracle.so (oracle/osqp_port.c).
+
+Fast sparse twin of oracle/osqp_np.py + oracle/mpc_np.py.  Only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import this; the product never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import time
+
+import numpy as np
+from scipy import sparse
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "_build", "liboracle.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class Settings(C.Structure):
+    _fields_ = [("rho", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double), ("eps_abs", C.c_double),
+                ("eps_rel", C.c_double), ("eps_prim_inf", C.c_double), ("eps_dual_inf", C.c_double),
+                ("max_iter", C.c_int32), ("check_termination", C.c_int32), ("scaling", C.c_int32),
+                ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32),
+                ("adaptive_rho_tolerance", C.c_double), ("polish", C.c_int32), ("ipm_max_iter", C.c_int32),
+                ("ipm_tol", C.c_double), ("ipm_reg", C.c_double), ("as_delta", C.c_double),
+                ("as_refine", C.c_int32), ("as_rounds", C.c_int32), ("cert_tol", C.c_double)]
+
+
+class Info(C.Structure):
+    _fields_ = [("status", C.c_int32), ("iters", C.c_int32), ("ipm_iters", C.c_int32), ("as_rounds", C.c_int32),
+                ("polished", C.c_int32), ("rho_updates", C.c_int32), ("pri_res", C.c_double),
+                ("dua_res", C.c_double), ("obj", C.c_double)]
+
+
+class MpcCfg(C.Structure):
+    _fields_ = [("N", C.c_int32), ("circular", C.c_int32), ("Q", C.c_double * 3), ("R", C.c_double * 2),
+                ("QN", C.c_double * 3), ("xmin", C.c_double * 3), ("xmax", C.c_double * 3),
+                ("umin", C.c_double * 2), ("umax", C.c_double * 2), ("ay_max", C.c_double),
+                ("wheelbase", C.c_double)]
+
+
+def settings(polish=2, **kw):
+    s = Settings(rho=0.1, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, eps_prim_inf=1e-4, eps_dual_inf=1e-4,
+                 max_iter=4000, check_termination=25, scaling=10, adaptive_rho=1, adaptive_rho_interval=50,
+                 adaptive_rho_tolerance=5.0, polish=polish, ipm_max_iter=50, ipm_tol=1e-9, ipm_reg=1e-8,
+                 as_delta=1e-9, as_refine=5, as_rounds=10, cert_tol=1e-8)
+    for k, v in kw.items():
+        setattr(s, k, v)
+    return s
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.run(["make", "-s", "-C", HERE], check=True)
+        _lib = C.CDLL(SO)
+    return _lib
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def solve(P, q, A, l, u, st: Settings | None = None):
+    """Generic QP through the C port.  P, A dense or scipy sparse."""
+    st = st or settings()
+    Pu = sparse.triu(sparse.csc_matrix(P), format="csc")
+    Ac = sparse.csc_matrix(A)
+    Pu.sort_indices()
+    Ac.sort_indices()
+    n, m = Pu.shape[0], Ac.shape[0]
+    q, l, u = (np.ascontiguousarray(v, float) for v in (q, l, u))
+    x, y = np.zeros(n), np.zeros(m)
+    info = Info()
+    Pp, Pi, Px = Pu.indptr.astype(np.int32), Pu.indices.astype(np.int32), Pu.data.astype(float)
+    Ap, Ai, Ax = Ac.indptr.astype(np.int32), Ac.indices.astype(np.int32), Ac.data.astype(float)
+    rc = lib().oracle_solve_csc(C.c_int(n), C.c_int(m), _i(Pp), _i(Pi), _d(Px), _d(q), _i(Ap), _i(Ai), _d(Ax), _d(l),
+                                _d(u), C.byref(st), None, _d(x), _d(y), C.byref(info))
+    assert rc == 0
+    return x, y, info
+
+
+def mpc_cfg(N, weights, limits_umin, limits_umax, xmin, xmax, ay_max, wheelbase, circular=True):
+    Q, R, QN = weights
+    c = MpcCfg(N=N, circular=int(circular), ay_max=ay_max, wheelbase=wheelbase)
+    for name, val, k in (("Q", Q, 3), ("R", R, 2), ("QN", QN, 3), ("xmin", xmin, 3), ("xmax", xmax, 3),
+                         ("umin", limits_umin, 2), ("umax", limits_umax, 2)):
+        setattr(c, name, (C.c_double * k)(*np.asarray(val, float)))
+    return c
+
+
+def mpc_assemble_dense(cfg: MpcCfg, kappa, v_ref, ds_next, wp, x0, cc, lb, ub):
+    N = cfg.N
+    n, m = 5 * N + 3, 8 * N + 6
+    kappa, v_ref, ds_next, x0, cc, lb, ub = (np.ascontiguousarray(a, float) for a in
+                                             (kappa, v_ref, ds_next, x0, cc, lb, ub))
+    Pd, q, A, l, u = np.zeros(n), np.zeros(n), np.zeros((m, n)), np.zeros(m), np.zeros(m)
+    nnz = C.c_int(0)
+    lib().oracle_mpc_assemble_dense(C.byref(cfg), C.c_int(kappa.size), _d(kappa), _d(v_ref), _d(ds_next), C.c_int(int(wp)),
+                                    _d(x0), _d(cc), _d(lb), _d(ub), _d(Pd), _d(q), _d(A), _d(l), _d(u), C.byref(nnz))
+    return Pd, q, A, l, u, nnz.value
+
+
+def mpc_batch(cfg: MpcCfg, st: Settings, kappa, v_ref, ds_next, wp_id, x0, cc, lb, ub, nthreads=0, want_y=False):
+    N = cfg.N
+    n, m = 5 * N + 3, 8 * N + 6
+    wp_id = np.ascontiguousarray(wp_id, np.int32)
+    B = wp_id.size
+    kappa, v_ref, ds_next, x0, cc, lb, ub = (np.ascontiguousarray(a, float) for a in
+                                             (kappa, v_ref, ds_next, x0, cc, lb, ub))
+    z, u0 = np.zeros((B, n)), np.zeros((B, 2))
+    status, iters, resid = np.zeros(B, np.int32), np.zeros((B, 3), np.int32), np.zeros((B, 2))
+    y = np.zeros((B, m)) if want_y else None
+    rc = lib().oracle_mpc_batch(C.byref(cfg), C.byref(st), C.c_int(kappa.size), _d(kappa), _d(v_ref), _d(ds_next),
+                                C.c_int(B), _i(wp_id), _d(x0), _d(cc), _d(lb), _d(ub), C.c_int(nthreads), _d(z), _d(u0),
+                                _i(status), _i(iters), _d(resid), _d(y))
+    assert rc == 0
+    return dict(z=z, u0=u0, status=status, iters=iters, resid=resid, y=y)
+
+
+def num_threads():
+    return int(lib().oracle_num_threads())
+
+
+def timed_baseline(track, sc, weights, limits, seconds=15.0, nthreads=0):
+    """bench.py's cpu_baseline leg: the reference-equivalent CPU path (assembly + fresh setup + ADMM +
+    certified polish per instance) on a bounded sample, all host cores."""
+    cfg = mpc_cfg(sc.N, weights, limits["umin"], limits["umax"], limits["xmin"], limits["xmax"], limits["ay_max"],
+                  limits["wheelbase"])
+    st = settings()
+    nt = nthreads or num_threads()
+    # calibrate on a small slice, then size the sample for about `seconds`
+    probe = min(sc.B, max(2 * nt, 16))
+    t0 = time.perf_counter()
+    mpc_batch(cfg, st, track.kappa, track.v_ref, track.ds_next, sc.wp_id[:probe], sc.x0[:probe], sc.cc_prev[:probe],
+              sc.lb[:probe], sc.ub[:probe], nt)
+    rate = probe / (time.perf_counter() - t0)
+    nsamp = int(min(sc.B, max(probe, rate * seconds)))
+    t0 = time.perf_counter()
+    out = mpc_batch(cfg, st, track.kappa, track.v_ref, track.ds_next, sc.wp_id[:nsamp], sc.x0[:nsamp],
+                    sc.cc_prev[:nsamp], sc.lb[:nsamp], sc.ub[:nsamp], nt)
+    dt = time.perf_counter() - t0
+    base = dict(value=nsamp / dt, unit="solves/s", cores=nt, kind="port",
+                sample="first %d instances of the workload; C restatement (oracle/osqp_port.c): numpy-equivalent "
+                       "assembly + fresh OSQP-style setup (Ruiz scaling, sparse LDL) + ADMM at OSQP defaults + "
+                       "certified polish per instance, OpenMP over instances" % nsamp)
+    return base, out

@@ -109,3 +109,25 @@ class Emul:
                                 _i(st), _i(it), _d(rs), _d(y))
         assert rc == 0
         return mpmpc.Solution(z, u0, st, it, rs, y)
+
+
+class EmuBackend:
+    """Drop-in for mpmpc.Handle in host-logic tests: same set_path / solve surface, kernels run in
+    the CPU lock-step emulation.  Test infrastructure only."""
+
+    class _T:
+        pass
+
+    def __init__(self, cfg, settings, emu=None):
+        self.cfg, self.settings = cfg, settings
+        self.emu = emu or Emul()
+        self.t = EmuBackend._T()
+        z = np.zeros((2, max(cfg.N, 1)))
+        self.t.ub_free = self.t.lb_free = self.t.ub_obstacles = self.t.lb_obstacles = z
+
+    def set_path(self, kappa, v_ref, ds_next):
+        self.t.kappa, self.t.v_ref, self.t.ds_next = (np.ascontiguousarray(a, float) for a in (kappa, v_ref, ds_next))
+
+    def solve(self, wp_id, x0, cc_prev, lb=None, ub=None, want_y=False):
+        qp = self.emu.assemble(self.cfg, self.t, (np.asarray(wp_id, np.int32), x0, cc_prev, lb, ub))
+        return self.emu.solve(self.cfg, self.settings, qp, G=64, want_y=want_y)
