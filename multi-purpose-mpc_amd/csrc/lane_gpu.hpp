@@ -9,6 +9,14 @@ namespace mpmpc {
 
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ double sqrt_(double a) { return __builtin_sqrt(a); }
+// 1/sqrt(a): hardware seed (v_rsq_f64) + one cubic and one quadratic Newton step in FMA form
+__device__ __forceinline__ double rsqrt_(double a) {
+  double r = __builtin_amdgcn_rsq(a);
+  double e = __builtin_fma(-(a * r), r, 1.0);
+  r = __builtin_fma(r * e, __builtin_fma(0.375, e, 0.5), r);
+  e = __builtin_fma(-(a * r), r, 1.0);
+  return __builtin_fma(r * e, 0.5, r);
+}
 __device__ __forceinline__ double abs_(double a) { return __builtin_fabs(a); }
 __device__ __forceinline__ double max_(double a, double b) { return a > b ? a : b; }
 __device__ __forceinline__ double min_(double a, double b) { return a < b ? a : b; }

@@ -173,7 +173,7 @@ struct Solver {
   R mI[3], a[6], b[2], g[5], p[5], q[5], D[5], Eeq[3], Eb[5], c;
   R leq[3], lb[5], ub[5];
   // ---- linear algebra
-  R hinv[5], Li[6], Ls[9];
+  R hinv[5], Li[6], Gf[9], Gb[9];
   // ---- ADMM state
   R x[5], zeq[3], zb[5], yeq[3], yb[5];
   R rho, rb[5], rbinv[5], rho_eq, rinv_eq;
@@ -341,26 +341,29 @@ struct Solver {
     for (int i = 0; i < 3; ++i) dk[i] = fma_(mI[i] * mI[i], h[i], r);
     MPMPC_UNROLL
     for (int i = 0; i < 9; ++i) M[i] = R(0.0);
+    // the neighbour's W depends on h only: fetch it once, not once per sweep step
+    R Wr[6];
+    MPMPC_UNROLL
+    for (int i = 0; i < 6; ++i) Wr[i] = L::up(W[i]);
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) dk[i] = dk[i] + Wr[i == 0 ? 0 : (i == 1 ? 2 : 5)];
+    R Ls[9];
     for (int s = 0; s <= N; ++s) {
-      R Wr[6], Mr[9];
-      MPMPC_UNROLL
-      for (int i = 0; i < 6; ++i) Wr[i] = L::up(W[i]);
+      R Mr[9];
       MPMPC_UNROLL
       for (int i = 0; i < 9; ++i) Mr[i] = L::up(M[i]);
-      R S00 = dk[0] + Wr[0] - fma_(Mr[2], Mr[2], fma_(Mr[1], Mr[1], Mr[0] * Mr[0]));
+      R S00 = dk[0] - fma_(Mr[2], Mr[2], fma_(Mr[1], Mr[1], Mr[0] * Mr[0]));
       R S10 = Wr[1] - fma_(Mr[5], Mr[2], fma_(Mr[4], Mr[1], Mr[3] * Mr[0]));
-      R S11 = dk[1] + Wr[2] - fma_(Mr[5], Mr[5], fma_(Mr[4], Mr[4], Mr[3] * Mr[3]));
+      R S11 = dk[1] - fma_(Mr[5], Mr[5], fma_(Mr[4], Mr[4], Mr[3] * Mr[3]));
       R S20 = Wr[3] - fma_(Mr[8], Mr[2], fma_(Mr[7], Mr[1], Mr[6] * Mr[0]));
       R S21 = Wr[4] - fma_(Mr[8], Mr[5], fma_(Mr[7], Mr[4], Mr[6] * Mr[3]));
-      R S22 = dk[2] + Wr[5] - fma_(Mr[8], Mr[8], fma_(Mr[7], Mr[7], Mr[6] * Mr[6]));
-      R l00 = sqrt_(S00);
-      R i00 = R(1.0) / l00;
+      R S22 = dk[2] - fma_(Mr[8], Mr[8], fma_(Mr[7], Mr[7], Mr[6] * Mr[6]));
+      // 3x3 Cholesky through reciprocal square roots: i_jj = 1 / l_jj
+      R i00 = rsqrt_(S00);
       R l10 = S10 * i00, l20 = S20 * i00;
-      R l11 = sqrt_(S11 - l10 * l10);
-      R i11 = R(1.0) / l11;
+      R i11 = rsqrt_(S11 - l10 * l10);
       R l21 = (S21 - l20 * l10) * i11;
-      R l22 = sqrt_(S22 - fma_(l21, l21, l20 * l20));
-      R i22 = R(1.0) / l22;
+      R i22 = rsqrt_(S22 - fma_(l21, l21, l20 * l20));
       R i10 = -(l10 * i00) * i11;
       R i21 = -(l21 * i11) * i22;
       R i20 = -(fma_(l21, i10, l20 * i00)) * i22;
@@ -377,29 +380,49 @@ struct Solver {
     for (int i = 0; i < 9; ++i) Ls[i] = sel(vx, Ls[i], R(0.0));
     Li[0] = sel(vx, Li[0], R(1.0)); Li[2] = sel(vx, Li[2], R(1.0)); Li[5] = sel(vx, Li[5], R(1.0));
     Li[1] = sel(vx, Li[1], R(0.0)); Li[3] = sel(vx, Li[3], R(0.0)); Li[4] = sel(vx, Li[4], R(0.0));
+    // recurrence matrices of the two substitution sweeps (stored negated, so a sweep step is 9 FMAs):
+    //   forward   y_k  = inv(L_kk) b_k + Gf_k y_{k-1},      Gf_k = -inv(L_kk) L_{k,k-1}
+    //   backward  nu_k = inv(L_kk)' y_k + Gb_k nu_{k+1},    Gb_k = -inv(L_kk)' L_{k+1,k}'
+    MPMPC_UNROLL
+    for (int j = 0; j < 3; ++j) {
+      Gf[0 + j] = -(Li[0] * Ls[0 + j]);
+      Gf[3 + j] = -fma_(Li[2], Ls[3 + j], Li[1] * Ls[0 + j]);
+      Gf[6 + j] = -fma_(Li[5], Ls[6 + j], fma_(Li[4], Ls[3 + j], Li[3] * Ls[0 + j]));
+    }
+    R Ln[9];
+    MPMPC_UNROLL
+    for (int i = 0; i < 9; ++i) Ln[i] = L::down(Ls[i]);          // L_{k+1,k}, row major
+    MPMPC_UNROLL
+    for (int j = 0; j < 3; ++j) {                                // Gb[i][j] = -sum_m Li[m][i] * Ln[j][m]
+      Gb[0 + j] = -fma_(Li[3], Ln[3 * j + 2], fma_(Li[1], Ln[3 * j + 1], Li[0] * Ln[3 * j + 0]));
+      Gb[3 + j] = -fma_(Li[4], Ln[3 * j + 2], Li[2] * Ln[3 * j + 1]);
+      Gb[6 + j] = -(Li[5] * Ln[3 * j + 2]);
+    }
   }
 
   MPMPC_HD void s_solve(const R bv[3], R nu[3]) const {
-    R y[3] = {R(0.0), R(0.0), R(0.0)};
+    // lane-parallel part first, then two sweeps whose serial step is one 3x3 matrix-vector product
+    R c0 = Li[0] * bv[0];
+    R c1 = fma_(Li[2], bv[1], Li[1] * bv[0]);
+    R c2 = fma_(Li[5], bv[2], fma_(Li[4], bv[1], Li[3] * bv[0]));
+    R y0(0.0), y1(0.0), y2(0.0);
     for (int s = 0; s <= N; ++s) {
-      R yp0 = L::up(y[0]), yp1 = L::up(y[1]), yp2 = L::up(y[2]);
-      R t0 = bv[0] - fma_(Ls[2], yp2, fma_(Ls[1], yp1, Ls[0] * yp0));
-      R t1 = bv[1] - fma_(Ls[5], yp2, fma_(Ls[4], yp1, Ls[3] * yp0));
-      R t2 = bv[2] - fma_(Ls[8], yp2, fma_(Ls[7], yp1, Ls[6] * yp0));
-      y[0] = Li[0] * t0;
-      y[1] = fma_(Li[2], t1, Li[1] * t0);
-      y[2] = fma_(Li[5], t2, fma_(Li[4], t1, Li[3] * t0));
+      R p0 = L::up(y0), p1 = L::up(y1), p2 = L::up(y2);
+      y0 = fma_(Gf[2], p2, fma_(Gf[1], p1, fma_(Gf[0], p0, c0)));
+      y1 = fma_(Gf[5], p2, fma_(Gf[4], p1, fma_(Gf[3], p0, c1)));
+      y2 = fma_(Gf[8], p2, fma_(Gf[7], p1, fma_(Gf[6], p0, c2)));
     }
-    nu[0] = nu[1] = nu[2] = R(0.0);
+    R d0 = fma_(Li[3], y2, fma_(Li[1], y1, Li[0] * y0));
+    R d1 = fma_(Li[4], y2, Li[2] * y1);
+    R d2 = Li[5] * y2;
+    R n0(0.0), n1(0.0), n2(0.0);
     for (int s = 0; s <= N; ++s) {
-      R g0 = fma_(Ls[6], nu[2], fma_(Ls[3], nu[1], Ls[0] * nu[0]));
-      R g1 = fma_(Ls[7], nu[2], fma_(Ls[4], nu[1], Ls[1] * nu[0]));
-      R g2 = fma_(Ls[8], nu[2], fma_(Ls[5], nu[1], Ls[2] * nu[0]));
-      R t0 = y[0] - L::down(g0), t1 = y[1] - L::down(g1), t2 = y[2] - L::down(g2);
-      nu[2] = Li[5] * t2;
-      nu[1] = fma_(Li[4], t2, Li[2] * t1);
-      nu[0] = fma_(Li[3], t2, fma_(Li[1], t1, Li[0] * t0));
+      R p0 = L::down(n0), p1 = L::down(n1), p2 = L::down(n2);
+      n0 = fma_(Gb[2], p2, fma_(Gb[1], p1, fma_(Gb[0], p0, d0)));
+      n1 = fma_(Gb[5], p2, fma_(Gb[4], p1, fma_(Gb[3], p0, d1)));
+      n2 = fma_(Gb[8], p2, fma_(Gb[7], p1, fma_(Gb[6], p0, d2)));
     }
+    nu[0] = n0; nu[1] = n1; nu[2] = n2;
   }
 
   // [diag(1/hinv) Aeq'; Aeq -r I] [xt; nu] = [rx; req]
@@ -707,7 +730,7 @@ struct Solver {
         MPMPC_UNROLL
         for (int i = 0; i < 3; ++i) nreq[i] = -rp[i];
         kkt_solve(rhs, nreq, dx, dnu);
-        {   // one refinement step
+        if (pass == 1) {   // the corrector direction gets one refinement step; the predictor only steers sigma
           R At2[5], Ad[3], r1[5], r2[3], ddx[5], ddnu[3];
           AeqT_mul(dnu, At2);
           Aeq_mul(dx, Ad);
@@ -806,13 +829,17 @@ struct Solver {
         MPMPC_UNROLL
         for (int i = 0; i < 3; ++i) r2[i] = leq[i] - Ax[i];
         kkt_solve(rhs, r2, dx, dnu);
+        R big(0.0);
         MPMPC_UNROLL
         for (int j = 0; j < 5; ++j) {
           ln[j] = ln[j] + sel(act[j], (dx[j] - r3[j]) / delta, zero);
           xn[j] = xn[j] + dx[j];
+          big = max_(big, sel(valid[j], abs_(dx[j]) - R(1e-14) * abs_(xn[j]), zero));
         }
         MPMPC_UNROLL
         for (int i = 0; i < 3; ++i) nn[i] = nn[i] + dnu[i];
+        // refinement has converged for every instance in the wave: stop early
+        if (rf >= 1 && !L::wany(todo & (L::gmax(big) > R(1e-15)))) break;
       }
       Mk anybad = L::mfalse();
       Mk vL[5], vU[5], bL[5], bU[5];
@@ -864,10 +891,17 @@ struct Solver {
       R cl = sel(fl, max_(-yu, R(0.0)) * abs_(xu - lo0[j]), sel(yu < R(0.0), R(1e300), R(0.0)));
       cv = max_(cv, sel(valid[j], max_(cu, cl), R(0.0)));
     }
+    // a NaN iterate must never pass: compare every entry against a finite bound explicitly
+    Mk bad = L::mfalse();
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) bad = bad | (valid[j] & !((abs_(xs[j]) < R(1e300)) & (abs_(lam[j]) < R(1e300))));
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) bad = bad | (vx & !(abs_(nus[i]) < R(1e300)));
+    bad = L::gany(bad);
     prim = L::gmax(pv);
     stat = L::gmax(sv);
     cv = L::gmax(cv);
-    return (prim <= R(tol)) & (stat <= R(tol)) & (cv <= R(tol));
+    return (prim <= R(tol)) & (stat <= R(tol)) & (cv <= R(tol)) & !bad;
   }
 
   MPMPC_HD void polish(const mpmpc_settings& st) {
