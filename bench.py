@@ -25,6 +25,7 @@ sys.path[:0] = [os.path.join(ROOT, "multi-purpose-mpc_amd")]
 
 import mpmpc  # noqa: E402
 import scenarios  # noqa: E402
+import sharding  # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
 FP64_VALU_PEAK = 78.6e12   # FLOP/s vector FP64 (spec)
@@ -45,6 +46,14 @@ def k1_bytes_per_solve(N):
 
 def k2_bytes_per_solve(N):
     return 8 * mpmpc.NUM_FIELDS * (N + 1) + 8 * (5 * N + 3 + 2 + 2) + 12
+
+
+def k2_flops_per_solve(N, admm_iters, ipm_iters):
+    """Useful FP64 flops of one solve: per-lane instruction census of the lock-step emulation
+    (tests/emul, -DMPMPC_COUNT_OPS; FMA = 2) times the N+1 lanes that hold a stage.  Setup (Ruiz
+    scaling + first factorisation) 4.3 k, 1.31 k per ADMM iteration, 8.9 k per interior-point
+    iteration of the polish (its active-set rounds amortised in).  DESIGN.md section 5."""
+    return (N + 1) * (4.3e3 + 1.31e3 * admm_iters + 8.9e3 * ipm_iters)
 
 
 def cpu_baseline(tr, sc, seconds=15.0):
@@ -82,8 +91,7 @@ def main():
     B = args.batch or spec["B"]
     # every rank gets its own slice of a world*B batch drawn from the config's seed
     sc_all = scenarios.make(args.config, tr, B=B * world)
-    sl = slice(rank * B, (rank + 1) * B)
-    wp, x0, cc, lb, ub = sc_all.wp_id[sl], sc_all.x0[sl], sc_all.cc_prev[sl], sc_all.lb[sl], sc_all.ub[sl]
+    wp, x0, cc, lb, ub = sharding.shard([sc_all.wp_id, sc_all.x0, sc_all.cc_prev, sc_all.lb, sc_all.ub], world, rank)
     N = sc_all.N
     Q, R, QN = scenarios.WEIGHTS[sc_all.weights]
     cfg = mpmpc.make_config(N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX,
@@ -106,12 +114,7 @@ def main():
     for _ in range(args.steps):
         h.solve_resident(B)
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = sharding.max_over_ranks(dist, time.perf_counter() - t0, device="cuda" if dist is not None else None)
 
     # per-kernel durations, HIP events on the library's own stream
     reps = max(5, min(args.steps, 20))
@@ -140,6 +143,12 @@ def main():
                            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bytes_k2 / (ms_k2 * 1e-3) / HBM_PEAK,
                            "traffic": None, "avg_ms": ms_k2,
                            "note": "K2 is FP64-VALU / dependency-chain bound, not HBM bound (DESIGN.md section 5)"}
+        flops_k2 = float(np.sum(k2_flops_per_solve(N, sol.iters[:, 0].astype(float), sol.iters[:, 1].astype(float))))
+        out["roofline_fp64"] = {"bound": "fp64-valu", "kernel": "mpmpc_solve_kernel",
+                                "achieved": flops_k2 / (ms_k2 * 1e-3) / 1e12, "peak": FP64_VALU_PEAK / 1e12,
+                                "unit": "TFLOP/s", "frac": flops_k2 / (ms_k2 * 1e-3) / FP64_VALU_PEAK,
+                                "flops_per_solve_mean": flops_k2 / B,
+                                "note": "useful flops (31 of 64 lanes hold a stage at N=30); the slowest wave sets the time"}
         bytes_k1 = k1_bytes_per_solve(N) * B
         out["roofline_assembly"] = {"bound": "hbm", "kernel": "mpmpc_assemble_kernel",
                                     "achieved": bytes_k1 / (ms_k1 * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,

@@ -11,6 +11,16 @@ namespace mpmpc {
 
 constexpr int EMU_W = 64;
 
+// Optional instruction census (tests/emul built with -DMPMPC_COUNT_OPS): wave-level FP64
+// instructions by class, used to state the algorithmic flop count of a solve in DESIGN.md.
+#ifdef MPMPC_COUNT_OPS
+struct OpCount { long long fma, addmul, div, sqrt, cmpsel, shift, reduce; };
+inline OpCount& op_count() { static OpCount c{0, 0, 0, 0, 0, 0, 0}; return c; }
+#define MPMPC_OP(f) (++op_count().f)
+#else
+#define MPMPC_OP(f) ((void)0)
+#endif
+
 struct VB { bool v[EMU_W]; };
 struct VI {
   int v[EMU_W];
@@ -24,10 +34,15 @@ struct VD {
 };
 
 #define MPMPC_EMU_BIN(op)                                                                       \
-  inline VD operator op(const VD& a, const VD& b) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] op b.v[i]; return r; } \
-  inline VD operator op(const VD& a, double b) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] op b; return r; }       \
-  inline VD operator op(double a, const VD& b) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a op b.v[i]; return r; }
-MPMPC_EMU_BIN(+) MPMPC_EMU_BIN(-) MPMPC_EMU_BIN(*) MPMPC_EMU_BIN(/)
+  inline VD operator op(const VD& a, const VD& b) { MPMPC_OP(cls); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] op b.v[i]; return r; } \
+  inline VD operator op(const VD& a, double b) { MPMPC_OP(cls); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] op b; return r; }       \
+  inline VD operator op(double a, const VD& b) { MPMPC_OP(cls); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a op b.v[i]; return r; }
+#define cls addmul
+MPMPC_EMU_BIN(+) MPMPC_EMU_BIN(-) MPMPC_EMU_BIN(*)
+#undef cls
+#define cls div
+MPMPC_EMU_BIN(/)
+#undef cls
 #undef MPMPC_EMU_BIN
 inline VD operator-(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = -a.v[i]; return r; }
 inline VD& operator+=(VD& a, const VD& b) { for (int i = 0; i < EMU_W; ++i) a.v[i] += b.v[i]; return a; }
@@ -54,15 +69,15 @@ inline VI mini(const VI& a, int b) { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i
 inline VI maxi(const VI& a, int b) { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] > b ? a.v[i] : b; return r; }
 inline VI operator*(const VI& a, int b) { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] * b; return r; }
 
-inline VD fma_(const VD& a, const VD& b, const VD& c) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::fma(a.v[i], b.v[i], c.v[i]); return r; }
-inline VD sqrt_(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::sqrt(a.v[i]); return r; }
-inline VD rsqrt_(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = 1.0 / std::sqrt(a.v[i]); return r; }
+inline VD fma_(const VD& a, const VD& b, const VD& c) { MPMPC_OP(fma); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::fma(a.v[i], b.v[i], c.v[i]); return r; }
+inline VD sqrt_(const VD& a) { MPMPC_OP(sqrt); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::sqrt(a.v[i]); return r; }
+inline VD rsqrt_(const VD& a) { MPMPC_OP(sqrt); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = 1.0 / std::sqrt(a.v[i]); return r; }
 inline VD abs_(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::fabs(a.v[i]); return r; }
-inline VD max_(const VD& a, const VD& b) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] > b.v[i] ? a.v[i] : b.v[i]; return r; }
-inline VD min_(const VD& a, const VD& b) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] < b.v[i] ? a.v[i] : b.v[i]; return r; }
+inline VD max_(const VD& a, const VD& b) { MPMPC_OP(cmpsel); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] > b.v[i] ? a.v[i] : b.v[i]; return r; }
+inline VD min_(const VD& a, const VD& b) { MPMPC_OP(cmpsel); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] < b.v[i] ? a.v[i] : b.v[i]; return r; }
 inline VD tan_(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::tan(a.v[i]); return r; }
 inline VD atan_(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::atan(a.v[i]); return r; }
-inline VD sel(const VB& m, const VD& a, const VD& b) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
+inline VD sel(const VB& m, const VD& a, const VD& b) { MPMPC_OP(cmpsel); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
 inline VI seli(const VB& m, const VI& a, const VI& b) { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
 inline VB selb(const VB& m, const VB& a, const VB& b) { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
 
@@ -82,12 +97,13 @@ struct LaneEmu {
   static VB mfalse() { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = false; return r; }
 
   // value of the previous / next stage's lane (0.0 at the ends of an instance)
-  static VD up(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (i % G == 0) ? 0.0 : a.v[i - 1]; return r; }
-  static VD down(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (i % G == G - 1) ? 0.0 : a.v[i + 1]; return r; }
+  static VD up(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (i % G == 0) ? 0.0 : a.v[i - 1]; return r; }
+  static VD down(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (i % G == G - 1) ? 0.0 : a.v[i + 1]; return r; }
 
   // butterfly all-reduce inside an instance's lanes; same association order as the GPU backend
   template <class F>
   static VD bfly(VD a, F f) {
+    MPMPC_OP(reduce);
     for (int off = 1; off < G; off <<= 1) {
       VD t;
       for (int i = 0; i < EMU_W; ++i) t.v[i] = a.v[i ^ off];

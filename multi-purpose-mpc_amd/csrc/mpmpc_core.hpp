@@ -183,6 +183,14 @@ struct Solver {
   R pri_res, dua_res;
 
   // ======================================================================== helpers
+  // Commit `nw` where the lane's instance is still running.  With one instance per wavefront
+  // (G = 64) the loops exit as soon as that instance stops, so the select is dropped.
+  MPMPC_HD static R keep(const Mk& on, const R& nw, const R& old) {
+    if constexpr (L::per_wave == 1) return nw; else return sel(on, nw, old);
+  }
+  MPMPC_HD static I keepi(const Mk& on, const I& nw, const I& old) {
+    if constexpr (L::per_wave == 1) return nw; else return seli(on, nw, old);
+  }
   MPMPC_HD static R limit(const R& v) {
     R r = sel(v < R(MIN_SCALING), R(1.0), v);
     return sel(r > R(MAX_SCALING), R(MAX_SCALING), r);
@@ -597,11 +605,11 @@ struct Solver {
         R zr = fma_(alpha, g[j] * xt[j], oma * zb[j]);
         R zn = min_(max_(fma_(yb[j], rbinv[j], zr), lb[j]), ub[j]);
         R dy = rb[j] * (zr - zn);
-        xprev[j] = sel(active, x[j], xprev[j]);
-        x[j] = sel(active, xn, x[j]);
-        zb[j] = sel(active, zn, zb[j]);
-        dyb[j] = sel(active, dy, dyb[j]);
-        yb[j] = sel(active, yb[j] + dy, yb[j]);
+        xprev[j] = keep(active, x[j], xprev[j]);
+        x[j] = keep(active, xn, x[j]);
+        zb[j] = keep(active, zn, zb[j]);
+        dyb[j] = keep(active, dy, dyb[j]);
+        yb[j] = keep(active, yb[j] + dy, yb[j]);
       }
       MPMPC_UNROLL
       for (int i = 0; i < 3; ++i) {
@@ -609,11 +617,11 @@ struct Solver {
         R zr = fma_(alpha, zt, oma * zeq[i]);
         R zn = leq[i];                                   // projection onto [l, l]
         R dy = rho_eq * (zr - zn);
-        zeq[i] = sel(active, zn, zeq[i]);
-        dyeq[i] = sel(active, dy, dyeq[i]);
-        yeq[i] = sel(active, yeq[i] + dy, yeq[i]);
+        zeq[i] = keep(active, zn, zeq[i]);
+        dyeq[i] = keep(active, dy, dyeq[i]);
+        yeq[i] = keep(active, yeq[i] + dy, yeq[i]);
       }
-      iters = seli(active, I(it), iters);
+      iters = keepi(active, I(it), iters);
       // ---- termination
       bool can_check = st.check_termination > 0 && (it % st.check_termination) == 0;
       bool can_adapt = st.adaptive_rho && st.adaptive_rho_interval > 0 && (it % st.adaptive_rho_interval) == 0;

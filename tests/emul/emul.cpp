@@ -49,3 +49,16 @@ extern "C" int emu_assemble(const mpmpc_config* cfg, int n_wp, const double* kap
 }
 
 extern "C" int emu_stage_ld(int N) { return stage_ld(N); }
+
+// instruction census of everything executed since the last reset (only with -DMPMPC_COUNT_OPS)
+extern "C" int emu_op_count(long long* out7, int reset) {
+#ifdef MPMPC_COUNT_OPS
+  OpCount& c = op_count();
+  out7[0] = c.fma; out7[1] = c.addmul; out7[2] = c.div; out7[3] = c.sqrt; out7[4] = c.cmpsel; out7[5] = c.shift; out7[6] = c.reduce;
+  if (reset) c = OpCount{0, 0, 0, 0, 0, 0, 0};
+  return 1;
+#else
+  (void)out7; (void)reset;
+  return 0;
+#endif
+}

@@ -1,0 +1,64 @@
+"""N>1 path on CPU: world size 2 over gloo.  Each rank solves its contiguous shard (kernels run in
+the CPU emulation here, on the GPU box the same sharding code drives libmpmpc.so), the only
+collectives are the MAX of the elapsed time and the optional gather of the controls."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import mpmpc
+import mpmpc_testlib as T
+import scenarios
+import sharding
+
+
+def test_shard_bounds_cover_batch():
+    for total in (1, 7, 1024, 65536 + 3):
+        for world in (1, 2, 3, 8):
+            cuts = [sharding.shard_bounds(total, world, r) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == total
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_bounds(10, 2, 2)
+
+
+def _worker(rank, world, port, total, N, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr = scenarios.sim_track()
+    sc = scenarios.make(4, tr, B=total, N=N)
+    wp, x0, cc, lb, ub = sharding.shard([sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub], world, rank)
+    cfg = T.stock_config(N, sc.weights)
+    backend = T.EmuBackend(cfg, mpmpc.default_settings())
+    backend.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+    sol = backend.solve(wp, x0, cc, lb, ub)
+    dt = sharding.max_over_ranks(dist, 0.25 * (rank + 1))
+    u_all, s_all = sharding.gather_controls(dist, sol.u0, sol.status, total)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), u=u_all, s=s_all, dt=dt, n_local=wp.size)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_match_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    total, N, world = 11, 10, 2          # odd batch: shards of 6 and 5
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, total, N, str(tmp_path)), nprocs=world, join=True)
+    tr = scenarios.sim_track()
+    sc = scenarios.make(4, tr, B=total, N=N)
+    cfg = T.stock_config(N, sc.weights)
+    ref = T.EmuBackend(cfg, mpmpc.default_settings())
+    ref.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+    full = ref.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    got = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    assert [int(g["n_local"]) for g in got] == [6, 5]
+    for g in got:                         # every rank holds the whole gathered result
+        assert np.array_equal(g["s"], full.status)
+        ok = full.status > 0
+        assert np.array_equal(g["u"][ok], full.u0[ok])
+        assert float(g["dt"]) == 0.5      # MAX over ranks of (0.25, 0.5)
