@@ -150,3 +150,70 @@ def test_errors_are_loud(track):
     h.close()
     with pytest.raises(ValueError):
         T.stock_config(2)
+
+
+# ---------------------------------------------------------------------------------------------
+# host classes on the real library: the reference's drop-in surface
+# ---------------------------------------------------------------------------------------------
+def _world():
+    import test_host_mpc as H
+    return H.build_world()
+
+
+def test_mpc_get_control_replays_reference_lap_on_gpu():
+    """MPC.get_control() through libmpmpc.so on the reference's own closed-loop trace (golden G6)."""
+    import test_host_mpc as H
+    from spatial_bicycle_models import TemporalState
+    g = np.load(M.GOLDEN + "/g6_closed_loop_N30.npz")
+    m, rp, car = H.build_world()
+    mpc = H.make_mpc(car, 30)                       # real backend
+    assert isinstance(mpc.optimizer, mpmpc.Handle)
+    n_inf = 0
+    for t in range(0, g["s"].size, 2):
+        car.s = float(g["s"][t])
+        car.temporal_state = TemporalState(*g["pose"][t])
+        mpc.current_control = g["cc_prev"][t].copy()
+        mpc.infeasibility_counter = int(g["counter"][t - 1]) if t > 0 else 0
+        u = mpc.get_control()
+        assert car.wp_id == g["wp_id"][t] and mpc.infeasibility_counter == g["counter"][t]
+        assert (mpc.last_status > 0) == (g["status"][t] > 0)
+        assert np.max(np.abs(u - g["u"][t])) <= 1e-6
+        n_inf += int(mpc.last_status < 0)
+    assert n_inf > 0
+
+
+def test_free_running_lap_on_gpu():
+    """src/simulation.py's while-loop (simulation.py:134-148) with our classes, plotting off."""
+    import test_host_mpc as H
+    g = np.load(M.GOLDEN + "/g6_closed_loop_N30.npz")
+    m, rp, car = H.build_world()
+    mpc = H.make_mpc(car, 30)
+    steps = 0
+    while car.s < rp.length and steps < 400:
+        u = mpc.get_control()
+        car.drive(u)
+        steps += 1
+    assert car.s >= rp.length
+    assert abs(steps - g["s"].size) <= 10           # the reference's lap: 207 steps
+
+
+def test_batch_mpc_matches_single_controller():
+    import test_host_mpc as H
+    from MPC import BatchMPC
+    from scipy import sparse
+    m, rp, car = H.build_world()
+    g = np.load(M.GOLDEN + "/g6_closed_loop_N30.npz")
+    Q, R, QN = sparse.diags([1.0, 0.0, 0.0]), sparse.diags([0.5, 0.0]), sparse.diags([1.0, 0.0, 0.0])
+    ic = {'umin': np.array([0.0, -np.tan(0.66) / car.length]), 'umax': np.array([1.0, np.tan(0.66) / car.length])}
+    sc = {'xmin': np.array([-np.inf] * 3), 'xmax': np.array([np.inf] * 3)}
+    idx = np.arange(0, 200, 5)
+    bm = BatchMPC(car, 30, Q, R, QN, sc, ic, 4.0, max_batch=idx.size)
+    wp, x0 = bm.spatial_states(g["s"][idx], g["pose"][idx])
+    assert np.array_equal(wp, g["wp_id"][idx]) and np.allclose(x0, g["x0"][idx], atol=1e-13)
+    u, plan, status, sol = bm.get_control_batch(wp, x0, g["cc_prev"][idx], g["lb"][idx], g["ub"][idx])
+    ok = g["status"][idx] > 0
+    assert np.array_equal(status > 0, ok)
+    assert np.max(np.abs(u[ok] - g["u"][idx][ok])) <= 1e-6
+    d = np.abs(plan[ok] - g["cc_next"][idx][ok])
+    d[:, -1] = 0.0
+    assert d.max() <= 1e-6
