@@ -73,8 +73,8 @@ inline VD fma_(const VD& a, const VD& b, const VD& c) { MPMPC_OP(fma); VD r; for
 inline VD sqrt_(const VD& a) { MPMPC_OP(sqrt); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::sqrt(a.v[i]); return r; }
 inline VD rsqrt_(const VD& a) { MPMPC_OP(sqrt); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = 1.0 / std::sqrt(a.v[i]); return r; }
 inline VD abs_(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::fabs(a.v[i]); return r; }
-inline VD max_(const VD& a, const VD& b) { MPMPC_OP(cmpsel); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] > b.v[i] ? a.v[i] : b.v[i]; return r; }
-inline VD min_(const VD& a, const VD& b) { MPMPC_OP(cmpsel); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i] < b.v[i] ? a.v[i] : b.v[i]; return r; }
+inline VD max_(const VD& a, const VD& b) { MPMPC_OP(cmpsel); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::fmax(a.v[i], b.v[i]); return r; }
+inline VD min_(const VD& a, const VD& b) { MPMPC_OP(cmpsel); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::fmin(a.v[i], b.v[i]); return r; }
 inline VD tan_(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::tan(a.v[i]); return r; }
 inline VD atan_(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::atan(a.v[i]); return r; }
 inline VD sel(const VB& m, const VD& a, const VD& b) { MPMPC_OP(cmpsel); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
@@ -111,8 +111,8 @@ struct LaneEmu {
     }
     return a;
   }
-  static VD gmax(const VD& a) { return bfly(a, [](double x, double y) { return x > y ? x : y; }); }
-  static VD gmin(const VD& a) { return bfly(a, [](double x, double y) { return x < y ? x : y; }); }
+  static VD gmax(const VD& a) { return bfly(a, [](double x, double y) { return std::fmax(x, y); }); }
+  static VD gmin(const VD& a) { return bfly(a, [](double x, double y) { return std::fmin(x, y); }); }
   static VD gsum(const VD& a) { return bfly(a, [](double x, double y) { return x + y; }); }
   static VB gany(const VB& m) {
     VB r;

@@ -18,8 +18,8 @@ __device__ __forceinline__ double rsqrt_(double a) {
   return __builtin_fma(r * e, 0.5, r);
 }
 __device__ __forceinline__ double abs_(double a) { return __builtin_fabs(a); }
-__device__ __forceinline__ double max_(double a, double b) { return a > b ? a : b; }
-__device__ __forceinline__ double min_(double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ double max_(double a, double b) { return __builtin_fmax(a, b); }   // v_max_f64
+__device__ __forceinline__ double min_(double a, double b) { return __builtin_fmin(a, b); }   // v_min_f64
 __device__ __forceinline__ double tan_(double a) { return ::tan(a); }
 __device__ __forceinline__ double atan_(double a) { return ::atan(a); }
 __device__ __forceinline__ double sel(bool m, double a, double b) { return m ? a : b; }
@@ -68,12 +68,12 @@ struct LaneGpu {
   }
   static __device__ __forceinline__ double gmax(double a) {
 #pragma unroll
-    for (int off = 1; off < G; off <<= 1) { double t = __shfl_xor(a, off, 64); a = a > t ? a : t; }
+    for (int off = 1; off < G; off <<= 1) { double t = __shfl_xor(a, off, 64); a = __builtin_fmax(a, t); }
     return a;
   }
   static __device__ __forceinline__ double gmin(double a) {
 #pragma unroll
-    for (int off = 1; off < G; off <<= 1) { double t = __shfl_xor(a, off, 64); a = a < t ? a : t; }
+    for (int off = 1; off < G; off <<= 1) { double t = __shfl_xor(a, off, 64); a = __builtin_fmin(a, t); }
     return a;
   }
   static __device__ __forceinline__ double gsum(double a) {

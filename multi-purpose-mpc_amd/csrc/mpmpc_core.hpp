@@ -960,7 +960,7 @@ struct Solver {
       polished = seli(good, I(1), polished);
       todo = todo & conv & !good;       // a diverged interior-point run is not retried
       if (!L::wany(todo)) break;
-      tol *= 1e-2;
+      tol *= 1e-4;      // a wrong active-set guess means the centring was too loose: tighten it a lot
     }
     // whatever is left could not be certified: keep the ADMM iterate, flag it
     Mk failed = run & (polished != 1);

@@ -79,7 +79,7 @@ class Settings:
     ipm_max_iter: int = 50
     as_delta: float = 1e-9
     as_refine: int = 5
-    as_rounds: int = 10
+    as_rounds: int = 4
     cert_tol: float = 1e-8
 
 
@@ -267,7 +267,7 @@ def solve(P, q, A, l, u, settings: Settings | None = None, trace=None) -> Result
                 res.x, res.y, res.polished, res.status = xs, ys, 1, SOLVED
                 res.pri_res, res.dua_res, res.obj = cert["prim"], cert["stat"], cert["obj"]
                 return res
-        ipm_tol *= 1e-2
+        ipm_tol *= 1e-4
     # not certified (typically a marginally infeasible problem that ADMM at a loose eps calls
     # solved): hand back the ADMM iterate, as stock OSQP would, flagged inaccurate
     res.polished, res.status = -1, SOLVED_INACCURATE

@@ -602,34 +602,45 @@ static int active_set_polish(work_t* w, const classes_t* cl, int* low, int* upp,
     kkt_t* K = kkt_build(&w->P, &w->A, rows, k);
     ldl_t* F = ldl_analyse(K->N, K->p, K->i, NULL);
     double* dv = (double*)malloc(sizeof(double) * (k > 0 ? k : 1));
-    for (int r = 0; r < k; ++r) dv[r] = st->as_delta;
     int N = n + k;
     double *rhs = (double*)malloc(sizeof(double) * N), *cor = (double*)malloc(sizeof(double) * N), *rr = (double*)malloc(sizeof(double) * N);
     long double* sol = (long double*)calloc(N, sizeof(long double));
-    int bad = kkt_fill_and_factor(w, K, F, st->as_delta, dv, k);
+    long double* acc = (long double*)malloc(sizeof(long double) * N);
     for (int j = 0; j < n; ++j) rhs[j] = -w->q[j];
     for (int r = 0; r < k; ++r) rhs[n + r] = upp[rows[r]] ? w->u[rows[r]] : w->l[rows[r]];
-    for (int rf = 0; rf <= st->as_refine && !bad; ++rf) {
-      /* residual rhs - K0 sol in extended precision (K0 = un-regularised reduced KKT) */
-      long double* acc = (long double*)malloc(sizeof(long double) * N);
-      for (int i = 0; i < N; ++i) acc[i] = rhs[i];
-      for (int j = 0; j < n; ++j)
-        for (int p = w->P.p[j]; p < w->P.p[j + 1]; ++p) {
-          int i = w->P.i[p];
-          acc[i] -= (long double)w->P.x[p] * sol[j];
-          if (i != j) acc[j] -= (long double)w->P.x[p] * sol[i];
-        }
-      for (int r = 0; r < k; ++r)
-        for (int p = K->At_p[rows[r]]; p < K->At_p[rows[r] + 1]; ++p) {
-          int j = K->At_i[p]; double a = w->A.x[K->At_k[p]];
-          acc[j] -= (long double)a * sol[n + r];
-          acc[n + r] -= (long double)a * sol[j];
-        }
-      for (int i = 0; i < N; ++i) rr[i] = (double)acc[i];
-      free(acc);
-      ldl_solve(F, rr, cor);
-      for (int i = 0; i < N; ++i) sol[i] += cor[i];
+    int bad = 0;
+    /* LDL' without pivoting of a quasi-definite matrix: if the refinement does not contract with the
+     * nominal regularisation, retry with a larger one (the refinement removes its bias anyway) */
+    double delta = st->as_delta;
+    for (int tries = 0; tries < 4; ++tries, delta *= 30.0) {
+      for (int r = 0; r < k; ++r) dv[r] = delta;
+      for (int i = 0; i < N; ++i) sol[i] = 0.0L;
+      bad = kkt_fill_and_factor(w, K, F, delta, dv, k);
+      long double resn = 0.0L;
+      for (int rf = 0; rf <= st->as_refine + 3 && !bad; ++rf) {
+        /* residual rhs - K0 sol in extended precision (K0 = un-regularised reduced KKT) */
+        for (int i = 0; i < N; ++i) acc[i] = rhs[i];
+        for (int j = 0; j < n; ++j)
+          for (int p = w->P.p[j]; p < w->P.p[j + 1]; ++p) {
+            int i = w->P.i[p];
+            acc[i] -= (long double)w->P.x[p] * sol[j];
+            if (i != j) acc[j] -= (long double)w->P.x[p] * sol[i];
+          }
+        for (int r = 0; r < k; ++r)
+          for (int p = K->At_p[rows[r]]; p < K->At_p[rows[r] + 1]; ++p) {
+            int j = K->At_i[p]; double a = w->A.x[K->At_k[p]];
+            acc[j] -= (long double)a * sol[n + r];
+            acc[n + r] -= (long double)a * sol[j];
+          }
+        resn = 0.0L;
+        for (int i = 0; i < N; ++i) { rr[i] = (double)acc[i]; long double t = acc[i] < 0 ? -acc[i] : acc[i]; if (t > resn) resn = t; }
+        if (resn < 1e-14L) break;
+        ldl_solve(F, rr, cor);
+        for (int i = 0; i < N; ++i) sol[i] += cor[i];
+      }
+      if (!bad && resn < 1e-11L) break;
     }
+    free(acc);
     for (int j = 0; j < n; ++j) x[j] = (double)sol[j];
     for (int r = 0; r < m; ++r) y[r] = 0;
     for (int r = 0; r < k; ++r) y[rows[r]] = (double)sol[n + r];
@@ -766,7 +777,7 @@ int oracle_solve_csc(int n, int m, const int* Pp, const int* Pi, const double* P
           good = 1;
         }
       }
-      tol *= 1e-2;
+      tol *= 1e-4;
     }
     if (!good) { info->status = SOLVED_INACCURATE; info->polished = -1; }
     free(cl.eq); free(cl.L); free(cl.U); free(low); free(upp); free(xi); free(yi); free(xa); free(ya); free(xs); free(ys);
