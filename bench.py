@@ -66,6 +66,21 @@ def cpu_baseline(tr, sc, seconds=15.0):
     return oracle_c.timed_baseline(tr, sc, scenarios.WEIGHTS[sc.weights], limits, seconds)
 
 
+def pmc_traffic_bytes(kernel_prefix, B):
+    """HBM bytes per launch of one kernel from the committed rocprofv3 PMC summary of THIS command
+    (profiles/r1/pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when no summary for this batch size exists."""
+    path = os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")
+    key_f, key_w = ("pmc_fetch", "pmc_write") if B == 1024 else ("pmc_fetch_b%d" % B, "pmc_write_b%d" % B)
+    try:
+        d = json.load(open(path))
+        f = next(v for k, v in d[key_f].items() if k.startswith(kernel_prefix))["FETCH_SIZE"]["mean"]
+        w = next(v for k, v in d[key_w].items() if k.startswith(kernel_prefix))["WRITE_SIZE"]["mean"]
+        return (2.0 * f + w) * 1024.0
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,7 +95,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):   # launched by torch.distributed.run
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -141,7 +156,8 @@ def main():
         bytes_k2 = k2_bytes_per_solve(N) * B
         out["roofline"] = {"bound": "hbm", "kernel": "mpmpc_solve_kernel", "achieved": bytes_k2 / (ms_k2 * 1e-3) / 1e9,
                            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bytes_k2 / (ms_k2 * 1e-3) / HBM_PEAK,
-                           "traffic": None, "avg_ms": ms_k2,
+                           "traffic": pmc_traffic_bytes("mpmpc_solve_kernel", B) if args.config == 2 else None,
+                           "algorithmic_bytes": bytes_k2, "avg_ms": ms_k2,
                            "note": "K2 is FP64-VALU / dependency-chain bound, not HBM bound (DESIGN.md section 5)"}
         flops_k2 = float(np.sum(k2_flops_per_solve(N, sol.iters[:, 0].astype(float), sol.iters[:, 1].astype(float))))
         out["roofline_fp64"] = {"bound": "fp64-valu", "kernel": "mpmpc_solve_kernel",
@@ -152,7 +168,9 @@ def main():
         bytes_k1 = k1_bytes_per_solve(N) * B
         out["roofline_assembly"] = {"bound": "hbm", "kernel": "mpmpc_assemble_kernel",
                                     "achieved": bytes_k1 / (ms_k1 * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
-                                    "unit": "GB/s", "frac": bytes_k1 / (ms_k1 * 1e-3) / HBM_PEAK, "avg_ms": ms_k1}
+                                    "unit": "GB/s", "frac": bytes_k1 / (ms_k1 * 1e-3) / HBM_PEAK, "avg_ms": ms_k1,
+                                    "traffic": pmc_traffic_bytes("mpmpc_assemble_kernel", B) if args.config == 2 else None,
+                                    "algorithmic_bytes": bytes_k1}
         st, cnt = np.unique(sol.status, return_counts=True)
         out["status_counts"] = {int(s): int(c) for s, c in zip(st, cnt)}
         out["iters"] = {"admm_mean": float(sol.iters[:, 0].mean()), "admm_max": int(sol.iters[:, 0].max()),
