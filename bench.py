@@ -45,7 +45,8 @@ def k1_bytes_per_solve(N):
 
 
 def k2_bytes_per_solve(N):
-    return 8 * mpmpc.NUM_FIELDS * (N + 1) + 8 * (5 * N + 3 + 2 + 2) + 12
+    # read the 27 stage fields; write z (5N+3), multipliers y (8N+6), u0, residuals, status, iterations
+    return 8 * mpmpc.NUM_FIELDS * (N + 1) + 8 * (5 * N + 3 + 8 * N + 6 + 2 + 2) + 12
 
 
 def k2_flops_per_solve(N, admm_iters, ipm_iters):

@@ -125,6 +125,14 @@ struct LaneEmu {
   }
   static bool wany(const VB& m) { for (int i = 0; i < EMU_W; ++i) if (m.v[i]) return true; return false; }
 
+  // "cold" per-lane storage (LDS on the GPU) for values that are only needed at termination checks
+  // and in the certificate, so that they do not occupy registers inside the iteration loops
+  static constexpr int cold_slots = 48;
+  static VD* cold() { static VD buf[cold_slots]; return buf; }
+  static void cold_put(int slot, const VD& a) { cold()[slot] = a; }
+  static VD cold_get(int slot) { return cold()[slot]; }
+  static void fence() {}
+
   static VD load(const double* p, const VI& idx, const VB& ok, double dflt) {
     VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = ok.v[i] ? p[idx.v[i]] : dflt; return r;
   }

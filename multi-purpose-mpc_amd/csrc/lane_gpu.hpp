@@ -89,6 +89,19 @@ struct LaneGpu {
   }
   static __device__ __forceinline__ bool wany(bool m) { return __ballot(m) != 0ull; }
 
+  // "cold" per-lane storage in LDS (one wavefront per block, slot-major: a wave access is 64
+  // consecutive doubles, conflict free) for values only needed at termination checks and in the
+  // certificate, so that they do not occupy registers - or worse, scratch - inside the loops
+  static constexpr int cold_slots = 48;          // 24 KB per wave
+  static __device__ __forceinline__ double* cold() {
+    __shared__ double buf[cold_slots * 64];
+    return buf;
+  }
+  static __device__ __forceinline__ void cold_put(int slot, double a) { cold()[slot * 64 + lane_id()] = a; }
+  static __device__ __forceinline__ double cold_get(int slot) { return cold()[slot * 64 + lane_id()]; }
+  // compiler-level fence: values parked before it are re-read after it, not kept in registers
+  static __device__ __forceinline__ void fence() { asm volatile("" ::: "memory"); }
+
   static __device__ __forceinline__ double load(const double* p, int idx, bool ok, double dflt) {
     return ok ? p[idx] : dflt;
   }

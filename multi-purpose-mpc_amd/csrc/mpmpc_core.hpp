@@ -575,6 +575,23 @@ struct Solver {
     return stt;
   }
 
+  // Scalings D, E, the cost diagonal and the previous iterate are only read at termination checks:
+  // they live in cold storage between checks.
+  MPMPC_HD void park_check_data() const {
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) { L::cold_put(j, D[j]); L::cold_put(5 + j, Eb[j]); L::cold_put(10 + j, p[j]); }
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) L::cold_put(15 + i, Eeq[i]);
+    L::fence();
+  }
+  MPMPC_HD void unpark_check_data() {
+    L::fence();
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) { D[j] = L::cold_get(j); Eb[j] = L::cold_get(5 + j); p[j] = L::cold_get(10 + j); }
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) Eeq[i] = L::cold_get(15 + i);
+  }
+
   MPMPC_HD void admm(const mpmpc_settings& st) {
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) { x[j] = zb[j] = yb[j] = xprev[j] = dyb[j] = R(0.0); }
@@ -590,6 +607,7 @@ struct Solver {
     Mk active = live;
     Info nf;
     info(nf);
+    park_check_data();
     for (int it = 1; it <= st.max_iter; ++it) {
       if (!L::wany(active)) break;
       // ---- one ADMM step (OSQP update_xz_tilde / update_x / update_z / update_y)
@@ -625,7 +643,7 @@ struct Solver {
       // ---- termination
       bool can_check = st.check_termination > 0 && (it % st.check_termination) == 0;
       bool can_adapt = st.adaptive_rho && st.adaptive_rho_interval > 0 && (it % st.adaptive_rho_interval) == 0;
-      if (can_check || can_adapt) info(nf);
+      if (can_check || can_adapt) { unpark_check_data(); info(nf); }
       if (can_check) {
         I stt = check(nf, st, false);
         Mk term = active & (stt != MPMPC_UNSOLVED);
@@ -645,6 +663,7 @@ struct Solver {
         }
       }
     }
+    unpark_check_data();
     // ---- ran out of iterations: OSQP's final exact, then approximate, check
     if (L::wany(active)) {
       info(nf);
@@ -691,8 +710,12 @@ struct Solver {
     R nb = max_(L::gsum(cnt), one);
     I stall(0);
     for (int it = 0; it <= st.ipm_max_iter; ++it) {
-      // ---- residuals
-      R At[5], rp[3], rd[5], rl[5], ru[5], rpin[5];
+      // ---- residuals (the slack residuals rl, ru, rpin are cheap functions of the iterate: they are
+      //      re-evaluated where needed instead of being carried across the sweeps)
+      auto rl_of = [&](int j) { return sel(bx.Lm[j], s.x[j] - bx.lo[j] - s.sl[j], zero); };
+      auto ru_of = [&](int j) { return sel(bx.Um[j], bx.hi[j] - s.x[j] - s.su[j], zero); };
+      auto rpin_of = [&](int j) { return sel(bx.pin[j], s.x[j] - bx.lo[j], zero); };
+      R At[5], rp[3], rd[5];
       AeqT_mul(s.nu, At);
       Aeq_mul(s.x, rp);
       R res(0.0), msum(0.0);
@@ -701,10 +724,7 @@ struct Solver {
       MPMPC_UNROLL
       for (int j = 0; j < 5; ++j) {
         rd[j] = fma_(p[j], s.x[j], q[j]) + At[j] - s.zl[j] + s.zu[j] + s.pi[j];
-        rl[j] = sel(bx.Lm[j], s.x[j] - bx.lo[j] - s.sl[j], zero);
-        ru[j] = sel(bx.Um[j], bx.hi[j] - s.x[j] - s.su[j], zero);
-        rpin[j] = sel(bx.pin[j], s.x[j] - bx.lo[j], zero);
-        res = max_(res, sel(valid[j], max_(max_(abs_(rd[j]), abs_(rpin[j])), max_(abs_(rl[j]), abs_(ru[j]))), zero));
+        res = max_(res, sel(valid[j], max_(max_(abs_(rd[j]), abs_(rpin_of(j))), max_(abs_(rl_of(j)), abs_(ru_of(j)))), zero));
         msum = msum + sel(bx.Lm[j], s.sl[j] * s.zl[j], zero) + sel(bx.Um[j], s.su[j] * s.zu[j], zero);
       }
       res = L::gmax(res);
@@ -733,8 +753,8 @@ struct Solver {
         R rhs[5], nreq[3];
         MPMPC_UNROLL
         for (int j = 0; j < 5; ++j)
-          rhs[j] = -rd[j] - sel(bx.Lm[j], (rcl[j] + s.zl[j] * rl[j]) / s.sl[j], zero) +
-                   sel(bx.Um[j], (rcu[j] + s.zu[j] * ru[j]) / s.su[j], zero) - sel(bx.pin[j], rpin[j] / reg, zero);
+          rhs[j] = -rd[j] - sel(bx.Lm[j], (rcl[j] + s.zl[j] * rl_of(j)) / s.sl[j], zero) +
+                   sel(bx.Um[j], (rcu[j] + s.zu[j] * ru_of(j)) / s.su[j], zero) - sel(bx.pin[j], rpin_of(j) / reg, zero);
         MPMPC_UNROLL
         for (int i = 0; i < 3; ++i) nreq[i] = -rp[i];
         kkt_solve(rhs, nreq, dx, dnu);
@@ -755,11 +775,11 @@ struct Solver {
         R ratio(1e300);
         MPMPC_UNROLL
         for (int j = 0; j < 5; ++j) {
-          dsl[j] = sel(bx.Lm[j], dx[j] + rl[j], zero);
-          dsu[j] = sel(bx.Um[j], -dx[j] + ru[j], zero);
+          dsl[j] = sel(bx.Lm[j], dx[j] + rl_of(j), zero);
+          dsu[j] = sel(bx.Um[j], -dx[j] + ru_of(j), zero);
           dzl[j] = sel(bx.Lm[j], (-rcl[j] - s.zl[j] * dsl[j]) / s.sl[j], zero);
           dzu[j] = sel(bx.Um[j], (-rcu[j] - s.zu[j] * dsu[j]) / s.su[j], zero);
-          dpi[j] = sel(bx.pin[j], (rpin[j] + dx[j]) / reg, zero);
+          dpi[j] = sel(bx.pin[j], (rpin_of(j) + dx[j]) / reg, zero);
           ratio = min_(ratio, sel(bx.Lm[j] & (dsl[j] < zero), -s.sl[j] / dsl[j], R(1e300)));
           ratio = min_(ratio, sel(bx.Um[j] & (dsu[j] < zero), -s.su[j] / dsu[j], R(1e300)));
           ratio = min_(ratio, sel(bx.Lm[j] & (dzl[j] < zero), -s.zl[j] / dzl[j], R(1e300)));
@@ -912,6 +932,31 @@ struct Solver {
     return (prim <= R(tol)) & (stat <= R(tol)) & (cv <= R(tol)) & !bad;
   }
 
+  // During the interior-point and active-set loops the scalings, the scaled row bounds and the ADMM
+  // point (kept as the fallback answer) are parked in cold storage: slots 0..41.
+  MPMPC_HD void stash() const {
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      L::cold_put(j, D[j]); L::cold_put(5 + j, Eb[j]); L::cold_put(10 + j, lb[j]); L::cold_put(15 + j, ub[j]);
+      L::cold_put(20 + j, x[j]); L::cold_put(25 + j, yb[j]); L::cold_put(37 + j, g[j]);
+    }
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) { L::cold_put(30 + i, Eeq[i]); L::cold_put(33 + i, yeq[i]); }
+    L::cold_put(36, c);
+    L::fence();
+  }
+  MPMPC_HD void unstash() {
+    L::fence();
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      D[j] = L::cold_get(j); Eb[j] = L::cold_get(5 + j); lb[j] = L::cold_get(10 + j); ub[j] = L::cold_get(15 + j);
+      x[j] = L::cold_get(20 + j); yb[j] = L::cold_get(25 + j); g[j] = L::cold_get(37 + j);
+    }
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) { Eeq[i] = L::cold_get(30 + i); yeq[i] = L::cold_get(33 + i); }
+    c = L::cold_get(36);
+  }
+
   MPMPC_HD void polish(const mpmpc_settings& st) {
     Mk run = live & ((status == MPMPC_SOLVED) | (status == MPMPC_SOLVED_INACCURATE) | (status == MPMPC_MAX_ITER_REACHED));
     if (!L::wany(run)) return;
@@ -934,6 +979,7 @@ struct Solver {
     double tol = st.ipm_tol;
     Mk todo = run;
     for (int attempt = 0; attempt < 2; ++attempt) {
+      stash();
       Mk conv = ipm(bx, s, st, tol, todo);
       Mk aL[5], aU[5];
       MPMPC_UNROLL
@@ -947,6 +993,7 @@ struct Solver {
       MPMPC_UNROLL
       for (int i = 0; i < 3; ++i) nus[i] = s.nu[i];
       Mk okm = active_set(bx, aL, aU, xs, nus, lam, st, todo & conv);
+      unstash();
       R prim, stat;
       Mk cert = certificate(xs, nus, lam, st.cert_tol, prim, stat);
       Mk good = todo & conv & okm & cert;
