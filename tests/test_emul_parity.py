@@ -104,3 +104,42 @@ def test_ragged_batch_and_group_packing(emu, track):
     for s in (s32, s16):
         assert np.array_equal(s.status, s64.status) and np.array_equal(s.iters, s64.iters)
         assert np.max(np.abs(s.z - s64.z)) < 1e-12
+
+
+def test_maximum_horizon_and_finite_state_boxes(emu, track):
+    """N = 63 (one lane per stage is the limit) with finite boxes on e_psi and t as well."""
+    import oracle_c as OC
+    N, B = 63, 4
+    sc = scenarios.make(2, track, B=B, N=50)                 # corridor tables hold 50 columns
+    lb = np.concatenate([sc.lb, np.repeat(sc.lb[:, -1:], N - 50, axis=1)], axis=1)
+    ub = np.concatenate([sc.ub, np.repeat(sc.ub[:, -1:], N - 50, axis=1)], axis=1)
+    cc = np.zeros((B, 2 * N))
+    Q, R, QN = scenarios.WEIGHTS["stock"]
+    xmin, xmax = np.array([-np.inf, -0.6, -np.inf]), np.array([np.inf, 0.6, 4.0])
+    cfg = mpmpc.make_config(N, Q, R, QN, xmin, xmax, scenarios.UMIN, scenarios.UMAX, 4.0, 0.12)
+    qp = emu.assemble(cfg, track, (sc.wp_id, sc.x0, cc, lb, ub))
+    sol = emu.solve(cfg, mpmpc.default_settings(), qp, G=64)
+    ocfg = OC.mpc_cfg(N, (Q, R, QN), scenarios.UMIN, scenarios.UMAX, xmin, xmax, 4.0, 0.12)
+    ref = OC.mpc_batch(ocfg, OC.settings(), track.kappa, track.v_ref, track.ds_next, sc.wp_id, sc.x0, cc, lb, ub)
+    assert np.array_equal(sol.status, ref["status"]) and np.all(sol.status == 1)
+    assert np.array_equal(sol.iters[:, 0], ref["iters"][:, 0])
+    assert np.max(np.abs(sol.u0 - ref["u0"])) <= 1e-6
+    assert np.all(np.abs(sol.z[:, 1:3 * (N + 1):3]) <= 0.6 + 1e-9)        # e_psi box respected
+
+
+def test_c_port_agrees_with_emulation_on_a_larger_sample(emu, track):
+    """Statuses, iteration counts and controls over 256 obstacle-corridor instances (incl. infeasible)."""
+    import oracle_c as OC
+    sc = scenarios.make(4, track, B=256)
+    cfg = T.stock_config(sc.N, sc.weights)
+    qp = emu.assemble(cfg, track, _inputs(sc))
+    sol = emu.solve(cfg, mpmpc.default_settings(), qp, G=64)
+    ocfg = OC.mpc_cfg(sc.N, scenarios.WEIGHTS[sc.weights], scenarios.UMIN, scenarios.UMAX, scenarios.XMIN,
+                      scenarios.XMAX, 4.0, 0.12)
+    ref = OC.mpc_batch(ocfg, OC.settings(), track.kappa, track.v_ref, track.ds_next, sc.wp_id, sc.x0, sc.cc_prev,
+                       sc.lb, sc.ub)
+    assert np.array_equal(sol.status, ref["status"])
+    assert np.array_equal(sol.iters[:, 0], ref["iters"][:, 0])
+    ok = sol.status == 1
+    assert ok.sum() > 200 and (sol.status == mpmpc.PRIMAL_INFEASIBLE).sum() > 0
+    assert np.max(np.abs(sol.u0[ok] - ref["u0"][ok])) <= 1e-6

@@ -217,3 +217,54 @@ def test_batch_mpc_matches_single_controller():
     d = np.abs(plan[ok] - g["cc_next"][idx][ok])
     d[:, -1] = 0.0
     assert d.max() <= 1e-6
+
+
+def test_maximum_horizon_and_finite_state_boxes_gpu(track):
+    import oracle_c as OC
+    N, B = 63, 6
+    sc = scenarios.make(2, track, B=B, N=50)
+    lb = np.concatenate([sc.lb, np.repeat(sc.lb[:, -1:], N - 50, axis=1)], axis=1)
+    ub = np.concatenate([sc.ub, np.repeat(sc.ub[:, -1:], N - 50, axis=1)], axis=1)
+    cc = np.zeros((B, 2 * N))
+    Q, R, QN = scenarios.WEIGHTS["stock"]
+    xmin, xmax = np.array([-np.inf, -0.6, -np.inf]), np.array([np.inf, 0.6, 4.0])
+    cfg = mpmpc.make_config(N, Q, R, QN, xmin, xmax, scenarios.UMIN, scenarios.UMAX, 4.0, 0.12, max_batch=B)
+    h = mpmpc.Handle(cfg)
+    h.set_path(track.kappa, track.v_ref, track.ds_next)
+    sol = h.solve(sc.wp_id, sc.x0, cc, lb, ub)
+    ocfg = OC.mpc_cfg(N, (Q, R, QN), scenarios.UMIN, scenarios.UMAX, xmin, xmax, 4.0, 0.12)
+    ref = OC.mpc_batch(ocfg, OC.settings(), track.kappa, track.v_ref, track.ds_next, sc.wp_id, sc.x0, cc, lb, ub)
+    assert np.array_equal(sol.status, ref["status"]) and np.all(sol.status == 1)
+    assert np.max(np.abs(sol.u0 - ref["u0"])) <= 1e-6
+    h.close()
+
+
+@pytest.mark.parametrize("cfgid,B", [(3, 512), (4, 4096)])
+def test_full_batches_against_c_oracle(cfgid, B, track):
+    """Large samples of configs 3 and 4 (incl. the G=32 two-instances-per-wave kernel at B=4096)
+    against the C port of the oracle: every status, every control."""
+    import oracle_c as OC
+    sc = scenarios.make(cfgid, track, B=B)
+    h = _handle(track, sc.N, sc.weights, B)
+    sol = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    ocfg = OC.mpc_cfg(sc.N, scenarios.WEIGHTS[sc.weights], scenarios.UMIN, scenarios.UMAX, scenarios.XMIN,
+                      scenarios.XMAX, 4.0, 0.12)
+    ref = OC.mpc_batch(ocfg, OC.settings(), track.kappa, track.v_ref, track.ds_next, sc.wp_id, sc.x0, sc.cc_prev,
+                       sc.lb, sc.ub)
+    assert np.mean(sol.status == ref["status"]) >= 0.999
+    both = (sol.status == 1) & (ref["status"] == 1)
+    assert both.mean() > 0.85
+    assert np.max(np.abs(sol.u0[both] - ref["u0"][both])) <= 1e-6
+    h.close()
+
+
+def test_open_path_end_is_an_error(track):
+    cfg = T.stock_config(30, max_batch=2, circular=False)
+    h = mpmpc.Handle(cfg)
+    h.set_path(track.kappa, track.v_ref, track.ds_next)
+    with pytest.raises(mpmpc.MpmpcError, match="Reached end of path"):
+        h.solve(np.array([180], np.int32), np.zeros((1, 3)), np.zeros((1, 60)), np.zeros((1, 30)), np.zeros((1, 30)))
+    ok = h.solve(np.array([100], np.int32), np.zeros((1, 3)), np.zeros((1, 60)), np.full((1, 30), -0.1),
+                 np.full((1, 30), 0.1))
+    assert ok.status[0] == 1
+    h.close()
