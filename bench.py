@@ -150,7 +150,7 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "config%d: batch=%d independent poses per GPU, %s weights, N=%d, %s corridor, "
-                                   "OSQP-default ADMM + certified polish" %
+                                   "OSQP-default ADMM, certified polish tried after 25 iterations" %
                                    (args.config, B, sc_all.weights, N, "obstacle" if sc_all.obstacles else "free"),
                        "batch_per_gpu": B, "horizon": N, "parallelism": "batch-shard x%d" % world},
         }

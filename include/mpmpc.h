@@ -75,6 +75,9 @@ typedef struct {
   double as_delta;
   int32_t as_refine, as_rounds;
   double cert_tol;
+  int32_t early_polish; /* > 0: try the polish after this many ADMM iterations; instances it cannot certify
+                           run the full ADMM (to max_iter / termination / infeasibility) and are polished
+                           again.  0: polish only after ADMM has terminated (OSQP's order). */
 } mpmpc_settings;
 
 const char* mpmpc_version(void);

@@ -592,23 +592,33 @@ struct Solver {
     for (int i = 0; i < 3; ++i) Eeq[i] = L::cold_get(15 + i);
   }
 
-  MPMPC_HD void admm(const mpmpc_settings& st) {
+  // Cold-started ADMM on the instances selected by `which`, at most `limit` iterations.  Instances
+  // still running at the limit (only possible when limit < max_iter) keep status UNSOLVED.
+  MPMPC_HD void admm(const mpmpc_settings& st, const Mk& which, int limit) {
+    const R zero(0.0);
     MPMPC_UNROLL
-    for (int j = 0; j < 5; ++j) { x[j] = zb[j] = yb[j] = xprev[j] = dyb[j] = R(0.0); }
+    for (int j = 0; j < 5; ++j) {
+      x[j] = keep(which, zero, x[j]); zb[j] = keep(which, zero, zb[j]); yb[j] = keep(which, zero, yb[j]);
+      xprev[j] = keep(which, zero, xprev[j]); dyb[j] = keep(which, zero, dyb[j]);
+    }
     MPMPC_UNROLL
-    for (int i = 0; i < 3; ++i) { zeq[i] = yeq[i] = dyeq[i] = R(0.0); }
-    status = I(MPMPC_UNSOLVED);
-    iters = I(0);
-    ipm_iters = I(0);
-    polished = I(0);
+    for (int i = 0; i < 3; ++i) {
+      zeq[i] = keep(which, zero, zeq[i]); yeq[i] = keep(which, zero, yeq[i]); dyeq[i] = keep(which, zero, dyeq[i]);
+    }
+    status = keepi(which, I(MPMPC_UNSOLVED), status);
+    iters = keepi(which, I(0), iters);
+    ipm_iters = keepi(which, I(0), ipm_iters);
+    polished = keepi(which, I(0), polished);
     set_rho(R(st.rho));
     admm_factor(st.sigma);
     const R alpha(st.alpha), oma(1.0 - st.alpha), sigma(st.sigma);
-    Mk active = live;
+    Mk active = which;
+    const bool full = limit >= st.max_iter;
+    if (limit > st.max_iter) limit = st.max_iter;
     Info nf;
     info(nf);
     park_check_data();
-    for (int it = 1; it <= st.max_iter; ++it) {
+    for (int it = 1; it <= limit; ++it) {
       if (!L::wany(active)) break;
       // ---- one ADMM step (OSQP update_xz_tilde / update_x / update_z / update_y)
       R rx[5], req[3], xt[5], nu[3];
@@ -665,7 +675,7 @@ struct Solver {
     }
     unpark_check_data();
     // ---- ran out of iterations: OSQP's final exact, then approximate, check
-    if (L::wany(active)) {
+    if (full && L::wany(active)) {
       info(nf);
       I s1 = check(nf, st, false);
       I s2 = check(nf, st, true);
@@ -673,8 +683,8 @@ struct Solver {
       status = seli(active, fin, status);
     }
     info(nf);
-    pri_res = nf.pri;
-    dua_res = nf.dua;
+    pri_res = keep(which, nf.pri, pri_res);
+    dua_res = keep(which, nf.dua, dua_res);
   }
 
   // ======================================================================== certified polish
@@ -957,12 +967,17 @@ struct Solver {
     c = L::cold_get(36);
   }
 
-  MPMPC_HD void polish(const mpmpc_settings& st) {
-    Mk run = live & ((status == MPMPC_SOLVED) | (status == MPMPC_SOLVED_INACCURATE) | (status == MPMPC_MAX_ITER_REACHED));
+  // `early`: also polish instances whose ADMM was stopped before it terminated (status UNSOLVED);
+  // those keep UNSOLVED when the polish cannot certify them, so the caller can resume ADMM.
+  MPMPC_HD void polish(const mpmpc_settings& st, bool early) {
+    Mk run = live & (polished != 1) &
+             ((status == MPMPC_SOLVED) | (status == MPMPC_SOLVED_INACCURATE) | (status == MPMPC_MAX_ITER_REACHED));
+    Mk unsolved = live & (status == MPMPC_UNSOLVED);
+    if (early) run = run | unsolved;
     if (!L::wany(run)) return;
     Box bx;
     make_box(bx);
-    const R theta(1e-3), zero(0.0), one(1.0);
+    const R theta(3e-3), zero(0.0), one(1.0);   // floor of the warm-started slacks / multipliers
     Ipm s;
     MPMPC_UNROLL
     for (int i = 0; i < 3; ++i) s.nu[i] = yeq[i];
@@ -1011,6 +1026,7 @@ struct Solver {
     }
     // whatever is left could not be certified: keep the ADMM iterate, flag it
     Mk failed = run & (polished != 1);
+    if (early) failed = failed & !unsolved;      // an uncertified early attempt is not a verdict
     status = seli(failed, I(MPMPC_SOLVED_INACCURATE), status);
     polished = seli(failed, I(-1), polished);
   }
@@ -1049,8 +1065,21 @@ struct Solver {
   MPMPC_HD void run(const double* qp, int B, int ld, const I& inst, const I& k, int N_, const mpmpc_settings& st) {
     load(qp, B, ld, inst, k, N_);
     scale(st.scaling);
-    admm(st);
-    if (st.polish) polish(st);
+    if (st.polish && st.early_polish > 0 && st.early_polish < st.max_iter) {
+      // The polish does not need a converged ADMM point, only a reasonable one: try it after
+      // `early_polish` iterations.  Whatever it cannot certify (infeasible or very hard instances)
+      // goes through the full OSQP iteration from a cold start, exactly as without the shortcut.
+      admm(st, live, st.early_polish);
+      polish(st, true);
+      Mk redo = live & (status == MPMPC_UNSOLVED);
+      if (L::wany(redo)) {
+        admm(st, redo, st.max_iter);
+        polish(st, false);
+      }
+    } else {
+      admm(st, live, st.max_iter);
+      if (st.polish) polish(st, false);
+    }
   }
 };
 

@@ -81,6 +81,7 @@ class Settings:
     as_refine: int = 5
     as_rounds: int = 4
     cert_tol: float = 1e-8
+    early_polish: int = 25      # polish=2 only: try the polish after this many ADMM iterations (0 = off)
 
 
 @dataclasses.dataclass
@@ -215,6 +216,14 @@ def solve(P, q, A, l, u, settings: Settings | None = None, trace=None) -> Result
             status = _check(w, info, dx, dy, st, approximate=False)
             if status != UNSOLVED:
                 break
+        if st.polish == 2 and it == st.early_polish and st.early_polish < st.max_iter:
+            # the polish only needs a reasonable starting point: try it now; if it cannot certify,
+            # the ADMM iteration simply goes on
+            early = Result(None, None, UNSOLVED, it, 0.0, 0.0, 0.0, 0, rho_updates, w.rho)
+            if _certified_polish(w, x, y, st, early):
+                xa, ya = w.unscale(x, y)
+                early.x_admm, early.y_admm = xa, ya
+                return early
         if st.adaptive_rho and st.adaptive_rho_interval and it % st.adaptive_rho_interval == 0:
             if not can_check:
                 info = _info(w, x, z, y)
@@ -251,6 +260,16 @@ def solve(P, q, A, l, u, settings: Settings | None = None, trace=None) -> Result
                 res.polished = -1
         return res
     # polish == 2: interior-point refinement + active-set iterations + certificate
+    if not _certified_polish(w, x, y, st, res):
+        # not certified (typically a marginally infeasible problem that ADMM at a loose eps calls
+        # solved): hand back the ADMM iterate, as stock OSQP would, flagged inaccurate
+        res.polished, res.status = -1, SOLVED_INACCURATE
+    return res
+
+
+def _certified_polish(w, x, y, st, res) -> bool:
+    """Interior-point refinement from the scaled point (x, y), iterated active-set solve, KKT
+    certificate.  On success writes the certified point into `res` and returns True."""
     ipm_tol = st.ipm_tol
     xi, yi = x, y
     for attempt in range(2):
@@ -266,12 +285,9 @@ def solve(P, q, A, l, u, settings: Settings | None = None, trace=None) -> Result
             if cert["ok_tol"](st.cert_tol):
                 res.x, res.y, res.polished, res.status = xs, ys, 1, SOLVED
                 res.pri_res, res.dua_res, res.obj = cert["prim"], cert["stat"], cert["obj"]
-                return res
+                return True
         ipm_tol *= 1e-4
-    # not certified (typically a marginally infeasible problem that ADMM at a loose eps calls
-    # solved): hand back the ADMM iterate, as stock OSQP would, flagged inaccurate
-    res.polished, res.status = -1, SOLVED_INACCURATE
-    return res
+    return False
 
 
 def _obj(w, xs):
@@ -390,7 +406,7 @@ def _row_classes(w: Workspace):
     return eq, L, U
 
 
-def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=1e-3):
+def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3):
     n, m = w.n, w.m
     eq, L, U = _row_classes(w)
     beq = w.l

@@ -43,6 +43,7 @@ typedef struct {
   double ipm_tol, ipm_reg, as_delta;
   int32_t as_refine, as_rounds;
   double cert_tol;
+  int32_t early_polish;
 } oracle_settings;
 
 typedef struct {
@@ -481,7 +482,7 @@ typedef struct { int *eq, *L, *U; } classes_t;
 static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double* x, double* y, double tol, int* iters_out, int* low, int* upp) {
   const oracle_settings* st = w->st;
   int n = w->n, m = w->m, N = n + m;
-  const double theta = 1e-3, reg = st->ipm_reg;
+  const double theta = 3e-3, reg = st->ipm_reg;
   double *Ax = (double*)malloc(sizeof(double) * m), *nu = (double*)calloc(m, sizeof(double));
   double *sl = (double*)malloc(sizeof(double) * m), *su = (double*)malloc(sizeof(double) * m);
   double *zl = (double*)malloc(sizeof(double) * m), *zu = (double*)malloc(sizeof(double) * m);
@@ -666,6 +667,48 @@ static int active_set_polish(work_t* w, const classes_t* cl, int* low, int* upp,
   return ok;
 }
 
+/* polish = 2: interior-point refinement from the scaled point (x, y), iterated active-set solve,
+ * KKT certificate.  On success writes the certified (unscaled) point and returns 1. */
+static int certified_polish(work_t* w, const double* x, const double* y, double* x_out, double* y_out, oracle_info* info) {
+  const oracle_settings* st = w->st;
+  int n = w->n, m = w->m;
+  classes_t cl; cl.eq = (int*)malloc(sizeof(int) * m); cl.L = (int*)malloc(sizeof(int) * m); cl.U = (int*)malloc(sizeof(int) * m);
+  for (int r = 0; r < m; ++r) {
+    int fl = w->l[r] > -INF_BOUND, fu = w->u[r] < INF_BOUND;
+    cl.eq[r] = fl && fu && (w->u[r] - w->l[r] <= 1e-12 * dmax(1.0, fabs(w->l[r])));
+    cl.L[r] = fl && !cl.eq[r]; cl.U[r] = fu && !cl.eq[r];
+  }
+  int *low = (int*)calloc(m, sizeof(int)), *upp = (int*)calloc(m, sizeof(int));
+  double *xi = (double*)malloc(sizeof(double) * n), *yi = (double*)malloc(sizeof(double) * m);
+  double *xa = (double*)malloc(sizeof(double) * n), *ya = (double*)malloc(sizeof(double) * m);
+  double *xs = (double*)malloc(sizeof(double) * n), *ys = (double*)malloc(sizeof(double) * m);
+  memcpy(xi, x, sizeof(double) * n); memcpy(yi, y, sizeof(double) * m);
+  double tol = st->ipm_tol;
+  int good = 0;
+  for (int attempt = 0; attempt < 2 && !good; ++attempt) {
+    int nit = 0;
+    int conv = ipm_refine(w, w->K, w->F, &cl, xi, yi, tol, &nit, low, upp);
+    info->ipm_iters += nit;
+    if (!conv) break;
+    int rounds = 0;
+    int okm = active_set_polish(w, &cl, low, upp, xa, ya, &rounds);
+    info->as_rounds += rounds;
+    if (okm) {
+      for (int j = 0; j < n; ++j) xs[j] = w->D[j] * xa[j];
+      for (int r = 0; r < m; ++r) ys[r] = w->E[r] * ya[r] * w->cinv;
+      double pv, sv;
+      if (certificate(w, xs, ys, st->cert_tol, &pv, &sv)) {
+        memcpy(x_out, xs, sizeof(double) * n); memcpy(y_out, ys, sizeof(double) * m);
+        info->status = SOLVED; info->polished = 1; info->pri_res = pv; info->dua_res = sv;
+        good = 1;
+      }
+    }
+    tol *= 1e-4;
+  }
+  free(cl.eq); free(cl.L); free(cl.U); free(low); free(upp); free(xi); free(yi); free(xa); free(ya); free(xs); free(ys);
+  return good;
+}
+
 /* ------------------------------------------------------------------ the solver */
 int oracle_solve_csc(int n, int m, const int* Pp, const int* Pi, const double* Px, const double* q, const int* Ap, const int* Ai,
                      const double* Ax_, const double* l, const double* u, const oracle_settings* st, const int* perm_in,
@@ -701,7 +744,7 @@ int oracle_solve_csc(int n, int m, const int* Pp, const int* Pi, const double* P
   double *tn = (double*)malloc(sizeof(double) * n), *tm = (double*)malloc(sizeof(double) * m);
   info_t o; o.Ax = (double*)malloc(sizeof(double) * m); o.Px = (double*)malloc(sizeof(double) * n); o.Aty = (double*)malloc(sizeof(double) * n);
   o.rp = (double*)malloc(sizeof(double) * m); o.rd = (double*)malloc(sizeof(double) * n);
-  int status = UNSOLVED, it = 0, rho_updates = 0;
+  int status = UNSOLVED, it = 0, rho_updates = 0, early_done = 0, early_ipm = 0, early_as = 0;
   compute_info(&w, x, z, y, &o);
   const double alpha = st->alpha;
   while (it < st->max_iter) {
@@ -722,6 +765,13 @@ int oracle_solve_csc(int n, int m, const int* Pp, const int* Pi, const double* P
     int can_adapt = st->adaptive_rho && st->adaptive_rho_interval > 0 && it % st->adaptive_rho_interval == 0;
     if (can_check || can_adapt) compute_info(&w, x, z, y, &o);
     if (can_check) { status = check_termination(&w, &o, z, dx, dy, 0, tn, tm); if (status != UNSOLVED) break; }
+    if (st->polish == 2 && it == st->early_polish && st->early_polish < st->max_iter) {
+      /* the polish only needs a reasonable starting point: try it now; if it cannot certify, ADMM goes on */
+      info->status = UNSOLVED; info->iters = it; info->rho_updates = rho_updates; info->ipm_iters = 0; info->as_rounds = 0; info->polished = 0;
+      if (certified_polish(&w, x, y, x_out, y_out, info)) { early_done = 1; break; }
+      /* the interior point re-used the KKT workspace: restore the ADMM factorisation */
+      kkt_fill_and_factor(&w, w.K, w.F, st->sigma, w.rho_inv, m);
+    }
     if (can_adapt) {
       double pr = ninf(o.rp, m) / (dmax(ninf(z, m), ninf(o.Ax, m)) + 1e-10);
       double du = ninf(o.rd, n) / (dmax(dmax(ninf(w.q, n), ninf(o.Aty, n)), ninf(o.Px, n)) + 1e-10);
@@ -733,6 +783,8 @@ int oracle_solve_csc(int n, int m, const int* Pp, const int* Pi, const double* P
       }
     }
   }
+  if (early_done) goto finish;
+  early_ipm = info->ipm_iters; early_as = info->as_rounds;
   if (status == UNSOLVED) {
     compute_info(&w, x, z, y, &o);
     status = check_termination(&w, &o, z, dx, dy, 0, tn, tm);
@@ -743,45 +795,14 @@ int oracle_solve_csc(int n, int m, const int* Pp, const int* Pi, const double* P
   for (int j = 0; j < n; ++j) x_out[j] = w.D[j] * x[j];
   for (int r = 0; r < m; ++r) y_out[r] = w.E[r] * y[r] * w.cinv;
   info->status = status; info->iters = it; info->rho_updates = rho_updates; info->pri_res = o.pri; info->dua_res = o.dua;
-  info->ipm_iters = 0; info->as_rounds = 0; info->polished = 0;
+  info->ipm_iters = st->polish == 2 && st->early_polish > 0 && it > st->early_polish ? early_ipm : 0;
+  info->as_rounds = st->polish == 2 && st->early_polish > 0 && it > st->early_polish ? early_as : 0;
+  info->polished = 0;
 
   if (st->polish == 2 && (status == SOLVED || status == SOLVED_INACCURATE || status == MAX_ITER_REACHED)) {
-    classes_t cl; cl.eq = (int*)malloc(sizeof(int) * m); cl.L = (int*)malloc(sizeof(int) * m); cl.U = (int*)malloc(sizeof(int) * m);
-    for (int r = 0; r < m; ++r) {
-      int fl = w.l[r] > -INF_BOUND, fu = w.u[r] < INF_BOUND;
-      cl.eq[r] = fl && fu && (w.u[r] - w.l[r] <= 1e-12 * dmax(1.0, fabs(w.l[r])));
-      cl.L[r] = fl && !cl.eq[r]; cl.U[r] = fu && !cl.eq[r];
-    }
-    int *low = (int*)calloc(m, sizeof(int)), *upp = (int*)calloc(m, sizeof(int));
-    double *xi = (double*)malloc(sizeof(double) * n), *yi = (double*)malloc(sizeof(double) * m);
-    double *xa = (double*)malloc(sizeof(double) * n), *ya = (double*)malloc(sizeof(double) * m);
-    double *xs = (double*)malloc(sizeof(double) * n), *ys = (double*)malloc(sizeof(double) * m);
-    memcpy(xi, x, sizeof(double) * n); memcpy(yi, y, sizeof(double) * m);
-    double tol = st->ipm_tol;
-    int good = 0;
-    for (int attempt = 0; attempt < 2 && !good; ++attempt) {
-      int nit = 0;
-      int conv = ipm_refine(&w, w.K, w.F, &cl, xi, yi, tol, &nit, low, upp);
-      info->ipm_iters += nit;
-      if (!conv) break;
-      int rounds = 0;
-      int okm = active_set_polish(&w, &cl, low, upp, xa, ya, &rounds);
-      info->as_rounds += rounds;
-      if (okm) {
-        for (int j = 0; j < n; ++j) xs[j] = w.D[j] * xa[j];
-        for (int r = 0; r < m; ++r) ys[r] = w.E[r] * ya[r] * w.cinv;
-        double pv, sv;
-        if (certificate(&w, xs, ys, st->cert_tol, &pv, &sv)) {
-          memcpy(x_out, xs, sizeof(double) * n); memcpy(y_out, ys, sizeof(double) * m);
-          info->status = SOLVED; info->polished = 1; info->pri_res = pv; info->dua_res = sv;
-          good = 1;
-        }
-      }
-      tol *= 1e-4;
-    }
-    if (!good) { info->status = SOLVED_INACCURATE; info->polished = -1; }
-    free(cl.eq); free(cl.L); free(cl.U); free(low); free(upp); free(xi); free(yi); free(xa); free(ya); free(xs); free(ys);
+    if (!certified_polish(&w, x, y, x_out, y_out, info)) { info->status = SOLVED_INACCURATE; info->polished = -1; }
   }
+finish:
   /* objective of the returned point */
   { double* g = (double*)malloc(sizeof(double) * n); sym_mul(&P0, x_out, g); double ob = 0; for (int j = 0; j < n; ++j) ob += 0.5 * x_out[j] * g[j] + q[j] * x_out[j]; info->obj = ob; free(g); }
   free(x); free(z); free(y); free(xp); free(zp); free(dx); free(dy); free(rhs); free(sol); free(tn); free(tm);
