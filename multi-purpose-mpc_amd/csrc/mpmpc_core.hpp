@@ -1065,20 +1065,21 @@ struct Solver {
   MPMPC_HD void run(const double* qp, int B, int ld, const I& inst, const I& k, int N_, const mpmpc_settings& st) {
     load(qp, B, ld, inst, k, N_);
     scale(st.scaling);
-    if (st.polish && st.early_polish > 0 && st.early_polish < st.max_iter) {
-      // The polish does not need a converged ADMM point, only a reasonable one: try it after
-      // `early_polish` iterations.  Whatever it cannot certify (infeasible or very hard instances)
-      // goes through the full OSQP iteration from a cold start, exactly as without the shortcut.
-      admm(st, live, st.early_polish);
-      polish(st, true);
-      Mk redo = live & (status == MPMPC_UNSOLVED);
-      if (L::wany(redo)) {
-        admm(st, redo, st.max_iter);
-        polish(st, false);
-      }
-    } else {
-      admm(st, live, st.max_iter);
-      if (st.polish) polish(st, false);
+    // The polish does not need a converged ADMM point, only a reasonable one: with early_polish > 0
+    // it is first tried after that many iterations.  Whatever it cannot certify (infeasible or very
+    // hard instances) goes through the full OSQP iteration from a cold start, exactly as without
+    // the shortcut, and is polished again.  One loop, so admm() / polish() are instantiated once.
+    bool early = st.polish && st.early_polish > 0 && st.early_polish < st.max_iter;
+    int limit = early ? st.early_polish : st.max_iter;
+    Mk which = live;
+    _Pragma("nounroll")
+    for (int pass = 0; pass < 2; ++pass) {
+      admm(st, which, limit);
+      if (st.polish) polish(st, early);
+      which = live & (status == MPMPC_UNSOLVED);
+      if (!early || !L::wany(which)) break;
+      early = false;
+      limit = st.max_iter;
     }
   }
 };

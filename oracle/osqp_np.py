@@ -76,7 +76,7 @@ class Settings:
     # polish=2 parameters
     ipm_tol: float = 1e-9
     ipm_reg: float = 1e-8
-    ipm_max_iter: int = 50
+    ipm_max_iter: int = 30
     as_delta: float = 1e-9
     as_refine: int = 5
     as_rounds: int = 4
