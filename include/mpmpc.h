@@ -102,6 +102,23 @@ int mpmpc_set_path(mpmpc_handle h, int32_t n_wp, const double* kappa, const doub
 int mpmpc_set_corridor(mpmpc_handle h, int32_t n_wp, int32_t n_cols, const double* ub,
                        const double* lb);
 
+/* Device-side corridor generation: the three calls below replace, for a map that
+ * changes between steps, the host loop of ReferencePath.update_path_constraints + _compute_free_segments
+ * + skimage.draw.line_aa + Map.w2m/m2w (src/reference_path.py:466-648, src/map.py:77-101).
+ *   mpmpc_set_map           Map.data (int8, 1 free / 0 occupied, row = y), Map.origin, Map.resolution
+ *   mpmpc_set_path_geometry per-waypoint x, y, psi and Waypoint.static_border_cells (world coordinates,
+ *                           [n_wp*2] each: upper/left border, lower/right border); needs mpmpc_set_path first
+ *   mpmpc_build_corridor    update_path_constraints(w+1, n_cols, min_width, safety_margin) for EVERY start
+ *                           waypoint w, written into the handle's corridor table (as mpmpc_set_corridor would)
+ *                           and optionally copied out ([n_wp x n_cols]; rows whose first horizon waypoint has no
+ *                           free segment - the reference raises there - are NaN).  *bad_rows counts those. */
+int mpmpc_set_map(mpmpc_handle h, int32_t height, int32_t width, const int8_t* data, double origin_x,
+                  double origin_y, double resolution);
+int mpmpc_set_path_geometry(mpmpc_handle h, int32_t n_wp, const double* x, const double* y, const double* psi,
+                            const double* border_ub, const double* border_lb);
+int mpmpc_build_corridor(mpmpc_handle h, int32_t n_cols, double min_width, double safety_margin, double* ub_out,
+                         double* lb_out, int32_t* bad_rows);
+
 /* replaces MPC._init_problem (src/MPC.py:61-155) for B instances: LTV linearisation
  * (src/spatial_bicycle_models.py:391-417) around waypoints wp_id+0..N-1, offsets, speed cap from
  * the previous plan cc_prev (src/MPC.py:86-87,111-113), box bounds, references, cost vectors.

@@ -152,8 +152,27 @@ class BatchMPC:
             raise RuntimeError("reference path has no speed profile (call compute_speed_profile first)")
         self.handle.set_path(kappa, v_ref, ds)
         self._path = model.reference_path
-        if corridor is not None:          # (ub, lb) tables [n_wp x >=N] of a static map
+        self.corridor_cols = None
+        if isinstance(corridor, str) and corridor == "device":
+            self.update_corridor_from_map()
+        elif corridor is not None:        # (ub, lb) tables [n_wp x >=N] of a static map
             self.handle.set_corridor(*corridor)
+
+    def update_corridor_from_map(self, n_cols=None):
+        """(Re)build the corridor table on the device from the path's map as it is NOW (obstacles
+        added since the last call included): update_path_constraints(w + 1, n_cols, 2*sm, sm) for every
+        start waypoint w (src/MPC.py:116-118, src/reference_path.py:522-648), without leaving the GPU.
+        Returns the number of start waypoints whose first horizon waypoint is fully blocked."""
+        rp, m = self._path, self._path.map
+        n_cols = int(n_cols or self.N)
+        wps = rp.waypoints
+        self.handle.set_map(m.data, m.origin, m.resolution)
+        self.handle.set_path_geometry([w.x for w in wps], [w.y for w in wps], [w.psi for w in wps],
+                                      [w.static_border_cells[0] for w in wps], [w.static_border_cells[1] for w in wps])
+        sm = self.model.safety_margin
+        _, _, bad = self.handle.build_corridor(n_cols, 2 * sm, sm, want_tables=False)
+        self.corridor_cols = n_cols
+        return bad
 
     def spatial_states(self, s, poses):
         """(wp_id[B], x0[B,3]) from arc lengths and world poses, as get_control does per car."""

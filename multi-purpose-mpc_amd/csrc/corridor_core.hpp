@@ -1,0 +1,182 @@
+// Dynamic drivable corridor per waypoint (e_y bounds of the horizon), scalar per-thread code that
+// compiles for gfx950 (K0 kernels in mpmpc_hip.hip) and for the host (tests/emul, CPU check).
+//
+// Replaces, for every start waypoint of the path at once,
+//   ReferencePath.update_path_constraints(wp_id, N, min_width, safety_margin)   src/reference_path.py:522-648
+//   ReferencePath._compute_free_segments(wp, min_width)                         src/reference_path.py:466-520
+//   Map.w2m / Map.m2w                                                           src/map.py:77-101
+//   skimage.draw.line_aa (third party, compiled only): Zingl's anti-aliased line with the error
+//     term kept in float32; the ORDER of the produced cells matters to the segment scan.
+// Quirks reproduced, not fixed: the forward projection of the previous borders adds
+// delta_s*cos(psi) to BOTH coordinates of the upper border and delta_s*sin(psi) to both of the
+// lower one (src/reference_path.py:559-562).
+//
+// Work split: the rasterised border segment of a waypoint does not depend on where the horizon
+// starts, so phase 1 extracts the free segments once per waypoint (one thread each) and phase 2
+// walks the horizon for every start waypoint (one thread each), reading phase 1's lists.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#ifndef MPMPC_HD
+#define MPMPC_HD inline
+#endif
+
+namespace mpmpc {
+
+constexpr int COR_MAXSEG = 8;       // free segments kept per waypoint (Sim_Track needs at most 3)
+constexpr double COR_PI = 3.141592653589793;
+
+struct MapView {
+  const int8_t* data;   // [height x width], 1 free / 0 occupied
+  int height, width;
+  double ox, oy, res;
+};
+
+MPMPC_HD void cor_w2m(const MapView& m, double x, double y, int& dx, int& dy) {
+  dx = (int)std::floor((x - m.ox) / m.res);
+  dy = (int)std::floor((y - m.oy) / m.res);
+}
+MPMPC_HD void cor_m2w(const MapView& m, int dx, int dy, double& x, double& y) {
+  x = (dx + 0.5) * m.res + m.ox;
+  y = (dy + 0.5) * m.res + m.oy;
+}
+MPMPC_HD double cor_wrap(double a) {   // np.mod(a + pi, 2 pi) - pi  (result of np.mod has the divisor's sign)
+  double t = std::fmod(a + COR_PI, 2.0 * COR_PI);
+  if (t < 0.0) t += 2.0 * COR_PI;
+  return t - COR_PI;
+}
+MPMPC_HD double cor_sign(double a) { return a > 0.0 ? 1.0 : (a < 0.0 ? -1.0 : 0.0); }
+
+// Scans the anti-aliased line from the upper border cell (r0,c0) to the lower one (r1,c1) and calls
+// visit(r, c) for every produced cell in skimage's order, the start cell included.
+template <class F>
+MPMPC_HD void cor_line_aa(int r0, int c0, int r1, int c1, F visit) {
+  const int dc = c0 < c1 ? c1 - c0 : c0 - c1, dr = r0 < r1 ? r1 - r0 : r0 - r1;
+  float err = (float)(dc - dr);
+  const int sign_c = c0 < c1 ? 1 : -1, sign_r = r0 < r1 ? 1 : -1;
+  const float ed = (dc + dr == 0) ? 1.0f : (float)std::sqrt((double)(dc * dc + dr * dr));
+  const float fdc = (float)dc, fdr = (float)dr;
+  int c = c0, r = r0;
+  for (;;) {
+    visit(r, c);
+    const float ep = err;
+    const int cp = c;
+    if (2.0f * ep >= -fdc) {
+      if (c == c1) break;
+      if (ep + fdr < ed) visit(r + sign_r, c);
+      err = err - fdr;
+      c += sign_c;
+    }
+    if (2.0f * ep <= fdr) {
+      if (r == r1) break;
+      if (fdc - ep < ed) visit(r, cp + sign_c);
+      err = err + fdc;
+      r += sign_r;
+    }
+  }
+}
+
+// Phase 1, one waypoint: free runs of its border segment that are wider than min_width.
+// seg[4*s + {0,1,2,3}] = (ub_x, ub_y, lb_x, lb_y) of segment s in world coordinates.
+MPMPC_HD int cor_free_segments(const MapView& m, double bux, double buy, double blx, double bly, double min_width,
+                               double* seg) {
+  int ux, uy, lx, ly;
+  cor_w2m(m, bux, buy, ux, uy);
+  cor_w2m(m, blx, bly, lx, ly);
+  int count = 0;
+  int sx = ux, sy = uy;       // start cell of the current run
+  bool in_free = false, first = true;
+  cor_line_aa(ux, uy, lx, ly, [&](int x, int y) {
+    if (first) { first = false; return; }              // the reference skips the first cell (x_list[1:])
+    const bool is_free = m.data[(long)y * m.width + x] == 1;
+    if (is_free) in_free = true;
+    if ((!is_free || (x == lx && y == ly)) && in_free) {
+      double ax, ay, bx, by;
+      cor_m2w(m, sx, sy, ax, ay);
+      cor_m2w(m, x, y, bx, by);
+      const double len = std::sqrt((ax - bx) * (ax - bx) + (ay - by) * (ay - by));
+      if (len > min_width && count < COR_MAXSEG) {
+        seg[4 * count + 0] = ax; seg[4 * count + 1] = ay; seg[4 * count + 2] = bx; seg[4 * count + 3] = by;
+        ++count;
+      }
+      sx = x; sy = y;
+      in_free = false;
+    } else if (!is_free && !in_free) {
+      sx = x; sy = y;
+    }
+  });
+  return count;
+}
+
+struct PathGeom {
+  const double *x, *y, *psi, *ds_next;   // per waypoint; ds_next[i] = |wp[i+1] - wp[i]| (circular)
+  int n_wp;
+  int circular;
+};
+
+// Phase 2, one start waypoint `wp_id`: ub / lb for the n_cols waypoints wp_id .. wp_id+n_cols-1.
+// Returns false when the first horizon waypoint has no free segment (the reference raises there).
+MPMPC_HD bool cor_select(const PathGeom& g, const double* segs, const int* nseg, int wp_id, int n_cols,
+                         double safety_margin, double* ub_out, double* lb_out) {
+  double prev_ux = 0, prev_uy = 0, prev_lx = 0, prev_ly = 0;
+  for (int n = 0; n < n_cols; ++n) {
+    int i = wp_id + n;
+    if (i >= g.n_wp) i = g.circular ? i % g.n_wp : g.n_wp - 1;
+    const double wx = g.x[i], wy = g.y[i], wpsi = g.psi[i];
+    const double* s = segs + (long)i * 4 * COR_MAXSEG;
+    const int cnt = nseg[i];
+    double pux, puy, plx, ply;
+    if (n == 0) {
+      if (cnt == 0) return false;
+      int best = 0;
+      double best_len = -1.0;
+      for (int k = 0; k < cnt; ++k) {
+        const double dx = s[4 * k] - s[4 * k + 2], dy = s[4 * k + 1] - s[4 * k + 3];
+        const double len = std::sqrt(dx * dx + dy * dy);
+        if (len > best_len) { best_len = len; best = k; }
+      }
+      pux = s[4 * best]; puy = s[4 * best + 1]; plx = s[4 * best + 2]; ply = s[4 * best + 3];
+    } else {
+      int ip = wp_id + n - 1;
+      if (ip >= g.n_wp) ip = g.circular ? ip % g.n_wp : g.n_wp - 1;
+      const double shift = g.ds_next[ip];            // wp_prev - wp (distance)
+      const double cp = std::cos(g.psi[ip]), sp = std::sin(g.psi[ip]);
+      const double qux = prev_ux + shift * cp, quy = prev_uy + shift * cp;
+      const double qlx = prev_lx + shift * sp, qly = prev_ly + shift * sp;
+      if (cnt >= 2) {
+        int best = 0;
+        double best_off = 0.0;
+        for (int k = 0; k < cnt; ++k) {
+          const double du = std::sqrt((s[4 * k] - qux) * (s[4 * k] - qux) + (s[4 * k + 1] - quy) * (s[4 * k + 1] - quy));
+          const double dl = std::sqrt((s[4 * k + 2] - qlx) * (s[4 * k + 2] - qlx) + (s[4 * k + 3] - qly) * (s[4 * k + 3] - qly));
+          const double off = (du + dl) / 2;
+          if (k == 0 || off < best_off) { best_off = off; best = k; }
+        }
+        pux = s[4 * best]; puy = s[4 * best + 1]; plx = s[4 * best + 2]; ply = s[4 * best + 3];
+      } else if (cnt == 1) {
+        pux = s[0]; puy = s[1]; plx = s[2]; ply = s[3];
+      } else {
+        pux = wx; puy = wy; plx = wx; ply = wy;
+      }
+    }
+    const double su = cor_sign(cor_wrap(std::atan2(puy - wy, pux - wx) - wpsi));
+    const double sl = cor_sign(cor_wrap(std::atan2(ply - wy, plx - wx) - wpsi));
+    double ub = su * std::sqrt((pux - wx) * (pux - wx) + (puy - wy) * (puy - wy));
+    double lb = sl * std::sqrt((plx - wx) * (plx - wx) + (ply - wy) * (ply - wy));
+    ub -= safety_margin;
+    lb += safety_margin;
+    if (ub < lb) { ub = 0.0; lb = 0.0; }
+    ub_out[n] = ub;
+    lb_out[n] = lb;
+    // border cells of the selected segment WITHOUT the margin, projected onto the normal of the waypoint
+    const double au = cor_wrap(COR_PI / 2 + wpsi), al = cor_wrap(-COR_PI / 2 + wpsi);
+    prev_ux = wx + (ub + safety_margin) * std::cos(au);
+    prev_uy = wy + (ub + safety_margin) * std::sin(au);
+    prev_lx = wx - (lb - safety_margin) * std::cos(al);
+    prev_ly = wy - (lb - safety_margin) * std::sin(al);
+  }
+  return true;
+}
+
+}  // namespace mpmpc

@@ -22,6 +22,7 @@
 #define MPMPC_HD __device__ __forceinline__
 #include "lane_gpu.hpp"
 #include "mpmpc_core.hpp"
+#include "corridor_core.hpp"
 
 using namespace mpmpc;
 
@@ -69,6 +70,34 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, mpmpc
   s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y);
 }
 
+// K0a: free segments of every waypoint's border line (one thread per waypoint; the rasterised line
+// is at most a few hundred cells, the grid is read through L2).
+__global__ __launch_bounds__(64) void mpmpc_free_segments_kernel(MapView map, int n_wp, const double* __restrict__ bub,
+                                                                 const double* __restrict__ blb, double min_width,
+                                                                 double* __restrict__ segs, int* __restrict__ nseg) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n_wp) return;
+  double seg[4 * COR_MAXSEG];
+  const int cnt = cor_free_segments(map, bub[2 * i], bub[2 * i + 1], blb[2 * i], blb[2 * i + 1], min_width, seg);
+  for (int k = 0; k < 4 * COR_MAXSEG; ++k) segs[(long)i * 4 * COR_MAXSEG + k] = k < 4 * cnt ? seg[k] : 0.0;
+  nseg[i] = cnt;
+}
+
+// K0b: horizon walk for every start waypoint w (table row w = update_path_constraints(w + 1, ...)).
+__global__ __launch_bounds__(64) void mpmpc_corridor_select_kernel(PathGeom g, const double* __restrict__ segs,
+                                                                   const int* __restrict__ nseg, int n_cols,
+                                                                   double safety_margin, double* __restrict__ ub_tab,
+                                                                   double* __restrict__ lb_tab, int* __restrict__ bad) {
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  if (w >= g.n_wp) return;
+  double* ub = ub_tab + (long)w * n_cols;
+  double* lb = lb_tab + (long)w * n_cols;
+  if (!cor_select(g, segs, nseg, w + 1, n_cols, safety_margin, ub, lb)) {
+    for (int n = 0; n < n_cols; ++n) { ub[n] = __builtin_nan(""); lb[n] = __builtin_nan(""); }
+    atomicAdd(bad, 1);
+  }
+}
+
 // ------------------------------------------------------------------------------------ host side
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -91,6 +120,13 @@ struct mpmpc_handle_s {
   // tables
   double *kappa = nullptr, *v_ref = nullptr, *ds_next = nullptr, *ub_tab = nullptr, *lb_tab = nullptr;
   int n_wp = 0, n_cols = 0;
+  // corridor generation on the device: grid, per-waypoint geometry, per-waypoint free segments
+  int8_t* map = nullptr;
+  int map_h = 0, map_w = 0;
+  double map_ox = 0, map_oy = 0, map_res = 0;
+  double *gx = nullptr, *gy = nullptr, *gpsi = nullptr, *bub = nullptr, *blb = nullptr, *segs = nullptr;
+  int *nseg = nullptr, *bad = nullptr;
+  int geom_n = 0;
   // per-batch inputs
   int* wp_id = nullptr;
   double *x0 = nullptr, *cc = nullptr, *lb = nullptr, *ub = nullptr;
@@ -150,8 +186,9 @@ int32_t mpmpc_stage_ld(int32_t N) { return host_stage_ld(N); }
 int mpmpc_destroy(mpmpc_handle h) {
   if (!h) return MPMPC_OK;
   (void)hipSetDevice(h->cfg.device);
-  void* ptrs[] = {h->kappa, h->v_ref, h->ds_next, h->ub_tab, h->lb_tab, h->wp_id, h->x0, h->cc, h->lb,
-                  h->ub,    h->qp,    h->z,       h->u0,     h->resid,  h->y,     h->status, h->iters};
+  void* ptrs[] = {h->kappa, h->v_ref, h->ds_next, h->ub_tab, h->lb_tab, h->wp_id, h->x0,  h->cc,   h->lb,  h->ub,
+                  h->qp,    h->z,     h->u0,      h->resid,  h->y,      h->status, h->iters, h->map, h->gx,  h->gy,
+                  h->gpsi,  h->bub,   h->blb,     h->segs,   h->nseg,   h->bad};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& e : h->ev)
@@ -260,6 +297,72 @@ int mpmpc_set_corridor(mpmpc_handle h, int32_t n_wp, int32_t n_cols, const doubl
   if (int rc = upload_table(h, &h->ub_tab, ub, (size_t)n_wp * n_cols)) return rc;
   if (int rc = upload_table(h, &h->lb_tab, lb, (size_t)n_wp * n_cols)) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
+  h->n_cols = n_cols;
+  return MPMPC_OK;
+}
+
+int mpmpc_set_map(mpmpc_handle h, int32_t height, int32_t width, const int8_t* data, double origin_x,
+                  double origin_y, double resolution) {
+  if (!h || !data) return fail(MPMPC_E_ARG, "NULL argument");
+  if (height < 1 || width < 1 || !(resolution > 0)) return fail(MPMPC_E_ARG, "map needs positive size and resolution");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (h->map) { HIP_TRY(hipFree(h->map)); h->map = nullptr; }
+  HIP_TRY(hipMalloc((void**)&h->map, (size_t)height * width));
+  HIP_TRY(hipMemcpyAsync(h->map, data, (size_t)height * width, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->map_h = height; h->map_w = width; h->map_ox = origin_x; h->map_oy = origin_y; h->map_res = resolution;
+  return MPMPC_OK;
+}
+
+int mpmpc_set_path_geometry(mpmpc_handle h, int32_t n_wp, const double* x, const double* y, const double* psi,
+                            const double* border_ub, const double* border_lb) {
+  if (!h || !x || !y || !psi || !border_ub || !border_lb) return fail(MPMPC_E_ARG, "NULL argument");
+  if (h->n_wp == 0 || n_wp != h->n_wp) return fail(MPMPC_E_STATE, "set the path first; n_wp must match it");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (int rc = upload_table(h, &h->gx, x, n_wp)) return rc;
+  if (int rc = upload_table(h, &h->gy, y, n_wp)) return rc;
+  if (int rc = upload_table(h, &h->gpsi, psi, n_wp)) return rc;
+  if (int rc = upload_table(h, &h->bub, border_ub, 2 * (size_t)n_wp)) return rc;
+  if (int rc = upload_table(h, &h->blb, border_lb, 2 * (size_t)n_wp)) return rc;
+  if (h->segs) { HIP_TRY(hipFree(h->segs)); h->segs = nullptr; }
+  if (h->nseg) { HIP_TRY(hipFree(h->nseg)); h->nseg = nullptr; }
+  if (!h->bad) HIP_TRY(hipMalloc((void**)&h->bad, sizeof(int)));
+  HIP_TRY(hipMalloc((void**)&h->segs, sizeof(double) * 4 * COR_MAXSEG * (size_t)n_wp));
+  HIP_TRY(hipMalloc((void**)&h->nseg, sizeof(int) * (size_t)n_wp));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->geom_n = n_wp;
+  return MPMPC_OK;
+}
+
+int mpmpc_build_corridor(mpmpc_handle h, int32_t n_cols, double min_width, double safety_margin, double* ub_out,
+                         double* lb_out, int32_t* bad_rows) {
+  if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  if (!h->map || h->geom_n == 0 || h->geom_n != h->n_wp)
+    return fail(MPMPC_E_STATE, "needs mpmpc_set_path, mpmpc_set_map and mpmpc_set_path_geometry first");
+  if (n_cols < h->cfg.N) return fail(MPMPC_E_ARG, "corridor table needs n_cols >= N");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const int n = h->n_wp;
+  if (h->n_cols != n_cols || !h->ub_tab) {
+    if (h->ub_tab) { HIP_TRY(hipFree(h->ub_tab)); h->ub_tab = nullptr; }
+    if (h->lb_tab) { HIP_TRY(hipFree(h->lb_tab)); h->lb_tab = nullptr; }
+    HIP_TRY(hipMalloc((void**)&h->ub_tab, sizeof(double) * (size_t)n * n_cols));
+    HIP_TRY(hipMalloc((void**)&h->lb_tab, sizeof(double) * (size_t)n * n_cols));
+  }
+  MapView mv{h->map, h->map_h, h->map_w, h->map_ox, h->map_oy, h->map_res};
+  PathGeom pg{h->gx, h->gy, h->gpsi, h->ds_next, n, h->cfg.circular};
+  HIP_TRY(hipMemsetAsync(h->bad, 0, sizeof(int), h->stream));
+  const int blocks = (n + 63) / 64;
+  hipLaunchKernelGGL(mpmpc_free_segments_kernel, dim3(blocks), dim3(64), 0, h->stream, mv, n, h->bub, h->blb, min_width,
+                     h->segs, h->nseg);
+  hipLaunchKernelGGL(mpmpc_corridor_select_kernel, dim3(blocks), dim3(64), 0, h->stream, pg, h->segs, h->nseg, n_cols,
+                     safety_margin, h->ub_tab, h->lb_tab, h->bad);
+  HIP_TRY(hipGetLastError());
+  int bad = 0;
+  HIP_TRY(hipMemcpyAsync(&bad, h->bad, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (ub_out) HIP_TRY(hipMemcpyAsync(ub_out, h->ub_tab, sizeof(double) * (size_t)n * n_cols, hipMemcpyDeviceToHost, h->stream));
+  if (lb_out) HIP_TRY(hipMemcpyAsync(lb_out, h->lb_tab, sizeof(double) * (size_t)n * n_cols, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (bad_rows) *bad_rows = bad;
   h->n_cols = n_cols;
   return MPMPC_OK;
 }

@@ -111,6 +111,9 @@ def load_library(path: str | None = None):
     lib.mpmpc_set_settings.argtypes = [h, C.POINTER(Settings)]
     lib.mpmpc_set_path.argtypes = [h, C.c_int32, _dp, _dp, _dp]
     lib.mpmpc_set_corridor.argtypes = [h, C.c_int32, C.c_int32, _dp, _dp]
+    lib.mpmpc_set_map.argtypes = [h, C.c_int32, C.c_int32, C.POINTER(C.c_int8), C.c_double, C.c_double, C.c_double]
+    lib.mpmpc_set_path_geometry.argtypes = [h, C.c_int32, _dp, _dp, _dp, _dp, _dp]
+    lib.mpmpc_build_corridor.argtypes = [h, C.c_int32, C.c_double, C.c_double, _dp, _dp, _ip]
     lib.mpmpc_assemble.argtypes = [h, C.c_int32, _ip, _dp, _dp, _dp, _dp, _dp]
     lib.mpmpc_stage_ld.argtypes = [C.c_int32]
     lib.mpmpc_stage_ld.restype = C.c_int32
@@ -127,7 +130,7 @@ def load_library(path: str | None = None):
 
 EXPORTS = ["mpmpc_version", "mpmpc_last_error", "mpmpc_device_count", "mpmpc_default_settings",
            "mpmpc_create", "mpmpc_destroy", "mpmpc_set_settings", "mpmpc_set_path", "mpmpc_set_corridor",
-           "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident",
+           "mpmpc_set_map", "mpmpc_set_path_geometry", "mpmpc_build_corridor", "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident",
            "mpmpc_sync", "mpmpc_download", "mpmpc_solve_resident_timed"]
 
 
@@ -189,6 +192,34 @@ class Handle:
             raise ValueError("corridor tables must be equal-shape [n_wp x n_cols]")
         self._check(self.lib.mpmpc_set_corridor(self._h, ub.shape[0], ub.shape[1], _d(ub), _d(lb)))
         self._have_table = True
+
+    # --- corridor generation on the device (dynamic maps)
+    def set_map(self, data, origin, resolution):
+        grid = np.ascontiguousarray(data, dtype=np.int8)
+        if grid.ndim != 2:
+            raise ValueError("map grid must be 2-D [height, width]")
+        self._check(self.lib.mpmpc_set_map(self._h, grid.shape[0], grid.shape[1],
+                                           grid.ctypes.data_as(C.POINTER(C.c_int8)), float(origin[0]),
+                                           float(origin[1]), float(resolution)))
+
+    def set_path_geometry(self, x, y, psi, border_ub, border_lb):
+        x, y, psi = (np.ascontiguousarray(a, dtype=np.float64) for a in (x, y, psi))
+        bu = np.ascontiguousarray(border_ub, dtype=np.float64).reshape(x.size, 2)
+        bl = np.ascontiguousarray(border_lb, dtype=np.float64).reshape(x.size, 2)
+        self._check(self.lib.mpmpc_set_path_geometry(self._h, x.size, _d(x), _d(y), _d(psi), _d(bu), _d(bl)))
+        self._n_wp = x.size
+
+    def build_corridor(self, n_cols, min_width, safety_margin, want_tables=True):
+        """update_path_constraints(w + 1, n_cols, ...) for every start waypoint w, on the device; the
+        handle then uses the result like a table given to set_corridor.  -> (ub, lb, bad_rows)"""
+        n = self._n_wp
+        ub = np.zeros((n, n_cols)) if want_tables else None
+        lb = np.zeros((n, n_cols)) if want_tables else None
+        bad = C.c_int32(0)
+        self._check(self.lib.mpmpc_build_corridor(self._h, int(n_cols), float(min_width), float(safety_margin),
+                                                  _d(ub), _d(lb), C.byref(bad)))
+        self._have_table = True
+        return ub, lb, bad.value
 
     def _inputs(self, wp_id, x0, cc_prev, lb, ub):
         wp = np.ascontiguousarray(wp_id, dtype=np.int32).ravel()

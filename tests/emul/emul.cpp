@@ -4,6 +4,8 @@
 // the oracle in the GPU-less authoring container.  Never loaded by the product.
 #include "lane_emu.hpp"
 #include "mpmpc_core.hpp"
+#include "corridor_core.hpp"
+#include <limits>
 
 using namespace mpmpc;
 
@@ -61,4 +63,25 @@ extern "C" int emu_op_count(long long* out7, int reset) {
   (void)out7; (void)reset;
   return 0;
 #endif
+}
+
+// host run of the corridor code that the K0 kernels execute per thread
+extern "C" int emu_corridor(int height, int width, const int8_t* data, double ox, double oy, double res, int n_wp,
+                            const double* x, const double* y, const double* psi, const double* ds_next, int circular,
+                            const double* bub, const double* blb, int n_cols, double min_width, double safety_margin,
+                            double* ub_tab, double* lb_tab, int* nseg_out) {
+  MapView mv{data, height, width, ox, oy, res};
+  PathGeom pg{x, y, psi, ds_next, n_wp, circular};
+  double* segs = new double[(size_t)n_wp * 4 * COR_MAXSEG]();
+  int* nseg = new int[n_wp];
+  for (int i = 0; i < n_wp; ++i) nseg[i] = cor_free_segments(mv, bub[2 * i], bub[2 * i + 1], blb[2 * i], blb[2 * i + 1], min_width, segs + (size_t)i * 4 * COR_MAXSEG);
+  int bad = 0;
+  for (int w = 0; w < n_wp; ++w)
+    if (!cor_select(pg, segs, nseg, w + 1, n_cols, safety_margin, ub_tab + (size_t)w * n_cols, lb_tab + (size_t)w * n_cols)) {
+      ++bad;
+      for (int n = 0; n < n_cols; ++n) ub_tab[(size_t)w * n_cols + n] = lb_tab[(size_t)w * n_cols + n] = std::numeric_limits<double>::quiet_NaN();
+    }
+  if (nseg_out) for (int i = 0; i < n_wp; ++i) nseg_out[i] = nseg[i];
+  delete[] segs; delete[] nseg;
+  return bad;
 }
