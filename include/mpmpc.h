@@ -119,6 +119,22 @@ int mpmpc_set_path_geometry(mpmpc_handle h, int32_t n_wp, const double* x, const
 int mpmpc_build_corridor(mpmpc_handle h, int32_t n_cols, double min_width, double safety_margin, double* ub_out,
                          double* lb_out, int32_t* bad_rows);
 
+/* Closed-loop batched rollout on the device: B cars driven through
+ * `while car.s < length: u = mpc.get_control(); car.drive(u)` (src/simulation.py:134-140) without a
+ * host round trip per step.  Each step = localise + t2s (src/spatial_bicycle_models.py:183-219,256-279)
+ * -> K1 -> K2 -> solution use / infeasibility fallback (src/MPC.py:185-220) + drive
+ * (src/spatial_bicycle_models.py:221-244).  Needs mpmpc_set_path, mpmpc_set_path_geometry and a corridor
+ * table (mpmpc_set_corridor or mpmpc_build_corridor).
+ *   init:  Ts = model.Ts; cum_lengths[n_wp] = cumsum(ReferencePath.segment_lengths); s[B] arc lengths;
+ *          pose[B*3] = (x, y, psi); cc0[B*2N] previous plans or NULL for zeros (MPC.__init__).
+ *   state: any output may be NULL.  alive: 1 running, 0 lap finished (s >= length), -1 ended by the
+ *          reference's exit(1) after N-1 consecutive infeasible steps. */
+int mpmpc_rollout_init(mpmpc_handle h, int32_t B, double Ts, const double* cum_lengths, const double* s,
+                       const double* pose, const double* cc0);
+int mpmpc_rollout_step(mpmpc_handle h, int32_t B, int32_t n_steps);
+int mpmpc_rollout_state(mpmpc_handle h, int32_t B, double* s, double* pose, double* cc, int32_t* wp_id,
+                        double* x0, double* u_last, int32_t* status, int32_t* counter, int32_t* alive);
+
 /* replaces MPC._init_problem (src/MPC.py:61-155) for B instances: LTV linearisation
  * (src/spatial_bicycle_models.py:391-417) around waypoints wp_id+0..N-1, offsets, speed cap from
  * the previous plan cc_prev (src/MPC.py:86-87,111-113), box bounds, references, cost vectors.

@@ -184,6 +184,20 @@ class BatchMPC:
         poses = np.asarray(poses, float)
         return wp.astype(np.int32), t2s_batch(poses[:, 0], poses[:, 1], poses[:, 2], wx, wy, wpsi)
 
+    def rollout(self, s, poses, n_steps, cc0=None):
+        """Drive B cars `n_steps` control steps on the device (localise, assemble, solve, fallback,
+        plant update: the loop of src/simulation.py:134-140) and return the final state dict
+        (s, pose, cc, wp_id, x0, u, status, counter, alive).  Needs a corridor table."""
+        rp = self._path
+        if getattr(self.handle, "_n_wp", None) != rp.n_waypoints:
+            wps = rp.waypoints
+            self.handle.set_path_geometry([w.x for w in wps], [w.y for w in wps], [w.psi for w in wps],
+                                          [w.static_border_cells[0] for w in wps],
+                                          [w.static_border_cells[1] for w in wps])
+        self.handle.rollout_init(self.model.Ts, np.cumsum(rp.segment_lengths), s, poses, cc0)
+        self.handle.rollout_step(n_steps)
+        return self.handle.rollout_state()
+
     def get_control_batch(self, wp_id, x0, cc_prev, lb=None, ub=None):
         """-> (u [B,2] = (v, delta), plan [B,2N] with delta entries, status [B], Solution)."""
         sol = self.handle.solve(wp_id, x0, cc_prev, lb, ub)

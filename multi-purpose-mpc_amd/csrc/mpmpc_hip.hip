@@ -23,6 +23,7 @@
 #include "lane_gpu.hpp"
 #include "mpmpc_core.hpp"
 #include "corridor_core.hpp"
+#include "rollout_core.hpp"
 
 using namespace mpmpc;
 
@@ -98,6 +99,35 @@ __global__ __launch_bounds__(64) void mpmpc_corridor_select_kernel(PathGeom g, c
   }
 }
 
+// K3a: where is each car on the path, and what is its path-relative state (one thread per car)
+__global__ __launch_bounds__(256) void mpmpc_localise_kernel(int B, int n_wp, const double* __restrict__ cum,
+                                                             const double* __restrict__ gx, const double* __restrict__ gy,
+                                                             const double* __restrict__ gpsi, const double* __restrict__ s,
+                                                             const double* __restrict__ pose, int* __restrict__ alive,
+                                                             int* __restrict__ wp_id, double* __restrict__ x0) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B || alive[i] != 1) return;
+  const int wp = ro_current_waypoint(cum, n_wp, s[i]);
+  if (wp < 0) { alive[i] = 0; return; }              // lap finished
+  wp_id[i] = wp;
+  ro_t2s(pose[3 * i], pose[3 * i + 1], pose[3 * i + 2], gx[wp], gy[wp], gpsi[wp], x0 + 3 * i);
+}
+
+// K3b: use the solution (or the fallback plan), drive the plant one step (one thread per car)
+__global__ __launch_bounds__(256) void mpmpc_advance_kernel(int B, int N, double L, double Ts, const double* __restrict__ kappa,
+                                                            const int* __restrict__ wp_id, const double* __restrict__ x0,
+                                                            const int* __restrict__ status, const double* __restrict__ z,
+                                                            double* __restrict__ cc, int* __restrict__ counter,
+                                                            int* __restrict__ alive, double* __restrict__ pose,
+                                                            double* __restrict__ s, double* __restrict__ u_last) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B || alive[i] != 1) return;
+  const int n = 5 * N + 3;
+  if (!ro_advance(N, L, Ts, status[i], z + (long)i * n, cc + (long)i * 2 * N, counter + i, x0 + 3 * i, kappa[wp_id[i]],
+                  pose + 3 * i, s + i, u_last + 2 * i))
+    alive[i] = -1;
+}
+
 // ------------------------------------------------------------------------------------ host side
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -127,6 +157,11 @@ struct mpmpc_handle_s {
   double *gx = nullptr, *gy = nullptr, *gpsi = nullptr, *bub = nullptr, *blb = nullptr, *segs = nullptr;
   int *nseg = nullptr, *bad = nullptr;
   int geom_n = 0;
+  // closed-loop rollout state
+  double *ro_cum = nullptr, *ro_s = nullptr, *ro_pose = nullptr, *ro_u = nullptr;
+  int *ro_counter = nullptr, *ro_alive = nullptr;
+  double ro_Ts = 0;
+  int ro_B = 0;
   // per-batch inputs
   int* wp_id = nullptr;
   double *x0 = nullptr, *cc = nullptr, *lb = nullptr, *ub = nullptr;
@@ -152,6 +187,9 @@ static int check_settings(const mpmpc_settings* s) {
     return fail(MPMPC_E_ARG, "polish needs ipm_reg, ipm_tol, as_delta > 0");
   return MPMPC_OK;
 }
+
+static int launch_assemble(mpmpc_handle h, int B);
+static int launch_solve(mpmpc_handle h, int B);
 
 extern "C" {
 
@@ -188,7 +226,8 @@ int mpmpc_destroy(mpmpc_handle h) {
   (void)hipSetDevice(h->cfg.device);
   void* ptrs[] = {h->kappa, h->v_ref, h->ds_next, h->ub_tab, h->lb_tab, h->wp_id, h->x0,  h->cc,   h->lb,  h->ub,
                   h->qp,    h->z,     h->u0,      h->resid,  h->y,      h->status, h->iters, h->map, h->gx,  h->gy,
-                  h->gpsi,  h->bub,   h->blb,     h->segs,   h->nseg,   h->bad};
+                  h->gpsi,  h->bub,   h->blb,     h->segs,   h->nseg,   h->bad,    h->ro_cum, h->ro_s, h->ro_pose,
+                  h->ro_u,  h->ro_counter, h->ro_alive};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& e : h->ev)
@@ -364,6 +403,84 @@ int mpmpc_build_corridor(mpmpc_handle h, int32_t n_cols, double min_width, doubl
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (bad_rows) *bad_rows = bad;
   h->n_cols = n_cols;
+  return MPMPC_OK;
+}
+
+int mpmpc_rollout_init(mpmpc_handle h, int32_t B, double Ts, const double* cum_lengths, const double* s,
+                       const double* pose, const double* cc0) {
+  if (!h || !cum_lengths || !s || !pose) return fail(MPMPC_E_ARG, "NULL argument");
+  if (B < 1 || B > h->cfg.max_batch) return fail(MPMPC_E_ARG, "B must be in [1, max_batch]");
+  if (!(Ts > 0)) return fail(MPMPC_E_ARG, "Ts must be > 0");
+  if (h->n_wp == 0 || h->geom_n != h->n_wp) return fail(MPMPC_E_STATE, "needs mpmpc_set_path and mpmpc_set_path_geometry");
+  if (h->n_cols == 0) return fail(MPMPC_E_STATE, "needs a corridor table (mpmpc_set_corridor / mpmpc_build_corridor)");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const size_t mb = (size_t)h->cfg.max_batch;
+  if (!h->ro_s) {
+    HIP_TRY(hipMalloc((void**)&h->ro_s, sizeof(double) * mb));
+    HIP_TRY(hipMalloc((void**)&h->ro_pose, sizeof(double) * 3 * mb));
+    HIP_TRY(hipMalloc((void**)&h->ro_u, sizeof(double) * 2 * mb));
+    HIP_TRY(hipMalloc((void**)&h->ro_counter, sizeof(int) * mb));
+    HIP_TRY(hipMalloc((void**)&h->ro_alive, sizeof(int) * mb));
+  }
+  if (int rc = upload_table(h, &h->ro_cum, cum_lengths, h->n_wp)) return rc;
+  const int N = h->cfg.N;
+  HIP_TRY(hipMemcpyAsync(h->ro_s, s, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->ro_pose, pose, sizeof(double) * 3 * B, hipMemcpyHostToDevice, h->stream));
+  if (cc0) HIP_TRY(hipMemcpyAsync(h->cc, cc0, sizeof(double) * 2 * N * B, hipMemcpyHostToDevice, h->stream));
+  else HIP_TRY(hipMemsetAsync(h->cc, 0, sizeof(double) * 2 * N * B, h->stream));
+  HIP_TRY(hipMemsetAsync(h->ro_counter, 0, sizeof(int) * B, h->stream));
+  HIP_TRY(hipMemsetAsync(h->ro_u, 0, sizeof(double) * 2 * B, h->stream));
+  HIP_TRY(hipMemsetAsync(h->wp_id, 0, sizeof(int) * B, h->stream));
+  HIP_TRY(hipMemsetAsync(h->x0, 0, sizeof(double) * 3 * B, h->stream));
+  HIP_TRY(hipMemsetAsync(h->status, 0, sizeof(int) * B, h->stream));
+  std::string ones(sizeof(int) * (size_t)B, '\0');
+  for (int i = 0; i < B; ++i) ((int*)ones.data())[i] = 1;
+  HIP_TRY(hipMemcpyAsync(h->ro_alive, ones.data(), sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->ro_Ts = Ts;
+  h->ro_B = B;
+  h->have_rows = false;       // the corridor comes from the table
+  h->uploaded = B;
+  return MPMPC_OK;
+}
+
+int mpmpc_rollout_step(mpmpc_handle h, int32_t B, int32_t n_steps) {
+  if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  if (B < 1 || B > h->ro_B) return fail(MPMPC_E_STATE, "call mpmpc_rollout_init for at least B cars first");
+  if (n_steps < 0) return fail(MPMPC_E_ARG, "n_steps must be >= 0");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const int blocks = (B + 255) / 256;
+  for (int t = 0; t < n_steps; ++t) {
+    hipLaunchKernelGGL(mpmpc_localise_kernel, dim3(blocks), dim3(256), 0, h->stream, B, h->n_wp, h->ro_cum, h->gx, h->gy,
+                       h->gpsi, h->ro_s, h->ro_pose, h->ro_alive, h->wp_id, h->x0);
+    if (int rc = launch_assemble(h, B)) return rc;
+    if (int rc = launch_solve(h, B)) return rc;
+    hipLaunchKernelGGL(mpmpc_advance_kernel, dim3(blocks), dim3(256), 0, h->stream, B, h->cfg.N, h->cfg.wheelbase, h->ro_Ts,
+                       h->kappa, h->wp_id, h->x0, h->status, h->z, h->cc, h->ro_counter, h->ro_alive, h->ro_pose, h->ro_s,
+                       h->ro_u);
+  }
+  HIP_TRY(hipGetLastError());
+  return MPMPC_OK;
+}
+
+int mpmpc_rollout_state(mpmpc_handle h, int32_t B, double* s, double* pose, double* cc, int32_t* wp_id, double* x0,
+                        double* u_last, int32_t* status, int32_t* counter, int32_t* alive) {
+  if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  if (B < 1 || B > h->ro_B) return fail(MPMPC_E_STATE, "call mpmpc_rollout_init for at least B cars first");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const int N = h->cfg.N;
+#define PULL(dst, src, bytes) if (dst) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream))
+  PULL(s, h->ro_s, sizeof(double) * B);
+  PULL(pose, h->ro_pose, sizeof(double) * 3 * B);
+  PULL(cc, h->cc, sizeof(double) * 2 * N * B);
+  PULL(wp_id, h->wp_id, sizeof(int) * B);
+  PULL(x0, h->x0, sizeof(double) * 3 * B);
+  PULL(u_last, h->ro_u, sizeof(double) * 2 * B);
+  PULL(status, h->status, sizeof(int) * B);
+  PULL(counter, h->ro_counter, sizeof(int) * B);
+  PULL(alive, h->ro_alive, sizeof(int) * B);
+#undef PULL
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return MPMPC_OK;
 }
 

@@ -114,6 +114,9 @@ def load_library(path: str | None = None):
     lib.mpmpc_set_map.argtypes = [h, C.c_int32, C.c_int32, C.POINTER(C.c_int8), C.c_double, C.c_double, C.c_double]
     lib.mpmpc_set_path_geometry.argtypes = [h, C.c_int32, _dp, _dp, _dp, _dp, _dp]
     lib.mpmpc_build_corridor.argtypes = [h, C.c_int32, C.c_double, C.c_double, _dp, _dp, _ip]
+    lib.mpmpc_rollout_init.argtypes = [h, C.c_int32, C.c_double, _dp, _dp, _dp, _dp]
+    lib.mpmpc_rollout_step.argtypes = [h, C.c_int32, C.c_int32]
+    lib.mpmpc_rollout_state.argtypes = [h, C.c_int32, _dp, _dp, _dp, _ip, _dp, _dp, _ip, _ip, _ip]
     lib.mpmpc_assemble.argtypes = [h, C.c_int32, _ip, _dp, _dp, _dp, _dp, _dp]
     lib.mpmpc_stage_ld.argtypes = [C.c_int32]
     lib.mpmpc_stage_ld.restype = C.c_int32
@@ -130,7 +133,8 @@ def load_library(path: str | None = None):
 
 EXPORTS = ["mpmpc_version", "mpmpc_last_error", "mpmpc_device_count", "mpmpc_default_settings",
            "mpmpc_create", "mpmpc_destroy", "mpmpc_set_settings", "mpmpc_set_path", "mpmpc_set_corridor",
-           "mpmpc_set_map", "mpmpc_set_path_geometry", "mpmpc_build_corridor", "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident",
+           "mpmpc_set_map", "mpmpc_set_path_geometry", "mpmpc_build_corridor", "mpmpc_rollout_init",
+           "mpmpc_rollout_step", "mpmpc_rollout_state", "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident",
            "mpmpc_sync", "mpmpc_download", "mpmpc_solve_resident_timed"]
 
 
@@ -220,6 +224,31 @@ class Handle:
                                                   _d(ub), _d(lb), C.byref(bad)))
         self._have_table = True
         return ub, lb, bad.value
+
+    # --- closed-loop rollout on the device
+    def rollout_init(self, Ts, cum_lengths, s, poses, cc0=None):
+        cum = np.ascontiguousarray(cum_lengths, dtype=np.float64)
+        s = np.ascontiguousarray(s, dtype=np.float64).ravel()
+        B = s.size
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(B, 3)
+        if cc0 is not None:
+            cc0 = np.ascontiguousarray(cc0, dtype=np.float64).reshape(B, 2 * self.N)
+        self._check(self.lib.mpmpc_rollout_init(self._h, B, float(Ts), _d(cum), _d(s), _d(poses), _d(cc0)))
+        self._ro_B = B
+        return B
+
+    def rollout_step(self, n_steps=1):
+        self._check(self.lib.mpmpc_rollout_step(self._h, self._ro_B, int(n_steps)))
+
+    def rollout_state(self):
+        B, N = self._ro_B, self.N
+        out = dict(s=np.zeros(B), pose=np.zeros((B, 3)), cc=np.zeros((B, 2 * N)), wp_id=np.zeros(B, np.int32),
+                   x0=np.zeros((B, 3)), u=np.zeros((B, 2)), status=np.zeros(B, np.int32),
+                   counter=np.zeros(B, np.int32), alive=np.zeros(B, np.int32))
+        self._check(self.lib.mpmpc_rollout_state(self._h, B, _d(out["s"]), _d(out["pose"]), _d(out["cc"]),
+                                                 _i(out["wp_id"]), _d(out["x0"]), _d(out["u"]), _i(out["status"]),
+                                                 _i(out["counter"]), _i(out["alive"])))
+        return out
 
     def _inputs(self, wp_id, x0, cc_prev, lb, ub):
         wp = np.ascontiguousarray(wp_id, dtype=np.int32).ravel()

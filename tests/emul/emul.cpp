@@ -5,6 +5,7 @@
 #include "lane_emu.hpp"
 #include "mpmpc_core.hpp"
 #include "corridor_core.hpp"
+#include "rollout_core.hpp"
 #include <limits>
 
 using namespace mpmpc;
@@ -84,4 +85,16 @@ extern "C" int emu_corridor(int height, int width, const int8_t* data, double ox
   if (nseg_out) for (int i = 0; i < n_wp; ++i) nseg_out[i] = nseg[i];
   delete[] segs; delete[] nseg;
   return bad;
+}
+
+// host runs of the per-car rollout code that the K3 kernels execute per thread
+extern "C" int emu_localise(int n_wp, const double* cum, const double* gx, const double* gy, const double* gpsi, double s,
+                            const double* pose, double* x0) {
+  int wp = ro_current_waypoint(cum, n_wp, s);
+  if (wp >= 0) ro_t2s(pose[0], pose[1], pose[2], gx[wp], gy[wp], gpsi[wp], x0);
+  return wp;
+}
+extern "C" int emu_advance(int N, double L, double Ts, int status, const double* z, double* cc, int* counter,
+                           const double* x0, double kappa_wp, double* pose, double* s, double* u_out) {
+  return ro_advance(N, L, Ts, status, z, cc, counter, x0, kappa_wp, pose, s, u_out) ? 1 : 0;
 }

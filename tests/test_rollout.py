@@ -1,0 +1,99 @@
+"""Closed-loop rollout: the per-car code of the K3 kernels on the host against the
+reference's own closed-loop trace (golden G6), and - on the GPU - B cars rolled out on the device
+against the host loop of src/simulation.py:134-140 run with our classes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import mpc_np as M
+import mpmpc
+import mpmpc_testlib as T
+
+dp = C.POINTER(C.c_double)
+
+
+def _d(a):
+    return a.ctypes.data_as(dp)
+
+
+def test_localise_and_advance_reproduce_reference_trace(emu):
+    g = np.load(M.GOLDEN + "/g6_closed_loop_N30.npz")
+    g1 = np.load(M.GOLDEN + "/g1_path_sim_track.npz")
+    N, L, Ts = 30, 0.12, 0.05
+    cum = np.ascontiguousarray(np.cumsum(g1["segment_lengths"]))
+    gx, gy, gpsi = (np.ascontiguousarray(g1[k]) for k in ("x", "y", "psi"))
+    steps = g["s"].size
+    for t in range(steps - 1):
+        pose = np.ascontiguousarray(g["pose"][t])
+        x0 = np.zeros(3)
+        wp = emu.lib.emu_localise(C.c_int(200), _d(cum), _d(gx), _d(gy), _d(gpsi), C.c_double(float(g["s"][t])), _d(pose), _d(x0))
+        assert wp == g["wp_id"][t] and np.allclose(x0, g["x0"][t], rtol=0, atol=1e-14)
+        # feed the reference's own solution of this step and compare the plant / plan update
+        cc = np.ascontiguousarray(g["cc_prev"][t].copy())
+        z = np.ascontiguousarray(np.nan_to_num(g["z"][t]))
+        counter = C.c_int(int(g["counter"][t - 1]) if t > 0 else 0)
+        s = C.c_double(float(g["s"][t]))
+        u = np.zeros(2)
+        alive = emu.lib.emu_advance(C.c_int(N), C.c_double(L), C.c_double(Ts), C.c_int(int(g["status"][t])), _d(z), _d(cc),
+                                    C.byref(counter), _d(x0), C.c_double(float(g1["kappa"][wp])), _d(pose), C.byref(s), _d(u))
+        assert alive == 1 and counter.value == g["counter"][t]
+        assert np.allclose(u, g["u"][t], rtol=0, atol=1e-15)
+        assert np.allclose(cc, g["cc_next"][t], rtol=0, atol=1e-15)
+        assert abs(s.value - g["s"][t + 1]) <= 1e-14 and np.allclose(pose, g["pose"][t + 1], rtol=0, atol=1e-14)
+    # past the end of the path: reported, not wrapped
+    assert emu.lib.emu_localise(C.c_int(200), _d(cum), _d(gx), _d(gy), _d(gpsi), C.c_double(float(cum[-1]) + 1.0),
+                                _d(pose), _d(x0)) == -1
+
+
+def test_advance_ends_the_run_after_n_minus_one_fallbacks(emu):
+    N = 6
+    cc = np.ascontiguousarray(np.arange(12, dtype=float) / 10)
+    counter = C.c_int(0)
+    pose, x0, u, z = np.zeros(3), np.zeros(3), np.zeros(2), np.zeros(5 * N + 3)
+    s = C.c_double(0.0)
+    alive = []
+    for _ in range(N - 1):
+        alive.append(emu.lib.emu_advance(C.c_int(N), C.c_double(0.12), C.c_double(0.05), C.c_int(-3), _d(z), _d(cc),
+                                         C.byref(counter), _d(x0), C.c_double(0.0), _d(pose), C.byref(s), _d(u)))
+    assert alive == [1, 1, 1, 1, 0] and counter.value == N - 1       # src/MPC.py:218-220
+    assert u[0] == cc[2 * (N - 1)] and u[1] == cc[2 * (N - 1) + 1]
+
+
+@pytest.mark.gpu
+def test_device_rollout_matches_host_loop():
+    import test_host_mpc as H
+    g1 = np.load(M.GOLDEN + "/g1_path_sim_track.npz")
+    g3 = np.load(M.GOLDEN + "/g3_corridor.npz")
+    N, steps = 30, 25
+    starts = np.array([0, 12, 37, 61, 88, 120, 150, 171])
+    cum = np.cumsum(g1["segment_lengths"])
+    B = starts.size
+    # ---- host: one controller per car, the reference's loop with our classes
+    host = []
+    for w in starts:
+        m, rp, car = H.build_world()
+        mpc = H.make_mpc(car, N)
+        car.s = float(cum[w])
+        car.temporal_state.x, car.temporal_state.y, car.temporal_state.psi = rp.waypoints[w].x, rp.waypoints[w].y, rp.waypoints[w].psi
+        for _ in range(steps):
+            u = mpc.get_control()
+            car.drive(u)
+        host.append((car.s, car.temporal_state.x, car.temporal_state.y, car.temporal_state.psi, u[0], u[1]))
+    host = np.array(host)
+    # ---- device: all cars at once
+    cfg = T.stock_config(N, max_batch=B)
+    h = mpmpc.Handle(cfg)
+    tr = __import__("scenarios").sim_track()
+    h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+    h.set_corridor(g3["ub_obstacles"], g3["lb_obstacles"])
+    h.set_path_geometry(g1["x"], g1["y"], g1["psi"], g1["border_ub"], g1["border_lb"])
+    poses = np.stack([g1["x"][starts], g1["y"][starts], g1["psi"][starts]], axis=1)
+    h.rollout_init(0.05, cum, cum[starts], poses)
+    h.rollout_step(steps)
+    st = h.rollout_state()
+    assert np.all(st["alive"] == 1)
+    assert np.max(np.abs(st["s"] - host[:, 0])) <= 1e-8
+    assert np.max(np.abs(st["pose"] - host[:, 1:4])) <= 1e-8
+    assert np.max(np.abs(st["u"] - host[:, 4:6])) <= 1e-6
+    h.close()
