@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--early-polish", type=int, default=None, help="override the early_polish solver setting")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,7 +113,8 @@ def main():
     Q, R, QN = scenarios.WEIGHTS[sc_all.weights]
     cfg = mpmpc.make_config(N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX,
                             scenarios.AY_MAX, scenarios.CAR_LENGTH, circular=True, max_batch=B, device=local_rank)
-    h = mpmpc.Handle(cfg, mpmpc.default_settings())
+    settings = mpmpc.default_settings() if args.early_polish is None else mpmpc.default_settings(early_polish=args.early_polish)
+    h = mpmpc.Handle(cfg, settings)
     h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
     h.upload(wp, x0, cc, lb, ub)          # inputs resident in HBM before the timed region
 
@@ -150,7 +152,7 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "config%d: batch=%d independent poses per GPU, %s weights, N=%d, %s corridor, "
-                                   "OSQP-default ADMM, certified polish tried after 25 iterations" %
+                                   "OSQP-default ADMM, certified polish tried after 15 iterations" %
                                    (args.config, B, sc_all.weights, N, "obstacle" if sc_all.obstacles else "free"),
                        "batch_per_gpu": B, "horizon": N, "parallelism": "batch-shard x%d" % world},
         }
