@@ -133,6 +133,12 @@ struct LaneEmu {
   static VD cold_get(int slot) { return cold()[slot]; }
   static void fence() {}
 
+  // output rows: the device stages them in LDS and writes them coalesced; same memory image here
+  template <class F>
+  static void rows(double* dst, int rowlen, const VI& inst, int /*n_inst*/, F fill) {
+    fill([&](const VI& idx, const VB& ok, const VD& v) { store(dst, inst * rowlen + idx, ok, v); });
+  }
+
   static VD load(const double* p, const VI& idx, const VB& ok, double dflt) {
     VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = ok.v[i] ? p[idx.v[i]] : dflt; return r;
   }

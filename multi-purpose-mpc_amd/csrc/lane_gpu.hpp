@@ -102,6 +102,22 @@ struct LaneGpu {
   // compiler-level fence: values parked before it are re-read after it, not kept in registers
   static __device__ __forceinline__ void fence() { asm volatile("" ::: "memory"); }
 
+  // Output rows (rowlen doubles per instance, instance-major in dst): the lanes drop their entries
+  // into the wave's LDS buffer at their place in the row, then the wave writes the 64/G rows it owns
+  // as one run of consecutive doubles.  fill(put) calls put(index in row, lane active, value).
+  template <class F>
+  static __device__ __forceinline__ void rows(double* dst, int rowlen, int inst, int n_inst, F fill) {
+    double* buf = cold();
+    __syncthreads();                              // one wave per block: orders the LDS accesses only
+    const int mine = slot() * rowlen;
+    fill([&](int idx, bool ok, double v) { if (ok) buf[mine + idx] = v; });
+    __syncthreads();
+    const int inst0 = inst - slot();              // first instance of this wave
+    const int cnt = (n_inst - inst0 < per_wave ? n_inst - inst0 : per_wave) * rowlen;
+    double* out = dst + (long)inst0 * rowlen;
+    for (int i = lane_id(); i < cnt; i += 64) out[i] = buf[i];
+  }
+
   static __device__ __forceinline__ double load(const double* p, int idx, bool ok, double dflt) {
     return ok ? p[idx] : dflt;
   }

@@ -163,7 +163,7 @@ struct Solver {
   using I = typename L::ival;
 
   // ---- lane context
-  int N;
+  int N, n_inst;
   Mk vx, vu, first;      // lane holds a real stage (k <= N), a real input (k < N), k == 0
   Mk valid[5];
   Mk live;               // this lane's instance exists
@@ -233,6 +233,7 @@ struct Solver {
   // ======================================================================== setup
   MPMPC_HD void load(const double* qp, int B, int ld, const I& inst, const I& k, int N_) {
     N = N_;
+    n_inst = B;
     live = inst < B;
     vx = live & (k <= N);
     vu = live & (k < N);
@@ -1037,20 +1038,25 @@ struct Solver {
                       int* it_out, double* resid, double* y) const {
     const int n = 5 * N + 3, m = 8 * N + 6;
     R cinv = R(1.0) / c;
+    // whole rows are staged per wave and written as consecutive doubles (lane backends: rows())
     if (z) {
-      MPMPC_UNROLL
-      for (int i = 0; i < 3; ++i) L::store(z, inst * n + k * 3 + i, vx, D[i] * x[i]);
-      L::store(z, inst * n + k * 2 + (3 * (N + 1)), vu, D[3] * x[3]);
-      L::store(z, inst * n + k * 2 + (3 * (N + 1) + 1), vu, D[4] * x[4]);
+      L::rows(z, n, inst, n_inst, [&](auto put) {
+        MPMPC_UNROLL
+        for (int i = 0; i < 3; ++i) put(k * 3 + i, vx, D[i] * x[i]);
+        put(k * 2 + (3 * (N + 1)), vu, D[3] * x[3]);
+        put(k * 2 + (3 * (N + 1) + 1), vu, D[4] * x[4]);
+      });
     }
     if (y) {
-      MPMPC_UNROLL
-      for (int i = 0; i < 3; ++i) {
-        L::store(y, inst * m + k * 3 + i, vx, (Eeq[i] * yeq[i]) * cinv);
-        L::store(y, inst * m + k * 3 + (3 * (N + 1) + i), vx, (Eb[i] * yb[i]) * cinv);
-      }
-      L::store(y, inst * m + k * 2 + (6 * (N + 1)), vu, (Eb[3] * yb[3]) * cinv);
-      L::store(y, inst * m + k * 2 + (6 * (N + 1) + 1), vu, (Eb[4] * yb[4]) * cinv);
+      L::rows(y, m, inst, n_inst, [&](auto put) {
+        MPMPC_UNROLL
+        for (int i = 0; i < 3; ++i) {
+          put(k * 3 + i, vx, (Eeq[i] * yeq[i]) * cinv);
+          put(k * 3 + (3 * (N + 1) + i), vx, (Eb[i] * yb[i]) * cinv);
+        }
+        put(k * 2 + (6 * (N + 1)), vu, (Eb[3] * yb[3]) * cinv);
+        put(k * 2 + (6 * (N + 1) + 1), vu, (Eb[4] * yb[4]) * cinv);
+      });
     }
     Mk lead = live & first;
     if (u0) {
