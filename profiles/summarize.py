@@ -19,15 +19,15 @@ if os.path.exists(os.path.join(O, "trace_b65536.json")):
     shutil.copy(os.path.join(O, "trace_b65536.json"), os.path.join(P, "bench_cfg2_b65536.json"))
 for src, dst in (("trace", "bench_cfg2_kernel_stats.csv"), ("trace_b65536", "bench_cfg2_b65536_kernel_stats.csv")):
     fs = glob.glob(os.path.join(O, src, "*", "*kernel_stats.csv"))
-    if fs:
-        shutil.copy(fs[0], os.path.join(P, dst))
+    if fs:                                   # gpurun merges runs into the same directory: newest wins
+        shutil.copy(max(fs, key=os.path.getmtime), os.path.join(P, dst))
 out = {}
 for name in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_fetch_b65536", "pmc_write_b65536"):
     fs = glob.glob(os.path.join(O, name, "*", "*counter_collection.csv"))
     if not fs:
         continue
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if "copy" not in k:
             agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
