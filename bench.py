@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--early-polish", type=int, default=None, help="override the early_polish solver setting")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
+                    help="override any solver setting of the device path (exploration; the oracle keeps its defaults)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,7 +115,11 @@ def main():
     Q, R, QN = scenarios.WEIGHTS[sc_all.weights]
     cfg = mpmpc.make_config(N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX,
                             scenarios.AY_MAX, scenarios.CAR_LENGTH, circular=True, max_batch=B, device=local_rank)
-    settings = mpmpc.default_settings() if args.early_polish is None else mpmpc.default_settings(early_polish=args.early_polish)
+    overrides = {} if args.early_polish is None else {"early_polish": args.early_polish}
+    for kv in args.set:
+        k, v = kv.split("=", 1)
+        overrides[k] = float(v) if any(c in v for c in ".eE") else int(v)
+    settings = mpmpc.default_settings(**overrides)
     h = mpmpc.Handle(cfg, settings)
     h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
     h.upload(wp, x0, cc, lb, ub)          # inputs resident in HBM before the timed region

@@ -82,8 +82,11 @@ inline VI seli(const VB& m, const VI& a, const VI& b) { VI r; for (int i = 0; i 
 inline VB selb(const VB& m, const VB& a, const VB& b) { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
 
 // G = lanes per instance (16, 32 or 64); one emulated wave carries 64/G instances.
-template <int G>
+// C = split of the twisted factorisation (mpmpc_core.hpp, factor): lanes [C, 2C) of an instance are
+// reversed in chain layout; C == G means no second chain.
+template <int G, int C = G / 2>
 struct LaneEmu {
+  static constexpr int split = C;
   using real = VD;
   using mask = VB;
   using ival = VI;
@@ -99,6 +102,16 @@ struct LaneEmu {
   // value of the previous / next stage's lane (0.0 at the ends of an instance)
   static VD up(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (i % G == 0) ? 0.0 : a.v[i - 1]; return r; }
   static VD down(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (i % G == G - 1) ? 0.0 : a.v[i + 1]; return r; }
+
+  // chain layout: reversal of the lanes [C, 2C) and one-lane shifts with zero inflow at the chain ends
+  static VD mirror(const VD& a) {
+    MPMPC_OP(shift);
+    VD r;
+    for (int i = 0; i < EMU_W; ++i) { int l = i % G; r.v[i] = (l >= C && l < 2 * C) ? a.v[i - l + 3 * C - 1 - l] : a.v[i]; }
+    return r;
+  }
+  static VD cup(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) { int l = i % G; r.v[i] = (l == 0 || l == C) ? 0.0 : a.v[i - 1]; } return r; }
+  static VD cdown(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) { int l = i % G; r.v[i] = (l == C - 1 || l == 2 * C - 1 || l == G - 1) ? 0.0 : a.v[i + 1]; } return r; }
 
   // butterfly all-reduce inside an instance's lanes; same association order as the GPU backend
   template <class F>

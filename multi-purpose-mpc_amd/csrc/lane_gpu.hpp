@@ -29,9 +29,13 @@ __device__ __forceinline__ int mini(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int maxi(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ bool selb(bool m, bool a, bool b) { return m ? a : b; }
 
-// DPP controls (GFX9): whole-wavefront shift by one lane.
-constexpr int DPP_WAVE_SHL1 = 0x130;   // lane i <- lane i+1
-constexpr int DPP_WAVE_SHR1 = 0x138;   // lane i <- lane i-1
+// DPP controls (GFX9)
+constexpr int DPP_ROW_SHL1 = 0x101;    // lane i <- lane i+1 inside each row of 16 lanes
+constexpr int DPP_ROW_SHR1 = 0x111;    // lane i <- lane i-1 inside each row of 16 lanes
+constexpr int DPP_WAVE_SHL1 = 0x130;   // lane i <- lane i+1 over the whole wavefront
+constexpr int DPP_WAVE_SHR1 = 0x138;   // lane i <- lane i-1 over the whole wavefront
+constexpr int DPP_ROW_MIRROR = 0x140;  // reverse the 16 lanes of each row
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;   // reverse each half row of 8 lanes
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_shift(double a) {
@@ -41,9 +45,21 @@ __device__ __forceinline__ double dpp_shift(double a) {
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
+// lanes selected by ROWS / BANKS take the permuted value, all others keep `keep`
+template <int CTRL, int ROWS, int BANKS, bool BOUND>
+__device__ __forceinline__ double dpp_merge(double keep, double a) {
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(keep), __double2loint(a), CTRL, ROWS, BANKS, BOUND);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(keep), __double2hiint(a), CTRL, ROWS, BANKS, BOUND);
+  return __hiloint2double(hi, lo);
+}
 
-template <int G>
+// G lanes per instance; C = split of the twisted factorisation (mpmpc_core.hpp, factor): in chain
+// layout the lanes [C, 2C) of an instance are reversed.  Supported: <64,16> (N + 1 <= 32), <64,32>,
+// <32,16>, <16,16> (no second chain).
+template <int G, int C = G / 2>
 struct LaneGpu {
+  static_assert((G == 64 && (C == 16 || C == 32)) || (G == 32 && C == 16) || (G == 16 && C == 16), "unsupported lane split");
+  static constexpr int split = C;
   using real = double;
   using mask = bool;
   using ival = int;
@@ -66,6 +82,39 @@ struct LaneGpu {
     if (G < 64) r = (stage() == G - 1) ? 0.0 : r;
     return r;
   }
+  // ---- chain layout of the twisted factorisation
+  static __device__ __forceinline__ double mirror(double a) {
+    if constexpr (C == G) {
+      return a;
+    } else if constexpr (C == 16) {
+      return dpp_merge<DPP_ROW_MIRROR, (G == 64 ? 0x2 : 0xA), 0xf, false>(a, a);     // rows 1 (and 3)
+    } else {                                                                          // <64,32>: lanes 32..63
+      const int src = lane_id() < 32 ? lane_id() : 95 - lane_id();
+      return __shfl(a, src, 64);
+    }
+  }
+  // one-lane shifts along the chains; lanes 0 and C (cup), C-1 and 2C-1 (cdown) of an instance read 0
+  static __device__ __forceinline__ double cup(double a) {
+    if constexpr (C == G) {
+      return up(a);
+    } else if constexpr (C == 16) {
+      return dpp_shift<DPP_ROW_SHR1>(a);                 // chains are rows: the row shift zero-fills
+    } else {
+      double r = dpp_shift<DPP_WAVE_SHR1>(a);
+      return dpp_merge<DPP_ROW_SHR1, 0x4, 0x1, true>(r, a);      // lanes 32..35 again, lane 32 <- 0
+    }
+  }
+  static __device__ __forceinline__ double cdown(double a) {
+    if constexpr (C == G) {
+      return down(a);
+    } else if constexpr (C == 16) {
+      return dpp_shift<DPP_ROW_SHL1>(a);
+    } else {
+      double r = dpp_shift<DPP_WAVE_SHL1>(a);
+      return dpp_merge<DPP_ROW_SHL1, 0x2, 0x8, true>(r, a);      // lanes 28..31 again, lane 31 <- 0
+    }
+  }
+
   static __device__ __forceinline__ double gmax(double a) {
 #pragma unroll
     for (int off = 1; off < G; off <<= 1) { double t = __shfl_xor(a, off, 64); a = __builtin_fmax(a, t); }

@@ -156,6 +156,10 @@ MPMPC_HD void assemble_lane(const mpmpc_config& c, const PathTables& t, int B, i
 // ------------------------------------------------------------------------------------------
 // K2: the solver.  All state is per lane.
 // ------------------------------------------------------------------------------------------
+// Lane split of the twisted factorisation for G lanes per instance and horizon N (shared by the
+// launcher and the emulation): the chains meet at lane C - 1.
+inline int lane_split(int G, int N) { return G == 16 ? 16 : (G == 32 ? 16 : (N + 1 <= 32 ? 16 : 32)); }
+
 template <class L>
 struct Solver {
   using R = typename L::real;
@@ -165,6 +169,7 @@ struct Solver {
   // ---- lane context
   int N, n_inst;
   Mk vx, vu, first;      // lane holds a real stage (k <= N), a real input (k < N), k == 0
+  Mk down_chain, is_mid, is_end, vxc;   // twisted factorisation: k >= C; chain-layout lanes C-1, 2C-1; chain-layout vx
   Mk valid[5];
   Mk live;               // this lane's instance exists
   // ---- unscaled bounds kept for the certificate
@@ -173,7 +178,7 @@ struct Solver {
   R mI[3], a[6], b[2], g[5], p[5], q[5], D[5], Eeq[3], Eb[5], c;
   R leq[3], lb[5], ub[5];
   // ---- linear algebra
-  R hinv[5], Li[6], Gf[9], Gb[9];
+  R hinv[5], Li[6], Gin[9], Gout[9];          // Li, Gin, Gout in chain layout (see factor)
   // ---- ADMM state
   R x[5], zeq[3], zb[5], yeq[3], yb[5];
   R rho, rb[5], rbinv[5], rho_eq, rinv_eq;
@@ -238,6 +243,14 @@ struct Solver {
     vx = live & (k <= N);
     vu = live & (k < N);
     first = (k == 0);
+    {
+      const int C = L::split;
+      down_chain = (k >= C);
+      is_mid = (k == C - 1);
+      is_end = (k == 2 * C - 1);
+      I kc = seli(down_chain & (k < 2 * C), k * (-1) + (3 * C - 1), k);
+      vxc = live & (kc <= N);
+    }
     valid[0] = valid[1] = valid[2] = vx;
     valid[3] = valid[4] = vu;
     I base = inst * ld + k;
@@ -330,43 +343,86 @@ struct Solver {
     }
   }
 
-  // Block-tridiagonal Cholesky of S = Aeq diag(h) Aeq' + r I  (3x3 blocks, one per lane).
-  // Lane k ends with Li = inv(L_kk) (lower) and Ls = L_{k,k-1}.
+  // Block-tridiagonal Cholesky of S = Aeq diag(h) Aeq' + r I  (3x3 blocks, one per lane), as a
+  // TWISTED factorisation: stages 0 .. C-2 are eliminated upwards, stages N .. C downwards, both at
+  // the same time, and the two chains meet in stage C-1 (C = L::split).  The serial depth of the
+  // factorisation and of each substitution sweep is max(C-1, N-C+1) + 1 steps instead of N + 1.
+  // Inside factor() / s_solve() the data lives in "chain layout": the lanes [C, 2C) of the instance
+  // are reversed (L::mirror), so that both chains advance by the same one-lane shift L::up and
+  // retreat by L::down (as L::cup / L::cdown: zero inflow at the chain ends).  Lane C-1 is the meeting stage ("mid"), lane 2C-1 holds stage C ("end").
+  // Per lane, in chain layout:  Li = inv(L_kk) (lower),  Gin = -inv(L_kk) M_in,  Gout = -inv(L_kk)' M_own'
+  // where M_in is the coupling block received from the chain predecessor and M_own the one handed on
+  // (L_{k+1,k} going up, U_{k-1,k} going down).  The end lane keeps M_own itself in Gout: its only
+  // outward neighbour is mid, reached through the two junction steps of s_solve.
+  MPMPC_HD int chain_steps() const {
+    const int C = L::split;
+    int fwd = N + 1 < C - 1 ? N + 1 : C - 1, bwd = N - C + 1;
+    return fwd > bwd ? fwd : bwd;
+  }
   MPMPC_HD void factor(const R h[5], const R& r) {
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) hinv[j] = h[j];
-    R W[6], T[7], dk[3], M[9];
-    R a0h = a[0] * h[0], a2h = a[2] * h[0], a4h = a[4] * h[0], a1h = a[1] * h[1], a3h = a[3] * h[1];
-    W[0] = fma_(a[1], a1h, a[0] * a0h);
-    W[1] = fma_(a[3], a1h, a[2] * a0h);
-    W[2] = fma_(b[0] * b[0], h[4], fma_(a[3], a3h, a[2] * a2h));
-    W[3] = a[4] * a0h;
-    W[4] = a[4] * a2h;
-    W[5] = fma_(b[1] * b[1], h[3], fma_(a[5] * a[5], h[2], a[4] * a4h));
-    T[0] = a0h * mI[0]; T[1] = a1h * mI[1];                 // row 0: cols 0,1
-    T[2] = a2h * mI[0]; T[3] = a3h * mI[1];                 // row 1: cols 0,1
-    T[4] = a4h * mI[0]; T[5] = (a[5] * h[2]) * mI[2];       // row 2: cols 0,2
+    R W[6], T[6], Dg[6], To[9];
+    {
+      R a0h = a[0] * h[0], a2h = a[2] * h[0], a4h = a[4] * h[0], a1h = a[1] * h[1], a3h = a[3] * h[1];
+      W[0] = fma_(a[1], a1h, a[0] * a0h);
+      W[1] = fma_(a[3], a1h, a[2] * a0h);
+      W[2] = fma_(b[0] * b[0], h[4], fma_(a[3], a3h, a[2] * a2h));
+      W[3] = a[4] * a0h;
+      W[4] = a[4] * a2h;
+      W[5] = fma_(b[1] * b[1], h[3], fma_(a[5] * a[5], h[2], a[4] * a4h));
+      T[0] = a0h * mI[0]; T[1] = a1h * mI[1];                 // S_{k+1,k} row 0: cols 0,1
+      T[2] = a2h * mI[0]; T[3] = a3h * mI[1];                 //           row 1: cols 0,1
+      T[4] = a4h * mI[0]; T[5] = (a[5] * h[2]) * mI[2];       //           row 2: cols 0,2
+    }
+    // diagonal block S_kk (lower: 00 10 11 20 21 22): own -I H -I' + r, plus the predecessor's W
     MPMPC_UNROLL
-    for (int i = 0; i < 3; ++i) dk[i] = fma_(mI[i] * mI[i], h[i], r);
+    for (int i = 0; i < 6; ++i) Dg[i] = L::up(W[i]);
+    Dg[0] = Dg[0] + fma_(mI[0] * mI[0], h[0], r);
+    Dg[2] = Dg[2] + fma_(mI[1] * mI[1], h[1], r);
+    Dg[5] = Dg[5] + fma_(mI[2] * mI[2], h[2], r);
+    // coupling handed on: S_{k+1,k} = T going up, S_{k-1,k} = T_{k-1}' going down, nothing from mid
+    {
+      R Tu[6];
+      MPMPC_UNROLL
+      for (int i = 0; i < 6; ++i) Tu[i] = L::up(T[i]);
+      const R zero(0.0);
+      To[0] = sel(down_chain, Tu[0], T[0]); To[1] = sel(down_chain, Tu[2], T[1]); To[2] = sel(down_chain, Tu[4], zero);
+      To[3] = sel(down_chain, Tu[1], T[2]); To[4] = sel(down_chain, Tu[3], T[3]); To[5] = zero;
+      To[6] = sel(down_chain, zero, T[4]);  To[7] = zero;                         To[8] = sel(down_chain, Tu[5], T[5]);
+      MPMPC_UNROLL
+      for (int i = 0; i < 9; ++i) To[i] = sel(is_mid, zero, To[i]);
+    }
+    MPMPC_UNROLL
+    for (int i = 0; i < 6; ++i) Dg[i] = L::mirror(Dg[i]);
+    MPMPC_UNROLL
+    for (int i = 0; i < 9; ++i) if (i != 5 && i != 7) To[i] = L::mirror(To[i]);
+    R M[9], Ls[9];
     MPMPC_UNROLL
     for (int i = 0; i < 9; ++i) M[i] = R(0.0);
-    // the neighbour's W depends on h only: fetch it once, not once per sweep step
-    R Wr[6];
-    MPMPC_UNROLL
-    for (int i = 0; i < 6; ++i) Wr[i] = L::up(W[i]);
-    MPMPC_UNROLL
-    for (int i = 0; i < 3; ++i) dk[i] = dk[i] + Wr[i == 0 ? 0 : (i == 1 ? 2 : 5)];
-    R Ls[9];
-    for (int s = 0; s <= N; ++s) {
+    const int last = chain_steps();
+    for (int s = 0; s <= last; ++s) {
       R Mr[9];
       MPMPC_UNROLL
-      for (int i = 0; i < 9; ++i) Mr[i] = L::up(M[i]);
-      R S00 = dk[0] - fma_(Mr[2], Mr[2], fma_(Mr[1], Mr[1], Mr[0] * Mr[0]));
-      R S10 = Wr[1] - fma_(Mr[5], Mr[2], fma_(Mr[4], Mr[1], Mr[3] * Mr[0]));
-      R S11 = dk[1] - fma_(Mr[5], Mr[5], fma_(Mr[4], Mr[4], Mr[3] * Mr[3]));
-      R S20 = Wr[3] - fma_(Mr[8], Mr[2], fma_(Mr[7], Mr[1], Mr[6] * Mr[0]));
-      R S21 = Wr[4] - fma_(Mr[8], Mr[5], fma_(Mr[7], Mr[4], Mr[6] * Mr[3]));
-      R S22 = dk[2] - fma_(Mr[8], Mr[8], fma_(Mr[7], Mr[7], Mr[6] * Mr[6]));
+      for (int i = 0; i < 9; ++i) Mr[i] = L::cup(M[i]);
+      R S00 = Dg[0] - fma_(Mr[2], Mr[2], fma_(Mr[1], Mr[1], Mr[0] * Mr[0]));
+      R S10 = Dg[1] - fma_(Mr[5], Mr[2], fma_(Mr[4], Mr[1], Mr[3] * Mr[0]));
+      R S11 = Dg[2] - fma_(Mr[5], Mr[5], fma_(Mr[4], Mr[4], Mr[3] * Mr[3]));
+      R S20 = Dg[3] - fma_(Mr[8], Mr[2], fma_(Mr[7], Mr[1], Mr[6] * Mr[0]));
+      R S21 = Dg[4] - fma_(Mr[8], Mr[5], fma_(Mr[7], Mr[4], Mr[6] * Mr[3]));
+      R S22 = Dg[5] - fma_(Mr[8], Mr[8], fma_(Mr[7], Mr[7], Mr[6] * Mr[6]));
+      if (s == last) {
+        // junction: both chains have settled; mid also loses the block of the end lane
+        R Mx[9];
+        MPMPC_UNROLL
+        for (int i = 0; i < 9; ++i) Mx[i] = sel(is_mid, L::down(L::mirror(M[i])), R(0.0));
+        S00 = S00 - fma_(Mx[2], Mx[2], fma_(Mx[1], Mx[1], Mx[0] * Mx[0]));
+        S10 = S10 - fma_(Mx[5], Mx[2], fma_(Mx[4], Mx[1], Mx[3] * Mx[0]));
+        S11 = S11 - fma_(Mx[5], Mx[5], fma_(Mx[4], Mx[4], Mx[3] * Mx[3]));
+        S20 = S20 - fma_(Mx[8], Mx[2], fma_(Mx[7], Mx[1], Mx[6] * Mx[0]));
+        S21 = S21 - fma_(Mx[8], Mx[5], fma_(Mx[7], Mx[4], Mx[6] * Mx[3]));
+        S22 = S22 - fma_(Mx[8], Mx[8], fma_(Mx[7], Mx[7], Mx[6] * Mx[6]));
+      }
       // 3x3 Cholesky through reciprocal square roots: i_jj = 1 / l_jj
       R i00 = rsqrt_(S00);
       R l10 = S10 * i00, l20 = S20 * i00;
@@ -379,59 +435,86 @@ struct Solver {
       Li[0] = i00; Li[1] = i10; Li[2] = i11; Li[3] = i20; Li[4] = i21; Li[5] = i22;
       MPMPC_UNROLL
       for (int i = 0; i < 9; ++i) Ls[i] = Mr[i];
-      // M = T * inv(L_kk)'  -> L_{k+1,k}, consumed by lane k+1 in the next sweep step
-      M[0] = T[0] * i00; M[1] = fma_(T[1], i11, T[0] * i10); M[2] = fma_(T[1], i21, T[0] * i20);
-      M[3] = T[2] * i00; M[4] = fma_(T[3], i11, T[2] * i10); M[5] = fma_(T[3], i21, T[2] * i20);
-      M[6] = T[4] * i00; M[7] = T[4] * i10;                  M[8] = fma_(T[5], i22, T[4] * i20);
+      // M = To * inv(L_kk)'  -> consumed by the next lane of the chain in the next sweep step
+      M[0] = To[0] * i00; M[1] = fma_(To[1], i11, To[0] * i10); M[2] = fma_(To[2], i22, fma_(To[1], i21, To[0] * i20));
+      M[3] = To[3] * i00; M[4] = fma_(To[4], i11, To[3] * i10); M[5] = fma_(To[4], i21, To[3] * i20);
+      M[6] = To[6] * i00; M[7] = To[6] * i10;                   M[8] = fma_(To[8], i22, To[6] * i20);
     }
-    // lanes beyond the horizon never receive settled neighbours: give them a benign block
-    MPMPC_UNROLL
-    for (int i = 0; i < 9; ++i) Ls[i] = sel(vx, Ls[i], R(0.0));
-    Li[0] = sel(vx, Li[0], R(1.0)); Li[2] = sel(vx, Li[2], R(1.0)); Li[5] = sel(vx, Li[5], R(1.0));
-    Li[1] = sel(vx, Li[1], R(0.0)); Li[3] = sel(vx, Li[3], R(0.0)); Li[4] = sel(vx, Li[4], R(0.0));
     // recurrence matrices of the two substitution sweeps (stored negated, so a sweep step is 9 FMAs):
-    //   forward   y_k  = inv(L_kk) b_k + Gf_k y_{k-1},      Gf_k = -inv(L_kk) L_{k,k-1}
-    //   backward  nu_k = inv(L_kk)' y_k + Gb_k nu_{k+1},    Gb_k = -inv(L_kk)' L_{k+1,k}'
+    //   inward    y_k  = inv(L_kk) b_k + Gin_k y_pred,        Gin_k  = -inv(L_kk) M_in
+    //   outward   nu_k = inv(L_kk)' y_k + Gout_k nu_succ,     Gout_k = -inv(L_kk)' M_own'
     MPMPC_UNROLL
     for (int j = 0; j < 3; ++j) {
-      Gf[0 + j] = -(Li[0] * Ls[0 + j]);
-      Gf[3 + j] = -fma_(Li[2], Ls[3 + j], Li[1] * Ls[0 + j]);
-      Gf[6 + j] = -fma_(Li[5], Ls[6 + j], fma_(Li[4], Ls[3 + j], Li[3] * Ls[0 + j]));
+      Gin[0 + j] = -(Li[0] * Ls[0 + j]);
+      Gin[3 + j] = -fma_(Li[2], Ls[3 + j], Li[1] * Ls[0 + j]);
+      Gin[6 + j] = -fma_(Li[5], Ls[6 + j], fma_(Li[4], Ls[3 + j], Li[3] * Ls[0 + j]));
     }
-    R Ln[9];
     MPMPC_UNROLL
-    for (int i = 0; i < 9; ++i) Ln[i] = L::down(Ls[i]);          // L_{k+1,k}, row major
-    MPMPC_UNROLL
-    for (int j = 0; j < 3; ++j) {                                // Gb[i][j] = -sum_m Li[m][i] * Ln[j][m]
-      Gb[0 + j] = -fma_(Li[3], Ln[3 * j + 2], fma_(Li[1], Ln[3 * j + 1], Li[0] * Ln[3 * j + 0]));
-      Gb[3 + j] = -fma_(Li[4], Ln[3 * j + 2], Li[2] * Ln[3 * j + 1]);
-      Gb[6 + j] = -(Li[5] * Ln[3 * j + 2]);
+    for (int j = 0; j < 3; ++j) {                                // Gout[i][j] = -sum_m Li[m][i] * M[j][m]
+      R g0 = -fma_(Li[3], M[3 * j + 2], fma_(Li[1], M[3 * j + 1], Li[0] * M[3 * j + 0]));
+      R g1 = -fma_(Li[4], M[3 * j + 2], Li[2] * M[3 * j + 1]);
+      R g2 = -(Li[5] * M[3 * j + 2]);
+      Gout[0 + j] = sel(is_end, M[0 + j], g0);
+      Gout[3 + j] = sel(is_end, M[3 + j], g1);
+      Gout[6 + j] = sel(is_end, M[6 + j], g2);
     }
   }
 
   MPMPC_HD void s_solve(const R bv[3], R nu[3]) const {
     // lane-parallel part first, then two sweeps whose serial step is one 3x3 matrix-vector product
-    R c0 = Li[0] * bv[0];
-    R c1 = fma_(Li[2], bv[1], Li[1] * bv[0]);
-    R c2 = fma_(Li[5], bv[2], fma_(Li[4], bv[1], Li[3] * bv[0]));
+    R b0 = sel(vxc, L::mirror(bv[0]), R(0.0)), b1 = sel(vxc, L::mirror(bv[1]), R(0.0)), b2 = sel(vxc, L::mirror(bv[2]), R(0.0));
+    R c0 = Li[0] * b0;
+    R c1 = fma_(Li[2], b1, Li[1] * b0);
+    R c2 = fma_(Li[5], b2, fma_(Li[4], b1, Li[3] * b0));
+    const int last = chain_steps();
     R y0(0.0), y1(0.0), y2(0.0);
-    for (int s = 0; s <= N; ++s) {
-      R p0 = L::up(y0), p1 = L::up(y1), p2 = L::up(y2);
-      y0 = fma_(Gf[2], p2, fma_(Gf[1], p1, fma_(Gf[0], p0, c0)));
-      y1 = fma_(Gf[5], p2, fma_(Gf[4], p1, fma_(Gf[3], p0, c1)));
-      y2 = fma_(Gf[8], p2, fma_(Gf[7], p1, fma_(Gf[6], p0, c2)));
+    for (int s = 0; s < last; ++s) {
+      R p0 = L::cup(y0), p1 = L::cup(y1), p2 = L::cup(y2);
+      y0 = fma_(Gin[2], p2, fma_(Gin[1], p1, fma_(Gin[0], p0, c0)));
+      y1 = fma_(Gin[5], p2, fma_(Gin[4], p1, fma_(Gin[3], p0, c1)));
+      y2 = fma_(Gin[8], p2, fma_(Gin[7], p1, fma_(Gin[6], p0, c2)));
+    }
+    {
+      // inward junction: the end lane forms M_own y, mid takes it on top of its chain input
+      R t0 = fma_(Gout[2], y2, fma_(Gout[1], y1, Gout[0] * y0));
+      R t1 = fma_(Gout[5], y2, fma_(Gout[4], y1, Gout[3] * y0));
+      R t2 = fma_(Gout[8], y2, fma_(Gout[7], y1, Gout[6] * y0));
+      const R zero(0.0);
+      t0 = sel(is_mid, L::down(L::mirror(t0)), zero);
+      t1 = sel(is_mid, L::down(L::mirror(t1)), zero);
+      t2 = sel(is_mid, L::down(L::mirror(t2)), zero);
+      R e0 = c0 - Li[0] * t0;
+      R e1 = c1 - fma_(Li[2], t1, Li[1] * t0);
+      R e2 = c2 - fma_(Li[5], t2, fma_(Li[4], t1, Li[3] * t0));
+      R p0 = L::cup(y0), p1 = L::cup(y1), p2 = L::cup(y2);
+      y0 = fma_(Gin[2], p2, fma_(Gin[1], p1, fma_(Gin[0], p0, e0)));
+      y1 = fma_(Gin[5], p2, fma_(Gin[4], p1, fma_(Gin[3], p0, e1)));
+      y2 = fma_(Gin[8], p2, fma_(Gin[7], p1, fma_(Gin[6], p0, e2)));
     }
     R d0 = fma_(Li[3], y2, fma_(Li[1], y1, Li[0] * y0));
     R d1 = fma_(Li[4], y2, Li[2] * y1);
     R d2 = Li[5] * y2;
-    R n0(0.0), n1(0.0), n2(0.0);
-    for (int s = 0; s <= N; ++s) {
-      R p0 = L::down(n0), p1 = L::down(n1), p2 = L::down(n2);
-      n0 = fma_(Gb[2], p2, fma_(Gb[1], p1, fma_(Gb[0], p0, d0)));
-      n1 = fma_(Gb[5], p2, fma_(Gb[4], p1, fma_(Gb[3], p0, d1)));
-      n2 = fma_(Gb[8], p2, fma_(Gb[7], p1, fma_(Gb[6], p0, d2)));
+    {
+      // outward junction: nu of mid is final (it has no successor); the end lane takes it through M_own'
+      const R zero(0.0);
+      R m0 = sel(is_end, L::mirror(L::up(d0)), zero);
+      R m1 = sel(is_end, L::mirror(L::up(d1)), zero);
+      R m2 = sel(is_end, L::mirror(L::up(d2)), zero);
+      R w0 = fma_(Gout[6], m2, fma_(Gout[3], m1, Gout[0] * m0));
+      R w1 = fma_(Gout[7], m2, fma_(Gout[4], m1, Gout[1] * m0));
+      R w2 = fma_(Gout[8], m2, fma_(Gout[5], m1, Gout[2] * m0));
+      d0 = d0 - fma_(Li[3], w2, fma_(Li[1], w1, Li[0] * w0));
+      d1 = d1 - fma_(Li[4], w2, Li[2] * w1);
+      d2 = d2 - Li[5] * w2;
     }
-    nu[0] = n0; nu[1] = n1; nu[2] = n2;
+    R n0(0.0), n1(0.0), n2(0.0);
+    for (int s = 0; s <= last; ++s) {
+      R p0 = L::cdown(n0), p1 = L::cdown(n1), p2 = L::cdown(n2);
+      n0 = fma_(Gout[2], p2, fma_(Gout[1], p1, fma_(Gout[0], p0, d0)));
+      n1 = fma_(Gout[5], p2, fma_(Gout[4], p1, fma_(Gout[3], p0, d1)));
+      n2 = fma_(Gout[8], p2, fma_(Gout[7], p1, fma_(Gout[6], p0, d2)));
+    }
+    nu[0] = L::mirror(n0); nu[1] = L::mirror(n1); nu[2] = L::mirror(n2);
   }
 
   // [diag(1/hinv) Aeq'; Aeq -r I] [xt; nu] = [rx; req]

@@ -57,13 +57,13 @@ __global__ __launch_bounds__(K1_THREADS) void mpmpc_assemble_kernel(
   }
 }
 
-template <int G>
+template <int G, int C>
 __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, mpmpc_settings st, int B, int ld,
                                                          const double* __restrict__ qp, double* __restrict__ z,
                                                          double* __restrict__ u0, int* __restrict__ status,
                                                          int* __restrict__ iters, double* __restrict__ resid,
                                                          double* __restrict__ y) {
-  using L = LaneGpu<G>;
+  using L = LaneGpu<G, C>;
   const int inst = blockIdx.x * L::per_wave + L::slot();
   const int k = L::stage();
   Solver<L> s;
@@ -531,12 +531,14 @@ static int launch_solve(mpmpc_handle h, int B) {
   if (N + 1 <= 16 && B >= 8192) G = 16;
   const int per = 64 / G;
   const int blocks = (B + per - 1) / per;
-#define LAUNCH(GG)                                                                                         \
-  hipLaunchKernelGGL(mpmpc_solve_kernel<GG>, dim3(blocks), dim3(64), 0, h->stream, h->cfg, h->st, B, h->ld, \
+  const int C = lane_split(G, N);        // where the two elimination chains of the factorisation meet
+#define LAUNCH(GG, CC)                                                                                          \
+  hipLaunchKernelGGL((mpmpc_solve_kernel<GG, CC>), dim3(blocks), dim3(64), 0, h->stream, h->cfg, h->st, B, h->ld, \
                      h->qp, h->z, h->u0, h->status, h->iters, h->resid, h->y)
-  if (G == 64) LAUNCH(64);
-  else if (G == 32) LAUNCH(32);
-  else LAUNCH(16);
+  if (G == 64 && C == 16) LAUNCH(64, 16);
+  else if (G == 64) LAUNCH(64, 32);
+  else if (G == 32) LAUNCH(32, 16);
+  else LAUNCH(16, 16);
 #undef LAUNCH
   HIP_TRY(hipGetLastError());
   return MPMPC_OK;

@@ -10,10 +10,10 @@
 
 using namespace mpmpc;
 
-template <int G>
+template <int G, int C>
 static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z,
                     double* u0, int* status, int* iters, double* resid, double* y) {
-  using L = LaneEmu<G>;
+  using L = LaneEmu<G, C>;
   const int ld = stage_ld(cfg->N);
   const int per = L::per_wave;
   for (int w0 = 0; w0 < B; w0 += per) {
@@ -28,9 +28,11 @@ static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const dou
 extern "C" int emu_solve(const mpmpc_config* cfg, const mpmpc_settings* st, int G, const double* qp, int B,
                          double* z, double* u0, int* status, int* iters, double* resid, double* y) {
   if (cfg->N + 1 > G) return -1;
-  if (G == 64) solve_g<64>(cfg, st, qp, B, z, u0, status, iters, resid, y);
-  else if (G == 32) solve_g<32>(cfg, st, qp, B, z, u0, status, iters, resid, y);
-  else if (G == 16) solve_g<16>(cfg, st, qp, B, z, u0, status, iters, resid, y);
+  const int C = lane_split(G, cfg->N);       // same variant as the launcher picks
+  if (G == 64 && C == 16) solve_g<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y);
+  else if (G == 64) solve_g<64, 32>(cfg, st, qp, B, z, u0, status, iters, resid, y);
+  else if (G == 32) solve_g<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y);
+  else if (G == 16) solve_g<16, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y);
   else return -1;
   return 0;
 }
