@@ -51,10 +51,13 @@ def k2_bytes_per_solve(N):
 
 def k2_flops_per_solve(N, admm_iters, ipm_iters):
     """Useful FP64 flops of one solve: per-lane instruction census of the lock-step emulation
-    (tests/emul, -DMPMPC_COUNT_OPS; FMA = 2) times the N+1 lanes that hold a stage.  Setup (Ruiz
-    scaling + first factorisation) 4.3 k, 1.31 k per ADMM iteration, 8.9 k per interior-point
-    iteration of the polish (its active-set rounds amortised in).  DESIGN.md section 5."""
-    return (N + 1) * (4.3e3 + 1.31e3 * admm_iters + 8.9e3 * ipm_iters)
+    (profiles/census.py: tests/emul with -DMPMPC_COUNT_OPS; FMA = 2, add/mul/div/sqrt = 1) times the
+    N+1 lanes that hold a stage.  Fitted per lane as setup + a * ADMM iterations + b * interior-point
+    iterations (active-set rounds and certificate amortised into b) at N = 30 and N = 50, linear in N
+    between: 2710 + 842 a + 5457 b and 1833 + 1424 a + 9296 b (rms error 4-6 %).  DESIGN.md section 5."""
+    t = (N - 30) / 20.0
+    c0, c1, c2 = 2710 + t * (1833 - 2710), 842.3 + t * (1424 - 842.3), 5457 + t * (9296 - 5457)
+    return (N + 1) * (c0 + c1 * admm_iters + c2 * ipm_iters)
 
 
 def cpu_baseline(tr, sc, seconds=15.0):
@@ -173,7 +176,7 @@ def main():
                                 "achieved": flops_k2 / (ms_k2 * 1e-3) / 1e12, "peak": FP64_VALU_PEAK / 1e12,
                                 "unit": "TFLOP/s", "frac": flops_k2 / (ms_k2 * 1e-3) / FP64_VALU_PEAK,
                                 "flops_per_solve_mean": flops_k2 / B,
-                                "note": "useful flops (31 of 64 lanes hold a stage at N=30); the slowest wave sets the time"}
+                                "note": "useful flops (N+1 of an instance's lanes hold a stage); the slowest wave sets the time"}
         bytes_k1 = k1_bytes_per_solve(N) * B
         out["roofline_assembly"] = {"bound": "hbm", "kernel": "mpmpc_assemble_kernel",
                                     "achieved": bytes_k1 / (ms_k1 * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
