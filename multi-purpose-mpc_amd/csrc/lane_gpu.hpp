@@ -17,6 +17,15 @@ __device__ __forceinline__ double rsqrt_(double a) {
   e = __builtin_fma(-(a * r), r, 1.0);
   return __builtin_fma(r * e, 0.5, r);
 }
+// 1/a: hardware seed (v_rcp_f64) + two Newton steps in FMA form; a product with it replaces the
+// full IEEE division sequence where the last bit does not matter (interior-point iteration)
+__device__ __forceinline__ double rcp_(double a) {
+  double r = __builtin_amdgcn_rcp(a);
+  double e = __builtin_fma(-a, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-a, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
 __device__ __forceinline__ double abs_(double a) { return __builtin_fabs(a); }
 __device__ __forceinline__ double max_(double a, double b) { return __builtin_fmax(a, b); }   // v_max_f64
 __device__ __forceinline__ double min_(double a, double b) { return __builtin_fmin(a, b); }   // v_min_f64

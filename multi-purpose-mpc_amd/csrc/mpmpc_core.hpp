@@ -796,7 +796,7 @@ struct Solver {
     R x[5], nu[3], sl[5], su[5], zl[5], zu[5], pi[5];
   };
   MPMPC_HD Mk ipm(const Box& bx, Ipm& s, const mpmpc_settings& st, double tol, const Mk& run) {
-    const R reg(st.ipm_reg), one(1.0), zero(0.0);
+    const R reg(st.ipm_reg), ireg(1.0 / st.ipm_reg), one(1.0), zero(0.0);
     Mk active = run, conv = L::mfalse();
     R cnt(0.0);
     MPMPC_UNROLL
@@ -828,14 +828,16 @@ struct Solver {
       active = active & !ok;
       if (it == st.ipm_max_iter || !L::wany(active)) break;
       ipm_iters = seli(active, ipm_iters + I(1), ipm_iters);
-      // ---- factor
-      R h[5];
+      // ---- factor.  Every division by a slack below is a product with its reciprocal, taken once.
+      R isl[5], isu[5], h[5];
       MPMPC_UNROLL
-      for (int j = 0; j < 5; ++j) {
-        R H = p[j] + reg + sel(bx.Lm[j], s.zl[j] / s.sl[j], zero) + sel(bx.Um[j], s.zu[j] / s.su[j], zero) +
-              sel(bx.pin[j], one / reg, zero);
-        h[j] = one / H;
-      }
+      for (int j = 0; j < 5; ++j) { isl[j] = rcp_(s.sl[j]); isu[j] = rcp_(s.su[j]); }
+      auto H_of = [&](int j) {
+        return p[j] + reg + sel(bx.Lm[j], s.zl[j] * isl[j], zero) + sel(bx.Um[j], s.zu[j] * isu[j], zero) +
+               sel(bx.pin[j], ireg, zero);
+      };
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) h[j] = rcp_(H_of(j));
       factor(h, reg);
       // ---- predictor and corrector share the factorisation
       R dx[5], dnu[3], dsl[5], dsu[5], dzl[5], dzu[5], dpi[5];
@@ -847,8 +849,8 @@ struct Solver {
         R rhs[5], nreq[3];
         MPMPC_UNROLL
         for (int j = 0; j < 5; ++j)
-          rhs[j] = -rd[j] - sel(bx.Lm[j], (rcl[j] + s.zl[j] * rl_of(j)) / s.sl[j], zero) +
-                   sel(bx.Um[j], (rcu[j] + s.zu[j] * ru_of(j)) / s.su[j], zero) - sel(bx.pin[j], rpin_of(j) / reg, zero);
+          rhs[j] = -rd[j] - sel(bx.Lm[j], (rcl[j] + s.zl[j] * rl_of(j)) * isl[j], zero) +
+                   sel(bx.Um[j], (rcu[j] + s.zu[j] * ru_of(j)) * isu[j], zero) - sel(bx.pin[j], rpin_of(j) * ireg, zero);
         MPMPC_UNROLL
         for (int i = 0; i < 3; ++i) nreq[i] = -rp[i];
         kkt_solve(rhs, nreq, dx, dnu);
@@ -857,7 +859,7 @@ struct Solver {
           AeqT_mul(dnu, At2);
           Aeq_mul(dx, Ad);
           MPMPC_UNROLL
-          for (int j = 0; j < 5; ++j) r1[j] = rhs[j] - (dx[j] / hinv[j] + At2[j]);
+          for (int j = 0; j < 5; ++j) r1[j] = rhs[j] - fma_(dx[j], H_of(j), At2[j]);
           MPMPC_UNROLL
           for (int i = 0; i < 3; ++i) r2[i] = nreq[i] - (Ad[i] - reg * dnu[i]);
           kkt_solve(r1, r2, ddx, ddnu);
@@ -866,20 +868,20 @@ struct Solver {
           MPMPC_UNROLL
           for (int i = 0; i < 3; ++i) dnu[i] = dnu[i] + ddnu[i];
         }
-        R ratio(1e300);
+        // largest step that keeps slacks and multipliers positive: 1 / max(-ds/s, -dz/z)
+        R blk(0.0);
         MPMPC_UNROLL
         for (int j = 0; j < 5; ++j) {
           dsl[j] = sel(bx.Lm[j], dx[j] + rl_of(j), zero);
           dsu[j] = sel(bx.Um[j], -dx[j] + ru_of(j), zero);
-          dzl[j] = sel(bx.Lm[j], (-rcl[j] - s.zl[j] * dsl[j]) / s.sl[j], zero);
-          dzu[j] = sel(bx.Um[j], (-rcu[j] - s.zu[j] * dsu[j]) / s.su[j], zero);
-          dpi[j] = sel(bx.pin[j], (rpin_of(j) + dx[j]) / reg, zero);
-          ratio = min_(ratio, sel(bx.Lm[j] & (dsl[j] < zero), -s.sl[j] / dsl[j], R(1e300)));
-          ratio = min_(ratio, sel(bx.Um[j] & (dsu[j] < zero), -s.su[j] / dsu[j], R(1e300)));
-          ratio = min_(ratio, sel(bx.Lm[j] & (dzl[j] < zero), -s.zl[j] / dzl[j], R(1e300)));
-          ratio = min_(ratio, sel(bx.Um[j] & (dzu[j] < zero), -s.zu[j] / dzu[j], R(1e300)));
+          dzl[j] = sel(bx.Lm[j], (-rcl[j] - s.zl[j] * dsl[j]) * isl[j], zero);
+          dzu[j] = sel(bx.Um[j], (-rcu[j] - s.zu[j] * dsu[j]) * isu[j], zero);
+          dpi[j] = sel(bx.pin[j], (rpin_of(j) + dx[j]) * ireg, zero);
+          blk = max_(blk, max_(sel(bx.Lm[j], -dsl[j] * isl[j], zero), sel(bx.Um[j], -dsu[j] * isu[j], zero)));
+          blk = max_(blk, max_(sel(bx.Lm[j], -dzl[j] * rcp_(s.zl[j]), zero), sel(bx.Um[j], -dzu[j] * rcp_(s.zu[j]), zero)));
         }
-        ratio = L::gmin(ratio);
+        blk = L::gmax(blk);
+        R ratio = sel(blk > zero, rcp_(blk), R(1e300));
         if (pass == 0) {
           alpha_aff = min_(one, ratio);
           R ms(0.0);
