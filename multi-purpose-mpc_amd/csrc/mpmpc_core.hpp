@@ -172,8 +172,10 @@ struct Solver {
   Mk down_chain, is_mid, is_end, vxc;   // twisted factorisation: k >= C; chain-layout lanes C-1, 2C-1; chain-layout vx
   Mk valid[5];
   Mk live;               // this lane's instance exists
-  // ---- unscaled bounds kept for the certificate
-  R lo0[5], hi0[5], beq0[3];
+  // ---- where this lane's stage fields live (the unscaled bounds are re-read for the certificate)
+  const double* qp_;
+  I base_;
+  int fstride_;
   // ---- scaled problem
   R mI[3], a[6], b[2], g[5], p[5], q[5], D[5], Eeq[3], Eb[5], c;
   R leq[3], lb[5], ub[5];
@@ -182,7 +184,8 @@ struct Solver {
   // ---- ADMM state
   R x[5], zeq[3], zb[5], yeq[3], yb[5];
   R rho, rb[5], rbinv[5], rho_eq, rinv_eq;
-  R xprev[5], dyeq[3], dyb[5];
+  // (the last step's x_prev, dy_eq, dy_box live in cold storage, slots 18..30: only the
+  //  infeasibility tests read them)
   // ---- results
   I status, iters, ipm_iters, polished;
   R pri_res, dua_res;
@@ -236,6 +239,12 @@ struct Solver {
   }
 
   // ======================================================================== setup
+  // field f of this lane's stage, straight from the stage-blocked QP; bounds clipped like OSQP does
+  MPMPC_HD R raw(int f, double dflt) const { return L::load(qp_, base_ + f * fstride_, vx, dflt); }
+  MPMPC_HD R beq_raw(int i) const { return raw(F_BEQ + i, 0.0); }
+  MPMPC_HD R lo_raw(int j) const { return max_(raw(F_LO + j, -INFTY), R(-INFTY)); }
+  MPMPC_HD R hi_raw(int j) const { return min_(raw(F_HI + j, INFTY), R(INFTY)); }
+
   MPMPC_HD void load(const double* qp, int B, int ld, const I& inst, const I& k, int N_) {
     N = N_;
     n_inst = B;
@@ -253,18 +262,18 @@ struct Solver {
     }
     valid[0] = valid[1] = valid[2] = vx;
     valid[3] = valid[4] = vu;
-    I base = inst * ld + k;
-    auto fld = [&](int f, double dflt) { return L::load(qp, base + f * (B * ld), vx, dflt); };
+    qp_ = qp;
+    base_ = inst * ld + k;
+    fstride_ = B * ld;
+    auto fld = [&](int f, double dflt) { return raw(f, dflt); };
     R ds = fld(F_DS, 0.0), a10 = fld(F_A10, 0.0), a20 = fld(F_A20, 0.0), b20 = fld(F_B20, 0.0);
     R one = sel(vu, R(1.0), R(0.0));
     a[0] = one; a[1] = ds; a[2] = a10; a[3] = one; a[4] = a20; a[5] = one;
     b[0] = ds; b[1] = b20;
     MPMPC_UNROLL
-    for (int i = 0; i < 3; ++i) { beq0[i] = fld(F_BEQ + i, 0.0); mI[i] = R(-1.0); Eeq[i] = R(1.0); }
+    for (int i = 0; i < 3; ++i) { mI[i] = R(-1.0); Eeq[i] = R(1.0); }
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) {
-      lo0[j] = max_(fld(F_LO + j, -INFTY), R(-INFTY));
-      hi0[j] = min_(fld(F_HI + j, INFTY), R(INFTY));
       q[j] = fld(F_Q + j, 0.0);
       p[j] = fld(F_P + j, 1.0);
       g[j] = R(1.0); D[j] = R(1.0); Eb[j] = R(1.0);
@@ -324,9 +333,9 @@ struct Solver {
       c = c * ct;
     }
     MPMPC_UNROLL
-    for (int i = 0; i < 3; ++i) leq[i] = Eeq[i] * beq0[i];
+    for (int i = 0; i < 3; ++i) leq[i] = Eeq[i] * beq_raw(i);
     MPMPC_UNROLL
-    for (int j = 0; j < 5; ++j) { lb[j] = Eb[j] * lo0[j]; ub[j] = Eb[j] * hi0[j]; }
+    for (int j = 0; j < 5; ++j) { lb[j] = Eb[j] * lo_raw(j); ub[j] = Eb[j] * hi_raw(j); }
   }
 
   // OSQP set_rho_vec(): per-row step size by constraint type
@@ -592,7 +601,9 @@ struct Solver {
 
   // OSQP is_primal_infeasible() on the last dual step
   MPMPC_HD Mk primal_infeasible(double eps) const {
-    R nrm(0.0), lhs(0.0), pd[5];
+    R nrm(0.0), lhs(0.0), pd[5], dyeq[3];
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) dyeq[i] = L::cold_get(COLD_DYEQ + i);
     MPMPC_UNROLL
     for (int i = 0; i < 3; ++i) {
       nrm = max_(nrm, sel(vx, abs_(Eeq[i] * dyeq[i]), R(0.0)));
@@ -601,7 +612,7 @@ struct Solver {
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) {
       Mk lo_inf = lb[j] < R(-INF_BOUND), up_inf = ub[j] > R(INF_BOUND);
-      R d = dyb[j];
+      R d = L::cold_get(COLD_DYB + j);
       d = sel(up_inf & lo_inf, R(0.0), sel(up_inf, min_(d, R(0.0)), sel(lo_inf, max_(d, R(0.0)), d)));
       pd[j] = d;
       nrm = max_(nrm, sel(valid[j], abs_(Eb[j] * d), R(0.0)));
@@ -623,7 +634,7 @@ struct Solver {
     R dx[5], nrm(0.0), qdx(0.0), pm(0.0);
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) {
-      dx[j] = x[j] - xprev[j];
+      dx[j] = x[j] - L::cold_get(COLD_XPREV + j);
       nrm = max_(nrm, sel(valid[j], abs_(D[j] * dx[j]), R(0.0)));
       qdx = qdx + sel(valid[j], q[j] * dx[j], R(0.0));
       pm = max_(pm, sel(valid[j], abs_((p[j] * dx[j]) / D[j]), R(0.0)));
@@ -661,6 +672,10 @@ struct Solver {
 
   // Scalings D, E, the cost diagonal and the previous iterate are only read at termination checks:
   // they live in cold storage between checks.
+  static constexpr int COLD_XPREV = 18, COLD_DYEQ = 23, COLD_DYB = 26;
+  MPMPC_HD static void put_delta(const Mk& on, int slot, const R& v) {
+    if constexpr (L::per_wave == 1) L::cold_put(slot, v); else L::cold_put(slot, sel(on, v, L::cold_get(slot)));
+  }
   MPMPC_HD void park_check_data() const {
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) { L::cold_put(j, D[j]); L::cold_put(5 + j, Eb[j]); L::cold_put(10 + j, p[j]); }
@@ -683,11 +698,11 @@ struct Solver {
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) {
       x[j] = keep(which, zero, x[j]); zb[j] = keep(which, zero, zb[j]); yb[j] = keep(which, zero, yb[j]);
-      xprev[j] = keep(which, zero, xprev[j]); dyb[j] = keep(which, zero, dyb[j]);
+      put_delta(which, COLD_XPREV + j, zero); put_delta(which, COLD_DYB + j, zero);
     }
     MPMPC_UNROLL
     for (int i = 0; i < 3; ++i) {
-      zeq[i] = keep(which, zero, zeq[i]); yeq[i] = keep(which, zero, yeq[i]); dyeq[i] = keep(which, zero, dyeq[i]);
+      zeq[i] = keep(which, zero, zeq[i]); yeq[i] = keep(which, zero, yeq[i]); put_delta(which, COLD_DYEQ + i, zero);
     }
     status = keepi(which, I(MPMPC_UNSOLVED), status);
     iters = keepi(which, I(0), iters);
@@ -711,32 +726,42 @@ struct Solver {
       MPMPC_UNROLL
       for (int i = 0; i < 3; ++i) req[i] = fma_(-yeq[i], rinv_eq, zeq[i]);
       kkt_solve(rx, req, xt, nu);
+      // the last step's (dx, dy) feed the infeasibility tests only: keep them where a check follows
+      const bool can_check = st.check_termination > 0 && (it % st.check_termination) == 0;
+      const bool can_adapt = st.adaptive_rho && st.adaptive_rho_interval > 0 && (it % st.adaptive_rho_interval) == 0;
+      const bool want_delta = can_check || it == limit;
+      if (want_delta) {
+        MPMPC_UNROLL
+        for (int j = 0; j < 5; ++j) put_delta(active, COLD_XPREV + j, x[j]);
+      }
+      R dyb_n[5], dyeq_n[3];
       MPMPC_UNROLL
       for (int j = 0; j < 5; ++j) {
         R xn = fma_(alpha, xt[j], oma * x[j]);
         R zr = fma_(alpha, g[j] * xt[j], oma * zb[j]);
         R zn = min_(max_(fma_(yb[j], rbinv[j], zr), lb[j]), ub[j]);
-        R dy = rb[j] * (zr - zn);
-        xprev[j] = keep(active, x[j], xprev[j]);
+        dyb_n[j] = rb[j] * (zr - zn);
         x[j] = keep(active, xn, x[j]);
         zb[j] = keep(active, zn, zb[j]);
-        dyb[j] = keep(active, dy, dyb[j]);
-        yb[j] = keep(active, yb[j] + dy, yb[j]);
+        yb[j] = keep(active, yb[j] + dyb_n[j], yb[j]);
       }
       MPMPC_UNROLL
       for (int i = 0; i < 3; ++i) {
         R zt = fma_(nu[i] - yeq[i], rinv_eq, zeq[i]);
         R zr = fma_(alpha, zt, oma * zeq[i]);
         R zn = leq[i];                                   // projection onto [l, l]
-        R dy = rho_eq * (zr - zn);
+        dyeq_n[i] = rho_eq * (zr - zn);
         zeq[i] = keep(active, zn, zeq[i]);
-        dyeq[i] = keep(active, dy, dyeq[i]);
-        yeq[i] = keep(active, yeq[i] + dy, yeq[i]);
+        yeq[i] = keep(active, yeq[i] + dyeq_n[i], yeq[i]);
+      }
+      if (want_delta) {
+        MPMPC_UNROLL
+        for (int j = 0; j < 5; ++j) put_delta(active, COLD_DYB + j, dyb_n[j]);
+        MPMPC_UNROLL
+        for (int i = 0; i < 3; ++i) put_delta(active, COLD_DYEQ + i, dyeq_n[i]);
       }
       iters = keepi(active, I(it), iters);
       // ---- termination
-      bool can_check = st.check_termination > 0 && (it % st.check_termination) == 0;
-      bool can_adapt = st.adaptive_rho && st.adaptive_rho_interval > 0 && (it % st.adaptive_rho_interval) == 0;
       if (can_check || can_adapt) { unpark_check_data(); info(nf); }
       if (can_check) {
         I stt = check(nf, st, false);
@@ -854,19 +879,31 @@ struct Solver {
         MPMPC_UNROLL
         for (int i = 0; i < 3; ++i) nreq[i] = -rp[i];
         kkt_solve(rhs, nreq, dx, dnu);
-        if (pass == 1) {   // the corrector direction gets one refinement step; the predictor only steers sigma
+        if (pass == 1) {   // the corrector direction gets one refinement step where the solve left a visible
+                           // residual (ill-conditioned late iterations); the predictor only steers sigma
           R At2[5], Ad[3], r1[5], r2[3], ddx[5], ddnu[3];
           AeqT_mul(dnu, At2);
           Aeq_mul(dx, Ad);
+          R big(0.0), ref(0.0);
           MPMPC_UNROLL
-          for (int j = 0; j < 5; ++j) r1[j] = rhs[j] - fma_(dx[j], H_of(j), At2[j]);
+          for (int j = 0; j < 5; ++j) {
+            r1[j] = rhs[j] - fma_(dx[j], H_of(j), At2[j]);
+            big = max_(big, sel(valid[j], abs_(r1[j]), zero));
+            ref = max_(ref, sel(valid[j], abs_(rhs[j]), zero));
+          }
           MPMPC_UNROLL
-          for (int i = 0; i < 3; ++i) r2[i] = nreq[i] - (Ad[i] - reg * dnu[i]);
-          kkt_solve(r1, r2, ddx, ddnu);
-          MPMPC_UNROLL
-          for (int j = 0; j < 5; ++j) dx[j] = dx[j] + ddx[j];
-          MPMPC_UNROLL
-          for (int i = 0; i < 3; ++i) dnu[i] = dnu[i] + ddnu[i];
+          for (int i = 0; i < 3; ++i) {
+            r2[i] = nreq[i] - (Ad[i] - reg * dnu[i]);
+            big = max_(big, sel(vx, abs_(r2[i]), zero));
+            ref = max_(ref, sel(vx, abs_(nreq[i]), zero));
+          }
+          if (L::wany(active & (L::gmax(big) > R(1e-10) * L::gmax(ref)))) {
+            kkt_solve(r1, r2, ddx, ddnu);
+            MPMPC_UNROLL
+            for (int j = 0; j < 5; ++j) dx[j] = dx[j] + ddx[j];
+            MPMPC_UNROLL
+            for (int i = 0; i < 3; ++i) dnu[i] = dnu[i] + ddnu[i];
+          }
         }
         // largest step that keeps slacks and multipliers positive: 1 / max(-ds/s, -dz/z)
         R blk(0.0);
@@ -1005,14 +1042,15 @@ struct Solver {
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) {
       R xu = D[j] * xs[j];
-      R viol = max_(max_(lo0[j] - xu, xu - hi0[j]), R(0.0));
+      const R lo0 = lo_raw(j), hi0 = hi_raw(j);
+      R viol = max_(max_(lo0 - xu, xu - hi0), R(0.0));
       pv = max_(pv, sel(valid[j], viol, R(0.0)));
       R rd = fma_(p[j], xs[j], q[j]) + At[j] + lam[j];
       sv = max_(sv, sel(valid[j], abs_(rd / D[j]) * cinv, R(0.0)));
       R yu = (lam[j] / D[j]) * cinv;                      // multiplier of the unscaled box row
-      Mk fu = hi0[j] < R(INF_BOUND), fl = lo0[j] > R(-INF_BOUND);
-      R cu = sel(fu, max_(yu, R(0.0)) * abs_(hi0[j] - xu), sel(yu > R(0.0), R(1e300), R(0.0)));
-      R cl = sel(fl, max_(-yu, R(0.0)) * abs_(xu - lo0[j]), sel(yu < R(0.0), R(1e300), R(0.0)));
+      Mk fu = hi0 < R(INF_BOUND), fl = lo0 > R(-INF_BOUND);
+      R cu = sel(fu, max_(yu, R(0.0)) * abs_(hi0 - xu), sel(yu > R(0.0), R(1e300), R(0.0)));
+      R cl = sel(fl, max_(-yu, R(0.0)) * abs_(xu - lo0), sel(yu < R(0.0), R(1e300), R(0.0)));
       cv = max_(cv, sel(valid[j], max_(cu, cl), R(0.0)));
     }
     // a NaN iterate must never pass: compare every entry against a finite bound explicitly
