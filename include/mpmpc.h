@@ -169,6 +169,19 @@ int mpmpc_download(mpmpc_handle h, int32_t B, double* z, double* u0, int32_t* st
 /* one resident pass with HIP events around each kernel on the handle's stream (ms) */
 int mpmpc_solve_resident_timed(mpmpc_handle h, int32_t B, float* ms_assemble, float* ms_solve);
 
+/* ---- speed profile (K4): replaces ReferencePath.compute_speed_profile, src/reference_path.py:289-354,
+ * the reference's second OSQP call site, for B paths of n + 1 waypoints at once (no handle needed):
+ *     min 1/2 |v|^2 - vmax' v   s.t.  a_min <= (v[i+1] - v[i]) / (2 li[i]) <= a_max,  v_min <= v[i] <= vmax[i],
+ *     vmax[i] = min(v_max, sqrt(ay_max / (|kappa[i]| + eps)))
+ * li [B][n]      distance waypoint i -> i+1            (src/reference_path.py:318)
+ * kappa [B][n]   curvature of waypoint i               (src/reference_path.py:320)
+ * limits [B][5]  a_min, a_max, v_min, v_max, ay_max    (the Constraints dict, src/reference_path.py:301-307)
+ * v [B][n]       <- speed_profile (the caller copies v[n-1] to the last waypoint, src/reference_path.py:351-353)
+ * status [B]     <- 1 KKT-certified optimum, 2 interior-point iterate (uncertified), -1 bad input
+ * iters [B]      <- interior-point iterations (may be NULL)                                              */
+int mpmpc_speed_profile(int32_t device, int32_t B, int32_t n, const double* li, const double* kappa,
+                        const double* limits, double eps, double* v, int32_t* status, int32_t* iters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,7 @@
 #include "mpmpc_core.hpp"
 #include "corridor_core.hpp"
 #include "rollout_core.hpp"
+#include "speed_core.hpp"
 
 using namespace mpmpc;
 
@@ -69,6 +70,40 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, mpmpc
   Solver<L> s;
   s.run(qp, B, ld, inst, k, cfg.N, st);
   s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y);
+}
+
+// K4: speed profile, one thread per path (a serial interior-point / active-set run over a scalar
+// tridiagonal system, speed_core.hpp); the workspace is path-minor so that the threads of a wave
+// touch consecutive addresses.
+__global__ __launch_bounds__(64) void mpmpc_speed_profile_kernel(int B, int n, const double* __restrict__ li,
+                                                                 const double* __restrict__ kappa,
+                                                                 const double* __restrict__ limits, double eps,
+                                                                 double* __restrict__ work, double* __restrict__ v,
+                                                                 int* __restrict__ status, int* __restrict__ iters) {
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= B) return;
+  SpWork W{work + p, n, B};
+  SpLimits lim{limits[5 * p], limits[5 * p + 1], limits[5 * p + 2], limits[5 * p + 3], limits[5 * p + 4]};
+  int it = 0;
+  status[p] = sp_solve(n, li + (long)p * n, kappa + (long)p * n, 1, lim, eps, W, v + (long)p * n, 1, &it);
+  iters[p] = it;
+}
+
+// Few paths (the usual case is one): one path per block with the workspace in LDS, so that the serial
+// run is bound by LDS latency instead of HBM latency.
+__global__ __launch_bounds__(64) void mpmpc_speed_profile_lds_kernel(int B, int n, const double* __restrict__ li,
+                                                                     const double* __restrict__ kappa,
+                                                                     const double* __restrict__ limits, double eps,
+                                                                     double* __restrict__ v, int* __restrict__ status,
+                                                                     int* __restrict__ iters) {
+  extern __shared__ double sp_lds[];
+  const int p = blockIdx.x;
+  if (threadIdx.x != 0 || p >= B) return;
+  SpWork W{sp_lds, n, 1};
+  SpLimits lim{limits[5 * p], limits[5 * p + 1], limits[5 * p + 2], limits[5 * p + 3], limits[5 * p + 4]};
+  int it = 0;
+  status[p] = sp_solve(n, li + (long)p * n, kappa + (long)p * n, 1, lim, eps, W, v + (long)p * n, 1, &it);
+  iters[p] = it;
 }
 
 // K0a: free segments of every waypoint's border line (one thread per waypoint; the rasterised line
@@ -568,6 +603,57 @@ int mpmpc_solve_resident_timed(mpmpc_handle h, int32_t B, float* ms_assemble, fl
   if (ms_assemble) *ms_assemble = a;
   if (ms_solve) *ms_solve = s;
   return MPMPC_OK;
+}
+
+int mpmpc_speed_profile(int32_t device, int32_t B, int32_t n, const double* li, const double* kappa,
+                        const double* limits, double eps, double* v, int32_t* status, int32_t* iters) {
+  if (B < 1 || n < 2) return fail(MPMPC_E_ARG, "speed profile needs B >= 1 paths of n >= 2 segments");
+  if (!li || !kappa || !limits || !v || !status) return fail(MPMPC_E_ARG, "li, kappa, limits, v, status must not be NULL");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(MPMPC_E_HIP, "no such HIP device");
+  HIP_TRY(hipSetDevice(device));
+  const size_t vec = sizeof(double) * (size_t)B * n;
+  double *d_li = nullptr, *d_kappa = nullptr, *d_lim = nullptr, *d_work = nullptr, *d_v = nullptr;
+  int *d_status = nullptr, *d_iters = nullptr;
+  hipStream_t stream = nullptr;
+  int rc = MPMPC_OK;
+#define SP_TRY(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess && rc == MPMPC_OK)                                                \
+      rc = fail(MPMPC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+  } while (0)
+  SP_TRY(hipStreamCreate(&stream));
+  SP_TRY(hipMalloc(&d_li, vec));
+  SP_TRY(hipMalloc(&d_kappa, vec));
+  SP_TRY(hipMalloc(&d_v, vec));
+  SP_TRY(hipMalloc(&d_lim, sizeof(double) * 5 * B));
+  SP_TRY(hipMalloc(&d_work, vec * SP_ARRAYS));
+  SP_TRY(hipMalloc(&d_status, sizeof(int) * B));
+  SP_TRY(hipMalloc(&d_iters, sizeof(int) * B));
+  if (rc == MPMPC_OK) {
+    SP_TRY(hipMemcpyAsync(d_li, li, vec, hipMemcpyHostToDevice, stream));
+    SP_TRY(hipMemcpyAsync(d_kappa, kappa, vec, hipMemcpyHostToDevice, stream));
+    SP_TRY(hipMemcpyAsync(d_lim, limits, sizeof(double) * 5 * B, hipMemcpyHostToDevice, stream));
+    const size_t lds = sizeof(double) * SP_ARRAYS * (size_t)n;
+    if (B <= 256 && lds <= 64 * 1024)
+      hipLaunchKernelGGL(mpmpc_speed_profile_lds_kernel, dim3(B), dim3(64), lds, stream, B, n, d_li, d_kappa, d_lim, eps,
+                         d_v, d_status, d_iters);
+    else
+      hipLaunchKernelGGL(mpmpc_speed_profile_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, B, n, d_li, d_kappa, d_lim,
+                         eps, d_work, d_v, d_status, d_iters);
+    SP_TRY(hipGetLastError());
+    SP_TRY(hipMemcpyAsync(v, d_v, vec, hipMemcpyDeviceToHost, stream));
+    SP_TRY(hipMemcpyAsync(status, d_status, sizeof(int) * B, hipMemcpyDeviceToHost, stream));
+    if (iters) SP_TRY(hipMemcpyAsync(iters, d_iters, sizeof(int) * B, hipMemcpyDeviceToHost, stream));
+    SP_TRY(hipStreamSynchronize(stream));
+  }
+#undef SP_TRY
+  for (void* ptr : {(void*)d_li, (void*)d_kappa, (void*)d_v, (void*)d_lim, (void*)d_work, (void*)d_status, (void*)d_iters})
+    (void)hipFree(ptr);
+  if (stream) (void)hipStreamDestroy(stream);
+  return rc;
 }
 
 int mpmpc_sync(mpmpc_handle h) {

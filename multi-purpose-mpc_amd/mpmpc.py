@@ -126,6 +126,7 @@ def load_library(path: str | None = None):
     lib.mpmpc_sync.argtypes = [h]
     lib.mpmpc_download.argtypes = [h, C.c_int32, _dp, _dp, _ip, _ip, _dp, _dp]
     lib.mpmpc_solve_resident_timed.argtypes = [h, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.mpmpc_speed_profile.argtypes = [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_double, _dp, _ip, _ip]
     if path is None:
         _lib = lib
     return lib
@@ -135,7 +136,7 @@ EXPORTS = ["mpmpc_version", "mpmpc_last_error", "mpmpc_device_count", "mpmpc_def
            "mpmpc_create", "mpmpc_destroy", "mpmpc_set_settings", "mpmpc_set_path", "mpmpc_set_corridor",
            "mpmpc_set_map", "mpmpc_set_path_geometry", "mpmpc_build_corridor", "mpmpc_rollout_init",
            "mpmpc_rollout_step", "mpmpc_rollout_state", "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident",
-           "mpmpc_sync", "mpmpc_download", "mpmpc_solve_resident_timed"]
+           "mpmpc_sync", "mpmpc_download", "mpmpc_solve_resident_timed", "mpmpc_speed_profile"]
 
 
 class MpmpcError(RuntimeError):
@@ -309,3 +310,22 @@ def device_count() -> int:
     n = C.c_int32(0)
     rc = load_library().mpmpc_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+def speed_profile(li, kappa, limits, eps=1e-12, device=0):
+    """Speed profiles of B paths on the device (K4, replaces compute_speed_profile's OSQP call,
+    src/reference_path.py:289-354).  li, kappa [B, n] (or [n]); limits [B, 5] (or [5]) =
+    (a_min, a_max, v_min, v_max, ay_max).  -> (v [B, n], status [B], iters [B])."""
+    lib = load_library()
+    li = np.atleast_2d(np.ascontiguousarray(li, float))
+    kappa = np.atleast_2d(np.ascontiguousarray(kappa, float))
+    B, n = li.shape
+    if kappa.shape != (B, n):
+        raise ValueError("li and kappa must have the same shape")
+    limits = np.ascontiguousarray(np.broadcast_to(np.atleast_2d(np.asarray(limits, float)), (B, 5)))
+    v = np.zeros((B, n))
+    status, iters = np.zeros(B, np.int32), np.zeros(B, np.int32)
+    rc = lib.mpmpc_speed_profile(device, B, n, _d(li), _d(kappa), _d(limits), float(eps), _d(v), _i(status), _i(iters))
+    if rc != 0:
+        raise MpmpcError("mpmpc_speed_profile: %s (rc=%d)" % (lib.mpmpc_last_error().decode(), rc))
+    return v, status, iters

@@ -180,10 +180,19 @@ class ReferencePath:
         A = np.vstack([D1, np.eye(n)])
         return np.eye(n), -1 * v_max, A, np.hstack([a_min, v_min]), np.hstack([a_max, v_max])
 
-    def compute_speed_profile(self, Constraints):
-        from _hostqp import solve_qp
-        P, q, A, l, u = self.speed_profile_qp(Constraints)
-        v, _, _ = solve_qp(P, q, A, l, u)
+    def compute_speed_profile(self, Constraints, solver=None):
+        """Reference velocity per waypoint (src/reference_path.py:289-354).  The QP is solved on the
+        device by libmpmpc.so (K4, mpmpc.speed_profile) to a KKT-certified optimum; `solver` is the
+        test hook for the CPU emulation of that kernel (same signature).  No host solver behind it."""
+        import mpmpc
+        n = self.n_waypoints - 1
+        li = np.array([self.get_waypoint(i + 1) - self.get_waypoint(i) for i in range(n)], float)
+        kappa = np.array([float(self.get_waypoint(i).kappa) for i in range(n)])
+        limits = [Constraints[k] for k in ('a_min', 'a_max', 'v_min', 'v_max', 'ay_max')]
+        v, status, _ = (solver or mpmpc.speed_profile)(li, kappa, limits, eps=self.eps)
+        if int(status[0]) < 0:
+            raise ValueError("speed profile: inconsistent constraints")
+        v = v[0]
         for i, wp in enumerate(self.waypoints[:-1]):
             wp.v_ref = v[i]
         self.waypoints[-1].v_ref = self.waypoints[-2].v_ref

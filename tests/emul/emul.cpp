@@ -100,3 +100,14 @@ extern "C" int emu_advance(int N, double L, double Ts, int status, const double*
                            const double* x0, double kappa_wp, double* pose, double* s, double* u_out) {
   return ro_advance(N, L, Ts, status, z, cc, counter, x0, kappa_wp, pose, s, u_out) ? 1 : 0;
 }
+
+// host run of the speed-profile code that mpmpc_speed_profile_kernel executes per thread
+#include "speed_core.hpp"
+#include <vector>
+extern "C" int emu_speed_profile(int n, const double* li, const double* kappa, const double* lim5, double eps,
+                                 double* v, int* iters) {
+  std::vector<double> ws((size_t)SP_ARRAYS * n);
+  SpWork W{ws.data(), n, 1};
+  SpLimits lim{lim5[0], lim5[1], lim5[2], lim5[3], lim5[4]};
+  return sp_solve(n, li, kappa, 1, lim, eps, W, v, 1, iters);
+}

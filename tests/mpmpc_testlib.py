@@ -111,6 +111,22 @@ class Emul:
         return mpmpc.Solution(z, u0, st, it, rs, y)
 
 
+def emu_speed_profile(li, kappa, limits, eps=1e-12, device=0):
+    """CPU emulation of mpmpc_speed_profile_kernel (same signature as mpmpc.speed_profile)."""
+    lib = Emul().lib
+    li = np.atleast_2d(np.ascontiguousarray(li, float))
+    kappa = np.atleast_2d(np.ascontiguousarray(kappa, float))
+    B, n = li.shape
+    limits = np.ascontiguousarray(np.broadcast_to(np.atleast_2d(np.asarray(limits, float)), (B, 5)))
+    v, status, iters = np.zeros((B, n)), np.zeros(B, np.int32), np.zeros(B, np.int32)
+    for p in range(B):
+        it = C.c_int(0)
+        status[p] = lib.emu_speed_profile(C.c_int(n), _d(li[p]), _d(kappa[p]), _d(limits[p]), C.c_double(eps), _d(v[p]),
+                                          C.byref(it))
+        iters[p] = it.value
+    return v, status, iters
+
+
 class EmuBackend:
     """Drop-in for mpmpc.Handle in host-logic tests: same set_path / solve surface, kernels run in
     the CPU lock-step emulation.  Test infrastructure only."""

@@ -271,3 +271,43 @@ def test_open_path_end_is_an_error(track):
                  np.full((1, 30), 0.1))
     assert ok.status[0] == 1
     h.close()
+
+
+@pytest.mark.gpu
+def test_speed_profile_on_device():
+    """K4 through the C ABI: the reference track's profile against G2 (the certified optimum of the
+    QP the reference hands to OSQP, src/reference_path.py:289-354), and a batch of perturbed paths
+    against the emulation of the same code."""
+    G = M.GOLDEN
+    g1 = np.load(G + "/g1_path_sim_track.npz")
+    g2 = np.load(G + "/g2_speed_profile.npz")
+    n = 199
+    li, kappa = g1["ds_next"][:n], g1["kappa"][:n].astype(float)
+    v, status, iters = mpmpc.speed_profile(li, kappa, g2["constraints"])
+    assert status[0] == 1 and 3 < iters[0] < 40
+    assert np.max(np.abs(v[0] - g2["x"])) < 1e-9
+    rng = np.random.default_rng(12)
+    B = 96                                                # LDS variant; the HBM-workspace variant below
+    LI = li[None, :] * rng.uniform(0.7, 1.4, (B, n))
+    KA = kappa[None, :] * rng.uniform(0.5, 3.0, (B, 1))
+    LIM = np.stack([-rng.uniform(0.05, 0.5, B), rng.uniform(0.1, 1.0, B), np.zeros(B), rng.uniform(0.6, 1.5, B),
+                    rng.uniform(1.0, 5.0, B)], axis=1)
+    LIM[5] = [0.5, -0.1, 0.0, 1.0, 4.0]                     # inconsistent: refused
+    v, status, iters = mpmpc.speed_profile(LI, KA, LIM)
+    ve, se, _ = T.emu_speed_profile(LI, KA, LIM)
+    assert np.array_equal(status, se) and status[5] == -1 and np.all(np.delete(status, 5) == 1)
+    ok = status == 1
+    assert np.max(np.abs(v[ok] - ve[ok])) < 1e-9
+    Bbig = 384
+    rep = np.arange(Bbig) % B
+    vb, sb, _ = mpmpc.speed_profile(LI[rep], KA[rep], LIM[rep])
+    assert np.array_equal(sb, status[rep]) and np.array_equal(vb[sb == 1], v[rep][sb == 1])
+    # the host class takes its profile from the device
+    from map import Map
+    from reference_path import ReferencePath
+    h, w = g1["grid_shape"]
+    m = Map.from_grid(np.unpackbits(g1["grid_free"])[:h * w].reshape(h, w).astype(np.int8), origin=[-1, -2], resolution=0.005)
+    rp = ReferencePath.from_tables(m, g1["x"], g1["y"], g1["psi"], g1["kappa"], circular=True,
+                                   border_ub=g1["border_ub"], border_lb=g1["border_lb"])
+    rp.compute_speed_profile(dict(zip(('a_min', 'a_max', 'v_min', 'v_max', 'ay_max'), g2["constraints"])))
+    assert np.max(np.abs(np.array([w_.v_ref for w_ in rp.waypoints]) - g2["v_ref"])) < 1e-9

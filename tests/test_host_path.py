@@ -1,9 +1,13 @@
 """Host-side mirror of the reference's path / map / model classes against golden data that the
 reference itself produced (tests/golden/make_golden.py)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
 import mpc_np as M
+import mpmpc_testlib as tl
 from map import Map, Obstacle, fill_small_holes, line_aa
 from reference_path import ReferencePath, Waypoint
 from spatial_bicycle_models import BicycleModel, SimpleSpatialState, TemporalState, current_waypoint_batch, t2s_batch
@@ -78,9 +82,38 @@ def test_speed_profile_matches_certified_reference_qp(sim_path):
     Aref = sparse.coo_matrix((g2["A_val"], (g2["A_row"], g2["A_col"])), shape=tuple(g2["A_shape"])).toarray()
     assert np.allclose(A, Aref, rtol=0, atol=1e-12) and np.allclose(q, g2["q"], atol=1e-14)
     assert np.allclose(l, g2["l"]) and np.allclose(u, g2["u"], atol=1e-14)
-    rp.compute_speed_profile(cons)
+    # the device kernel's code, run through its CPU emulation (the product call has no host solver)
+    rp.compute_speed_profile(cons, solver=tl.emu_speed_profile)
     v = np.array([w.v_ref for w in rp.waypoints])
     assert np.max(np.abs(v - g2["v_ref"])) < 1e-9
+
+
+def test_speed_profile_kernel_code_against_dense_oracle():
+    """K4's algorithm (emulated) against the oracle's dense certified QP solve on perturbed paths:
+    other limits, tighter curvature caps, acceleration-limited stretches."""
+    import osqp_np
+    g1 = np.load(G + "/g1_path_sim_track.npz")
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        n = int(rng.integers(20, 199))
+        li = np.ascontiguousarray(g1["ds_next"][:n] * rng.uniform(0.7, 1.4, n))
+        kappa = np.ascontiguousarray(g1["kappa"][:n].astype(float) * rng.uniform(0.5, 3.0))
+        lim = np.array([-rng.uniform(0.05, 0.5), rng.uniform(0.1, 1.0), 0.0, rng.uniform(0.6, 1.5), rng.uniform(1.0, 5.0)])
+        v, status, iters = tl.emu_speed_profile(li, kappa, lim)
+        assert status[0] == 1 and 3 < iters[0] < 40
+        vmax = np.minimum(lim[3], np.sqrt(lim[4] / (np.abs(kappa) + 1e-12)))
+        D1 = np.zeros((n - 1, n))
+        for i in range(n - 1):
+            D1[i, i], D1[i, i + 1] = -1 / (2 * li[i]), 1 / (2 * li[i])
+        A = np.vstack([D1, np.eye(n)])
+        l = np.hstack([np.full(n - 1, lim[0]), np.full(n, lim[2])])
+        u = np.hstack([np.full(n - 1, lim[1]), vmax])
+        r = osqp_np.solve(np.eye(n), -vmax, A, l, u, osqp_np.Settings(polish=2, max_iter=20000))
+        assert r.status == 1
+        assert np.max(np.abs(v[0] - r.x)) < 1e-8, trial
+    # inconsistent limits are refused, not solved
+    _, status, _ = tl.emu_speed_profile(g1["ds_next"][:10], g1["kappa"][:10].astype(float), [0.5, -0.1, 0, 1, 4])
+    assert status[0] == -1
 
 
 @pytest.mark.parametrize("obst", [False, True])
