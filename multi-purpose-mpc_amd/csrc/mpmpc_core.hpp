@@ -156,6 +156,24 @@ MPMPC_HD void assemble_lane(const mpmpc_config& c, const PathTables& t, int B, i
 // ------------------------------------------------------------------------------------------
 // K2: the solver.  All state is per lane.
 // ------------------------------------------------------------------------------------------
+// Solver settings plus the constants derived from them.  A wave-uniform double that the kernel has to
+// COMPUTE sits in a VGPR pair for as long as it is live (there is no scalar FP64 unit), while one that
+// arrives as a kernel argument is an SGPR pair usable as an operand directly: derive them on the host.
+struct SolverParams : mpmpc_settings {
+  double one_minus_alpha, inv_ipm_reg, inv_as_delta;
+  double eps_abs10, eps_rel10, eps_prim_inf10, eps_dual_inf10;     // OSQP's approximate check: 10 x eps
+};
+inline SolverParams make_params(const mpmpc_settings& st) {
+  SolverParams p;
+  static_cast<mpmpc_settings&>(p) = st;
+  p.one_minus_alpha = 1.0 - st.alpha;
+  p.inv_ipm_reg = 1.0 / st.ipm_reg;
+  p.inv_as_delta = 1.0 / st.as_delta;
+  p.eps_abs10 = st.eps_abs * 10.0; p.eps_rel10 = st.eps_rel * 10.0;
+  p.eps_prim_inf10 = st.eps_prim_inf * 10.0; p.eps_dual_inf10 = st.eps_dual_inf * 10.0;
+  return p;
+}
+
 // Lane split of the twisted factorisation for G lanes per instance and horizon N (shared by the
 // launcher and the emulation): the chains meet at lane C - 1.
 inline int lane_split(int G, int N) { return G == 16 ? 16 : (G == 32 ? 16 : (N + 1 <= 32 ? 16 : 32)); }
@@ -656,13 +674,13 @@ struct Solver {
     return (nrm > R(eps)) & (qdx < -(c * R(eps)) * nrm) & (pm < (c * R(eps)) * nrm) & !bad;
   }
 
-  MPMPC_HD I check(const Info& o, const mpmpc_settings& st, bool approximate) const {
-    double k = approximate ? 10.0 : 1.0;
-    R eps_prim = R(st.eps_abs * k) + R(st.eps_rel * k) * max_(o.n_z, o.n_Ax);
-    R eps_dual = R(st.eps_abs * k) + R(st.eps_rel * k) * max_(max_(o.n_q, o.n_Aty), o.n_Px);
+  MPMPC_HD I check(const Info& o, const SolverParams& st, bool approximate) const {
+    const double ea = approximate ? st.eps_abs10 : st.eps_abs, er = approximate ? st.eps_rel10 : st.eps_rel;
+    R eps_prim = R(ea) + R(er) * max_(o.n_z, o.n_Ax);
+    R eps_dual = R(ea) + R(er) * max_(max_(o.n_q, o.n_Aty), o.n_Px);
     Mk prim_ok = o.pri < eps_prim, dual_ok = o.dua < eps_dual;
-    Mk pinf = !prim_ok & primal_infeasible(st.eps_prim_inf * k);
-    Mk dinf = !dual_ok & dual_infeasible(st.eps_dual_inf * k);
+    Mk pinf = !prim_ok & primal_infeasible(approximate ? st.eps_prim_inf10 : st.eps_prim_inf);
+    Mk dinf = !dual_ok & dual_infeasible(approximate ? st.eps_dual_inf10 : st.eps_dual_inf);
     I stt(MPMPC_UNSOLVED);
     stt = seli(dinf, I(MPMPC_DUAL_INFEASIBLE), stt);
     stt = seli(pinf, I(MPMPC_PRIMAL_INFEASIBLE), stt);
@@ -693,7 +711,7 @@ struct Solver {
 
   // Cold-started ADMM on the instances selected by `which`, at most `limit` iterations.  Instances
   // still running at the limit (only possible when limit < max_iter) keep status UNSOLVED.
-  MPMPC_HD void admm(const mpmpc_settings& st, const Mk& which, int limit) {
+  MPMPC_HD void admm(const SolverParams& st, const Mk& which, int limit) {
     const R zero(0.0);
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) {
@@ -710,7 +728,7 @@ struct Solver {
     polished = keepi(which, I(0), polished);
     set_rho(R(st.rho));
     admm_factor(st.sigma);
-    const R alpha(st.alpha), oma(1.0 - st.alpha), sigma(st.sigma);
+    const R alpha(st.alpha), oma(st.one_minus_alpha), sigma(st.sigma);
     Mk active = which;
     const bool full = limit >= st.max_iter;
     if (limit > st.max_iter) limit = st.max_iter;
@@ -820,8 +838,8 @@ struct Solver {
   struct Ipm {
     R x[5], nu[3], sl[5], su[5], zl[5], zu[5], pi[5];
   };
-  MPMPC_HD Mk ipm(const Box& bx, Ipm& s, const mpmpc_settings& st, double tol, const Mk& run) {
-    const R reg(st.ipm_reg), ireg(1.0 / st.ipm_reg), one(1.0), zero(0.0);
+  MPMPC_HD Mk ipm(const Box& bx, Ipm& s, const SolverParams& st, double tol, const Mk& run) {
+    const R reg(st.ipm_reg), ireg(st.inv_ipm_reg), one(1.0), zero(0.0);
     Mk active = run, conv = L::mfalse();
     R cnt(0.0);
     MPMPC_UNROLL
@@ -958,8 +976,8 @@ struct Solver {
   // OSQP's polish solve on a given active set, iterated with primal-dual active-set updates.
   // On success (xs, nus, lam) is a KKT point of the scaled problem.
   MPMPC_HD Mk active_set(const Box& bx, Mk aL[5], Mk aU[5], R xs[5], R nus[3], R lam[5],
-                         const mpmpc_settings& st, const Mk& run) {
-    const R delta(st.as_delta), zero(0.0), one(1.0), tol(1e-9);
+                         const SolverParams& st, const Mk& run) {
+    const R delta(st.as_delta), idelta(st.inv_as_delta), zero(0.0), one(1.0), tol(1e-9);
     Mk todo = run, okm = L::mfalse();
     for (int rnd = 0; rnd < st.as_rounds; ++rnd) {
       if (!L::wany(todo)) break;
@@ -969,7 +987,7 @@ struct Solver {
       for (int j = 0; j < 5; ++j) {
         act[j] = aL[j] | aU[j] | bx.pin[j];
         bound[j] = sel(aU[j], bx.hi[j], bx.lo[j]);
-        h[j] = one / (p[j] + delta + sel(act[j], one / delta, zero));
+        h[j] = one / (p[j] + delta + sel(act[j], idelta, zero));
       }
       factor(h, delta);
       R xn[5], nn[3], ln[5];
@@ -985,7 +1003,7 @@ struct Solver {
         for (int j = 0; j < 5; ++j) {
           R r1 = -q[j] - p[j] * xn[j] - At[j] - ln[j];
           r3[j] = sel(act[j], bound[j] - xn[j], zero);
-          rhs[j] = r1 + r3[j] / delta;
+          rhs[j] = fma_(r3[j], idelta, r1);
         }
         MPMPC_UNROLL
         for (int i = 0; i < 3; ++i) r2[i] = leq[i] - Ax[i];
@@ -993,7 +1011,7 @@ struct Solver {
         R big(0.0);
         MPMPC_UNROLL
         for (int j = 0; j < 5; ++j) {
-          ln[j] = ln[j] + sel(act[j], (dx[j] - r3[j]) / delta, zero);
+          ln[j] = ln[j] + sel(act[j], (dx[j] - r3[j]) * idelta, zero);
           xn[j] = xn[j] + dx[j];
           big = max_(big, sel(valid[j], abs_(dx[j]) - R(1e-14) * abs_(xn[j]), zero));
         }
@@ -1093,7 +1111,7 @@ struct Solver {
 
   // `early`: also polish instances whose ADMM was stopped before it terminated (status UNSOLVED);
   // those keep UNSOLVED when the polish cannot certify them, so the caller can resume ADMM.
-  MPMPC_HD void polish(const mpmpc_settings& st, bool early) {
+  MPMPC_HD void polish(const SolverParams& st, bool early) {
     Mk run = live & (polished != 1) &
              ((status == MPMPC_SOLVED) | (status == MPMPC_SOLVED_INACCURATE) | (status == MPMPC_MAX_ITER_REACHED));
     Mk unsolved = live & (status == MPMPC_UNSOLVED);
@@ -1191,7 +1209,7 @@ struct Solver {
     if (resid) { L::store(resid, inst * 2, lead, pri_res); L::store(resid, inst * 2 + 1, lead, dua_res); }
   }
 
-  MPMPC_HD void run(const double* qp, int B, int ld, const I& inst, const I& k, int N_, const mpmpc_settings& st) {
+  MPMPC_HD void run(const double* qp, int B, int ld, const I& inst, const I& k, int N_, const SolverParams& st) {
     load(qp, B, ld, inst, k, N_);
     scale(st.scaling);
     // The polish does not need a converged ADMM point, only a reasonable one: with early_polish > 0

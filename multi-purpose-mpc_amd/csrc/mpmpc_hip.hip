@@ -59,7 +59,7 @@ __global__ __launch_bounds__(K1_THREADS) void mpmpc_assemble_kernel(
 }
 
 template <int G, int C>
-__global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, mpmpc_settings st, int B, int ld,
+__global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, SolverParams st, int B, int ld,
                                                          const double* __restrict__ qp, double* __restrict__ z,
                                                          double* __restrict__ u0, int* __restrict__ status,
                                                          int* __restrict__ iters, double* __restrict__ resid,
@@ -567,8 +567,9 @@ static int launch_solve(mpmpc_handle h, int B) {
   const int per = 64 / G;
   const int blocks = (B + per - 1) / per;
   const int C = lane_split(G, N);        // where the two elimination chains of the factorisation meet
+  const SolverParams prm = make_params(h->st);
 #define LAUNCH(GG, CC)                                                                                          \
-  hipLaunchKernelGGL((mpmpc_solve_kernel<GG, CC>), dim3(blocks), dim3(64), 0, h->stream, h->cfg, h->st, B, h->ld, \
+  hipLaunchKernelGGL((mpmpc_solve_kernel<GG, CC>), dim3(blocks), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, \
                      h->qp, h->z, h->u0, h->status, h->iters, h->resid, h->y)
   if (G == 64 && C == 16) LAUNCH(64, 16);
   else if (G == 64) LAUNCH(64, 32);

@@ -20,7 +20,7 @@ static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const dou
     VI inst = L::slot() + w0;
     VI k = L::stage();
     Solver<L> s;
-    s.run(qp, B, ld, inst, k, cfg->N, *st);
+    s.run(qp, B, ld, inst, k, cfg->N, make_params(*st));
     s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y);
   }
 }
