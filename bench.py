@@ -60,7 +60,7 @@ def k2_flops_per_solve(N, admm_iters, ipm_iters):
     return (N + 1) * (c0 + c1 * admm_iters + c2 * ipm_iters)
 
 
-def cpu_baseline(tr, sc, seconds=15.0):
+def cpu_baseline(tr, sc, seconds=10.0):
     """The oracle's C port (oracle/osqp_port.c: own restatement of the reference's assembly + OSQP +
     certified polish) timed on the host cores of this box, on a bounded sample of the workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
