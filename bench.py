@@ -197,6 +197,7 @@ def main():
             out["status_agreement"] = float(np.mean(ref["status"] == sol.status[:ns]))
             out["parity_sample"] = int(ns)
             out["host_cores"] = os.cpu_count()
+            out["host_cores_usable"] = base.get("usable_cpus")
         print(json.dumps(out))
     h.close()
     if dist is not None:

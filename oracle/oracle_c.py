@@ -134,6 +134,25 @@ def num_threads():
     return int(lib().oracle_num_threads())
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a container
+    on a 256-thread host may be limited to a few of them; oversubscribing the quota is far slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(round(q / per))))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def timed_baseline(track, sc, weights, limits, seconds=15.0, nthreads=0):
     """bench.py's cpu_baseline leg: the reference-equivalent CPU path (assembly + fresh setup + ADMM +
     certified polish per instance) on a bounded sample, all host cores."""
@@ -147,8 +166,8 @@ def timed_baseline(track, sc, weights, limits, seconds=15.0, nthreads=0):
         out = mpc_batch(*args, sc.wp_id[:n], sc.x0[:n], sc.cc_prev[:n], sc.lb[:n], sc.ub[:n], nt)
         return n / (time.perf_counter() - t0), out
 
-    # threads: all hardware threads or one per physical core (SMT siblings often lose), whichever is faster
-    cand = [nthreads] if nthreads else sorted({num_threads(), max(1, num_threads() // 2)})
+    # threads: what the container may use, or half of it (SMT siblings often lose), whichever is faster
+    cand = [nthreads] if nthreads else sorted({usable_cpus(), max(1, usable_cpus() // 2)})
     probe = min(sc.B, max(2 * max(cand), 16))
     run(probe, cand[0])                                   # warm the caches / thread pool
     rates = {nt: run(probe, nt)[0] for nt in cand}
@@ -160,7 +179,7 @@ def timed_baseline(track, sc, weights, limits, seconds=15.0, nthreads=0):
         _, out = run(nsamp, nt)
         reps += 1
     dt = (time.perf_counter() - t0) / reps
-    base = dict(value=nsamp / dt, unit="solves/s", cores=nt, kind="port",
+    base = dict(value=nsamp / dt, unit="solves/s", cores=nt, kind="port", usable_cpus=usable_cpus(),
                 sample="first %d instances of the workload, %d passes (%.1f s); C restatement (oracle/osqp_port.c): numpy-equivalent "
                        "assembly + fresh OSQP-style setup (Ruiz scaling, sparse LDL) + ADMM at OSQP defaults + "
                        "certified polish per instance, OpenMP over instances" % (nsamp, reps, dt * reps))
