@@ -168,17 +168,20 @@ def timed_baseline(track, sc, weights, limits, seconds=15.0, nthreads=0):
 
     # threads: what the container may use, or half of it (SMT siblings often lose), whichever is faster
     cand = [nthreads] if nthreads else sorted({usable_cpus(), max(1, usable_cpus() // 2)})
-    probe = min(sc.B, max(2 * max(cand), 16))
-    run(probe, cand[0])                                   # warm the caches / thread pool
-    rates = {nt: run(probe, nt)[0] for nt in cand}
-    nt = max(rates, key=rates.get)
-    # about `seconds` of wall time: the first nsamp instances, passed over until the time is up
-    nsamp = int(min(sc.B, max(probe, rates[nt] * seconds)))
-    reps, t0 = 0, time.perf_counter()
-    while reps == 0 or time.perf_counter() - t0 < seconds:
-        _, out = run(nsamp, nt)
-        reps += 1
-    dt = (time.perf_counter() - t0) / reps
+    run(min(sc.B, max(2 * max(cand), 16)), cand[-1])              # warm the caches / thread pool
+    # every candidate gets its share of about `seconds` of wall time: passes over the workload's instances
+    # until its time is up; the fastest one is the baseline
+    best = None
+    for nt_c in cand:
+        reps, t0 = 0, time.perf_counter()
+        while reps == 0 or time.perf_counter() - t0 < seconds / len(cand):
+            _, out_c = run(sc.B, nt_c)
+            reps += 1
+        dt_c = (time.perf_counter() - t0) / reps
+        if best is None or dt_c < best[0]:
+            best = (dt_c, nt_c, reps, out_c)
+    dt, nt, reps, out = best
+    nsamp = sc.B
     base = dict(value=nsamp / dt, unit="solves/s", cores=nt, kind="port", usable_cpus=usable_cpus(),
                 sample="first %d instances of the workload, %d passes (%.1f s); C restatement (oracle/osqp_port.c): numpy-equivalent "
                        "assembly + fresh OSQP-style setup (Ruiz scaling, sparse LDL) + ADMM at OSQP defaults + "
