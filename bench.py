@@ -161,8 +161,9 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "config%d: batch=%d independent poses per GPU, %s weights, N=%d, %s corridor, "
-                                   "OSQP-default ADMM, certified polish tried after 15 iterations" %
-                                   (args.config, B, sc_all.weights, N, "obstacle" if sc_all.obstacles else "free"),
+                                   "OSQP-default ADMM, certified polish tried after %d iterations" %
+                                   (args.config, B, sc_all.weights, N, "obstacle" if sc_all.obstacles else "free",
+                                    settings.early_polish),
                        "batch_per_gpu": B, "horizon": N, "parallelism": "batch-shard x%d" % world},
         }
         bytes_k2 = k2_bytes_per_solve(N) * B
@@ -186,7 +187,14 @@ def main():
         st, cnt = np.unique(sol.status, return_counts=True)
         out["status_counts"] = {int(s): int(c) for s, c in zip(st, cnt)}
         out["iters"] = {"admm_mean": float(sol.iters[:, 0].mean()), "admm_max": int(sol.iters[:, 0].max()),
-                        "ipm_mean": float(sol.iters[:, 1].mean()), "ipm_max": int(sol.iters[:, 1].max())}
+                        "ipm_mean": float(sol.iters[:, 1].mean()), "ipm_max": int(sol.iters[:, 1].max()),
+                        "ipm_histogram": {int(k): int(v) for k, v in zip(*np.unique(sol.iters[:, 1], return_counts=True))}}
+        # the same step from HOST buffers (mpmpc_solve: upload + K1 + K2 + download): reported, never `value`
+        t1 = time.perf_counter()
+        for _ in range(5):
+            h.solve(wp, x0, cc, lb, ub)
+        out["host_buffers"] = {"value": 5 * B / (time.perf_counter() - t1), "unit": "solves/s",
+                               "note": "PCIe-inclusive rate of mpmpc_solve on one GPU (pageable numpy buffers)"}
         if not args.no_cpu:
             sc_rank = scenarios.Scenario(sc_all.name, N, sc_all.weights, sc_all.obstacles, wp, x0, cc, lb, ub)
             base, ref = cpu_baseline(tr, sc_rank)
@@ -195,6 +203,19 @@ def main():
             both = (ref["status"] == 1) & (sol.status[:ns] == 1)
             out["max_abs_u_minus_uref"] = float(np.max(np.abs(sol.u0[:ns][both] - ref["u0"][both]))) if both.any() else None
             out["status_agreement"] = float(np.mean(ref["status"] == sol.status[:ns]))
+            # whole plan (z without the cost-free kappa_{N-1} and e_psi_N) against the certified optimum
+            keep = np.ones(5 * N + 3, bool)
+            keep[[3 * N + 1, 5 * N + 2]] = False
+            out["max_abs_plan_minus_ref"] = (float(np.max(np.abs(sol.z[:ns][both][:, keep] - ref["z"][both][:, keep])))
+                                            if both.any() else None)
+            # what stock settings deliver: OSQP defaults (eps 1e-3, no polish) on the device against the same optimum
+            h.set_settings(mpmpc.default_settings(polish=0, early_polish=0))
+            stock = h.solve(wp[:ns], x0[:ns], cc[:ns], lb[:ns], ub[:ns])
+            ok = both & ((stock.status == 1) | (stock.status == 2))
+            out["stock_osqp_settings"] = {
+                "max_abs_u_minus_uref": float(np.max(np.abs(stock.u0[ok] - ref["u0"][ok]))) if ok.any() else None,
+                "admm_iters_mean": float(stock.iters[:, 0].mean()), "admm_iters_max": int(stock.iters[:, 0].max()),
+                "note": "device run at OSQP's defaults (eps_abs = eps_rel = 1e-3, no polish) vs the certified optimum"}
             out["parity_sample"] = int(ns)
             out["host_cores"] = os.cpu_count()
             out["host_cores_usable"] = base.get("usable_cpus")
