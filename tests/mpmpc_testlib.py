@@ -70,6 +70,52 @@ def qp_to_dense(qp_i, N):
     return Pd, q, A, l, u
 
 
+def kkt_batch(qp, N, z, y):
+    """Vectorised KKT residuals of a whole batch from the stage-blocked fields qp [27, B, LD]:
+    (prim, stat, comp) [B] each, in the reference's unscaled problem (rows [dynamics; state boxes; input
+    boxes], src/MPC.py:128-147).  Independent of the kernels' own certificate: plain numpy on the
+    K1 output and the returned (z, y)."""
+    B = qp.shape[1]
+    f = qp[:, :, :N + 1]
+    ne = 3 * (N + 1)
+    x = z[:, :ne].reshape(B, N + 1, 3)
+    u = z[:, ne:].reshape(B, N, 2)
+    nu = y[:, :ne].reshape(B, N + 1, 3)
+    yx = y[:, ne:2 * ne].reshape(B, N + 1, 3)
+    yu = y[:, 2 * ne:].reshape(B, N, 2)
+    ds, a10, a20, b20 = (f[i, :, :N] for i in range(4))
+    # dynamics rows: -x_k + A_{k-1} x_{k-1} + B_{k-1} u_{k-1} = beq_k
+    r = -x.copy()
+    r[:, 1:, 0] += x[:, :-1, 0] + ds * x[:, :-1, 1]
+    r[:, 1:, 1] += a10 * x[:, :-1, 0] + x[:, :-1, 1] + ds * u[:, :, 1]
+    r[:, 1:, 2] += a20 * x[:, :-1, 0] + x[:, :-1, 2] + b20 * u[:, :, 0]
+    beq = np.moveaxis(f[4:7], 0, -1)
+    lo_x, hi_x = np.moveaxis(f[7:10], 0, -1), np.moveaxis(f[12:15], 0, -1)
+    lo_u, hi_u = np.moveaxis(f[10:12, :, :N], 0, -1), np.moveaxis(f[15:17, :, :N], 0, -1)
+    viol = lambda v, lo, hi: np.maximum(np.maximum(lo - v, v - hi), 0.0)
+    prim = np.maximum(np.abs(r - beq).max(axis=(1, 2)),
+                      np.maximum(viol(x, lo_x, hi_x).max(axis=(1, 2)), viol(u, lo_u, hi_u).max(axis=(1, 2))))
+    # stationarity: P z + q + A' y
+    sx = np.moveaxis(f[22:25], 0, -1) * x + np.moveaxis(f[17:20], 0, -1) - nu + yx
+    sx[:, :-1, 0] += nu[:, 1:, 0] + a10 * nu[:, 1:, 1] + a20 * nu[:, 1:, 2]
+    sx[:, :-1, 1] += ds * nu[:, 1:, 0] + nu[:, 1:, 1]
+    sx[:, :-1, 2] += nu[:, 1:, 2]
+    su = np.moveaxis(f[25:27, :, :N], 0, -1) * u + np.moveaxis(f[20:22, :, :N], 0, -1) + yu
+    su[:, :, 0] += b20 * nu[:, 1:, 2]
+    su[:, :, 1] += ds * nu[:, 1:, 1]
+    stat = np.maximum(np.abs(sx).max(axis=(1, 2)), np.abs(su).max(axis=(1, 2)))
+
+    def comp(v, lo, hi, mult):
+        with np.errstate(invalid="ignore"):
+            return _comp(v, lo, hi, mult)
+
+    def _comp(v, lo, hi, mult):
+        up = np.where(hi < 1e20, np.maximum(mult, 0.0) * np.abs(hi - v), np.where(mult > 0, np.inf, 0.0))
+        dn = np.where(lo > -1e20, np.maximum(-mult, 0.0) * np.abs(v - lo), np.where(mult < 0, np.inf, 0.0))
+        return np.maximum(up, dn).max(axis=(1, 2))
+    return prim, stat, np.maximum(comp(x, lo_x, hi_x, yx), comp(u, lo_u, hi_u, yu))
+
+
 class Emul:
     """ctypes view of tests/_build/libmpmpc_emul.so (CPU lock-step emulation of the kernels)."""
 

@@ -261,6 +261,35 @@ def test_full_batches_against_c_oracle(cfgid, B, track):
     h.close()
 
 
+@pytest.mark.parametrize("cfgid,B", [(5, 65536), (2, 65536)])
+def test_baseline_batch_sizes_carry_kkt_certificates(cfgid, B, track):
+    """BASELINE.json's largest batches (config 5: 65 536 obstacle-course instances; config 2's poses at
+    the same size) through a size-independent property: every instance reported solved satisfies the
+    KKT conditions of ITS OWN assembled QP to 1e-8 (vectorised numpy on K1's output and K2's z, y),
+    every instance of the obstacle course is either certified, flagged inaccurate or flagged infeasible,
+    and the batch is invariant (statuses, iteration counts; controls to 1e-9) under a permutation of the
+    instances: no cross-talk between the instances that share a wavefront."""
+    sc = scenarios.make(cfgid, track, B=B)
+    h = _handle(track, sc.N, sc.weights, B)
+    qp = h.assemble(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    sol = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+    ok = sol.status == 1
+    prim, stat, comp = T.kkt_batch(qp[:, ok, :], sc.N, sol.z[ok], sol.y[ok])
+    assert max(prim.max(), stat.max(), comp.max()) <= 1e-8
+    assert set(np.unique(sol.status)) <= {1, 2, -3}
+    if cfgid == 2:
+        assert ok.all()
+    else:
+        assert 0.85 < ok.mean() < 0.95 and (sol.status == -3).mean() > 0.05
+    perm = np.random.default_rng(0).permutation(B)
+    sol2 = h.solve(sc.wp_id[perm], sc.x0[perm], sc.cc_prev[perm], sc.lb[perm], sc.ub[perm])
+    assert np.array_equal(sol2.status, sol.status[perm]) and np.array_equal(sol2.iters, sol.iters[perm])
+    # (not bit-for-bit: instances sharing a wavefront run the refinement loops until both are done)
+    both = sol.status[perm] == 1
+    assert np.max(np.abs(sol2.u0[both] - sol.u0[perm][both])) <= 1e-9
+    h.close()
+
+
 def test_open_path_end_is_an_error(track):
     cfg = T.stock_config(30, max_batch=2, circular=False)
     h = mpmpc.Handle(cfg)
