@@ -290,6 +290,24 @@ def test_baseline_batch_sizes_carry_kkt_certificates(cfgid, B, track):
     h.close()
 
 
+@pytest.mark.parametrize("cfgid,N", [(2, 10), (4, 10), (4, 3), (2, 15)])
+def test_every_lane_packing_gives_the_same_answers(cfgid, N, track, monkeypatch):
+    """64, 32 and 16 lanes per instance (1, 2, 4 instances per wavefront; the launcher picks by batch
+    size, MPMPC_LANES_PER_INSTANCE forces one): same statuses, same iteration counts, same controls."""
+    sc = scenarios.make(cfgid, track, B=203, N=N)
+    h = _handle(track, sc.N, sc.weights, sc.B)
+    sols = {}
+    for g in (64, 32, 16):
+        monkeypatch.setenv("MPMPC_LANES_PER_INSTANCE", str(g))
+        sols[g] = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    monkeypatch.delenv("MPMPC_LANES_PER_INSTANCE")
+    for g in (32, 16):
+        assert np.array_equal(sols[g].status, sols[64].status) and np.array_equal(sols[g].iters[:, 0], sols[64].iters[:, 0])
+        ok = sols[64].status == 1
+        assert np.max(np.abs(sols[g].u0[ok] - sols[64].u0[ok])) <= 1e-9
+    h.close()
+
+
 def test_open_path_end_is_an_error(track):
     cfg = T.stock_config(30, max_batch=2, circular=False)
     h = mpmpc.Handle(cfg)
