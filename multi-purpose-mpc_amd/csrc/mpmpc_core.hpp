@@ -428,7 +428,7 @@ struct Solver {
     MPMPC_UNROLL
     for (int i = 0; i < 9; ++i) M[i] = R(0.0);
     const int last = chain_steps();
-    for (int s = 0; s <= last; ++s) {
+    auto fstep = [&](bool junction) {
       R Mr[9];
       MPMPC_UNROLL
       for (int i = 0; i < 9; ++i) Mr[i] = L::cup(M[i]);
@@ -438,7 +438,7 @@ struct Solver {
       R S20 = Dg[3] - fma_(Mr[8], Mr[2], fma_(Mr[7], Mr[1], Mr[6] * Mr[0]));
       R S21 = Dg[4] - fma_(Mr[8], Mr[5], fma_(Mr[7], Mr[4], Mr[6] * Mr[3]));
       R S22 = Dg[5] - fma_(Mr[8], Mr[8], fma_(Mr[7], Mr[7], Mr[6] * Mr[6]));
-      if (s == last) {
+      if (junction) {
         // junction: both chains have settled; mid also loses the block of the end lane
         R Mx[9];
         MPMPC_UNROLL
@@ -466,6 +466,12 @@ struct Solver {
       M[0] = To[0] * i00; M[1] = fma_(To[1], i11, To[0] * i10); M[2] = fma_(To[2], i22, fma_(To[1], i21, To[0] * i20));
       M[3] = To[3] * i00; M[4] = fma_(To[4], i11, To[3] * i10); M[5] = fma_(To[4], i21, To[3] * i20);
       M[6] = To[6] * i00; M[7] = To[6] * i10;                   M[8] = fma_(To[8], i22, To[6] * i20);
+    };
+    {
+      int s = 0;                                   // two steps per trip (see s_solve), then the junction step
+      for (; s + 2 <= last; s += 2) { fstep(false); fstep(false); }
+      for (; s < last; ++s) fstep(false);
+      fstep(true);
     }
     // recurrence matrices of the two substitution sweeps (stored negated, so a sweep step is 9 FMAs):
     //   inward    y_k  = inv(L_kk) b_k + Gin_k y_pred,        Gin_k  = -inv(L_kk) M_in
@@ -495,11 +501,18 @@ struct Solver {
     R c2 = fma_(Li[5], b2, fma_(Li[4], b1, Li[3] * b0));
     const int last = chain_steps();
     R y0(0.0), y1(0.0), y2(0.0);
-    for (int s = 0; s < last; ++s) {
+    // A loop-back branch costs about as much as six of the step's fifteen instructions, and the compiler
+    // may not partially unroll a loop of convergent (DPP) operations: four steps per trip by hand.
+    auto in_step = [&]() {
       R p0 = L::cup(y0), p1 = L::cup(y1), p2 = L::cup(y2);
       y0 = fma_(Gin[2], p2, fma_(Gin[1], p1, fma_(Gin[0], p0, c0)));
       y1 = fma_(Gin[5], p2, fma_(Gin[4], p1, fma_(Gin[3], p0, c1)));
       y2 = fma_(Gin[8], p2, fma_(Gin[7], p1, fma_(Gin[6], p0, c2)));
+    };
+    {
+      int s = 0;
+      for (; s + 4 <= last; s += 4) { in_step(); in_step(); in_step(); in_step(); }
+      for (; s < last; ++s) in_step();
     }
     {
       // inward junction: the end lane forms M_own y, mid takes it on top of its chain input
@@ -535,11 +548,16 @@ struct Solver {
       d2 = d2 - Li[5] * w2;
     }
     R n0(0.0), n1(0.0), n2(0.0);
-    for (int s = 0; s <= last; ++s) {
+    auto out_step = [&]() {
       R p0 = L::cdown(n0), p1 = L::cdown(n1), p2 = L::cdown(n2);
       n0 = fma_(Gout[2], p2, fma_(Gout[1], p1, fma_(Gout[0], p0, d0)));
       n1 = fma_(Gout[5], p2, fma_(Gout[4], p1, fma_(Gout[3], p0, d1)));
       n2 = fma_(Gout[8], p2, fma_(Gout[7], p1, fma_(Gout[6], p0, d2)));
+    };
+    {
+      int s = 0;
+      for (; s + 4 <= last + 1; s += 4) { out_step(); out_step(); out_step(); out_step(); }
+      for (; s <= last; ++s) out_step();
     }
     nu[0] = L::mirror(n0); nu[1] = L::mirror(n1); nu[2] = L::mirror(n2);
   }
