@@ -1,0 +1,122 @@
+"""Regenerates the measured sections of profiles/README.md from profiles/<round>/ (bench lines, rocprofv3
+kernel stats, PMC summary):  python profiles/make_readme.py r1"""
+import csv
+import json
+import os
+import sys
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r1"
+HERE = os.path.dirname(os.path.abspath(__file__))
+R = os.path.join(HERE, rnd) + "/"
+d2, d3, d4, db = (json.load(open(R + "bench_%s.json" % c)) for c in ("cfg2", "cfg3", "cfg4", "cfg2_b65536"))
+p = json.load(open(R + "pmc_summary.json"))
+
+
+def avg_ns(fname, what):
+    return [float(r["AverageNs"]) for r in csv.DictReader(open(R + fname)) if what in r["Name"]][0]
+
+
+def pmc(section, kernel, counter):
+    return [v for k, v in p[section].items() if kernel in k][0][counter]["mean"]
+
+
+k2, k1 = avg_ns("bench_cfg2_kernel_stats.csv", "solve"), avg_ns("bench_cfg2_kernel_stats.csv", "assemble")
+k2b, k1b = avg_ns("bench_cfg2_b65536_kernel_stats.csv", "solve"), avg_ns("bench_cfg2_b65536_kernel_stats.csv", "assemble")
+f, w = pmc("pmc_fetch", "solve", "FETCH_SIZE"), pmc("pmc_write", "solve", "WRITE_SIZE")
+fa, wa = pmc("pmc_fetch", "assemble", "FETCH_SIZE"), pmc("pmc_write", "assemble", "WRITE_SIZE")
+fb, wb = pmc("pmc_fetch_b65536", "solve", "FETCH_SIZE"), pmc("pmc_write_b65536", "solve", "WRITE_SIZE")
+fab, wab = pmc("pmc_fetch_b65536", "assemble", "FETCH_SIZE"), pmc("pmc_write_b65536", "assemble", "WRITE_SIZE")
+waves = pmc("pmc_sq1", "solve", "SQ_WAVES")
+valu, salu, lds = (pmc("pmc_sq1", "solve", c) / waves for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"))
+act = pmc("pmc_sq2", "solve", "SQ_ACTIVE_INST_VALU") / pmc("pmc_sq1", "solve", "SQ_INSTS_VALU")
+wait = pmc("pmc_sq2", "solve", "SQ_WAIT_ANY") / pmc("pmc_sq1", "solve", "SQ_WAVE_CYCLES")
+hist = d2["iters"]["ipm_histogram"]
+st = d2["stock_osqp_settings"]
+counts4 = d4["status_counts"]
+
+txt = f'''# profiles — measured on MI355X (gfx950), ROCm 7.2; host 2× AMD EPYC 9575F, of which the container may use 16 CPUs
+
+Round 1 (`profiles/{rnd}/`).  All from `bench.py` runs on a fresh 1-GPU box; JSON lines are the bench
+output, `*_kernel_stats.csv` is `rocprofv3 --kernel-trace --stats` of the same command,
+`pmc_summary.json` holds per-kernel means of separate `rocprofv3 --pmc` passes of the same command
+(FETCH_SIZE and WRITE_SIZE each in its own pass; the SQ counters in two passes of 8).  `collect.sh` gathers,
+`summarize.py` condenses, `make_readme.py` writes the tables below; `census.py` (instruction census → flop
+model), `pmc_admm.sh` (PMC cost of one ADMM iteration), `ab.sh` (A/B of two builds on one box), `quick.sh`,
+`cpu_scaling.py` (thread scaling of the CPU baseline) and `micro/exec_half.hip` (instruction-cost
+micro-benchmark) are the helpers used while tuning.
+
+## Headline (config 2: B = 1024 independent poses, N = 30, stock weights, free corridor)
+
+| quantity | value | source |
+|---|---|---|
+| QP solves / s (K1 + K2, inputs resident in HBM) | **{d2["value"]/1e6:.2f} M** | `bench_cfg2.json` `value` |
+| ms per step (batch of 1024) | {d2["ms_per_step"]:.3f} | `ms_per_step` |
+| `max|u − u_ref|`, u = (v₀, δ₀), over all 1024 instances | {d2["max_abs_u_minus_uref"]:.1e} (tolerance 1e-6) | `max_abs_u_minus_uref` |
+| whole plan without the cost-free κ_(N−1), e_ψ,N | {d2["max_abs_plan_minus_ref"]:.1e} | `max_abs_plan_minus_ref` |
+| status agreement with the oracle | {100*d2["status_agreement"]:.0f} % | `status_agreement` |
+| K2 `mpmpc_solve_kernel<64,16>` average launch | {d2["roofline"]["avg_ms"]:.4f} ms (HIP events) / {k2/1e6:.4f} ms (rocprofv3) | `roofline.avg_ms`, `bench_cfg2_kernel_stats.csv` |
+| K1 `mpmpc_assemble_kernel` average launch | {d2["roofline_assembly"]["avg_ms"]*1e3:.1f} µs (events, includes event overhead) / {k1/1e3:.1f} µs (rocprofv3) | same |
+| CPU baseline: C port of the reference-equivalent path, {d2["cpu_baseline"]["cores"]} threads (the container's CPU quota) | {d2["cpu_baseline"]["value"]/1e3:.1f} k solves/s | `cpu_baseline`, `cpu_scaling.txt` |
+| same step from host buffers (`mpmpc_solve`, PCIe-inclusive) | {d2["host_buffers"]["value"]/1e6:.2f} M solves/s | `host_buffers` |
+| ADMM iterations; interior-point iterations mean / max (histogram) | 15 (early polish); {d2["iters"]["ipm_mean"]:.1f} / {d2["iters"]["ipm_max"]} ({", ".join("%s: %d" % kv for kv in sorted(hist.items(), key=lambda kv: int(kv[0])))}) | `iters` |
+| the device at OSQP's defaults (ε = 1e-3, no polish) vs the optimum | up to {st["max_abs_u_minus_uref"]:.2f} rad in δ₀ after {st["admm_iters_mean"]:.0f} ADMM iterations (mean) | `stock_osqp_settings` |
+
+Rooflines for the dominant kernel K2 at this size:
+
+* HBM (`roofline`): algorithmic 9 932 B/solve (read the 27-field stage-blocked QP, write z, y, u, status,
+  iterations, residuals) → {d2["roofline"]["achieved"]:.1f} GB/s = **{100*d2["roofline"]["frac"]:.2f} % of 8 TB/s**.  K2 is not an HBM kernel (DESIGN.md §5); the
+  number is reported because the contract asks for it.
+  PMC traffic: FETCH_SIZE {f:,.0f} KB (×2, gfx950 correction) + WRITE_SIZE {w:,.0f} KB = {(2*f+w)*1024/1e6:.1f} MB per launch against
+  10.2 MB algorithmic ({(2*f+w)*1024/10170368:.2f}×).  The excess is one-off register-spill traffic (92 B/lane of scratch: loop-invariant
+  values the compiler parks at kernel start, ≈ 5 KB written per wave) plus the padded stage rows.
+  History: lane-strided 8-byte output stores had cost a 64-byte write each (WRITE_SIZE 23.7 MB) until the rows
+  were staged through LDS.
+* FP64 vector (`roofline_fp64`): {d2["roofline_fp64"]["flops_per_solve_mean"]/1e6:.2f} MFLOP useful per solve (instruction census of the emulation,
+  `census.py`) → {d2["roofline_fp64"]["achieved"]:.1f} TFLOP/s = **{100*d2["roofline_fp64"]["frac"]:.1f} % of 78.6 TFLOP/s**; 31 of 64 lanes hold a stage, and during the serial
+  sweeps one lane per chain does useful work, which is what bounds this figure.
+* SQ counters (per wave, mean): {valu/1e3:.0f} k VALU instructions, {salu/1e3:.1f} k SALU, {lds/1e3:.1f} k LDS; SQ_ACTIVE_INST_VALU /
+  SQ_INSTS_VALU = {act:.2f} quad-cycles: with one wave per SIMD every vector instruction, FP64 or not, costs
+  4 cycles, so kernel time ≈ 4 cycles × dynamic instruction count of the slowest wave (+ {100*wait:.0f} % SQ_WAIT_ANY).
+  One ADMM iteration: 928 VALU + 58 SALU instructions, 1 215 quad-cycles = 2.1 µs (`pmc_admm.sh`); a taken
+  loop-back branch costs about 25 cycles (`micro/exec_half.hip`), which is why the sweeps take four steps per trip.
+
+K1 at this size moves 8.6 MB in {k1/1e3:.1f} µs (launch-latency dominated): {8601600/k1:.0f} GB/s = {100*8601600/k1/8000:.0f} % of peak by rocprofv3
+time, {100*d2["roofline_assembly"]["frac"]:.1f} % by event time.  PMC: FETCH_SIZE {fa:.0f} KB (×2 = {2*fa*1024/1e6:.2f} MB; algorithmic inputs 1.03 MB),
+WRITE_SIZE {wa:,.0f} KB (the padded 27 × 1024 × 32 doubles exactly).  At B = 65 536 (`bench_cfg2_b65536*`)
+K1 takes {k1b/1e3:.0f} µs (rocprofv3; {db["roofline_assembly"]["avg_ms"]*1e3:.0f} µs by events) for 551 MB = **{550502400/k1b/1e3:.1f} TB/s, {100*550502400/k1b/8000:.0f} % of the 8 TB/s peak** ({100*550502400/k1b/6300:.0f} % of
+the 6.3 TB/s achievable); PMC traffic there is {(2*fab+wab)*1024/1e6:.0f} MB.
+
+## Other configurations (single runs, `--steps 5`)
+
+Config 2's distribution at B = 2048 (two instances per wave from there on): 7.1 M solves/s, K2 0.27 ms —
+the headline batch of 1024 fills every SIMD with one wave but only 31 of its 64 lanes.
+
+| config | B | N | solves/s | K2 ms | status counts | max|u−u_ref| | status agreement | CPU port solves/s (threads) |
+|---|---|---|---|---|---|---|---|---|
+| 2 | 65 536 | 30 | {db["value"]/1e6:.2f} M | {db["roofline"]["avg_ms"]:.2f} (`<32,16>`: two instances per wave) | all solved | – | – | – |
+| 3 time-optimal | 4 096 | 50 | {d3["value"]/1e6:.2f} M | {d3["roofline"]["avg_ms"]:.2f} (`<64,32>`) | all solved | {d3["max_abs_u_minus_uref"]:.1e} | {100*d3["status_agreement"]:.0f} % | {d3["cpu_baseline"]["value"]/1e3:.1f} k ({d3["cpu_baseline"]["cores"]}) |
+| 4 obstacles | 8 192 | 30 | {d4["value"]/1e3:.0f} k | {d4["roofline"]["avg_ms"]:.1f} (`<32,16>`) | {counts4.get("1", 0)} solved, {counts4.get("-3", 0)} primal infeasible, {counts4.get("2", 0)} inaccurate | {d4["max_abs_u_minus_uref"]:.1e} | {100*d4["status_agreement"]:.0f} % | {d4["cpu_baseline"]["value"]/1e3:.1f} k ({d4["cpu_baseline"]["cores"]}) |
+
+At B = 65 536 K2's PMC traffic is {(2*fb+wb)*1024/1e6:.0f} MB per launch against 651 MB algorithmic ({(2*fb+wb)*1024/650903552:.2f}×: the `<32,16>` variant
+carries 160 B/lane of scratch).
+
+Config 4's time is set by the slowest waves: instances the early polish cannot certify restart the full
+OSQP iteration; infeasible ones need a median of 675 and up to 3 925 ADMM iterations before OSQP's
+certificate fires (solved ones: median 100, max 450), and five reach `max_iter` = 4 000, i.e. at least
+4 000 × 2.1 µs of strictly serial work however the rest is scheduled.
+
+CPU baseline: the GPU box reports 256 hardware threads but its cgroup allows 16 CPUs (`cpu.max` = 1600000/100000);
+`cpu_scaling.txt` shows linear scaling to 16 threads (1.5 k solves/s per thread) and collapse beyond, so the
+baseline runs on the quota.
+
+A bench line's `roofline.traffic` is read from the `pmc_summary.json` that is present when `bench.py` runs, so
+it reflects the previous PMC collection of the same build (`collect.sh` is run twice per refresh).
+
+## History of the headline in this round (config 2, solves/s)
+
+1.44 M first fused kernel → 1.94 M (recurrence matrices, zero scratch) → 2.25 M (early polish) → 2.63 M
+(early polish after 15, coalesced output rows) → 3.42 M (twisted factorisation) → 3.62 M (slack reciprocals)
+→ 3.9 M (conditional refinement, LDS-parked deltas, SGPR constants) → 4.2 M (sweeps four steps per loop trip).
+'''
+open(os.path.join(HERE, "README.md"), "w").write(txt)
+print("profiles/README.md written")
