@@ -36,7 +36,7 @@ extern "C" {
 #define MPMPC_MAX_ITER_REACHED (-2)
 #define MPMPC_PRIMAL_INFEASIBLE (-3)
 #define MPMPC_DUAL_INFEASIBLE (-4)
-#define MPMPC_UNSOLVED (-10)
+#define MPMPC_UNSOLVED (-10) /* no verdict: the iterate is not finite (NaN / Inf in the inputs) */
 
 /* error codes */
 #define MPMPC_OK 0

@@ -1246,6 +1246,12 @@ struct Solver {
       early = false;
       limit = st.max_iter;
     }
+    // non-finite data (a NaN pose, say) must not come back as a "solved" plan: no verdict at all, so
+    // that the caller takes its fallback branch (src/MPC.py:208-220) instead of driving NaN controls
+    Mk bad = L::mfalse();
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) bad = bad | (valid[j] & !(abs_(x[j]) < R(1e300)));
+    status = seli(live & L::gany(bad), I(MPMPC_UNSOLVED), status);
   }
 };
 

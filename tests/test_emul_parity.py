@@ -145,3 +145,21 @@ def test_c_port_agrees_with_emulation_on_a_larger_sample(emu, track):
     ok = sol.status == 1
     assert ok.sum() > 200 and (sol.status == mpmpc.PRIMAL_INFEASIBLE).sum() > 0
     assert np.max(np.abs(sol.u0[ok] - ref["u0"][ok])) <= 1e-6
+
+
+def test_non_finite_inputs_get_no_verdict(emu, track):
+    """A NaN / Inf pose or previous plan must not come back as a solved plan: status UNSOLVED (-10), which the
+    host class treats like an infeasibility verdict (fallback branch); the neighbours in the batch are untouched."""
+    sc = scenarios.make(2, track, B=6)
+    cfg = T.stock_config(sc.N, sc.weights)
+    x0, cc = sc.x0.copy(), sc.cc_prev.copy()
+    x0[1, 0], x0[2, 1] = np.nan, np.inf
+    cc[4, :] = np.nan
+    for G in (64, 32):
+        qp = emu.assemble(cfg, track, (sc.wp_id, x0, cc, sc.lb, sc.ub))
+        sol = emu.solve(cfg, mpmpc.default_settings(), qp, G=G)
+        clean = emu.solve(cfg, mpmpc.default_settings(), emu.assemble(cfg, track, (sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)), G=G)
+        assert list(sol.status[[1, 2]]) == [mpmpc.UNSOLVED, mpmpc.UNSOLVED]
+        for i in (0, 3, 5):
+            assert sol.status[i] == clean.status[i] == 1 and np.max(np.abs(sol.u0[i] - clean.u0[i])) <= 1e-9
+        assert sol.status[4] in (1, mpmpc.UNSOLVED)        # a NaN previous plan only disables the speed cap or poisons it

@@ -308,6 +308,23 @@ def test_every_lane_packing_gives_the_same_answers(cfgid, N, track, monkeypatch)
     h.close()
 
 
+def test_non_finite_inputs_get_no_verdict_on_device(track, monkeypatch):
+    """NaN / Inf poses: status UNSOLVED (-10), never a solved plan, never a hang; the other instances of
+    the batch (and of the same wavefront, with 32 lanes per instance) are untouched."""
+    sc = scenarios.make(2, track, B=6)
+    h = _handle(track, sc.N, sc.weights, sc.B)
+    x0 = sc.x0.copy()
+    x0[1, 0], x0[2, 1] = np.nan, np.inf
+    clean = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    for g in (64, 32):
+        monkeypatch.setenv("MPMPC_LANES_PER_INSTANCE", str(g))
+        sol = h.solve(sc.wp_id, x0, sc.cc_prev, sc.lb, sc.ub)
+        assert list(sol.status[[1, 2]]) == [mpmpc.UNSOLVED, mpmpc.UNSOLVED]
+        for i in (0, 3, 4, 5):
+            assert sol.status[i] == clean.status[i] == 1 and np.max(np.abs(sol.u0[i] - clean.u0[i])) <= 1e-9
+    h.close()
+
+
 def test_open_path_end_is_an_error(track):
     cfg = T.stock_config(30, max_batch=2, circular=False)
     h = mpmpc.Handle(cfg)
