@@ -108,7 +108,8 @@ class ReferencePath:
         sy = [np.mean(ys[c - sd:c + sd + 1]) for c in centres]
         return self._construct_waypoints(list(zip(sx, sy)))
 
-    def _construct_waypoints(self, coords):
+    def _construct_waypoints(self, waypoint_coordinates):
+        coords = waypoint_coordinates
         out = []
         for i in range(len(coords) - 1):
             here, ahead = np.array(coords[i]), np.array(coords[i + 1])
