@@ -1137,7 +1137,10 @@ struct Solver {
     if (!L::wany(run)) return;
     Box bx;
     make_box(bx);
-    const R theta(3e-3), zero(0.0), one(1.0);   // floor of the warm-started slacks / multipliers
+    // floor of the warm-started slacks / multipliers: the closer the ADMM point is to feasibility (unscaled
+    // primal residual), the more its small slacks can be trusted:  theta = pri_res / 80  in [3e-4, 3e-3]
+    const R zero(0.0), one(1.0);
+    const R theta = min_(R(3e-3), max_(R(3e-4), pri_res * R(0.0125)));
     Ipm s;
     MPMPC_UNROLL
     for (int i = 0; i < 3; ++i) s.nu[i] = yeq[i];

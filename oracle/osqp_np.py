@@ -220,7 +220,7 @@ def solve(P, q, A, l, u, settings: Settings | None = None, trace=None) -> Result
             # the polish only needs a reasonable starting point: try it now; if it cannot certify,
             # the ADMM iteration simply goes on
             early = Result(None, None, UNSOLVED, it, 0.0, 0.0, 0.0, 0, rho_updates, w.rho)
-            if _certified_polish(w, x, y, st, early):
+            if _certified_polish(w, x, y, st, early, _warm_start_floor(_info(w, x, z, y)["pri_res"])):
                 xa, ya = w.unscale(x, y)
                 early.x_admm, early.y_admm = xa, ya
                 return early
@@ -260,20 +260,26 @@ def solve(P, q, A, l, u, settings: Settings | None = None, trace=None) -> Result
                 res.polished = -1
         return res
     # polish == 2: interior-point refinement + active-set iterations + certificate
-    if not _certified_polish(w, x, y, st, res):
+    if not _certified_polish(w, x, y, st, res, _warm_start_floor(info["pri_res"])):
         # not certified (typically a marginally infeasible problem that ADMM at a loose eps calls
         # solved): hand back the ADMM iterate, as stock OSQP would, flagged inaccurate
         res.polished, res.status = -1, SOLVED_INACCURATE
     return res
 
 
-def _certified_polish(w, x, y, st, res) -> bool:
+def _warm_start_floor(pri_res):
+    """Floor of the warm-started slacks / multipliers of the interior-point stage: the closer the ADMM
+    point is to feasibility, the more its small slacks can be trusted (pri_res / 80 in [3e-4, 3e-3])."""
+    return min(3e-3, max(3e-4, 0.0125 * pri_res))
+
+
+def _certified_polish(w, x, y, st, res, theta=3e-3) -> bool:
     """Interior-point refinement from the scaled point (x, y), iterated active-set solve, KKT
     certificate.  On success writes the certified point into `res` and returns True."""
     ipm_tol = st.ipm_tol
     xi, yi = x, y
     for attempt in range(2):
-        xi, yi, nit, conv, act = _ipm_refine(w, xi, yi, st, ipm_tol)
+        xi, yi, nit, conv, act = _ipm_refine(w, xi, yi, st, ipm_tol, theta)
         res.ipm_iters += nit
         if not conv:
             break

@@ -479,10 +479,10 @@ static int certificate(const work_t* w, const double* xs, const double* ys, doub
 /* ------------------------------------------------------------------ polish stage 1: interior point */
 typedef struct { int *eq, *L, *U; } classes_t;
 
-static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double* x, double* y, double tol, int* iters_out, int* low, int* upp) {
+static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double* x, double* y, double tol, double theta, int* iters_out, int* low, int* upp) {
   const oracle_settings* st = w->st;
   int n = w->n, m = w->m, N = n + m;
-  const double theta = 3e-3, reg = st->ipm_reg;
+  const double reg = st->ipm_reg;
   double *Ax = (double*)malloc(sizeof(double) * m), *nu = (double*)calloc(m, sizeof(double));
   double *sl = (double*)malloc(sizeof(double) * m), *su = (double*)malloc(sizeof(double) * m);
   double *zl = (double*)malloc(sizeof(double) * m), *zu = (double*)malloc(sizeof(double) * m);
@@ -669,7 +669,10 @@ static int active_set_polish(work_t* w, const classes_t* cl, int* low, int* upp,
 
 /* polish = 2: interior-point refinement from the scaled point (x, y), iterated active-set solve,
  * KKT certificate.  On success writes the certified (unscaled) point and returns 1. */
-static int certified_polish(work_t* w, const double* x, const double* y, double* x_out, double* y_out, oracle_info* info) {
+/* floor of the warm-started slacks / multipliers: pri_res / 80 in [3e-4, 3e-3] (closer ADMM point, smaller floor) */
+static double warm_start_floor(double pri_res) { return dmin(3e-3, dmax(3e-4, 0.0125 * pri_res)); }
+
+static int certified_polish(work_t* w, const double* x, const double* y, double theta, double* x_out, double* y_out, oracle_info* info) {
   const oracle_settings* st = w->st;
   int n = w->n, m = w->m;
   classes_t cl; cl.eq = (int*)malloc(sizeof(int) * m); cl.L = (int*)malloc(sizeof(int) * m); cl.U = (int*)malloc(sizeof(int) * m);
@@ -687,7 +690,7 @@ static int certified_polish(work_t* w, const double* x, const double* y, double*
   int good = 0;
   for (int attempt = 0; attempt < 2 && !good; ++attempt) {
     int nit = 0;
-    int conv = ipm_refine(w, w->K, w->F, &cl, xi, yi, tol, &nit, low, upp);
+    int conv = ipm_refine(w, w->K, w->F, &cl, xi, yi, tol, theta, &nit, low, upp);
     info->ipm_iters += nit;
     if (!conv) break;
     int rounds = 0;
@@ -768,7 +771,8 @@ int oracle_solve_csc(int n, int m, const int* Pp, const int* Pi, const double* P
     if (st->polish == 2 && it == st->early_polish && st->early_polish < st->max_iter) {
       /* the polish only needs a reasonable starting point: try it now; if it cannot certify, ADMM goes on */
       info->status = UNSOLVED; info->iters = it; info->rho_updates = rho_updates; info->ipm_iters = 0; info->as_rounds = 0; info->polished = 0;
-      if (certified_polish(&w, x, y, x_out, y_out, info)) { early_done = 1; break; }
+      compute_info(&w, x, z, y, &o);
+      if (certified_polish(&w, x, y, warm_start_floor(o.pri), x_out, y_out, info)) { early_done = 1; break; }
       /* the interior point re-used the KKT workspace: restore the ADMM factorisation */
       kkt_fill_and_factor(&w, w.K, w.F, st->sigma, w.rho_inv, m);
     }
@@ -800,7 +804,7 @@ int oracle_solve_csc(int n, int m, const int* Pp, const int* Pi, const double* P
   info->polished = 0;
 
   if (st->polish == 2 && (status == SOLVED || status == SOLVED_INACCURATE || status == MAX_ITER_REACHED)) {
-    if (!certified_polish(&w, x, y, x_out, y_out, info)) { info->status = SOLVED_INACCURATE; info->polished = -1; }
+    if (!certified_polish(&w, x, y, warm_start_floor(o.pri), x_out, y_out, info)) { info->status = SOLVED_INACCURATE; info->polished = -1; }
   }
 finish:
   /* objective of the returned point */
