@@ -78,6 +78,9 @@ typedef struct {
   int32_t early_polish; /* > 0: try the polish after this many ADMM iterations; instances it cannot certify
                            run the full ADMM (to max_iter / termination / infeasibility) and are polished
                            again.  0: polish only after ADMM has terminated (OSQP's order). */
+  int32_t early_scaling; /* Ruiz passes done before the early polish attempt (0 or >= scaling: all of them).  The
+                            remaining scaling - early_scaling passes are done before the full ADMM run, which
+                            therefore sees exactly OSQP's `scaling` passes. */
 } mpmpc_settings;
 
 const char* mpmpc_version(void);

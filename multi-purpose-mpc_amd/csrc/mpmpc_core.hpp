@@ -299,8 +299,10 @@ struct Solver {
     c = R(1.0);
   }
 
-  // OSQP scale_data(): `passes` Ruiz sweeps with cost normalisation, then l, u <- E l, E u
-  MPMPC_HD void scale(int passes) {
+  // OSQP scale_data(): `passes` Ruiz sweeps with cost normalisation, then l, u <- E l, E u.  Resumable:
+  // scale(a) followed by scale(b) is scale(a + b) bit for bit; instances outside `on` keep their scaling
+  // (their factors are forced to exactly 1).
+  MPMPC_HD void scale(int passes, const Mk& on) {
     const R n_total(double(5 * N + 3));
     for (int it = 0; it < passes; ++it) {
       R cn[5], rn[3], r_own[3];
@@ -321,7 +323,9 @@ struct Solver {
         Etb[j] = R(1.0) / sqrt_(limit(abs_(g[j])));
       }
       MPMPC_UNROLL
-      for (int i = 0; i < 3; ++i) { Et[i] = R(1.0) / sqrt_(limit(rn[i])); Etd[i] = L::down(Et[i]); }
+      for (int j = 0; j < 5; ++j) { Dt[j] = keep(on, Dt[j], R(1.0)); Etb[j] = keep(on, Etb[j], R(1.0)); }
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) { Et[i] = keep(on, R(1.0) / sqrt_(limit(rn[i])), R(1.0)); Etd[i] = L::down(Et[i]); }
       MPMPC_UNROLL
       for (int j = 0; j < 5; ++j) {
         p[j] = (Dt[j] * p[j]) * Dt[j];
@@ -345,7 +349,7 @@ struct Solver {
       }
       R ct = L::gsum(s) / n_total;
       R nq = limit(L::gmax(mq));
-      ct = R(1.0) / limit(max_(ct, nq));
+      ct = keep(on, R(1.0) / limit(max_(ct, nq)), R(1.0));
       MPMPC_UNROLL
       for (int j = 0; j < 5; ++j) { p[j] = p[j] * ct; q[j] = q[j] * ct; }
       c = c * ct;
@@ -1232,16 +1236,19 @@ struct Solver {
 
   MPMPC_HD void run(const double* qp, int B, int ld, const I& inst, const I& k, int N_, const SolverParams& st) {
     load(qp, B, ld, inst, k, N_);
-    scale(st.scaling);
     // The polish does not need a converged ADMM point, only a reasonable one: with early_polish > 0
-    // it is first tried after that many iterations.  Whatever it cannot certify (infeasible or very
-    // hard instances) goes through the full OSQP iteration from a cold start, exactly as without
-    // the shortcut, and is polished again.  One loop, so admm() / polish() are instantiated once.
+    // it is first tried after that many iterations, on a problem that has seen early_scaling of the
+    // Ruiz passes.  Whatever it cannot certify (infeasible or very hard instances) gets the remaining
+    // passes and goes through the full OSQP iteration from a cold start, exactly as without the
+    // shortcut, and is polished again.  One loop, so admm() / polish() are instantiated once.
     bool early = st.polish && st.early_polish > 0 && st.early_polish < st.max_iter;
     int limit = early ? st.early_polish : st.max_iter;
+    int passes = early && st.early_scaling > 0 && st.early_scaling < st.scaling ? st.early_scaling : st.scaling;
     Mk which = live;
     _Pragma("nounroll")
     for (int pass = 0; pass < 2; ++pass) {
+      scale(passes, which);
+      passes = st.scaling - passes;
       admm(st, which, limit);
       if (st.polish) polish(st, early);
       which = live & (status == MPMPC_UNSOLVED);

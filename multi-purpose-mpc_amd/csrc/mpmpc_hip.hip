@@ -215,6 +215,7 @@ static int check_settings(const mpmpc_settings* s) {
   if (!(s->rho > 0) || !(s->sigma > 0) || !(s->alpha > 0 && s->alpha < 2))
     return fail(MPMPC_E_ARG, "need rho > 0, sigma > 0, 0 < alpha < 2");
   if (s->early_polish < 0) return fail(MPMPC_E_ARG, "early_polish must be >= 0");
+  if (s->early_scaling < 0) return fail(MPMPC_E_ARG, "early_scaling must be >= 0");
   if (s->max_iter < 0 || s->check_termination < 0 || s->scaling < 0 || s->ipm_max_iter < 0 || s->as_rounds < 0 ||
       s->as_refine < 0)
     return fail(MPMPC_E_ARG, "iteration counts must be non-negative");
@@ -253,6 +254,7 @@ void mpmpc_default_settings(mpmpc_settings* s) {
   s->polish = 2; s->ipm_max_iter = 30; s->ipm_tol = 1e-9; s->ipm_reg = 1e-8;
   s->as_delta = 1e-9; s->as_refine = 5; s->as_rounds = 4; s->cert_tol = 1e-8;
   s->early_polish = 15;
+  s->early_scaling = 4;
 }
 
 int32_t mpmpc_stage_ld(int32_t N) { return host_stage_ld(N); }

@@ -82,6 +82,7 @@ class Settings:
     as_rounds: int = 4
     cert_tol: float = 1e-8
     early_polish: int = 15      # polish=2 only: try the polish after this many ADMM iterations (0 = off)
+    early_scaling: int = 4      # Ruiz passes before that attempt; the rest precede the full ADMM run
 
 
 @dataclasses.dataclass
@@ -185,8 +186,25 @@ class Workspace:
 
 
 def solve(P, q, A, l, u, settings: Settings | None = None, trace=None) -> Result:
-    """OSQP: osqp_solve().  `trace`, if a list, receives (iter, x_scaled, z, y) copies."""
+    """OSQP: osqp_solve().  `trace`, if a list, receives (iter, x_scaled, z, y) copies.
+
+    With an early polish attempt (polish=2, early_polish > 0) only `early_scaling` of the Ruiz passes
+    come first; what the attempt cannot certify is solved again from a cold start on the problem with
+    all `scaling` passes, exactly as OSQP would."""
     st = settings or Settings()
+    if st.polish == 2 and 0 < st.early_polish < st.max_iter and 0 < st.early_scaling < st.scaling:
+        first = _solve(P, q, A, l, u, dataclasses.replace(st, scaling=st.early_scaling, early_scaling=0), trace,
+                       stop_after_early=True)
+        if first is not None:
+            return first
+        if trace is not None:
+            del trace[:]
+        full = _solve(P, q, A, l, u, dataclasses.replace(st, early_polish=0), trace)
+        return full
+    return _solve(P, q, A, l, u, st, trace)
+
+
+def _solve(P, q, A, l, u, st: Settings, trace=None, stop_after_early=False):
     w = Workspace(P, q, A, l, u, st)
     n, m = w.n, w.m
     x, y, z = np.zeros(n), np.zeros(m), np.zeros(m)
@@ -224,6 +242,8 @@ def solve(P, q, A, l, u, settings: Settings | None = None, trace=None) -> Result
                 xa, ya = w.unscale(x, y)
                 early.x_admm, early.y_admm = xa, ya
                 return early
+            if stop_after_early:
+                return None
         if st.adaptive_rho and st.adaptive_rho_interval and it % st.adaptive_rho_interval == 0:
             if not can_check:
                 info = _info(w, x, z, y)

@@ -43,7 +43,7 @@ typedef struct {
   double ipm_tol, ipm_reg, as_delta;
   int32_t as_refine, as_rounds;
   double cert_tol;
-  int32_t early_polish;
+  int32_t early_polish, early_scaling;
 } oracle_settings;
 
 typedef struct {
@@ -325,11 +325,12 @@ static void copy_csc(csc* dst, const csc* src) {
   dst->x = (double*)malloc(sizeof(double) * (nnz > 0 ? nnz : 1)); memcpy(dst->x, src->x, sizeof(double) * nnz);
 }
 
-static void scale_data(work_t* w) {
+/* `passes` Ruiz sweeps; resumable: the bounds are always recomputed from the unscaled copies */
+static void scale_data(work_t* w, int passes) {
   int n = w->n, m = w->m;
   double* Dt = (double*)malloc(sizeof(double) * n);
   double* Et = (double*)malloc(sizeof(double) * m);
-  for (int it = 0; it < w->st->scaling; ++it) {
+  for (int it = 0; it < passes; ++it) {
     for (int j = 0; j < n; ++j) Dt[j] = 0;
     for (int r = 0; r < m; ++r) Et[r] = 0;
     for (int j = 0; j < n; ++j)
@@ -363,7 +364,7 @@ static void scale_data(work_t* w) {
     for (int j = 0; j < n; ++j) w->q[j] *= ct;
     w->c *= ct;
   }
-  for (int r = 0; r < m; ++r) { w->l[r] *= w->E[r]; w->u[r] *= w->E[r]; }
+  for (int r = 0; r < m; ++r) { w->l[r] = w->l0c[r] * w->E[r]; w->u[r] = w->u0c[r] * w->E[r]; }
   free(Dt); free(Et);
 }
 
@@ -728,7 +729,11 @@ int oracle_solve_csc(int n, int m, const int* Pp, const int* Pi, const double* P
   w.E = (double*)malloc(sizeof(double) * m); w.Einv = (double*)malloc(sizeof(double) * m);
   for (int j = 0; j < n; ++j) w.D[j] = 1; for (int r = 0; r < m; ++r) w.E[r] = 1;
   w.c = 1.0;
-  if (st->scaling) scale_data(&w);
+  /* with an early polish attempt only early_scaling of the Ruiz passes come first; an instance the attempt
+     cannot certify gets the rest and restarts ADMM from cold */
+  const int early_on = st->polish == 2 && st->early_polish > 0 && st->early_polish < st->max_iter;
+  int passes_done = early_on && st->early_scaling > 0 && st->early_scaling < st->scaling ? st->early_scaling : st->scaling;
+  if (passes_done) scale_data(&w, passes_done);
   for (int j = 0; j < n; ++j) w.Dinv[j] = 1.0 / w.D[j];
   for (int r = 0; r < m; ++r) w.Einv[r] = 1.0 / w.E[r];
   w.cinv = 1.0 / w.c;
@@ -747,7 +752,7 @@ int oracle_solve_csc(int n, int m, const int* Pp, const int* Pi, const double* P
   double *tn = (double*)malloc(sizeof(double) * n), *tm = (double*)malloc(sizeof(double) * m);
   info_t o; o.Ax = (double*)malloc(sizeof(double) * m); o.Px = (double*)malloc(sizeof(double) * n); o.Aty = (double*)malloc(sizeof(double) * n);
   o.rp = (double*)malloc(sizeof(double) * m); o.rd = (double*)malloc(sizeof(double) * n);
-  int status = UNSOLVED, it = 0, rho_updates = 0, early_done = 0, early_ipm = 0, early_as = 0;
+  int status = UNSOLVED, it = 0, rho_updates = 0, early_done = 0, early_ipm = 0, early_as = 0, early_failed = 0;
   compute_info(&w, x, z, y, &o);
   const double alpha = st->alpha;
   while (it < st->max_iter) {
@@ -768,11 +773,27 @@ int oracle_solve_csc(int n, int m, const int* Pp, const int* Pi, const double* P
     int can_adapt = st->adaptive_rho && st->adaptive_rho_interval > 0 && it % st->adaptive_rho_interval == 0;
     if (can_check || can_adapt) compute_info(&w, x, z, y, &o);
     if (can_check) { status = check_termination(&w, &o, z, dx, dy, 0, tn, tm); if (status != UNSOLVED) break; }
-    if (st->polish == 2 && it == st->early_polish && st->early_polish < st->max_iter) {
+    if (early_on && !early_failed && it == st->early_polish) {
       /* the polish only needs a reasonable starting point: try it now; if it cannot certify, ADMM goes on */
       info->status = UNSOLVED; info->iters = it; info->rho_updates = rho_updates; info->ipm_iters = 0; info->as_rounds = 0; info->polished = 0;
       compute_info(&w, x, z, y, &o);
       if (certified_polish(&w, x, y, warm_start_floor(o.pri), x_out, y_out, info)) { early_done = 1; break; }
+      if (passes_done < st->scaling) {
+        /* not certified: the remaining Ruiz passes, then the full OSQP iteration from a cold start */
+        scale_data(&w, st->scaling - passes_done);
+        passes_done = st->scaling;
+        for (int j = 0; j < n; ++j) w.Dinv[j] = 1.0 / w.D[j];
+        for (int r = 0; r < m; ++r) w.Einv[r] = 1.0 / w.E[r];
+        w.cinv = 1.0 / w.c;
+        w.rho = st->rho; rho_updates = 0;
+        set_rho_vec(&w);
+        memset(x, 0, sizeof(double) * n); memset(z, 0, sizeof(double) * m); memset(y, 0, sizeof(double) * m);
+        memset(dx, 0, sizeof(double) * n); memset(dy, 0, sizeof(double) * m);
+        early_ipm = info->ipm_iters; early_as = info->as_rounds; early_failed = 1;
+        it = 0;
+        kkt_fill_and_factor(&w, w.K, w.F, st->sigma, w.rho_inv, m);
+        continue;
+      }
       /* the interior point re-used the KKT workspace: restore the ADMM factorisation */
       kkt_fill_and_factor(&w, w.K, w.F, st->sigma, w.rho_inv, m);
     }
@@ -788,7 +809,7 @@ int oracle_solve_csc(int n, int m, const int* Pp, const int* Pi, const double* P
     }
   }
   if (early_done) goto finish;
-  early_ipm = info->ipm_iters; early_as = info->as_rounds;
+  if (!early_failed) { early_ipm = info->ipm_iters; early_as = info->as_rounds; }
   if (status == UNSOLVED) {
     compute_info(&w, x, z, y, &o);
     status = check_termination(&w, &o, z, dx, dy, 0, tn, tm);
