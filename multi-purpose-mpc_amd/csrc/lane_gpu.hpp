@@ -9,22 +9,19 @@ namespace mpmpc {
 
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ double sqrt_(double a) { return __builtin_sqrt(a); }
-// 1/sqrt(a): hardware seed (v_rsq_f64) + one cubic and one quadratic Newton step in FMA form
+// 1/sqrt(a): hardware seed (v_rsq_f64, measured relative error 5e-8) + one cubic Newton step in FMA form:
+// 1.24 ulp, the same as with a further quadratic step (profiles/micro/rsq_accuracy.hip)
 __device__ __forceinline__ double rsqrt_(double a) {
   double r = __builtin_amdgcn_rsq(a);
   double e = __builtin_fma(-(a * r), r, 1.0);
-  r = __builtin_fma(r * e, __builtin_fma(0.375, e, 0.5), r);
-  e = __builtin_fma(-(a * r), r, 1.0);
-  return __builtin_fma(r * e, 0.5, r);
+  return __builtin_fma(r * e, __builtin_fma(0.375, e, 0.5), r);
 }
-// 1/a: hardware seed (v_rcp_f64) + two Newton steps in FMA form; a product with it replaces the
-// full IEEE division sequence where the last bit does not matter (interior-point iteration)
+// 1/a: hardware seed (v_rcp_f64, 5e-8) + one cubic step r (1 + e + e^2): 1.0 ulp; a product with it replaces
+// the full IEEE division sequence where the last bit does not matter (interior-point iteration)
 __device__ __forceinline__ double rcp_(double a) {
   double r = __builtin_amdgcn_rcp(a);
   double e = __builtin_fma(-a, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  e = __builtin_fma(-a, r, 1.0);
-  return __builtin_fma(r, e, r);
+  return __builtin_fma(r, __builtin_fma(e, e, e), r);
 }
 __device__ __forceinline__ double abs_(double a) { return __builtin_fabs(a); }
 __device__ __forceinline__ double max_(double a, double b) { return __builtin_fmax(a, b); }   // v_max_f64
