@@ -436,30 +436,31 @@ struct Solver {
       R Mr[9];
       MPMPC_UNROLL
       for (int i = 0; i < 9; ++i) Mr[i] = L::cup(M[i]);
-      R S00 = Dg[0] - fma_(Mr[2], Mr[2], fma_(Mr[1], Mr[1], Mr[0] * Mr[0]));
-      R S10 = Dg[1] - fma_(Mr[5], Mr[2], fma_(Mr[4], Mr[1], Mr[3] * Mr[0]));
-      R S11 = Dg[2] - fma_(Mr[5], Mr[5], fma_(Mr[4], Mr[4], Mr[3] * Mr[3]));
-      R S20 = Dg[3] - fma_(Mr[8], Mr[2], fma_(Mr[7], Mr[1], Mr[6] * Mr[0]));
-      R S21 = Dg[4] - fma_(Mr[8], Mr[5], fma_(Mr[7], Mr[4], Mr[6] * Mr[3]));
-      R S22 = Dg[5] - fma_(Mr[8], Mr[8], fma_(Mr[7], Mr[7], Mr[6] * Mr[6]));
+      // S = Dg - Mr Mr' (lower part), products subtracted inside the FMAs
+      R S00 = fma_(-Mr[2], Mr[2], fma_(-Mr[1], Mr[1], fma_(-Mr[0], Mr[0], Dg[0])));
+      R S10 = fma_(-Mr[5], Mr[2], fma_(-Mr[4], Mr[1], fma_(-Mr[3], Mr[0], Dg[1])));
+      R S11 = fma_(-Mr[5], Mr[5], fma_(-Mr[4], Mr[4], fma_(-Mr[3], Mr[3], Dg[2])));
+      R S20 = fma_(-Mr[8], Mr[2], fma_(-Mr[7], Mr[1], fma_(-Mr[6], Mr[0], Dg[3])));
+      R S21 = fma_(-Mr[8], Mr[5], fma_(-Mr[7], Mr[4], fma_(-Mr[6], Mr[3], Dg[4])));
+      R S22 = fma_(-Mr[8], Mr[8], fma_(-Mr[7], Mr[7], fma_(-Mr[6], Mr[6], Dg[5])));
       if (junction) {
         // junction: both chains have settled; mid also loses the block of the end lane
         R Mx[9];
         MPMPC_UNROLL
         for (int i = 0; i < 9; ++i) Mx[i] = sel(is_mid, L::down(L::mirror(M[i])), R(0.0));
-        S00 = S00 - fma_(Mx[2], Mx[2], fma_(Mx[1], Mx[1], Mx[0] * Mx[0]));
-        S10 = S10 - fma_(Mx[5], Mx[2], fma_(Mx[4], Mx[1], Mx[3] * Mx[0]));
-        S11 = S11 - fma_(Mx[5], Mx[5], fma_(Mx[4], Mx[4], Mx[3] * Mx[3]));
-        S20 = S20 - fma_(Mx[8], Mx[2], fma_(Mx[7], Mx[1], Mx[6] * Mx[0]));
-        S21 = S21 - fma_(Mx[8], Mx[5], fma_(Mx[7], Mx[4], Mx[6] * Mx[3]));
-        S22 = S22 - fma_(Mx[8], Mx[8], fma_(Mx[7], Mx[7], Mx[6] * Mx[6]));
+        S00 = fma_(-Mx[2], Mx[2], fma_(-Mx[1], Mx[1], fma_(-Mx[0], Mx[0], S00)));
+        S10 = fma_(-Mx[5], Mx[2], fma_(-Mx[4], Mx[1], fma_(-Mx[3], Mx[0], S10)));
+        S11 = fma_(-Mx[5], Mx[5], fma_(-Mx[4], Mx[4], fma_(-Mx[3], Mx[3], S11)));
+        S20 = fma_(-Mx[8], Mx[2], fma_(-Mx[7], Mx[1], fma_(-Mx[6], Mx[0], S20)));
+        S21 = fma_(-Mx[8], Mx[5], fma_(-Mx[7], Mx[4], fma_(-Mx[6], Mx[3], S21)));
+        S22 = fma_(-Mx[8], Mx[8], fma_(-Mx[7], Mx[7], fma_(-Mx[6], Mx[6], S22)));
       }
       // 3x3 Cholesky through reciprocal square roots: i_jj = 1 / l_jj
       R i00 = rsqrt_(S00);
       R l10 = S10 * i00, l20 = S20 * i00;
-      R i11 = rsqrt_(S11 - l10 * l10);
-      R l21 = (S21 - l20 * l10) * i11;
-      R i22 = rsqrt_(S22 - fma_(l21, l21, l20 * l20));
+      R i11 = rsqrt_(fma_(-l10, l10, S11));
+      R l21 = fma_(-l20, l10, S21) * i11;
+      R i22 = rsqrt_(fma_(-l21, l21, fma_(-l20, l20, S22)));
       R i10 = -(l10 * i00) * i11;
       R i21 = -(l21 * i11) * i22;
       R i20 = -(fma_(l21, i10, l20 * i00)) * i22;
