@@ -915,8 +915,8 @@ struct Solver {
         R rhs[5], nreq[3];
         MPMPC_UNROLL
         for (int j = 0; j < 5; ++j)
-          rhs[j] = -rd[j] - sel(bx.Lm[j], (rcl[j] + s.zl[j] * rl_of(j)) * isl[j], zero) +
-                   sel(bx.Um[j], (rcu[j] + s.zu[j] * ru_of(j)) * isu[j], zero) - sel(bx.pin[j], rpin_of(j) * ireg, zero);
+          rhs[j] = -rd[j] - sel(bx.Lm[j], fma_(s.zl[j], rl_of(j), rcl[j]) * isl[j], zero) +
+                   sel(bx.Um[j], fma_(s.zu[j], ru_of(j), rcu[j]) * isu[j], zero) - sel(bx.pin[j], rpin_of(j) * ireg, zero);
         MPMPC_UNROLL
         for (int i = 0; i < 3; ++i) nreq[i] = -rp[i];
         kkt_solve(rhs, nreq, dx, dnu);
@@ -952,8 +952,8 @@ struct Solver {
         for (int j = 0; j < 5; ++j) {
           dsl[j] = sel(bx.Lm[j], dx[j] + rl_of(j), zero);
           dsu[j] = sel(bx.Um[j], -dx[j] + ru_of(j), zero);
-          dzl[j] = sel(bx.Lm[j], (-rcl[j] - s.zl[j] * dsl[j]) * isl[j], zero);
-          dzu[j] = sel(bx.Um[j], (-rcu[j] - s.zu[j] * dsu[j]) * isu[j], zero);
+          dzl[j] = sel(bx.Lm[j], -fma_(s.zl[j], dsl[j], rcl[j]) * isl[j], zero);
+          dzu[j] = sel(bx.Um[j], -fma_(s.zu[j], dsu[j], rcu[j]) * isu[j], zero);
           dpi[j] = sel(bx.pin[j], (rpin_of(j) + dx[j]) * ireg, zero);
           blk = max_(blk, max_(sel(bx.Lm[j], -dsl[j] * isl[j], zero), sel(bx.Um[j], -dsu[j] * isu[j], zero)));
           blk = max_(blk, max_(sel(bx.Lm[j], -dzl[j] * rcp_(s.zl[j]), zero), sel(bx.Um[j], -dzu[j] * rcp_(s.zu[j]), zero)));
@@ -965,15 +965,16 @@ struct Solver {
           R ms(0.0);
           MPMPC_UNROLL
           for (int j = 0; j < 5; ++j)
-            ms = ms + sel(bx.Lm[j], (s.sl[j] + alpha_aff * dsl[j]) * (s.zl[j] + alpha_aff * dzl[j]), zero) +
-                 sel(bx.Um[j], (s.su[j] + alpha_aff * dsu[j]) * (s.zu[j] + alpha_aff * dzu[j]), zero);
+            ms = ms + sel(bx.Lm[j], fma_(alpha_aff, dsl[j], s.sl[j]) * fma_(alpha_aff, dzl[j], s.zl[j]), zero) +
+                 sel(bx.Um[j], fma_(alpha_aff, dsu[j], s.su[j]) * fma_(alpha_aff, dzu[j], s.zu[j]), zero);
           R mu_aff = L::gsum(ms) / nb;
           R sg = mu_aff / max_(mu, R(1e-300));
           sg = sg * sg * sg;
+          const R sgmu = sg * mu;
           MPMPC_UNROLL
           for (int j = 0; j < 5; ++j) {
-            rcl[j] = s.sl[j] * s.zl[j] - sg * mu + dsl[j] * dzl[j];
-            rcu[j] = s.su[j] * s.zu[j] - sg * mu + dsu[j] * dzu[j];
+            rcl[j] = fma_(dsl[j], dzl[j], fma_(s.sl[j], s.zl[j], -sgmu));
+            rcu[j] = fma_(dsu[j], dzu[j], fma_(s.su[j], s.zu[j], -sgmu));
           }
         } else {
           R al = min_(one, R(0.995) * ratio);
