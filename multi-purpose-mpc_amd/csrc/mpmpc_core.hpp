@@ -1236,14 +1236,17 @@ struct Solver {
     if (resid) { L::store(resid, inst * 2, lead, pri_res); L::store(resid, inst * 2 + 1, lead, dua_res); }
   }
 
-  MPMPC_HD void run(const double* qp, int B, int ld, const I& inst, const I& k, int N_, const SolverParams& st) {
+  // mode 0: early attempt + full run; 1: early attempt only (uncertified instances stay UNSOLVED);
+  // 2: full run only (the second launch of a packed batch, see mpmpc_solve_kernel)
+  MPMPC_HD void run(const double* qp, int B, int ld, const I& inst, const I& k, int N_, const SolverParams& st,
+                    int mode = 0) {
     load(qp, B, ld, inst, k, N_);
     // The polish does not need a converged ADMM point, only a reasonable one: with early_polish > 0
     // it is first tried after that many iterations, on a problem that has seen early_scaling of the
     // Ruiz passes.  Whatever it cannot certify (infeasible or very hard instances) gets the remaining
     // passes and goes through the full OSQP iteration from a cold start, exactly as without the
     // shortcut, and is polished again.  One loop, so admm() / polish() are instantiated once.
-    bool early = st.polish && st.early_polish > 0 && st.early_polish < st.max_iter;
+    bool early = mode != 2 && st.polish && st.early_polish > 0 && st.early_polish < st.max_iter;
     int limit = early ? st.early_polish : st.max_iter;
     int passes = early && st.early_scaling > 0 && st.early_scaling < st.scaling ? st.early_scaling : st.scaling;
     Mk which = live;
@@ -1254,7 +1257,7 @@ struct Solver {
       admm(st, which, limit);
       if (st.polish) polish(st, early);
       which = live & (status == MPMPC_UNSOLVED);
-      if (!early || !L::wany(which)) break;
+      if (!early || mode == 1 || !L::wany(which)) break;
       early = false;
       limit = st.max_iter;
     }

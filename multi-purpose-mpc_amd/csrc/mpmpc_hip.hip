@@ -59,18 +59,29 @@ __global__ __launch_bounds__(K1_THREADS) void mpmpc_assemble_kernel(
   }
 }
 
+// mode 0: the whole solve (early polish attempt, then the full OSQP run of what it could not certify).
+// mode 1: the early attempt only; the ids of uncertified instances are appended to tail[1..], tail[0] counts.
+// mode 2: the full run only, on the instances listed in tail (one per wave).
+// A packed launch (2 or 4 instances per wave) uses modes 1 + 2: the few instances that need hundreds or
+// thousands of ADMM iterations then run one per wave, on the faster G = 64 code, instead of holding a
+// packed wave (and its finished partner lanes) for the whole tail.
 template <int G, int C>
 __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, SolverParams st, int B, int ld,
                                                          const double* __restrict__ qp, double* __restrict__ z,
                                                          double* __restrict__ u0, int* __restrict__ status,
                                                          int* __restrict__ iters, double* __restrict__ resid,
-                                                         double* __restrict__ y) {
+                                                         double* __restrict__ y, int mode, int* __restrict__ tail) {
   using L = LaneGpu<G, C>;
-  const int inst = blockIdx.x * L::per_wave + L::slot();
+  int inst = blockIdx.x * L::per_wave + L::slot();
+  if (mode == 2) {
+    if ((int)blockIdx.x >= tail[0]) return;       // wave-uniform: G = 64 here
+    inst = tail[1 + blockIdx.x];
+  }
   const int k = L::stage();
   Solver<L> s;
-  s.run(qp, B, ld, inst, k, cfg.N, st);
+  s.run(qp, B, ld, inst, k, cfg.N, st, mode);
   s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y);
+  if (mode == 1 && k == 0 && inst < B && s.status == MPMPC_UNSOLVED) tail[1 + atomicAdd(tail, 1)] = inst;
 }
 
 // K4: speed profile, one thread per path (a serial interior-point / active-set run over a scalar
@@ -206,6 +217,8 @@ struct mpmpc_handle_s {
   // stage-blocked QP and outputs
   double *qp = nullptr, *z = nullptr, *u0 = nullptr, *resid = nullptr, *y = nullptr;
   int *status = nullptr, *iters = nullptr;
+  // instances the early pass of a packed (2 or 4 per wave) launch could not certify: [0] = count, [1..] = ids
+  int* tail = nullptr;
 };
 
 static int host_stage_ld(int N) { return N + 1 <= 16 ? 16 : (N + 1 <= 32 ? 32 : 64); }
@@ -265,7 +278,7 @@ int mpmpc_destroy(mpmpc_handle h) {
   void* ptrs[] = {h->kappa, h->v_ref, h->ds_next, h->ub_tab, h->lb_tab, h->wp_id, h->x0,  h->cc,   h->lb,  h->ub,
                   h->qp,    h->z,     h->u0,      h->resid,  h->y,      h->status, h->iters, h->map, h->gx,  h->gy,
                   h->gpsi,  h->bub,   h->blb,     h->segs,   h->nseg,   h->bad,    h->ro_cum, h->ro_s, h->ro_pose,
-                  h->ro_u,  h->ro_counter, h->ro_alive};
+                  h->ro_u,  h->ro_counter, h->ro_alive, h->tail};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& e : h->ev)
@@ -325,6 +338,7 @@ int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_
   ALLOC(h->y, B * h->m);
   ALLOC(h->status, B);
   ALLOC(h->iters, B * 2);
+  ALLOC(h->tail, B + 1);
 #undef ALLOC
   hipError_t e = hipStreamCreate(&h->stream);
   for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
@@ -574,15 +588,23 @@ static int launch_solve(mpmpc_handle h, int B) {
   }
   const int per = 64 / G;
   const int blocks = (B + per - 1) / per;
-  const int C = lane_split(G, N);        // where the two elimination chains of the factorisation meet
   const SolverParams prm = make_params(h->st);
-#define LAUNCH(GG, CC)                                                                                          \
-  hipLaunchKernelGGL((mpmpc_solve_kernel<GG, CC>), dim3(blocks), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, \
-                     h->qp, h->z, h->u0, h->status, h->iters, h->resid, h->y)
-  if (G == 64 && C == 16) LAUNCH(64, 16);
-  else if (G == 64) LAUNCH(64, 32);
-  else if (G == 32) LAUNCH(32, 16);
-  else LAUNCH(16, 16);
+  const bool early = prm.polish && prm.early_polish > 0 && prm.early_polish < prm.max_iter;
+  const int first_mode = (G < 64 && early) ? 1 : 0;      // packed launches hand their tail to a second one
+#define LAUNCH(GG, CC, MODE, BLOCKS)                                                                             \
+  hipLaunchKernelGGL((mpmpc_solve_kernel<GG, CC>), dim3(BLOCKS), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, \
+                     h->qp, h->z, h->u0, h->status, h->iters, h->resid, h->y, MODE, h->tail)
+  if (first_mode == 1) HIP_TRY(hipMemsetAsync(h->tail, 0, sizeof(int), h->stream));
+  const int C = lane_split(G, N);        // where the two elimination chains of the factorisation meet
+  if (G == 64 && C == 16) LAUNCH(64, 16, first_mode, blocks);
+  else if (G == 64) LAUNCH(64, 32, first_mode, blocks);
+  else if (G == 32) LAUNCH(32, 16, first_mode, blocks);
+  else LAUNCH(16, 16, first_mode, blocks);
+  if (first_mode == 1) {
+    // the tail is short (infeasible / very hard instances); waves beyond its length return at once
+    if (lane_split(64, N) == 16) LAUNCH(64, 16, 2, B);
+    else LAUNCH(64, 32, 2, B);
+  }
 #undef LAUNCH
   HIP_TRY(hipGetLastError());
   return MPMPC_OK;
