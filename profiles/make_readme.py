@@ -86,6 +86,12 @@ WRITE_SIZE {wa:,.0f} KB (the padded 27 × 1024 × 32 doubles exactly).  At B = 6
 K1 takes {k1b/1e3:.0f} µs (rocprofv3; {db["roofline_assembly"]["avg_ms"]*1e3:.0f} µs by events) for 551 MB = **{550502400/k1b/1e3:.1f} TB/s, {100*550502400/k1b/8000:.0f} % of the 8 TB/s peak** ({100*550502400/k1b/6300:.0f} % of
 the 6.3 TB/s achievable); PMC traffic there is {(2*fab+wab)*1024/1e6:.0f} MB.
 
+## Single instance (the drop-in case)
+
+`latency_b1.py`: one `mpmpc_solve` call with B = 1 from host buffers takes 0.27 ms end to end (K1 7 µs, K2 148 µs by
+events; the rest is two small PCIe copies and the launch path) — the reference spends ≈ 24 ms per control step in
+Python + OSQP.
+
 ## Other configurations (single runs, `--steps 5`)
 
 Config 2's distribution at B = 2048 (two instances per wave from there on): 7.1 M solves/s, K2 0.27 ms —
