@@ -217,6 +217,10 @@ struct mpmpc_handle_s {
   // stage-blocked QP and outputs
   double *qp = nullptr, *z = nullptr, *u0 = nullptr, *resid = nullptr, *y = nullptr;
   int *status = nullptr, *iters = nullptr;
+  // pinned host staging for mpmpc_upload / mpmpc_download (small copies from pageable memory are
+  // synchronous and slow; nullptr above STAGE_LIMIT bytes: large batches amortise the direct path)
+  char *stage_in = nullptr, *stage_out = nullptr;
+  size_t stage_in_bytes = 0, stage_out_bytes = 0;
   // instances the early pass of a packed (2 or 4 per wave) launch could not certify: [0] = count, [1..] = ids
   int* tail = nullptr;
 };
@@ -281,6 +285,8 @@ int mpmpc_destroy(mpmpc_handle h) {
                   h->ro_u,  h->ro_counter, h->ro_alive, h->tail};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (h->stage_in) (void)hipHostFree(h->stage_in);
+  if (h->stage_out) (void)hipHostFree(h->stage_out);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -340,6 +346,15 @@ int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_
   ALLOC(h->iters, B * 2);
   ALLOC(h->tail, B + 1);
 #undef ALLOC
+  {
+    const size_t STAGE_LIMIT = 64u << 20;
+    const size_t in_b = B * (sizeof(int) + sizeof(double) * (3 + 4 * N)) + 64;          // + alignment slack
+    const size_t out_b = B * (sizeof(double) * (h->n + h->m + 4) + sizeof(int) * 3) + 64;
+    if (in_b <= STAGE_LIMIT && hipHostMalloc((void**)&h->stage_in, in_b, hipHostMallocDefault) == hipSuccess) h->stage_in_bytes = in_b;
+    else h->stage_in = nullptr;
+    if (out_b <= STAGE_LIMIT && hipHostMalloc((void**)&h->stage_out, out_b, hipHostMallocDefault) == hipSuccess) h->stage_out_bytes = out_b;
+    else h->stage_out = nullptr;
+  }
   hipError_t e = hipStreamCreate(&h->stream);
   for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
   if (e != hipSuccess) {
@@ -550,12 +565,19 @@ int mpmpc_upload(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* 
     if (!h->cfg.circular && wp_id[i] + N >= h->n_wp) return fail(MPMPC_E_ARG, "Reached end of path!");
   }
   HIP_TRY(hipSetDevice(h->cfg.device));
-  HIP_TRY(hipMemcpyAsync(h->wp_id, wp_id, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->x0, x0, sizeof(double) * 3 * B, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->cc, cc_prev, sizeof(double) * 2 * N * B, hipMemcpyHostToDevice, h->stream));
+  // through pinned staging when there is one: the copies are then truly asynchronous and cheap to issue
+  char* stage = h->stage_in;
+  auto push = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+    const void* from = src;
+    if (stage) { std::memcpy(stage, src, bytes); from = stage; stage += (bytes + 7) & ~size_t(7); }
+    return hipMemcpyAsync(dst, from, bytes, hipMemcpyHostToDevice, h->stream);
+  };
+  HIP_TRY(push(h->wp_id, wp_id, sizeof(int) * B));
+  HIP_TRY(push(h->x0, x0, sizeof(double) * 3 * B));
+  HIP_TRY(push(h->cc, cc_prev, sizeof(double) * 2 * N * B));
   if (lb) {
-    HIP_TRY(hipMemcpyAsync(h->lb, lb, sizeof(double) * N * B, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->ub, ub, sizeof(double) * N * B, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(push(h->lb, lb, sizeof(double) * N * B));
+    HIP_TRY(push(h->ub, ub, sizeof(double) * N * B));
   }
   HIP_TRY(hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller
   h->have_rows = lb != nullptr;
@@ -699,13 +721,23 @@ int mpmpc_download(mpmpc_handle h, int32_t B, double* z, double* u0, int32_t* st
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
   if (B < 1 || B > h->uploaded) return fail(MPMPC_E_STATE, "B exceeds the uploaded batch");
   HIP_TRY(hipSetDevice(h->cfg.device));
-  if (z) HIP_TRY(hipMemcpyAsync(z, h->z, sizeof(double) * h->n * B, hipMemcpyDeviceToHost, h->stream));
-  if (u0) HIP_TRY(hipMemcpyAsync(u0, h->u0, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, h->stream));
-  if (status) HIP_TRY(hipMemcpyAsync(status, h->status, sizeof(int) * B, hipMemcpyDeviceToHost, h->stream));
-  if (iters) HIP_TRY(hipMemcpyAsync(iters, h->iters, sizeof(int) * 2 * B, hipMemcpyDeviceToHost, h->stream));
-  if (resid) HIP_TRY(hipMemcpyAsync(resid, h->resid, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, h->stream));
-  if (y) HIP_TRY(hipMemcpyAsync(y, h->y, sizeof(double) * h->m * B, hipMemcpyDeviceToHost, h->stream));
+  struct Pull { void* user; const char* staged; size_t bytes; } pulls[6];
+  int np = 0;
+  char* stage = h->stage_out;
+  auto pull = [&](void* user, const void* dev, size_t bytes) -> hipError_t {
+    if (!user) return hipSuccess;
+    void* to = user;
+    if (stage) { to = stage; pulls[np++] = Pull{user, stage, bytes}; stage += (bytes + 7) & ~size_t(7); }
+    return hipMemcpyAsync(to, dev, bytes, hipMemcpyDeviceToHost, h->stream);
+  };
+  HIP_TRY(pull(z, h->z, sizeof(double) * h->n * B));
+  HIP_TRY(pull(u0, h->u0, sizeof(double) * 2 * B));
+  HIP_TRY(pull(status, h->status, sizeof(int) * B));
+  HIP_TRY(pull(iters, h->iters, sizeof(int) * 2 * B));
+  HIP_TRY(pull(resid, h->resid, sizeof(double) * 2 * B));
+  HIP_TRY(pull(y, h->y, sizeof(double) * h->m * B));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < np; ++i) std::memcpy(pulls[i].user, pulls[i].staged, pulls[i].bytes);
   return MPMPC_OK;
 }
 

@@ -88,8 +88,8 @@ the 6.3 TB/s achievable); PMC traffic there is {(2*fab+wab)*1024/1e6:.0f} MB.
 
 ## Single instance (the drop-in case)
 
-`latency_b1.py`: one `mpmpc_solve` call with B = 1 from host buffers takes 0.27 ms end to end (K1 7 µs, K2 148 µs by
-events; the rest is two small PCIe copies and the launch path) — the reference spends ≈ 24 ms per control step in
+`latency_b1.py`: one `mpmpc_solve` call with B = 1 from host buffers takes 0.20 ms end to end (K1 7 µs, K2 148 µs by
+events; the rest is the PCIe copies through pinned staging and the launch path; 0.27 ms before the staging) — the reference spends ≈ 24 ms per control step in
 Python + OSQP.
 
 ## Other configurations (single runs, `--steps 5`)
