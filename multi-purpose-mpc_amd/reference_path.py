@@ -197,6 +197,7 @@ class ReferencePath:
         for i, wp in enumerate(self.waypoints[:-1]):
             wp.v_ref = v[i]
         self.waypoints[-1].v_ref = self.waypoints[-2].v_ref
+        self.tables_version = getattr(self, "tables_version", 0) + 1     # the controller re-uploads its path tables
 
     # ------------------------------------------------------------------ access
     def get_waypoint(self, wp_id):

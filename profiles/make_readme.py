@@ -90,7 +90,9 @@ the 6.3 TB/s achievable); PMC traffic there is {(2*fab+wab)*1024/1e6:.0f} MB.
 
 `latency_b1.py`: one `mpmpc_solve` call with B = 1 from host buffers takes 0.20 ms end to end (K1 7 µs, K2 148 µs by
 events; the rest is the PCIe copies through pinned staging and the launch path; 0.27 ms before the staging) — the reference spends ≈ 24 ms per control step in
-Python + OSQP (SURVEY §8a).
+Python + OSQP (SURVEY §8a).  `latency_get_control.py`: the whole `MPC.get_control()` + `drive()` step of the
+host class takes 4.6 ms with the corridor computed on the host like the reference and 0.57 ms with
+`corridor="device"` (K0 table on the GPU, rebuilt when the map changes).
 
 ## Other configurations (single runs, `--steps 5`)
 

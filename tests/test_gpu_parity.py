@@ -200,6 +200,29 @@ def test_free_running_lap_on_gpu():
     assert abs(steps - g["s"].size) <= 10           # the reference's lap: 207 steps
 
 
+def test_device_corridor_in_the_single_car_loop():
+    """MPC(..., corridor="device"): the corridor of every step comes from the K0 table on the GPU instead of
+    ReferencePath.update_path_constraints on the host.  Same controls as the host-corridor controller, step by
+    step on identical states, before and after an obstacle is added to the map (the table is rebuilt)."""
+    import time
+    import test_host_mpc as H
+    from map import Obstacle
+    m, rp, car = H.build_world()
+    host, dev = H.make_mpc(car, 30), H.make_mpc(car, 30, corridor="device")
+    t_host = t_dev = 0.0
+    for step in range(60):
+        if step == 30:
+            m.add_obstacles([Obstacle(cx=float(rp.waypoints[car.wp_id + 12].x), cy=float(rp.waypoints[car.wp_id + 12].y), radius=0.03)])
+        dev.current_control = np.array(host.current_control)
+        dev.infeasibility_counter = host.infeasibility_counter
+        t = time.perf_counter(); u_dev = dev.get_control(); t_dev += time.perf_counter() - t
+        t = time.perf_counter(); u_host = host.get_control(); t_host += time.perf_counter() - t
+        assert dev.last_status == host.last_status
+        assert np.max(np.abs(u_dev - u_host)) <= 1e-8, step
+        car.drive(u_host)
+    assert t_dev < t_host
+
+
 def test_batch_mpc_matches_single_controller():
     import test_host_mpc as H
     from MPC import BatchMPC

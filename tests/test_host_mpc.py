@@ -30,7 +30,7 @@ def build_world(obstacles=True):
     return m, rp, car
 
 
-def make_mpc(car, N, backend=None):
+def make_mpc(car, N, backend=None, corridor="host"):
     from scipy import sparse
     Q, R, QN = sparse.diags([1.0, 0.0, 0.0]), sparse.diags([0.5, 0.0]), sparse.diags([1.0, 0.0, 0.0])
     ic = {'umin': np.array([0.0, -np.tan(0.66) / car.length]), 'umax': np.array([1.0, np.tan(0.66) / car.length])}
@@ -38,7 +38,7 @@ def make_mpc(car, N, backend=None):
     if backend == "emu":
         cfg = T.stock_config(N)
         backend = T.EmuBackend(cfg, mpmpc.default_settings())
-    return MPC(car, N, Q, R, QN, sc, ic, 4.0, backend=backend)
+    return MPC(car, N, Q, R, QN, sc, ic, 4.0, backend=backend, corridor=corridor)
 
 
 @pytest.mark.parametrize("N,stride", [(10, 1), (30, 3)])
