@@ -121,6 +121,20 @@ struct LaneGpu {
     }
   }
 
+  // ---- half-wave exchange (G = 64, N + 1 <= 32: lanes 32..63 carry the inputs of the stage on lane - 32)
+  // from_upper(a): every lane gets a of lane | 32;  from_lower(a): every lane gets a of lane & 31.
+  // v_permlane32_swap on (a, a) produces both at once, one instruction per dword, no LDS.
+  static __device__ __forceinline__ double from_upper(double a) {
+    auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(a), false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(a), false, false);
+    return __hiloint2double((int)hi[1], (int)lo[1]);
+  }
+  static __device__ __forceinline__ double from_lower(double a) {
+    auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(a), false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(a), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]);
+  }
+
   static __device__ __forceinline__ double gmax(double a) {
 #pragma unroll
     for (int off = 1; off < G; off <<= 1) { double t = __shfl_xor(a, off, 64); a = __builtin_fmax(a, t); }

@@ -188,6 +188,12 @@ struct Solver {
   int N, n_inst;
   Mk vx, vu, first;      // lane holds a real stage (k <= N), a real input (k < N), k == 0
   Mk down_chain, is_mid, is_end, vxc;   // twisted factorisation: k >= C; chain-layout lanes C-1, 2C-1; chain-layout vx
+  // Split layout of the interior-point stage (kSplit: G = 64 and N + 1 <= 32, so lanes 32..63 are free): lane k
+  // keeps the three states of stage k, lane k + 32 takes its two inputs (entries v, kappa, -).  sU = upper
+  // half, val3 = which of the lane's three entries exist, bU = the B-block numbers (ds, b20) on the upper lanes.
+  static constexpr bool kSplit = (L::group == 64 && L::split == 16);
+  Mk sU, val3[3];
+  R bU[2];
   Mk valid[5];
   Mk live;               // this lane's instance exists
   // ---- where this lane's stage fields live (the unscaled bounds are re-read for the certificate)
@@ -277,6 +283,11 @@ struct Solver {
       is_end = (k == 2 * C - 1);
       I kc = seli(down_chain & (k < 2 * C), k * (-1) + (3 * C - 1), k);
       vxc = live & (kc <= N);
+      if constexpr (kSplit) {
+        sU = (k >= 32);
+        Mk vU = live & sU & (k < N + 32);            // stage k - 32 has inputs
+        val3[0] = selb(sU, vU, vx); val3[1] = selb(sU, vU, vx); val3[2] = vx & !sU;
+      }
     }
     valid[0] = valid[1] = valid[2] = vx;
     valid[3] = valid[4] = vu;
@@ -393,15 +404,20 @@ struct Solver {
   MPMPC_HD void factor(const R h[5], const R& r) {
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) hinv[j] = h[j];
+    factor_core(h, (b[0] * b[0]) * h[4], (b[1] * b[1]) * h[3], r);
+  }
+  // hx = 1/H of the three states; w2b, w5b = b0^2 h_kappa, b1^2 h_v (what the inputs add to A H A' + B H B')
+  MPMPC_HD void factor_core(const R hx[3], const R& w2b, const R& w5b, const R& r) {
+    const R* h = hx;
     R W[6], T[6], Dg[6], To[9];
     {
       R a0h = a[0] * h[0], a2h = a[2] * h[0], a4h = a[4] * h[0], a1h = a[1] * h[1], a3h = a[3] * h[1];
       W[0] = fma_(a[1], a1h, a[0] * a0h);
       W[1] = fma_(a[3], a1h, a[2] * a0h);
-      W[2] = fma_(b[0] * b[0], h[4], fma_(a[3], a3h, a[2] * a2h));
+      W[2] = fma_(a[3], a3h, a[2] * a2h) + w2b;
       W[3] = a[4] * a0h;
       W[4] = a[4] * a2h;
-      W[5] = fma_(b[1] * b[1], h[3], fma_(a[5] * a[5], h[2], a[4] * a4h));
+      W[5] = fma_(a[5] * a[5], h[2], a[4] * a4h) + w5b;
       T[0] = a0h * mI[0]; T[1] = a1h * mI[1];                 // S_{k+1,k} row 0: cols 0,1
       T[2] = a2h * mI[0]; T[3] = a3h * mI[1];                 //           row 1: cols 0,1
       T[4] = a4h * mI[0]; T[5] = (a[5] * h[2]) * mI[2];       //           row 2: cols 0,2
@@ -579,6 +595,72 @@ struct Solver {
     AeqT_mul(nu, s);
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) xt[j] = hinv[j] * (rx[j] - s[j]);
+  }
+
+  // ---- the same operators on the split layout (S = true: 3 entries per lane, see kSplit) or the plain one
+  template <bool S> static constexpr int EN = S ? 3 : 5;
+  MPMPC_HD void to3(const R v[5], R o[3]) const {          // stage vector -> split layout
+    R t3 = L::from_lower(v[3]), t4 = L::from_lower(v[4]);
+    o[0] = sel(sU, t3, v[0]); o[1] = sel(sU, t4, v[1]); o[2] = sel(sU, R(0.0), v[2]);
+  }
+  MPMPC_HD void from3(const R v3[3], R o[5]) const {       // back: the lower lanes get all five entries
+    o[0] = v3[0]; o[1] = v3[1]; o[2] = v3[2];
+    o[3] = L::from_upper(v3[0]); o[4] = L::from_upper(v3[1]);
+  }
+  template <bool S>
+  MPMPC_HD void Aeq_mul_t(const R* v, R r[3]) const {
+    if constexpr (!S) {
+      Aeq_mul(v, r);
+    } else {
+      // upper lanes form B u of their stage and hand it to the lower lane, which adds A x
+      R c1 = L::from_upper(bU[0] * v[1]), c2 = L::from_upper(bU[1] * v[0]);
+      R w[3];
+      w[0] = fma_(a[1], v[1], a[0] * v[0]);
+      w[1] = fma_(a[3], v[1], a[2] * v[0]) + c1;
+      w[2] = fma_(a[5], v[2], a[4] * v[0]) + c2;
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) r[i] = fma_(mI[i], v[i], L::up(w[i]));
+    }
+  }
+  template <bool S>
+  MPMPC_HD void AeqT_mul_t(const R nu[3], R* t) const {
+    if constexpr (!S) {
+      AeqT_mul(nu, t);
+    } else {
+      R nd[3];
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) nd[i] = L::down(nu[i]);
+      R u1 = L::from_lower(nd[1]), u2 = L::from_lower(nd[2]);       // the upper lanes need nu of stage k + 1 too
+      t[0] = fma_(bU[1], u2, fma_(a[4], nd[2], fma_(a[2], nd[1], fma_(a[0], nd[0], mI[0] * nu[0]))));
+      t[1] = fma_(bU[0], u1, fma_(a[3], nd[1], fma_(a[1], nd[0], mI[1] * nu[1])));
+      t[2] = fma_(a[5], nd[2], mI[2] * nu[2]);
+    }
+  }
+  template <bool S>
+  MPMPC_HD void factor_t(const R* h, const R& r) {
+    if constexpr (!S) {
+      factor(h, r);
+    } else {
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) hinv[e] = h[e];
+      R w2b = L::from_upper((bU[0] * bU[0]) * h[1]), w5b = L::from_upper((bU[1] * bU[1]) * h[0]);
+      w2b = sel(sU, R(0.0), w2b); w5b = sel(sU, R(0.0), w5b);
+      factor_core(h, w2b, w5b, r);
+    }
+  }
+  template <bool S>
+  MPMPC_HD void kkt_solve_t(const R* rx, const R req[3], R* xt, R nu[3]) const {
+    constexpr int E = EN<S>;
+    R t[E], bv[3], s[E];
+    MPMPC_UNROLL
+    for (int j = 0; j < E; ++j) t[j] = hinv[j] * rx[j];
+    Aeq_mul_t<S>(t, bv);
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) bv[i] = bv[i] - req[i];
+    s_solve(bv, nu);
+    AeqT_mul_t<S>(nu, s);
+    MPMPC_UNROLL
+    for (int j = 0; j < E; ++j) xt[j] = hinv[j] * (rx[j] - s[j]);
   }
 
   MPMPC_HD void admm_factor(double sigma) {
@@ -839,10 +921,12 @@ struct Solver {
 
   // ======================================================================== certified polish
   // Variable-space view of the box rows: g x in [lb, ub]  <=>  x in [lo, hi].
-  struct Box {
-    R lo[5], hi[5];
-    Mk Lm[5], Um[5], pin[5];
+  template <bool S>
+  struct BoxT {
+    R lo[EN<S>], hi[EN<S>];
+    Mk Lm[EN<S>], Um[EN<S>], pin[EN<S>];
   };
+  using Box = BoxT<false>;
   MPMPC_HD void make_box(Box& bx) const {
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) {
@@ -858,15 +942,21 @@ struct Solver {
 
   // Regularised Mehrotra predictor-corrector, warm started at (xw, nuw, ybw).  Linear systems
   // go through the same block-tridiagonal Schur factorisation as the ADMM step.
-  struct Ipm {
-    R x[5], nu[3], sl[5], su[5], zl[5], zu[5], pi[5];
+  template <bool S>
+  struct IpmT {
+    R x[EN<S>], nu[3], sl[EN<S>], su[EN<S>], zl[EN<S>], zu[EN<S>], pi[EN<S>];
   };
-  MPMPC_HD Mk ipm(const Box& bx, Ipm& s, const SolverParams& st, double tol, const Mk& run) {
+  using Ipm = IpmT<false>;
+  // pp, qq, vm: cost diagonal, cost vector and validity masks of the lane's entries in the layout S
+  template <bool S>
+  MPMPC_HD Mk ipm(const BoxT<S>& bx, IpmT<S>& s, const R* pp, const R* qq, const Mk* vm, const SolverParams& st,
+                  double tol, const Mk& run) {
+    constexpr int E = EN<S>;
     const R reg(st.ipm_reg), ireg(st.inv_ipm_reg), one(1.0), zero(0.0);
     Mk active = run, conv = L::mfalse();
     R cnt(0.0);
     MPMPC_UNROLL
-    for (int j = 0; j < 5; ++j) cnt = cnt + sel(bx.Lm[j], one, zero) + sel(bx.Um[j], one, zero);
+    for (int j = 0; j < E; ++j) cnt = cnt + sel(bx.Lm[j], one, zero) + sel(bx.Um[j], one, zero);
     R nb = max_(L::gsum(cnt), one);
     I stall(0);
     for (int it = 0; it <= st.ipm_max_iter; ++it) {
@@ -875,16 +965,16 @@ struct Solver {
       auto rl_of = [&](int j) { return sel(bx.Lm[j], s.x[j] - bx.lo[j] - s.sl[j], zero); };
       auto ru_of = [&](int j) { return sel(bx.Um[j], bx.hi[j] - s.x[j] - s.su[j], zero); };
       auto rpin_of = [&](int j) { return sel(bx.pin[j], s.x[j] - bx.lo[j], zero); };
-      R At[5], rp[3], rd[5];
-      AeqT_mul(s.nu, At);
-      Aeq_mul(s.x, rp);
+      R At[E], rp[3], rd[E];
+      AeqT_mul_t<S>(s.nu, At);
+      Aeq_mul_t<S>(s.x, rp);
       R res(0.0), msum(0.0);
       MPMPC_UNROLL
       for (int i = 0; i < 3; ++i) { rp[i] = rp[i] - leq[i]; res = max_(res, sel(vx, abs_(rp[i]), zero)); }
       MPMPC_UNROLL
-      for (int j = 0; j < 5; ++j) {
-        rd[j] = fma_(p[j], s.x[j], q[j]) + At[j] - s.zl[j] + s.zu[j] + s.pi[j];
-        res = max_(res, sel(valid[j], max_(max_(abs_(rd[j]), abs_(rpin_of(j))), max_(abs_(rl_of(j)), abs_(ru_of(j)))), zero));
+      for (int j = 0; j < E; ++j) {
+        rd[j] = fma_(pp[j], s.x[j], qq[j]) + At[j] - s.zl[j] + s.zu[j] + s.pi[j];
+        res = max_(res, sel(vm[j], max_(max_(abs_(rd[j]), abs_(rpin_of(j))), max_(abs_(rl_of(j)), abs_(ru_of(j)))), zero));
         msum = msum + sel(bx.Lm[j], s.sl[j] * s.zl[j], zero) + sel(bx.Um[j], s.su[j] * s.zu[j], zero);
       }
       res = L::gmax(res);
@@ -895,42 +985,42 @@ struct Solver {
       if (it == st.ipm_max_iter || !L::wany(active)) break;
       ipm_iters = seli(active, ipm_iters + I(1), ipm_iters);
       // ---- factor.  Every division by a slack below is a product with its reciprocal, taken once.
-      R isl[5], isu[5], h[5];
+      R isl[E], isu[E], h[E];
       MPMPC_UNROLL
-      for (int j = 0; j < 5; ++j) { isl[j] = rcp_(s.sl[j]); isu[j] = rcp_(s.su[j]); }
+      for (int j = 0; j < E; ++j) { isl[j] = rcp_(s.sl[j]); isu[j] = rcp_(s.su[j]); }
       auto H_of = [&](int j) {
-        return p[j] + reg + sel(bx.Lm[j], s.zl[j] * isl[j], zero) + sel(bx.Um[j], s.zu[j] * isu[j], zero) +
+        return pp[j] + reg + sel(bx.Lm[j], s.zl[j] * isl[j], zero) + sel(bx.Um[j], s.zu[j] * isu[j], zero) +
                sel(bx.pin[j], ireg, zero);
       };
       MPMPC_UNROLL
-      for (int j = 0; j < 5; ++j) h[j] = rcp_(H_of(j));
-      factor(h, reg);
+      for (int j = 0; j < E; ++j) h[j] = rcp_(H_of(j));
+      factor_t<S>(h, reg);
       // ---- predictor and corrector share the factorisation
-      R dx[5], dnu[3], dsl[5], dsu[5], dzl[5], dzu[5], dpi[5];
-      R rcl[5], rcu[5];
+      R dx[E], dnu[3], dsl[E], dsu[E], dzl[E], dzu[E], dpi[E];
+      R rcl[E], rcu[E];
       MPMPC_UNROLL
-      for (int j = 0; j < 5; ++j) { rcl[j] = s.sl[j] * s.zl[j]; rcu[j] = s.su[j] * s.zu[j]; }
+      for (int j = 0; j < E; ++j) { rcl[j] = s.sl[j] * s.zl[j]; rcu[j] = s.su[j] * s.zu[j]; }
       R alpha_aff(1.0);
       for (int pass = 0; pass < 2; ++pass) {
-        R rhs[5], nreq[3];
+        R rhs[E], nreq[3];
         MPMPC_UNROLL
-        for (int j = 0; j < 5; ++j)
+        for (int j = 0; j < E; ++j)
           rhs[j] = -rd[j] - sel(bx.Lm[j], fma_(s.zl[j], rl_of(j), rcl[j]) * isl[j], zero) +
                    sel(bx.Um[j], fma_(s.zu[j], ru_of(j), rcu[j]) * isu[j], zero) - sel(bx.pin[j], rpin_of(j) * ireg, zero);
         MPMPC_UNROLL
         for (int i = 0; i < 3; ++i) nreq[i] = -rp[i];
-        kkt_solve(rhs, nreq, dx, dnu);
+        kkt_solve_t<S>(rhs, nreq, dx, dnu);
         if (pass == 1) {   // the corrector direction gets one refinement step where the solve left a visible
                            // residual (ill-conditioned late iterations); the predictor only steers sigma
-          R At2[5], Ad[3], r1[5], r2[3], ddx[5], ddnu[3];
-          AeqT_mul(dnu, At2);
-          Aeq_mul(dx, Ad);
+          R At2[E], Ad[3], r1[E], r2[3], ddx[E], ddnu[3];
+          AeqT_mul_t<S>(dnu, At2);
+          Aeq_mul_t<S>(dx, Ad);
           R big(0.0), ref(0.0);
           MPMPC_UNROLL
-          for (int j = 0; j < 5; ++j) {
+          for (int j = 0; j < E; ++j) {
             r1[j] = rhs[j] - fma_(dx[j], H_of(j), At2[j]);
-            big = max_(big, sel(valid[j], abs_(r1[j]), zero));
-            ref = max_(ref, sel(valid[j], abs_(rhs[j]), zero));
+            big = max_(big, sel(vm[j], abs_(r1[j]), zero));
+            ref = max_(ref, sel(vm[j], abs_(rhs[j]), zero));
           }
           MPMPC_UNROLL
           for (int i = 0; i < 3; ++i) {
@@ -939,9 +1029,9 @@ struct Solver {
             ref = max_(ref, sel(vx, abs_(nreq[i]), zero));
           }
           if (L::wany(active & (L::gmax(big) > R(1e-10) * L::gmax(ref)))) {
-            kkt_solve(r1, r2, ddx, ddnu);
+            kkt_solve_t<S>(r1, r2, ddx, ddnu);
             MPMPC_UNROLL
-            for (int j = 0; j < 5; ++j) dx[j] = dx[j] + ddx[j];
+            for (int j = 0; j < E; ++j) dx[j] = dx[j] + ddx[j];
             MPMPC_UNROLL
             for (int i = 0; i < 3; ++i) dnu[i] = dnu[i] + ddnu[i];
           }
@@ -949,7 +1039,7 @@ struct Solver {
         // largest step that keeps slacks and multipliers positive: 1 / max(-ds/s, -dz/z)
         R blk(0.0);
         MPMPC_UNROLL
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < E; ++j) {
           dsl[j] = sel(bx.Lm[j], dx[j] + rl_of(j), zero);
           dsu[j] = sel(bx.Um[j], -dx[j] + ru_of(j), zero);
           dzl[j] = sel(bx.Lm[j], -fma_(s.zl[j], dsl[j], rcl[j]) * isl[j], zero);
@@ -964,7 +1054,7 @@ struct Solver {
           alpha_aff = min_(one, ratio);
           R ms(0.0);
           MPMPC_UNROLL
-          for (int j = 0; j < 5; ++j)
+          for (int j = 0; j < E; ++j)
             ms = ms + sel(bx.Lm[j], fma_(alpha_aff, dsl[j], s.sl[j]) * fma_(alpha_aff, dzl[j], s.zl[j]), zero) +
                  sel(bx.Um[j], fma_(alpha_aff, dsu[j], s.su[j]) * fma_(alpha_aff, dzu[j], s.zu[j]), zero);
           R mu_aff = L::gsum(ms) / nb;
@@ -972,7 +1062,7 @@ struct Solver {
           sg = sg * sg * sg;
           const R sgmu = sg * mu;
           MPMPC_UNROLL
-          for (int j = 0; j < 5; ++j) {
+          for (int j = 0; j < E; ++j) {
             rcl[j] = fma_(dsl[j], dzl[j], fma_(s.sl[j], s.zl[j], -sgmu));
             rcu[j] = fma_(dsu[j], dzu[j], fma_(s.su[j], s.zu[j], -sgmu));
           }
@@ -980,7 +1070,7 @@ struct Solver {
           R al = min_(one, R(0.995) * ratio);
           stall = seli(active & (al < R(1e-6)), stall + I(1), I(0));
           MPMPC_UNROLL
-          for (int j = 0; j < 5; ++j) {
+          for (int j = 0; j < E; ++j) {
             s.x[j] = sel(active, fma_(al, dx[j], s.x[j]), s.x[j]);
             s.sl[j] = sel(active, fma_(al, dsl[j], s.sl[j]), s.sl[j]);
             s.su[j] = sel(active, fma_(al, dsu[j], s.su[j]), s.su[j]);
@@ -1160,22 +1250,77 @@ struct Solver {
       s.zu[j] = sel(bx.Um[j], max_(yv, theta), zero);
       s.pi[j] = sel(bx.pin[j], yv, zero);
     }
+    // the interior-point stage runs in the split layout where the upper half-wave is free (kSplit)
+    constexpr bool S = kSplit;
+    constexpr int E = EN<S>;
+    BoxT<S> bi;
+    IpmT<S> si;
+    R pp[E], qq[E];
+    Mk vm[E];
+    if constexpr (S) {
+      MPMPC_UNROLL
+      for (int i = 0; i < 2; ++i) bU[i] = sel(sU, L::from_lower(b[i]), zero);
+      to3(bx.lo, bi.lo); to3(bx.hi, bi.hi); to3(p, pp); to3(q, qq);
+      to3(s.x, si.x); to3(s.sl, si.sl); to3(s.su, si.su); to3(s.zl, si.zl); to3(s.zu, si.zu); to3(s.pi, si.pi);
+      R mL[5], mU[5], mP[5], m3[3];
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) { mL[j] = sel(bx.Lm[j], one, zero); mU[j] = sel(bx.Um[j], one, zero); mP[j] = sel(bx.pin[j], one, zero); }
+      to3(mL, m3);
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) bi.Lm[e] = m3[e] > R(0.5);
+      to3(mU, m3);
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) bi.Um[e] = m3[e] > R(0.5);
+      to3(mP, m3);
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) { bi.pin[e] = m3[e] > R(0.5); vm[e] = val3[e]; }
+      // the third entry of the upper lanes does not exist: a unit slack pair keeps its arithmetic finite
+      si.sl[2] = sel(sU, one, si.sl[2]); si.su[2] = sel(sU, one, si.su[2]);
+      pp[2] = sel(sU, one, pp[2]);
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) si.nu[i] = s.nu[i];
+    } else {
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) {
+        bi.lo[j] = bx.lo[j]; bi.hi[j] = bx.hi[j]; bi.Lm[j] = bx.Lm[j]; bi.Um[j] = bx.Um[j]; bi.pin[j] = bx.pin[j];
+        si.x[j] = s.x[j]; si.sl[j] = s.sl[j]; si.su[j] = s.su[j]; si.zl[j] = s.zl[j]; si.zu[j] = s.zu[j]; si.pi[j] = s.pi[j];
+        pp[j] = p[j]; qq[j] = q[j]; vm[j] = valid[j];
+      }
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) si.nu[i] = s.nu[i];
+    }
     double tol = st.ipm_tol;
     Mk todo = run;
     for (int attempt = 0; attempt < 2; ++attempt) {
       stash();
-      Mk conv = ipm(bx, s, st, tol, todo);
+      Mk conv = ipm<S>(bi, si, pp, qq, vm, st, tol, todo);
       Mk aL[5], aU[5];
-      MPMPC_UNROLL
-      for (int j = 0; j < 5; ++j) {
-        aL[j] = bx.Lm[j] & (s.zl[j] > s.sl[j]);
-        aU[j] = bx.Um[j] & (s.zu[j] > s.su[j]) & !aL[j];
-      }
       R xs[5], nus[3], lam[5];
+      if constexpr (S) {
+        R g3[3], g5[5];
+        MPMPC_UNROLL
+        for (int e = 0; e < 3; ++e) g3[e] = sel(bi.Lm[e] & (si.zl[e] > si.sl[e]), one, zero);
+        from3(g3, g5);
+        MPMPC_UNROLL
+        for (int j = 0; j < 5; ++j) aL[j] = bx.Lm[j] & (g5[j] > R(0.5));
+        MPMPC_UNROLL
+        for (int e = 0; e < 3; ++e) g3[e] = sel(bi.Um[e] & (si.zu[e] > si.su[e]), one, zero);
+        from3(g3, g5);
+        MPMPC_UNROLL
+        for (int j = 0; j < 5; ++j) aU[j] = bx.Um[j] & (g5[j] > R(0.5)) & !aL[j];
+        from3(si.x, xs);
+      } else {
+        MPMPC_UNROLL
+        for (int j = 0; j < 5; ++j) {
+          aL[j] = bx.Lm[j] & (si.zl[j] > si.sl[j]);
+          aU[j] = bx.Um[j] & (si.zu[j] > si.su[j]) & !aL[j];
+          xs[j] = si.x[j];
+        }
+      }
       MPMPC_UNROLL
-      for (int j = 0; j < 5; ++j) { xs[j] = s.x[j]; lam[j] = zero; }
+      for (int j = 0; j < 5; ++j) lam[j] = zero;
       MPMPC_UNROLL
-      for (int i = 0; i < 3; ++i) nus[i] = s.nu[i];
+      for (int i = 0; i < 3; ++i) nus[i] = si.nu[i];
       Mk okm = active_set(bx, aL, aU, xs, nus, lam, st, todo & conv);
       unstash();
       R prim, stat;
