@@ -67,8 +67,8 @@ Rooflines for the dominant kernel K2 at this size:
   iterations, residuals) → {d2["roofline"]["achieved"]:.1f} GB/s = **{100*d2["roofline"]["frac"]:.2f} % of 8 TB/s**.  K2 is not an HBM kernel; the
   number is reported because the contract asks for it.
   PMC traffic: FETCH_SIZE {f:,.0f} KB (×2, gfx950 correction) + WRITE_SIZE {w:,.0f} KB = {(2*f+w)*1024/1e6:.1f} MB per launch against
-  10.2 MB algorithmic ({(2*f+w)*1024/10170368:.2f}×).  The excess is one-off register-spill traffic (52 B/lane of scratch: loop-invariant
-  values the compiler parks at kernel start, ≈ 3 KB written per wave) plus the padded stage rows.
+  10.2 MB algorithmic ({(2*f+w)*1024/10170368:.2f}×).  The excess is one-off register-spill traffic (the `<64,16>` kernel has no scratch left; what remains is the
+  padding of the stage rows and of the staged output rows) plus the padded stage rows.
   History: lane-strided 8-byte output stores had cost a 64-byte write each (WRITE_SIZE 23.7 MB) until the rows
   were staged through LDS.
 * FP64 vector (`roofline_fp64`): {d2["roofline_fp64"]["flops_per_solve_mean"]/1e6:.2f} MFLOP useful per solve (instruction census of the emulation,
@@ -77,7 +77,7 @@ Rooflines for the dominant kernel K2 at this size:
 * SQ counters (per wave, mean): {valu/1e3:.0f} k VALU instructions, {salu/1e3:.1f} k SALU, {lds/1e3:.1f} k LDS; SQ_ACTIVE_INST_VALU /
   SQ_INSTS_VALU = {act:.2f} quad-cycles: with one wave per SIMD every vector instruction, FP64 or not, costs
   4 cycles, so kernel time ≈ 4 cycles × dynamic instruction count of the slowest wave (+ {100*wait:.0f} % SQ_WAIT_ANY).
-  One ADMM iteration: 917 VALU + 58 SALU instructions, 1 178 quad-cycles = 2.0 µs (`pmc_admm.sh`); a taken
+  One ADMM iteration: 903 VALU + 68 SALU instructions, 1 187 quad-cycles = 2.0 µs (`pmc_admm.sh`); a taken
   loop-back branch costs about 25 cycles (`micro/exec_half.hip`), which is why the sweeps take four steps per trip.
 
 K1 at this size moves 8.6 MB in {k1/1e3:.1f} µs (launch-latency dominated): {8601600/k1:.0f} GB/s = {100*8601600/k1/8000:.0f} % of peak by rocprofv3
@@ -126,7 +126,8 @@ it reflects the previous PMC collection of the same build (`collect.sh` is run t
 (early polish after 15, coalesced output rows) → 3.42 M (twisted factorisation) → 3.62 M (slack reciprocals)
 → 3.9 M (conditional refinement, LDS-parked deltas, SGPR constants) → 4.2 M (sweeps four steps per loop trip)
 → 4.3 M (warm-start floor from the ADMM residual) → 4.5 M (early attempt on four Ruiz passes) → 4.6–5.0 M (one
-cubic Newton step in rsqrt / rcp, FMA-folded factor step and slack arithmetic; box-to-box spread ±4 %).
+cubic Newton step in rsqrt / rcp, FMA-folded factor step and slack arithmetic; box-to-box spread ±4 %)
+→ 4.9–5.2 M (interior-point stage in the split layout).
 '''
 open(os.path.join(HERE, "README.md"), "w").write(txt)
 print("profiles/README.md written")
