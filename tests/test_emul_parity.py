@@ -63,7 +63,10 @@ def test_admm_stock_matches_oracle(G, emu, track):
         assert abs(sol.resid[i, 0] - r.pri_res) < 1e-9 and abs(sol.resid[i, 1] - r.dua_res) < 1e-9
 
 
-@pytest.mark.parametrize("cfgid,B,N,G", [(2, 12, 30, 64), (4, 16, 30, 32), (3, 4, 50, 64), (2, 8, 10, 16), (4, 8, 3, 16)])
+# (G = 64 with N + 1 <= 32 runs the interior-point stage in the split layout: N = 31 fills both half-waves,
+#  N = 32 is the first horizon that cannot split)
+@pytest.mark.parametrize("cfgid,B,N,G", [(2, 12, 30, 64), (4, 16, 30, 32), (3, 4, 50, 64), (2, 8, 10, 16), (4, 8, 3, 16),
+                                         (4, 6, 31, 64), (2, 4, 32, 64), (4, 6, 10, 64), (2, 4, 3, 64)])
 def test_certified_matches_oracle(cfgid, B, N, G, emu, track):
     """max |u - u_ref| <= 1e-6 (north-star tolerance); measured ~1e-15."""
     sc = scenarios.make(cfgid, track, B=B, N=N)

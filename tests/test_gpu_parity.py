@@ -74,7 +74,7 @@ def test_admm_stock_matches_oracle(track):
     h.close()
 
 
-@pytest.mark.parametrize("cfgid,B,N", [(2, 48, 30), (4, 48, 30), (3, 12, 50), (2, 16, 10), (4, 16, 3)])
+@pytest.mark.parametrize("cfgid,B,N", [(2, 48, 30), (4, 48, 30), (3, 12, 50), (2, 16, 10), (4, 16, 3), (4, 12, 31), (2, 8, 32)])
 def test_certified_matches_oracle(cfgid, B, N, track):
     """max |u - u_ref| <= 1e-6 with u_ref the oracle's KKT-certified optimum"""
     sc = scenarios.make(cfgid, track, B=B, N=N)
