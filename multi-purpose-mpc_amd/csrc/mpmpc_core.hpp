@@ -1089,14 +1089,18 @@ struct Solver {
         R At[5], Ax[3], rhs[5], r2[3], r3[5], dx[5], dnu[3];
         AeqT_mul(nn, At);
         Aeq_mul(xn, Ax);
+        R rs(0.0);                       // KKT residual of the unregularised system at (xn, nn, ln)
         MPMPC_UNROLL
         for (int j = 0; j < 5; ++j) {
           R r1 = -q[j] - p[j] * xn[j] - At[j] - ln[j];
           r3[j] = sel(act[j], bound[j] - xn[j], zero);
           rhs[j] = fma_(r3[j], idelta, r1);
+          rs = max_(rs, sel(valid[j], max_(abs_(r1), abs_(r3[j])), zero));
         }
         MPMPC_UNROLL
-        for (int i = 0; i < 3; ++i) r2[i] = leq[i] - Ax[i];
+        for (int i = 0; i < 3; ++i) { r2[i] = leq[i] - Ax[i]; rs = max_(rs, sel(vx, abs_(r2[i]), zero)); }
+        // the point already satisfies the system to rounding level (1e-15) for every instance in the wave: no further solve
+        if (rf >= 1 && !L::wany(todo & (L::gmax(rs) > R(1e-15)))) break;
         kkt_solve(rhs, r2, dx, dnu);
         R big(0.0);
         MPMPC_UNROLL
