@@ -58,7 +58,7 @@ micro-benchmark) are the helpers used while tuning.
 | K1 `mpmpc_assemble_kernel` average launch | {d2["roofline_assembly"]["avg_ms"]*1e3:.1f} µs (events, includes event overhead) / {k1/1e3:.1f} µs (rocprofv3) | same |
 | CPU baseline: C port of the reference-equivalent path, {d2["cpu_baseline"]["cores"]} threads (the container's CPU quota) | {d2["cpu_baseline"]["value"]/1e3:.1f} k solves/s | `cpu_baseline`, `cpu_scaling.txt` |
 | same step from host buffers (`mpmpc_solve`, PCIe-inclusive) | {d2["host_buffers"]["value"]/1e6:.2f} M solves/s | `host_buffers` |
-| ADMM iterations; interior-point iterations mean / max (histogram) | 15 (early polish); {d2["iters"]["ipm_mean"]:.1f} / {d2["iters"]["ipm_max"]} ({", ".join("%s: %d" % kv for kv in sorted(hist.items(), key=lambda kv: int(kv[0])))}) | `iters` |
+| ADMM iterations; interior-point iterations mean / max (histogram) | {d2["iters"]["admm_max"]} (early polish); {d2["iters"]["ipm_mean"]:.1f} / {d2["iters"]["ipm_max"]} ({", ".join("%s: %d" % kv for kv in sorted(hist.items(), key=lambda kv: int(kv[0])))}) | `iters` |
 | the device at OSQP's defaults (ε = 1e-3, no polish) vs the optimum | up to {st["max_abs_u_minus_uref"]:.2f} rad in δ₀ after {st["admm_iters_mean"]:.0f} ADMM iterations (mean) | `stock_osqp_settings` |
 
 Rooflines for the dominant kernel K2 at this size:
@@ -88,10 +88,10 @@ the 6.3 TB/s achievable); PMC traffic there is {(2*fab+wab)*1024/1e6:.0f} MB.
 
 ## Single instance (the drop-in case)
 
-`latency_b1.py`: one `mpmpc_solve` call with B = 1 from host buffers takes 0.20 ms end to end (K1 7 µs, K2 148 µs by
+`latency_b1.py`: one `mpmpc_solve` call with B = 1 from host buffers takes 0.17 ms end to end (K1 7 µs, K2 114 µs by
 events; the rest is the PCIe copies through pinned staging and the launch path; 0.27 ms before the staging) — the reference spends ≈ 24 ms per control step in
 Python + OSQP (SURVEY §8a).  `latency_get_control.py`: the whole `MPC.get_control()` + `drive()` step of the
-host class takes 4.6 ms with the corridor computed on the host like the reference and 0.57 ms with
+host class takes 4.7 ms with the corridor computed on the host like the reference and 0.52 ms with
 `corridor="device"` (K0 table on the GPU, rebuilt when the map changes).
 
 ## Other configurations (single runs, `--steps 5`)
@@ -127,7 +127,8 @@ it reflects the previous PMC collection of the same build (`collect.sh` is run t
 → 3.9 M (conditional refinement, LDS-parked deltas, SGPR constants) → 4.2 M (sweeps four steps per loop trip)
 → 4.3 M (warm-start floor from the ADMM residual) → 4.5 M (early attempt on four Ruiz passes) → 4.6–5.0 M (one
 cubic Newton step in rsqrt / rcp, FMA-folded factor step and slack arithmetic; box-to-box spread ±4 %)
-→ 4.9–5.2 M (interior-point stage in the split layout).
+→ 4.9–5.2 M (interior-point stage in the split layout) → 5.2 M (no iterative refinement of the directions,
+residual-based exit of the active-set refinement) → 5.8 M (early attempt after one ADMM iteration).
 '''
 open(os.path.join(HERE, "README.md"), "w").write(txt)
 print("profiles/README.md written")

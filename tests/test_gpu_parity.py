@@ -92,7 +92,7 @@ def test_certified_matches_oracle(cfgid, B, N, track):
         assert sol.status[i] == r.status
         # same ADMM iteration count, unless exactly one side certified at the early-polish attempt
         # (the dense numpy interior point is less robust than the kernel's / the C port's)
-        assert sol.iters[i, 0] == r.iters or 15 in (sol.iters[i, 0], r.iters)
+        assert sol.iters[i, 0] == r.iters or 1 in (sol.iters[i, 0], r.iters)
         if r.status == O.SOLVED:
             n_cert += 1
             uref = np.array([r.x[3 * (N + 1)], np.arctan(r.x[3 * (N + 1) + 1] * L)])
