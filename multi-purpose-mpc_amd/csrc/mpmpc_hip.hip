@@ -271,7 +271,7 @@ void mpmpc_default_settings(mpmpc_settings* s) {
   s->polish = 2; s->ipm_max_iter = 30; s->ipm_tol = 1e-9; s->ipm_reg = 1e-8;
   s->as_delta = 1e-9; s->as_refine = 5; s->as_rounds = 4; s->cert_tol = 1e-8;
   s->early_polish = 1;
-  s->early_scaling = 4;
+  s->early_scaling = 2;
 }
 
 int32_t mpmpc_stage_ld(int32_t N) { return host_stage_ld(N); }

@@ -82,7 +82,7 @@ class Settings:
     as_rounds: int = 4
     cert_tol: float = 1e-8
     early_polish: int = 1       # polish=2 only: try the polish after this many ADMM iterations (0 = off)
-    early_scaling: int = 4      # Ruiz passes before that attempt; the rest precede the full ADMM run
+    early_scaling: int = 2      # Ruiz passes before that attempt; the rest precede the full ADMM run
 
 
 @dataclasses.dataclass

@@ -128,7 +128,7 @@ it reflects the previous PMC collection of the same build (`collect.sh` is run t
 → 4.3 M (warm-start floor from the ADMM residual) → 4.5 M (early attempt on four Ruiz passes) → 4.6–5.0 M (one
 cubic Newton step in rsqrt / rcp, FMA-folded factor step and slack arithmetic; box-to-box spread ±4 %)
 → 4.9–5.2 M (interior-point stage in the split layout) → 5.2 M (no iterative refinement of the directions,
-residual-based exit of the active-set refinement) → 5.8 M (early attempt after one ADMM iteration).
+residual-based exit of the active-set refinement) → 5.8 M (early attempt after one ADMM iteration) → 6.0 M (on two Ruiz passes).
 '''
 open(os.path.join(HERE, "README.md"), "w").write(txt)
 print("profiles/README.md written")
