@@ -135,21 +135,28 @@ struct LaneGpu {
     return __hiloint2double((int)hi[0], (int)lo[0]);
   }
 
-  static __device__ __forceinline__ double gmax(double a) {
-#pragma unroll
-    for (int off = 1; off < G; off <<= 1) { double t = __shfl_xor(a, off, 64); a = __builtin_fmax(a, t); }
+  // Instance-wide all-reduce without LDS: a butterfly whose partner permutations are DPP modifiers inside a
+  // row (quad_perm xor 1 / xor 2, row_half_mirror, row_mirror: after the first two steps the quads - then the
+  // half rows - are uniform, so any lane of the other half is as good as the xor partner and the sums come out
+  // bit-identical to the xor butterfly) and the gfx950 row / half-wave swaps above it.  With __shfl_xor every
+  // step was a ds_bpermute round trip, ~100 cycles of exposed latency at one wave per SIMD.
+  template <class F>
+  static __device__ __forceinline__ double bfly(double a, F f) {
+    a = f(a, dpp_shift<0xB1>(a));                       // quad_perm [1,0,3,2]
+    a = f(a, dpp_shift<0x4E>(a));                       // quad_perm [2,3,0,1]
+    a = f(a, dpp_shift<DPP_ROW_HALF_MIRROR>(a));
+    a = f(a, dpp_shift<DPP_ROW_MIRROR>(a));
+    if constexpr (G >= 32) {                            // rows 0|1 and 2|3
+      auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(a), false, false);
+      auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(a), false, false);
+      a = f(__hiloint2double((int)hi[0], (int)lo[0]), __hiloint2double((int)hi[1], (int)lo[1]));
+    }
+    if constexpr (G == 64) a = f(from_lower(a), from_upper(a));
     return a;
   }
-  static __device__ __forceinline__ double gmin(double a) {
-#pragma unroll
-    for (int off = 1; off < G; off <<= 1) { double t = __shfl_xor(a, off, 64); a = __builtin_fmin(a, t); }
-    return a;
-  }
-  static __device__ __forceinline__ double gsum(double a) {
-#pragma unroll
-    for (int off = 1; off < G; off <<= 1) { double t = __shfl_xor(a, off, 64); a = a + t; }
-    return a;
-  }
+  static __device__ __forceinline__ double gmax(double a) { return bfly(a, [](double x, double y) { return __builtin_fmax(x, y); }); }
+  static __device__ __forceinline__ double gmin(double a) { return bfly(a, [](double x, double y) { return __builtin_fmin(x, y); }); }
+  static __device__ __forceinline__ double gsum(double a) { return bfly(a, [](double x, double y) { return x + y; }); }
   static __device__ __forceinline__ bool gany(bool m) {
     unsigned long long b = __ballot(m);
     if (G == 64) return b != 0ull;
