@@ -77,7 +77,7 @@ Rooflines for the dominant kernel K2 at this size:
 * SQ counters (per wave, mean): {valu/1e3:.0f} k VALU instructions, {salu/1e3:.1f} k SALU, {lds/1e3:.1f} k LDS; SQ_ACTIVE_INST_VALU /
   SQ_INSTS_VALU = {act:.2f} quad-cycles: with one wave per SIMD every vector instruction, FP64 or not, costs
   4 cycles, so kernel time ≈ 4 cycles × dynamic instruction count of the slowest wave (+ {100*wait:.0f} % SQ_WAIT_ANY).
-  One ADMM iteration: 903 VALU + 68 SALU instructions, 1 187 quad-cycles = 2.0 µs (`pmc_admm.sh`); a taken
+  One ADMM iteration: 901 VALU + 60 SALU instructions, 1 165 quad-cycles = 1.9 µs (`pmc_admm.sh`); a taken
   loop-back branch costs about 25 cycles (`micro/exec_half.hip`), which is why the sweeps take four steps per trip.
 
 K1 at this size moves 8.6 MB in {k1/1e3:.1f} µs (launch-latency dominated): {8601600/k1:.0f} GB/s = {100*8601600/k1/8000:.0f} % of peak by rocprofv3
@@ -88,7 +88,7 @@ the 6.3 TB/s achievable); PMC traffic there is {(2*fab+wab)*1024/1e6:.0f} MB.
 
 ## Single instance (the drop-in case)
 
-`latency_b1.py`: one `mpmpc_solve` call with B = 1 from host buffers takes 0.17 ms end to end (K1 7 µs, K2 114 µs by
+`latency_b1.py`: one `mpmpc_solve` call with B = 1 from host buffers takes 0.17 ms end to end (K1 7 µs, K2 104 µs by
 events; the rest is the PCIe copies through pinned staging and the launch path; 0.27 ms before the staging) — the reference spends ≈ 24 ms per control step in
 Python + OSQP (SURVEY §8a).  `latency_get_control.py`: the whole `MPC.get_control()` + `drive()` step of the
 host class takes 4.7 ms with the corridor computed on the host like the reference and 0.52 ms with
@@ -128,7 +128,7 @@ it reflects the previous PMC collection of the same build (`collect.sh` is run t
 → 4.3 M (warm-start floor from the ADMM residual) → 4.5 M (early attempt on four Ruiz passes) → 4.6–5.0 M (one
 cubic Newton step in rsqrt / rcp, FMA-folded factor step and slack arithmetic; box-to-box spread ±4 %)
 → 4.9–5.2 M (interior-point stage in the split layout) → 5.2 M (no iterative refinement of the directions,
-residual-based exit of the active-set refinement) → 5.8 M (early attempt after one ADMM iteration) → 6.0 M (on two Ruiz passes).
+residual-based exit of the active-set refinement) → 5.8 M (early attempt after one ADMM iteration) → 6.0 M (on two Ruiz passes) → 6.4–6.8 M (reductions through DPP / permlane swaps instead of ds_bpermute).
 '''
 open(os.path.join(HERE, "README.md"), "w").write(txt)
 print("profiles/README.md written")
