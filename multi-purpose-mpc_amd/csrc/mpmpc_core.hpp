@@ -212,6 +212,7 @@ struct Solver {
   //  infeasibility tests read them)
   // ---- results
   I status, iters, ipm_iters, polished;
+  I act_bits;            // active set of the certified point: bit j lower, bit 5 + j upper, bit 30 = valid (warm start)
   R pri_res, dua_res;
 
   // ======================================================================== helpers
@@ -1203,6 +1204,49 @@ struct Solver {
     c = L::cold_get(36);
   }
 
+  MPMPC_HD static I pack_active(const Mk aL[5], const Mk aU[5]) {
+    I v(1 << 30);
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) v = v + seli(aL[j], I(1 << j), I(0)) + seli(aU[j], I(32 << j), I(0));
+    return v;
+  }
+  // Warm start (closed loop): `guess` is the active set of the previous step's certified plan, already shifted to
+  // this step's stages.  One or two active-set rounds from it usually reproduce the optimum; whatever they
+  // cannot certify goes through the normal path.  Runs on the scaled problem, before any ADMM.
+  MPMPC_HD void warm_polish(const SolverParams& st, const I& guess, const Mk& run) {
+    Box bx;
+    make_box(bx);
+    Mk aL[5], aU[5];
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      aL[j] = bx.Lm[j] & bit_(guess, j);
+      aU[j] = bx.Um[j] & bit_(guess, 5 + j) & !aL[j];
+    }
+    const R zero(0.0);
+    R xs[5], nus[3], lam[5];
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) xs[j] = lam[j] = zero;
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) nus[i] = zero;
+    // two rounds at most: a guess that needs more is not worth more than the normal path (the slowest car of
+    // the batch decides the step)
+    SolverParams sw = st;
+    sw.as_rounds = st.as_rounds < 2 ? st.as_rounds : 2;
+    Mk okm = active_set(bx, aL, aU, xs, nus, lam, sw, run);
+    R prim, stat;
+    Mk cert = certificate(xs, nus, lam, st.cert_tol, prim, stat);
+    Mk good = run & okm & cert;
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) { x[j] = sel(good, xs[j], x[j]); yb[j] = sel(good, lam[j] / g[j], yb[j]); }
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) yeq[i] = sel(good, nus[i], yeq[i]);
+    pri_res = sel(good, prim, pri_res);
+    dua_res = sel(good, stat, dua_res);
+    status = seli(good, I(MPMPC_SOLVED), status);
+    polished = seli(good, I(1), polished);
+    act_bits = seli(good, pack_active(aL, aU), act_bits);
+  }
+
   // `early`: also polish instances whose ADMM was stopped before it terminated (status UNSOLVED);
   // those keep UNSOLVED when the polish cannot certify them, so the caller can resume ADMM.
   MPMPC_HD void polish(const SolverParams& st, bool early) {
@@ -1314,6 +1358,7 @@ struct Solver {
       dua_res = sel(good, stat, dua_res);
       status = seli(good, I(MPMPC_SOLVED), status);
       polished = seli(good, I(1), polished);
+      act_bits = seli(good, pack_active(aL, aU), act_bits);
       todo = todo & conv & !good;       // a diverged interior-point run is not retried
       if (!L::wany(todo)) break;
       tol *= 1e-4;      // a wrong active-set guess means the centring was too loose: tighten it a lot
@@ -1328,7 +1373,8 @@ struct Solver {
   // ======================================================================== output
   // z in the reference's ordering, u0 = (v_0, delta_0), multipliers in the reference's row order
   MPMPC_HD void store(const I& inst, const I& k, double wheelbase, double* z, double* u0, int* st_out,
-                      int* it_out, double* resid, double* y) const {
+                      int* it_out, double* resid, double* y, int* act = nullptr, int ld = 0) const {
+    if (act) L::storei(act, inst * ld + k, vx, act_bits);
     const int n = 5 * N + 3, m = 8 * N + 6;
     R cinv = R(1.0) / c;
     // whole rows are staged per wave and written as consecutive doubles (lane backends: rows())
@@ -1363,8 +1409,11 @@ struct Solver {
 
   // mode 0: early attempt + full run; 1: early attempt only (uncertified instances stay UNSOLVED);
   // 2: full run only (the second launch of a packed batch, see mpmpc_solve_kernel)
+  // guess: shifted active set of the previous closed-loop step (bit 30 set where there is one), or 0
+  // (WARM is a template flag so that the batch kernels do not carry the warm-start code at all)
+  template <bool WARM = false>
   MPMPC_HD void run(const double* qp, int B, int ld, const I& inst, const I& k, int N_, const SolverParams& st,
-                    int mode = 0) {
+                    int mode = 0, const I& guess = I(0)) {
     load(qp, B, ld, inst, k, N_);
     // The polish does not need a converged ADMM point, only a reasonable one: with early_polish > 0
     // it is first tried after that many iterations, on a problem that has seen early_scaling of the
@@ -1375,10 +1424,24 @@ struct Solver {
     int limit = early ? st.early_polish : st.max_iter;
     int passes = early && st.early_scaling > 0 && st.early_scaling < st.scaling ? st.early_scaling : st.scaling;
     Mk which = live;
+    act_bits = I(0);
+    Mk warm = L::mfalse();
+    if constexpr (WARM) warm = L::gany(live & bit_(guess, 30));
     _Pragma("nounroll")
     for (int pass = 0; pass < 2; ++pass) {
       scale(passes, which);
       passes = st.scaling - passes;
+      if (WARM && pass == 0 && mode != 2 && st.polish && L::wany(warm)) {
+        status = I(MPMPC_UNSOLVED); iters = I(0); ipm_iters = I(0); polished = I(0);
+        pri_res = R(0.0); dua_res = R(0.0);
+        MPMPC_UNROLL
+        for (int j = 0; j < 5; ++j) { x[j] = R(0.0); yb[j] = R(0.0); }
+        MPMPC_UNROLL
+        for (int i = 0; i < 3; ++i) yeq[i] = R(0.0);
+        warm_polish(st, guess, warm);
+        which = live & (status == MPMPC_UNSOLVED);
+        if (!L::wany(which)) break;
+      }
       admm(st, which, limit);
       if (st.polish) polish(st, early);
       which = live & (status == MPMPC_UNSOLVED);

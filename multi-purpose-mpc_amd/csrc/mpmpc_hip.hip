@@ -65,12 +65,13 @@ __global__ __launch_bounds__(K1_THREADS) void mpmpc_assemble_kernel(
 // A packed launch (2 or 4 instances per wave) uses modes 1 + 2: the few instances that need hundreds or
 // thousands of ADMM iterations then run one per wave, on the faster G = 64 code, instead of holding a
 // packed wave (and its finished partner lanes) for the whole tail.
-template <int G, int C>
+template <int G, int C, bool WARM>
 __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, SolverParams st, int B, int ld,
                                                          const double* __restrict__ qp, double* __restrict__ z,
                                                          double* __restrict__ u0, int* __restrict__ status,
                                                          int* __restrict__ iters, double* __restrict__ resid,
-                                                         double* __restrict__ y, int mode, int* __restrict__ tail) {
+                                                         double* __restrict__ y, int mode, int* __restrict__ tail,
+                                                         int* __restrict__ act, const int* __restrict__ shift) {
   using L = LaneGpu<G, C>;
   int inst = blockIdx.x * L::per_wave + L::slot();
   if (mode == 2) {
@@ -78,9 +79,15 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
     inst = tail[1 + blockIdx.x];
   }
   const int k = L::stage();
+  // closed loop: the active set the previous step certified for this car, moved on by the waypoints it advanced
+  int guess = 0;
+  if (WARM && act && shift && inst < B && k <= cfg.N) {
+    int kk = k + shift[inst];
+    guess = act[inst * ld + (kk > cfg.N ? cfg.N : kk)];
+  }
   Solver<L> s;
-  s.run(qp, B, ld, inst, k, cfg.N, st, mode);
-  s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y);
+  s.template run<WARM>(qp, B, ld, inst, k, cfg.N, st, mode, guess);
+  s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y, WARM ? act : nullptr, ld);
   if (mode == 1 && k == 0 && inst < B && s.status == MPMPC_UNSOLVED) tail[1 + atomicAdd(tail, 1)] = inst;
 }
 
@@ -151,11 +158,17 @@ __global__ __launch_bounds__(256) void mpmpc_localise_kernel(int B, int n_wp, co
                                                              const double* __restrict__ gx, const double* __restrict__ gy,
                                                              const double* __restrict__ gpsi, const double* __restrict__ s,
                                                              const double* __restrict__ pose, int* __restrict__ alive,
-                                                             int* __restrict__ wp_id, double* __restrict__ x0) {
+                                                             int* __restrict__ wp_id, double* __restrict__ x0,
+                                                             int* __restrict__ shift) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= B || alive[i] != 1) return;
   const int wp = ro_current_waypoint(cum, n_wp, s[i]);
   if (wp < 0) { alive[i] = 0; return; }              // lap finished
+  if (shift) {                                        // waypoints advanced since the last step (warm start)
+    int d = wp - wp_id[i];
+    if (d < 0) d += n_wp;
+    shift[i] = d;
+  }
   wp_id[i] = wp;
   ro_t2s(pose[3 * i], pose[3 * i + 1], pose[3 * i + 2], gx[wp], gy[wp], gpsi[wp], x0 + 3 * i);
 }
@@ -207,6 +220,8 @@ struct mpmpc_handle_s {
   // closed-loop rollout state
   double *ro_cum = nullptr, *ro_s = nullptr, *ro_pose = nullptr, *ro_u = nullptr;
   int *ro_counter = nullptr, *ro_alive = nullptr;
+  int *ro_act = nullptr, *ro_shift = nullptr;      // warm start: certified active sets [B x ld], waypoints advanced [B]
+  int ro_warm = 1;
   double ro_Ts = 0;
   int ro_B = 0;
   // per-batch inputs
@@ -243,7 +258,7 @@ static int check_settings(const mpmpc_settings* s) {
 }
 
 static int launch_assemble(mpmpc_handle h, int B);
-static int launch_solve(mpmpc_handle h, int B);
+static int launch_solve(mpmpc_handle h, int B, bool closed_loop = false);
 
 extern "C" {
 
@@ -282,7 +297,7 @@ int mpmpc_destroy(mpmpc_handle h) {
   void* ptrs[] = {h->kappa, h->v_ref, h->ds_next, h->ub_tab, h->lb_tab, h->wp_id, h->x0,  h->cc,   h->lb,  h->ub,
                   h->qp,    h->z,     h->u0,      h->resid,  h->y,      h->status, h->iters, h->map, h->gx,  h->gy,
                   h->gpsi,  h->bub,   h->blb,     h->segs,   h->nseg,   h->bad,    h->ro_cum, h->ro_s, h->ro_pose,
-                  h->ro_u,  h->ro_counter, h->ro_alive, h->tail};
+                  h->ro_u,  h->ro_counter, h->ro_alive, h->tail, h->ro_act, h->ro_shift};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->stage_in) (void)hipHostFree(h->stage_in);
@@ -488,6 +503,8 @@ int mpmpc_rollout_init(mpmpc_handle h, int32_t B, double Ts, const double* cum_l
     HIP_TRY(hipMalloc((void**)&h->ro_u, sizeof(double) * 2 * mb));
     HIP_TRY(hipMalloc((void**)&h->ro_counter, sizeof(int) * mb));
     HIP_TRY(hipMalloc((void**)&h->ro_alive, sizeof(int) * mb));
+    HIP_TRY(hipMalloc((void**)&h->ro_act, sizeof(int) * mb * h->ld));
+    HIP_TRY(hipMalloc((void**)&h->ro_shift, sizeof(int) * mb));
   }
   if (int rc = upload_table(h, &h->ro_cum, cum_lengths, h->n_wp)) return rc;
   const int N = h->cfg.N;
@@ -496,6 +513,8 @@ int mpmpc_rollout_init(mpmpc_handle h, int32_t B, double Ts, const double* cum_l
   if (cc0) HIP_TRY(hipMemcpyAsync(h->cc, cc0, sizeof(double) * 2 * N * B, hipMemcpyHostToDevice, h->stream));
   else HIP_TRY(hipMemsetAsync(h->cc, 0, sizeof(double) * 2 * N * B, h->stream));
   HIP_TRY(hipMemsetAsync(h->ro_counter, 0, sizeof(int) * B, h->stream));
+  HIP_TRY(hipMemsetAsync(h->ro_act, 0, sizeof(int) * (size_t)B * h->ld, h->stream));     // no guess yet
+  HIP_TRY(hipMemsetAsync(h->ro_shift, 0, sizeof(int) * B, h->stream));
   HIP_TRY(hipMemsetAsync(h->ro_u, 0, sizeof(double) * 2 * B, h->stream));
   HIP_TRY(hipMemsetAsync(h->wp_id, 0, sizeof(int) * B, h->stream));
   HIP_TRY(hipMemsetAsync(h->x0, 0, sizeof(double) * 3 * B, h->stream));
@@ -519,14 +538,20 @@ int mpmpc_rollout_step(mpmpc_handle h, int32_t B, int32_t n_steps) {
   const int blocks = (B + 255) / 256;
   for (int t = 0; t < n_steps; ++t) {
     hipLaunchKernelGGL(mpmpc_localise_kernel, dim3(blocks), dim3(256), 0, h->stream, B, h->n_wp, h->ro_cum, h->gx, h->gy,
-                       h->gpsi, h->ro_s, h->ro_pose, h->ro_alive, h->wp_id, h->x0);
+                       h->gpsi, h->ro_s, h->ro_pose, h->ro_alive, h->wp_id, h->x0, h->ro_shift);
     if (int rc = launch_assemble(h, B)) return rc;
-    if (int rc = launch_solve(h, B)) return rc;
+    if (int rc = launch_solve(h, B, true)) return rc;
     hipLaunchKernelGGL(mpmpc_advance_kernel, dim3(blocks), dim3(256), 0, h->stream, B, h->cfg.N, h->cfg.wheelbase, h->ro_Ts,
                        h->kappa, h->wp_id, h->x0, h->status, h->z, h->cc, h->ro_counter, h->ro_alive, h->ro_pose, h->ro_s,
                        h->ro_u);
   }
   HIP_TRY(hipGetLastError());
+  return MPMPC_OK;
+}
+
+int mpmpc_rollout_warm_start(mpmpc_handle h, int32_t enable) {
+  if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  h->ro_warm = enable ? 1 : 0;
   return MPMPC_OK;
 }
 
@@ -596,8 +621,10 @@ static int launch_assemble(mpmpc_handle h, int B) {
   return MPMPC_OK;
 }
 
-static int launch_solve(mpmpc_handle h, int B) {
+static int launch_solve(mpmpc_handle h, int B, bool closed_loop) {
   const int N = h->cfg.N;
+  int* warm_act = closed_loop && h->ro_warm ? h->ro_act : nullptr;
+  const int* warm_shift = closed_loop && h->ro_warm ? h->ro_shift : nullptr;
   // lanes per instance: one instance per wave while there are no more instances than SIMDs (1024);
   // beyond that the smallest power of two holding N+1 stages, so that a wave carries 2 or 4 instances
   // (measured at N = 30: B = 2048 takes 0.28 ms with 32 lanes per instance, 0.47 ms with 64)
@@ -613,9 +640,14 @@ static int launch_solve(mpmpc_handle h, int B) {
   const SolverParams prm = make_params(h->st);
   const bool early = prm.polish && prm.early_polish > 0 && prm.early_polish < prm.max_iter;
   const int first_mode = (G < 64 && early) ? 1 : 0;      // packed launches hand their tail to a second one
-#define LAUNCH(GG, CC, MODE, BLOCKS)                                                                             \
-  hipLaunchKernelGGL((mpmpc_solve_kernel<GG, CC>), dim3(BLOCKS), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, \
-                     h->qp, h->z, h->u0, h->status, h->iters, h->resid, h->y, MODE, h->tail)
+#define LAUNCH_W(GG, CC, WW, MODE, BLOCKS)                                                                            \
+  hipLaunchKernelGGL((mpmpc_solve_kernel<GG, CC, WW>), dim3(BLOCKS), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, \
+                     h->qp, h->z, h->u0, h->status, h->iters, h->resid, h->y, MODE, h->tail, warm_act, warm_shift)
+#define LAUNCH(GG, CC, MODE, BLOCKS)                                \
+  do {                                                              \
+    if (warm_act) LAUNCH_W(GG, CC, true, MODE, BLOCKS);             \
+    else LAUNCH_W(GG, CC, false, MODE, BLOCKS);                     \
+  } while (0)
   if (first_mode == 1) HIP_TRY(hipMemsetAsync(h->tail, 0, sizeof(int), h->stream));
   const int C = lane_split(G, N);        // where the two elimination chains of the factorisation meet
   if (G == 64 && C == 16) LAUNCH(64, 16, first_mode, blocks);
@@ -627,6 +659,7 @@ static int launch_solve(mpmpc_handle h, int B) {
     if (lane_split(64, N) == 16) LAUNCH(64, 16, 2, B);
     else LAUNCH(64, 32, 2, B);
   }
+#undef LAUNCH_W
 #undef LAUNCH
   HIP_TRY(hipGetLastError());
   return MPMPC_OK;

@@ -117,6 +117,7 @@ def load_library(path: str | None = None):
     lib.mpmpc_build_corridor.argtypes = [h, C.c_int32, C.c_double, C.c_double, _dp, _dp, _ip]
     lib.mpmpc_rollout_init.argtypes = [h, C.c_int32, C.c_double, _dp, _dp, _dp, _dp]
     lib.mpmpc_rollout_step.argtypes = [h, C.c_int32, C.c_int32]
+    lib.mpmpc_rollout_warm_start.argtypes = [h, C.c_int32]
     lib.mpmpc_rollout_state.argtypes = [h, C.c_int32, _dp, _dp, _dp, _ip, _dp, _dp, _ip, _ip, _ip]
     lib.mpmpc_assemble.argtypes = [h, C.c_int32, _ip, _dp, _dp, _dp, _dp, _dp]
     lib.mpmpc_stage_ld.argtypes = [C.c_int32]
@@ -136,7 +137,7 @@ def load_library(path: str | None = None):
 EXPORTS = ["mpmpc_version", "mpmpc_last_error", "mpmpc_device_count", "mpmpc_default_settings",
            "mpmpc_create", "mpmpc_destroy", "mpmpc_set_settings", "mpmpc_set_path", "mpmpc_set_corridor",
            "mpmpc_set_map", "mpmpc_set_path_geometry", "mpmpc_build_corridor", "mpmpc_rollout_init",
-           "mpmpc_rollout_step", "mpmpc_rollout_state", "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident",
+           "mpmpc_rollout_step", "mpmpc_rollout_warm_start", "mpmpc_rollout_state", "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident",
            "mpmpc_sync", "mpmpc_download", "mpmpc_solve_resident_timed", "mpmpc_speed_profile"]
 
 
@@ -238,6 +239,10 @@ class Handle:
         self._check(self.lib.mpmpc_rollout_init(self._h, B, float(Ts), _d(cum), _d(s), _d(poses), _d(cc0)))
         self._ro_B = B
         return B
+
+    def rollout_warm_start(self, enable=True):
+        """closed loop: try the previous step's shifted active set first (default on)"""
+        self._check(self.lib.mpmpc_rollout_warm_start(self._h, int(bool(enable))))
 
     def rollout_step(self, n_steps=1):
         self._check(self.lib.mpmpc_rollout_step(self._h, self._ro_B, int(n_steps)))

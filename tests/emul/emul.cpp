@@ -12,16 +12,23 @@ using namespace mpmpc;
 
 template <int G, int C>
 static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z,
-                    double* u0, int* status, int* iters, double* resid, double* y) {
+                    double* u0, int* status, int* iters, double* resid, double* y, const int* guess = nullptr,
+                    int* act = nullptr) {
   using L = LaneEmu<G, C>;
   const int ld = stage_ld(cfg->N);
   const int per = L::per_wave;
   for (int w0 = 0; w0 < B; w0 += per) {
     VI inst = L::slot() + w0;
     VI k = L::stage();
+    VI gs;
+    for (int i = 0; i < EMU_W; ++i) {
+      const int in = inst.v[i], kk = k.v[i];
+      gs.v[i] = (guess && in < B && kk <= cfg->N) ? guess[in * ld + kk] : 0;
+    }
     Solver<L> s;
-    s.run(qp, B, ld, inst, k, cfg->N, make_params(*st));
-    s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y);
+    if (guess) s.template run<true>(qp, B, ld, inst, k, cfg->N, make_params(*st), 0, gs);
+    else s.run(qp, B, ld, inst, k, cfg->N, make_params(*st));
+    s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y, act, ld);
   }
 }
 
@@ -33,6 +40,21 @@ extern "C" int emu_solve(const mpmpc_config* cfg, const mpmpc_settings* st, int 
   else if (G == 64) solve_g<64, 32>(cfg, st, qp, B, z, u0, status, iters, resid, y);
   else if (G == 32) solve_g<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y);
   else if (G == 16) solve_g<16, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y);
+  else return -1;
+  return 0;
+}
+
+// the closed-loop variant: `guess` [B x ld] = active sets to start from (bit 30 = valid), `act` [B x ld] <- the
+// active sets of the certified points (what mpmpc_solve_kernel<..., true> reads and writes in a rollout)
+extern "C" int emu_solve_warm(const mpmpc_config* cfg, const mpmpc_settings* st, int G, const double* qp, int B,
+                              const int* guess, double* z, double* u0, int* status, int* iters, double* resid,
+                              double* y, int* act) {
+  if (cfg->N + 1 > G) return -1;
+  const int C = lane_split(G, cfg->N);
+  if (G == 64 && C == 16) solve_g<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, guess, act);
+  else if (G == 64) solve_g<64, 32>(cfg, st, qp, B, z, u0, status, iters, resid, y, guess, act);
+  else if (G == 32) solve_g<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, guess, act);
+  else if (G == 16) solve_g<16, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, guess, act);
   else return -1;
   return 0;
 }

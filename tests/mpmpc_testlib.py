@@ -156,6 +156,20 @@ class Emul:
         assert rc == 0
         return mpmpc.Solution(z, u0, st, it, rs, y)
 
+    def solve_warm(self, cfg, settings, qp, guess, G=64):
+        """closed-loop variant: start from the active sets `guess` [B, ld]; -> (Solution, act [B, ld])"""
+        B = qp.shape[1]
+        N = cfg.N
+        n, m = 5 * N + 3, 8 * N + 6
+        z, u0, y = np.zeros((B, n)), np.zeros((B, 2)), np.zeros((B, m))
+        st, it, rs = np.zeros(B, np.int32), np.zeros((B, 2), np.int32), np.zeros((B, 2))
+        act = np.zeros((B, mpmpc.stage_ld(N)), np.int32)
+        guess = np.ascontiguousarray(guess, np.int32)
+        rc = self.lib.emu_solve_warm(C.byref(cfg), C.byref(settings), C.c_int(G), _d(np.ascontiguousarray(qp)), C.c_int(B),
+                                     _i(guess), _d(z), _d(u0), _i(st), _i(it), _d(rs), _d(y), _i(act))
+        assert rc == 0
+        return mpmpc.Solution(z, u0, st, it, rs, y), act
+
 
 def emu_speed_profile(li, kappa, limits, eps=1e-12, device=0):
     """CPU emulation of mpmpc_speed_profile_kernel (same signature as mpmpc.speed_profile)."""

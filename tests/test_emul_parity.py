@@ -166,3 +166,27 @@ def test_non_finite_inputs_get_no_verdict(emu, track):
         for i in (0, 3, 5):
             assert sol.status[i] == clean.status[i] == 1 and np.max(np.abs(sol.u0[i] - clean.u0[i])) <= 1e-9
         assert sol.status[4] in (1, mpmpc.UNSOLVED)        # a NaN previous plan only disables the speed cap or poisons it
+
+
+@pytest.mark.parametrize("cfgid,G", [(2, 64), (4, 32), (3, 64)])
+def test_warm_start_reproduces_the_cold_solution(cfgid, G, emu, track):
+    """Closed-loop warm start: active-set rounds from a given active set.  From the cold solve's own active set
+    every certified instance is certified again without a single ADMM / interior-point iteration and with the
+    same plan; from a WRONG guess (all bounds active) the normal path takes over and the answer is the same."""
+    sc = scenarios.make(cfgid, track, B=12)
+    cfg = T.stock_config(sc.N, sc.weights)
+    qp = emu.assemble(cfg, track, _inputs(sc), obstacles=sc.obstacles)
+    st = mpmpc.default_settings()
+    cold, act = emu.solve_warm(cfg, st, qp, np.zeros((sc.B, mpmpc.stage_ld(sc.N)), np.int32), G=G)
+    ref = emu.solve(cfg, st, qp, G=G)
+    assert np.array_equal(cold.status, ref.status) and np.array_equal(cold.u0, ref.u0)      # no guess: the plain path
+    ok = cold.status == 1
+    assert np.all((act[ok, 0] >> 30) & 1) and not np.any(act[~ok])
+    warm, act2 = emu.solve_warm(cfg, st, qp, act, G=G)
+    assert np.array_equal(warm.status, cold.status)
+    assert np.all(warm.iters[ok] == 0)
+    assert np.max(np.abs(warm.u0[ok] - cold.u0[ok])) <= 1e-9 and np.array_equal(act2[ok], act[ok])
+    wrong = np.where(act != 0, (1 << 30) | 0x3FF, 0).astype(np.int32)
+    again, _ = emu.solve_warm(cfg, st, qp, wrong, G=G)
+    assert np.array_equal(again.status, cold.status)
+    assert np.max(np.abs(again.u0[ok] - cold.u0[ok])) <= 1e-9

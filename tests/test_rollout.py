@@ -97,3 +97,32 @@ def test_device_rollout_matches_host_loop():
     assert np.max(np.abs(st["pose"] - host[:, 1:4])) <= 1e-8
     assert np.max(np.abs(st["u"] - host[:, 4:6])) <= 1e-6
     h.close()
+
+
+@pytest.mark.gpu
+def test_rollout_warm_start_changes_nothing_but_the_time():
+    """The closed loop with the warm start (previous step's shifted active set first, default) and without it:
+    same trajectories, same statuses; most steps of the warm run need no ADMM / interior-point iteration."""
+    g1 = np.load(M.GOLDEN + "/g1_path_sim_track.npz")
+    g3 = np.load(M.GOLDEN + "/g3_corridor.npz")
+    N, steps, B = 30, 40, 96
+    tr = __import__("scenarios").sim_track()
+    cum = np.cumsum(g1["segment_lengths"])
+    starts = np.random.default_rng(3).integers(0, 200, B)
+    poses = np.stack([g1["x"][starts], g1["y"][starts], g1["psi"][starts]], axis=1)
+    out = {}
+    for warm in (False, True):
+        h = mpmpc.Handle(T.stock_config(N, max_batch=B))
+        h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+        h.set_corridor(g3["ub_free"], g3["lb_free"])
+        h.set_path_geometry(g1["x"], g1["y"], g1["psi"], g1["border_ub"], g1["border_lb"])
+        h.rollout_warm_start(warm)
+        h.rollout_init(0.05, cum, cum[starts], poses)
+        h.rollout_step(steps)
+        out[warm] = (h.rollout_state(), h.download(B))
+        h.close()
+    (a, sa), (b, sb) = out[False], out[True]
+    assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["alive"], b["alive"])
+    assert np.max(np.abs(a["s"] - b["s"])) <= 1e-8 and np.max(np.abs(a["pose"] - b["pose"])) <= 1e-8
+    assert np.all(sa.iters[:, 0] >= 1)                    # cold: every step runs the early attempt
+    assert np.mean(sb.iters[:, 0] == 0) > 0.7             # warm: most cars certified straight from the guess
