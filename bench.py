@@ -54,9 +54,9 @@ def k2_flops_per_solve(N, admm_iters, ipm_iters):
     (profiles/census.py: tests/emul with -DMPMPC_COUNT_OPS; FMA = 2, add/mul/div/sqrt = 1) times the
     N+1 lanes that hold a stage.  Fitted per lane as setup + a * ADMM iterations + b * interior-point
     iterations (active-set rounds and certificate amortised into b) at N = 30 and N = 50, linear in N
-    between: 3044 + 838 a + 4541 b and 713 + 1429 a + 7888 b (rms error 5-6 %).  DESIGN.md section 5."""
+    between: 2816 + 844 a + 3985 b and 0 + 1434 a + 7097 b (rms error 5 %).  DESIGN.md section 5."""
     t = (N - 30) / 20.0
-    c0, c1, c2 = 3044 + t * (713 - 3044), 837.8 + t * (1429 - 837.8), 4541 + t * (7888 - 4541)
+    c0, c1, c2 = 2816 + t * (0 - 2816), 843.6 + t * (1434 - 843.6), 3985 + t * (7097 - 3985)
     return (N + 1) * (c0 + c1 * admm_iters + c2 * ipm_iters)
 
 

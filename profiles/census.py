@@ -46,7 +46,8 @@ for config in configs:
             mix.append(list(out))
             dflt.append(not kw)
 A, b, mix, dflt = np.array(rows), np.array(rhs), np.array(mix, float), np.array(dflt)
-coef, *_ = np.linalg.lstsq(A / b[:, None], np.ones_like(b), rcond=None)       # relative least squares
+from scipy.optimize import nnls                                                # relative least squares, coefficients >= 0
+coef, _ = nnls(A / b[:, None], np.ones_like(b))
 res = (A @ coef - b) / b
 print("configs %s (N=%d): flops per lane = %.4g + %.4g * admm_iters + %.4g * ipm_iters   (rms error %.1f %%, at the "
       "defaults %.1f %% with bias %+.1f %%; %d solves)" % (configs, N, coef[0], coef[1], coef[2], 100 * np.sqrt(np.mean(res ** 2)),
