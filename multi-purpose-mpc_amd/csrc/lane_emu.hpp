@@ -80,6 +80,7 @@ inline VD tan_(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std
 inline VD atan_(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::atan(a.v[i]); return r; }
 inline VD sel(const VB& m, const VD& a, const VD& b) { MPMPC_OP(cmpsel); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
 inline VI seli(const VB& m, const VI& a, const VI& b) { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
+inline VB within_(const VI& v, int lo, int hi) { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = v.v[i] >= lo && v.v[i] <= hi; return r; }
 inline VB bit_(const VI& v, int b) { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = ((v.v[i] >> b) & 1) != 0; return r; }
 inline VB selb(const VB& m, const VB& a, const VB& b) { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
 

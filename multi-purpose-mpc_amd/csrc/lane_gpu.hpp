@@ -35,6 +35,7 @@ __device__ __forceinline__ int mini(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int maxi(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ bool selb(bool m, bool a, bool b) { return m ? a : b; }
 __device__ __forceinline__ bool bit_(int v, int b) { return ((v >> b) & 1) != 0; }
+__device__ __forceinline__ bool within_(int v, int lo, int hi) { return (unsigned)(v - lo) <= (unsigned)(hi - lo); }   // lo <= v <= hi
 
 // DPP controls (GFX9)
 constexpr int DPP_ROW_SHL1 = 0x101;    // lane i <- lane i+1 inside each row of 16 lanes

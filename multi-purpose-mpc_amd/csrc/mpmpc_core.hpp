@@ -23,6 +23,9 @@
 #define MPMPC_HD inline
 #endif
 #define MPMPC_UNROLL _Pragma("unroll")
+#ifndef MPMPC_HOST_DEVICE
+#define MPMPC_HOST_DEVICE
+#endif
 
 namespace mpmpc {
 
@@ -177,6 +180,12 @@ inline SolverParams make_params(const mpmpc_settings& st) {
 // Lane split of the twisted factorisation for G lanes per instance and horizon N (shared by the
 // launcher and the emulation): the chains meet at lane C - 1.
 inline int lane_split(int G, int N) { return G == 16 ? 16 : (G == 32 ? 16 : (N + 1 <= 32 ? 16 : 32)); }
+// Stage 0 sits on lane lane_offset of its instance, so that the two chains are equally long for any horizon:
+// lanes off .. C-1 climb through stages 0 .. C-1-off, lanes C .. descend through N .. C-off (no second chain: 0).
+MPMPC_HOST_DEVICE inline int lane_offset(int G, int C, int N) {
+  const int o = C - (N + 2) / 2;
+  return (C >= G || o < 0) ? 0 : o;
+}
 
 template <class L>
 struct Solver {
@@ -185,7 +194,7 @@ struct Solver {
   using I = typename L::ival;
 
   // ---- lane context
-  int N, n_inst;
+  int N, n_inst, off_;    // off_: lane of stage 0 inside the group (lane_offset)
   Mk vx, vu, first;      // lane holds a real stage (k <= N), a real input (k < N), k == 0
   Mk down_chain, is_mid, is_end, vxc;   // twisted factorisation: k >= C; chain-layout lanes C-1, 2C-1; chain-layout vx
   // Split layout of the interior-point stage (kSplit: G = 64 and N + 1 <= 32, so lanes 32..63 are free): lane k
@@ -274,19 +283,21 @@ struct Solver {
     N = N_;
     n_inst = B;
     live = inst < B;
-    vx = live & (k <= N);
-    vu = live & (k < N);
+    vx = live & within_(k, 0, N);
+    vu = live & within_(k, 0, N - 1);
     first = (k == 0);
     {
       const int C = L::split;
-      down_chain = (k >= C);
-      is_mid = (k == C - 1);
-      is_end = (k == 2 * C - 1);
-      I kc = seli(down_chain & (k < 2 * C), k * (-1) + (3 * C - 1), k);
-      vxc = live & (kc <= N);
+      off_ = lane_offset(L::group, C, N);
+      I kl = k + off_;                                  // lane inside the instance's group
+      down_chain = (kl >= C);
+      is_mid = (kl == C - 1);
+      is_end = (kl == 2 * C - 1);
+      I kc = seli(down_chain & (kl < 2 * C), kl * (-1) + (3 * C - 1), kl) - off_;      // stage held in chain layout
+      vxc = live & within_(kc, 0, N);
       if constexpr (kSplit) {
-        sU = (k >= 32);
-        Mk vU = live & sU & (k < N + 32);            // stage k - 32 has inputs
+        sU = (kl >= 32);
+        Mk vU = live & within_(kl, 32 + off_, N + 31 + off_);             // stage kl - 32 - off has inputs
         val3[0] = selb(sU, vU, vx); val3[1] = selb(sU, vU, vx); val3[2] = vx & !sU;
       }
     }
@@ -399,7 +410,7 @@ struct Solver {
   // outward neighbour is mid, reached through the two junction steps of s_solve.
   MPMPC_HD int chain_steps() const {
     const int C = L::split;
-    int fwd = N + 1 < C - 1 ? N + 1 : C - 1, bwd = N - C + 1;
+    int fwd = N + 1 < C - 1 - off_ ? N + 1 : C - 1 - off_, bwd = N - C + off_ + 1;
     return fwd > bwd ? fwd : bwd;
   }
   MPMPC_HD void factor(const R h[5], const R& r) {

@@ -21,6 +21,7 @@
 #include <string>
 
 #define MPMPC_HD __device__ __forceinline__
+#define MPMPC_HOST_DEVICE __host__ __device__
 #include "lane_gpu.hpp"
 #include "mpmpc_core.hpp"
 #include "corridor_core.hpp"
@@ -78,10 +79,10 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
     if ((int)blockIdx.x >= tail[0]) return;       // wave-uniform: G = 64 here
     inst = tail[1 + blockIdx.x];
   }
-  const int k = L::stage();
+  const int k = L::stage() - lane_offset(G, C, cfg.N);      // stage of this lane (negative / > N: none)
   // closed loop: the active set the previous step certified for this car, moved on by the waypoints it advanced
   int guess = 0;
-  if (WARM && act && shift && inst < B && k <= cfg.N) {
+  if (WARM && act && shift && inst < B && k >= 0 && k <= cfg.N) {
     int kk = k + shift[inst];
     guess = act[inst * ld + (kk > cfg.N ? cfg.N : kk)];
   }

@@ -19,11 +19,11 @@ static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const dou
   const int per = L::per_wave;
   for (int w0 = 0; w0 < B; w0 += per) {
     VI inst = L::slot() + w0;
-    VI k = L::stage();
+    VI k = L::stage() - lane_offset(G, C, cfg->N);
     VI gs;
     for (int i = 0; i < EMU_W; ++i) {
       const int in = inst.v[i], kk = k.v[i];
-      gs.v[i] = (guess && in < B && kk <= cfg->N) ? guess[in * ld + kk] : 0;
+      gs.v[i] = (guess && in < B && kk >= 0 && kk <= cfg->N) ? guess[in * ld + kk] : 0;
     }
     Solver<L> s;
     if (guess) s.template run<true>(qp, B, ld, inst, k, cfg->N, make_params(*st), 0, gs);
