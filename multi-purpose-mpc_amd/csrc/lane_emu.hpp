@@ -113,9 +113,11 @@ struct LaneEmu {
     for (int i = 0; i < EMU_W; ++i) { int l = i % G; r.v[i] = (l >= C && l < 2 * C) ? a.v[i - l + 3 * C - 1 - l] : a.v[i]; }
     return r;
   }
-  // (with C = 16 the device uses row shifts: every row of 16 lanes is zero-filled, also the rows beyond 2C)
-  static VD cup(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) { int l = i % G; r.v[i] = (l == 0 || l == C || (C == 16 && l % 16 == 0)) ? 0.0 : a.v[i - 1]; } return r; }
-  static VD cdown(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) { int l = i % G; r.v[i] = (l == C - 1 || l == 2 * C - 1 || l == G - 1 || (C == 16 && l % 16 == 15)) ? 0.0 : a.v[i + 1]; } return r; }
+  // (exactly what the device does: with C = 16 row shifts, every row of 16 lanes zero-filled, also the rows beyond
+  //  2C; with C = 32 plain wavefront shifts, so lane 32 / lane 31 do receive their neighbour's value - which the
+  //  zero coupling block of the meeting stage multiplies away, see lane_gpu.hpp)
+  static VD cup(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) { int l = i % G; r.v[i] = (l == 0 || (l == C && C != 32) || (C == 16 && l % 16 == 0)) ? 0.0 : a.v[i - 1]; } return r; }
+  static VD cdown(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) { int l = i % G; r.v[i] = ((l == C - 1 && C != 32) || l == 2 * C - 1 || l == G - 1 || (C == 16 && l % 16 == 15)) ? 0.0 : a.v[i + 1]; } return r; }
 
   // half-wave exchange (see lane_gpu.hpp)
   static VD from_upper(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i | 32]; return r; }

@@ -108,8 +108,10 @@ struct LaneGpu {
     } else if constexpr (C == 16) {
       return dpp_shift<DPP_ROW_SHR1>(a);                 // chains are rows: the row shift zero-fills
     } else {
-      double r = dpp_shift<DPP_WAVE_SHR1>(a);
-      return dpp_merge<DPP_ROW_SHR1, 0x4, 0x1, true>(r, a);      // lanes 32..35 again, lane 32 <- 0
+      // <64,32>: lane 32 (head of the descending chain) receives lane 31's value instead of 0.  That is harmless:
+      // lane 31 is the meeting stage, whose outgoing block is exactly zero (To = 0 in factor), so lane 32's
+      // recurrence matrix Gin = -Li M_in is zero and whatever arrives in the sweeps is multiplied by it.
+      return dpp_shift<DPP_WAVE_SHR1>(a);
     }
   }
   static __device__ __forceinline__ double cdown(double a) {
@@ -118,8 +120,8 @@ struct LaneGpu {
     } else if constexpr (C == 16) {
       return dpp_shift<DPP_ROW_SHL1>(a);
     } else {
-      double r = dpp_shift<DPP_WAVE_SHL1>(a);
-      return dpp_merge<DPP_ROW_SHL1, 0x2, 0x8, true>(r, a);      // lanes 28..31 again, lane 31 <- 0
+      // <64,32>: lane 31 (the meeting stage) receives lane 32's value instead of 0; its Gout is zero (M_own = 0)
+      return dpp_shift<DPP_WAVE_SHL1>(a);
     }
   }
 
