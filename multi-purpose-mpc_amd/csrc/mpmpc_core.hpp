@@ -23,6 +23,11 @@
 #define MPMPC_HD inline
 #endif
 #define MPMPC_UNROLL _Pragma("unroll")
+#ifndef MPMPC_TICK_BEGIN          // phase clocks of profiling builds (mpmpc_hip.hip, -DMPMPC_PHASE_CLOCK)
+#define MPMPC_TICK_BEGIN(i) ((void)0)
+#define MPMPC_TICK_END(i) ((void)0)
+#define MPMPC_TICK_COUNT(i) ((void)0)
+#endif
 #ifndef MPMPC_HOST_DEVICE
 #define MPMPC_HOST_DEVICE
 #endif
@@ -977,6 +982,7 @@ struct Solver {
       auto rl_of = [&](int j) { return sel(bx.Lm[j], s.x[j] - bx.lo[j] - s.sl[j], zero); };
       auto ru_of = [&](int j) { return sel(bx.Um[j], bx.hi[j] - s.x[j] - s.su[j], zero); };
       auto rpin_of = [&](int j) { return sel(bx.pin[j], s.x[j] - bx.lo[j], zero); };
+      MPMPC_TICK_BEGIN(10);
       R At[E], rp[3], rd[E];
       AeqT_mul_t<S>(s.nu, At);
       Aeq_mul_t<S>(s.x, rp);
@@ -994,7 +1000,10 @@ struct Solver {
       Mk ok = (res < R(tol)) & (mu < R(tol));
       conv = conv | (active & ok);
       active = active & !ok;
+      MPMPC_TICK_END(10);
       if (it == st.ipm_max_iter || !L::wany(active)) break;
+      MPMPC_TICK_COUNT(16);
+      MPMPC_TICK_BEGIN(11);
       ipm_iters = seli(active, ipm_iters + I(1), ipm_iters);
       // ---- factor.  Every division by a slack below is a product with its reciprocal, taken once.
       R isl[E], isu[E], h[E];
@@ -1007,6 +1016,7 @@ struct Solver {
       MPMPC_UNROLL
       for (int j = 0; j < E; ++j) h[j] = rcp_(H_of(j));
       factor_t<S>(h, reg);
+      MPMPC_TICK_END(11);
       // ---- predictor and corrector share the factorisation.  (No iterative refinement of the directions: over
       //      thousands of instances of every configuration it changed neither an iteration count nor a status -
       //      the answer is made by the active-set solve that follows, which does refine.)
@@ -1023,7 +1033,9 @@ struct Solver {
                    sel(bx.Um[j], fma_(s.zu[j], ru_of(j), rcu[j]) * isu[j], zero) - sel(bx.pin[j], rpin_of(j) * ireg, zero);
         MPMPC_UNROLL
         for (int i = 0; i < 3; ++i) nreq[i] = -rp[i];
+        MPMPC_TICK_BEGIN(12);
         kkt_solve_t<S>(rhs, nreq, dx, dnu);
+        MPMPC_TICK_END(12);
         // largest step that keeps slacks and multipliers positive: 1 / max(-ds/s, -dz/z)
         R blk(0.0);
         MPMPC_UNROLL
@@ -1091,7 +1103,10 @@ struct Solver {
         bound[j] = sel(aU[j], bx.hi[j], bx.lo[j]);
         h[j] = one / (p[j] + delta + sel(act[j], idelta, zero));
       }
+      MPMPC_TICK_COUNT(17);
+      MPMPC_TICK_BEGIN(13);
       factor(h, delta);
+      MPMPC_TICK_END(13);
       R xn[5], nn[3], ln[5];
       MPMPC_UNROLL
       for (int j = 0; j < 5; ++j) xn[j] = ln[j] = zero;
@@ -1113,7 +1128,10 @@ struct Solver {
         for (int i = 0; i < 3; ++i) { r2[i] = leq[i] - Ax[i]; rs = max_(rs, sel(vx, abs_(r2[i]), zero)); }
         // the point already satisfies the system to rounding level (1e-15) for every instance in the wave: no further solve
         if (rf >= 1 && !L::wany(todo & (L::gmax(rs) > R(1e-15)))) break;
+        MPMPC_TICK_COUNT(18);
+        MPMPC_TICK_BEGIN(14);
         kkt_solve(rhs, r2, dx, dnu);
+        MPMPC_TICK_END(14);
         R big(0.0);
         MPMPC_UNROLL
         for (int j = 0; j < 5; ++j) {
@@ -1328,7 +1346,9 @@ struct Solver {
     Mk todo = run;
     for (int attempt = 0; attempt < 2; ++attempt) {
       stash();
+      MPMPC_TICK_BEGIN(4);
       Mk conv = ipm<S>(bi, si, pp, qq, vm, st, tol, todo);
+      MPMPC_TICK_END(4);
       Mk aL[5], aU[5];
       R xs[5], nus[3], lam[5];
       if constexpr (S) {
@@ -1356,10 +1376,14 @@ struct Solver {
       for (int j = 0; j < 5; ++j) lam[j] = zero;
       MPMPC_UNROLL
       for (int i = 0; i < 3; ++i) nus[i] = si.nu[i];
+      MPMPC_TICK_BEGIN(5);
       Mk okm = active_set(bx, aL, aU, xs, nus, lam, st, todo & conv);
+      MPMPC_TICK_END(5);
       unstash();
       R prim, stat;
+      MPMPC_TICK_BEGIN(6);
       Mk cert = certificate(xs, nus, lam, st.cert_tol, prim, stat);
+      MPMPC_TICK_END(6);
       Mk good = todo & conv & okm & cert;
       MPMPC_UNROLL
       for (int j = 0; j < 5; ++j) { x[j] = sel(good, xs[j], x[j]); yb[j] = sel(good, lam[j] / g[j], yb[j]); }
@@ -1425,7 +1449,9 @@ struct Solver {
   template <bool WARM = false>
   MPMPC_HD void run(const double* qp, int B, int ld, const I& inst, const I& k, int N_, const SolverParams& st,
                     int mode = 0, const I& guess = I(0)) {
+    MPMPC_TICK_BEGIN(0);
     load(qp, B, ld, inst, k, N_);
+    MPMPC_TICK_END(0);
     // The polish does not need a converged ADMM point, only a reasonable one: with early_polish > 0
     // it is first tried after that many iterations, on a problem that has seen early_scaling of the
     // Ruiz passes.  Whatever it cannot certify (infeasible or very hard instances) gets the remaining
@@ -1440,7 +1466,9 @@ struct Solver {
     if constexpr (WARM) warm = L::gany(live & bit_(guess, 30));
     _Pragma("nounroll")
     for (int pass = 0; pass < 2; ++pass) {
+      MPMPC_TICK_BEGIN(1);
       scale(passes, which);
+      MPMPC_TICK_END(1);
       passes = st.scaling - passes;
       if (WARM && pass == 0 && mode != 2 && st.polish && L::wany(warm)) {
         status = I(MPMPC_UNSOLVED); iters = I(0); ipm_iters = I(0); polished = I(0);
@@ -1453,8 +1481,12 @@ struct Solver {
         which = live & (status == MPMPC_UNSOLVED);
         if (!L::wany(which)) break;
       }
+      MPMPC_TICK_BEGIN(2);
       admm(st, which, limit);
+      MPMPC_TICK_END(2);
+      MPMPC_TICK_BEGIN(3);
       if (st.polish) polish(st, early);
+      MPMPC_TICK_END(3);
       which = live & (status == MPMPC_UNSOLVED);
       if (!early || mode == 1 || !L::wany(which)) break;
       early = false;

@@ -22,6 +22,13 @@
 
 #define MPMPC_HD __device__ __forceinline__
 #define MPMPC_HOST_DEVICE __host__ __device__
+#ifdef MPMPC_PHASE_CLOCK
+// profiling builds only (profiles/phases.sh): per-wave time of the phases of K2 in 10 ns ticks
+__device__ long long g_phase[4096 * 32];
+#define MPMPC_TICK_BEGIN(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) g_phase[blockIdx.x * 32 + (i)] -= wall_clock64(); } while (0)
+#define MPMPC_TICK_END(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) g_phase[blockIdx.x * 32 + (i)] += wall_clock64(); } while (0)
+#define MPMPC_TICK_COUNT(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) g_phase[blockIdx.x * 32 + (i)] += 1; } while (0)
+#endif
 #include "lane_gpu.hpp"
 #include "mpmpc_core.hpp"
 #include "corridor_core.hpp"
@@ -86,9 +93,13 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
     int kk = k + shift[inst];
     guess = act[inst * ld + (kk > cfg.N ? cfg.N : kk)];
   }
+  MPMPC_TICK_BEGIN(8);
   Solver<L> s;
   s.template run<WARM>(qp, B, ld, inst, k, cfg.N, st, mode, guess);
+  MPMPC_TICK_BEGIN(7);
   s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y, WARM ? act : nullptr, ld);
+  MPMPC_TICK_END(7);
+  MPMPC_TICK_END(8);
   if (mode == 1 && k == 0 && inst < B && s.status == MPMPC_UNSOLVED) tail[1 + atomicAdd(tail, 1)] = inst;
 }
 
@@ -285,7 +296,7 @@ void mpmpc_default_settings(mpmpc_settings* s) {
   s->max_iter = 4000; s->check_termination = 25; s->scaling = 10;
   s->adaptive_rho = 1; s->adaptive_rho_interval = 50; s->adaptive_rho_tolerance = 5.0;
   s->polish = 2; s->ipm_max_iter = 30; s->ipm_tol = 1e-9; s->ipm_reg = 1e-8;
-  s->as_delta = 1e-9; s->as_refine = 5; s->as_rounds = 4; s->cert_tol = 1e-8;
+  s->as_delta = 1e-10; s->as_refine = 5; s->as_rounds = 4; s->cert_tol = 1e-8;
   s->early_polish = 1;
   s->early_scaling = 2;
 }
@@ -797,3 +808,14 @@ int mpmpc_solve(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x
 }
 
 }  // extern "C"
+
+#ifdef MPMPC_PHASE_CLOCK
+extern "C" int mpmpc_debug_phase(long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(long long) * 4096 * 32) != hipSuccess) return -1;
+  if (reset) {
+    static long long zeros[4096 * 32];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), zeros, sizeof(zeros)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
