@@ -739,6 +739,17 @@ struct Solver {
     o.s_rd = L::gmax(srd); o.s_q = L::gmax(sq); o.s_Aty = L::gmax(sAty); o.s_Px = L::gmax(sPx);
   }
 
+  // unscaled primal residual only (what the early polish attempt wants to know about the ADMM point)
+  MPMPC_HD R primal_residual() const {
+    R Axe[3], pri(0.0);
+    Aeq_mul(x, Axe);
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) pri = max_(pri, sel(vx, abs_((R(1.0) / Eeq[i]) * (Axe[i] - zeq[i])), R(0.0)));
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) pri = max_(pri, sel(valid[j], abs_((R(1.0) / Eb[j]) * (g[j] * x[j] - zb[j])), R(0.0)));
+    return L::gmax(pri);
+  }
+
   // OSQP is_primal_infeasible() on the last dual step
   MPMPC_HD Mk primal_infeasible(double eps) const {
     R nrm(0.0), lhs(0.0), pd[5], dyeq[3];
@@ -855,7 +866,6 @@ struct Solver {
     const bool full = limit >= st.max_iter;
     if (limit > st.max_iter) limit = st.max_iter;
     Info nf;
-    info(nf);
     park_check_data();
     for (int it = 1; it <= limit; ++it) {
       if (!L::wany(active)) break;
@@ -931,9 +941,16 @@ struct Solver {
       I fin = seli(s1 != MPMPC_UNSOLVED, s1, seli(s2 != MPMPC_UNSOLVED, s2, I(MPMPC_MAX_ITER_REACHED)));
       status = seli(active, fin, status);
     }
-    info(nf);
-    pri_res = keep(which, nf.pri, pri_res);
-    dua_res = keep(which, nf.dua, dua_res);
+    if (full) {
+      info(nf);
+      pri_res = keep(which, nf.pri, pri_res);
+      dua_res = keep(which, nf.dua, dua_res);
+    } else {
+      // stopped early for a polish attempt: that only asks for the primal residual (warm-start floor);
+      // what it cannot certify runs the whole iteration again and gets its residuals there
+      pri_res = keep(which, primal_residual(), pri_res);
+      dua_res = keep(which, R(0.0), dua_res);
+    }
   }
 
   // ======================================================================== certified polish
