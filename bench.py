@@ -45,8 +45,10 @@ def k1_bytes_per_solve(N):
 
 
 def k2_bytes_per_solve(N):
-    # read the 27 stage fields; write z (5N+3), multipliers y (8N+6), u0, residuals, status, iterations
-    return 8 * mpmpc.NUM_FIELDS * (N + 1) + 8 * (5 * N + 3 + 8 * N + 6 + 2 + 2) + 12
+    # the solve launch assembles its own QP: read wp_id, x0 (3), cc_prev (2N), lb, ub (N each); write the 27 stage
+    # fields (the tail launch and the certificate re-read them); write z (5N+3), multipliers y (8N+6), u0,
+    # residuals, status, iterations
+    return 4 + 8 * (3 + 4 * N) + 8 * mpmpc.NUM_FIELDS * (N + 1) + 8 * (5 * N + 3 + 8 * N + 6 + 2 + 2) + 12
 
 
 def k2_flops_per_solve(N, admm_iters, ipm_iters):
@@ -189,7 +191,7 @@ def main():
         out["iters"] = {"admm_mean": float(sol.iters[:, 0].mean()), "admm_max": int(sol.iters[:, 0].max()),
                         "ipm_mean": float(sol.iters[:, 1].mean()), "ipm_max": int(sol.iters[:, 1].max()),
                         "ipm_histogram": {int(k): int(v) for k, v in zip(*np.unique(sol.iters[:, 1], return_counts=True))}}
-        # the same step from HOST buffers (mpmpc_solve: upload + K1 + K2 + download): reported, never `value`
+        # the same step from HOST buffers (mpmpc_solve: upload + assembly and solve in one launch + download): reported, never `value`
         t1 = time.perf_counter()
         for _ in range(5):
             h.solve(wp, x0, cc, lb, ub)

@@ -127,7 +127,7 @@ MPMPC_HD void assemble_lane(const mpmpc_config& c, const PathTables& t, int B, i
   using Mk = typename L::mask;
   using I = typename L::ival;
   const int N = c.N;
-  Mk ok = (inst < B) & (k <= N);
+  Mk ok = (inst < B) & (k >= 0) & (k <= N);        // (K2 keeps lanes before stage 0: lane_offset)
   StageIn<L> in;
   in.first = (k == 0);
   in.has_u = ok & (k < N);

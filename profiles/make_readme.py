@@ -49,7 +49,7 @@ micro-benchmark) are the helpers used while tuning.
 
 | quantity | value | source |
 |---|---|---|
-| QP solves / s (K1 + K2, inputs resident in HBM) | **{d2["value"]/1e6:.2f} M** | `bench_cfg2.json` `value` |
+| QP solves / s (assembly + solve, inputs resident in HBM) | **{d2["value"]/1e6:.2f} M** | `bench_cfg2.json` `value` |
 | ms per step (batch of 1024) | {d2["ms_per_step"]:.3f} | `ms_per_step` |
 | `max|u − u_ref|`, u = (v₀, δ₀), over all 1024 instances | {d2["max_abs_u_minus_uref"]:.1e} (tolerance 1e-6) | `max_abs_u_minus_uref` |
 | whole plan without the cost-free κ_(N−1), e_ψ,N | {d2["max_abs_plan_minus_ref"]:.1e} | `max_abs_plan_minus_ref` |
