@@ -45,10 +45,9 @@ def k1_bytes_per_solve(N):
 
 
 def k2_bytes_per_solve(N):
-    # the solve launch assembles its own QP: read wp_id, x0 (3), cc_prev (2N), lb, ub (N each); write the 27 stage
-    # fields (the tail launch and the certificate re-read them); write z (5N+3), multipliers y (8N+6), u0,
-    # residuals, status, iterations
-    return 4 + 8 * (3 + 4 * N) + 8 * mpmpc.NUM_FIELDS * (N + 1) + 8 * (5 * N + 3 + 8 * N + 6 + 2 + 2) + 12
+    # the solve launch assembles its own QP in registers: read wp_id, x0 (3), cc_prev (2N), lb, ub (N each); write
+    # z (5N+3), multipliers y (8N+6), u0, residuals, status, iterations.  (The stage-blocked QP is not materialised.)
+    return 4 + 8 * (3 + 4 * N) + 8 * (5 * N + 3 + 8 * N + 6 + 2 + 2) + 12
 
 
 def k2_flops_per_solve(N, admm_iters, ipm_iters):

@@ -119,10 +119,11 @@ struct PathTables {
 
 // One (instance, stage) of K1: gather the waypoint data, build the fields, store them
 // stage-blocked as qp[(field * B + inst) * ld + k] (consecutive lanes -> consecutive addresses).
+// (assemble_fields: the 27 fields in registers - what the solve kernel goes on with; assemble_lane: K1, stores them)
 template <class L>
-MPMPC_HD void assemble_lane(const mpmpc_config& c, const PathTables& t, int B, int ld, const typename L::ival& inst,
-                            const typename L::ival& k, const int* wp_id, const double* x0, const double* cc,
-                            const double* lb, const double* ub, double* qp) {
+MPMPC_HD void assemble_fields(const mpmpc_config& c, const PathTables& t, int B, const typename L::ival& inst,
+                              const typename L::ival& k, const int* wp_id, const double* x0, const double* cc,
+                              const double* lb, const double* ub, typename L::real* out) {
   using R = typename L::real;
   using Mk = typename L::mask;
   using I = typename L::ival;
@@ -154,8 +155,17 @@ MPMPC_HD void assemble_lane(const mpmpc_config& c, const PathTables& t, int B, i
     in.lbk = L::load(t.lb_tab, wp * t.n_cols + k - 1, inner, 0.0);
     in.ubk = L::load(t.ub_tab, wp * t.n_cols + k - 1, inner, 0.0);
   }
-  R out[MPMPC_NUM_FIELDS];
   assemble_stage<L>(c, in, out);
+}
+template <class L>
+MPMPC_HD void assemble_lane(const mpmpc_config& c, const PathTables& t, int B, int ld, const typename L::ival& inst,
+                            const typename L::ival& k, const int* wp_id, const double* x0, const double* cc,
+                            const double* lb, const double* ub, double* qp) {
+  using R = typename L::real;
+  using I = typename L::ival;
+  R out[MPMPC_NUM_FIELDS];
+  assemble_fields<L>(c, t, B, inst, k, wp_id, x0, cc, lb, ub, out);
+  typename L::mask ok = (inst < B) & (k >= 0) & (k <= c.N);
   I base = inst * ld + k;
   MPMPC_UNROLL
   for (int f = 0; f < MPMPC_NUM_FIELDS; ++f) L::store(qp, base + f * (B * ld), ok, out[f]);
@@ -211,9 +221,6 @@ struct Solver {
   Mk valid[5];
   Mk live;               // this lane's instance exists
   // ---- where this lane's stage fields live (the unscaled bounds are re-read for the certificate)
-  const double* qp_;
-  I base_;
-  int fstride_;
   // ---- scaled problem
   R mI[3], a[6], b[2], g[5], p[5], q[5], D[5], Eeq[3], Eb[5], c;
   R leq[3], lb[5], ub[5];
@@ -279,12 +286,22 @@ struct Solver {
 
   // ======================================================================== setup
   // field f of this lane's stage, straight from the stage-blocked QP; bounds clipped like OSQP does
-  MPMPC_HD R raw(int f, double dflt) const { return L::load(qp_, base_ + f * fstride_, vx, dflt); }
-  MPMPC_HD R beq_raw(int i) const { return raw(F_BEQ + i, 0.0); }
-  MPMPC_HD R lo_raw(int j) const { return max_(raw(F_LO + j, -INFTY), R(-INFTY)); }
-  MPMPC_HD R hi_raw(int j) const { return min_(raw(F_HI + j, INFTY), R(INFTY)); }
+  // (the unscaled offsets and bounds are needed again after the Ruiz passes and in the certificate: they wait in
+  //  cold storage, slots COLD_RAW .., so that no field is ever re-read from memory)
+  static constexpr int COLD_RAW = 42;
+  MPMPC_HD R beq_raw(int i) const { return L::cold_get(COLD_RAW + i); }
+  MPMPC_HD R lo_raw(int j) const { return L::cold_get(COLD_RAW + 3 + j); }
+  MPMPC_HD R hi_raw(int j) const { return L::cold_get(COLD_RAW + 8 + j); }
+  // the 27 stage fields of (inst, k) from a stage-blocked QP in memory (K1's output)
+  MPMPC_HD static void fetch_fields(const double* qp, int B, int ld, const I& inst, const I& k, int N_, R* fields) {
+    Mk ok = (inst < B) & within_(k, 0, N_);
+    I base = inst * ld + k;
+    MPMPC_UNROLL
+    for (int f = 0; f < MPMPC_NUM_FIELDS; ++f) fields[f] = L::load(qp, base + f * (B * ld), ok, 0.0);
+  }
 
-  MPMPC_HD void load(const double* qp, int B, int ld, const I& inst, const I& k, int N_) {
+  // fields: the 27 stage fields of this lane's (instance, stage) - assemble_fields, or fetch_fields
+  MPMPC_HD void load(const R* fields, int B, const I& inst, const I& k, int N_) {
     N = N_;
     n_inst = B;
     live = inst < B;
@@ -308,10 +325,14 @@ struct Solver {
     }
     valid[0] = valid[1] = valid[2] = vx;
     valid[3] = valid[4] = vu;
-    qp_ = qp;
-    base_ = inst * ld + k;
-    fstride_ = B * ld;
-    auto fld = [&](int f, double dflt) { return raw(f, dflt); };
+    auto fld = [&](int f, double dflt) { return sel(vx, fields[f], R(dflt)); };
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) L::cold_put(COLD_RAW + i, fld(F_BEQ + i, 0.0));
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      L::cold_put(COLD_RAW + 3 + j, max_(fld(F_LO + j, -INFTY), R(-INFTY)));
+      L::cold_put(COLD_RAW + 8 + j, min_(fld(F_HI + j, INFTY), R(INFTY)));
+    }
     R ds = fld(F_DS, 0.0), a10 = fld(F_A10, 0.0), a20 = fld(F_A20, 0.0), b20 = fld(F_B20, 0.0);
     R one = sel(vu, R(1.0), R(0.0));
     a[0] = one; a[1] = ds; a[2] = a10; a[3] = one; a[4] = a20; a[5] = one;
@@ -1464,10 +1485,10 @@ struct Solver {
   // guess: shifted active set of the previous closed-loop step (bit 30 set where there is one), or 0
   // (WARM is a template flag so that the batch kernels do not carry the warm-start code at all)
   template <bool WARM = false>
-  MPMPC_HD void run(const double* qp, int B, int ld, const I& inst, const I& k, int N_, const SolverParams& st,
+  MPMPC_HD void run(const R* fields, int B, const I& inst, const I& k, int N_, const SolverParams& st,
                     int mode = 0, const I& guess = I(0)) {
     MPMPC_TICK_BEGIN(0);
-    load(qp, B, ld, inst, k, N_);
+    load(fields, B, inst, k, N_);
     MPMPC_TICK_END(0);
     // The polish does not need a converged ADMM point, only a reasonable one: with early_polish > 0
     // it is first tried after that many iterations, on a problem that has seen early_scaling of the

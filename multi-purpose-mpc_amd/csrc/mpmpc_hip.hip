@@ -73,9 +73,9 @@ __global__ __launch_bounds__(K1_THREADS) void mpmpc_assemble_kernel(
 // A packed launch (2 or 4 instances per wave) uses modes 1 + 2: the few instances that need hundreds or
 // thousands of ADMM iterations then run one per wave, on the faster G = 64 code, instead of holding a
 // packed wave (and its finished partner lanes) for the whole tail.
-// asm_in.wp_id != NULL: the launch assembles its own QP first (K1 fused into K2: every lane builds the fields of
-// its (instance, stage), writes them to qp - the tail launch and the certificate re-read them - and goes on with
-// them; what a separate K1 launch costs at the headline batch is its latency, 7 of 150 us).
+// The launch assembles its own QP: every lane builds the 27 fields of its (instance, stage) with K1's code
+// (assemble_fields) and goes on with them in registers - the stage-blocked QP is never written to or read from
+// memory on this path (mpmpc_assemble, the parity / debug export, is what runs K1 proper).
 struct AssembleIn {
   PathTables tab;
   const int* wp_id;
@@ -83,12 +83,11 @@ struct AssembleIn {
 };
 template <int G, int C, bool WARM>
 __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, SolverParams st, int B, int ld,
-                                                         double* qp, double* __restrict__ z,
+                                                         AssembleIn ain, double* __restrict__ z,
                                                          double* __restrict__ u0, int* __restrict__ status,
                                                          int* __restrict__ iters, double* __restrict__ resid,
                                                          double* __restrict__ y, int mode, int* __restrict__ tail,
-                                                         int* __restrict__ act, const int* __restrict__ shift,
-                                                         AssembleIn asm_in) {
+                                                         int* __restrict__ act, const int* __restrict__ shift) {
   using L = LaneGpu<G, C>;
   int inst = blockIdx.x * L::per_wave + L::slot();
   if (mode == 2) {
@@ -96,8 +95,6 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
     inst = tail[1 + blockIdx.x];
   }
   const int k = L::stage() - lane_offset(G, C, cfg.N);      // stage of this lane (negative / > N: none)
-  if (asm_in.wp_id != nullptr && mode != 2)
-    assemble_lane<LaneGpu<64>>(cfg, asm_in.tab, B, ld, inst, k, asm_in.wp_id, asm_in.x0, asm_in.cc, asm_in.lb, asm_in.ub, qp);
   // closed loop: the active set the previous step certified for this car, moved on by the waypoints it advanced
   int guess = 0;
   if (WARM && act && shift && inst < B && k >= 0 && k <= cfg.N) {
@@ -105,8 +102,10 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
     guess = act[inst * ld + (kk > cfg.N ? cfg.N : kk)];
   }
   MPMPC_TICK_BEGIN(8);
+  double fields[MPMPC_NUM_FIELDS];
+  assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
   Solver<L> s;
-  s.template run<WARM>(qp, B, ld, inst, k, cfg.N, st, mode, guess);
+  s.template run<WARM>(fields, B, inst, k, cfg.N, st, mode, guess);
   MPMPC_TICK_BEGIN(7);
   s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y, WARM ? act : nullptr, ld);
   MPMPC_TICK_END(7);
@@ -281,7 +280,7 @@ static int check_settings(const mpmpc_settings* s) {
 }
 
 static int launch_assemble(mpmpc_handle h, int B);
-static int launch_solve(mpmpc_handle h, int B, bool closed_loop = false, bool assemble_inside = false);
+static int launch_solve(mpmpc_handle h, int B, bool closed_loop = false);
 
 extern "C" {
 
@@ -562,7 +561,7 @@ int mpmpc_rollout_step(mpmpc_handle h, int32_t B, int32_t n_steps) {
   for (int t = 0; t < n_steps; ++t) {
     hipLaunchKernelGGL(mpmpc_localise_kernel, dim3(blocks), dim3(256), 0, h->stream, B, h->n_wp, h->ro_cum, h->gx, h->gy,
                        h->gpsi, h->ro_s, h->ro_pose, h->ro_alive, h->wp_id, h->x0, h->ro_shift);
-    if (int rc = launch_solve(h, B, true, true)) return rc;
+    if (int rc = launch_solve(h, B, true)) return rc;
     hipLaunchKernelGGL(mpmpc_advance_kernel, dim3(blocks), dim3(256), 0, h->stream, B, h->cfg.N, h->cfg.wheelbase, h->ro_Ts,
                        h->kappa, h->wp_id, h->x0, h->status, h->z, h->cc, h->ro_counter, h->ro_alive, h->ro_pose, h->ro_s,
                        h->ro_u);
@@ -643,14 +642,12 @@ static int launch_assemble(mpmpc_handle h, int B) {
   return MPMPC_OK;
 }
 
-static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool assemble_inside) {
+static int launch_solve(mpmpc_handle h, int B, bool closed_loop) {
   const int N = h->cfg.N;
-  AssembleIn ain{};
-  if (assemble_inside) {
-    ain.tab = PathTables{h->kappa, h->v_ref, h->ds_next, h->n_wp, h->ub_tab, h->lb_tab, h->n_cols};
-    ain.wp_id = h->wp_id; ain.x0 = h->x0; ain.cc = h->cc;
-    ain.lb = h->have_rows ? h->lb : nullptr; ain.ub = h->have_rows ? h->ub : nullptr;
-  }
+  AssembleIn ain;
+  ain.tab = PathTables{h->kappa, h->v_ref, h->ds_next, h->n_wp, h->ub_tab, h->lb_tab, h->n_cols};
+  ain.wp_id = h->wp_id; ain.x0 = h->x0; ain.cc = h->cc;
+  ain.lb = h->have_rows ? h->lb : nullptr; ain.ub = h->have_rows ? h->ub : nullptr;
   int* warm_act = closed_loop && h->ro_warm ? h->ro_act : nullptr;
   const int* warm_shift = closed_loop && h->ro_warm ? h->ro_shift : nullptr;
   // lanes per instance: one instance per wave while there are no more instances than SIMDs (1024);
@@ -670,7 +667,7 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool assemble_i
   const int first_mode = (G < 64 && early) ? 1 : 0;      // packed launches hand their tail to a second one
 #define LAUNCH_W(GG, CC, WW, MODE, BLOCKS)                                                                            \
   hipLaunchKernelGGL((mpmpc_solve_kernel<GG, CC, WW>), dim3(BLOCKS), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, \
-                     h->qp, h->z, h->u0, h->status, h->iters, h->resid, h->y, MODE, h->tail, warm_act, warm_shift, ain)
+                     ain, h->z, h->u0, h->status, h->iters, h->resid, h->y, MODE, h->tail, warm_act, warm_shift)
 #define LAUNCH(GG, CC, MODE, BLOCKS)                                \
   do {                                                              \
     if (warm_act) LAUNCH_W(GG, CC, true, MODE, BLOCKS);             \
@@ -697,7 +694,7 @@ int mpmpc_solve_resident(mpmpc_handle h, int32_t B) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
   if (B < 1 || B > h->uploaded) return fail(MPMPC_E_STATE, "B exceeds the uploaded batch");
   HIP_TRY(hipSetDevice(h->cfg.device));
-  return launch_solve(h, B, false, true);      // one launch: the assembly runs inside K2
+  return launch_solve(h, B);      // one launch: the assembly runs inside K2
 }
 
 int mpmpc_solve_resident_timed(mpmpc_handle h, int32_t B, float* ms_assemble, float* ms_solve) {
@@ -707,7 +704,7 @@ int mpmpc_solve_resident_timed(mpmpc_handle h, int32_t B, float* ms_assemble, fl
   HIP_TRY(hipEventRecord(h->ev[0], h->stream));
   if (int rc = launch_assemble(h, B)) return rc;
   HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-  if (int rc = launch_solve(h, B, false, true)) return rc;
+  if (int rc = launch_solve(h, B)) return rc;
   HIP_TRY(hipEventRecord(h->ev[2], h->stream));
   HIP_TRY(hipEventSynchronize(h->ev[2]));
   float a = 0.f, s = 0.f;

@@ -26,8 +26,10 @@ static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const dou
       gs.v[i] = (guess && in < B && kk >= 0 && kk <= cfg->N) ? guess[in * ld + kk] : 0;
     }
     Solver<L> s;
-    if (guess) s.template run<true>(qp, B, ld, inst, k, cfg->N, make_params(*st), 0, gs);
-    else s.run(qp, B, ld, inst, k, cfg->N, make_params(*st));
+    typename L::real fields[MPMPC_NUM_FIELDS];
+    Solver<L>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    if (guess) s.template run<true>(fields, B, inst, k, cfg->N, make_params(*st), 0, gs);
+    else s.run(fields, B, inst, k, cfg->N, make_params(*st));
     s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y, act, ld);
   }
 }
