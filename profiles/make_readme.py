@@ -63,14 +63,15 @@ micro-benchmark) are the helpers used while tuning.
 
 Rooflines for the dominant kernel K2 at this size:
 
-* HBM (`roofline`): algorithmic 9 932 B/solve (read the 27-field stage-blocked QP, write z, y, u, status,
-  iterations, residuals) → {d2["roofline"]["achieved"]:.1f} GB/s = **{100*d2["roofline"]["frac"]:.2f} % of 8 TB/s**.  K2 is not an HBM kernel (DESIGN.md §5); the
+* HBM (`roofline`): algorithmic {d2["roofline"]["algorithmic_bytes"]/d2["config"]["batch_per_gpu"]:,.0f} B/solve (read wp_id, x0, the previous plan and the corridor
+  rows; write z, y, u, status, iterations, residuals — the solve launch assembles its QP in registers) →
+  {d2["roofline"]["achieved"]:.1f} GB/s = **{100*d2["roofline"]["frac"]:.2f} % of 8 TB/s**.  K2 is not an HBM kernel (DESIGN.md §5); the
   number is reported because the contract asks for it.
   PMC traffic: FETCH_SIZE {f:,.0f} KB (×2, gfx950 correction) + WRITE_SIZE {w:,.0f} KB = {(2*f+w)*1024/1e6:.1f} MB per launch against
-  10.2 MB algorithmic ({(2*f+w)*1024/10170368:.2f}×).  The excess is one-off register-spill traffic (the `<64,16>` kernel has no scratch left; what remains is the
-  padding of the stage rows and of the staged output rows) plus the padded stage rows.
-  History: lane-strided 8-byte output stores had cost a 64-byte write each (WRITE_SIZE 23.7 MB) until the rows
-  were staged through LDS.
+  {d2["roofline"]["algorithmic_bytes"]/1e6:.1f} MB algorithmic ({(2*f+w)*1024/d2["roofline"]["algorithmic_bytes"]:.2f}×; no scratch: what is left above 1× is the shared path tables, the code and the
+  partial 64-byte lines at the ends of the output rows).
+  History: 5× while the loops spilled and the outputs were lane-strided 8-byte stores (WRITE_SIZE 23.7 MB); 1.16× with
+  LDS-staged output rows; the materialised stage-blocked QP (6.7 KB per solve each way) went when K1 was fused in.
 * FP64 vector (`roofline_fp64`): {d2["roofline_fp64"]["flops_per_solve_mean"]/1e6:.2f} MFLOP useful per solve (instruction census of the emulation,
   `census.py`) → {d2["roofline_fp64"]["achieved"]:.1f} TFLOP/s = **{100*d2["roofline_fp64"]["frac"]:.1f} % of 78.6 TFLOP/s**; 31 of 64 lanes hold a stage, and during the serial
   sweeps one lane per chain does useful work, which is what bounds this figure.
@@ -105,8 +106,8 @@ the headline batch of 1024 fills every SIMD with one wave but only 31 of its 64 
 | 3 time-optimal | 4 096 | 50 | {d3["value"]/1e6:.2f} M | {d3["roofline"]["avg_ms"]:.2f} (`<64,32>`) | all solved | {d3["max_abs_u_minus_uref"]:.1e} | {100*d3["status_agreement"]:.0f} % | {d3["cpu_baseline"]["value"]/1e3:.1f} k ({d3["cpu_baseline"]["cores"]}) |
 | 4 obstacles | 8 192 | 30 | {d4["value"]/1e3:.0f} k | {d4["roofline"]["avg_ms"]:.1f} (`<32,16>`) | {counts4.get("1", 0)} solved, {counts4.get("-3", 0)} primal infeasible, {counts4.get("2", 0)} inaccurate | {d4["max_abs_u_minus_uref"]:.1e} | {100*d4["status_agreement"]:.0f} % | {d4["cpu_baseline"]["value"]/1e3:.1f} k ({d4["cpu_baseline"]["cores"]}) |
 
-At B = 65 536 K2's PMC traffic is {(2*fb+wb)*1024/1e6:.0f} MB per launch against 651 MB algorithmic ({(2*fb+wb)*1024/650903552:.2f}×: the `<32,16>` variant
-carries 160 B/lane of scratch).
+At B = 65 536 K2's PMC traffic is {(2*fb+wb)*1024/1e6:.0f} MB per launch against {db["roofline"]["algorithmic_bytes"]/1e6:.0f} MB algorithmic ({(2*fb+wb)*1024/db["roofline"]["algorithmic_bytes"]:.2f}×; the packed
+variants have no scratch left either).
 
 Config 4's time is set by the slowest waves: instances the early polish cannot certify restart the full
 OSQP iteration; infeasible ones need a median of 675 and up to 3 925 ADMM iterations before OSQP's
@@ -128,7 +129,9 @@ it reflects the previous PMC collection of the same build (`collect.sh` is run t
 → 4.3 M (warm-start floor from the ADMM residual) → 4.5 M (early attempt on four Ruiz passes) → 4.6–5.0 M (one
 cubic Newton step in rsqrt / rcp, FMA-folded factor step and slack arithmetic; box-to-box spread ±4 %)
 → 4.9–5.2 M (interior-point stage in the split layout) → 5.2 M (no iterative refinement of the directions,
-residual-based exit of the active-set refinement) → 5.8 M (early attempt after one ADMM iteration) → 6.0 M (on two Ruiz passes) → 6.4–6.8 M (reductions through DPP / permlane swaps instead of ds_bpermute).
+residual-based exit of the active-set refinement) → 5.8 M (early attempt after one ADMM iteration) → 6.0 M (on two Ruiz passes) → 6.4–6.8 M (reductions through DPP / permlane swaps instead of ds_bpermute) → 6.7 M (active-set
+regularisation 1e-10) → 6.85 M (early attempt computes only the primal residual it uses) → 7.1–7.6 M (assembly inside
+the solve launch, QP fields in registers / LDS: no stage-blocked QP in memory, no scratch, 410 VGPRs).
 '''
 open(os.path.join(HERE, "README.md"), "w").write(txt)
 print("profiles/README.md written")
