@@ -1181,6 +1181,18 @@ struct Solver {
         for (int i = 0; i < 3; ++i) nn[i] = nn[i] + dnu[i];
         // refinement has converged for every instance in the wave: stop early
         if (rf >= 1 && !L::wany(todo & (L::gmax(big) > R(1e-15)))) break;
+        // ... or every instance still in the wave has a violation far beyond what refinement can still move
+        // (1e-6): this active set is wrong, the next round does not need its exact solution
+        // (one instance per wave only: a packed wave would need all its instances to agree, and rarely does)
+        if (L::per_wave == 1 && rf >= 1 && rf < st.as_refine) {
+          const R far(1e-6);
+          Mk clear = L::mfalse();
+          MPMPC_UNROLL
+          for (int j = 0; j < 5; ++j)
+            clear = clear | (bx.Lm[j] & !aL[j] & (xn[j] < bx.lo[j] - far)) | (bx.Um[j] & !aU[j] & (xn[j] > bx.hi[j] + far)) |
+                    (aL[j] & (ln[j] > far)) | (aU[j] & (ln[j] < -far));
+          if (!L::wany(todo & !L::gany(clear))) break;
+        }
       }
       Mk anybad = L::mfalse();
       Mk vL[5], vU[5], bL[5], bU[5];
