@@ -54,6 +54,13 @@ def main():
         print("%-24s mean %8.2f us   max %8.2f us" % (name, t[:, i].mean() * 0.01, t[:, i].max() * 0.01))
     for i, name in COUNTS.items():
         print("%-24s mean %8.2f      max %8.0f" % (name, t[:, i].mean(), t[:, i].max()))
+    # what the slowest waves spend their time on (the launch ends with them)
+    order = np.argsort(-t[:, 8])[:8]
+    print("slowest waves: body us | ipm its, us | as rounds, solves, us")
+    for w in order:
+        print("  wave %5d: %7.2f | %2.0f %7.2f | %1.0f %2.0f %6.2f" % (w, t[w, 8] * 0.01, t[w, 16], t[w, 4] * 0.01, t[w, 17], t[w, 18], t[w, 5] * 0.01))
+    q = np.percentile(t[:, 8], [50, 90, 99, 100]) * 0.01
+    print("body percentiles 50/90/99/100: %.1f %.1f %.1f %.1f us" % tuple(q))
 
 
 if __name__ == "__main__":
