@@ -251,6 +251,11 @@ struct mpmpc_handle_s {
   double *x0 = nullptr, *cc = nullptr, *lb = nullptr, *ub = nullptr;
   bool have_rows = false;     // per-instance corridor rows uploaded (else: table)
   int uploaded = 0;
+  // the inputs of a batch lie back to back in ONE device block (wp_id, x0, cc, lb, ub, laid out for the batch size
+  // of the last upload), and so do the outputs (u0, resid, status, iters, z, y): an upload or a download through
+  // the pinned staging buffers is then a single copy instead of five or six - what a single-car call is made of
+  char *in_block = nullptr, *out_block = nullptr;
+  int laid_out = 0;
   // stage-blocked QP and outputs
   double *qp = nullptr, *z = nullptr, *u0 = nullptr, *resid = nullptr, *y = nullptr;
   int *status = nullptr, *iters = nullptr;
@@ -313,11 +318,50 @@ void mpmpc_default_settings(mpmpc_settings* s) {
 
 int32_t mpmpc_stage_ld(int32_t N) { return host_stage_ld(N); }
 
+static size_t pad8(size_t b) { return (b + 7) & ~size_t(7); }
+struct BlockLayout {
+  size_t wp_id, x0, cc, lb, ub, in_end_cc, in_end;          // byte offsets in in_block
+  size_t u0, resid, status, iters, z, y, out_end_z, out_end;  // byte offsets in out_block
+};
+static BlockLayout block_layout(int N, int B) {
+  BlockLayout L;
+  const size_t d = sizeof(double), n = 5 * (size_t)N + 3, m = 8 * (size_t)N + 6, b = (size_t)B;
+  L.wp_id = 0;
+  L.x0 = pad8(sizeof(int) * b);
+  L.cc = L.x0 + d * 3 * b;
+  L.lb = L.in_end_cc = L.cc + d * 2 * N * b;
+  L.ub = L.lb + d * N * b;
+  L.in_end = L.ub + d * N * b;
+  L.u0 = 0;
+  L.resid = L.u0 + d * 2 * b;
+  L.status = L.resid + d * 2 * b;
+  L.iters = L.status + pad8(sizeof(int) * b);
+  L.z = L.iters + pad8(sizeof(int) * 2 * b);
+  L.y = L.out_end_z = L.z + d * n * b;
+  L.out_end = L.y + d * m * b;
+  return L;
+}
+static void lay_out(mpmpc_handle h, int B) {
+  const BlockLayout L = block_layout(h->cfg.N, B);
+  h->wp_id = (int*)(h->in_block + L.wp_id);
+  h->x0 = (double*)(h->in_block + L.x0);
+  h->cc = (double*)(h->in_block + L.cc);
+  h->lb = (double*)(h->in_block + L.lb);
+  h->ub = (double*)(h->in_block + L.ub);
+  h->u0 = (double*)(h->out_block + L.u0);
+  h->resid = (double*)(h->out_block + L.resid);
+  h->status = (int*)(h->out_block + L.status);
+  h->iters = (int*)(h->out_block + L.iters);
+  h->z = (double*)(h->out_block + L.z);
+  h->y = (double*)(h->out_block + L.y);
+  h->laid_out = B;
+}
+
 int mpmpc_destroy(mpmpc_handle h) {
   if (!h) return MPMPC_OK;
   (void)hipSetDevice(h->cfg.device);
-  void* ptrs[] = {h->kappa, h->v_ref, h->ds_next, h->ub_tab, h->lb_tab, h->wp_id, h->x0,  h->cc,   h->lb,  h->ub,
-                  h->qp,    h->z,     h->u0,      h->resid,  h->y,      h->status, h->iters, h->map, h->gx,  h->gy,
+  void* ptrs[] = {h->kappa, h->v_ref, h->ds_next, h->ub_tab, h->lb_tab, h->in_block, h->out_block,
+                  h->qp,    h->map, h->gx,  h->gy,
                   h->gpsi,  h->bub,   h->blb,     h->segs,   h->nseg,   h->bad,    h->ro_cum, h->ro_s, h->ro_pose,
                   h->ro_u,  h->ro_counter, h->ro_alive, h->tail, h->ro_act, h->ro_shift};
   for (void* p : ptrs)
@@ -369,24 +413,16 @@ int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_
       return fail(MPMPC_E_HIP, std::string("hipMalloc " #ptr ": ") + hipGetErrorString(e_)); \
     }                                                                                    \
   } while (0)
-  ALLOC(h->wp_id, B);
-  ALLOC(h->x0, B * 3);
-  ALLOC(h->cc, B * 2 * N);
-  ALLOC(h->lb, B * N);
-  ALLOC(h->ub, B * N);
+  const BlockLayout lay = block_layout(cfg->N, cfg->max_batch);
+  ALLOC(h->in_block, lay.in_end);
+  ALLOC(h->out_block, lay.out_end);
+  lay_out(h, cfg->max_batch);
   ALLOC(h->qp, (size_t)MPMPC_NUM_FIELDS * B * h->ld);
-  ALLOC(h->z, B * h->n);
-  ALLOC(h->u0, B * 2);
-  ALLOC(h->resid, B * 2);
-  ALLOC(h->y, B * h->m);
-  ALLOC(h->status, B);
-  ALLOC(h->iters, B * 2);
   ALLOC(h->tail, B + 1);
 #undef ALLOC
   {
     const size_t STAGE_LIMIT = 64u << 20;
-    const size_t in_b = B * (sizeof(int) + sizeof(double) * (3 + 4 * N)) + 64;          // + alignment slack
-    const size_t out_b = B * (sizeof(double) * (h->n + h->m + 4) + sizeof(int) * 3) + 64;
+    const size_t in_b = lay.in_end, out_b = lay.out_end;
     if (in_b <= STAGE_LIMIT && hipHostMalloc((void**)&h->stage_in, in_b, hipHostMallocDefault) == hipSuccess) h->stage_in_bytes = in_b;
     else h->stage_in = nullptr;
     if (out_b <= STAGE_LIMIT && hipHostMalloc((void**)&h->stage_out, out_b, hipHostMallocDefault) == hipSuccess) h->stage_out_bytes = out_b;
@@ -530,6 +566,7 @@ int mpmpc_rollout_init(mpmpc_handle h, int32_t B, double Ts, const double* cum_l
   }
   if (int rc = upload_table(h, &h->ro_cum, cum_lengths, h->n_wp)) return rc;
   const int N = h->cfg.N;
+  if (B != h->laid_out) lay_out(h, B);
   HIP_TRY(hipMemcpyAsync(h->ro_s, s, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->ro_pose, pose, sizeof(double) * 3 * B, hipMemcpyHostToDevice, h->stream));
   if (cc0) HIP_TRY(hipMemcpyAsync(h->cc, cc0, sizeof(double) * 2 * N * B, hipMemcpyHostToDevice, h->stream));
@@ -611,19 +648,27 @@ int mpmpc_upload(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* 
     if (!h->cfg.circular && wp_id[i] + N >= h->n_wp) return fail(MPMPC_E_ARG, "Reached end of path!");
   }
   HIP_TRY(hipSetDevice(h->cfg.device));
-  // through pinned staging when there is one: the copies are then truly asynchronous and cheap to issue
-  char* stage = h->stage_in;
-  auto push = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
-    const void* from = src;
-    if (stage) { std::memcpy(stage, src, bytes); from = stage; stage += (bytes + 7) & ~size_t(7); }
-    return hipMemcpyAsync(dst, from, bytes, hipMemcpyHostToDevice, h->stream);
-  };
-  HIP_TRY(push(h->wp_id, wp_id, sizeof(int) * B));
-  HIP_TRY(push(h->x0, x0, sizeof(double) * 3 * B));
-  HIP_TRY(push(h->cc, cc_prev, sizeof(double) * 2 * N * B));
-  if (lb) {
-    HIP_TRY(push(h->lb, lb, sizeof(double) * N * B));
-    HIP_TRY(push(h->ub, ub, sizeof(double) * N * B));
+  if (B != h->laid_out) lay_out(h, B);
+  const BlockLayout L = block_layout(N, B);
+  if (h->stage_in) {
+    // through pinned staging: the batch is gathered in the device block's own layout and goes over in one copy
+    char* st = h->stage_in;
+    std::memcpy(st + L.wp_id, wp_id, sizeof(int) * B);
+    std::memcpy(st + L.x0, x0, sizeof(double) * 3 * B);
+    std::memcpy(st + L.cc, cc_prev, sizeof(double) * 2 * N * B);
+    if (lb) {
+      std::memcpy(st + L.lb, lb, sizeof(double) * N * B);
+      std::memcpy(st + L.ub, ub, sizeof(double) * N * B);
+    }
+    HIP_TRY(hipMemcpyAsync(h->in_block, st, lb ? L.in_end : L.in_end_cc, hipMemcpyHostToDevice, h->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(h->wp_id, wp_id, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->x0, x0, sizeof(double) * 3 * B, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->cc, cc_prev, sizeof(double) * 2 * N * B, hipMemcpyHostToDevice, h->stream));
+    if (lb) {
+      HIP_TRY(hipMemcpyAsync(h->lb, lb, sizeof(double) * N * B, hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(hipMemcpyAsync(h->ub, ub, sizeof(double) * N * B, hipMemcpyHostToDevice, h->stream));
+    }
   }
   HIP_TRY(hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller
   h->have_rows = lb != nullptr;
@@ -778,6 +823,20 @@ int mpmpc_download(mpmpc_handle h, int32_t B, double* z, double* u0, int32_t* st
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
   if (B < 1 || B > h->uploaded) return fail(MPMPC_E_STATE, "B exceeds the uploaded batch");
   HIP_TRY(hipSetDevice(h->cfg.device));
+  if (h->stage_out && B == h->laid_out) {
+    // the whole batch was laid out for this B: one copy of the output block (without y, z when they are not wanted)
+    const BlockLayout L = block_layout(h->cfg.N, B);
+    char* st = h->stage_out;
+    HIP_TRY(hipMemcpyAsync(st, h->out_block, y ? L.out_end : (z ? L.out_end_z : L.z), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (z) std::memcpy(z, st + L.z, sizeof(double) * h->n * B);
+    if (u0) std::memcpy(u0, st + L.u0, sizeof(double) * 2 * B);
+    if (status) std::memcpy(status, st + L.status, sizeof(int) * B);
+    if (iters) std::memcpy(iters, st + L.iters, sizeof(int) * 2 * B);
+    if (resid) std::memcpy(resid, st + L.resid, sizeof(double) * 2 * B);
+    if (y) std::memcpy(y, st + L.y, sizeof(double) * h->m * B);
+    return MPMPC_OK;
+  }
   struct Pull { void* user; const char* staged; size_t bytes; } pulls[6];
   int np = 0;
   char* stage = h->stage_out;
