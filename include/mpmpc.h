@@ -166,7 +166,8 @@ int mpmpc_solve(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x
 
 /* Split form of mpmpc_solve for callers that keep inputs resident in HBM (benchmarks, closed
  * loops): upload once, launch any number of times (asynchronous on the handle's stream),
- * synchronise, download. */
+ * synchronise, download.  mpmpc_upload returns as soon as the caller's buffers may be reused; the
+ * transfer itself is ordered before everything launched after it on the handle's stream. */
 int mpmpc_upload(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x0,
                  const double* cc_prev, const double* lb, const double* ub);
 int mpmpc_solve_resident(mpmpc_handle h, int32_t B);

@@ -229,6 +229,8 @@ struct mpmpc_handle_s {
   int ld = 0, n = 0, m = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_in = nullptr;      // the last staged upload has left the pinned buffer
+  bool in_flight = false;
   // tables
   double *kappa = nullptr, *v_ref = nullptr, *ds_next = nullptr, *ub_tab = nullptr, *lb_tab = nullptr;
   int n_wp = 0, n_cols = 0;
@@ -370,6 +372,7 @@ int mpmpc_destroy(mpmpc_handle h) {
   if (h->stage_out) (void)hipHostFree(h->stage_out);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
+  if (h->ev_in) (void)hipEventDestroy(h->ev_in);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return MPMPC_OK;
@@ -430,6 +433,7 @@ int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_
   }
   hipError_t e = hipStreamCreate(&h->stream);
   for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming);
   if (e != hipSuccess) {
     mpmpc_destroy(h);
     return fail(MPMPC_E_HIP, std::string("stream/event creation: ") + hipGetErrorString(e));
@@ -651,7 +655,10 @@ int mpmpc_upload(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* 
   if (B != h->laid_out) lay_out(h, B);
   const BlockLayout L = block_layout(N, B);
   if (h->stage_in) {
-    // through pinned staging: the batch is gathered in the device block's own layout and goes over in one copy
+    // through pinned staging: the batch is gathered in the device block's own layout and goes over in one copy.
+    // The caller's buffers are free as soon as they are gathered, so nothing waits for the copy here - only the
+    // NEXT upload does, before it overwrites the staging buffer.
+    if (h->in_flight) HIP_TRY(hipEventSynchronize(h->ev_in));
     char* st = h->stage_in;
     std::memcpy(st + L.wp_id, wp_id, sizeof(int) * B);
     std::memcpy(st + L.x0, x0, sizeof(double) * 3 * B);
@@ -661,6 +668,8 @@ int mpmpc_upload(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* 
       std::memcpy(st + L.ub, ub, sizeof(double) * N * B);
     }
     HIP_TRY(hipMemcpyAsync(h->in_block, st, lb ? L.in_end : L.in_end_cc, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipEventRecord(h->ev_in, h->stream));
+    h->in_flight = true;
   } else {
     HIP_TRY(hipMemcpyAsync(h->wp_id, wp_id, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->x0, x0, sizeof(double) * 3 * B, hipMemcpyHostToDevice, h->stream));
@@ -669,8 +678,8 @@ int mpmpc_upload(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* 
       HIP_TRY(hipMemcpyAsync(h->lb, lb, sizeof(double) * N * B, hipMemcpyHostToDevice, h->stream));
       HIP_TRY(hipMemcpyAsync(h->ub, ub, sizeof(double) * N * B, hipMemcpyHostToDevice, h->stream));
     }
+    HIP_TRY(hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller
   }
-  HIP_TRY(hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller
   h->have_rows = lb != nullptr;
   h->uploaded = B;
   return MPMPC_OK;
