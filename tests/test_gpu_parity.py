@@ -140,6 +140,37 @@ def test_ragged_and_single_instance(track):
     h.close()
 
 
+def test_block_layout_prefix_download_and_relayout(track):
+    """Inputs / outputs of a batch live in one device block each, laid out for the uploaded batch size: a prefix
+    of the batch can still be launched and downloaded, a later upload of another size re-lays the blocks out, and
+    the optional outputs (y, z) can be left out of a download."""
+    sc = scenarios.make(4, track, B=24, N=10)
+    h = _handle(track, 10, "stock", 32)
+    full = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+    # resident form, prefix of the uploaded batch (download of B' < uploaded takes the per-array path)
+    h.upload(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    h.solve_resident(9)
+    h.sync()
+    part = h.download(9, want_y=True)
+    for a, b in ((part.z, full.z), (part.y, full.y), (part.u0, full.u0), (part.status, full.status),
+                 (part.iters, full.iters), (part.resid, full.resid)):
+        assert np.array_equal(a, b[:9])
+    # the whole batch, without y (one copy of the block up to z)
+    h.solve_resident(24)
+    h.sync()
+    noy = h.download(24, want_y=False)
+    assert noy.y is None and np.array_equal(noy.z, full.z) and np.array_equal(noy.status, full.status)
+    # another batch size on the same handle: blocks are laid out again
+    sub = slice(5, 12)
+    small = h.solve(sc.wp_id[sub], sc.x0[sub], sc.cc_prev[sub], sc.lb[sub], sc.ub[sub], want_y=True)
+    assert np.array_equal(small.z, full.z[sub]) and np.array_equal(small.y, full.y[sub])
+    assert np.array_equal(small.status, full.status[sub]) and np.array_equal(small.u0, full.u0[sub])
+    # and back
+    again = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+    assert np.array_equal(again.z, full.z) and np.array_equal(again.y, full.y)
+    h.close()
+
+
 def test_errors_are_loud(track):
     cfg = T.stock_config(30, max_batch=4)
     h = mpmpc.Handle(cfg)
