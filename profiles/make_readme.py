@@ -42,6 +42,9 @@ output, `*_kernel_stats.csv` is `rocprofv3 --kernel-trace --stats` of the same c
 (FETCH_SIZE and WRITE_SIZE each in its own pass; the SQ counters in two passes of 8).  `collect.sh` gathers,
 `summarize.py` condenses, `make_readme.py` writes the tables below; `census.py` (instruction census → flop
 model), `pmc_admm.sh` (PMC cost of one ADMM iteration), `ab.sh` (A/B of two builds on one box), `quick.sh`,
+`phases.py` (per-wave phase clocks of a `-DMPMPC_PHASE_CLOCK` build: where K2's time goes, which waves are the
+slowest; outputs in `r1/phases_*.txt`), `sweep.sh` / `sweep_parity.sh` (solver-setting sweeps through `bench.py --set`),
+`gsel.sh` (lanes per instance against batch size), `latency_b1.py` / `latency_get_control.py` (single-car calls),
 `cpu_scaling.py` (thread scaling of the CPU baseline) and `micro/exec_half.hip` (instruction-cost
 micro-benchmark) are the helpers used while tuning.
 
