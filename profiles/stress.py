@@ -1,0 +1,50 @@
+"""Randomised device-vs-emulation sweep over horizons, weightings, corridor kinds and batch sizes (run on the GPU box):
+    python profiles/stress.py [seed]
+Every combination must agree in status and iteration counts, and in z / u0 to 1e-9 (the emulation runs the same lane
+code on the CPU in lock step)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for d in ("multi-purpose-mpc_amd", "tests", "oracle"):
+    sys.path.insert(0, os.path.join(ROOT, d))
+import mpmpc            # noqa: E402
+import mpmpc_testlib as T   # noqa: E402
+import scenarios        # noqa: E402
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+tr = scenarios.sim_track()
+em = T.Emul()
+worst, n_inst, bad = 0.0, 0, 0
+for trial in range(40):
+    N = int(rng.choice([3, 4, 7, 10, 15, 16, 17, 24, 30, 31, 32, 33, 40, 45, 50]))
+    cfg_id = int(rng.choice([2, 3, 4]))
+    B = int(rng.integers(1, 40))
+    weights = scenarios.CONFIGS[cfg_id]["weights"]
+    sc = scenarios.make(cfg_id, tr, B=B, N=N)
+    # shuffle the instances so that every trial sees other poses
+    perm = rng.permutation(B)
+    wp, x0, cc, lb, ub = sc.wp_id[perm], sc.x0[perm], sc.cc_prev[perm], sc.lb[perm], sc.ub[perm]
+    x0 = x0 + rng.normal(0, 0.01, x0.shape) * np.array([1.0, 1.0, 0.0])
+    cfg = T.stock_config(N, weights, max_batch=B)
+    Q, R, QN = scenarios.WEIGHTS[weights]
+    h = mpmpc.Handle(cfg)
+    h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+    dev = h.solve(wp, x0, cc, lb, ub, want_y=True)
+    qp = em.assemble(cfg, tr, (wp, x0, cc, lb, ub))
+    for G in sorted({64, 32 if N + 1 <= 32 else 64, 16 if N + 1 <= 16 else 64}):
+        emu = em.solve(cfg, mpmpc.default_settings(), qp, G=G)
+        same = np.array_equal(dev.status, emu.status) and np.array_equal(dev.iters, emu.iters)
+        ok = dev.status == 1
+        dz = float(np.abs(dev.z[ok] - emu.z[ok]).max()) if ok.any() else 0.0
+        du = float(np.abs(dev.u0[ok] - emu.u0[ok]).max()) if ok.any() else 0.0
+        worst = max(worst, dz, du)
+        if not same or dz > 1e-9 or du > 1e-9:
+            bad += 1
+            print("MISMATCH trial %d N=%d cfg=%d B=%d G=%d: status/iters equal %s, dz %.2e du %.2e" % (trial, N, cfg_id, B, G, same, dz, du))
+    n_inst += B
+    h.close()
+print("trials 40, instances %d, mismatches %d, worst |device - emulation| %.2e" % (n_inst, bad, worst))
+sys.exit(1 if bad else 0)
