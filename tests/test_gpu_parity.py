@@ -140,6 +140,34 @@ def test_ragged_and_single_instance(track):
     h.close()
 
 
+@pytest.mark.parametrize("seed", [11, 12])
+def test_randomised_horizons_weights_and_batches_against_emulation(seed, track, emu):
+    """Random (horizon, weighting / corridor kind, batch size, shuffled and perturbed poses): the device and the
+    lock-step emulation of the same lane code agree in status, iteration counts and, to 1e-9, in z and u0 - for
+    every lane packing the horizon allows (profiles/stress.py is the long form of this sweep)."""
+    rng = np.random.default_rng(seed)
+    for _ in range(10):
+        N = int(rng.choice([3, 4, 7, 10, 15, 16, 17, 24, 30, 31, 32, 33, 40, 45, 50]))
+        cfg_id = int(rng.choice([2, 3, 4]))
+        B = int(rng.integers(1, 24))
+        weights = scenarios.CONFIGS[cfg_id]["weights"]
+        sc = scenarios.make(cfg_id, track, B=B, N=N)
+        perm = rng.permutation(B)
+        wp, x0, cc, lb, ub = sc.wp_id[perm], sc.x0[perm], sc.cc_prev[perm], sc.lb[perm], sc.ub[perm]
+        x0 = x0 + rng.normal(0, 0.01, x0.shape) * np.array([1.0, 1.0, 0.0])
+        h = _handle(track, N, weights, B)
+        dev = h.solve(wp, x0, cc, lb, ub, want_y=True)
+        h.close()
+        cfg = T.stock_config(N, weights, max_batch=B)
+        qp = emu.assemble(cfg, track, (wp, x0, cc, lb, ub))
+        for G in sorted({64, 32 if N + 1 <= 32 else 64, 16 if N + 1 <= 16 else 64}):
+            ref = emu.solve(cfg, mpmpc.default_settings(), qp, G=G)
+            assert np.array_equal(dev.status, ref.status) and np.array_equal(dev.iters, ref.iters), (N, cfg_id, B, G)
+            ok = dev.status == 1
+            if ok.any():
+                assert np.abs(dev.z[ok] - ref.z[ok]).max() < 1e-9 and np.abs(dev.u0[ok] - ref.u0[ok]).max() < 1e-9
+
+
 def test_block_layout_prefix_download_and_relayout(track):
     """Inputs / outputs of a batch live in one device block each, laid out for the uploaded batch size: a prefix
     of the batch can still be launched and downloaded, a later upload of another size re-lays the blocks out, and
