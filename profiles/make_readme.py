@@ -45,8 +45,10 @@ model), `pmc_admm.sh` (PMC cost of one ADMM iteration), `ab.sh` (A/B of two buil
 `phases.py` (per-wave phase clocks of a `-DMPMPC_PHASE_CLOCK` build: where K2's time goes, which waves are the
 slowest; outputs in `r1/phases_*.txt`), `sweep.sh` / `sweep_parity.sh` (solver-setting sweeps through `bench.py --set`),
 `gsel.sh` (lanes per instance against batch size), `latency_b1.py` / `latency_get_control.py` (single-car calls),
-`cpu_scaling.py` (thread scaling of the CPU baseline) and `micro/exec_half.hip` (instruction-cost
-micro-benchmark) are the helpers used while tuning.
+`cpu_scaling.py` (thread scaling of the CPU baseline), `micro/exec_half.hip` (instruction-cost micro-benchmark) and
+`micro/rsq_cost.hip` (a `v_rsq_f64` seed costs what `cvt + v_rsq_f32 + cvt` costs, 31 ns per rsqrt + cubic step in a
+dependent chain, 21 ns with four independent ones, i.e. ≈ 3 ns per FP64 instruction of a single wave; both reach
+1.2 ulp) are the helpers used while tuning.
 
 ## Headline (config 2: B = 1024 independent poses, N = 30, stock weights, free corridor)
 
