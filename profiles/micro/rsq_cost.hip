@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <random>
 #include <vector>
 __device__ __forceinline__ double rsq64(double a) {
@@ -46,20 +47,28 @@ __global__ void acc(const double* x, double* out, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { out[2 * i] = rsq64(x[i]); out[2 * i + 1] = rsq32(x[i]); }
 }
-int main() {
+int main(int argc, char** argv) {
+  const int blocks = argc > 1 ? atoi(argv[1]) : 1024;      // 1024 = one wave per SIMD; 2048 / 4096: two / four
   double* d;
   (void)hipMalloc(&d, sizeof(double) * ((1 << 20) + 8));
+  printf("%d waves of 64 lanes\n", blocks);
   const int iters = 20000;
   double ticks;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   auto report = [&](const char* name, int per) {
+    (void)hipEventRecord(e1);
     (void)hipDeviceSynchronize();
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("[kernel %.3f ms] ", ms);
     (void)hipMemcpy(&ticks, d + (1 << 20), sizeof(double), hipMemcpyDeviceToHost);
     printf("%-44s %7.1f ns per rsqrt\n", name, ticks * 10.0 / iters / per);
   };
-  chain<0><<<1024, 64>>>(d, iters, 1.0); report("v_rsq_f64 + cubic, dependent chain", 1);
-  chain<1><<<1024, 64>>>(d, iters, 1.0); report("cvt + v_rsq_f32 + cvt + cubic, dependent", 1);
-  indep<0><<<1024, 64>>>(d, iters, 1.0); report("v_rsq_f64 + cubic, 4 independent", 4);
-  indep<1><<<1024, 64>>>(d, iters, 1.0); report("cvt + v_rsq_f32 + cvt + cubic, 4 independent", 4);
+  (void)hipEventRecord(e0); chain<0><<<blocks, 64>>>(d, iters, 1.0); report("v_rsq_f64 + cubic, dependent chain", 1);
+  (void)hipEventRecord(e0); chain<1><<<blocks, 64>>>(d, iters, 1.0); report("cvt + v_rsq_f32 + cvt + cubic, dependent", 1);
+  (void)hipEventRecord(e0); indep<0><<<blocks, 64>>>(d, iters, 1.0); report("v_rsq_f64 + cubic, 4 independent", 4);
+  (void)hipEventRecord(e0); indep<1><<<blocks, 64>>>(d, iters, 1.0); report("cvt + v_rsq_f32 + cvt + cubic, 4 independent", 4);
   const int n = 1 << 19;
   std::vector<double> x(n), out(2 * n);
   std::mt19937_64 g(1);
