@@ -8,7 +8,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for d in ("multi-purpose-mpc_amd", "tests", "oracle"):
+for d in ("multi-purpose-mpc_amd", "tests"):
     sys.path.insert(0, os.path.join(ROOT, d))
 import mpmpc            # noqa: E402
 import mpmpc_testlib as T   # noqa: E402
