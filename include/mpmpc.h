@@ -135,9 +135,11 @@ int mpmpc_build_corridor(mpmpc_handle h, int32_t n_cols, double min_width, doubl
 int mpmpc_rollout_init(mpmpc_handle h, int32_t B, double Ts, const double* cum_lengths, const double* s,
                        const double* pose, const double* cc0);
 int mpmpc_rollout_step(mpmpc_handle h, int32_t B, int32_t n_steps);
-/* Warm start of the closed loop (default on): each step first tries active-set rounds from the active set the
- * previous step certified for the same car, shifted by the waypoints it advanced; what they cannot certify goes
- * through the normal path.  The reference cold-starts every step (src/MPC.py:158). */
+/* Warm start of the closed loop: each step first tries active-set rounds from the active set the previous step
+ * certified for the same car, shifted by the waypoints it advanced; what they cannot certify goes through the
+ * normal path.  enable: 0 off, 1 on, 2 (default) on where it pays - fleets of more than 1024 cars (several cars per
+ * wavefront) and of at most 16; in between a step ends with its slowest car, and one car in fourteen misses its
+ * guess.  The reference cold-starts every step (src/MPC.py:158). */
 int mpmpc_rollout_warm_start(mpmpc_handle h, int32_t enable);
 int mpmpc_rollout_state(mpmpc_handle h, int32_t B, double* s, double* pose, double* cc, int32_t* wp_id,
                         double* x0, double* u_last, int32_t* status, int32_t* counter, int32_t* alive);

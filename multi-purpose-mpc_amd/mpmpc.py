@@ -241,8 +241,9 @@ class Handle:
         return B
 
     def rollout_warm_start(self, enable=True):
-        """closed loop: try the previous step's shifted active set first (default on)"""
-        self._check(self.lib.mpmpc_rollout_warm_start(self._h, int(bool(enable))))
+        """closed loop: try the previous step's shifted active set first.  True / False force it on / off, "auto"
+        (the handle's default) uses it for fleets of more than 1024 or at most 16 cars, where it pays."""
+        self._check(self.lib.mpmpc_rollout_warm_start(self._h, 2 if enable == "auto" else int(bool(enable))))
 
     def rollout_step(self, n_steps=1):
         self._check(self.lib.mpmpc_rollout_step(self._h, self._ro_B, int(n_steps)))

@@ -23,7 +23,7 @@ for B in (8, 1024, 8192):
     rng = np.random.default_rng(7)
     starts = rng.integers(0, 200, B)
     res = {}
-    for warm in (False, True):
+    for warm in (False, True, "auto"):
         h = mpmpc.Handle(T.stock_config(N, max_batch=B))
         h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
         h.set_corridor(g3["ub_free"], g3["lb_free"])
@@ -42,6 +42,7 @@ for B in (8, 1024, 8192):
         st_["warm_hits"] = float(np.mean(sol_.iters[:, 0] == 0))
         res[warm] = (dt, st_)
         h.close()
+    print("         default (auto): %.3f ms/step" % (res["auto"][0] * 1e3))
     a, b = res[False][1], res[True][1]
     print("B=%5d: %.3f ms/step cold, %.3f ms/step warm (x%.1f); after %d steps max |ds| %.2e, max |dpose| %.2e, alive %d / %d, counters %d / %d" %
           (B, res[False][0] * 1e3, res[True][0] * 1e3, res[False][0] / res[True][0], steps + 5, np.max(np.abs(a["s"] - b["s"])),
