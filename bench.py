@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py - MPC QP solves/sec on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-A step = one pass of the hot path (K1 assembly + K2 ADMM/polish) over one batch of B synthetic
-controller instances whose inputs are already resident in HBM.  N=1 workload: config 2 of
+A step = one pass of the hot path (assembly + ADMM / certified polish, one launch of the solve kernel, which
+builds its QP in registers) over one batch of B synthetic controller instances whose inputs are already
+resident in HBM.  N=1 workload: config 2 of
 BASELINE.json (B=1024 independent initial poses, reference tracking, horizon 30).  With --gpus N
 every rank solves its own batch of the same size (weak scaling, no data-path collective; the
 instances are independent) and `value` is the whole-job rate.
