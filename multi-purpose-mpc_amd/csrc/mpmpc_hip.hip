@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 
@@ -145,6 +146,95 @@ __global__ __launch_bounds__(64) void mpmpc_speed_profile_lds_kernel(int B, int 
   int it = 0;
   status[p] = sp_solve(n, li + (long)p * n, kappa + (long)p * n, 1, lim, eps, W, v + (long)p * n, 1, &it);
   iters[p] = it;
+}
+
+// One WAVEFRONT per path: the elementwise loops of sp_solve_t run strided over the 64 lanes, reductions are
+// shuffles, and the tridiagonal systems are solved by parallel cyclic reduction in LDS - "factor" keeps the two
+// multipliers of every row and level (ceil(log2 n) levels) and the final reciprocal diagonal, "solve" applies them to
+// a right-hand side.  Everything (25 work arrays + 25 n doubles of cyclic-reduction state) lives in LDS.
+struct SpWave {
+  double* x;          // cyclic-reduction state behind the SP_ARRAYS work arrays
+  int cap;            // row capacity (n of the launch)
+  int levels = 0;
+  __device__ int first() const { return threadIdx.x; }
+  __device__ int step() const { return 64; }
+  __device__ void sync() const { __syncthreads(); }
+  __device__ double rmax(double v) const {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+  }
+  __device__ double rsum(double v) const {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  }
+  __device__ bool any(bool b) const { __syncthreads(); return __ballot(b) != 0ull; }
+  // layout of x: A0 B0 C0 A1 B1 C1 (double-buffered rows), D0 D1, BINV, then K1[l], K2[l] per level
+  __device__ double* arr(int a) const { return x + (long)a * cap; }
+  __device__ void tri_factor(const SpWork& W, int n) const {
+    const int lane = threadIdx.x;
+    double *a0 = arr(0), *b0 = arr(1), *c0 = arr(2), *a1 = arr(3), *b1 = arr(4), *c1 = arr(5);
+    for (int i = lane; i < n; i += 64) {
+      a0[i] = i > 0 ? W(SP_ME, i - 1) : 0.0;
+      b0[i] = W(SP_MD, i);
+      c0[i] = i + 1 < n ? W(SP_ME, i) : 0.0;
+    }
+    __syncthreads();
+    int l = 0;
+    for (int s = 1; s < n; s <<= 1, ++l) {
+      double *k1 = arr(9 + 2 * l), *k2 = arr(10 + 2 * l);
+      for (int i = lane; i < n; i += 64) {
+        const bool lo = i - s >= 0, hi = i + s < n;
+        const double m1 = lo ? a0[i] / b0[i - s] : 0.0, m2 = hi ? c0[i] / b0[i + s] : 0.0;
+        k1[i] = m1; k2[i] = m2;
+        a1[i] = lo ? -a0[i - s] * m1 : 0.0;
+        c1[i] = hi ? -c0[i + s] * m2 : 0.0;
+        b1[i] = b0[i] - (lo ? c0[i - s] * m1 : 0.0) - (hi ? a0[i + s] * m2 : 0.0);
+      }
+      __syncthreads();
+      double* t;
+      t = a0; a0 = a1; a1 = t; t = b0; b0 = b1; b1 = t; t = c0; c0 = c1; c1 = t;
+    }
+    double* binv = arr(8);
+    for (int i = lane; i < n; i += 64) binv[i] = 1.0 / b0[i];
+    __syncthreads();
+  }
+  __device__ void tri_solve(const SpWork& W, int n) const {
+    const int lane = threadIdx.x;
+    double *d0 = arr(6), *d1 = arr(7);
+    for (int i = lane; i < n; i += 64) d0[i] = W(SP_RHS, i);
+    __syncthreads();
+    int l = 0;
+    for (int s = 1; s < n; s <<= 1, ++l) {
+      const double *k1 = arr(9 + 2 * l), *k2 = arr(10 + 2 * l);
+      for (int i = lane; i < n; i += 64)
+        d1[i] = d0[i] - (i - s >= 0 ? d0[i - s] * k1[i] : 0.0) - (i + s < n ? d0[i + s] * k2[i] : 0.0);
+      __syncthreads();
+      double* t = d0; d0 = d1; d1 = t;
+    }
+    const double* binv = arr(8);
+    for (int i = lane; i < n; i += 64) W(SP_DX, i) = d0[i] * binv[i];
+    __syncthreads();
+  }
+};
+__host__ __device__ inline int sp_wave_arrays(int n) {      // doubles of SpWave state per row
+  int levels = 0;
+  for (int s = 1; s < n; s <<= 1) ++levels;
+  return 9 + 2 * levels;
+}
+__global__ __launch_bounds__(64) void mpmpc_speed_profile_wave_kernel(int B, int n, const double* __restrict__ li,
+                                                                      const double* __restrict__ kappa,
+                                                                      const double* __restrict__ limits, double eps,
+                                                                      double* __restrict__ v, int* __restrict__ status,
+                                                                      int* __restrict__ iters) {
+  extern __shared__ double sp_lds[];
+  const int p = blockIdx.x;
+  if (p >= B) return;
+  SpWork W{sp_lds, n, 1};
+  SpWave pol{sp_lds + (long)SP_ARRAYS * n, n};
+  SpLimits lim{limits[5 * p], limits[5 * p + 1], limits[5 * p + 2], limits[5 * p + 3], limits[5 * p + 4]};
+  int it = 0;
+  const int st = sp_solve_t(pol, n, li + (long)p * n, kappa + (long)p * n, 1, lim, eps, W, v + (long)p * n, 1, &it);
+  if (threadIdx.x == 0) { status[p] = st; iters[p] = it; }
 }
 
 // K0a: free segments of every waypoint's border line (one thread per waypoint; the rasterised line
@@ -774,6 +864,17 @@ int mpmpc_solve_resident_timed(mpmpc_handle h, int32_t B, float* ms_assemble, fl
   return MPMPC_OK;
 }
 
+// device scratch of mpmpc_speed_profile, kept between calls (one per process; a call is a set-up step, and without
+// this its cost was allocation: 3.5 of 4 ms for a single path)
+struct SpScratch {
+  std::mutex mu;
+  int device = -1;
+  size_t bytes = 0;
+  char* block = nullptr;
+  hipStream_t stream = nullptr;
+};
+static SpScratch g_sp;
+
 int mpmpc_speed_profile(int32_t device, int32_t B, int32_t n, const double* li, const double* kappa,
                         const double* limits, double eps, double* v, int32_t* status, int32_t* iters) {
   if (B < 1 || n < 2) return fail(MPMPC_E_ARG, "speed profile needs B >= 1 paths of n >= 2 segments");
@@ -783,46 +884,49 @@ int mpmpc_speed_profile(int32_t device, int32_t B, int32_t n, const double* li, 
   if (device < 0 || device >= ndev) return fail(MPMPC_E_HIP, "no such HIP device");
   HIP_TRY(hipSetDevice(device));
   const size_t vec = sizeof(double) * (size_t)B * n;
-  double *d_li = nullptr, *d_kappa = nullptr, *d_lim = nullptr, *d_work = nullptr, *d_v = nullptr;
-  int *d_status = nullptr, *d_iters = nullptr;
-  hipStream_t stream = nullptr;
-  int rc = MPMPC_OK;
-#define SP_TRY(expr)                                                                       \
-  do {                                                                                     \
-    hipError_t e_ = (expr);                                                                \
-    if (e_ != hipSuccess && rc == MPMPC_OK)                                                \
-      rc = fail(MPMPC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
-  } while (0)
-  SP_TRY(hipStreamCreate(&stream));
-  SP_TRY(hipMalloc(&d_li, vec));
-  SP_TRY(hipMalloc(&d_kappa, vec));
-  SP_TRY(hipMalloc(&d_v, vec));
-  SP_TRY(hipMalloc(&d_lim, sizeof(double) * 5 * B));
-  SP_TRY(hipMalloc(&d_work, vec * SP_ARRAYS));
-  SP_TRY(hipMalloc(&d_status, sizeof(int) * B));
-  SP_TRY(hipMalloc(&d_iters, sizeof(int) * B));
-  if (rc == MPMPC_OK) {
-    SP_TRY(hipMemcpyAsync(d_li, li, vec, hipMemcpyHostToDevice, stream));
-    SP_TRY(hipMemcpyAsync(d_kappa, kappa, vec, hipMemcpyHostToDevice, stream));
-    SP_TRY(hipMemcpyAsync(d_lim, limits, sizeof(double) * 5 * B, hipMemcpyHostToDevice, stream));
-    const size_t lds = sizeof(double) * SP_ARRAYS * (size_t)n;
-    if (B <= 256 && lds <= 64 * 1024)
-      hipLaunchKernelGGL(mpmpc_speed_profile_lds_kernel, dim3(B), dim3(64), lds, stream, B, n, d_li, d_kappa, d_lim, eps,
-                         d_v, d_status, d_iters);
-    else
-      hipLaunchKernelGGL(mpmpc_speed_profile_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, B, n, d_li, d_kappa, d_lim,
-                         eps, d_work, d_v, d_status, d_iters);
-    SP_TRY(hipGetLastError());
-    SP_TRY(hipMemcpyAsync(v, d_v, vec, hipMemcpyDeviceToHost, stream));
-    SP_TRY(hipMemcpyAsync(status, d_status, sizeof(int) * B, hipMemcpyDeviceToHost, stream));
-    if (iters) SP_TRY(hipMemcpyAsync(iters, d_iters, sizeof(int) * B, hipMemcpyDeviceToHost, stream));
-    SP_TRY(hipStreamSynchronize(stream));
+  const size_t lds = sizeof(double) * SP_ARRAYS * (size_t)n;
+  const size_t lds_wave = sizeof(double) * (SP_ARRAYS + sp_wave_arrays(n)) * (size_t)n;
+  const bool wave = lds_wave <= 156 * 1024, small = !wave && B <= 256 && lds <= 64 * 1024;
+  // one block: li, kappa, v, limits, status, iters (+ the HBM workspace of the thread-per-path kernel)
+  const size_t o_li = 0, o_kappa = vec, o_v = 2 * vec, o_lim = 3 * vec, o_status = o_lim + pad8(sizeof(double) * 5 * B),
+               o_iters = o_status + pad8(sizeof(int) * (size_t)B), o_work = o_iters + pad8(sizeof(int) * (size_t)B),
+               need = o_work + ((wave || small) ? 0 : vec * SP_ARRAYS);
+  std::lock_guard<std::mutex> lock(g_sp.mu);
+  if (g_sp.device != device || g_sp.bytes < need) {
+    if (g_sp.block) { (void)hipSetDevice(g_sp.device); (void)hipFree(g_sp.block); (void)hipSetDevice(device); }
+    if (g_sp.stream && g_sp.device != device) { (void)hipStreamDestroy(g_sp.stream); g_sp.stream = nullptr; }
+    g_sp.block = nullptr; g_sp.bytes = 0; g_sp.device = device;
+    HIP_TRY(hipMalloc((void**)&g_sp.block, need));
+    g_sp.bytes = need;
   }
-#undef SP_TRY
-  for (void* ptr : {(void*)d_li, (void*)d_kappa, (void*)d_v, (void*)d_lim, (void*)d_work, (void*)d_status, (void*)d_iters})
-    (void)hipFree(ptr);
-  if (stream) (void)hipStreamDestroy(stream);
-  return rc;
+  if (!g_sp.stream) HIP_TRY(hipStreamCreate(&g_sp.stream));
+  hipStream_t stream = g_sp.stream;
+  char* blk = g_sp.block;
+  double *d_li = (double*)(blk + o_li), *d_kappa = (double*)(blk + o_kappa), *d_v = (double*)(blk + o_v),
+         *d_lim = (double*)(blk + o_lim), *d_work = (double*)(blk + o_work);
+  int *d_status = (int*)(blk + o_status), *d_iters = (int*)(blk + o_iters);
+  HIP_TRY(hipMemcpyAsync(d_li, li, vec, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(d_kappa, kappa, vec, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(d_lim, limits, sizeof(double) * 5 * B, hipMemcpyHostToDevice, stream));
+  if (wave) {
+    // one wavefront per path (any batch size): lane-parallel arithmetic, cyclic reduction for the tridiagonal solves
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpmpc_speed_profile_wave_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wave));
+    hipLaunchKernelGGL(mpmpc_speed_profile_wave_kernel, dim3(B), dim3(64), lds_wave, stream, B, n, d_li, d_kappa, d_lim,
+                       eps, d_v, d_status, d_iters);
+  } else if (small) {
+    hipLaunchKernelGGL(mpmpc_speed_profile_lds_kernel, dim3(B), dim3(64), lds, stream, B, n, d_li, d_kappa, d_lim, eps,
+                       d_v, d_status, d_iters);
+  } else {
+    hipLaunchKernelGGL(mpmpc_speed_profile_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, B, n, d_li, d_kappa, d_lim,
+                       eps, d_work, d_v, d_status, d_iters);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(v, d_v, vec, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(status, d_status, sizeof(int) * B, hipMemcpyDeviceToHost, stream));
+  if (iters) HIP_TRY(hipMemcpyAsync(iters, d_iters, sizeof(int) * B, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  return MPMPC_OK;
 }
 
 int mpmpc_sync(mpmpc_handle h) {

@@ -420,6 +420,23 @@ def test_open_path_end_is_an_error(track):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 3, 5, 63, 64, 65, 128, 129, 199, 300, 420])
+def test_speed_profile_path_lengths(n):
+    """K4's wave-per-path kernel (lane-strided loops, cyclic reduction of the tridiagonal systems) for path lengths
+    around the wave width and the powers of two, and - n = 420 - the thread-per-path kernel that takes over when
+    the work arrays no longer fit the LDS: all against the emulation of the scalar code."""
+    rng = np.random.default_rng(100 + n)
+    B = 7
+    LI = rng.uniform(0.03, 0.06, (B, n))
+    KA = rng.normal(0.0, 2.0, (B, n)) * (rng.uniform(0, 1, (B, n)) < 0.5)
+    LIM = np.stack([-rng.uniform(0.05, 0.5, B), rng.uniform(0.1, 1.0, B), np.zeros(B), rng.uniform(0.6, 1.5, B),
+                    rng.uniform(1.0, 5.0, B)], axis=1)
+    v, status, iters = mpmpc.speed_profile(LI, KA, LIM)
+    ve, se, _ = T.emu_speed_profile(LI, KA, LIM)
+    assert np.array_equal(status, se) and np.all(status == 1)
+    assert np.max(np.abs(v - ve)) < 1e-9
+
+
 def test_speed_profile_on_device():
     """K4 through the C ABI: the reference track's profile against G2 (the certified optimum of the
     QP the reference hands to OSQP, src/reference_path.py:289-354), and a batch of perturbed paths
