@@ -7,8 +7,9 @@
 //   K2  mpmpc_solve_kernel<G>   one 64-lane wavefront per 64/G instances, lane = horizon stage;
 //                               Ruiz scaling, OSQP ADMM, certified polish, all state in VGPRs,
 //                               stage coupling by DPP shifts, norms by wavefront reductions.
-//                               FP64-VALU / dependency-chain bound; touches HBM only to read the
-//                               27 stage fields and to write the solution.
+//                               FP64-VALU bound (time = instructions x 2.9 ns); builds its QP per lane with
+//                               K1's code and keeps it in registers: HBM sees the batch inputs and the solution.
+//   K0 / K3 / K4                corridor tables from the map, closed-loop rollout, speed profile (see below).
 //
 // No CPU path exists in this library: every compute entry point needs a HIP device.
 #include <hip/hip_runtime.h>
@@ -114,9 +115,10 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
   if (mode == 1 && k == 0 && inst < B && s.status == MPMPC_UNSOLVED) tail[1 + atomicAdd(tail, 1)] = inst;
 }
 
-// K4: speed profile, one thread per path (a serial interior-point / active-set run over a scalar
-// tridiagonal system, speed_core.hpp); the workspace is path-minor so that the threads of a wave
-// touch consecutive addresses.
+// K4: speed profile.  The kernel of choice is mpmpc_speed_profile_wave_kernel below (one wavefront per path); these
+// two run the same code one thread per path (a serial interior-point / active-set run over a scalar tridiagonal
+// system, speed_core.hpp) for paths too long for the LDS: workspace path-minor in HBM, so that the threads of a
+// wave touch consecutive addresses, or in LDS for a few paths.
 __global__ __launch_bounds__(64) void mpmpc_speed_profile_kernel(int B, int n, const double* __restrict__ li,
                                                                  const double* __restrict__ kappa,
                                                                  const double* __restrict__ limits, double eps,
