@@ -126,3 +126,26 @@ def test_rollout_warm_start_changes_nothing_but_the_time():
     assert np.max(np.abs(a["s"] - b["s"])) <= 1e-8 and np.max(np.abs(a["pose"] - b["pose"])) <= 1e-8
     assert np.all(sa.iters[:, 0] >= 1)                    # cold: every step runs the early attempt
     assert np.mean(sb.iters[:, 0] == 0) > 0.7             # warm: most cars certified straight from the guess
+
+
+@pytest.mark.gpu
+def test_rollout_warm_start_default_is_used_where_it_pays():
+    """Default ("auto"): fleets of at most 16 cars and packed launches (more than 1024 cars) start from the previous
+    step's active sets, fleets in between do not (a step ends with its slowest car there)."""
+    g1 = np.load(M.GOLDEN + "/g1_path_sim_track.npz")
+    g3 = np.load(M.GOLDEN + "/g3_corridor.npz")
+    tr = __import__("scenarios").sim_track()
+    cum = np.cumsum(g1["segment_lengths"])
+    for B, expect_warm in ((8, True), (96, False), (1100, True)):
+        starts = np.random.default_rng(5).integers(0, 200, B)
+        poses = np.stack([g1["x"][starts], g1["y"][starts], g1["psi"][starts]], axis=1)
+        h = mpmpc.Handle(T.stock_config(30, max_batch=B))
+        h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+        h.set_corridor(g3["ub_free"], g3["lb_free"])
+        h.set_path_geometry(g1["x"], g1["y"], g1["psi"], g1["border_ub"], g1["border_lb"])
+        h.rollout_init(0.05, cum, cum[starts], poses)          # no rollout_warm_start call: the default
+        h.rollout_step(6)
+        sol = h.download(B)
+        h.close()
+        hits = float(np.mean(sol.iters[:, 0] == 0))
+        assert (hits > 0.5) if expect_warm else (hits == 0.0), (B, hits)
