@@ -190,3 +190,18 @@ def test_warm_start_reproduces_the_cold_solution(cfgid, G, emu, track):
     again, _ = emu.solve_warm(cfg, st, qp, wrong, G=G)
     assert np.array_equal(again.status, cold.status)
     assert np.max(np.abs(again.u0[ok] - cold.u0[ok])) <= 1e-9
+
+
+@pytest.mark.parametrize("N,G", [(3, 64), (3, 16), (10, 64), (10, 16), (30, 64), (30, 32), (50, 64)])
+def test_emulated_kernels_reach_the_g5_optima_of_the_reference_qps(N, G, emu, track):
+    """The reference's own captured inputs (G4: wp_id, x0, previous plan, corridor rows) through K1 + K2 as emulated
+    lane code: statuses of G5 and its certified optima to 1e-6 (the north-star tolerance; measured ~1e-8)."""
+    g4 = np.load(M.GOLDEN + "/g4_assembly_N%d.npz" % N)
+    g5 = np.load(M.GOLDEN + "/g5_solutions_N%d.npz" % N)
+    cfg = T.stock_config(N, str(g4["weights"][0]))
+    qp = emu.assemble(cfg, track, (g4["wp_id"].astype(np.int32), g4["x0"], g4["cc_prev"], g4["lb"], g4["ub"]))
+    sol = emu.solve(cfg, mpmpc.default_settings(), qp, G=G)
+    assert np.array_equal(sol.status, g5["status"])
+    ok = g5["status"] == 1
+    assert np.max(np.abs(sol.z[ok] - g5["x"][ok])) < 1e-6
+    assert np.max(np.abs(sol.z[ok][:, -2 * N:-2 * N + 2] - g5["x"][ok][:, -2 * N:-2 * N + 2])) < 1e-8      # (v_0, kappa_0)

@@ -60,6 +60,24 @@ def test_k1_matches_reference_capture(track):
     h.close()
 
 
+@pytest.mark.parametrize("N", [3, 10, 30, 50])
+def test_device_reaches_the_g5_optima_of_the_reference_qps(N, track):
+    """The reference's own captured inputs (G4) through the C ABI: statuses of G5 and its certified optima to 1e-6
+    (the north-star tolerance), first control to 1e-8."""
+    g4 = np.load(M.GOLDEN + "/g4_assembly_N%d.npz" % N)
+    g5 = np.load(M.GOLDEN + "/g5_solutions_N%d.npz" % N)
+    B = g4["s"].size
+    h = _handle(track, N, str(g4["weights"][0]), B)
+    sol = h.solve(g4["wp_id"].astype(np.int32), g4["x0"], g4["cc_prev"], g4["lb"], g4["ub"], want_y=True)
+    h.close()
+    assert np.array_equal(sol.status, g5["status"])
+    ok = g5["status"] == 1
+    assert np.max(np.abs(sol.z[ok] - g5["x"][ok])) < 1e-6
+    assert np.max(np.abs(sol.z[ok][:, -2 * N:-2 * N + 2] - g5["x"][ok][:, -2 * N:-2 * N + 2])) < 1e-8
+    L = 0.12
+    assert np.max(np.abs(sol.u0[ok, 1] - np.arctan(g5["x"][ok][:, -2 * N + 1] * L))) < 1e-8
+
+
 def test_admm_stock_matches_oracle(track):
     """stock OSQP settings, no polish: the reference's own solver call (src/MPC.py:159,183)"""
     sc = scenarios.make(2, track, B=24)

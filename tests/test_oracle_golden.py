@@ -83,3 +83,37 @@ def test_osqp_restatement_statuses(otrack):
     P, q, A, l, u = M.assemble(otrack, 5, np.array([0.01, 0.0, 0.0]), np.zeros(2 * N), lb2, ub2, N, w, lim)
     r = O.solve(P, q, A, l, u, O.Settings())
     assert r.status == O.PRIMAL_INFEASIBLE
+
+
+@pytest.mark.parametrize("N", [3, 10, 30, 50])
+def test_g5_solutions_are_kkt_points_of_the_reference_qps(N):
+    """G5 (tests/golden/make_g5.py): the stored optimum of every QP the reference handed to osqp.setup (G4) passes the
+    solver-independent KKT certificate on THAT data, and agrees with the objective HiGHS reports where HiGHS
+    terminated (a sanity cross-check only, SURVEY 8c: HiGHS stops at its 1e-7 feasibility tolerance, so its
+    objective sits a few 1e-6 on either side of the optimum)."""
+    g4 = np.load(M.GOLDEN + "/g4_assembly_N%d.npz" % N)
+    g5 = np.load(M.GOLDEN + "/g5_solutions_N%d.npz" % N)
+    n, m = 5 * N + 3, 8 * N + 6
+    assert np.sum(g5["status"] == 1) >= 15 and np.any(g5["status"] == -3)       # feasible and infeasible captures
+    for c in np.flatnonzero(g5["status"] == 1):
+        lo, hi = g4["A_case_ptr"][c], g4["A_case_ptr"][c + 1]
+        A = sparse.csc_matrix((g4["A_data"][lo:hi], g4["A_indices"][lo:hi], g4["A_indptr"][c]), shape=(m, n)).toarray()
+        k = O.kkt_certificate(np.diag(g4["P_diag"][c]), g4["q"][c], A, g4["l"][c], g4["u"][c], g5["x"][c], g5["y"][c])
+        assert k["ok_tol"](1e-8), (N, c, k["prim"], k["stat"], k["comp"])
+        assert abs(k["obj"] - g5["obj"][c]) <= 1e-12 * max(1.0, abs(k["obj"]))
+        if np.isfinite(g5["obj_highs"][c]):
+            assert abs(k["obj"] - g5["obj_highs"][c]) <= 2e-5 * max(1.0, abs(k["obj"]))
+
+
+@pytest.mark.parametrize("N", [3, 30])
+def test_oracle_reproduces_g5(N):
+    g4 = np.load(M.GOLDEN + "/g4_assembly_N%d.npz" % N)
+    g5 = np.load(M.GOLDEN + "/g5_solutions_N%d.npz" % N)
+    n, m = 5 * N + 3, 8 * N + 6
+    for c in range(0, g4["s"].size, 5):
+        lo, hi = g4["A_case_ptr"][c], g4["A_case_ptr"][c + 1]
+        A = sparse.csc_matrix((g4["A_data"][lo:hi], g4["A_indices"][lo:hi], g4["A_indptr"][c]), shape=(m, n)).toarray()
+        r = O.solve(np.diag(g4["P_diag"][c]), g4["q"][c], A, g4["l"][c], g4["u"][c], O.Settings(polish=2))
+        assert r.status == g5["status"][c] and r.iters == g5["admm_iters"][c]
+        if r.status == 1:
+            assert np.max(np.abs(r.x - g5["x"][c])) < 1e-9
