@@ -72,6 +72,41 @@ def cpu_baseline(tr, sc, seconds=10.0):
     return oracle_c.timed_baseline(tr, sc, scenarios.WEIGHTS[sc.weights], limits, seconds)
 
 
+def stock_osqp_leg(tr, sc, ref, seconds=3.0):
+    """if the `osqp` package happens to be importable on this box, time the reference-equivalent path
+    with it - numpy assembly (oracle/mpc_np.py) + osqp.OSQP().setup(...).solve() per instance at stock defaults,
+    one process - and report how far stock OSQP's controls are from the certified optimum.  It is installed
+    neither in this image nor on the GPU boxes of this pool, so normally this returns a one-line note."""
+    try:
+        import osqp  # noqa: F401
+    except Exception:
+        return {"available": False, "note": "python package `osqp` is not installed on this box"}
+    try:
+        from scipy import sparse
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import mpc_np as M
+        otrack = M.Track.sim_track()
+        w = M.Weights.time_optimal() if sc.weights == "time_optimal" else M.Weights.stock()
+        lim = M.Limits.stock()
+        t0, done, worst = time.perf_counter(), 0, 0.0
+        for i in range(sc.wp_id.size):
+            P, q, A, l, u = M.assemble(otrack, int(sc.wp_id[i]), sc.x0[i], sc.cc_prev[i], sc.lb[i], sc.ub[i], sc.N, w, lim)
+            prob = osqp.OSQP()
+            prob.setup(P=sparse.csc_matrix(P), q=q, A=sparse.csc_matrix(A), l=l, u=u, verbose=False)
+            res = prob.solve()
+            done += 1
+            if i < ref["status"].size and ref["status"][i] == 1 and res.x is not None and res.x[0] is not None:
+                u0 = np.array([res.x[-2 * sc.N], np.arctan(res.x[-2 * sc.N + 1] * scenarios.CAR_LENGTH)])
+                worst = max(worst, float(np.max(np.abs(u0 - ref["u0"][i]))))
+            if time.perf_counter() - t0 > seconds:
+                break
+        return {"available": True, "value": done / (time.perf_counter() - t0), "unit": "solves/s", "cores": 1,
+                "sample": "%d instances, numpy assembly + stock osqp (defaults) per instance, one process" % done,
+                "max_abs_u_minus_uref": worst}
+    except Exception as e:          # never let an optional leg break the bench line
+        return {"available": True, "note": "stock-osqp leg failed: %r" % (e,)}
+
+
 def pmc_traffic_bytes(kernel_prefix, B):
     """HBM bytes per launch of one kernel from the committed rocprofv3 PMC summary of THIS command
     (profiles/r1/pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as
@@ -218,6 +253,7 @@ def main():
                 "max_abs_u_minus_uref": float(np.max(np.abs(stock.u0[ok] - ref["u0"][ok]))) if ok.any() else None,
                 "admm_iters_mean": float(stock.iters[:, 0].mean()), "admm_iters_max": int(stock.iters[:, 0].max()),
                 "note": "device run at OSQP's defaults (eps_abs = eps_rel = 1e-3, no polish) vs the certified optimum"}
+            out["stock_osqp_package"] = stock_osqp_leg(tr, sc_rank, ref)
             out["parity_sample"] = int(ns)
             out["host_cores"] = os.cpu_count()
             out["host_cores_usable"] = base.get("usable_cpus")
