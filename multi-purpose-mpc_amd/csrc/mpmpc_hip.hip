@@ -294,11 +294,16 @@ __global__ __launch_bounds__(256) void mpmpc_advance_kernel(int B, int N, double
                                                             double* __restrict__ cc, int* __restrict__ counter,
                                                             int* __restrict__ alive, double* __restrict__ pose,
                                                             double* __restrict__ s, double* __restrict__ u_last) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  // one thread per (car, plan entry): the N arctangents of a car's new plan are independent; the thread of entry 0
+  // then drives the car (it reads only plan entries it wrote itself, or - fallback - entries nobody writes)
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  const int i = g / N, k = g - i * N;
   if (i >= B || alive[i] != 1) return;
   const int n = 5 * N + 3;
-  if (!ro_advance(N, L, Ts, status[i], z + (long)i * n, cc + (long)i * 2 * N, counter + i, x0 + 3 * i, kappa[wp_id[i]],
-                  pose + 3 * i, s + i, u_last + 2 * i))
+  const int st = status[i];
+  if (ro_usable(st)) ro_plan_entry(N, L, z + (long)i * n, cc + (long)i * 2 * N, k);
+  if (k == 0 && !ro_drive(N, L, Ts, st, cc + (long)i * 2 * N, counter + i, x0 + 3 * i, kappa[wp_id[i]], pose + 3 * i,
+                          s + i, u_last + 2 * i))
     alive[i] = -1;
 }
 
@@ -695,7 +700,7 @@ int mpmpc_rollout_step(mpmpc_handle h, int32_t B, int32_t n_steps) {
     hipLaunchKernelGGL(mpmpc_localise_kernel, dim3(blocks), dim3(256), 0, h->stream, B, h->n_wp, h->ro_cum, h->gx, h->gy,
                        h->gpsi, h->ro_s, h->ro_pose, h->ro_alive, h->wp_id, h->x0, h->ro_shift);
     if (int rc = launch_solve(h, B, true)) return rc;
-    hipLaunchKernelGGL(mpmpc_advance_kernel, dim3(blocks), dim3(256), 0, h->stream, B, h->cfg.N, h->cfg.wheelbase, h->ro_Ts,
+    hipLaunchKernelGGL(mpmpc_advance_kernel, dim3((B * h->cfg.N + 255) / 256), dim3(256), 0, h->stream, B, h->cfg.N, h->cfg.wheelbase, h->ro_Ts,
                        h->kappa, h->wp_id, h->x0, h->status, h->z, h->cc, h->ro_counter, h->ro_alive, h->ro_pose, h->ro_s,
                        h->ro_u);
   }

@@ -43,16 +43,19 @@ MPMPC_HD void ro_t2s(double px, double py, double ppsi, double wx, double wy, do
 
 // One car, after the solve.  cc [2N] is MPC.current_control (updated in place), z the primal
 // solution, x0 / kappa_wp the pre-step spatial state and the curvature of the current waypoint.
+// Split in two so that the device can give every plan entry its own thread (ro_plan_entry for k = 0..N-1, then
+// ro_drive by the thread that wrote entry 0); ro_advance is the same thing for one thread per car.
+MPMPC_HD bool ro_usable(int status) { return status == 1 || status == 2 || status == -2; }
+MPMPC_HD void ro_plan_entry(int N, double L, const double* z, double* cc, int k) {
+  const double* uu = z + 3 * (N + 1);
+  cc[2 * k] = uu[2 * k];
+  cc[2 * k + 1] = std::atan(uu[2 * k + 1] * L);
+}
 // Returns false when the run ends (N-1 consecutive infeasible steps: the reference calls exit(1)).
-MPMPC_HD bool ro_advance(int N, double L, double Ts, int status, const double* z, double* cc, int* counter,
-                         const double* x0, double kappa_wp, double* pose, double* s, double* u_out) {
+MPMPC_HD bool ro_drive(int N, double L, double Ts, int status, const double* cc, int* counter, const double* x0,
+                       double kappa_wp, double* pose, double* s, double* u_out) {
   double v, delta;
-  if (status == 1 || status == 2 || status == -2) {
-    const double* uu = z + 3 * (N + 1);
-    for (int k = 0; k < N; ++k) {
-      cc[2 * k] = uu[2 * k];
-      cc[2 * k + 1] = std::atan(uu[2 * k + 1] * L);
-    }
+  if (ro_usable(status)) {
     v = cc[0];
     delta = cc[1];
     *counter = 0;
@@ -72,6 +75,12 @@ MPMPC_HD bool ro_advance(int N, double L, double Ts, int status, const double* z
   const double s_dot = 1.0 / (1.0 - x0[0] * kappa_wp) * v * std::cos(x0[1]);
   *s += s_dot * Ts;
   return true;
+}
+MPMPC_HD bool ro_advance(int N, double L, double Ts, int status, const double* z, double* cc, int* counter,
+                         const double* x0, double kappa_wp, double* pose, double* s, double* u_out) {
+  if (ro_usable(status))
+    for (int k = 0; k < N; ++k) ro_plan_entry(N, L, z, cc, k);
+  return ro_drive(N, L, Ts, status, cc, counter, x0, kappa_wp, pose, s, u_out);
 }
 
 }  // namespace mpmpc

@@ -34,6 +34,23 @@ hist = d2["iters"]["ipm_histogram"]
 st = d2["stock_osqp_settings"]
 counts4 = d4["status_counts"]
 
+import csv as _csv
+_what = {"mpmpc_free_segments_kernel": "K0a: free runs of every waypoint's rasterised border line (200 threads)",
+         "mpmpc_corridor_select_kernel": "K0b: segment selection along the horizon for 200 start waypoints x 50 columns",
+         "mpmpc_localise_kernel": "K3a: waypoint search + path-relative state, 1 024 cars",
+         "mpmpc_solve_kernel": "K2 inside the closed loop (1 024 cars, cold start)",
+         "mpmpc_advance_kernel": "K3b: plan hand-over (one thread per plan entry) + plant step, 1 024 cars",
+         "mpmpc_speed_profile_wave_kernel": "K4: one wavefront per path (mean over 1-path and 1 024-path launches)"}
+_rows = []
+try:
+    for _r in _csv.DictReader(open(os.path.join(HERE, rnd, "next_rows_kernel_stats.csv"))):
+        _name = _r["Name"].replace("void ", "").split("(")[0].split("<")[0]
+        if _name in _what:
+            _rows.append("| `%s` | %.1f µs (%s launches) | %s |" % (_name, float(_r["AverageNs"]) / 1e3, _r["Calls"], _what[_name]))
+    NEXT_ROWS = "\n".join(_rows)
+    NEXT_TXT = "".join("    " + l for l in open(os.path.join(HERE, rnd, "next_rows.txt")))
+except OSError:
+    NEXT_ROWS, NEXT_TXT = "| - | - | not collected |", "    (not collected)"
 txt = f'''# profiles — measured on MI355X (gfx950), ROCm 7.2; host 2× AMD EPYC 9575F, of which the container may use 16 CPUs
 
 Round 1 (`profiles/{rnd}/`).  All from `bench.py` runs on a fresh 1-GPU box; JSON lines are the bench
@@ -125,6 +142,17 @@ baseline runs on the quota.
 
 A bench line's `roofline.traffic` is read from the `pmc_summary.json` that is present when `bench.py` runs, so
 it reflects the previous PMC collection of the same build (`collect.sh` is run twice per refresh).
+
+## The "next" rows (SURVEY §8f): K0, K3, K4
+
+`next_rows.py` runs them in one process; `r1/next_rows_kernel_stats.csv` is `rocprofv3 --kernel-trace --stats` of it,
+`r1/next_rows.txt` its own timings (host calls):
+
+{NEXT_TXT}
+
+| kernel | average | what |
+|---|---|---|
+{NEXT_ROWS}
 
 ## History of the headline in this round (config 2, solves/s)
 
