@@ -115,67 +115,115 @@ struct PathGeom {
   int circular;
 };
 
+// From the chosen border cells (pux, puy) / (plx, ply) of a waypoint to its bounds: sign by side, safety margin,
+// collapse, and the border cells of the selection WITHOUT the margin projected onto the waypoint's normal (what the
+// next waypoint of the horizon measures its candidates against).  o = ub, lb, prev_ux, prev_uy, prev_lx, prev_ly.
+constexpr int COR_WPC = 6;
+MPMPC_HD void cor_bounds(double wx, double wy, double wpsi, double pux, double puy, double plx, double ply,
+                         double safety_margin, double* o) {
+  const double su = cor_sign(cor_wrap(std::atan2(puy - wy, pux - wx) - wpsi));
+  const double sl = cor_sign(cor_wrap(std::atan2(ply - wy, plx - wx) - wpsi));
+  double ub = su * std::sqrt((pux - wx) * (pux - wx) + (puy - wy) * (puy - wy));
+  double lb = sl * std::sqrt((plx - wx) * (plx - wx) + (ply - wy) * (ply - wy));
+  ub -= safety_margin;
+  lb += safety_margin;
+  if (ub < lb) { ub = 0.0; lb = 0.0; }
+  o[0] = ub;
+  o[1] = lb;
+  const double au = cor_wrap(COR_PI / 2 + wpsi), al = cor_wrap(-COR_PI / 2 + wpsi);
+  o[2] = wx + (ub + safety_margin) * std::cos(au);
+  o[3] = wy + (ub + safety_margin) * std::sin(au);
+  o[4] = wx - (lb - safety_margin) * std::cos(al);
+  o[5] = wy - (lb - safety_margin) * std::sin(al);
+}
+// A waypoint with at most one free segment leaves nothing to choose, whatever the horizon did before it: its
+// bounds are computed once per waypoint (phase 1) instead of once per (start waypoint, column) - on Sim_Track
+// that is every waypoint of the free map and all but a handful with the obstacles.
+MPMPC_HD void cor_forced(const PathGeom& g, const double* segs, const int* nseg, int i, double safety_margin, double* o) {
+  const double wx = g.x[i], wy = g.y[i];
+  const double* s = segs + (long)i * 4 * COR_MAXSEG;
+  if (nseg[i] == 1) cor_bounds(wx, wy, g.psi[i], s[0], s[1], s[2], s[3], safety_margin, o);
+  else cor_bounds(wx, wy, g.psi[i], wx, wy, wx, wy, safety_margin, o);
+}
+
+// One column of phase 2 when the waypoint has several free segments: the largest one at the first waypoint of the
+// horizon, otherwise the one closest to the forward projection of the previous column's border cells (prev: rows 2..5
+// of its cor_bounds output; ip = previous waypoint).  o <- this column's cor_bounds output.
+MPMPC_HD void cor_choose(const PathGeom& g, const double* segs, const int* nseg, int i, int ip, bool first,
+                         const double* prev, double safety_margin, double* o) {
+  const double wx = g.x[i], wy = g.y[i], wpsi = g.psi[i];
+  const double* s = segs + (long)i * 4 * COR_MAXSEG;
+  const int cnt = nseg[i];
+  int best = 0;
+  if (first) {
+    double best_len = -1.0;
+    for (int k = 0; k < cnt; ++k) {
+      const double dx = s[4 * k] - s[4 * k + 2], dy = s[4 * k + 1] - s[4 * k + 3];
+      const double len = std::sqrt(dx * dx + dy * dy);
+      if (len > best_len) { best_len = len; best = k; }
+    }
+  } else {
+    const double shift = g.ds_next[ip];            // wp_prev - wp (distance)
+    const double cp = std::cos(g.psi[ip]), sp = std::sin(g.psi[ip]);
+    const double qux = prev[2] + shift * cp, quy = prev[3] + shift * cp;
+    const double qlx = prev[4] + shift * sp, qly = prev[5] + shift * sp;
+    double best_off = 0.0;
+    for (int k = 0; k < cnt; ++k) {
+      const double du = std::sqrt((s[4 * k] - qux) * (s[4 * k] - qux) + (s[4 * k + 1] - quy) * (s[4 * k + 1] - quy));
+      const double dl = std::sqrt((s[4 * k + 2] - qlx) * (s[4 * k + 2] - qlx) + (s[4 * k + 3] - qly) * (s[4 * k + 3] - qly));
+      const double off = (du + dl) / 2;
+      if (k == 0 || off < best_off) { best_off = off; best = k; }
+    }
+  }
+  cor_bounds(wx, wy, wpsi, s[4 * best], s[4 * best + 1], s[4 * best + 2], s[4 * best + 3], safety_margin, o);
+}
+MPMPC_HD int cor_wp(const PathGeom& g, int i) { return i >= g.n_wp ? (g.circular ? i % g.n_wp : g.n_wp - 1) : i; }
+
 // Phase 2, one start waypoint `wp_id`: ub / lb for the n_cols waypoints wp_id .. wp_id+n_cols-1.
 // Returns false when the first horizon waypoint has no free segment (the reference raises there).
+// wpc: the per-waypoint rows of cor_forced (waypoints with at most one free segment).
 MPMPC_HD bool cor_select(const PathGeom& g, const double* segs, const int* nseg, int wp_id, int n_cols,
-                         double safety_margin, double* ub_out, double* lb_out) {
-  double prev_ux = 0, prev_uy = 0, prev_lx = 0, prev_ly = 0;
+                         double safety_margin, double* ub_out, double* lb_out, const double* wpc) {
+  double o[COR_WPC] = {0, 0, 0, 0, 0, 0};
   for (int n = 0; n < n_cols; ++n) {
-    int i = wp_id + n;
-    if (i >= g.n_wp) i = g.circular ? i % g.n_wp : g.n_wp - 1;
-    const double wx = g.x[i], wy = g.y[i], wpsi = g.psi[i];
-    const double* s = segs + (long)i * 4 * COR_MAXSEG;
+    const int i = cor_wp(g, wp_id + n);
     const int cnt = nseg[i];
-    double pux, puy, plx, ply;
-    if (n == 0) {
-      if (cnt == 0) return false;
-      int best = 0;
-      double best_len = -1.0;
-      for (int k = 0; k < cnt; ++k) {
-        const double dx = s[4 * k] - s[4 * k + 2], dy = s[4 * k + 1] - s[4 * k + 3];
-        const double len = std::sqrt(dx * dx + dy * dy);
-        if (len > best_len) { best_len = len; best = k; }
-      }
-      pux = s[4 * best]; puy = s[4 * best + 1]; plx = s[4 * best + 2]; ply = s[4 * best + 3];
+    if (n == 0 && cnt == 0) return false;
+    if (cnt <= 1) {
+      for (int k = 0; k < COR_WPC; ++k) o[k] = wpc[(long)i * COR_WPC + k];
     } else {
-      int ip = wp_id + n - 1;
-      if (ip >= g.n_wp) ip = g.circular ? ip % g.n_wp : g.n_wp - 1;
-      const double shift = g.ds_next[ip];            // wp_prev - wp (distance)
-      const double cp = std::cos(g.psi[ip]), sp = std::sin(g.psi[ip]);
-      const double qux = prev_ux + shift * cp, quy = prev_uy + shift * cp;
-      const double qlx = prev_lx + shift * sp, qly = prev_ly + shift * sp;
-      if (cnt >= 2) {
-        int best = 0;
-        double best_off = 0.0;
-        for (int k = 0; k < cnt; ++k) {
-          const double du = std::sqrt((s[4 * k] - qux) * (s[4 * k] - qux) + (s[4 * k + 1] - quy) * (s[4 * k + 1] - quy));
-          const double dl = std::sqrt((s[4 * k + 2] - qlx) * (s[4 * k + 2] - qlx) + (s[4 * k + 3] - qly) * (s[4 * k + 3] - qly));
-          const double off = (du + dl) / 2;
-          if (k == 0 || off < best_off) { best_off = off; best = k; }
-        }
-        pux = s[4 * best]; puy = s[4 * best + 1]; plx = s[4 * best + 2]; ply = s[4 * best + 3];
-      } else if (cnt == 1) {
-        pux = s[0]; puy = s[1]; plx = s[2]; ply = s[3];
-      } else {
-        pux = wx; puy = wy; plx = wx; ply = wy;
-      }
+      double prev[COR_WPC];
+      for (int k = 0; k < COR_WPC; ++k) prev[k] = o[k];
+      cor_choose(g, segs, nseg, i, cor_wp(g, wp_id + n - 1), n == 0, prev, safety_margin, o);
     }
-    const double su = cor_sign(cor_wrap(std::atan2(puy - wy, pux - wx) - wpsi));
-    const double sl = cor_sign(cor_wrap(std::atan2(ply - wy, plx - wx) - wpsi));
-    double ub = su * std::sqrt((pux - wx) * (pux - wx) + (puy - wy) * (puy - wy));
-    double lb = sl * std::sqrt((plx - wx) * (plx - wx) + (ply - wy) * (ply - wy));
-    ub -= safety_margin;
-    lb += safety_margin;
-    if (ub < lb) { ub = 0.0; lb = 0.0; }
-    ub_out[n] = ub;
-    lb_out[n] = lb;
-    // border cells of the selected segment WITHOUT the margin, projected onto the normal of the waypoint
-    const double au = cor_wrap(COR_PI / 2 + wpsi), al = cor_wrap(-COR_PI / 2 + wpsi);
-    prev_ux = wx + (ub + safety_margin) * std::cos(au);
-    prev_uy = wy + (ub + safety_margin) * std::sin(au);
-    prev_lx = wx - (lb - safety_margin) * std::cos(al);
-    prev_ly = wy - (lb - safety_margin) * std::sin(al);
+    ub_out[n] = o[0];
+    lb_out[n] = o[1];
   }
+  return true;
+}
+
+// The same for ONE column n of the horizon that starts at wp_id, on its own (the device gives every (start
+// waypoint, column) pair a thread): a column is sequential only through the run of multi-segment waypoints right
+// before it, which is replayed from the last forced column (or from the first waypoint's largest-segment rule).
+// Returns false when the horizon's first waypoint has no free segment.
+MPMPC_HD bool cor_select_one(const PathGeom& g, const double* segs, const int* nseg, int wp_id, int n,
+                             double safety_margin, const double* wpc, double* ub, double* lb) {
+  if (nseg[cor_wp(g, wp_id)] == 0) return false;
+  int m = n;                                   // first column of the run to replay
+  while (m > 0 && nseg[cor_wp(g, wp_id + m)] >= 2) --m;
+  double o[COR_WPC] = {0, 0, 0, 0, 0, 0};
+  for (int c = m; c <= n; ++c) {
+    const int i = cor_wp(g, wp_id + c);
+    if (nseg[i] <= 1) {
+      for (int k = 0; k < COR_WPC; ++k) o[k] = wpc[(long)i * COR_WPC + k];
+    } else {
+      double prev[COR_WPC];
+      for (int k = 0; k < COR_WPC; ++k) prev[k] = o[k];
+      cor_choose(g, segs, nseg, i, cor_wp(g, wp_id + c - 1), c == 0, prev, safety_margin, o);
+    }
+  }
+  *ub = o[0];
+  *lb = o[1];
   return true;
 }
 

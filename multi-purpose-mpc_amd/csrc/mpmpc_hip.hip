@@ -241,30 +241,39 @@ __global__ __launch_bounds__(64) void mpmpc_speed_profile_wave_kernel(int B, int
 
 // K0a: free segments of every waypoint's border line (one thread per waypoint; the rasterised line
 // is at most a few hundred cells, the grid is read through L2).
-__global__ __launch_bounds__(64) void mpmpc_free_segments_kernel(MapView map, int n_wp, const double* __restrict__ bub,
+// (a waypoint with at most one free segment also gets its bounds here, once, instead of once per start waypoint
+//  and column in K0b: cor_forced)
+__global__ __launch_bounds__(64) void mpmpc_free_segments_kernel(MapView map, PathGeom g, const double* __restrict__ bub,
                                                                  const double* __restrict__ blb, double min_width,
-                                                                 double* __restrict__ segs, int* __restrict__ nseg) {
+                                                                 double safety_margin, double* __restrict__ segs,
+                                                                 int* __restrict__ nseg, double* __restrict__ wpc) {
   const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= n_wp) return;
+  if (i >= g.n_wp) return;
   double seg[4 * COR_MAXSEG];
   const int cnt = cor_free_segments(map, bub[2 * i], bub[2 * i + 1], blb[2 * i], blb[2 * i + 1], min_width, seg);
   for (int k = 0; k < 4 * COR_MAXSEG; ++k) segs[(long)i * 4 * COR_MAXSEG + k] = k < 4 * cnt ? seg[k] : 0.0;
   nseg[i] = cnt;
+  if (cnt <= 1) cor_forced(g, segs, nseg, i, safety_margin, wpc + (long)i * COR_WPC);
 }
 
 // K0b: horizon walk for every start waypoint w (table row w = update_path_constraints(w + 1, ...)).
-__global__ __launch_bounds__(64) void mpmpc_corridor_select_kernel(PathGeom g, const double* __restrict__ segs,
-                                                                   const int* __restrict__ nseg, int n_cols,
-                                                                   double safety_margin, double* __restrict__ ub_tab,
-                                                                   double* __restrict__ lb_tab, int* __restrict__ bad) {
-  const int w = blockIdx.x * 64 + threadIdx.x;
+// K0b: one thread per (start waypoint, column): cor_select_one replays only the short run of multi-segment waypoints
+// right before its column, everything else is a row of K0a's per-waypoint table.
+__global__ __launch_bounds__(256) void mpmpc_corridor_select_kernel(PathGeom g, const double* __restrict__ segs,
+                                                                    const int* __restrict__ nseg, int n_cols,
+                                                                    double safety_margin, double* __restrict__ ub_tab,
+                                                                    double* __restrict__ lb_tab, int* __restrict__ bad,
+                                                                    const double* __restrict__ wpc) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int w = t / n_cols, n = t - w * n_cols;
   if (w >= g.n_wp) return;
-  double* ub = ub_tab + (long)w * n_cols;
-  double* lb = lb_tab + (long)w * n_cols;
-  if (!cor_select(g, segs, nseg, w + 1, n_cols, safety_margin, ub, lb)) {
-    for (int n = 0; n < n_cols; ++n) { ub[n] = __builtin_nan(""); lb[n] = __builtin_nan(""); }
-    atomicAdd(bad, 1);
+  double ub, lb;
+  if (!cor_select_one(g, segs, nseg, w + 1, n, safety_margin, wpc, &ub, &lb)) {
+    ub = lb = __builtin_nan("");
+    if (n == 0) atomicAdd(bad, 1);
   }
+  ub_tab[(long)w * n_cols + n] = ub;
+  lb_tab[(long)w * n_cols + n] = lb;
 }
 
 // K3a: where is each car on the path, and what is its path-relative state (one thread per car)
@@ -607,7 +616,7 @@ int mpmpc_set_path_geometry(mpmpc_handle h, int32_t n_wp, const double* x, const
   if (h->segs) { HIP_TRY(hipFree(h->segs)); h->segs = nullptr; }
   if (h->nseg) { HIP_TRY(hipFree(h->nseg)); h->nseg = nullptr; }
   if (!h->bad) HIP_TRY(hipMalloc((void**)&h->bad, sizeof(int)));
-  HIP_TRY(hipMalloc((void**)&h->segs, sizeof(double) * 4 * COR_MAXSEG * (size_t)n_wp));
+  HIP_TRY(hipMalloc((void**)&h->segs, sizeof(double) * (4 * COR_MAXSEG + COR_WPC) * (size_t)n_wp));   // + cor_forced rows
   HIP_TRY(hipMalloc((void**)&h->nseg, sizeof(int) * (size_t)n_wp));
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->geom_n = n_wp;
@@ -632,10 +641,11 @@ int mpmpc_build_corridor(mpmpc_handle h, int32_t n_cols, double min_width, doubl
   PathGeom pg{h->gx, h->gy, h->gpsi, h->ds_next, n, h->cfg.circular};
   HIP_TRY(hipMemsetAsync(h->bad, 0, sizeof(int), h->stream));
   const int blocks = (n + 63) / 64;
-  hipLaunchKernelGGL(mpmpc_free_segments_kernel, dim3(blocks), dim3(64), 0, h->stream, mv, n, h->bub, h->blb, min_width,
-                     h->segs, h->nseg);
-  hipLaunchKernelGGL(mpmpc_corridor_select_kernel, dim3(blocks), dim3(64), 0, h->stream, pg, h->segs, h->nseg, n_cols,
-                     safety_margin, h->ub_tab, h->lb_tab, h->bad);
+  double* wpc = h->segs + (size_t)4 * COR_MAXSEG * n;
+  hipLaunchKernelGGL(mpmpc_free_segments_kernel, dim3(blocks), dim3(64), 0, h->stream, mv, pg, h->bub, h->blb, min_width,
+                     safety_margin, h->segs, h->nseg, wpc);
+  hipLaunchKernelGGL(mpmpc_corridor_select_kernel, dim3((n * n_cols + 255) / 256), dim3(256), 0, h->stream, pg, h->segs,
+                     h->nseg, n_cols, safety_margin, h->ub_tab, h->lb_tab, h->bad, wpc);
   HIP_TRY(hipGetLastError());
   int bad = 0;
   HIP_TRY(hipMemcpyAsync(&bad, h->bad, sizeof(int), hipMemcpyDeviceToHost, h->stream));

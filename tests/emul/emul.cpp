@@ -102,14 +102,28 @@ extern "C" int emu_corridor(int height, int width, const int8_t* data, double ox
   double* segs = new double[(size_t)n_wp * 4 * COR_MAXSEG]();
   int* nseg = new int[n_wp];
   for (int i = 0; i < n_wp; ++i) nseg[i] = cor_free_segments(mv, bub[2 * i], bub[2 * i + 1], blb[2 * i], blb[2 * i + 1], min_width, segs + (size_t)i * 4 * COR_MAXSEG);
+  double* wpc = new double[(size_t)n_wp * COR_WPC]();
+  for (int i = 0; i < n_wp; ++i)
+    if (nseg[i] <= 1) cor_forced(pg, segs, nseg, i, safety_margin, wpc + (size_t)i * COR_WPC);
   int bad = 0;
-  for (int w = 0; w < n_wp; ++w)
-    if (!cor_select(pg, segs, nseg, w + 1, n_cols, safety_margin, ub_tab + (size_t)w * n_cols, lb_tab + (size_t)w * n_cols)) {
+  for (int w = 0; w < n_wp; ++w) {
+    if (!cor_select(pg, segs, nseg, w + 1, n_cols, safety_margin, ub_tab + (size_t)w * n_cols, lb_tab + (size_t)w * n_cols, wpc)) {
       ++bad;
       for (int n = 0; n < n_cols; ++n) ub_tab[(size_t)w * n_cols + n] = lb_tab[(size_t)w * n_cols + n] = std::numeric_limits<double>::quiet_NaN();
+      continue;
     }
+    // the per-column form the device runs (one thread per (start waypoint, column)) must give the same bits
+    for (int n = 0; n < n_cols; ++n) {
+      double ub, lb;
+      if (!cor_select_one(pg, segs, nseg, w + 1, n, safety_margin, wpc, &ub, &lb) || ub != ub_tab[(size_t)w * n_cols + n] ||
+          lb != lb_tab[(size_t)w * n_cols + n]) {
+        delete[] segs; delete[] nseg; delete[] wpc;
+        return -1000;
+      }
+    }
+  }
   if (nseg_out) for (int i = 0; i < n_wp; ++i) nseg_out[i] = nseg[i];
-  delete[] segs; delete[] nseg;
+  delete[] segs; delete[] nseg; delete[] wpc;
   return bad;
 }
 
