@@ -79,6 +79,51 @@ MPMPC_HD void cor_line_aa(int r0, int c0, int r1, int c1, F visit) {
 
 // Phase 1, one waypoint: free runs of its border segment that are wider than min_width.
 // seg[4*s + {0,1,2,3}] = (ub_x, ub_y, lb_x, lb_y) of segment s in world coordinates.
+// The scan is a small state machine over the cells of the line in skimage's order; it is written against two
+// callables so that the device can separate the three things a cell costs - producing its coordinates (serial
+// arithmetic), fetching its occupancy (a memory round trip) and the state machine - and overlap the fetches:
+//   n_cells                      cells of the line after the skipped first one (the reference scans x_list[1:])
+//   cell(k, x, y)                coordinates of cell k
+//   is_free(k)                   occupancy of cell k
+template <class Cell, class Free>
+MPMPC_HD int cor_scan_cells(const MapView& m, int ux, int uy, int lx, int ly, double min_width, int n_cells, Cell cell,
+                            Free is_free_at, double* seg) {
+  int count = 0;
+  int sx = ux, sy = uy;       // start cell of the current run
+  bool in_free = false;
+  for (int k = 0; k < n_cells; ++k) {
+    int x, y;
+    cell(k, x, y);
+    const bool is_free = is_free_at(k);
+    if (is_free) in_free = true;
+    if ((!is_free || (x == lx && y == ly)) && in_free) {
+      double ax, ay, bx, by;
+      cor_m2w(m, sx, sy, ax, ay);
+      cor_m2w(m, x, y, bx, by);
+      const double len = std::sqrt((ax - bx) * (ax - bx) + (ay - by) * (ay - by));
+      if (len > min_width && count < COR_MAXSEG) {
+        seg[4 * count + 0] = ax; seg[4 * count + 1] = ay; seg[4 * count + 2] = bx; seg[4 * count + 3] = by;
+        ++count;
+      }
+      sx = x; sy = y;
+      in_free = false;
+    } else if (!is_free && !in_free) {
+      sx = x; sy = y;
+    }
+  }
+  return count;
+}
+// cells of the line (first one skipped) packed as (y << 15 | x) into idx[0..cap); returns how many there are
+// (possibly more than cap: the caller then takes the direct route, as it does for maps beyond 32767 cells a side)
+MPMPC_HD int cor_line_cells(const MapView& m, int ux, int uy, int lx, int ly, int* idx, int cap, int stride) {
+  int n = -1;                                           // -1: the first cell is skipped
+  cor_line_aa(ux, uy, lx, ly, [&](int x, int y) {
+    if (n >= 0 && n < cap) idx[(long)n * stride] = (y << 15) | x;
+    ++n;
+  });
+  return n;
+}
+// direct route: one thread walks the line and reads the grid as it goes
 MPMPC_HD int cor_free_segments(const MapView& m, double bux, double buy, double blx, double bly, double min_width,
                                double* seg) {
   int ux, uy, lx, ly;
@@ -107,6 +152,31 @@ MPMPC_HD int cor_free_segments(const MapView& m, double bux, double buy, double 
     }
   });
   return count;
+}
+// staged route: cell list first (idx / val: cap entries each, element k at [k * stride]), then all occupancies,
+// then the scan.  Same result as cor_free_segments, bit for bit; falls back to it when the line is longer than cap.
+MPMPC_HD int cor_free_segments_staged(const MapView& m, double bux, double buy, double blx, double bly, double min_width,
+                                      double* seg, int* idx, int cap, int stride) {
+  int ux, uy, lx, ly;
+  cor_w2m(m, bux, buy, ux, uy);
+  cor_w2m(m, blx, bly, lx, ly);
+  if (m.width > 32767 || m.height > 32767) return cor_free_segments(m, bux, buy, blx, bly, min_width, seg);
+  const int n = cor_line_cells(m, ux, uy, lx, ly, idx, cap, stride);
+  if (n > cap) return cor_free_segments(m, bux, buy, blx, bly, min_width, seg);
+  // occupancies: independent loads, 32 in flight; bit 30 of the packed cell <- free
+  auto at = [&](int p) { return m.data[(long)(p >> 15) * m.width + (p & 32767)]; };
+  int k = 0;
+  constexpr int W = 32;                     // loads in flight per thread
+  for (; k + W <= n; k += W) {
+    int id[W], v[W];
+    for (int j = 0; j < W; ++j) id[j] = idx[(long)(k + j) * stride];
+    for (int j = 0; j < W; ++j) v[j] = at(id[j]);
+    for (int j = 0; j < W; ++j) idx[(long)(k + j) * stride] = id[j] | (v[j] == 1 ? (1 << 30) : 0);
+  }
+  for (; k < n; ++k) { const int id = idx[(long)k * stride]; idx[(long)k * stride] = id | (at(id) == 1 ? (1 << 30) : 0); }
+  return cor_scan_cells(m, ux, uy, lx, ly, min_width, n,
+                        [&](int c, int& x, int& y) { const int id = idx[(long)c * stride] & ((1 << 30) - 1); y = id >> 15; x = id & 32767; },
+                        [&](int c) { return (idx[(long)c * stride] >> 30) != 0; }, seg);
 }
 
 struct PathGeom {

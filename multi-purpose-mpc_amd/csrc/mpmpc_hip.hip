@@ -247,10 +247,15 @@ __global__ __launch_bounds__(64) void mpmpc_free_segments_kernel(MapView map, Pa
                                                                  const double* __restrict__ blb, double min_width,
                                                                  double safety_margin, double* __restrict__ segs,
                                                                  int* __restrict__ nseg, double* __restrict__ wpc) {
+  // the cells of a thread's line wait in LDS (element k of thread t at [k * 64 + t]) so that their occupancies can be
+  // fetched several at a time instead of one round trip per cell
+  constexpr int CAP = 250;
+  __shared__ int cells[64 * CAP];
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= g.n_wp) return;
   double seg[4 * COR_MAXSEG];
-  const int cnt = cor_free_segments(map, bub[2 * i], bub[2 * i + 1], blb[2 * i], blb[2 * i + 1], min_width, seg);
+  const int cnt = cor_free_segments_staged(map, bub[2 * i], bub[2 * i + 1], blb[2 * i], blb[2 * i + 1], min_width, seg,
+                                           cells + threadIdx.x, CAP, 64);
   for (int k = 0; k < 4 * COR_MAXSEG; ++k) segs[(long)i * 4 * COR_MAXSEG + k] = k < 4 * cnt ? seg[k] : 0.0;
   nseg[i] = cnt;
   if (cnt <= 1) cor_forced(g, segs, nseg, i, safety_margin, wpc + (long)i * COR_WPC);

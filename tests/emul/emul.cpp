@@ -2,6 +2,8 @@
 // Instantiates the lane-generic core of multi-purpose-mpc_amd/csrc/mpmpc_core.hpp with the
 // 64-lane emulated wavefront of lane_emu.hpp so the kernel algorithm can be checked against
 // the oracle in the GPU-less authoring container.  Never loaded by the product.
+#include <cstring>
+#include <initializer_list>
 #include "lane_emu.hpp"
 #include "mpmpc_core.hpp"
 #include "corridor_core.hpp"
@@ -101,7 +103,20 @@ extern "C" int emu_corridor(int height, int width, const int8_t* data, double ox
   PathGeom pg{x, y, psi, ds_next, n_wp, circular};
   double* segs = new double[(size_t)n_wp * 4 * COR_MAXSEG]();
   int* nseg = new int[n_wp];
-  for (int i = 0; i < n_wp; ++i) nseg[i] = cor_free_segments(mv, bub[2 * i], bub[2 * i + 1], blb[2 * i], blb[2 * i + 1], min_width, segs + (size_t)i * 4 * COR_MAXSEG);
+  for (int i = 0; i < n_wp; ++i) {
+    nseg[i] = cor_free_segments(mv, bub[2 * i], bub[2 * i + 1], blb[2 * i], blb[2 * i + 1], min_width, segs + (size_t)i * 4 * COR_MAXSEG);
+    // the staged form the device runs (cell list, occupancies, scan) must give the same bits - also with a buffer
+    // that is too small, where it has to fall back
+    for (int cap : {250, 7}) {
+      int cells[250];
+      double seg2[4 * COR_MAXSEG] = {0};
+      const int c2 = cor_free_segments_staged(mv, bub[2 * i], bub[2 * i + 1], blb[2 * i], blb[2 * i + 1], min_width, seg2, cells, cap, 1);
+      if (c2 != nseg[i] || std::memcmp(seg2, segs + (size_t)i * 4 * COR_MAXSEG, sizeof(double) * 4 * c2) != 0) {
+        delete[] segs; delete[] nseg;
+        return -2000;
+      }
+    }
+  }
   double* wpc = new double[(size_t)n_wp * COR_WPC]();
   for (int i = 0; i < n_wp; ++i)
     if (nseg[i] <= 1) cor_forced(pg, segs, nseg, i, safety_margin, wpc + (size_t)i * COR_WPC);
@@ -141,6 +156,7 @@ extern "C" int emu_advance(int N, double L, double Ts, int status, const double*
 
 // host run of the speed-profile code that mpmpc_speed_profile_kernel executes per thread
 #include "speed_core.hpp"
+#include <cstring>
 #include <vector>
 extern "C" int emu_speed_profile(int n, const double* li, const double* kappa, const double* lim5, double eps,
                                  double* v, int* iters) {
