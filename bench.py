@@ -8,8 +8,13 @@ BASELINE.json (B=1024 independent initial poses, reference tracking, horizon 30)
 every rank solves its own batch of the same size (weak scaling, no data-path collective; the
 instances are independent) and `value` is the whole-job rate.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4] [--batch B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5] [--batch B]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` with N > 1 and no launcher environment (RANK / WORLD_SIZE unset) starts the N ranks itself: this
+process, which has not touched a GPU yet, runs `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+as a CHILD and exits with its code.  Under a launcher, WORLD_SIZE must equal --gpus or the run stops.
+`--config 5` is BASELINE config 5: 8 192 instances per rank (65 536 over 8 GPUs), config-4 distribution.
 """
 from __future__ import annotations
 
@@ -22,11 +27,12 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path[:0] = [os.path.join(ROOT, "multi-purpose-mpc_amd")]
+sys.path[:0] = [os.path.join(ROOT, "multi-purpose-mpc_amd"), ROOT]
 
 import mpmpc  # noqa: E402
 import scenarios  # noqa: E402
 import sharding  # noqa: E402
+import bench_dist  # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
 FP64_VALU_PEAK = 78.6e12   # FLOP/s vector FP64 (spec)
@@ -130,24 +136,45 @@ def main():
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--lanes", type=int, default=0, help="force 64 / 32 / 16 lanes per instance (tuning; 0 = automatic)")
     ap.add_argument("--early-polish", type=int, default=None, help="override the early_polish solver setting")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="override any solver setting of the device path (exploration; the oracle keeps its defaults)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        # Start the ranks as children of this process, which has made no GPU call (never re-exec a process that has).
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        rc = subprocess.run(cmd).returncode
+        if rc != 0:
+            sys.stderr.write("bench.py: the %d-rank run failed (exit code %d)\n" % (args.gpus, rc))
+        sys.exit(rc)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     dist = None
-    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):   # launched by torch.distributed.run
+    if launched:   # launched by torch.distributed.run (also with one rank)
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            sys.exit("bench.py: process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
 
     tr = scenarios.sim_track()
     spec = scenarios.CONFIGS[args.config]
-    B = args.batch or spec["B"]
+    B = args.batch or spec.get("B_per_gpu", spec["B"])     # per rank (weak scaling)
     # every rank gets its own slice of a world*B batch drawn from the config's seed
     sc_all = scenarios.make(args.config, tr, B=B * world)
     wp, x0, cc, lb, ub = sharding.shard([sc_all.wp_id, sc_all.x0, sc_all.cc_prev, sc_all.lb, sc_all.ub], world, rank)
@@ -162,6 +189,7 @@ def main():
     settings = mpmpc.default_settings(**overrides)
     h = mpmpc.Handle(cfg, settings)
     h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+    h.set_packing(args.lanes)
     h.upload(wp, x0, cc, lb, ub)          # inputs resident in HBM before the timed region
 
     def barrier():
@@ -178,7 +206,10 @@ def main():
     for _ in range(args.steps):
         h.solve_resident(B)
     barrier()
-    dt = sharding.max_over_ranks(dist, time.perf_counter() - t0, device="cuda" if dist is not None else None)
+    dt_mine = time.perf_counter() - t0
+    dev = "cuda" if dist is not None else None
+    dt = bench_dist.max_over_ranks(dist, dt_mine, device=dev)
+    dt_ranks = bench_dist.all_ranks(dist, dt_mine, device=dev)
 
     # per-kernel durations, HIP events on the library's own stream
     reps = max(5, min(args.steps, 20))
@@ -190,6 +221,25 @@ def main():
     ms_k1, ms_k2 = float(np.mean(ka)), float(np.mean(ks))
     sol = h.download(B, want_y=False)
 
+    # one result buffer, outside the timed region: the shards' controls gathered on every rank (the only data
+    # collective a caller of the sharded path may want), checked on rank 0 against ONE process solving the whole
+    # world*B batch of the same seed on its own GPU
+    gather_check = None
+    if dist is not None and world > 1:
+        u_all, s_all = bench_dist.gather_controls(dist, sol.u0, sol.status, B * world, device=dev)
+        if rank == 0:
+            cfg1 = mpmpc.make_config(N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX,
+                                     scenarios.AY_MAX, scenarios.CAR_LENGTH, circular=True, max_batch=B * world,
+                                     device=local_rank)
+            h1 = mpmpc.Handle(cfg1, settings)
+            h1.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+            one = h1.solve(sc_all.wp_id, sc_all.x0, sc_all.cc_prev, sc_all.lb, sc_all.ub)
+            h1.close()
+            okm = (one.status == 1) & (s_all == 1)
+            gather_check = {"instances": int(B * world), "status_equal": bool(np.array_equal(one.status, s_all)),
+                            "max_abs_u_diff": float(np.max(np.abs(one.u0[okm] - u_all[okm]))) if okm.any() else None,
+                            "note": "all-gathered (u0, status) of the %d shards vs one process solving the whole batch" % world}
+
     if rank == 0:
         value = world * B * args.steps / dt
         out = {
@@ -197,12 +247,16 @@ def main():
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "world_size": int(dist.get_world_size()) if dist is not None else 1,
+            "ms_per_step_by_rank": [1e3 * t / args.steps for t in dt_ranks],
             "config": {"workload": "config%d: batch=%d independent poses per GPU, %s weights, N=%d, %s corridor, "
                                    "OSQP-default ADMM, certified polish tried after %d iterations" %
                                    (args.config, B, sc_all.weights, N, "obstacle" if sc_all.obstacles else "free",
                                     settings.early_polish),
                        "batch_per_gpu": B, "horizon": N, "parallelism": "batch-shard x%d" % world},
         }
+        if gather_check is not None:
+            out["gather_check"] = gather_check
         bytes_k2 = k2_bytes_per_solve(N) * B
         out["roofline"] = {"bound": "hbm", "kernel": "mpmpc_solve_kernel", "achieved": bytes_k2 / (ms_k2 * 1e-3) / 1e9,
                            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bytes_k2 / (ms_k2 * 1e-3) / HBM_PEAK,

@@ -92,6 +92,10 @@ void mpmpc_default_settings(mpmpc_settings* s);
 int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_handle* out);
 int mpmpc_destroy(mpmpc_handle h);
 int mpmpc_set_settings(mpmpc_handle h, const mpmpc_settings* settings);
+/* Lanes of a 64-lane wavefront given to one QP instance by the solve launches: 0 (default) = chosen from the batch
+ * size (one instance per wave up to 1024 instances, then the smallest of 64 / 32 / 16 that holds the N + 1 stages);
+ * 64 / 32 / 16 force that packing (parity tests and tuning; every packing returns the same answers). */
+int mpmpc_set_packing(mpmpc_handle h, int32_t lanes_per_instance);
 
 /* replaces the per-stage ReferencePath.get_waypoint() / Waypoint.__sub__ reads of
  * src/MPC.py:93-97 (src/reference_path.py:50-57,356-371): per-waypoint kappa, v_ref and the

@@ -378,6 +378,7 @@ struct mpmpc_handle_s {
   size_t stage_in_bytes = 0, stage_out_bytes = 0;
   // instances the early pass of a packed (2 or 4 per wave) launch could not certify: [0] = count, [1..] = ids
   int* tail = nullptr;
+  int force_lanes = 0;      // mpmpc_set_packing: 0 = chosen from the batch size
 };
 
 static int host_stage_ld(int N) { return N + 1 <= 16 ? 16 : (N + 1 <= 32 ? 32 : 64); }
@@ -402,7 +403,10 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop = false);
 
 extern "C" {
 
-const char* mpmpc_version(void) { return "mpmpc 0.1.0 (gfx950, float64)"; }
+#ifndef MPMPC_SRC_HASH
+#define MPMPC_SRC_HASH "unhashed"
+#endif
+const char* mpmpc_version(void) { return "mpmpc 0.2.0 (gfx950, float64, src " MPMPC_SRC_HASH ")"; }
 const char* mpmpc_last_error(void) { return g_err.c_str(); }
 
 int mpmpc_device_count(int32_t* count) {
@@ -550,6 +554,15 @@ int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_
     return fail(MPMPC_E_HIP, std::string("stream/event creation: ") + hipGetErrorString(e));
   }
   *out = h;
+  return MPMPC_OK;
+}
+
+int mpmpc_set_packing(mpmpc_handle h, int32_t lanes_per_instance) {
+  if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  const int g = lanes_per_instance;
+  if (g != 0 && g != 16 && g != 32 && g != 64) return fail(MPMPC_E_ARG, "lanes_per_instance must be 0 (auto), 16, 32 or 64");
+  if (g != 0 && h->cfg.N + 1 > g) return fail(MPMPC_E_ARG, "lanes_per_instance must hold the N + 1 stages of an instance");
+  h->force_lanes = g;
   return MPMPC_OK;
 }
 
@@ -820,10 +833,7 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop) {
   int G = 64;
   if (N + 1 <= 32 && B > 1024) G = 32;
   if (N + 1 <= 16 && B > 2048) G = 16;
-  if (const char* f = std::getenv("MPMPC_LANES_PER_INSTANCE")) {      // tuning aid: force 64 / 32 / 16
-    const int g = std::atoi(f);
-    if ((g == 64 || g == 32 || g == 16) && N + 1 <= g) G = g;
-  }
+  if (h->force_lanes && N + 1 <= h->force_lanes) G = h->force_lanes;      // mpmpc_set_packing
   // closed loop: the previous step's active sets as a first guess.  A launch with one instance per wave ends with
   // its slowest car, and with more than a handful of cars one of them always misses its guess (hit rate 91-93 %
   // per car and step: the miss pays for the attempt AND the normal path, 1024 cars -7 %), so "auto" warm-starts the

@@ -110,6 +110,7 @@ def load_library(path: str | None = None):
     lib.mpmpc_create.argtypes = [C.POINTER(Config), C.POINTER(Settings), C.POINTER(h)]
     lib.mpmpc_destroy.argtypes = [h]
     lib.mpmpc_set_settings.argtypes = [h, C.POINTER(Settings)]
+    lib.mpmpc_set_packing.argtypes = [h, C.c_int32]
     lib.mpmpc_set_path.argtypes = [h, C.c_int32, _dp, _dp, _dp]
     lib.mpmpc_set_corridor.argtypes = [h, C.c_int32, C.c_int32, _dp, _dp]
     lib.mpmpc_set_map.argtypes = [h, C.c_int32, C.c_int32, C.POINTER(C.c_int8), C.c_double, C.c_double, C.c_double]
@@ -135,7 +136,7 @@ def load_library(path: str | None = None):
 
 
 EXPORTS = ["mpmpc_version", "mpmpc_last_error", "mpmpc_device_count", "mpmpc_default_settings",
-           "mpmpc_create", "mpmpc_destroy", "mpmpc_set_settings", "mpmpc_set_path", "mpmpc_set_corridor",
+           "mpmpc_create", "mpmpc_destroy", "mpmpc_set_settings", "mpmpc_set_packing", "mpmpc_set_path", "mpmpc_set_corridor",
            "mpmpc_set_map", "mpmpc_set_path_geometry", "mpmpc_build_corridor", "mpmpc_rollout_init",
            "mpmpc_rollout_step", "mpmpc_rollout_warm_start", "mpmpc_rollout_state", "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident",
            "mpmpc_sync", "mpmpc_download", "mpmpc_solve_resident_timed", "mpmpc_speed_profile"]
@@ -185,6 +186,10 @@ class Handle:
     def set_settings(self, settings: Settings):
         self.settings = settings
         self._check(self.lib.mpmpc_set_settings(self._h, C.byref(settings)))
+
+    def set_packing(self, lanes_per_instance: int = 0):
+        """0 = automatic; 64 / 32 / 16 force that many lanes of a wavefront per instance (tests, tuning)."""
+        self._check(self.lib.mpmpc_set_packing(self._h, int(lanes_per_instance)))
 
     def set_path(self, kappa, v_ref, ds_next):
         k, v, d = (np.ascontiguousarray(a, dtype=np.float64) for a in (kappa, v_ref, ds_next))

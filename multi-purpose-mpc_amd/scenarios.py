@@ -78,7 +78,8 @@ CONFIGS = {
     2: dict(B=1024, N=30, weights="stock", obstacles=False, seed=2),
     3: dict(B=4096, N=50, weights="time_optimal", obstacles=False, seed=3),
     4: dict(B=8192, N=30, weights="stock", obstacles=True, seed=4),
-    5: dict(B=65536, N=30, weights="stock", obstacles=True, seed=5),
+    # config 5: 65 536 instances over 8 GPUs = contiguous shards of 8 192 per GPU
+    5: dict(B=65536, B_per_gpu=8192, N=30, weights="stock", obstacles=True, seed=5),
 }
 
 

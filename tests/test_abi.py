@@ -45,6 +45,13 @@ def test_struct_layouts_match_header(lib):
     assert b"gfx950" in lib.mpmpc_version()
 
 
+def test_loaded_library_was_built_from_this_tree(lib):
+    """The binary that ships to the GPU box must be the tree's: its version string carries the hash of the sources
+    it was compiled from (a stale .so had been passing for the committed code)."""
+    import __graft_entry__ as g
+    assert g.source_hash().encode() in lib.mpmpc_version(), lib.mpmpc_version()
+
+
 def test_argument_validation_without_device(lib):
     """Errors that are detected before any device call are reported through the ABI's error channel."""
     h = C.c_void_p()

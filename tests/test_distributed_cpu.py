@@ -12,6 +12,9 @@ import mpmpc_testlib as T
 import scenarios
 import sharding
 
+sys.path.insert(0, T.ROOT)
+import bench_dist  # noqa: E402
+
 
 def test_shard_bounds_cover_batch():
     for total in (1, 7, 1024, 65536 + 3):
@@ -37,8 +40,8 @@ def _worker(rank, world, port, total, N, out_dir):
     backend = T.EmuBackend(cfg, mpmpc.default_settings())
     backend.set_path(tr.kappa, tr.v_ref, tr.ds_next)
     sol = backend.solve(wp, x0, cc, lb, ub)
-    dt = sharding.max_over_ranks(dist, 0.25 * (rank + 1))
-    u_all, s_all = sharding.gather_controls(dist, sol.u0, sol.status, total)
+    dt = bench_dist.max_over_ranks(dist, 0.25 * (rank + 1))
+    u_all, s_all = bench_dist.gather_controls(dist, sol.u0, sol.status, total)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), u=u_all, s=s_all, dt=dt, n_local=wp.size)
     dist.barrier()
     dist.destroy_process_group()
@@ -62,3 +65,31 @@ def test_two_ranks_gloo_match_single_process(tmp_path):
         ok = full.status > 0
         assert np.array_equal(g["u"][ok], full.u0[ok])
         assert float(g["dt"]) == 0.5      # MAX over ranks of (0.25, 0.5)
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(T.ROOT, "bench.py")] + args, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+@pytest.mark.skipif(mpmpc.device_count() > 0, reason="checks the behaviour of a box without GPUs")
+def test_bench_gpus_flag_cannot_lie_without_gpus():
+    """`bench.py --gpus 2` starts two ranks itself; on a box without GPUs they fail, and so does the command -
+    it can no longer print an n_gpus:1 line when asked for more."""
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu"])
+    assert r.returncode != 0
+    assert '"n_gpus"' not in r.stdout
+    assert "2-rank run failed" in r.stderr
+
+
+def test_bench_rejects_a_world_size_that_differs_from_gpus():
+    r = _run_bench(["--gpus", "4", "--steps", "1", "--warmup", "0", "--no-cpu"],
+                   {"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
+    assert r.returncode != 0
+    assert "WORLD_SIZE=2" in (r.stderr + r.stdout)
+    assert '"n_gpus"' not in r.stdout

@@ -391,16 +391,16 @@ def test_baseline_batch_sizes_carry_kkt_certificates(cfgid, B, track):
 
 
 @pytest.mark.parametrize("cfgid,N", [(2, 10), (4, 10), (4, 3), (2, 15)])
-def test_every_lane_packing_gives_the_same_answers(cfgid, N, track, monkeypatch):
+def test_every_lane_packing_gives_the_same_answers(cfgid, N, track):
     """64, 32 and 16 lanes per instance (1, 2, 4 instances per wavefront; the launcher picks by batch
-    size, MPMPC_LANES_PER_INSTANCE forces one): same statuses, same iteration counts, same controls."""
+    size, mpmpc_set_packing forces one): same statuses, same iteration counts, same controls."""
     sc = scenarios.make(cfgid, track, B=203, N=N)
     h = _handle(track, sc.N, sc.weights, sc.B)
     sols = {}
     for g in (64, 32, 16):
-        monkeypatch.setenv("MPMPC_LANES_PER_INSTANCE", str(g))
+        h.set_packing(g)
         sols[g] = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
-    monkeypatch.delenv("MPMPC_LANES_PER_INSTANCE")
+    h.set_packing(0)
     for g in (32, 16):
         assert np.array_equal(sols[g].status, sols[64].status) and np.array_equal(sols[g].iters[:, 0], sols[64].iters[:, 0])
         ok = sols[64].status == 1
@@ -408,7 +408,7 @@ def test_every_lane_packing_gives_the_same_answers(cfgid, N, track, monkeypatch)
     h.close()
 
 
-def test_non_finite_inputs_get_no_verdict_on_device(track, monkeypatch):
+def test_non_finite_inputs_get_no_verdict_on_device(track):
     """NaN / Inf poses: status UNSOLVED (-10), never a solved plan, never a hang; the other instances of
     the batch (and of the same wavefront, with 32 lanes per instance) are untouched."""
     sc = scenarios.make(2, track, B=6)
@@ -417,7 +417,7 @@ def test_non_finite_inputs_get_no_verdict_on_device(track, monkeypatch):
     x0[1, 0], x0[2, 1] = np.nan, np.inf
     clean = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
     for g in (64, 32):
-        monkeypatch.setenv("MPMPC_LANES_PER_INSTANCE", str(g))
+        h.set_packing(g)
         sol = h.solve(sc.wp_id, x0, sc.cc_prev, sc.lb, sc.ub)
         assert list(sol.status[[1, 2]]) == [mpmpc.UNSOLVED, mpmpc.UNSOLVED]
         for i in (0, 3, 4, 5):
