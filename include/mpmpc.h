@@ -81,6 +81,16 @@ typedef struct {
   int32_t early_scaling; /* Ruiz passes done before the early polish attempt (0 or >= scaling: all of them).  The
                             remaining scaling - early_scaling passes are done before the full ADMM run, which
                             therefore sees exactly OSQP's `scaling` passes. */
+  int32_t phase1;        /* 1: an instance the early polish attempt cannot certify is first tested for infeasibility -
+                            least-squares phase 1 (every inequality row softened, nothing else in the cost) by the same
+                            interior-point code; its multipliers are a Farkas ray, checked with OSQP's own
+                            primal-infeasibility criterion (eps_prim_inf) -> MPMPC_PRIMAL_INFEASIBLE after ~5-10
+                            interior-point iterations instead of hundreds or thousands of ADMM iterations; z then holds
+                            the least-violation point, y the ray, resid[0] the largest bound violation of z.  What it
+                            cannot decide runs the full ADMM as before.  0: OSQP's ADMM decides infeasibility. */
+  double ipm_diverged;   /* the interior point gives up when mu exceeds this multiple of its smallest value so far
+                            (multipliers blowing up: infeasible, phase 1 decides) */
+  double phase1_theta;   /* start value of phase 1's slacks and multipliers (row space) */
 } mpmpc_settings;
 
 const char* mpmpc_version(void);
@@ -135,10 +145,16 @@ int mpmpc_build_corridor(mpmpc_handle h, int32_t n_cols, double min_width, doubl
  *   init:  Ts = model.Ts; cum_lengths[n_wp] = cumsum(ReferencePath.segment_lengths); s[B] arc lengths;
  *          pose[B*3] = (x, y, psi); cc0[B*2N] previous plans or NULL for zeros (MPC.__init__).
  *   state: any output may be NULL.  alive: 1 running, 0 lap finished (s >= length), -1 ended by the
- *          reference's exit(1) after N-1 consecutive infeasible steps. */
+ *          reference's exit(1) after N-1 consecutive infeasible steps.
+ * The rollout keeps its plans, waypoint ids and states in the handle's batch blocks: mpmpc_upload / mpmpc_solve /
+ * mpmpc_assemble on the SAME handle overwrite them, after which mpmpc_rollout_step / _state / _set_counters return
+ * MPMPC_E_STATE until mpmpc_rollout_init is called again.  (mpmpc_download and mpmpc_build_corridor are fine.) */
 int mpmpc_rollout_init(mpmpc_handle h, int32_t B, double Ts, const double* cum_lengths, const double* s,
                        const double* pose, const double* cc0);
 int mpmpc_rollout_step(mpmpc_handle h, int32_t B, int32_t n_steps);
+/* MPC.infeasibility_counter of every car (src/MPC.py:206,215), to resume a recorded run: values in [0, N-2].
+ * mpmpc_rollout_init starts every car at 0. */
+int mpmpc_rollout_set_counters(mpmpc_handle h, int32_t B, const int32_t* counter);
 /* Warm start of the closed loop: each step first tries active-set rounds from the active set the previous step
  * certified for the same car, shifted by the waypoints it advanced; what they cannot certify goes through the
  * normal path.  enable: 0 off, 1 on, 2 (default) on where it pays - fleets of more than 1024 cars (several cars per

@@ -150,7 +150,7 @@ struct LaneEmu {
 
   // "cold" per-lane storage (LDS on the GPU) for values that are only needed at termination checks
   // and in the certificate, so that they do not occupy registers inside the iteration loops
-  static constexpr int cold_slots = 56;
+  static constexpr int cold_slots = 66;
   static VD* cold() { static VD buf[cold_slots]; return buf; }
   static void cold_put(int slot, const VD& a) { cold()[slot] = a; }
   static VD cold_get(int slot) { return cold()[slot]; }

@@ -288,7 +288,7 @@ struct Solver {
   // field f of this lane's stage, straight from the stage-blocked QP; bounds clipped like OSQP does
   // (the unscaled offsets and bounds are needed again after the Ruiz passes and in the certificate: they wait in
   //  cold storage, slots COLD_RAW .., so that no field is ever re-read from memory)
-  static constexpr int COLD_RAW = 42;
+  static constexpr int COLD_RAW = 42, COLD_COST = 56;
   MPMPC_HD R beq_raw(int i) const { return L::cold_get(COLD_RAW + i); }
   MPMPC_HD R lo_raw(int j) const { return L::cold_get(COLD_RAW + 3 + j); }
   MPMPC_HD R hi_raw(int j) const { return L::cold_get(COLD_RAW + 8 + j); }
@@ -1003,7 +1003,15 @@ struct Solver {
   };
   using Ipm = IpmT<false>;
   // pp, qq, vm: cost diagonal, cost vector and validity masks of the lane's entries in the layout S
-  template <bool S>
+  //
+  // SOFT = true is PHASE 1 (see phase1()): every box entry j with a finite side reads  lo <= x_j + w_j <= hi  with
+  // the cost 1/2 w_j^2 and nothing else in the cost (pp, qq are not read).  Stationarity in w gives w = zl - zu, so w
+  // is never stored: it shifts the slack residuals, and eliminating its Newton step  dw = k ((cu - cl) - th dx),
+  // k = 1 / (1 + th),  th = zl / sl + zu / su,  leaves the hard problem's reduced system with  k th = 1 - k  in place
+  // of th on the diagonal and  k (cu - cl)  in place of  cu - cl  on the right-hand side.  Pinned entries stay hard.
+  // The loop also ends for an instance as soon as its multipliers pass the Farkas test in the scaled problem
+  // (|A'y| <= eps |y|, support <= -eps |y|): what is asked of phase 1 is a ray, not a converged point.
+  template <bool S, bool SOFT = false>
   MPMPC_HD Mk ipm(const BoxT<S>& bx, IpmT<S>& s, const R* pp, const R* qq, const Mk* vm, const SolverParams& st,
                   double tol, const Mk& run) {
     constexpr int E = EN<S>;
@@ -1014,11 +1022,13 @@ struct Solver {
     for (int j = 0; j < E; ++j) cnt = cnt + sel(bx.Lm[j], one, zero) + sel(bx.Um[j], one, zero);
     R nb = max_(L::gsum(cnt), one);
     I stall(0);
+    R mu_min(1e300);
     for (int it = 0; it <= st.ipm_max_iter; ++it) {
       // ---- residuals (the slack residuals rl, ru, rpin are cheap functions of the iterate: they are
       //      re-evaluated where needed instead of being carried across the sweeps)
-      auto rl_of = [&](int j) { return sel(bx.Lm[j], s.x[j] - bx.lo[j] - s.sl[j], zero); };
-      auto ru_of = [&](int j) { return sel(bx.Um[j], bx.hi[j] - s.x[j] - s.su[j], zero); };
+      auto w_of = [&](int j) { return SOFT ? s.zl[j] - s.zu[j] : zero; };
+      auto rl_of = [&](int j) { return sel(bx.Lm[j], s.x[j] + w_of(j) - bx.lo[j] - s.sl[j], zero); };
+      auto ru_of = [&](int j) { return sel(bx.Um[j], bx.hi[j] - s.x[j] - w_of(j) - s.su[j], zero); };
       auto rpin_of = [&](int j) { return sel(bx.pin[j], s.x[j] - bx.lo[j], zero); };
       MPMPC_TICK_BEGIN(10);
       R At[E], rp[3], rd[E];
@@ -1029,17 +1039,44 @@ struct Solver {
       for (int i = 0; i < 3; ++i) { rp[i] = rp[i] - leq[i]; res = max_(res, sel(vx, abs_(rp[i]), zero)); }
       MPMPC_UNROLL
       for (int j = 0; j < E; ++j) {
-        rd[j] = fma_(pp[j], s.x[j], qq[j]) + At[j] - s.zl[j] + s.zu[j] + s.pi[j];
+        if constexpr (SOFT) rd[j] = At[j] - s.zl[j] + s.zu[j] + s.pi[j];
+        else rd[j] = fma_(pp[j], s.x[j], qq[j]) + At[j] - s.zl[j] + s.zu[j] + s.pi[j];
         res = max_(res, sel(vm[j], max_(max_(abs_(rd[j]), abs_(rpin_of(j))), max_(abs_(rl_of(j)), abs_(ru_of(j)))), zero));
         msum = msum + sel(bx.Lm[j], s.sl[j] * s.zl[j], zero) + sel(bx.Um[j], s.su[j] * s.zu[j], zero);
       }
       res = L::gmax(res);
       R mu = L::gsum(msum) / nb;
       Mk ok = (res < R(tol)) & (mu < R(tol));
+      if constexpr (SOFT) {
+        // Farkas test on the multipliers y = (nu, zu - zl + pi) in the scaled problem: A'y is the dual residual rd itself
+        R ny(0.0), na(0.0), sup(0.0);
+        MPMPC_UNROLL
+        for (int i = 0; i < 3; ++i) { ny = max_(ny, sel(vx, abs_(s.nu[i]), zero)); sup = sup + sel(vx, leq[i] * s.nu[i], zero); }
+        MPMPC_UNROLL
+        for (int j = 0; j < E; ++j) {
+          R lam = s.zu[j] - s.zl[j] + s.pi[j];
+          ny = max_(ny, sel(vm[j], abs_(lam), zero));
+          na = max_(na, sel(vm[j], abs_(rd[j]), zero));
+          // hi max(lam, 0) + lo min(lam, 0); an infinite side carries no multiplier (zl / zu are zero there)
+          sup = sup + sel(vm[j] & (lam > zero) & (bx.Um[j] | bx.pin[j]), sel(bx.pin[j], bx.lo[j], bx.hi[j]) * lam, zero) +
+                sel(vm[j] & (lam < zero) & (bx.Lm[j] | bx.pin[j]), bx.lo[j] * lam, zero);
+        }
+        ny = L::gmax(ny); na = L::gmax(na); sup = L::gsum(sup);
+        const R thr = R(st.eps_prim_inf) * ny;
+        ok = ok | ((ny > R(st.eps_prim_inf)) & (na < thr) & (sup < -thr));
+      }
       conv = conv | (active & ok);
       active = active & !ok;
       MPMPC_TICK_END(10);
       if (it == st.ipm_max_iter || !L::wany(active)) break;
+      if constexpr (!SOFT) {
+        // the complementarity measure of a feasible problem falls (nearly) monotonically; on an infeasible one the
+        // multipliers blow up within a few iterations (mu jumps by 4-5 orders of magnitude): give up at once, phase 1
+        // is what can decide such an instance
+        active = active & !(mu > R(st.ipm_diverged) * mu_min);
+        mu_min = min_(mu_min, mu);
+        if (!L::wany(active)) break;
+      }
       MPMPC_TICK_COUNT(16);
       MPMPC_TICK_BEGIN(11);
       ipm_iters = seli(active, ipm_iters + I(1), ipm_iters);
@@ -1047,9 +1084,15 @@ struct Solver {
       R isl[E], isu[E], h[E];
       MPMPC_UNROLL
       for (int j = 0; j < E; ++j) { isl[j] = rcp_(s.sl[j]); isu[j] = rcp_(s.su[j]); }
+      [[maybe_unused]] R kap[E];        // phase 1: k = 1 / (1 + th) of the soft entries, th = zl / sl + zu / su
       auto H_of = [&](int j) {
-        return pp[j] + reg + sel(bx.Lm[j], s.zl[j] * isl[j], zero) + sel(bx.Um[j], s.zu[j] * isu[j], zero) +
-               sel(bx.pin[j], ireg, zero);
+        if constexpr (SOFT) {
+          kap[j] = rcp_(one + sel(bx.Lm[j], s.zl[j] * isl[j], zero) + sel(bx.Um[j], s.zu[j] * isu[j], zero));
+          return (reg + one) - kap[j] + sel(bx.pin[j], ireg, zero);          // k th = 1 - k
+        } else {
+          return pp[j] + reg + sel(bx.Lm[j], s.zl[j] * isl[j], zero) + sel(bx.Um[j], s.zu[j] * isu[j], zero) +
+                 sel(bx.pin[j], ireg, zero);
+        }
       };
       MPMPC_UNROLL
       for (int j = 0; j < E; ++j) h[j] = rcp_(H_of(j));
@@ -1065,10 +1108,18 @@ struct Solver {
       R alpha_aff(1.0);
       for (int pass = 0; pass < 2; ++pass) {
         R rhs[E], nreq[3];
+        [[maybe_unused]] R cul[E];          // phase 1: cu - cl of the entry
         MPMPC_UNROLL
-        for (int j = 0; j < E; ++j)
-          rhs[j] = -rd[j] - sel(bx.Lm[j], fma_(s.zl[j], rl_of(j), rcl[j]) * isl[j], zero) +
-                   sel(bx.Um[j], fma_(s.zu[j], ru_of(j), rcu[j]) * isu[j], zero) - sel(bx.pin[j], rpin_of(j) * ireg, zero);
+        for (int j = 0; j < E; ++j) {
+          if constexpr (SOFT) {
+            cul[j] = sel(bx.Um[j], fma_(s.zu[j], ru_of(j), rcu[j]) * isu[j], zero) -
+                     sel(bx.Lm[j], fma_(s.zl[j], rl_of(j), rcl[j]) * isl[j], zero);
+            rhs[j] = fma_(kap[j], cul[j], -rd[j]) - sel(bx.pin[j], rpin_of(j) * ireg, zero);
+          } else {
+            rhs[j] = -rd[j] - sel(bx.Lm[j], fma_(s.zl[j], rl_of(j), rcl[j]) * isl[j], zero) +
+                     sel(bx.Um[j], fma_(s.zu[j], ru_of(j), rcu[j]) * isu[j], zero) - sel(bx.pin[j], rpin_of(j) * ireg, zero);
+          }
+        }
         MPMPC_UNROLL
         for (int i = 0; i < 3; ++i) nreq[i] = -rp[i];
         MPMPC_TICK_BEGIN(12);
@@ -1078,8 +1129,10 @@ struct Solver {
         R blk(0.0);
         MPMPC_UNROLL
         for (int j = 0; j < E; ++j) {
-          dsl[j] = sel(bx.Lm[j], dx[j] + rl_of(j), zero);
-          dsu[j] = sel(bx.Um[j], -dx[j] + ru_of(j), zero);
+          R ex = dx[j];                     // step of x + w:  dx + k ((cu - cl) - th dx) = k (dx + cu - cl)
+          if constexpr (SOFT) ex = kap[j] * (dx[j] + cul[j]);
+          dsl[j] = sel(bx.Lm[j], ex + rl_of(j), zero);
+          dsu[j] = sel(bx.Um[j], -ex + ru_of(j), zero);
           dzl[j] = sel(bx.Lm[j], -fma_(s.zl[j], dsl[j], rcl[j]) * isl[j], zero);
           dzu[j] = sel(bx.Um[j], -fma_(s.zu[j], dsu[j], rcu[j]) * isu[j], zero);
           dpi[j] = sel(bx.pin[j], (rpin_of(j) + dx[j]) * ireg, zero);
@@ -1455,6 +1508,115 @@ struct Solver {
     polished = seli(failed, I(-1), polished);
   }
 
+  // ======================================================================== phase 1
+  // Is the instance infeasible?  (st.phase1; runs on what the early polish attempt could not certify, before any full
+  // ADMM run.)   min 1/2 |w|^2  s.t.  the dynamics rows and pinned entries as they are,  lo <= x_j + w_j <= hi  on every
+  // other entry with a finite side.  Always feasible; optimum 0 iff the QP is feasible; and at its optimum the
+  // multipliers y = (nu, zu - zl) satisfy A'y = 0 and  u'max(y,0) + l'min(y,0) = -|w|^2:  a Farkas ray.  The ray is
+  // then put to OSQP's own test (primal_infeasible: unscaled norms, eps_prim_inf) - a solver-independent verdict,
+  // reached in 5-10 interior-point iterations instead of the hundreds or thousands of ADMM iterations OSQP needs.
+  // Certified instances: status PRIMAL_INFEASIBLE, x = least-violation point, (yeq, yb) = the ray, pri_res = largest
+  // bound violation of x (unscaled).  Everything else is left untouched (status stays UNSOLVED).
+  MPMPC_HD void phase1(const SolverParams& st, const Mk& run) {
+    if (!L::wany(run)) return;
+    Box bx;
+    make_box(bx);
+    const R zero(0.0), one(1.0), theta(st.phase1_theta);
+    // cold start in row space (x = 0, slacks max(distance to the bound, theta), multipliers theta), expressed in the
+    // variable space the iteration works in: s_var = s_row / g, z_var = g z_row
+    Ipm s;
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) s.nu[i] = zero;
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      const R ig = one / g[j];
+      s.x[j] = zero;
+      s.sl[j] = sel(bx.Lm[j], max_(-lb[j], theta) * ig, one);
+      s.su[j] = sel(bx.Um[j], max_(ub[j], theta) * ig, one);
+      s.zl[j] = sel(bx.Lm[j], theta * g[j], zero);
+      s.zu[j] = sel(bx.Um[j], theta * g[j], zero);
+      s.pi[j] = zero;
+    }
+    constexpr bool S = kSplit;
+    constexpr int E = EN<S>;
+    BoxT<S> bi;
+    IpmT<S> si;
+    R pp[E], qq[E];
+    Mk vm[E];
+    if constexpr (S) {
+      MPMPC_UNROLL
+      for (int i = 0; i < 2; ++i) bU[i] = sel(sU, L::from_lower(b[i]), zero);
+      to3(bx.lo, bi.lo); to3(bx.hi, bi.hi);
+      to3(s.x, si.x); to3(s.sl, si.sl); to3(s.su, si.su); to3(s.zl, si.zl); to3(s.zu, si.zu); to3(s.pi, si.pi);
+      R mL[5], mU[5], mP[5], m3[3];
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) { mL[j] = sel(bx.Lm[j], one, zero); mU[j] = sel(bx.Um[j], one, zero); mP[j] = sel(bx.pin[j], one, zero); }
+      to3(mL, m3);
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) bi.Lm[e] = m3[e] > R(0.5);
+      to3(mU, m3);
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) bi.Um[e] = m3[e] > R(0.5);
+      to3(mP, m3);
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) { bi.pin[e] = m3[e] > R(0.5); vm[e] = val3[e]; pp[e] = qq[e] = zero; }
+      si.sl[2] = sel(sU, one, si.sl[2]); si.su[2] = sel(sU, one, si.su[2]);
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) si.nu[i] = s.nu[i];
+    } else {
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) {
+        bi.lo[j] = bx.lo[j]; bi.hi[j] = bx.hi[j]; bi.Lm[j] = bx.Lm[j]; bi.Um[j] = bx.Um[j]; bi.pin[j] = bx.pin[j];
+        si.x[j] = s.x[j]; si.sl[j] = s.sl[j]; si.su[j] = s.su[j]; si.zl[j] = s.zl[j]; si.zu[j] = s.zu[j]; si.pi[j] = s.pi[j];
+        pp[j] = qq[j] = zero; vm[j] = valid[j];
+      }
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) si.nu[i] = s.nu[i];
+    }
+    stash();
+    // phase 1 has no use for the cost: it waits in cold storage as well (slots COLD_COST ..)
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) { L::cold_put(COLD_COST + j, p[j]); L::cold_put(COLD_COST + 5 + j, q[j]); }
+    L::fence();
+    MPMPC_TICK_BEGIN(9);
+    ipm<S, true>(bi, si, pp, qq, vm, st, st.ipm_tol, run);
+    MPMPC_TICK_END(9);
+    L::fence();
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) { p[j] = L::cold_get(COLD_COST + j); q[j] = L::cold_get(COLD_COST + 5 + j); }
+    // back to five entries per lane: point and ray (lam = zu - zl + pi in variable space, yb = lam / g in row space)
+    R xs[5], lam[5], nus[3];
+    if constexpr (S) {
+      R l3[3];
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) l3[e] = si.zu[e] - si.zl[e] + si.pi[e];
+      from3(l3, lam);
+      from3(si.x, xs);
+    } else {
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) { lam[j] = si.zu[j] - si.zl[j] + si.pi[j]; xs[j] = si.x[j]; }
+    }
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) nus[i] = si.nu[i];
+    unstash();
+    // OSQP's test reads its ray from the cold slots of the last dual step
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) L::cold_put(COLD_DYB + j, sel(valid[j], lam[j] / g[j], zero));
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) L::cold_put(COLD_DYEQ + i, sel(vx, nus[i], zero));
+    L::fence();
+    Mk cert = run & primal_infeasible(st.eps_prim_inf);
+    R prim, stat;
+    certificate(xs, nus, lam, st.cert_tol, prim, stat);
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) { x[j] = sel(cert, xs[j], x[j]); yb[j] = sel(cert, lam[j] / g[j], yb[j]); }
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) yeq[i] = sel(cert, nus[i], yeq[i]);
+    pri_res = sel(cert, prim, pri_res);
+    dua_res = sel(cert, zero, dua_res);
+    status = seli(cert, I(MPMPC_PRIMAL_INFEASIBLE), status);
+  }
+
   // ======================================================================== output
   // z in the reference's ordering, u0 = (v_0, delta_0), multipliers in the reference's row order
   MPMPC_HD void store(const I& inst, const I& k, double wheelbase, double* z, double* u0, int* st_out,
@@ -1496,20 +1658,25 @@ struct Solver {
   // 2: full run only (the second launch of a packed batch, see mpmpc_solve_kernel)
   // guess: shifted active set of the previous closed-loop step (bit 30 set where there is one), or 0
   // (WARM is a template flag so that the batch kernels do not carry the warm-start code at all)
-  template <bool WARM = false>
+  // base_ipm: interior-point iterations the instance already spent in an earlier launch (mode 2)
+  // P1: carry the phase-1 code (the packed kernels do not: their launches hand what they cannot certify to a
+  //     one-instance-per-wave launch, mode 2, and that is where phase 1 runs)
+  template <bool WARM = false, bool P1 = true>
   MPMPC_HD void run(const R* fields, int B, const I& inst, const I& k, int N_, const SolverParams& st,
-                    int mode = 0, const I& guess = I(0)) {
+                    int mode = 0, const I& guess = I(0), const I& base_ipm = I(0)) {
     MPMPC_TICK_BEGIN(0);
     load(fields, B, inst, k, N_);
     MPMPC_TICK_END(0);
     // The polish does not need a converged ADMM point, only a reasonable one: with early_polish > 0
     // it is first tried after that many iterations, on a problem that has seen early_scaling of the
-    // Ruiz passes.  Whatever it cannot certify (infeasible or very hard instances) gets the remaining
-    // passes and goes through the full OSQP iteration from a cold start, exactly as without the
-    // shortcut, and is polished again.  One loop, so admm() / polish() are instantiated once.
-    bool early = mode != 2 && st.polish && st.early_polish > 0 && st.early_polish < st.max_iter;
+    // Ruiz passes (stage 0).  What it cannot certify is first asked whether it is feasible at all (phase 1, on the
+    // same scaling) and then gets the remaining passes and goes through the full OSQP iteration from a cold start,
+    // exactly as without the shortcut, and is polished again (stage 1).  One loop, so admm() / polish() are
+    // instantiated once.
+    const bool two_stage = st.polish && st.early_polish > 0 && st.early_polish < st.max_iter;
+    bool early = two_stage && mode != 2;
     int limit = early ? st.early_polish : st.max_iter;
-    int passes = early && st.early_scaling > 0 && st.early_scaling < st.scaling ? st.early_scaling : st.scaling;
+    int passes = two_stage && st.early_scaling > 0 && st.early_scaling < st.scaling ? st.early_scaling : st.scaling;
     Mk which = live;
     act_bits = I(0);
     Mk warm = L::mfalse();
@@ -1531,14 +1698,34 @@ struct Solver {
         which = live & (status == MPMPC_UNSOLVED);
         if (!L::wany(which)) break;
       }
-      MPMPC_TICK_BEGIN(2);
-      admm(st, which, limit);
-      MPMPC_TICK_END(2);
-      MPMPC_TICK_BEGIN(3);
-      if (st.polish) polish(st, early);
-      MPMPC_TICK_END(3);
-      which = live & (status == MPMPC_UNSOLVED);
-      if (!early || mode == 1 || !L::wany(which)) break;
+      if (pass == 0 && mode == 2 && two_stage) {
+        // second launch of a packed batch: the early attempt was made (and failed) in the first one
+        status = I(MPMPC_UNSOLVED); iters = I(0); ipm_iters = base_ipm; polished = I(0);
+        pri_res = R(0.0); dua_res = R(0.0);
+        MPMPC_UNROLL
+        for (int j = 0; j < 5; ++j) { x[j] = R(0.0); yb[j] = R(0.0); }
+        MPMPC_UNROLL
+        for (int i = 0; i < 3; ++i) yeq[i] = R(0.0);
+      } else {
+        MPMPC_TICK_BEGIN(2);
+        admm(st, which, limit);
+        MPMPC_TICK_END(2);
+        MPMPC_TICK_BEGIN(3);
+        if (st.polish) polish(st, early);
+        MPMPC_TICK_END(3);
+        which = live & (status == MPMPC_UNSOLVED);
+        if (!early || mode == 1 || !L::wany(which)) break;
+      }
+      // end of the early stage: is what it could not certify feasible at all?  (still on the early scaling)
+      if constexpr (P1) {
+        if (st.phase1) {
+          phase1(st, which);
+          // (what phase 1 certifies keeps the ADMM iteration count of the early attempt it followed)
+          iters = seli(which & (status == MPMPC_PRIMAL_INFEASIBLE), I(st.early_polish), iters);
+          which = live & (status == MPMPC_UNSOLVED);
+          if (!L::wany(which)) break;
+        }
+      }
       early = false;
       limit = st.max_iter;
     }

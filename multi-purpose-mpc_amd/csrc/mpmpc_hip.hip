@@ -107,7 +107,9 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
   double fields[MPMPC_NUM_FIELDS];
   assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
   Solver<L> s;
-  s.template run<WARM>(fields, B, inst, k, cfg.N, st, mode, guess);
+  // (second launch of a packed batch: the interior-point iterations the first launch spent on this instance)
+  const int base_ipm = (mode == 2 && iters) ? iters[inst * 2 + 1] : 0;
+  s.template run<WARM, (G == 64)>(fields, B, inst, k, cfg.N, st, mode, guess, base_ipm);
   MPMPC_TICK_BEGIN(7);
   s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y, WARM ? act : nullptr, ld);
   MPMPC_TICK_END(7);
@@ -359,6 +361,7 @@ struct mpmpc_handle_s {
   int ro_warm = 2;      // 0 off, 1 on, 2 where it pays (see launch_solve)
   double ro_Ts = 0;
   int ro_B = 0;
+  bool ro_valid = false;      // the batch blocks still hold the rollout's plans / waypoint ids / states
   // per-batch inputs
   int* wp_id = nullptr;
   double *x0 = nullptr, *cc = nullptr, *lb = nullptr, *ub = nullptr;
@@ -395,6 +398,8 @@ static int check_settings(const mpmpc_settings* s) {
   if (s->polish != 0 && s->polish != 2) return fail(MPMPC_E_ARG, "polish must be 0 or 2");
   if (s->polish == 2 && (!(s->ipm_reg > 0) || !(s->as_delta > 0) || !(s->ipm_tol > 0)))
     return fail(MPMPC_E_ARG, "polish needs ipm_reg, ipm_tol, as_delta > 0");
+  if (s->phase1 != 0 && s->phase1 != 1) return fail(MPMPC_E_ARG, "phase1 must be 0 or 1");
+  if (!(s->ipm_diverged > 1) || !(s->phase1_theta > 0)) return fail(MPMPC_E_ARG, "need ipm_diverged > 1, phase1_theta > 0");
   return MPMPC_OK;
 }
 
@@ -431,6 +436,9 @@ void mpmpc_default_settings(mpmpc_settings* s) {
   s->as_delta = 1e-10; s->as_refine = 5; s->as_rounds = 4; s->cert_tol = 1e-8;
   s->early_polish = 1;
   s->early_scaling = 2;
+  s->phase1 = 1;
+  s->ipm_diverged = 1e3;
+  s->phase1_theta = 1.0;
 }
 
 int32_t mpmpc_stage_ld(int32_t N) { return host_stage_ld(N); }
@@ -713,14 +721,29 @@ int mpmpc_rollout_init(mpmpc_handle h, int32_t B, double Ts, const double* cum_l
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->ro_Ts = Ts;
   h->ro_B = B;
+  h->ro_valid = true;
   h->have_rows = false;       // the corridor comes from the table
   h->uploaded = B;
+  return MPMPC_OK;
+}
+
+int mpmpc_rollout_set_counters(mpmpc_handle h, int32_t B, const int32_t* counter) {
+  if (!h || !counter) return fail(MPMPC_E_ARG, "NULL argument");
+  if (B < 1 || B > h->ro_B || !h->ro_valid) return fail(MPMPC_E_STATE, "call mpmpc_rollout_init for at least B cars first");
+  for (int i = 0; i < B; ++i)
+    if (counter[i] < 0 || counter[i] >= h->cfg.N - 1) return fail(MPMPC_E_ARG, "infeasibility counters must be in [0, N - 2]");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipMemcpyAsync(h->ro_counter, counter, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return MPMPC_OK;
 }
 
 int mpmpc_rollout_step(mpmpc_handle h, int32_t B, int32_t n_steps) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
   if (B < 1 || B > h->ro_B) return fail(MPMPC_E_STATE, "call mpmpc_rollout_init for at least B cars first");
+  if (!h->ro_valid)
+    return fail(MPMPC_E_STATE, "the rollout's state was overwritten by an upload / solve / assemble on this handle: "
+                               "call mpmpc_rollout_init again (or use a second handle for single solves)");
   if (n_steps < 0) return fail(MPMPC_E_ARG, "n_steps must be >= 0");
   HIP_TRY(hipSetDevice(h->cfg.device));
   const int blocks = (B + 255) / 256;
@@ -746,6 +769,9 @@ int mpmpc_rollout_state(mpmpc_handle h, int32_t B, double* s, double* pose, doub
                         double* u_last, int32_t* status, int32_t* counter, int32_t* alive) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
   if (B < 1 || B > h->ro_B) return fail(MPMPC_E_STATE, "call mpmpc_rollout_init for at least B cars first");
+  if (!h->ro_valid)
+    return fail(MPMPC_E_STATE, "the rollout's state was overwritten by an upload / solve / assemble on this handle: "
+                               "call mpmpc_rollout_init again");
   HIP_TRY(hipSetDevice(h->cfg.device));
   const int N = h->cfg.N;
 #define PULL(dst, src, bytes) if (dst) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream))
@@ -777,6 +803,7 @@ int mpmpc_upload(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* 
     if (!h->cfg.circular && wp_id[i] + N >= h->n_wp) return fail(MPMPC_E_ARG, "Reached end of path!");
   }
   HIP_TRY(hipSetDevice(h->cfg.device));
+  h->ro_valid = false;        // the batch blocks are about to be re-laid out and overwritten
   if (B != h->laid_out) lay_out(h, B);
   const BlockLayout L = block_layout(N, B);
   if (h->stage_in) {

@@ -41,7 +41,8 @@ class Settings(C.Structure):
                 ("polish", C.c_int32), ("ipm_max_iter", C.c_int32),
                 ("ipm_tol", C.c_double), ("ipm_reg", C.c_double), ("as_delta", C.c_double),
                 ("as_refine", C.c_int32), ("as_rounds", C.c_int32), ("cert_tol", C.c_double),
-                ("early_polish", C.c_int32), ("early_scaling", C.c_int32)]
+                ("early_polish", C.c_int32), ("early_scaling", C.c_int32), ("phase1", C.c_int32),
+                ("ipm_diverged", C.c_double), ("phase1_theta", C.c_double)]
 
 
 def default_settings(**kw) -> Settings:
@@ -49,7 +50,7 @@ def default_settings(**kw) -> Settings:
                  eps_dual_inf=1e-4, max_iter=4000, check_termination=25, scaling=10, adaptive_rho=1,
                  adaptive_rho_interval=50, adaptive_rho_tolerance=5.0, polish=2, ipm_max_iter=30,
                  ipm_tol=1e-9, ipm_reg=1e-8, as_delta=1e-10, as_refine=5, as_rounds=4, cert_tol=1e-8, early_polish=1,
-                 early_scaling=2)
+                 early_scaling=2, phase1=1, ipm_diverged=1e3, phase1_theta=1.0)
     for k, v in kw.items():
         if not hasattr(s, k):
             raise TypeError("unknown solver setting %r" % k)
@@ -118,6 +119,7 @@ def load_library(path: str | None = None):
     lib.mpmpc_build_corridor.argtypes = [h, C.c_int32, C.c_double, C.c_double, _dp, _dp, _ip]
     lib.mpmpc_rollout_init.argtypes = [h, C.c_int32, C.c_double, _dp, _dp, _dp, _dp]
     lib.mpmpc_rollout_step.argtypes = [h, C.c_int32, C.c_int32]
+    lib.mpmpc_rollout_set_counters.argtypes = [h, C.c_int32, _ip]
     lib.mpmpc_rollout_warm_start.argtypes = [h, C.c_int32]
     lib.mpmpc_rollout_state.argtypes = [h, C.c_int32, _dp, _dp, _dp, _ip, _dp, _dp, _ip, _ip, _ip]
     lib.mpmpc_assemble.argtypes = [h, C.c_int32, _ip, _dp, _dp, _dp, _dp, _dp]
@@ -138,7 +140,7 @@ def load_library(path: str | None = None):
 EXPORTS = ["mpmpc_version", "mpmpc_last_error", "mpmpc_device_count", "mpmpc_default_settings",
            "mpmpc_create", "mpmpc_destroy", "mpmpc_set_settings", "mpmpc_set_packing", "mpmpc_set_path", "mpmpc_set_corridor",
            "mpmpc_set_map", "mpmpc_set_path_geometry", "mpmpc_build_corridor", "mpmpc_rollout_init",
-           "mpmpc_rollout_step", "mpmpc_rollout_warm_start", "mpmpc_rollout_state", "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident",
+           "mpmpc_rollout_step", "mpmpc_rollout_set_counters", "mpmpc_rollout_warm_start", "mpmpc_rollout_state", "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident",
            "mpmpc_sync", "mpmpc_download", "mpmpc_solve_resident_timed", "mpmpc_speed_profile"]
 
 
@@ -244,6 +246,11 @@ class Handle:
         self._check(self.lib.mpmpc_rollout_init(self._h, B, float(Ts), _d(cum), _d(s), _d(poses), _d(cc0)))
         self._ro_B = B
         return B
+
+    def rollout_set_counters(self, counters):
+        """MPC.infeasibility_counter of every car (to resume a recorded run)"""
+        c = np.ascontiguousarray(counters, dtype=np.int32).ravel()
+        self._check(self.lib.mpmpc_rollout_set_counters(self._h, c.size, _i(c)))
 
     def rollout_warm_start(self, enable=True):
         """closed loop: try the previous step's shifted active set first.  True / False force it on / off, "auto"

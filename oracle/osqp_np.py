@@ -77,6 +77,7 @@ class Settings:
     ipm_tol: float = 1e-9
     ipm_reg: float = 1e-8
     ipm_max_iter: int = 30
+    ipm_diverged: float = 1e3    # interior point stops when mu exceeds this multiple of its smallest value so far
     as_delta: float = 1e-9      # (the device uses 1e-10: fewer refinement solves; a general LDL of this KKT matrix loses
                                 #  accuracy there - the plan moves by 1e-5 - so the checker keeps OSQP-polish-like 1e-9)
     as_refine: int = 5
@@ -84,6 +85,9 @@ class Settings:
     cert_tol: float = 1e-8
     early_polish: int = 1       # polish=2 only: try the polish after this many ADMM iterations (0 = off)
     early_scaling: int = 2      # Ruiz passes before that attempt; the rest precede the full ADMM run
+    phase1: int = 1             # polish=2: what the early attempt cannot certify is first tested for infeasibility
+                                # (least-squares phase 1 -> Farkas ray -> PRIMAL_INFEASIBLE) before any full ADMM run
+    phase1_theta: float = 1.0   # start value of its slacks / multipliers
 
 
 @dataclasses.dataclass
@@ -243,6 +247,16 @@ def _solve(P, q, A, l, u, st: Settings, trace=None, stop_after_early=False):
                 xa, ya = w.unscale(x, y)
                 early.x_admm, early.y_admm = xa, ya
                 return early
+            if st.phase1:
+                # not certified: before any long ADMM run, ask whether the problem is infeasible at all
+                px, py, pit, cert = _phase1(w, st)
+                early.ipm_iters += pit
+                if cert:
+                    early.x, early.y = w.unscale(px, py)          # least-violation point, Farkas ray
+                    early.status, early.polished = PRIMAL_INFEASIBLE, 0
+                    early.pri_res = kkt_certificate(w.P0, w.q0, w.A0, w.l0, w.u0, early.x, early.y)["prim"]
+                    early.x_admm, early.y_admm = w.unscale(x, y)
+                    return early
             if stop_after_early:
                 return None
         if st.adaptive_rho and st.adaptive_rho_interval and it % st.adaptive_rho_interval == 0:
@@ -433,12 +447,18 @@ def _row_classes(w: Workspace):
     return eq, L, U
 
 
-def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3):
+def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, stop=None):
+    """`soft` (phase 1, see _phase1): per-row gamma^2 >= 0.  A soft row r reads  l <= (Ax)_r + gamma_r w_r <= u  with
+    the cost 1/2 w_r^2 and NO other cost (P, q are taken as zero); w_r = gamma_r (zl_r - zu_r) is eliminated, which
+    leaves the same iteration with  (Ax)_r - gamma_r^2 y_r  in place of (Ax)_r in the slack equations and
+    gamma_r^2 added to the row's diagonal entry of the reduced KKT matrix.  `stop(x, y)`: optional early exit."""
     n, m = w.n, w.m
     eq, L, U = _row_classes(w)
     beq = w.l
     x = x0.copy()
     Ax = w.A @ x
+    P, q = (w.P, w.q) if soft is None else (np.zeros_like(w.P), np.zeros_like(w.q))
+    g2 = np.zeros(m) if soft is None else np.where(L | U, soft, 0.0)
     nu = np.where(eq, y0, 0.0)
     sl = np.where(L, np.maximum(Ax - w.l, theta), 1.0)
     su = np.where(U, np.maximum(w.u - Ax, theta), 1.0)
@@ -449,27 +469,38 @@ def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3):
     conv = False
     it = 0
     stalled = 0
+    mu_min = np.inf
     for it in range(st.ipm_max_iter + 1):
         Ax = w.A @ x
         y = nu + zu - zl
-        rd = w.P @ x + w.q + w.A.T @ y
+        rd = P @ x + q + w.A.T @ y
         req = np.where(eq, Ax - beq, 0.0)
-        rl = np.where(L, Ax - w.l - sl, 0.0)
-        ru = np.where(U, w.u - Ax - su, 0.0)
+        rl = np.where(L, Ax - g2 * (zu - zl) - w.l - sl, 0.0)
+        ru = np.where(U, w.u - Ax + g2 * (zu - zl) - su, 0.0)
         mu = (np.sum(sl * zl * L) + np.sum(su * zu * U)) / nb
         res = max(_ninf(rd), _ninf(req), _ninf(rl), _ninf(ru))
         if res < tol and mu < tol:
             conv = True
             break
+        if stop is not None and stop(x, y):
+            conv = True
+            break
         if it == st.ipm_max_iter:
             break
+        # the complementarity measure of a feasible problem falls (nearly) monotonically; on an infeasible one the
+        # multipliers blow up within a few iterations (mu jumps by 4-5 orders of magnitude): give up at once, the
+        # phase-1 test is the one that can decide such an instance
+        if soft is None and mu > st.ipm_diverged * mu_min:
+            break
+        mu_min = min(mu_min, mu)
         wt = np.where(L, zl / sl, 0.0) + np.where(U, zu / su, 0.0)
         d = np.where(eq, reg, np.where(L | U, 1.0 / np.maximum(wt, 1e-300), 1e30))
+        dk = d + g2                     # soft rows: gamma^2 on top of the barrier term
         K = np.zeros((n + m, n + m))
-        K[:n, :n] = w.P + reg * np.eye(n)
+        K[:n, :n] = P + reg * np.eye(n)
         K[:n, n:] = w.A.T
         K[n:, :n] = w.A
-        K[n:, n:] = -np.diag(d)
+        K[n:, n:] = -np.diag(dk)
         lu = sla.lu_factor(K)
 
         def newton(rcl, rcu):
@@ -478,11 +509,11 @@ def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3):
             rhs = np.concatenate([-rd, rhs2])
             sol = sla.lu_solve(lu, rhs)
             # one refinement step against the un-regularised Newton matrix
-            K0x = w.P @ sol[:n] + w.A.T @ sol[n:]
-            K0y = w.A @ sol[:n] - np.where(eq, 0.0, d) * sol[n:]
+            K0x = P @ sol[:n] + w.A.T @ sol[n:]
+            K0y = w.A @ sol[:n] - np.where(eq, 0.0, dk) * sol[n:]
             sol = sol + sla.lu_solve(lu, rhs - np.concatenate([K0x, K0y]))
             dx, dyv = sol[:n], sol[n:]
-            Adx = w.A @ dx
+            Adx = w.A @ dx - g2 * dyv
             dsl = np.where(L, Adx + rl, 0.0)
             dsu = np.where(U, -Adx + ru, 0.0)
             dzl = np.where(L, (-rcl - zl * dsl) / sl, 0.0)
@@ -510,6 +541,45 @@ def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3):
     y = nu + zu - zl
     act = dict(eq=eq, low=L & (zl > sl), upp=U & (zu > su) & ~(L & (zl > sl)), L=L, U=U)
     return x, y, it, conv, act
+
+
+# ---------------------------------------------------------------------------
+# Phase 1: is the QP infeasible?  (polish=2, phase1=1; runs on what the early polish attempt could not certify)
+#     min 1/2 |w|^2   s.t.  equality rows as they are,  l <= (Ax)_r + gamma_r w_r <= u  on every other finite row
+# (every inequality row soft, nothing else in the cost).  Always feasible when the equality rows are; its optimum is
+# zero iff the QP is feasible; and at its optimum the multipliers y satisfy  A'y = 0  and
+# u'max(y,0) + l'min(y,0) = -|w|^2 < 0:  a Farkas ray, the certificate OSQP's own infeasibility test asks for
+# (is_primal_infeasible), reached by ~10 interior-point iterations on the structured KKT system instead of
+# hundreds or thousands of ADMM iterations.  gamma_r = max |A_r.| of the SCALED row (the box rows of the MPC problem
+# have one entry, g), i.e. unit weight on a violation measured in the scaled variable.
+# ---------------------------------------------------------------------------
+def farkas_certificate(A, l, u, y, eps=1e-4):
+    """Solver-independent check that y proves  {x : l <= Ax <= u}  empty (unscaled data), with OSQP's normalisation:
+    |A'y|_inf <= eps |y|_inf  and  u'max(y,0) + l'min(y,0) <= -eps |y|_inf, y's wrong-signed entries on one-sided rows
+    projected away first.  Returns dict(ok, support, aty, norm) - support and aty relative to |y|_inf."""
+    A = np.asarray(A, float)
+    l = np.maximum(np.asarray(l, float), -OSQP_INFTY)
+    u = np.minimum(np.asarray(u, float), OSQP_INFTY)
+    lo_inf = l < -OSQP_INFTY * MIN_SCALING
+    up_inf = u > OSQP_INFTY * MIN_SCALING
+    y = np.where(up_inf & lo_inf, 0.0, np.where(up_inf, np.minimum(y, 0.0), np.where(lo_inf, np.maximum(y, 0.0), y)))
+    nrm = _ninf(y)
+    if not (nrm > 0.0) or not np.all(np.isfinite(y)):
+        return dict(ok=False, support=0.0, aty=0.0, norm=nrm)
+    support = float(np.sum(u * np.maximum(y, 0.0) + l * np.minimum(y, 0.0))) / nrm
+    aty = _ninf(A.T @ y) / nrm
+    return dict(ok=bool(support < -eps and aty < eps), support=support, aty=aty, norm=nrm)
+
+
+def _phase1(w: Workspace, st: Settings, x0=None):
+    """Phase 1 on the scaled problem of `w`.  -> (x, y, iterations, certified): certified means (x, y) passed OSQP's
+    primal-infeasibility test (unscaled norms, eps_prim_inf) with y as the ray."""
+    n, m = w.n, w.m
+    soft = np.max(np.abs(w.A), axis=1) ** 2
+    stop = lambda x, y: _primal_infeasible(w, y, st.eps_prim_inf)
+    x, y, it, conv, _ = _ipm_refine(w, np.zeros(n) if x0 is None else x0, np.zeros(m), st, st.ipm_tol, st.phase1_theta,
+                                    soft=soft, stop=stop)
+    return x, y, it, bool(_primal_infeasible(w, y, st.eps_prim_inf))
 
 
 # ---------------------------------------------------------------------------

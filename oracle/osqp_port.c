@@ -43,7 +43,8 @@ typedef struct {
   double ipm_tol, ipm_reg, as_delta;
   int32_t as_refine, as_rounds;
   double cert_tol;
-  int32_t early_polish, early_scaling;
+  int32_t early_polish, early_scaling, phase1;
+  double ipm_diverged, phase1_theta;
 } oracle_settings;
 
 typedef struct {
@@ -480,7 +481,12 @@ static int certificate(const work_t* w, const double* xs, const double* ys, doub
 /* ------------------------------------------------------------------ polish stage 1: interior point */
 typedef struct { int *eq, *L, *U; } classes_t;
 
-static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double* x, double* y, double tol, double theta, int* iters_out, int* low, int* upp) {
+/* soft (phase 1, see phase1()): per-row gamma^2 or NULL.  A soft row reads  l <= (Ax)_r + gamma_r w_r <= u  with the cost
+ * 1/2 w_r^2 (the caller has zeroed P and q); w_r = gamma_r (zl_r - zu_r) is eliminated: (Ax)_r - gamma_r^2 y_r replaces
+ * (Ax)_r in the slack equations and gamma_r^2 is added to the row's diagonal entry of the reduced KKT matrix.  In that
+ * mode the loop also ends as soon as the multipliers pass OSQP's primal-infeasibility test. */
+static int primal_infeasible(const work_t* w, const double* dy, double eps, double* tn, double* tm);
+static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double* x, double* y, double tol, double theta, int* iters_out, int* low, int* upp, const double* soft) {
   const oracle_settings* st = w->st;
   int n = w->n, m = w->m, N = n + m;
   const double reg = st->ipm_reg;
@@ -507,6 +513,10 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
   }
   if (nb < 1) nb = 1;
   int conv = 0, it = 0, stalled = 0;
+  double mu_min = 1e300;
+  double* g2 = (double*)calloc(m, sizeof(double));
+  double* dk = (double*)malloc(sizeof(double) * m);
+  if (soft) for (int r = 0; r < m; ++r) g2[r] = (cl->L[r] || cl->U[r]) ? soft[r] : 0.0;
   for (it = 0; it <= st->ipm_max_iter; ++it) {
     csc_mul(&w->A, x, Ax);
     for (int r = 0; r < m; ++r) yy[r] = nu[r] + zu[r] - zl[r];
@@ -515,20 +525,26 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
     for (int j = 0; j < n; ++j) { rd[j] += w->q[j] + tn[j]; res = dmax(res, fabs(rd[j])); }
     for (int r = 0; r < m; ++r) {
       req[r] = cl->eq[r] ? Ax[r] - w->l[r] : 0.0;
-      rl[r] = cl->L[r] ? Ax[r] - w->l[r] - sl[r] : 0.0;
-      ru[r] = cl->U[r] ? w->u[r] - Ax[r] - su[r] : 0.0;
+      rl[r] = cl->L[r] ? Ax[r] - g2[r] * (zu[r] - zl[r]) - w->l[r] - sl[r] : 0.0;
+      ru[r] = cl->U[r] ? w->u[r] - Ax[r] + g2[r] * (zu[r] - zl[r]) - su[r] : 0.0;
       res = dmax(res, dmax(fabs(req[r]), dmax(fabs(rl[r]), fabs(ru[r]))));
       if (cl->L[r]) mu += sl[r] * zl[r];
       if (cl->U[r]) mu += su[r] * zu[r];
     }
     mu /= nb;
     if (res < tol && mu < tol) { conv = 1; break; }
+    if (soft && primal_infeasible(w, yy, st->eps_prim_inf, tn, tm)) { conv = 1; break; }
     if (it == st->ipm_max_iter) break;
+    /* mu of a feasible problem falls (nearly) monotonically; on an infeasible one the multipliers blow up within a few
+       iterations: give up at once, phase 1 is what can decide such an instance */
+    if (!soft && mu > st->ipm_diverged * mu_min) break;
+    mu_min = dmin(mu_min, mu);
     for (int r = 0; r < m; ++r) {
       double wt = (cl->L[r] ? zl[r] / sl[r] : 0.0) + (cl->U[r] ? zu[r] / su[r] : 0.0);
       d[r] = cl->eq[r] ? reg : ((cl->L[r] || cl->U[r]) ? 1.0 / dmax(wt, 1e-300) : 1e30);
+      dk[r] = d[r] + g2[r];
     }
-    if (kkt_fill_and_factor(w, K, F, reg, d, m) != 0) break;
+    if (kkt_fill_and_factor(w, K, F, reg, dk, m) != 0) break;
     for (int r = 0; r < m; ++r) { rcl[r] = sl[r] * zl[r]; rcu[r] = su[r] * zu[r]; }
     double a = 1.0;
     for (int pass = 0; pass < 2; ++pass) {
@@ -542,10 +558,11 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
       sym_mul(&w->P, sol, tn); csc_tmul(&w->A, sol + n, res2);
       for (int j = 0; j < n; ++j) res2[j] = rhs[j] - (tn[j] + res2[j]);
       csc_mul(&w->A, sol, tm);
-      for (int r = 0; r < m; ++r) res2[n + r] = rhs[n + r] - (tm[r] - (cl->eq[r] ? 0.0 : d[r]) * sol[n + r]);
+      for (int r = 0; r < m; ++r) res2[n + r] = rhs[n + r] - (tm[r] - (cl->eq[r] ? 0.0 : dk[r]) * sol[n + r]);
       ldl_solve(F, res2, cor);
       for (int k = 0; k < N; ++k) sol[k] += cor[k];
       csc_mul(&w->A, sol, tm);
+      for (int r = 0; r < m; ++r) tm[r] -= g2[r] * sol[n + r];
       double ratio = 1e300;
       for (int r = 0; r < m; ++r) {
         dsl[r] = cl->L[r] ? tm[r] + rl[r] : 0.0;
@@ -587,6 +604,7 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
   *iters_out = it;
   free(Ax); free(nu); free(sl); free(su); free(zl); free(zu); free(rd); free(req); free(rl); free(ru); free(d); free(rhs); free(sol);
   free(res2); free(cor); free(rcl); free(rcu); free(dsl); free(dsu); free(dzl); free(dzu); free(tn); free(tm); free(yy);
+  free(g2); free(dk);
   return conv;
 }
 
@@ -691,7 +709,7 @@ static int certified_polish(work_t* w, const double* x, const double* y, double 
   int good = 0;
   for (int attempt = 0; attempt < 2 && !good; ++attempt) {
     int nit = 0;
-    int conv = ipm_refine(w, w->K, w->F, &cl, xi, yi, tol, theta, &nit, low, upp);
+    int conv = ipm_refine(w, w->K, w->F, &cl, xi, yi, tol, theta, &nit, low, upp, NULL);
     info->ipm_iters += nit;
     if (!conv) break;
     int rounds = 0;
@@ -711,6 +729,47 @@ static int certified_polish(work_t* w, const double* x, const double* y, double 
   }
   free(cl.eq); free(cl.L); free(cl.U); free(low); free(upp); free(xi); free(yi); free(xa); free(ya); free(xs); free(ys);
   return good;
+}
+
+/* ------------------------------------------------------------------ phase 1: is the QP infeasible?
+ *     min 1/2 |w|^2   s.t.  equality rows as they are,  l <= (Ax)_r + gamma_r w_r <= u  on every other finite row
+ * Always feasible when the equality rows are; optimum 0 iff the QP is feasible; at its optimum the multipliers y satisfy
+ * A'y = 0 and u'max(y,0) + l'min(y,0) = -|w|^2 < 0: a Farkas ray, put to OSQP's own primal-infeasibility test.
+ * gamma_r = max |A_r.| of the scaled row.  Returns 1 when certified; x_out: least-violation point, y_out: the ray. */
+static int phase1(work_t* w, double* x_out, double* y_out, oracle_info* info) {
+  const oracle_settings* st = w->st;
+  int n = w->n, m = w->m;
+  classes_t cl; cl.eq = (int*)malloc(sizeof(int) * m); cl.L = (int*)malloc(sizeof(int) * m); cl.U = (int*)malloc(sizeof(int) * m);
+  for (int r = 0; r < m; ++r) {
+    int fl = w->l[r] > -INF_BOUND, fu = w->u[r] < INF_BOUND;
+    cl.eq[r] = fl && fu && (w->u[r] - w->l[r] <= 1e-12 * dmax(1.0, fabs(w->l[r])));
+    cl.L[r] = fl && !cl.eq[r]; cl.U[r] = fu && !cl.eq[r];
+  }
+  double* soft = (double*)calloc(m, sizeof(double));
+  for (int j = 0; j < n; ++j)
+    for (int k = w->A.p[j]; k < w->A.p[j + 1]; ++k) soft[w->A.i[k]] = dmax(soft[w->A.i[k]], fabs(w->A.x[k]));
+  for (int r = 0; r < m; ++r) soft[r] *= soft[r];
+  int pnnz = w->P.p[n];
+  double* Psave = (double*)malloc(sizeof(double) * (pnnz > 0 ? pnnz : 1)); memcpy(Psave, w->P.x, sizeof(double) * pnnz);
+  double* qsave = (double*)malloc(sizeof(double) * n); memcpy(qsave, w->q, sizeof(double) * n);
+  memset(w->P.x, 0, sizeof(double) * pnnz); memset(w->q, 0, sizeof(double) * n);
+  double *x = (double*)calloc(n, sizeof(double)), *y = (double*)calloc(m, sizeof(double));
+  double *tn = (double*)malloc(sizeof(double) * n), *tm = (double*)malloc(sizeof(double) * m);
+  int *low = (int*)calloc(m, sizeof(int)), *upp = (int*)calloc(m, sizeof(int));
+  int nit = 0;
+  ipm_refine(w, w->K, w->F, &cl, x, y, st->ipm_tol, st->phase1_theta, &nit, low, upp, soft);
+  info->ipm_iters += nit;
+  int cert = primal_infeasible(w, y, st->eps_prim_inf, tn, tm);
+  memcpy(w->P.x, Psave, sizeof(double) * pnnz); memcpy(w->q, qsave, sizeof(double) * n);
+  if (cert) {
+    for (int j = 0; j < n; ++j) x_out[j] = w->D[j] * x[j];
+    for (int r = 0; r < m; ++r) y_out[r] = w->E[r] * y[r] * w->cinv;
+    double pv, sv;
+    certificate(w, x_out, y_out, st->cert_tol, &pv, &sv);
+    info->status = PRIMAL_INFEASIBLE; info->polished = 0; info->pri_res = pv; info->dua_res = 0.0;
+  }
+  free(cl.eq); free(cl.L); free(cl.U); free(soft); free(Psave); free(qsave); free(x); free(y); free(tn); free(tm); free(low); free(upp);
+  return cert;
 }
 
 /* ------------------------------------------------------------------ the solver */
@@ -778,6 +837,8 @@ int oracle_solve_csc(int n, int m, const int* Pp, const int* Pi, const double* P
       info->status = UNSOLVED; info->iters = it; info->rho_updates = rho_updates; info->ipm_iters = 0; info->as_rounds = 0; info->polished = 0;
       compute_info(&w, x, z, y, &o);
       if (certified_polish(&w, x, y, warm_start_floor(o.pri), x_out, y_out, info)) { early_done = 1; break; }
+      /* not certified: before any long ADMM run, ask whether the problem is infeasible at all */
+      if (st->phase1 && phase1(&w, x_out, y_out, info)) { early_done = 1; break; }
       if (passes_done < st->scaling) {
         /* not certified: the remaining Ruiz passes, then the full OSQP iteration from a cold start */
         scale_data(&w, st->scaling - passes_done);

@@ -13,6 +13,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    # the library every test loads must be the tree's: (re)build it before anything can dlopen a stale one
+    # (a no-op when the hash of the sources matches the one the binary was built from)
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.build_library()
+
+
 @pytest.fixture(scope="session")
 def track():
     import scenarios

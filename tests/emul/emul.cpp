@@ -9,30 +9,41 @@
 #include "corridor_core.hpp"
 #include "rollout_core.hpp"
 #include <limits>
+#include <vector>
 
 using namespace mpmpc;
 
+// mode / tail as in mpmpc_solve_kernel: mode 1 appends the instances it leaves UNSOLVED to tail[1..] (tail[0] counts),
+// mode 2 runs one wave per listed instance
 template <int G, int C>
 static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z,
                     double* u0, int* status, int* iters, double* resid, double* y, const int* guess = nullptr,
-                    int* act = nullptr) {
+                    int* act = nullptr, int mode = 0, int* tail = nullptr) {
   using L = LaneEmu<G, C>;
   const int ld = stage_ld(cfg->N);
   const int per = L::per_wave;
-  for (int w0 = 0; w0 < B; w0 += per) {
-    VI inst = L::slot() + w0;
+  const int waves = mode == 2 ? tail[0] : (B + per - 1) / per;
+  for (int w = 0; w < waves; ++w) {
+    VI inst = L::slot() + w * per;
+    if (mode == 2) inst = VI(tail[1 + w]);
     VI k = L::stage() - lane_offset(G, C, cfg->N);
-    VI gs;
+    VI gs, base(0);
     for (int i = 0; i < EMU_W; ++i) {
       const int in = inst.v[i], kk = k.v[i];
       gs.v[i] = (guess && in < B && kk >= 0 && kk <= cfg->N) ? guess[in * ld + kk] : 0;
+      if (mode == 2) base.v[i] = iters[in * 2 + 1];
     }
     Solver<L> s;
     typename L::real fields[MPMPC_NUM_FIELDS];
     Solver<L>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
-    if (guess) s.template run<true>(fields, B, inst, k, cfg->N, make_params(*st), 0, gs);
-    else s.run(fields, B, inst, k, cfg->N, make_params(*st));
+    // (like the device: the packed kernels carry no phase-1 code when they run as the first of two launches)
+    if (guess) s.template run<true>(fields, B, inst, k, cfg->N, make_params(*st), mode, gs, base);
+    else if (mode == 1) s.template run<false, (G == 64)>(fields, B, inst, k, cfg->N, make_params(*st), mode, VI(0), base);
+    else s.run(fields, B, inst, k, cfg->N, make_params(*st), mode, VI(0), base);
     s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y, act, ld);
+    if (mode == 1)
+      for (int i = 0; i < EMU_W; ++i)
+        if (k.v[i] == 0 && inst.v[i] < B && s.status.v[i] == MPMPC_UNSOLVED) tail[1 + tail[0]++] = inst.v[i];
   }
 }
 
@@ -45,6 +56,24 @@ extern "C" int emu_solve(const mpmpc_config* cfg, const mpmpc_settings* st, int 
   else if (G == 32) solve_g<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y);
   else if (G == 16) solve_g<16, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y);
   else return -1;
+  return 0;
+}
+
+// what launch_solve does with a packed batch (G < 64 and an early polish attempt): the packed kernel in mode 1, then
+// the <64, C> kernel in mode 2 on the instances it left unsolved (phase 1, full ADMM run); otherwise one launch.
+extern "C" int emu_solve_launch(const mpmpc_config* cfg, const mpmpc_settings* st, int G, const double* qp, int B,
+                                double* z, double* u0, int* status, int* iters, double* resid, double* y, int* n_tail) {
+  if (cfg->N + 1 > G) return -1;
+  const bool early = st->polish && st->early_polish > 0 && st->early_polish < st->max_iter;
+  if (n_tail) *n_tail = 0;
+  if (G == 64 || !early) return emu_solve(cfg, st, G, qp, B, z, u0, status, iters, resid, y);
+  std::vector<int> tail(B + 1, 0);
+  if (G == 32) solve_g<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 1, tail.data());
+  else if (G == 16) solve_g<16, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 1, tail.data());
+  else return -1;
+  if (n_tail) *n_tail = tail[0];
+  if (lane_split(64, cfg->N) == 16) solve_g<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 2, tail.data());
+  else solve_g<64, 32>(cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 2, tail.data());
   return 0;
 }
 

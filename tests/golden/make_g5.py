@@ -68,6 +68,7 @@ def main():
         X, Y = np.full((C, n), np.nan), np.full((C, m), np.nan)
         status, iters, ipm = np.zeros(C, np.int32), np.zeros(C, np.int32), np.zeros(C, np.int32)
         cert = np.full((C, 3), np.nan)
+        farkas = np.full((C, 2), np.nan)       # infeasible cases: support / |y|, |A'y| / |y| of the stored ray
         obj, obj_highs = np.full(C, np.nan), np.full(C, np.nan)
         for c in range(C):
             lo, hi = g["A_case_ptr"][c], g["A_case_ptr"][c + 1]
@@ -83,11 +84,18 @@ def main():
                 obj[c] = k["obj"]
                 if N <= 30:
                     obj_highs[c] = highs_objective(P, q, A, l, u)
+            elif r.status == O.PRIMAL_INFEASIBLE:
+                # infeasible capture: the least-violation point of phase 1 and the Farkas ray that proves it
+                X[c], Y[c] = r.x, r.y
+                f = O.farkas_certificate(A, l, u, r.y)
+                farkas[c] = f["support"], f["aty"]
+                assert f["ok"], (N, c, f)
             print("N=%d case %2d: status %2d, %4d ADMM + %2d interior-point iterations, certificate %.1e, obj %.9g (HiGHS %.9g)" %
                   (N, c, r.status, r.iters, r.ipm_iters, np.nanmax(cert[c]) if np.isfinite(cert[c]).any() else np.nan, obj[c], obj_highs[c]))
         np.savez_compressed(os.path.join(HERE, "g5_solutions_N%d.npz" % N), x=X, y=Y, status=status, admm_iters=iters,
-                            ipm_iters=ipm, certificate=cert, obj=obj, obj_highs=obj_highs,
-                            note=np.array(["certified optimum of the G4 capture of the same index; oracle/osqp_np.py polish=2"]))
+                            ipm_iters=ipm, certificate=cert, obj=obj, obj_highs=obj_highs, farkas=farkas,
+                            note=np.array(["certified optimum (or, status -3, least-violation point + Farkas ray) of the G4 capture "
+                                           "of the same index; oracle/osqp_np.py polish=2, phase1=1"]))
 
 
 if __name__ == "__main__":

@@ -157,7 +157,8 @@ def stage_assembly():
     for rp in worlds.values():
         for w, v in zip(rp.waypoints, v_ref):
             w.v_ref = v
-    for N, weights, ncase in ((3, "stock", 16), (10, "stock", 24), (30, "stock", 32), (50, "time_optimal", 24)):
+    # 256 captures in all; the first 16 / 24 / 32 / 24 of each horizon are the cases of round 1
+    for N, weights, ncase in ((3, "stock", 32), (10, "stock", 64), (30, "stock", 96), (50, "time_optimal", 64)):
         rng = np.random.default_rng(1000 + N)
         rec = {k: [] for k in ("s", "pose", "cc_prev", "obst", "wp_id", "x0", "lb", "ub", "q", "l", "u",
                                "P_diag", "P_nnz", "A_indptr", "A_indices", "A_data")}
@@ -232,7 +233,7 @@ def stage_loop():
         car, mpc = make_controller(rp, N, "stock")
         rp.compute_speed_profile(dict(SPEED))
         rec = {k: [] for k in ("s", "pose", "cc_prev", "wp_id", "x0", "lb", "ub", "status", "u", "counter",
-                               "z", "cc_next")}
+                               "z", "cc_next", "pred_x", "pred_y")}
         exited = False
         while car.s < rp.length:
             s, pose = car.s, [car.temporal_state.x, car.temporal_state.y, car.temporal_state.psi]
@@ -258,6 +259,11 @@ def stage_loop():
             rec["counter"].append(mpc.infeasibility_counter)
             rec["z"].append(res.x if res.status > 0 else np.full(5 * N + 3, np.nan))
             rec["cc_next"].append(mpc.current_control.copy())
+            # MPC.update_prediction (src/MPC.py:224-248): what the reference stores for plotting after this step
+            # (unchanged by an infeasible step: the previous prediction stays)
+            px, py = mpc.current_prediction if mpc.current_prediction is not None else ([np.nan] * (N - 2), [np.nan] * (N - 2))
+            rec["pred_x"].append(np.array(px, float))
+            rec["pred_y"].append(np.array(py, float))
             car.drive(u)
         np.savez_compressed(os.path.join(HERE, "g6_closed_loop_N%d.npz" % N),
                             **{k: np.array(v) for k, v in rec.items()}, N=np.array([N]),

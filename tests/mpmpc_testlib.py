@@ -116,6 +116,44 @@ def kkt_batch(qp, N, z, y):
     return prim, stat, np.maximum(comp(x, lo_x, hi_x, yx), comp(u, lo_u, hi_u, yu))
 
 
+def farkas_batch(qp, N, y, eps=1e-4):
+    """Vectorised check that the rays y [B, 8N+6] prove their QPs infeasible (OSQP's primal-infeasibility criterion,
+    plain numpy on K1's stage fields qp [27, B, LD], rows [dynamics; state boxes; input boxes] as in
+    src/MPC.py:128-147):  |A'y|_inf <= eps |y|_inf  and  u'max(y,0) + l'min(y,0) <= -eps |y|_inf, with no multiplier
+    mass on an infinite side.  -> (ok [B], support / |y| [B], |A'y| / |y| [B])"""
+    B = qp.shape[1]
+    f = qp[:, :, :N + 1]
+    ne = 3 * (N + 1)
+    nu = y[:, :ne].reshape(B, N + 1, 3)
+    yx = y[:, ne:2 * ne].reshape(B, N + 1, 3)
+    yu = y[:, 2 * ne:].reshape(B, N, 2)
+    ds, a10, a20, b20 = (f[i, :, :N] for i in range(4))
+    beq = np.moveaxis(f[4:7], 0, -1)
+    lo_x, hi_x = np.moveaxis(f[7:10], 0, -1), np.moveaxis(f[12:15], 0, -1)
+    lo_u, hi_u = np.moveaxis(f[10:12, :, :N], 0, -1), np.moveaxis(f[15:17, :, :N], 0, -1)
+    # A'y per variable (the stationarity expression of kkt_batch without P z + q)
+    sx = -nu + yx
+    sx[:, :-1, 0] += nu[:, 1:, 0] + a10 * nu[:, 1:, 1] + a20 * nu[:, 1:, 2]
+    sx[:, :-1, 1] += ds * nu[:, 1:, 0] + nu[:, 1:, 1]
+    sx[:, :-1, 2] += nu[:, 1:, 2]
+    su = yu.copy()
+    su[:, :, 0] += b20 * nu[:, 1:, 2]
+    su[:, :, 1] += ds * nu[:, 1:, 1]
+    nrm = np.maximum(np.abs(y).max(axis=1), 1e-300)
+    aty = np.maximum(np.abs(sx).max(axis=(1, 2)), np.abs(su).max(axis=(1, 2))) / nrm
+
+    def side(mult, lo, hi):
+        fin_hi, fin_lo = hi < 1e20, lo > -1e20
+        wrong = ((mult > 0) & ~fin_hi) | ((mult < 0) & ~fin_lo)
+        val = np.where(fin_hi, hi, 0.0) * np.maximum(mult, 0.0) + np.where(fin_lo, lo, 0.0) * np.minimum(mult, 0.0)
+        return val.sum(axis=(1, 2)), wrong.any(axis=(1, 2))
+    s1, w1 = side(yx, lo_x, hi_x)
+    s2, w2 = side(yu, lo_u, hi_u)
+    support = ((beq * nu).sum(axis=(1, 2)) + s1 + s2) / nrm
+    ok = (support <= -eps) & (aty <= eps) & ~w1 & ~w2 & np.isfinite(y).all(axis=1)
+    return ok, support, aty
+
+
 class Emul:
     """ctypes view of tests/_build/libmpmpc_emul.so (CPU lock-step emulation of the kernels)."""
 
@@ -155,6 +193,20 @@ class Emul:
                                 _i(st), _i(it), _d(rs), _d(y))
         assert rc == 0
         return mpmpc.Solution(z, u0, st, it, rs, y)
+
+    def solve_launch(self, cfg, settings, qp, G=64):
+        """what the launcher does: a packed batch (G < 64) runs its early pass packed and its tail one per wave.
+        -> (Solution, number of instances handed to the second launch)"""
+        B = qp.shape[1]
+        N = cfg.N
+        n, m = 5 * N + 3, 8 * N + 6
+        z, u0, y = np.zeros((B, n)), np.zeros((B, 2)), np.zeros((B, m))
+        st, it, rs = np.zeros(B, np.int32), np.zeros((B, 2), np.int32), np.zeros((B, 2))
+        nt = C.c_int(0)
+        rc = self.lib.emu_solve_launch(C.byref(cfg), C.byref(settings), C.c_int(G), _d(np.ascontiguousarray(qp)), C.c_int(B),
+                                       _d(z), _d(u0), _i(st), _i(it), _d(rs), _d(y), C.byref(nt))
+        assert rc == 0
+        return mpmpc.Solution(z, u0, st, it, rs, y), nt.value
 
     def solve_warm(self, cfg, settings, qp, guess, G=64):
         """closed-loop variant: start from the active sets `guess` [B, ld]; -> (Solution, act [B, ld])"""

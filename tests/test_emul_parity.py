@@ -205,3 +205,73 @@ def test_emulated_kernels_reach_the_g5_optima_of_the_reference_qps(N, G, emu, tr
     ok = g5["status"] == 1
     assert np.max(np.abs(sol.z[ok] - g5["x"][ok])) < 1e-6
     assert np.max(np.abs(sol.z[ok][:, -2 * N:-2 * N + 2] - g5["x"][ok][:, -2 * N:-2 * N + 2])) < 1e-8      # (v_0, kappa_0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Phase 1: infeasible instances leave with a Farkas ray after a few interior-point iterations
+# ---------------------------------------------------------------------------------------------------------------
+def _farkas_ok(qp_i, N, y, eps=1e-4):
+    """OSQP's primal-infeasibility criterion on the dense (A, l, u) rebuilt from K1's fields: plain numpy."""
+    Pd, q, A, l, u = T.qp_to_dense(qp_i, N)
+    return O.farkas_certificate(A, l, u, y, eps)["ok"]
+
+
+@pytest.mark.parametrize("G", [64, 32])
+def test_phase1_certifies_every_infeasible_instance_without_admm(G, emu, track):
+    """512 obstacle-corridor instances (config 4): every instance ends as a certified optimum or with a certified
+    Farkas ray, nobody runs more than the ONE ADMM iteration of the early attempt, statuses and iteration counts are
+    the C oracle's, and the rays check out with plain numpy on K1's output."""
+    import oracle_c as OC
+    sc = scenarios.make(4, track, B=512)
+    cfg = T.stock_config(sc.N, sc.weights)
+    qp = emu.assemble(cfg, track, _inputs(sc))
+    sol, n_tail = emu.solve_launch(cfg, mpmpc.default_settings(), qp, G=G)
+    ocfg = OC.mpc_cfg(sc.N, scenarios.WEIGHTS[sc.weights], scenarios.UMIN, scenarios.UMAX, scenarios.XMIN,
+                      scenarios.XMAX, 4.0, 0.12)
+    ref = OC.mpc_batch(ocfg, OC.settings(), track.kappa, track.v_ref, track.ds_next, sc.wp_id, sc.x0, sc.cc_prev,
+                       sc.lb, sc.ub, want_y=True)
+    assert np.array_equal(sol.status, ref["status"])
+    assert set(np.unique(sol.status)) == {1, mpmpc.PRIMAL_INFEASIBLE}
+    assert np.all(sol.iters[:, 0] == 1) and np.all(ref["iters"][:, 0] == 1)
+    inf = np.flatnonzero(sol.status == mpmpc.PRIMAL_INFEASIBLE)
+    assert inf.size >= 30
+    assert n_tail == (inf.size if G < 64 else 0)          # a packed launch hands exactly those to its second launch
+    for i in inf:
+        assert _farkas_ok(qp[:, i, :], sc.N, sol.y[i]) and _farkas_ok(qp[:, i, :], sc.N, ref["y"][i])
+        assert sol.resid[i, 0] > 1e-4                      # the least-violation point does violate a bound
+    ok = sol.status == 1
+    assert np.max(np.abs(sol.u0[ok] - ref["u0"][ok])) <= 1e-6
+    # interior-point iterations of an infeasible instance: failed attempt (stopped by the divergence test) + phase 1
+    assert np.median(sol.iters[inf, 1]) <= 14
+
+
+def test_phase1_off_restores_osqps_own_verdicts(emu, track):
+    """phase1 = 0: what the early attempt cannot certify runs OSQP's ADMM to its own verdict (hundreds of iterations),
+    as in round 1; the infeasible set it finds is a subset of the one phase 1 proves (ADMM at eps = 1e-3 calls marginally
+    infeasible instances "solved", and the polish then flags them inaccurate)."""
+    sc = scenarios.make(4, track, B=96)
+    cfg = T.stock_config(sc.N, sc.weights)
+    qp = emu.assemble(cfg, track, _inputs(sc))
+    on = emu.solve(cfg, mpmpc.default_settings(), qp, G=64)
+    off = emu.solve(cfg, mpmpc.default_settings(phase1=0), qp, G=64)
+    solved = on.status == 1
+    assert np.array_equal(off.status[solved], on.status[solved]) and np.array_equal(off.u0[solved], on.u0[solved])
+    rest = ~solved
+    assert rest.sum() >= 5 and np.all(on.status[rest] == mpmpc.PRIMAL_INFEASIBLE)
+    assert np.all(np.isin(off.status[rest], (mpmpc.PRIMAL_INFEASIBLE, mpmpc.SOLVED_INACCURATE, mpmpc.MAX_ITER_REACHED)))
+    assert np.all(off.iters[rest, 0] >= 25) and np.all(on.iters[rest, 0] == 1)
+    for i in np.flatnonzero(rest):
+        Pd, q, A, l, u = T.qp_to_dense(qp[:, i, :], sc.N)
+        r = O.solve(np.diag(Pd), q, A, l, u, O.Settings(polish=2, phase1=0))
+        assert r.status == off.status[i] and r.iters == off.iters[i, 0]
+
+
+def test_phase1_leaves_feasible_batches_alone(emu, track):
+    """Configs 2 and 3 never reach phase 1: identical outputs with phase1 on and off."""
+    for cid, B in ((2, 64), (3, 32)):
+        sc = scenarios.make(cid, track, B=B)
+        cfg = T.stock_config(sc.N, sc.weights)
+        qp = emu.assemble(cfg, track, _inputs(sc))
+        a = emu.solve(cfg, mpmpc.default_settings(), qp, G=64)
+        b = emu.solve(cfg, mpmpc.default_settings(phase1=0), qp, G=64)
+        assert np.all(a.status == 1) and np.array_equal(a.z, b.z) and np.array_equal(a.iters, b.iters)

@@ -64,7 +64,10 @@ def test_get_control_reproduces_reference_lap(N, stride):
             d = np.abs(mpc.current_control - g["cc_next"][t])
             d[-1] = 0.0                                   # kappa_{N-1} is cost free
             assert d.max() <= 1e-6
-            assert len(mpc.current_prediction[0]) == N - 2
+            # MPC.update_prediction (src/MPC.py:224-248): the reference's own (x_pred, y_pred) of this step
+            px, py = mpc.current_prediction
+            assert len(px) == len(py) == N - 2
+            assert np.max(np.abs(np.array(px) - g["pred_x"][t])) <= 1e-6 and np.max(np.abs(np.array(py) - g["pred_y"][t])) <= 1e-6
         else:
             n_inf += 1
             assert np.array_equal(mpc.current_control, g["cc_prev"][t])

@@ -105,6 +105,55 @@ def test_g5_solutions_are_kkt_points_of_the_reference_qps(N):
             assert abs(k["obj"] - g5["obj_highs"][c]) <= 2e-5 * max(1.0, abs(k["obj"]))
 
 
+@pytest.mark.parametrize("N", [3, 10, 30, 50])
+def test_g5_infeasible_captures_carry_a_farkas_ray(N):
+    """Every capture G5 calls infeasible comes with a ray y that PROVES it on the reference's own (A, l, u):
+    |A'y| <= eps |y| and u'max(y,0) + l'min(y,0) <= -eps |y| (OSQP's criterion, eps_prim_inf = 1e-4) - checked here with
+    plain numpy on the G4 data, independent of any solver.  And no capture is left in between: certified optimum or
+    certified infeasible."""
+    g4 = np.load(M.GOLDEN + "/g4_assembly_N%d.npz" % N)
+    g5 = np.load(M.GOLDEN + "/g5_solutions_N%d.npz" % N)
+    n, m = 5 * N + 3, 8 * N + 6
+    assert set(np.unique(g5["status"])) <= {1, -3}
+    for c in np.flatnonzero(g5["status"] == -3):
+        lo, hi = g4["A_case_ptr"][c], g4["A_case_ptr"][c + 1]
+        A = sparse.csc_matrix((g4["A_data"][lo:hi], g4["A_indices"][lo:hi], g4["A_indptr"][c]), shape=(m, n)).toarray()
+        y = g5["y"][c]
+        l = np.maximum(g4["l"][c], -1e30)
+        u = np.minimum(g4["u"][c], 1e30)
+        # multipliers on an infinite side must vanish (a one-sided row only pushes one way)
+        assert np.all(y[u >= 1e26] <= 0) and np.all(y[l <= -1e26] >= 0)
+        nrm = np.max(np.abs(y))
+        assert np.max(np.abs(A.T @ y)) <= 1e-4 * nrm
+        assert np.sum(u * np.maximum(y, 0) + l * np.minimum(y, 0)) <= -1e-4 * nrm
+        f = O.farkas_certificate(A, g4["l"][c], g4["u"][c], y)
+        assert f["ok"] and abs(f["support"] - g5["farkas"][c, 0]) <= 1e-12 + 1e-9 * abs(f["support"])
+        # and the ADMM iteration never ran beyond the early attempt
+        assert g5["admm_iters"][c] == 1
+
+
+def test_farkas_certificate_rejects_what_is_not_a_ray(otrack):
+    N = 10
+    lim, w = M.Limits.stock(), M.Weights.stock()
+    lb, ub = np.full(N, -0.1), np.full(N, 0.1)
+    P, q, A, l, u = M.assemble(otrack, 5, np.array([0.01, 0.05, 0.0]), np.zeros(2 * N), lb, ub, N, w, lim)
+    r = O.solve(P, q, A, l, u, O.Settings(polish=2))
+    assert r.status == O.SOLVED
+    assert not O.farkas_certificate(A, l, u, r.y)["ok"]                  # multipliers of a feasible problem
+    assert not O.farkas_certificate(A, l, u, np.zeros(l.size))["ok"]
+    rng = np.random.default_rng(0)
+    assert not O.farkas_certificate(A, l, u, rng.normal(size=l.size))["ok"]
+    lb2, ub2 = lb.copy(), ub.copy()
+    lb2[0], ub2[0] = 0.09, 0.1                             # unreachable from e_y = 0.01 in one step
+    P, q, A, l, u = M.assemble(otrack, 5, np.array([0.01, 0.0, 0.0]), np.zeros(2 * N), lb2, ub2, N, w, lim)
+    r1 = O.solve(P, q, A, l, u, O.Settings(polish=2))                    # phase 1: a handful of interior-point iterations
+    r0 = O.solve(P, q, A, l, u, O.Settings(polish=2, phase1=0))          # OSQP's ADMM: hundreds of iterations, same verdict
+    assert r1.status == r0.status == O.PRIMAL_INFEASIBLE
+    assert r1.iters == 1 and r0.iters > 25
+    assert O.farkas_certificate(A, l, u, r1.y)["ok"]
+    assert not O.farkas_certificate(A, l, u, -r1.y)["ok"]
+
+
 @pytest.mark.parametrize("N", [3, 30])
 def test_oracle_reproduces_g5(N):
     g4 = np.load(M.GOLDEN + "/g4_assembly_N%d.npz" % N)

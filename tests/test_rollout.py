@@ -149,3 +149,82 @@ def test_rollout_warm_start_default_is_used_where_it_pays():
         h.close()
         hits = float(np.mean(sol.iters[:, 0] == 0))
         assert (hits > 0.5) if expect_warm else (hits == 0.0), (B, hits)
+
+
+def _g6_handle(N, B):
+    g1 = np.load(M.GOLDEN + "/g1_path_sim_track.npz")
+    g3 = np.load(M.GOLDEN + "/g3_corridor.npz")
+    tr = __import__("scenarios").sim_track()
+    h = mpmpc.Handle(T.stock_config(N, max_batch=B))
+    h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+    h.set_corridor(g3["ub_obstacles"], g3["lb_obstacles"])
+    h.set_path_geometry(g1["x"], g1["y"], g1["psi"], g1["border_ub"], g1["border_lb"])
+    return h, np.cumsum(g1["segment_lengths"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [10, 30])
+def test_device_rollout_replays_the_reference_trace(N):
+    """K3 on the GPU against the reference's OWN closed loop (golden G6: src/simulation.py:134-140 driven through the
+    reference classes), teacher-forced: every recorded step becomes one car (its s, pose, previous plan and
+    infeasibility counter), ONE rollout step runs localise -> solve -> advance for all of them, and each car must land
+    where the reference's step landed: waypoint, spatial state, verdict, control, new plan, counter, next s and pose."""
+    g = np.load(M.GOLDEN + "/g6_closed_loop_N%d.npz" % N)
+    T_ = g["s"].size
+    h, cum = _g6_handle(N, T_)
+    prev_counter = np.concatenate([[0], g["counter"][:-1]]).astype(np.int32)
+    h.rollout_warm_start(False)
+    h.rollout_init(0.05, cum, g["s"], g["pose"], cc0=g["cc_prev"])
+    h.rollout_set_counters(prev_counter)
+    h.rollout_step(1)
+    st = h.rollout_state()
+    h.close()
+    assert np.array_equal(st["wp_id"], g["wp_id"])
+    assert np.max(np.abs(st["x0"] - g["x0"])) <= 1e-13
+    ok = g["status"] > 0
+    assert np.array_equal(st["status"] > 0, ok) and (~ok).sum() >= 5            # the fallback branch is exercised
+    assert np.array_equal(st["counter"], g["counter"])
+    assert np.max(np.abs(st["u"] - g["u"])) <= 1e-6
+    d = np.abs(st["cc"] - g["cc_next"])
+    d[:, -1] = 0.0                                                              # kappa_{N-1} is cost free
+    assert d.max() <= 1e-6
+    assert np.all(st["alive"] == 1)
+    assert np.max(np.abs(st["s"][:-1] - g["s"][1:])) <= 1e-7
+    assert np.max(np.abs(st["pose"][:-1] - g["pose"][1:])) <= 1e-7
+
+
+@pytest.mark.gpu
+def test_device_rollout_ends_like_the_reference_at_horizon_10():
+    """Config 1's own horizon: the reference's lap at N = 10 ends with exit(1) after N - 1 consecutive infeasible
+    steps (src/MPC.py:218-220).  A car put on the last recorded state ends the same way (alive = -1) on the device."""
+    g = np.load(M.GOLDEN + "/g6_closed_loop_N10.npz")
+    assert bool(g["exited"][0])
+    t = g["s"].size - 1
+    h, cum = _g6_handle(10, 1)
+    h.rollout_init(0.05, cum, g["s"][t:t + 1], g["pose"][t:t + 1], cc0=g["cc_prev"][t:t + 1])
+    h.rollout_set_counters(g["counter"][t - 1:t])
+    h.rollout_step(12)
+    st = h.rollout_state()
+    h.close()
+    assert st["alive"][0] == -1 and st["counter"][0] == 9
+
+
+@pytest.mark.gpu
+def test_rollout_state_is_guarded_against_interleaved_solves():
+    """a single mpmpc_solve between rollout steps used to continue the rollout on garbage."""
+    g = np.load(M.GOLDEN + "/g6_closed_loop_N30.npz")
+    h, cum = _g6_handle(30, 4)
+    h.rollout_init(0.05, cum, g["s"][:4], g["pose"][:4])
+    h.rollout_step(2)
+    ref = h.rollout_state()
+    h.download(4)                                   # reading results is fine
+    h.rollout_step(1)
+    h.solve(g["wp_id"][:2].astype(np.int32), g["x0"][:2], g["cc_prev"][:2], g["lb"][:2], g["ub"][:2])
+    with pytest.raises(mpmpc.MpmpcError, match="rollout_init"):
+        h.rollout_step(1)
+    with pytest.raises(mpmpc.MpmpcError):
+        h.rollout_state()
+    h.rollout_init(0.05, cum, ref["s"], ref["pose"], cc0=ref["cc"])
+    h.rollout_step(1)
+    assert np.all(h.rollout_state()["alive"] == 1)
+    h.close()
