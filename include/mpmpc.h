@@ -84,13 +84,18 @@ typedef struct {
   int32_t phase1;        /* 1: an instance the early polish attempt cannot certify is first tested for infeasibility -
                             least-squares phase 1 (every inequality row softened, nothing else in the cost) by the same
                             interior-point code; its multipliers are a Farkas ray, checked with OSQP's own
-                            primal-infeasibility criterion (eps_prim_inf) -> MPMPC_PRIMAL_INFEASIBLE after ~5-10
+                            primal-infeasibility criterion (at phase1_eps) -> MPMPC_PRIMAL_INFEASIBLE after ~5-10
                             interior-point iterations instead of hundreds or thousands of ADMM iterations; z then holds
                             the least-violation point, y the ray, resid[0] the largest bound violation of z.  What it
                             cannot decide runs the full ADMM as before.  0: OSQP's ADMM decides infeasibility. */
   double ipm_diverged;   /* the interior point gives up when mu exceeds this multiple of its smallest value so far
                             (multipliers blowing up: infeasible, phase 1 decides) */
   double phase1_theta;   /* start value of phase 1's slacks and multipliers (row space) */
+  double phase1_eps;     /* eps of OSQP's primal-infeasibility test when it is applied to phase 1's ray (default 1e-6).
+                            eps_prim_inf = 1e-4 is calibrated for ADMM's slowly converging dual steps; the interior-point
+                            ray satisfies |A'y| <= 1e-7 |y|, so the test can be sharper: an instance whose corridor
+                            cannot be met by a few tenths of a millimetre is still proved infeasible instead of being
+                            handed to the ADMM iteration (which calls it "solved" at eps = 1e-3; status 2). */
 } mpmpc_settings;
 
 const char* mpmpc_version(void);

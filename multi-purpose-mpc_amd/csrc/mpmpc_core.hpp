@@ -1062,8 +1062,8 @@ struct Solver {
                 sel(vm[j] & (lam < zero) & (bx.Lm[j] | bx.pin[j]), bx.lo[j] * lam, zero);
         }
         ny = L::gmax(ny); na = L::gmax(na); sup = L::gsum(sup);
-        const R thr = R(st.eps_prim_inf) * ny;
-        ok = ok | ((ny > R(st.eps_prim_inf)) & (na < thr) & (sup < -thr));
+        const R thr = R(st.phase1_eps) * ny;
+        ok = ok | ((ny > R(st.phase1_eps)) & (na < thr) & (sup < -thr));
       }
       conv = conv | (active & ok);
       active = active & !ok;
@@ -1513,7 +1513,7 @@ struct Solver {
   // ADMM run.)   min 1/2 |w|^2  s.t.  the dynamics rows and pinned entries as they are,  lo <= x_j + w_j <= hi  on every
   // other entry with a finite side.  Always feasible; optimum 0 iff the QP is feasible; and at its optimum the
   // multipliers y = (nu, zu - zl) satisfy A'y = 0 and  u'max(y,0) + l'min(y,0) = -|w|^2:  a Farkas ray.  The ray is
-  // then put to OSQP's own test (primal_infeasible: unscaled norms, eps_prim_inf) - a solver-independent verdict,
+  // then put to OSQP's own test (primal_infeasible: unscaled norms, at phase1_eps) - a solver-independent verdict,
   // reached in 5-10 interior-point iterations instead of the hundreds or thousands of ADMM iterations OSQP needs.
   // Certified instances: status PRIMAL_INFEASIBLE, x = least-violation point, (yeq, yb) = the ray, pri_res = largest
   // bound violation of x (unscaled).  Everything else is left untouched (status stays UNSOLVED).
@@ -1605,7 +1605,7 @@ struct Solver {
     MPMPC_UNROLL
     for (int i = 0; i < 3; ++i) L::cold_put(COLD_DYEQ + i, sel(vx, nus[i], zero));
     L::fence();
-    Mk cert = run & primal_infeasible(st.eps_prim_inf);
+    Mk cert = run & primal_infeasible(st.phase1_eps);
     R prim, stat;
     certificate(xs, nus, lam, st.cert_tol, prim, stat);
     MPMPC_UNROLL

@@ -399,7 +399,8 @@ static int check_settings(const mpmpc_settings* s) {
   if (s->polish == 2 && (!(s->ipm_reg > 0) || !(s->as_delta > 0) || !(s->ipm_tol > 0)))
     return fail(MPMPC_E_ARG, "polish needs ipm_reg, ipm_tol, as_delta > 0");
   if (s->phase1 != 0 && s->phase1 != 1) return fail(MPMPC_E_ARG, "phase1 must be 0 or 1");
-  if (!(s->ipm_diverged > 1) || !(s->phase1_theta > 0)) return fail(MPMPC_E_ARG, "need ipm_diverged > 1, phase1_theta > 0");
+  if (!(s->ipm_diverged > 1) || !(s->phase1_theta > 0) || !(s->phase1_eps > 0))
+    return fail(MPMPC_E_ARG, "need ipm_diverged > 1, phase1_theta > 0, phase1_eps > 0");
   return MPMPC_OK;
 }
 
@@ -439,6 +440,7 @@ void mpmpc_default_settings(mpmpc_settings* s) {
   s->phase1 = 1;
   s->ipm_diverged = 1e3;
   s->phase1_theta = 1.0;
+  s->phase1_eps = 1e-6;
 }
 
 int32_t mpmpc_stage_ld(int32_t N) { return host_stage_ld(N); }

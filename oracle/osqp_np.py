@@ -88,6 +88,9 @@ class Settings:
     phase1: int = 1             # polish=2: what the early attempt cannot certify is first tested for infeasibility
                                 # (least-squares phase 1 -> Farkas ray -> PRIMAL_INFEASIBLE) before any full ADMM run
     phase1_theta: float = 1.0   # start value of its slacks / multipliers
+    phase1_eps: float = 1e-6    # OSQP's primal-infeasibility test on phase 1's ray uses this eps: the interior-point ray is
+                                # accurate to ~1e-7 (|A'y| / |y|), so the test can be much sharper than eps_prim_inf = 1e-4,
+                                # which is calibrated for ADMM's slowly converging dual steps
 
 
 @dataclasses.dataclass
@@ -576,10 +579,10 @@ def _phase1(w: Workspace, st: Settings, x0=None):
     primal-infeasibility test (unscaled norms, eps_prim_inf) with y as the ray."""
     n, m = w.n, w.m
     soft = np.max(np.abs(w.A), axis=1) ** 2
-    stop = lambda x, y: _primal_infeasible(w, y, st.eps_prim_inf)
+    stop = lambda x, y: _primal_infeasible(w, y, st.phase1_eps)
     x, y, it, conv, _ = _ipm_refine(w, np.zeros(n) if x0 is None else x0, np.zeros(m), st, st.ipm_tol, st.phase1_theta,
                                     soft=soft, stop=stop)
-    return x, y, it, bool(_primal_infeasible(w, y, st.eps_prim_inf))
+    return x, y, it, bool(_primal_infeasible(w, y, st.phase1_eps))
 
 
 # ---------------------------------------------------------------------------

@@ -44,7 +44,7 @@ typedef struct {
   int32_t as_refine, as_rounds;
   double cert_tol;
   int32_t early_polish, early_scaling, phase1;
-  double ipm_diverged, phase1_theta;
+  double ipm_diverged, phase1_theta, phase1_eps;
 } oracle_settings;
 
 typedef struct {
@@ -533,7 +533,7 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
     }
     mu /= nb;
     if (res < tol && mu < tol) { conv = 1; break; }
-    if (soft && primal_infeasible(w, yy, st->eps_prim_inf, tn, tm)) { conv = 1; break; }
+    if (soft && primal_infeasible(w, yy, st->phase1_eps, tn, tm)) { conv = 1; break; }
     if (it == st->ipm_max_iter) break;
     /* mu of a feasible problem falls (nearly) monotonically; on an infeasible one the multipliers blow up within a few
        iterations: give up at once, phase 1 is what can decide such an instance */
@@ -759,7 +759,7 @@ static int phase1(work_t* w, double* x_out, double* y_out, oracle_info* info) {
   int nit = 0;
   ipm_refine(w, w->K, w->F, &cl, x, y, st->ipm_tol, st->phase1_theta, &nit, low, upp, soft);
   info->ipm_iters += nit;
-  int cert = primal_infeasible(w, y, st->eps_prim_inf, tn, tm);
+  int cert = primal_infeasible(w, y, st->phase1_eps, tn, tm);
   memcpy(w->P.x, Psave, sizeof(double) * pnnz); memcpy(w->q, qsave, sizeof(double) * n);
   if (cert) {
     for (int j = 0; j < n; ++j) x_out[j] = w->D[j] * x[j];

@@ -87,7 +87,7 @@ def main():
             elif r.status == O.PRIMAL_INFEASIBLE:
                 # infeasible capture: the least-violation point of phase 1 and the Farkas ray that proves it
                 X[c], Y[c] = r.x, r.y
-                f = O.farkas_certificate(A, l, u, r.y)
+                f = O.farkas_certificate(A, l, u, r.y, O.Settings().phase1_eps)
                 farkas[c] = f["support"], f["aty"]
                 assert f["ok"], (N, c, f)
             print("N=%d case %2d: status %2d, %4d ADMM + %2d interior-point iterations, certificate %.1e, obj %.9g (HiGHS %.9g)" %

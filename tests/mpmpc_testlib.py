@@ -116,9 +116,9 @@ def kkt_batch(qp, N, z, y):
     return prim, stat, np.maximum(comp(x, lo_x, hi_x, yx), comp(u, lo_u, hi_u, yu))
 
 
-def farkas_batch(qp, N, y, eps=1e-4):
+def farkas_batch(qp, N, y, eps=1e-6):
     """Vectorised check that the rays y [B, 8N+6] prove their QPs infeasible (OSQP's primal-infeasibility criterion,
-    plain numpy on K1's stage fields qp [27, B, LD], rows [dynamics; state boxes; input boxes] as in
+    plain numpy on K1's stage fields qp [27, B, LD]; eps = the library's phase1_eps; rows [dynamics; state boxes; input boxes] as in
     src/MPC.py:128-147):  |A'y|_inf <= eps |y|_inf  and  u'max(y,0) + l'min(y,0) <= -eps |y|_inf, with no multiplier
     mass on an infinite side.  -> (ok [B], support / |y| [B], |A'y| / |y| [B])"""
     B = qp.shape[1]

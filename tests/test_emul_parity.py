@@ -210,7 +210,7 @@ def test_emulated_kernels_reach_the_g5_optima_of_the_reference_qps(N, G, emu, tr
 # ---------------------------------------------------------------------------------------------------------------
 # Phase 1: infeasible instances leave with a Farkas ray after a few interior-point iterations
 # ---------------------------------------------------------------------------------------------------------------
-def _farkas_ok(qp_i, N, y, eps=1e-4):
+def _farkas_ok(qp_i, N, y, eps=1e-6):
     """OSQP's primal-infeasibility criterion on the dense (A, l, u) rebuilt from K1's fields: plain numpy."""
     Pd, q, A, l, u = T.qp_to_dense(qp_i, N)
     return O.farkas_certificate(A, l, u, y, eps)["ok"]

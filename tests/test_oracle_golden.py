@@ -108,7 +108,7 @@ def test_g5_solutions_are_kkt_points_of_the_reference_qps(N):
 @pytest.mark.parametrize("N", [3, 10, 30, 50])
 def test_g5_infeasible_captures_carry_a_farkas_ray(N):
     """Every capture G5 calls infeasible comes with a ray y that PROVES it on the reference's own (A, l, u):
-    |A'y| <= eps |y| and u'max(y,0) + l'min(y,0) <= -eps |y| (OSQP's criterion, eps_prim_inf = 1e-4) - checked here with
+    |A'y| <= eps |y| and u'max(y,0) + l'min(y,0) <= -eps |y| (OSQP's criterion at the oracle's phase1_eps = 1e-6) - checked here with
     plain numpy on the G4 data, independent of any solver.  And no capture is left in between: certified optimum or
     certified infeasible."""
     g4 = np.load(M.GOLDEN + "/g4_assembly_N%d.npz" % N)
@@ -124,9 +124,9 @@ def test_g5_infeasible_captures_carry_a_farkas_ray(N):
         # multipliers on an infinite side must vanish (a one-sided row only pushes one way)
         assert np.all(y[u >= 1e26] <= 0) and np.all(y[l <= -1e26] >= 0)
         nrm = np.max(np.abs(y))
-        assert np.max(np.abs(A.T @ y)) <= 1e-4 * nrm
-        assert np.sum(u * np.maximum(y, 0) + l * np.minimum(y, 0)) <= -1e-4 * nrm
-        f = O.farkas_certificate(A, g4["l"][c], g4["u"][c], y)
+        assert np.max(np.abs(A.T @ y)) <= 1e-6 * nrm
+        assert np.sum(u * np.maximum(y, 0) + l * np.minimum(y, 0)) <= -1e-6 * nrm
+        f = O.farkas_certificate(A, g4["l"][c], g4["u"][c], y, 1e-6)
         assert f["ok"] and abs(f["support"] - g5["farkas"][c, 0]) <= 1e-12 + 1e-9 * abs(f["support"])
         # and the ADMM iteration never ran beyond the early attempt
         assert g5["admm_iters"][c] == 1
@@ -150,8 +150,8 @@ def test_farkas_certificate_rejects_what_is_not_a_ray(otrack):
     r0 = O.solve(P, q, A, l, u, O.Settings(polish=2, phase1=0))          # OSQP's ADMM: hundreds of iterations, same verdict
     assert r1.status == r0.status == O.PRIMAL_INFEASIBLE
     assert r1.iters == 1 and r0.iters > 25
-    assert O.farkas_certificate(A, l, u, r1.y)["ok"]
-    assert not O.farkas_certificate(A, l, u, -r1.y)["ok"]
+    assert O.farkas_certificate(A, l, u, r1.y, 1e-6)["ok"]
+    assert not O.farkas_certificate(A, l, u, -r1.y, 1e-6)["ok"]
 
 
 @pytest.mark.parametrize("N", [3, 30])
