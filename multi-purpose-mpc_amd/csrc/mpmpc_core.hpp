@@ -1124,6 +1124,23 @@ struct Solver {
         for (int i = 0; i < 3; ++i) nreq[i] = -rp[i];
         MPMPC_TICK_BEGIN(12);
         kkt_solve_t<S>(rhs, nreq, dx, dnu);
+        if constexpr (SOFT) {
+          // One refinement step against the UN-regularised Newton matrix (phase 1 only: it is rare, and what it is
+          // asked for is a clean ray - |A'y| / |y| drops from ~1e-6 to ~1e-9, far below the margin phase1_eps asks
+          // of the support; the optimum of the hard problem is made by the refining active-set solve instead).
+          R Ad[3], Atd[E], r1[E], r2[3], ddx[E], ddn[3];
+          Aeq_mul_t<S>(dx, Ad);
+          AeqT_mul_t<S>(dnu, Atd);
+          MPMPC_UNROLL
+          for (int j = 0; j < E; ++j) r1[j] = rhs[j] - fma_(rcp_(h[j]) - reg, dx[j], Atd[j]);
+          MPMPC_UNROLL
+          for (int i = 0; i < 3; ++i) r2[i] = nreq[i] - Ad[i];
+          kkt_solve_t<S>(r1, r2, ddx, ddn);
+          MPMPC_UNROLL
+          for (int j = 0; j < E; ++j) dx[j] = dx[j] + sel(vm[j], ddx[j], zero);
+          MPMPC_UNROLL
+          for (int i = 0; i < 3; ++i) dnu[i] = dnu[i] + sel(vx, ddn[i], zero);
+        }
         MPMPC_TICK_END(12);
         // largest step that keeps slacks and multipliers positive: 1 / max(-ds/s, -dz/z)
         R blk(0.0);

@@ -447,7 +447,7 @@ def test_baseline_batch_sizes_carry_kkt_certificates(cfgid, B, track):
     # infeasible by so little (a tenth of a millimetre of corridor) that its ray stays below phase1_eps: ADMM at
     # eps = 1e-3 calls it solved, the polish cannot certify it, status 2 (one instance of config 5's 65 536)
     marginal = sol.status == 2
-    assert set(np.unique(sol.status)) <= {1, 2, -3} and marginal.sum() <= 4
+    assert set(np.unique(sol.status)) <= {1, 2, -3} and marginal.sum() <= 2
     assert np.all(sol.iters[~marginal, 0] == 1)
     if cfgid == 2:
         assert ok.all()
