@@ -38,34 +38,46 @@ HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
 FP64_VALU_PEAK = 78.6e12   # FLOP/s vector FP64 (spec)
 
 
-def algorithmic_bytes_per_solve(N, materialised=True):
-    """compulsory inputs + outputs per solve, plus the stage-blocked QP written by
-    K1 and read by K2 when the two-kernel split materialises it."""
-    inp = 8 * (7 * N + 3)
-    out = 8 * (5 * N + 3 + 2) + 8
-    qp = 2 * 8 * mpmpc.NUM_FIELDS * (N + 1) if materialised else 0
-    return inp + out + qp
+def algorithmic_bytes_per_solve(N):
+    """SURVEY.md 8(d), compulsory traffic of one solve, independent of the kernel design:
+    inputs  x0 (3) + per stage (kappa, v_ref, ds, lb, ub, cc_prev[2]) = 8 (7N + 3) B,
+    outputs z (5N + 3) + u0 (2) doubles + status / iterations 8 B    = 8 (5N + 5) + 8 B:   2 952 B at N = 30."""
+    return 8 * (7 * N + 3) + 8 * (5 * N + 3 + 2) + 8
 
 
 def k1_bytes_per_solve(N):
+    """the stand-alone assembly kernel (mpmpc_assemble, off the solve path): inputs + the stage-blocked QP it writes"""
     return 8 * (7 * N + 3) + 8 * mpmpc.NUM_FIELDS * (N + 1)
 
 
-def k2_bytes_per_solve(N):
-    # the solve launch assembles its own QP in registers: read wp_id, x0 (3), cc_prev (2N), lb, ub (N each); write
-    # z (5N+3), multipliers y (8N+6), u0, residuals, status, iterations.  (The stage-blocked QP is not materialised.)
-    return 4 + 8 * (3 + 4 * N) + 8 * (5 * N + 3 + 8 * N + 6 + 2 + 2) + 12
+# FP64 flops of one solve at the default settings, fitted on the instruction census of the lock-step emulation of the
+# SAME lane code (profiles/census.py; FMA = 2, other arithmetic = 1, compares / selects / lane moves = 0) as
+#     flops = c0 + c1 * interior-point iterations      (rms error 2.5-5 %)
+# "algorithmic": the structure-exploiting count of the implemented recurrence (SURVEY 8d) - lane-parallel instructions
+#   count for the lanes that hold a stage, every serial sweep of the twisted factorisation / substitutions counts ONE
+#   step per stage (per stage: factor 180 flops, KKT solve 110).
+# "executed": every wave instruction times the N + 1 stage-holding lanes, serial steps as often as they are executed
+#   (round 1's figure).
+# key: (one lane per stage with the split interior-point layout, i.e. N + 1 <= 32;  certified optimal / Farkas-certified)
+_FLOPS = {
+    (True, 1): dict(algorithmic=(81447.0, 40273.0), executed=(300857.0, 96760.0), N=30),
+    (True, -3): dict(algorithmic=(132612.0, 42339.0), executed=(318920.0, 104347.0), N=30),
+    (False, 1): dict(algorithmic=(47970.0, 64030.0), executed=(215726.0, 288391.0), N=50),
+}
 
 
-def k2_flops_per_solve(N, admm_iters, ipm_iters):
-    """Useful FP64 flops of one solve: per-lane instruction census of the lock-step emulation
-    (profiles/census.py: tests/emul with -DMPMPC_COUNT_OPS; FMA = 2, add/mul/div/sqrt = 1) times the
-    N+1 lanes that hold a stage.  Fitted per lane as setup + a * ADMM iterations + b * interior-point
-    iterations (active-set rounds and certificate amortised into b) at N = 30 and N = 50, linear in N
-    between: 2816 + 844 a + 3985 b and 0 + 1434 a + 7097 b (rms error 5 %).  DESIGN.md section 5."""
-    t = (N - 30) / 20.0
-    c0, c1, c2 = 2816 + t * (0 - 2816), 843.6 + t * (1434 - 843.6), 3985 + t * (7097 - 3985)
-    return (N + 1) * (c0 + c1 * admm_iters + c2 * ipm_iters)
+def k2_flops(N, status, ipm_iters, kind):
+    """flops of a batch by the fit above, scaled linearly in the number of stages away from the fitted horizon"""
+    total = 0.0
+    split = N + 1 <= 32
+    for stt in (1, -3):
+        m = (status == stt) if stt == -3 else (status != -3)
+        if not m.any():
+            continue
+        f = _FLOPS.get((split, stt)) or _FLOPS[(split, 1)]
+        c0, c1 = f[kind]
+        total += float(np.sum(c0 + c1 * ipm_iters[m].astype(float))) * (N + 1) / (f["N"] + 1)
+    return total
 
 
 def cpu_baseline(tr, sc, seconds=10.0):
@@ -113,19 +125,27 @@ def stock_osqp_leg(tr, sc, ref, seconds=3.0):
         return {"available": True, "note": "stock-osqp leg failed: %r" % (e,)}
 
 
-def pmc_traffic_bytes(kernel_prefix, B):
+def pmc_traffic_bytes(kernel_prefix, B, lib_version):
     """HBM bytes per launch of one kernel from the committed rocprofv3 PMC summary of THIS command
-    (profiles/r1/pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  None when no summary for this batch size exists."""
-    path = os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")
+    (profiles/r2/pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  The summary records the source hash of the library it was measured
+    on: the figure is only reported when the library running now was built from the same sources, otherwise None
+    (with the reason) - a counter reading of another kernel is not this run's traffic."""
+    path = os.path.join(ROOT, "profiles", "r2", "pmc_summary.json")
     key_f, key_w = ("pmc_fetch", "pmc_write") if B == 1024 else ("pmc_fetch_b%d" % B, "pmc_write_b%d" % B)
     try:
         d = json.load(open(path))
+    except Exception:
+        return None, "no PMC summary committed (profiles/r2/pmc_summary.json)"
+    src = d.get("library_source_hash", "")
+    if not src or src not in lib_version:
+        return None, "profiles/r2/pmc_summary.json was measured on library sources %s, this run is %s" % (src or "?", lib_version)
+    try:
         f = next(v for k, v in d[key_f].items() if k.startswith(kernel_prefix))["FETCH_SIZE"]["mean"]
         w = next(v for k, v in d[key_w].items() if k.startswith(kernel_prefix))["WRITE_SIZE"]["mean"]
-        return (2.0 * f + w) * 1024.0
+        return (2.0 * f + w) * 1024.0, "profiles/r2/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same library sources %s)" % src
     except Exception:
-        return None
+        return None, "profiles/r2/pmc_summary.json has no counters for this kernel at B = %d" % B
 
 
 def main():
@@ -190,6 +210,7 @@ def main():
     h = mpmpc.Handle(cfg, settings)
     h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
     h.set_packing(args.lanes)
+    h.set_outputs(want_y=False)          # the step needs (u0, z, status): no multipliers are stored
     h.upload(wp, x0, cc, lb, ub)          # inputs resident in HBM before the timed region
 
     def barrier():
@@ -257,24 +278,35 @@ def main():
         }
         if gather_check is not None:
             out["gather_check"] = gather_check
-        bytes_k2 = k2_bytes_per_solve(N) * B
+        lib_version = h.lib.mpmpc_version().decode()
+        out["library"] = lib_version
+        bytes_k2 = algorithmic_bytes_per_solve(N) * B
+        traffic, traffic_src = pmc_traffic_bytes("mpmpc_solve_kernel", B, lib_version) if args.config == 2 else (None, "PMC passes are collected for config 2 only")
         out["roofline"] = {"bound": "hbm", "kernel": "mpmpc_solve_kernel", "achieved": bytes_k2 / (ms_k2 * 1e-3) / 1e9,
                            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bytes_k2 / (ms_k2 * 1e-3) / HBM_PEAK,
-                           "traffic": pmc_traffic_bytes("mpmpc_solve_kernel", B) if args.config == 2 else None,
-                           "algorithmic_bytes": bytes_k2, "avg_ms": ms_k2,
-                           "note": "K2 is FP64-VALU / dependency-chain bound, not HBM bound (DESIGN.md section 5)"}
-        flops_k2 = float(np.sum(k2_flops_per_solve(N, sol.iters[:, 0].astype(float), sol.iters[:, 1].astype(float))))
-        out["roofline_fp64"] = {"bound": "fp64-valu", "kernel": "mpmpc_solve_kernel",
-                                "achieved": flops_k2 / (ms_k2 * 1e-3) / 1e12, "peak": FP64_VALU_PEAK / 1e12,
-                                "unit": "TFLOP/s", "frac": flops_k2 / (ms_k2 * 1e-3) / FP64_VALU_PEAK,
-                                "flops_per_solve_mean": flops_k2 / B,
-                                "note": "useful flops (N+1 of an instance's lanes hold a stage); the slowest wave sets the time"}
+                           "traffic": traffic, "traffic_source": traffic_src,
+                           "algorithmic_bytes": bytes_k2, "bytes_per_solve": algorithmic_bytes_per_solve(N), "avg_ms": ms_k2,
+                           "note": "SURVEY 8(d) bytes: 8(7N+3) in + 8(5N+5)+8 out per solve; the launch writes no multipliers here "
+                                   "(mpmpc_set_outputs(0)).  K2 is FP64-VALU / dependency-chain bound, not HBM bound (DESIGN.md "
+                                   "section 5): see roofline_fp64"}
+        ipm = sol.iters[:, 1]
+        fa, fe = k2_flops(N, sol.status, ipm, "algorithmic"), k2_flops(N, sol.status, ipm, "executed")
+        out["roofline_fp64"] = {"bound": "fp64-valu", "kernel": "mpmpc_solve_kernel", "peak": FP64_VALU_PEAK / 1e12, "unit": "TFLOP/s",
+                                "achieved": fa / (ms_k2 * 1e-3) / 1e12, "frac": fa / (ms_k2 * 1e-3) / FP64_VALU_PEAK,
+                                "frac_algorithmic": fa / (ms_k2 * 1e-3) / FP64_VALU_PEAK,
+                                "frac_executed": fe / (ms_k2 * 1e-3) / FP64_VALU_PEAK,
+                                "flops_per_solve_algorithmic": fa / B, "flops_per_solve_executed": fe / B,
+                                "note": "algorithmic = structure-exploiting count of the implemented recurrence (one step per stage "
+                                        "and serial sweep; per stage: factor 180, KKT solve 110 flops); executed = wave "
+                                        "instructions x stage-holding lanes; both fitted on the census of the emulated lane "
+                                        "code (profiles/census.py, bench.py:_FLOPS)"}
         bytes_k1 = k1_bytes_per_solve(N) * B
-        out["roofline_assembly"] = {"bound": "hbm", "kernel": "mpmpc_assemble_kernel",
+        out["roofline_assembly"] = {"bound": "hbm", "kernel": "mpmpc_assemble_kernel", "on_solve_path": False,
                                     "achieved": bytes_k1 / (ms_k1 * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
                                     "unit": "GB/s", "frac": bytes_k1 / (ms_k1 * 1e-3) / HBM_PEAK, "avg_ms": ms_k1,
-                                    "traffic": pmc_traffic_bytes("mpmpc_assemble_kernel", B) if args.config == 2 else None,
-                                    "algorithmic_bytes": bytes_k1}
+                                    "algorithmic_bytes": bytes_k1,
+                                    "note": "the stand-alone K1 (mpmpc_assemble, parity / debug export) timed beside the solve "
+                                            "launch; the solve launch assembles its own QP in registers"}
         st, cnt = np.unique(sol.status, return_counts=True)
         out["status_counts"] = {int(s): int(c) for s, c in zip(st, cnt)}
         out["iters"] = {"admm_mean": float(sol.iters[:, 0].mean()), "admm_max": int(sol.iters[:, 0].max()),

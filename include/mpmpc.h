@@ -198,6 +198,10 @@ int mpmpc_solve(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x
 int mpmpc_upload(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x0,
                  const double* cc_prev, const double* lb, const double* ub);
 int mpmpc_solve_resident(mpmpc_handle h, int32_t B);
+/* Do resident launches store the multipliers y (46 % of a solve's output bytes)?  Default 1.  mpmpc_solve decides per
+ * call (y == NULL: not stored), the closed-loop rollout never stores them.  mpmpc_download refuses a y the last launch
+ * did not produce. */
+int mpmpc_set_outputs(mpmpc_handle h, int32_t want_y);
 int mpmpc_sync(mpmpc_handle h);
 int mpmpc_download(mpmpc_handle h, int32_t B, double* z, double* u0, int32_t* status,
                    int32_t* iters, double* resid, double* y);

@@ -14,9 +14,30 @@ constexpr int EMU_W = 64;
 // Optional instruction census (tests/emul built with -DMPMPC_COUNT_OPS): wave-level FP64
 // instructions by class, used to state the algorithmic flop count of a solve in DESIGN.md.
 #ifdef MPMPC_COUNT_OPS
+// Counters by execution context (mpmpc_core.hpp marks the contexts): 0 = lane-parallel code, one stage per lane;
+// 1 = lane-parallel code in the split layout of the interior point (states on lanes 0..31, inputs on 32..63);
+// 2 = inside a serial sweep of the twisted factorisation / substitution (every step is executed by all lanes, but
+// each stage's step does useful work exactly once per sweep).  serial_useful accumulates, per sweep, the flops of
+// ONE step (section flops / steps): multiplied by the N + 1 stages that is the structure-exploiting flop count.
 struct OpCount { long long fma, addmul, div, sqrt, cmpsel, shift, reduce; };
-inline OpCount& op_count() { static OpCount c{0, 0, 0, 0, 0, 0, 0}; return c; }
+struct OpCensus {
+  OpCount c[3];
+  int mode = 0;
+  double serial_useful = 0.0;
+  long long mark = 0;
+};
+inline OpCensus& op_census() { static OpCensus s{}; return s; }
+inline OpCount& op_count() { return op_census().c[op_census().mode]; }
+inline long long op_flops(const OpCount& c) { return 2 * c.fma + c.addmul + c.div + c.sqrt; }
 #define MPMPC_OP(f) (++op_count().f)
+struct OpModeScope {          // RAII: contexts nest (a sweep inside the split interior point)
+  int prev;
+  explicit OpModeScope(int m) : prev(op_census().mode) { op_census().mode = m; }
+  ~OpModeScope() { op_census().mode = prev; }
+};
+#define MPMPC_COUNT_CONTEXT(m) OpModeScope mpmpc_count_scope_(m)
+#define MPMPC_SERIAL_BEGIN() OpModeScope mpmpc_serial_scope_(2); op_census().mark = op_flops(op_census().c[2])
+#define MPMPC_SERIAL_END(nsteps) op_census().serial_useful += double(op_flops(op_census().c[2]) - op_census().mark) / double((nsteps) > 0 ? (nsteps) : 1)
 #else
 #define MPMPC_OP(f) ((void)0)
 #endif

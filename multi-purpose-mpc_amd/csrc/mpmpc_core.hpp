@@ -31,6 +31,11 @@
 #ifndef MPMPC_HOST_DEVICE
 #define MPMPC_HOST_DEVICE
 #endif
+#ifndef MPMPC_COUNT_CONTEXT      // instruction census of the emulation (lane_emu.hpp, -DMPMPC_COUNT_OPS)
+#define MPMPC_COUNT_CONTEXT(m) ((void)0)
+#define MPMPC_SERIAL_BEGIN() ((void)0)
+#define MPMPC_SERIAL_END(nsteps) ((void)0)
+#endif
 
 namespace mpmpc {
 
@@ -527,10 +532,12 @@ struct Solver {
       M[6] = To[6] * i00; M[7] = To[6] * i10;                   M[8] = fma_(To[8], i22, To[6] * i20);
     };
     {
+      MPMPC_SERIAL_BEGIN();
       int s = 0;                                   // two steps per trip (see s_solve), then the junction step
       for (; s + 2 <= last; s += 2) { fstep(false); fstep(false); }
       for (; s < last; ++s) fstep(false);
       fstep(true);
+      MPMPC_SERIAL_END(last + 1);
     }
     // recurrence matrices of the two substitution sweeps (stored negated, so a sweep step is 9 FMAs):
     //   inward    y_k  = inv(L_kk) b_k + Gin_k y_pred,        Gin_k  = -inv(L_kk) M_in
@@ -569,12 +576,15 @@ struct Solver {
       y2 = fma_(Gin[8], p2, fma_(Gin[7], p1, fma_(Gin[6], p0, c2)));
     };
     {
+      MPMPC_SERIAL_BEGIN();
       int s = 0;
       for (; s + 4 <= last; s += 4) { in_step(); in_step(); in_step(); in_step(); }
       for (; s < last; ++s) in_step();
+      MPMPC_SERIAL_END(last);
     }
     {
       // inward junction: the end lane forms M_own y, mid takes it on top of its chain input
+      MPMPC_SERIAL_BEGIN();                        // (census: useful on the two lanes of the junction only)
       R t0 = fma_(Gout[2], y2, fma_(Gout[1], y1, Gout[0] * y0));
       R t1 = fma_(Gout[5], y2, fma_(Gout[4], y1, Gout[3] * y0));
       R t2 = fma_(Gout[8], y2, fma_(Gout[7], y1, Gout[6] * y0));
@@ -589,12 +599,14 @@ struct Solver {
       y0 = fma_(Gin[2], p2, fma_(Gin[1], p1, fma_(Gin[0], p0, e0)));
       y1 = fma_(Gin[5], p2, fma_(Gin[4], p1, fma_(Gin[3], p0, e1)));
       y2 = fma_(Gin[8], p2, fma_(Gin[7], p1, fma_(Gin[6], p0, e2)));
+      MPMPC_SERIAL_END(N + 1);
     }
     R d0 = fma_(Li[3], y2, fma_(Li[1], y1, Li[0] * y0));
     R d1 = fma_(Li[4], y2, Li[2] * y1);
     R d2 = Li[5] * y2;
     {
       // outward junction: nu of mid is final (it has no successor); the end lane takes it through M_own'
+      MPMPC_SERIAL_BEGIN();
       const R zero(0.0);
       R m0 = sel(is_end, L::mirror(L::up(d0)), zero);
       R m1 = sel(is_end, L::mirror(L::up(d1)), zero);
@@ -605,6 +617,7 @@ struct Solver {
       d0 = d0 - fma_(Li[3], w2, fma_(Li[1], w1, Li[0] * w0));
       d1 = d1 - fma_(Li[4], w2, Li[2] * w1);
       d2 = d2 - Li[5] * w2;
+      MPMPC_SERIAL_END(N + 1);
     }
     R n0(0.0), n1(0.0), n2(0.0);
     auto out_step = [&]() {
@@ -614,9 +627,11 @@ struct Solver {
       n2 = fma_(Gout[8], p2, fma_(Gout[7], p1, fma_(Gout[6], p0, d2)));
     };
     {
+      MPMPC_SERIAL_BEGIN();
       int s = 0;
       for (; s + 4 <= last + 1; s += 4) { out_step(); out_step(); out_step(); out_step(); }
       for (; s <= last; ++s) out_step();
+      MPMPC_SERIAL_END(last + 1);
     }
     nu[0] = L::mirror(n0); nu[1] = L::mirror(n1); nu[2] = L::mirror(n2);
   }
@@ -1015,6 +1030,7 @@ struct Solver {
   MPMPC_HD Mk ipm(const BoxT<S>& bx, IpmT<S>& s, const R* pp, const R* qq, const Mk* vm, const SolverParams& st,
                   double tol, const Mk& run) {
     constexpr int E = EN<S>;
+    MPMPC_COUNT_CONTEXT(S ? 1 : 0);
     const R reg(st.ipm_reg), ireg(st.inv_ipm_reg), one(1.0), zero(0.0);
     Mk active = run, conv = L::mfalse();
     R cnt(0.0);

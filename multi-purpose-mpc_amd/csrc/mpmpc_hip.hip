@@ -382,6 +382,8 @@ struct mpmpc_handle_s {
   // instances the early pass of a packed (2 or 4 per wave) launch could not certify: [0] = count, [1..] = ids
   int* tail = nullptr;
   int force_lanes = 0;      // mpmpc_set_packing: 0 = chosen from the batch size
+  bool resident_y = true;   // mpmpc_set_outputs: do resident launches store the multipliers y (46 % of the output bytes)?
+  bool y_valid = false;     // the last solve launch stored y
 };
 
 static int host_stage_ld(int N) { return N + 1 <= 16 ? 16 : (N + 1 <= 32 ? 32 : 64); }
@@ -405,7 +407,7 @@ static int check_settings(const mpmpc_settings* s) {
 }
 
 static int launch_assemble(mpmpc_handle h, int B);
-static int launch_solve(mpmpc_handle h, int B, bool closed_loop = false);
+static int launch_solve(mpmpc_handle h, int B, bool closed_loop = false, bool want_y = true);
 
 extern "C" {
 
@@ -752,7 +754,7 @@ int mpmpc_rollout_step(mpmpc_handle h, int32_t B, int32_t n_steps) {
   for (int t = 0; t < n_steps; ++t) {
     hipLaunchKernelGGL(mpmpc_localise_kernel, dim3(blocks), dim3(256), 0, h->stream, B, h->n_wp, h->ro_cum, h->gx, h->gy,
                        h->gpsi, h->ro_s, h->ro_pose, h->ro_alive, h->wp_id, h->x0, h->ro_shift);
-    if (int rc = launch_solve(h, B, true)) return rc;
+    if (int rc = launch_solve(h, B, true, false)) return rc;      // (the plant step reads z and the status only)
     hipLaunchKernelGGL(mpmpc_advance_kernel, dim3((B * h->cfg.N + 255) / 256), dim3(256), 0, h->stream, B, h->cfg.N, h->cfg.wheelbase, h->ro_Ts,
                        h->kappa, h->wp_id, h->x0, h->status, h->z, h->cc, h->ro_counter, h->ro_alive, h->ro_pose, h->ro_s,
                        h->ro_u);
@@ -850,8 +852,10 @@ static int launch_assemble(mpmpc_handle h, int B) {
   return MPMPC_OK;
 }
 
-static int launch_solve(mpmpc_handle h, int B, bool closed_loop) {
+static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y) {
   const int N = h->cfg.N;
+  double* y_out = want_y ? h->y : nullptr;        // nobody wants the multipliers: the kernel skips their stores
+  h->y_valid = want_y;
   AssembleIn ain;
   ain.tab = PathTables{h->kappa, h->v_ref, h->ds_next, h->n_wp, h->ub_tab, h->lb_tab, h->n_cols};
   ain.wp_id = h->wp_id; ain.x0 = h->x0; ain.cc = h->cc;
@@ -877,7 +881,7 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop) {
   const int first_mode = (G < 64 && early) ? 1 : 0;      // packed launches hand their tail to a second one
 #define LAUNCH_W(GG, CC, WW, MODE, BLOCKS)                                                                            \
   hipLaunchKernelGGL((mpmpc_solve_kernel<GG, CC, WW>), dim3(BLOCKS), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, \
-                     ain, h->z, h->u0, h->status, h->iters, h->resid, h->y, MODE, h->tail, warm_act, warm_shift)
+                     ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, MODE, h->tail, warm_act, warm_shift)
 #define LAUNCH(GG, CC, MODE, BLOCKS)                                \
   do {                                                              \
     if (warm_act) LAUNCH_W(GG, CC, true, MODE, BLOCKS);             \
@@ -904,7 +908,13 @@ int mpmpc_solve_resident(mpmpc_handle h, int32_t B) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
   if (B < 1 || B > h->uploaded) return fail(MPMPC_E_STATE, "B exceeds the uploaded batch");
   HIP_TRY(hipSetDevice(h->cfg.device));
-  return launch_solve(h, B);      // one launch: the assembly runs inside K2
+  return launch_solve(h, B, false, h->resident_y);      // one launch: the assembly runs inside K2
+}
+
+int mpmpc_set_outputs(mpmpc_handle h, int32_t want_y) {
+  if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  h->resident_y = want_y != 0;
+  return MPMPC_OK;
 }
 
 int mpmpc_solve_resident_timed(mpmpc_handle h, int32_t B, float* ms_assemble, float* ms_solve) {
@@ -914,7 +924,7 @@ int mpmpc_solve_resident_timed(mpmpc_handle h, int32_t B, float* ms_assemble, fl
   HIP_TRY(hipEventRecord(h->ev[0], h->stream));
   if (int rc = launch_assemble(h, B)) return rc;
   HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-  if (int rc = launch_solve(h, B)) return rc;
+  if (int rc = launch_solve(h, B, false, h->resident_y)) return rc;
   HIP_TRY(hipEventRecord(h->ev[2], h->stream));
   HIP_TRY(hipEventSynchronize(h->ev[2]));
   float a = 0.f, s = 0.f;
@@ -1001,6 +1011,8 @@ int mpmpc_download(mpmpc_handle h, int32_t B, double* z, double* u0, int32_t* st
                    double* resid, double* y) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
   if (B < 1 || B > h->uploaded) return fail(MPMPC_E_STATE, "B exceeds the uploaded batch");
+  if (y && !h->y_valid)
+    return fail(MPMPC_E_STATE, "the last solve launch did not store the multipliers (mpmpc_set_outputs(h, 0) / closed loop)");
   HIP_TRY(hipSetDevice(h->cfg.device));
   if (h->stage_out && B == h->laid_out) {
     // the whole batch was laid out for this B: one copy of the output block (without y, z when they are not wanted)
@@ -1053,7 +1065,8 @@ int mpmpc_solve(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x
                 const double* lb, const double* ub, double* z, double* u0, int32_t* status, int32_t* iters,
                 double* resid, double* y) {
   if (int rc = mpmpc_upload(h, B, wp_id, x0, cc_prev, lb, ub)) return rc;
-  if (int rc = mpmpc_solve_resident(h, B)) return rc;
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (int rc = launch_solve(h, B, false, y != nullptr)) return rc;      // no y asked for: none stored
   return mpmpc_download(h, B, z, u0, status, iters, resid, y);
 }
 

@@ -128,6 +128,7 @@ def load_library(path: str | None = None):
     lib.mpmpc_solve.argtypes = [h, C.c_int32, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _dp]
     lib.mpmpc_upload.argtypes = [h, C.c_int32, _ip, _dp, _dp, _dp, _dp]
     lib.mpmpc_solve_resident.argtypes = [h, C.c_int32]
+    lib.mpmpc_set_outputs.argtypes = [h, C.c_int32]
     lib.mpmpc_sync.argtypes = [h]
     lib.mpmpc_download.argtypes = [h, C.c_int32, _dp, _dp, _ip, _ip, _dp, _dp]
     lib.mpmpc_solve_resident_timed.argtypes = [h, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -140,7 +141,7 @@ def load_library(path: str | None = None):
 EXPORTS = ["mpmpc_version", "mpmpc_last_error", "mpmpc_device_count", "mpmpc_default_settings",
            "mpmpc_create", "mpmpc_destroy", "mpmpc_set_settings", "mpmpc_set_packing", "mpmpc_set_path", "mpmpc_set_corridor",
            "mpmpc_set_map", "mpmpc_set_path_geometry", "mpmpc_build_corridor", "mpmpc_rollout_init",
-           "mpmpc_rollout_step", "mpmpc_rollout_set_counters", "mpmpc_rollout_warm_start", "mpmpc_rollout_state", "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident",
+           "mpmpc_rollout_step", "mpmpc_rollout_set_counters", "mpmpc_rollout_warm_start", "mpmpc_rollout_state", "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident", "mpmpc_set_outputs",
            "mpmpc_sync", "mpmpc_download", "mpmpc_solve_resident_timed", "mpmpc_speed_profile"]
 
 
@@ -310,6 +311,10 @@ class Handle:
 
     def solve_resident(self, B):
         self._check(self.lib.mpmpc_solve_resident(self._h, B))
+
+    def set_outputs(self, want_y=True):
+        """resident launches store the multipliers y (default) or skip them (46 % of the output bytes)"""
+        self._check(self.lib.mpmpc_set_outputs(self._h, int(bool(want_y))))
 
     def sync(self):
         self._check(self.lib.mpmpc_sync(self._h))

@@ -1,16 +1,16 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for one round on the GPU box:
-#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash profiles/collect.sh r1'
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash profiles/collect.sh r2'
 # Raw output lands in gpurun_out/<round>/ (scratch); profiles/summarize.py turns it into the
 # committed summaries under profiles/<round>/.
 set -u
-ROUND=${1:-r1}
+ROUND=${1:-r2}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$ROUND
 mkdir -p "$O"
 cd "$R"
 python bench.py > "$O/bench_cfg2.json" 2> "$O/bench_cfg2.err"
-for c in 3 4; do python bench.py --config $c --steps 5 --warmup 1 > "$O/bench_cfg$c.json" 2>/dev/null; done
+for c in 3 4 5; do python bench.py --config $c --steps 20 --warmup 2 > "$O/bench_cfg$c.json" 2>/dev/null; done
 cd /tmp; export TMPDIR=/tmp
 prof() { out=$1; shift; rocprofv3 "$@" --output-format csv -d "$O/$out" -- python3 "$R/bench.py" ${BENCH_ARGS:-} --no-cpu > "$O/$out.json" 2>/dev/null; }
 BENCH_ARGS="" prof trace --kernel-trace --stats
@@ -18,6 +18,8 @@ BENCH_ARGS="--steps 5 --warmup 1" prof pmc_fetch --pmc FETCH_SIZE
 BENCH_ARGS="--steps 5 --warmup 1" prof pmc_write --pmc WRITE_SIZE
 BENCH_ARGS="--steps 5 --warmup 1" prof pmc_sq1 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 BENCH_ARGS="--steps 5 --warmup 1" prof pmc_sq2 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_FLAT
+BENCH_ARGS="--config 4 --steps 20 --warmup 2" prof trace_cfg4 --kernel-trace --stats
+BENCH_ARGS="--config 5 --steps 20 --warmup 2" prof trace_cfg5 --kernel-trace --stats
 BENCH_ARGS="--batch 65536 --steps 5 --warmup 1" prof trace_b65536 --kernel-trace --stats
 BENCH_ARGS="--batch 65536 --steps 3 --warmup 1" prof pmc_fetch_b65536 --pmc FETCH_SIZE
 BENCH_ARGS="--batch 65536 --steps 3 --warmup 1" prof pmc_write_b65536 --pmc WRITE_SIZE

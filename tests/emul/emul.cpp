@@ -111,19 +111,68 @@ extern "C" int emu_assemble(const mpmpc_config* cfg, int n_wp, const double* kap
 extern "C" int emu_stage_ld(int N) { return stage_ld(N); }
 
 // instruction census of everything executed since the last reset (only with -DMPMPC_COUNT_OPS)
+// out7: wave instructions by class, all contexts together
 extern "C" int emu_op_count(long long* out7, int reset) {
 #ifdef MPMPC_COUNT_OPS
-  OpCount& c = op_count();
-  out7[0] = c.fma; out7[1] = c.addmul; out7[2] = c.div; out7[3] = c.sqrt; out7[4] = c.cmpsel; out7[5] = c.shift; out7[6] = c.reduce;
-  if (reset) c = OpCount{0, 0, 0, 0, 0, 0, 0};
+  OpCensus& s = op_census();
+  for (int i = 0; i < 7; ++i) out7[i] = 0;
+  for (int m = 0; m < 3; ++m) {
+    const OpCount& c = s.c[m];
+    out7[0] += c.fma; out7[1] += c.addmul; out7[2] += c.div; out7[3] += c.sqrt; out7[4] += c.cmpsel; out7[5] += c.shift; out7[6] += c.reduce;
+  }
+  if (reset) s = OpCensus{};
   return 1;
 #else
   (void)out7; (void)reset;
   return 0;
 #endif
 }
+// out4: FP64 flops (FMA = 2) of the wave instructions by context - lane-parallel, lane-parallel in the split layout,
+// inside serial sweeps (as executed) - and the flops of ONE step per serial sweep (what a stage needs of it)
+extern "C" int emu_op_flops(double* out4, int reset) {
+#ifdef MPMPC_COUNT_OPS
+  OpCensus& s = op_census();
+  out4[0] = double(op_flops(s.c[0])); out4[1] = double(op_flops(s.c[1])); out4[2] = double(op_flops(s.c[2]));
+  out4[3] = s.serial_useful;
+  if (reset) s = OpCensus{};
+  return 1;
+#else
+  (void)out4; (void)reset;
+  return 0;
+#endif
+}
 
-// host run of the corridor code that the K0 kernels execute per thread
+// Structure-exploiting flop count of the two linear-algebra pieces every iteration is made of, measured on the
+// counting build: one factor() and one kkt_solve() of a <64,16> instance of horizon N with unit data.
+// out4: factor lane-parallel, factor one-serial-step, kkt_solve lane-parallel, kkt_solve one-step-per-sweep (summed)
+extern "C" int emu_census_pieces(int N, double* out4) {
+#ifdef MPMPC_COUNT_OPS
+  using L = LaneEmu<64, 16>;
+  if (N + 1 > 32) return 0;
+  Solver<L> s;
+  typename L::real fields[MPMPC_NUM_FIELDS];
+  for (int f = 0; f < MPMPC_NUM_FIELDS; ++f) fields[f] = VD(f == F_DS ? 0.05 : (f >= F_P ? 1.0 : (f >= F_HI && f < F_Q ? 1.0 : (f >= F_LO && f < F_HI ? -1.0 : 0.01))));
+  VI inst(0), k = L::stage() - lane_offset(64, 16, N);
+  s.load(fields, 1, inst, k, N);
+  VD h[5], rx[5], req[3], xt[5], nu[3];
+  for (int j = 0; j < 5; ++j) { h[j] = VD(0.5); rx[j] = VD(1.0); }
+  for (int i = 0; i < 3; ++i) req[i] = VD(1.0);
+  double o[4];
+  op_census() = OpCensus{};
+  s.factor(h, VD(1e-3));
+  out4[0] = double(op_flops(op_census().c[0])); out4[1] = op_census().serial_useful;
+  op_census() = OpCensus{};
+  s.kkt_solve(rx, req, xt, nu);
+  out4[2] = double(op_flops(op_census().c[0])); out4[3] = op_census().serial_useful;
+  op_census() = OpCensus{};
+  (void)o;
+  return 1;
+#else
+  (void)N; (void)out4;
+  return 0;
+#endif
+}
+
 extern "C" int emu_corridor(int height, int width, const int8_t* data, double ox, double oy, double res, int n_wp,
                             const double* x, const double* y, const double* psi, const double* ds_next, int circular,
                             const double* bub, const double* blb, int n_cols, double min_width, double safety_margin,
