@@ -21,11 +21,18 @@
 #ifndef MPMPC_HD
 #define MPMPC_HD inline
 #endif
+#ifndef MPMPC_HOST_DEVICE
+#define MPMPC_HOST_DEVICE
+#endif
 
 namespace mpmpc {
 
-constexpr int COR_MAXSEG = 8;       // free segments kept per waypoint (Sim_Track needs at most 3)
+constexpr int COR_MAXSEG = 8;       // free segments kept per waypoint (Sim_Track needs at most 3); more is an ERROR, not a cut
+constexpr int COR_CELL_CAP = 1024;  // cells of one rasterised border line the device stages (Sim_Track: ~95); more is an error
+constexpr int COR_MAX_SIDE = 65534; // map cells per side (cell coordinates travel as 16-bit pairs with a +1 bias)
+constexpr int COR_E_SEGMENTS = -1, COR_E_CELLS = -2;      // return values of the free-segment scans
 constexpr double COR_PI = 3.141592653589793;
+constexpr int COR_TRIG = 6;         // per-waypoint trigonometric constants, computed ONCE ON THE HOST (cor_trig_row)
 
 struct MapView {
   const int8_t* data;   // [height x width], 1 free / 0 occupied
@@ -33,7 +40,7 @@ struct MapView {
   double ox, oy, res;
 };
 
-MPMPC_HD void cor_w2m(const MapView& m, double x, double y, int& dx, int& dy) {
+MPMPC_HOST_DEVICE inline void cor_w2m(const MapView& m, double x, double y, int& dx, int& dy) {
   dx = (int)std::floor((x - m.ox) / m.res);
   dy = (int)std::floor((y - m.oy) / m.res);
 }
@@ -41,12 +48,27 @@ MPMPC_HD void cor_m2w(const MapView& m, int dx, int dy, double& x, double& y) {
   x = (dx + 0.5) * m.res + m.ox;
   y = (dy + 0.5) * m.res + m.oy;
 }
-MPMPC_HD double cor_wrap(double a) {   // np.mod(a + pi, 2 pi) - pi  (result of np.mod has the divisor's sign)
+// Occupancy of a cell; anything outside the grid counts as occupied.  (The border cells themselves are validated on
+// the host; the anti-aliased neighbours of a line along the map edge may step one cell outside.  The reference would
+// raise IndexError past the upper edges and silently wrap around at -1.)
+MPMPC_HD bool cor_cell_free(const MapView& m, int x, int y) {
+  return (unsigned)x < (unsigned)m.width && (unsigned)y < (unsigned)m.height && m.data[(long)y * m.width + x] == 1;
+}
+// The six numbers of a waypoint that need libm: cos / sin of its heading (forward projection of the previous borders,
+// src/reference_path.py:559-562) and of the two normals psi +- pi/2 wrapped to (-pi, pi] (src/reference_path.py:
+// 624-631).  Computed by the host's libm - the same one numpy's results in golden G3 agree with bit for bit - in
+// mpmpc_set_path_geometry, so that the device tables contain no device-libm result at all.
+inline double cor_wrap_host(double a) {
   double t = std::fmod(a + COR_PI, 2.0 * COR_PI);
   if (t < 0.0) t += 2.0 * COR_PI;
   return t - COR_PI;
 }
-MPMPC_HD double cor_sign(double a) { return a > 0.0 ? 1.0 : (a < 0.0 ? -1.0 : 0.0); }
+inline void cor_trig_row(double psi, double* t) {
+  const double au = cor_wrap_host(COR_PI / 2 + psi), al = cor_wrap_host(-COR_PI / 2 + psi);
+  t[0] = std::cos(psi); t[1] = std::sin(psi);
+  t[2] = std::cos(au); t[3] = std::sin(au);
+  t[4] = std::cos(al); t[5] = std::sin(al);
+}
 
 // Scans the anti-aliased line from the upper border cell (r0,c0) to the lower one (r1,c1) and calls
 // visit(r, c) for every produced cell in skimage's order, the start cell included.
@@ -101,7 +123,8 @@ MPMPC_HD int cor_scan_cells(const MapView& m, int ux, int uy, int lx, int ly, do
       cor_m2w(m, sx, sy, ax, ay);
       cor_m2w(m, x, y, bx, by);
       const double len = std::sqrt((ax - bx) * (ax - bx) + (ay - by) * (ay - by));
-      if (len > min_width && count < COR_MAXSEG) {
+      if (len > min_width) {
+        if (count == COR_MAXSEG) return COR_E_SEGMENTS;
         seg[4 * count + 0] = ax; seg[4 * count + 1] = ay; seg[4 * count + 2] = bx; seg[4 * count + 3] = by;
         ++count;
       }
@@ -113,17 +136,20 @@ MPMPC_HD int cor_scan_cells(const MapView& m, int ux, int uy, int lx, int ly, do
   }
   return count;
 }
-// cells of the line (first one skipped) packed as (y << 15 | x) into idx[0..cap); returns how many there are
-// (possibly more than cap: the caller then takes the direct route, as it does for maps beyond 32767 cells a side)
-MPMPC_HD int cor_line_cells(const MapView& m, int ux, int uy, int lx, int ly, int* idx, int cap, int stride) {
+// cells of the line (first one skipped) as 16-bit pairs (x + 1) | (y + 1) << 16 into idx[0..cap); returns how many
+// there are (possibly more than cap: the caller reports COR_E_CELLS)
+MPMPC_HD int cor_line_cells(int ux, int uy, int lx, int ly, int* idx, int cap) {
   int n = -1;                                           // -1: the first cell is skipped
   cor_line_aa(ux, uy, lx, ly, [&](int x, int y) {
-    if (n >= 0 && n < cap) idx[(long)n * stride] = (y << 15) | x;
+    if (n >= 0 && n < cap) idx[n] = (x + 1) | ((y + 1) << 16);
     ++n;
   });
   return n;
 }
-// direct route: one thread walks the line and reads the grid as it goes
+MPMPC_HD void cor_unpack_cell(int id, int& x, int& y) { x = (id & 0xffff) - 1; y = ((id >> 16) & 0xffff) - 1; }
+// one thread walks the line and reads the grid as it goes (host emulation; the device stages the cells of a line in
+// LDS and lets the lanes of a wavefront fetch the occupancies: mpmpc_free_segments_kernel).  Returns the number of
+// free segments wider than min_width, or COR_E_SEGMENTS when there are more than COR_MAXSEG.
 MPMPC_HD int cor_free_segments(const MapView& m, double bux, double buy, double blx, double bly, double min_width,
                                double* seg) {
   int ux, uy, lx, ly;
@@ -131,19 +157,19 @@ MPMPC_HD int cor_free_segments(const MapView& m, double bux, double buy, double 
   cor_w2m(m, blx, bly, lx, ly);
   int count = 0;
   int sx = ux, sy = uy;       // start cell of the current run
-  bool in_free = false, first = true;
+  bool in_free = false, first = true, overflow = false;
   cor_line_aa(ux, uy, lx, ly, [&](int x, int y) {
     if (first) { first = false; return; }              // the reference skips the first cell (x_list[1:])
-    const bool is_free = m.data[(long)y * m.width + x] == 1;
+    const bool is_free = cor_cell_free(m, x, y);
     if (is_free) in_free = true;
     if ((!is_free || (x == lx && y == ly)) && in_free) {
       double ax, ay, bx, by;
       cor_m2w(m, sx, sy, ax, ay);
       cor_m2w(m, x, y, bx, by);
       const double len = std::sqrt((ax - bx) * (ax - bx) + (ay - by) * (ay - by));
-      if (len > min_width && count < COR_MAXSEG) {
-        seg[4 * count + 0] = ax; seg[4 * count + 1] = ay; seg[4 * count + 2] = bx; seg[4 * count + 3] = by;
-        ++count;
+      if (len > min_width) {
+        if (count == COR_MAXSEG) overflow = true;
+        else { seg[4 * count + 0] = ax; seg[4 * count + 1] = ay; seg[4 * count + 2] = bx; seg[4 * count + 3] = by; ++count; }
       }
       sx = x; sy = y;
       in_free = false;
@@ -151,48 +177,37 @@ MPMPC_HD int cor_free_segments(const MapView& m, double bux, double buy, double 
       sx = x; sy = y;
     }
   });
-  return count;
-}
-// staged route: cell list first (idx / val: cap entries each, element k at [k * stride]), then all occupancies,
-// then the scan.  Same result as cor_free_segments, bit for bit; falls back to it when the line is longer than cap.
-MPMPC_HD int cor_free_segments_staged(const MapView& m, double bux, double buy, double blx, double bly, double min_width,
-                                      double* seg, int* idx, int cap, int stride) {
-  int ux, uy, lx, ly;
-  cor_w2m(m, bux, buy, ux, uy);
-  cor_w2m(m, blx, bly, lx, ly);
-  if (m.width > 32767 || m.height > 32767) return cor_free_segments(m, bux, buy, blx, bly, min_width, seg);
-  const int n = cor_line_cells(m, ux, uy, lx, ly, idx, cap, stride);
-  if (n > cap) return cor_free_segments(m, bux, buy, blx, bly, min_width, seg);
-  // occupancies: independent loads, 32 in flight; bit 30 of the packed cell <- free
-  auto at = [&](int p) { return m.data[(long)(p >> 15) * m.width + (p & 32767)]; };
-  int k = 0;
-  constexpr int W = 32;                     // loads in flight per thread
-  for (; k + W <= n; k += W) {
-    int id[W], v[W];
-    for (int j = 0; j < W; ++j) id[j] = idx[(long)(k + j) * stride];
-    for (int j = 0; j < W; ++j) v[j] = at(id[j]);
-    for (int j = 0; j < W; ++j) idx[(long)(k + j) * stride] = id[j] | (v[j] == 1 ? (1 << 30) : 0);
-  }
-  for (; k < n; ++k) { const int id = idx[(long)k * stride]; idx[(long)k * stride] = id | (at(id) == 1 ? (1 << 30) : 0); }
-  return cor_scan_cells(m, ux, uy, lx, ly, min_width, n,
-                        [&](int c, int& x, int& y) { const int id = idx[(long)c * stride] & ((1 << 30) - 1); y = id >> 15; x = id & 32767; },
-                        [&](int c) { return (idx[(long)c * stride] >> 30) != 0; }, seg);
+  return overflow ? COR_E_SEGMENTS : count;
 }
 
 struct PathGeom {
   const double *x, *y, *psi, *ds_next;   // per waypoint; ds_next[i] = |wp[i+1] - wp[i]| (circular)
   int n_wp;
   int circular;
+  const double* trig;                    // [n_wp x COR_TRIG], cor_trig_row of every waypoint (host libm)
 };
+
+// sign(wrap(atan2(py - wy, px - wx) - psi)) without an arctangent: the wrapped angle between the heading and the
+// direction to the point is positive iff the point lies to the left of the heading, i.e. iff the cross product
+// cos(psi) dy - sin(psi) dx is positive; on the heading line itself the angle is 0 (ahead: sign 0) or pi, which
+// np.mod wraps to -pi (behind: sign -1).  Same value as the reference's expression (src/reference_path.py:598-603)
+// wherever that one is not itself decided by the last bit of its arctangent.
+MPMPC_HD double cor_side(double wx, double wy, double cpsi, double spsi, double px, double py) {
+  const double dx = px - wx, dy = py - wy;
+  const double cross = cpsi * dy - spsi * dx;
+  if (cross > 0.0) return 1.0;
+  if (cross < 0.0) return -1.0;
+  return (cpsi * dx + spsi * dy) < 0.0 ? -1.0 : 0.0;
+}
 
 // From the chosen border cells (pux, puy) / (plx, ply) of a waypoint to its bounds: sign by side, safety margin,
 // collapse, and the border cells of the selection WITHOUT the margin projected onto the waypoint's normal (what the
 // next waypoint of the horizon measures its candidates against).  o = ub, lb, prev_ux, prev_uy, prev_lx, prev_ly.
 constexpr int COR_WPC = 6;
-MPMPC_HD void cor_bounds(double wx, double wy, double wpsi, double pux, double puy, double plx, double ply,
+MPMPC_HD void cor_bounds(double wx, double wy, const double* tr, double pux, double puy, double plx, double ply,
                          double safety_margin, double* o) {
-  const double su = cor_sign(cor_wrap(std::atan2(puy - wy, pux - wx) - wpsi));
-  const double sl = cor_sign(cor_wrap(std::atan2(ply - wy, plx - wx) - wpsi));
+  const double su = cor_side(wx, wy, tr[0], tr[1], pux, puy);
+  const double sl = cor_side(wx, wy, tr[0], tr[1], plx, ply);
   double ub = su * std::sqrt((pux - wx) * (pux - wx) + (puy - wy) * (puy - wy));
   double lb = sl * std::sqrt((plx - wx) * (plx - wx) + (ply - wy) * (ply - wy));
   ub -= safety_margin;
@@ -200,11 +215,10 @@ MPMPC_HD void cor_bounds(double wx, double wy, double wpsi, double pux, double p
   if (ub < lb) { ub = 0.0; lb = 0.0; }
   o[0] = ub;
   o[1] = lb;
-  const double au = cor_wrap(COR_PI / 2 + wpsi), al = cor_wrap(-COR_PI / 2 + wpsi);
-  o[2] = wx + (ub + safety_margin) * std::cos(au);
-  o[3] = wy + (ub + safety_margin) * std::sin(au);
-  o[4] = wx - (lb - safety_margin) * std::cos(al);
-  o[5] = wy - (lb - safety_margin) * std::sin(al);
+  o[2] = wx + (ub + safety_margin) * tr[2];
+  o[3] = wy + (ub + safety_margin) * tr[3];
+  o[4] = wx - (lb - safety_margin) * tr[4];
+  o[5] = wy - (lb - safety_margin) * tr[5];
 }
 // A waypoint with at most one free segment leaves nothing to choose, whatever the horizon did before it: its
 // bounds are computed once per waypoint (phase 1) instead of once per (start waypoint, column) - on Sim_Track
@@ -212,8 +226,9 @@ MPMPC_HD void cor_bounds(double wx, double wy, double wpsi, double pux, double p
 MPMPC_HD void cor_forced(const PathGeom& g, const double* segs, const int* nseg, int i, double safety_margin, double* o) {
   const double wx = g.x[i], wy = g.y[i];
   const double* s = segs + (long)i * 4 * COR_MAXSEG;
-  if (nseg[i] == 1) cor_bounds(wx, wy, g.psi[i], s[0], s[1], s[2], s[3], safety_margin, o);
-  else cor_bounds(wx, wy, g.psi[i], wx, wy, wx, wy, safety_margin, o);
+  const double* tr = g.trig + (long)i * COR_TRIG;
+  if (nseg[i] == 1) cor_bounds(wx, wy, tr, s[0], s[1], s[2], s[3], safety_margin, o);
+  else cor_bounds(wx, wy, tr, wx, wy, wx, wy, safety_margin, o);
 }
 
 // One column of phase 2 when the waypoint has several free segments: the largest one at the first waypoint of the
@@ -221,7 +236,7 @@ MPMPC_HD void cor_forced(const PathGeom& g, const double* segs, const int* nseg,
 // of its cor_bounds output; ip = previous waypoint).  o <- this column's cor_bounds output.
 MPMPC_HD void cor_choose(const PathGeom& g, const double* segs, const int* nseg, int i, int ip, bool first,
                          const double* prev, double safety_margin, double* o) {
-  const double wx = g.x[i], wy = g.y[i], wpsi = g.psi[i];
+  const double wx = g.x[i], wy = g.y[i];
   const double* s = segs + (long)i * 4 * COR_MAXSEG;
   const int cnt = nseg[i];
   int best = 0;
@@ -234,7 +249,7 @@ MPMPC_HD void cor_choose(const PathGeom& g, const double* segs, const int* nseg,
     }
   } else {
     const double shift = g.ds_next[ip];            // wp_prev - wp (distance)
-    const double cp = std::cos(g.psi[ip]), sp = std::sin(g.psi[ip]);
+    const double cp = g.trig[(long)ip * COR_TRIG], sp = g.trig[(long)ip * COR_TRIG + 1];
     const double qux = prev[2] + shift * cp, quy = prev[3] + shift * cp;
     const double qlx = prev[4] + shift * sp, qly = prev[5] + shift * sp;
     double best_off = 0.0;
@@ -245,7 +260,7 @@ MPMPC_HD void cor_choose(const PathGeom& g, const double* segs, const int* nseg,
       if (k == 0 || off < best_off) { best_off = off; best = k; }
     }
   }
-  cor_bounds(wx, wy, wpsi, s[4 * best], s[4 * best + 1], s[4 * best + 2], s[4 * best + 3], safety_margin, o);
+  cor_bounds(wx, wy, g.trig + (long)i * COR_TRIG, s[4 * best], s[4 * best + 1], s[4 * best + 2], s[4 * best + 3], safety_margin, o);
 }
 MPMPC_HD int cor_wp(const PathGeom& g, int i) { return i >= g.n_wp ? (g.circular ? i % g.n_wp : g.n_wp - 1) : i; }
 

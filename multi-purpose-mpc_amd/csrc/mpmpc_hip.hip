@@ -21,6 +21,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #define MPMPC_HD __device__ __forceinline__
 #define MPMPC_HOST_DEVICE __host__ __device__
@@ -241,24 +242,46 @@ __global__ __launch_bounds__(64) void mpmpc_speed_profile_wave_kernel(int B, int
   if (threadIdx.x == 0) { status[p] = st; iters[p] = it; }
 }
 
-// K0a: free segments of every waypoint's border line (one thread per waypoint; the rasterised line
-// is at most a few hundred cells, the grid is read through L2).
-// (a waypoint with at most one free segment also gets its bounds here, once, instead of once per start waypoint
-//  and column in K0b: cor_forced)
+// K0a: free segments of every waypoint's border line, one WAVEFRONT per waypoint.  Lane 0 walks Zingl's anti-aliased
+// line (a float32 recurrence in skimage's exact cell order: inherently serial, ~95 cells on Sim_Track) and leaves the
+// cells in LDS; all 64 lanes then fetch the occupancies (one memory round trip for the whole line instead of one per
+// cell; cells outside the grid count as occupied); lane 0 runs the run-length state machine over the LDS copy and, for
+// a waypoint with at most one free segment, computes its bounds once (cor_forced) instead of once per start waypoint
+// and column in K0b.  A line longer than COR_CELL_CAP cells or with more than COR_MAXSEG free segments raises *err
+// (1 / 2) - mpmpc_build_corridor then fails instead of working with a truncated list.
 __global__ __launch_bounds__(64) void mpmpc_free_segments_kernel(MapView map, PathGeom g, const double* __restrict__ bub,
                                                                  const double* __restrict__ blb, double min_width,
                                                                  double safety_margin, double* __restrict__ segs,
-                                                                 int* __restrict__ nseg, double* __restrict__ wpc) {
-  // the cells of a thread's line wait in LDS (element k of thread t at [k * 64 + t]) so that their occupancies can be
-  // fetched several at a time instead of one round trip per cell
-  constexpr int CAP = 250;
-  __shared__ int cells[64 * CAP];
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= g.n_wp) return;
-  double seg[4 * COR_MAXSEG];
-  const int cnt = cor_free_segments_staged(map, bub[2 * i], bub[2 * i + 1], blb[2 * i], blb[2 * i + 1], min_width, seg,
-                                           cells + threadIdx.x, CAP, 64);
-  for (int k = 0; k < 4 * COR_MAXSEG; ++k) segs[(long)i * 4 * COR_MAXSEG + k] = k < 4 * cnt ? seg[k] : 0.0;
+                                                                 int* __restrict__ nseg, double* __restrict__ wpc,
+                                                                 int* __restrict__ err) {
+  __shared__ int cells[COR_CELL_CAP];
+  __shared__ unsigned char occ[COR_CELL_CAP];
+  __shared__ int s_n;
+  const int i = blockIdx.x, lane = threadIdx.x;
+  int ux, uy, lx, ly;
+  cor_w2m(map, bub[2 * i], bub[2 * i + 1], ux, uy);
+  cor_w2m(map, blb[2 * i], blb[2 * i + 1], lx, ly);
+  if (lane == 0) s_n = cor_line_cells(ux, uy, lx, ly, cells, COR_CELL_CAP);
+  __syncthreads();
+  const int n = s_n;
+  int cnt;
+  if (n > COR_CELL_CAP) {
+    cnt = COR_E_CELLS;
+  } else {
+    for (int k = lane; k < n; k += 64) {
+      int x, y;
+      cor_unpack_cell(cells[k], x, y);
+      occ[k] = cor_cell_free(map, x, y) ? 1 : 0;
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    double seg[4 * COR_MAXSEG];
+    cnt = cor_scan_cells(map, ux, uy, lx, ly, min_width, n, [&](int c, int& x, int& y) { cor_unpack_cell(cells[c], x, y); },
+                         [&](int c) { return occ[c] != 0; }, seg);
+    for (int k = 0; k < 4 * COR_MAXSEG; ++k) segs[(long)i * 4 * COR_MAXSEG + k] = (cnt > 0 && k < 4 * cnt) ? seg[k] : 0.0;
+  }
+  if (lane != 0) return;
+  if (cnt < 0) { atomicMax(err, cnt == COR_E_CELLS ? 1 : 2); cnt = 0; }
   nseg[i] = cnt;
   if (cnt <= 1) cor_forced(g, segs, nseg, i, safety_margin, wpc + (long)i * COR_WPC);
 }
@@ -351,9 +374,10 @@ struct mpmpc_handle_s {
   int8_t* map = nullptr;
   int map_h = 0, map_w = 0;
   double map_ox = 0, map_oy = 0, map_res = 0;
-  double *gx = nullptr, *gy = nullptr, *gpsi = nullptr, *bub = nullptr, *blb = nullptr, *segs = nullptr;
-  int *nseg = nullptr, *bad = nullptr;
+  double *gx = nullptr, *gy = nullptr, *gpsi = nullptr, *bub = nullptr, *blb = nullptr, *segs = nullptr, *gtrig = nullptr;
+  int *nseg = nullptr, *bad = nullptr;      // bad[0]: start waypoints without a free segment, bad[1]: K0a overflow code
   int geom_n = 0;
+  std::vector<double> host_bub, host_blb;   // border points, kept to validate them against the map of the moment
   // closed-loop rollout state
   double *ro_cum = nullptr, *ro_s = nullptr, *ro_pose = nullptr, *ro_u = nullptr;
   int *ro_counter = nullptr, *ro_alive = nullptr;
@@ -491,7 +515,7 @@ int mpmpc_destroy(mpmpc_handle h) {
   (void)hipSetDevice(h->cfg.device);
   void* ptrs[] = {h->kappa, h->v_ref, h->ds_next, h->ub_tab, h->lb_tab, h->in_block, h->out_block,
                   h->qp,    h->map, h->gx,  h->gy,
-                  h->gpsi,  h->bub,   h->blb,     h->segs,   h->nseg,   h->bad,    h->ro_cum, h->ro_s, h->ro_pose,
+                  h->gpsi,  h->bub,   h->blb,     h->segs,   h->nseg,   h->bad,    h->ro_cum, h->ro_s, h->ro_pose, h->gtrig,
                   h->ro_u,  h->ro_counter, h->ro_alive, h->tail, h->ro_act, h->ro_shift};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -624,6 +648,7 @@ int mpmpc_set_map(mpmpc_handle h, int32_t height, int32_t width, const int8_t* d
                   double origin_y, double resolution) {
   if (!h || !data) return fail(MPMPC_E_ARG, "NULL argument");
   if (height < 1 || width < 1 || !(resolution > 0)) return fail(MPMPC_E_ARG, "map needs positive size and resolution");
+  if (height > COR_MAX_SIDE || width > COR_MAX_SIDE) return fail(MPMPC_E_ARG, "map sides are limited to 65534 cells");
   HIP_TRY(hipSetDevice(h->cfg.device));
   if (h->map) { HIP_TRY(hipFree(h->map)); h->map = nullptr; }
   HIP_TRY(hipMalloc((void**)&h->map, (size_t)height * width));
@@ -643,9 +668,19 @@ int mpmpc_set_path_geometry(mpmpc_handle h, int32_t n_wp, const double* x, const
   if (int rc = upload_table(h, &h->gpsi, psi, n_wp)) return rc;
   if (int rc = upload_table(h, &h->bub, border_ub, 2 * (size_t)n_wp)) return rc;
   if (int rc = upload_table(h, &h->blb, border_lb, 2 * (size_t)n_wp)) return rc;
+  {
+    // everything of a waypoint that needs libm, from the HOST's libm: the device tables then hold no device-libm
+    // result (bit-exact against the reference's tables, golden G3)
+    std::vector<double> trig((size_t)n_wp * COR_TRIG);
+    for (int i = 0; i < n_wp; ++i) cor_trig_row(psi[i], trig.data() + (size_t)i * COR_TRIG);
+    if (int rc = upload_table(h, &h->gtrig, trig.data(), trig.size())) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));      // `trig` leaves scope
+  }
+  h->host_bub.assign(border_ub, border_ub + 2 * (size_t)n_wp);
+  h->host_blb.assign(border_lb, border_lb + 2 * (size_t)n_wp);
   if (h->segs) { HIP_TRY(hipFree(h->segs)); h->segs = nullptr; }
   if (h->nseg) { HIP_TRY(hipFree(h->nseg)); h->nseg = nullptr; }
-  if (!h->bad) HIP_TRY(hipMalloc((void**)&h->bad, sizeof(int)));
+  if (!h->bad) HIP_TRY(hipMalloc((void**)&h->bad, 2 * sizeof(int)));
   HIP_TRY(hipMalloc((void**)&h->segs, sizeof(double) * (4 * COR_MAXSEG + COR_WPC) * (size_t)n_wp));   // + cor_forced rows
   HIP_TRY(hipMalloc((void**)&h->nseg, sizeof(int) * (size_t)n_wp));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -668,20 +703,35 @@ int mpmpc_build_corridor(mpmpc_handle h, int32_t n_cols, double min_width, doubl
     HIP_TRY(hipMalloc((void**)&h->lb_tab, sizeof(double) * (size_t)n * n_cols));
   }
   MapView mv{h->map, h->map_h, h->map_w, h->map_ox, h->map_oy, h->map_res};
-  PathGeom pg{h->gx, h->gy, h->gpsi, h->ds_next, n, h->cfg.circular};
-  HIP_TRY(hipMemsetAsync(h->bad, 0, sizeof(int), h->stream));
-  const int blocks = (n + 63) / 64;
+  PathGeom pg{h->gx, h->gy, h->gpsi, h->ds_next, n, h->cfg.circular, h->gtrig};
+  // the border cells of every waypoint must lie on the map of the moment (numpy indexing in the reference raises
+  // IndexError past the upper edges and silently wraps around below zero: here both are an error)
+  for (int i = 0; i < n; ++i) {
+    int cx[2], cy[2];
+    cor_w2m(mv, h->host_bub[2 * i], h->host_bub[2 * i + 1], cx[0], cy[0]);
+    cor_w2m(mv, h->host_blb[2 * i], h->host_blb[2 * i + 1], cx[1], cy[1]);
+    for (int e = 0; e < 2; ++e)
+      if (cx[e] < 0 || cx[e] >= h->map_w || cy[e] < 0 || cy[e] >= h->map_h)
+        return fail(MPMPC_E_ARG, "border cell of waypoint " + std::to_string(i) + " lies outside the map");
+  }
+  HIP_TRY(hipMemsetAsync(h->bad, 0, 2 * sizeof(int), h->stream));
   double* wpc = h->segs + (size_t)4 * COR_MAXSEG * n;
-  hipLaunchKernelGGL(mpmpc_free_segments_kernel, dim3(blocks), dim3(64), 0, h->stream, mv, pg, h->bub, h->blb, min_width,
-                     safety_margin, h->segs, h->nseg, wpc);
+  hipLaunchKernelGGL(mpmpc_free_segments_kernel, dim3(n), dim3(64), 0, h->stream, mv, pg, h->bub, h->blb, min_width,
+                     safety_margin, h->segs, h->nseg, wpc, h->bad + 1);
   hipLaunchKernelGGL(mpmpc_corridor_select_kernel, dim3((n * n_cols + 255) / 256), dim3(256), 0, h->stream, pg, h->segs,
                      h->nseg, n_cols, safety_margin, h->ub_tab, h->lb_tab, h->bad, wpc);
   HIP_TRY(hipGetLastError());
-  int bad = 0;
-  HIP_TRY(hipMemcpyAsync(&bad, h->bad, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  int bad2[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(bad2, h->bad, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   if (ub_out) HIP_TRY(hipMemcpyAsync(ub_out, h->ub_tab, sizeof(double) * (size_t)n * n_cols, hipMemcpyDeviceToHost, h->stream));
   if (lb_out) HIP_TRY(hipMemcpyAsync(lb_out, h->lb_tab, sizeof(double) * (size_t)n * n_cols, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (bad2[1] != 0) {
+    h->n_cols = 0;        // the table is not usable
+    return fail(MPMPC_E_ARG, bad2[1] == 1 ? "a waypoint's border line has more than 1024 cells (COR_CELL_CAP)"
+                                           : "a waypoint's border line has more than 8 free segments (COR_MAXSEG)");
+  }
+  const int bad = bad2[0];
   if (bad_rows) *bad_rows = bad;
   h->n_cols = n_cols;
   return MPMPC_OK;
@@ -935,16 +985,17 @@ int mpmpc_solve_resident_timed(mpmpc_handle h, int32_t B, float* ms_assemble, fl
   return MPMPC_OK;
 }
 
-// device scratch of mpmpc_speed_profile, kept between calls (one per process; a call is a set-up step, and without
-// this its cost was allocation: 3.5 of 4 ms for a single path)
+// device scratch of mpmpc_speed_profile, kept between calls (a call is a set-up step, and without this its cost was
+// allocation: 3.5 of 4 ms for a single path).  One scratch per device, each behind its own mutex: callers on
+// different devices neither serialise nor free each other's block.
 struct SpScratch {
   std::mutex mu;
-  int device = -1;
   size_t bytes = 0;
   char* block = nullptr;
   hipStream_t stream = nullptr;
 };
-static SpScratch g_sp;
+constexpr int SP_MAX_DEVICES = 64;
+static SpScratch g_sp_dev[SP_MAX_DEVICES];
 
 int mpmpc_speed_profile(int32_t device, int32_t B, int32_t n, const double* li, const double* kappa,
                         const double* limits, double eps, double* v, int32_t* status, int32_t* iters) {
@@ -962,11 +1013,12 @@ int mpmpc_speed_profile(int32_t device, int32_t B, int32_t n, const double* li, 
   const size_t o_li = 0, o_kappa = vec, o_v = 2 * vec, o_lim = 3 * vec, o_status = o_lim + pad8(sizeof(double) * 5 * B),
                o_iters = o_status + pad8(sizeof(int) * (size_t)B), o_work = o_iters + pad8(sizeof(int) * (size_t)B),
                need = o_work + ((wave || small) ? 0 : vec * SP_ARRAYS);
+  if (device >= SP_MAX_DEVICES) return fail(MPMPC_E_ARG, "device ordinal beyond the speed-profile scratch table");
+  SpScratch& g_sp = g_sp_dev[device];
   std::lock_guard<std::mutex> lock(g_sp.mu);
-  if (g_sp.device != device || g_sp.bytes < need) {
-    if (g_sp.block) { (void)hipSetDevice(g_sp.device); (void)hipFree(g_sp.block); (void)hipSetDevice(device); }
-    if (g_sp.stream && g_sp.device != device) { (void)hipStreamDestroy(g_sp.stream); g_sp.stream = nullptr; }
-    g_sp.block = nullptr; g_sp.bytes = 0; g_sp.device = device;
+  if (g_sp.bytes < need) {
+    if (g_sp.block) (void)hipFree(g_sp.block);
+    g_sp.block = nullptr; g_sp.bytes = 0;
     HIP_TRY(hipMalloc((void**)&g_sp.block, need));
     g_sp.bytes = need;
   }

@@ -173,25 +173,45 @@ extern "C" int emu_census_pieces(int N, double* out4) {
 #endif
 }
 
+// returns the number of start waypoints without a free segment (>= 0), or: -3000 a border cell outside the map,
+// -3001 more than COR_MAXSEG free segments on a line (what mpmpc_build_corridor reports as errors), -1000 the two
+// forms of the column walk disagree
 extern "C" int emu_corridor(int height, int width, const int8_t* data, double ox, double oy, double res, int n_wp,
                             const double* x, const double* y, const double* psi, const double* ds_next, int circular,
                             const double* bub, const double* blb, int n_cols, double min_width, double safety_margin,
                             double* ub_tab, double* lb_tab, int* nseg_out) {
   MapView mv{data, height, width, ox, oy, res};
-  PathGeom pg{x, y, psi, ds_next, n_wp, circular};
+  std::vector<double> trig((size_t)n_wp * COR_TRIG);
+  for (int i = 0; i < n_wp; ++i) cor_trig_row(psi[i], trig.data() + (size_t)i * COR_TRIG);
+  PathGeom pg{x, y, psi, ds_next, n_wp, circular, trig.data()};
+  for (int i = 0; i < n_wp; ++i) {
+    int cx, cy;
+    cor_w2m(mv, bub[2 * i], bub[2 * i + 1], cx, cy);
+    if (cx < 0 || cx >= width || cy < 0 || cy >= height) return -3000;
+    cor_w2m(mv, blb[2 * i], blb[2 * i + 1], cx, cy);
+    if (cx < 0 || cx >= width || cy < 0 || cy >= height) return -3000;
+  }
   double* segs = new double[(size_t)n_wp * 4 * COR_MAXSEG]();
   int* nseg = new int[n_wp];
   for (int i = 0; i < n_wp; ++i) {
     nseg[i] = cor_free_segments(mv, bub[2 * i], bub[2 * i + 1], blb[2 * i], blb[2 * i + 1], min_width, segs + (size_t)i * 4 * COR_MAXSEG);
-    // the staged form the device runs (cell list, occupancies, scan) must give the same bits - also with a buffer
-    // that is too small, where it has to fall back
-    for (int cap : {250, 7}) {
-      int cells[250];
+    if (nseg[i] < 0) { delete[] segs; delete[] nseg; return -3001; }
+    // the staged form the device runs (cells of the line as packed 16-bit pairs, then the scan over the copy) must
+    // give the same bits
+    {
+      int cells[COR_CELL_CAP];
       double seg2[4 * COR_MAXSEG] = {0};
-      const int c2 = cor_free_segments_staged(mv, bub[2 * i], bub[2 * i + 1], blb[2 * i], blb[2 * i + 1], min_width, seg2, cells, cap, 1);
-      if (c2 != nseg[i] || std::memcmp(seg2, segs + (size_t)i * 4 * COR_MAXSEG, sizeof(double) * 4 * c2) != 0) {
-        delete[] segs; delete[] nseg;
-        return -2000;
+      int ux, uy, lx, ly;
+      cor_w2m(mv, bub[2 * i], bub[2 * i + 1], ux, uy);
+      cor_w2m(mv, blb[2 * i], blb[2 * i + 1], lx, ly);
+      const int n = cor_line_cells(ux, uy, lx, ly, cells, COR_CELL_CAP);
+      if (n <= COR_CELL_CAP) {
+        const int c2 = cor_scan_cells(mv, ux, uy, lx, ly, min_width, n, [&](int c, int& cx, int& cy) { cor_unpack_cell(cells[c], cx, cy); },
+                                      [&](int c) { int cx, cy; cor_unpack_cell(cells[c], cx, cy); return cor_cell_free(mv, cx, cy); }, seg2);
+        if (c2 != nseg[i] || std::memcmp(seg2, segs + (size_t)i * 4 * COR_MAXSEG, sizeof(double) * 4 * c2) != 0) {
+          delete[] segs; delete[] nseg;
+          return -2000;
+        }
       }
     }
   }
