@@ -48,7 +48,10 @@ typedef struct mpmpc_handle_s* mpmpc_handle;
 
 /* Controller constants: what MPC.__init__ stores (src/MPC.py:15-59) plus the model's wheelbase
  * (src/spatial_bicycle_models.py:130) and the path's `circular` flag (src/reference_path.py:96).
- * Q, R, QN are the DIAGONALS of the reference's weight matrices (src/simulation.py:101-103). */
+ * Q, R are the DIAGONALS of the reference's weight matrices (its cost vector only ever uses diag(Q), diag(R),
+ * src/MPC.py:153-155); QN is used as a whole by the reference (src/MPC.py:150,154): its diagonal goes into QN, its
+ * off-diagonal entries (symmetric) into QN_offdiag.  With a non-zero QN_offdiag the solve launches give every instance
+ * its own wavefront (the packed kernels carry no code for the dense terminal block). */
 typedef struct {
   int32_t N;          /* horizon, 3 <= N <= MPMPC_MAX_HORIZON (the kappa_pred quirk of MPC.py:86 needs N >= 3) */
   int32_t max_batch;  /* largest B of any later call */
@@ -59,6 +62,7 @@ typedef struct {
   double umin[2], umax[2]; /* InputConstraints 'umin','umax' in (v, kappa) */
   double ay_max;           /* MPC.ay_max */
   double wheelbase;        /* model.length */
+  double QN_offdiag[3];    /* QN[0][1], QN[0][2], QN[1][2] (= their transposes); all zero for the reference's weights */
 } mpmpc_config;
 
 /* Solver settings: OSQP 0.6.x names and defaults for the ADMM stage (what

@@ -17,8 +17,9 @@ polish).  There is no CPU solver behind this class: without the library / a devi
 `BatchMPC` is the one API extension: B independent controller instances per call (scenario
 sweeps, Monte-Carlo initial poses) on one device.
 
-Restrictions (checked, not silently ignored): Q, R, QN must be diagonal (the reference's cost
-vector only ever uses diag(Q), diag(R), src/MPC.py:153-155); 3 <= N <= 63.
+Restrictions (checked, not silently ignored): Q and R must be diagonal (the reference's cost
+vector only ever uses diag(Q), diag(R), src/MPC.py:153-155); QN may be any symmetric positive
+semidefinite 3x3 matrix (the reference uses it as a whole, src/MPC.py:150,154); 3 <= N <= 63.
 """
 from __future__ import annotations
 
@@ -41,9 +42,19 @@ def _diagonal(M, n, name):
     return np.diag(D).astype(float)
 
 
+def _symmetric(M, n, name):
+    D = M.toarray() if hasattr(M, "toarray") else np.asarray(M, float)
+    D = np.atleast_2d(D).astype(float)
+    if D.shape != (n, n):
+        raise ValueError("%s must be %dx%d" % (name, n, n))
+    if not np.array_equal(D, D.T):
+        raise ValueError("%s must be symmetric" % name)
+    return D
+
+
 def _make_config(model, N, Q, R, QN, StateConstraints, InputConstraints, ay_max, max_batch, device):
     rp = model.reference_path
-    return mpmpc.make_config(N, _diagonal(Q, 3, "Q"), _diagonal(R, 2, "R"), _diagonal(QN, 3, "QN"),
+    return mpmpc.make_config(N, _diagonal(Q, 3, "Q"), _diagonal(R, 2, "R"), _symmetric(QN, 3, "QN"),
                              StateConstraints['xmin'], StateConstraints['xmax'],
                              InputConstraints['umin'], InputConstraints['umax'], ay_max, model.length,
                              circular=rp.circular, max_batch=max_batch, device=device)

@@ -101,7 +101,9 @@ MPMPC_HD void assemble_stage(const mpmpc_config& c, const StageIn<L>& in, typena
   MPMPC_UNROLL
   for (int i = 0; i < 3; ++i) {
     R xr = (i == 0) ? xr0 : zero;
-    out[F_Q + i] = sel(in.terminal, -(R(c.QN[i]) * xr), R(-c.Q[i]) * xr);
+    // terminal stage: -QN . xr with xr = (xr0, 0, 0), i.e. minus the first column of QN times xr0 (src/MPC.py:154)
+    const double qn_i0 = i == 0 ? c.QN[0] : c.QN_offdiag[i - 1];
+    out[F_Q + i] = sel(in.terminal, -(R(qn_i0) * xr0), R(-c.Q[i]) * xr);
     out[F_P + i] = sel(in.terminal, R(c.QN[i]), R(c.Q[i]));
   }
   out[F_Q + 3] = sel(in.has_u, R(-c.R[0]) * in.v, zero);
@@ -207,7 +209,13 @@ MPMPC_HOST_DEVICE inline int lane_offset(int G, int C, int N) {
   return (C >= G || o < 0) ? 0 : o;
 }
 
-template <class L>
+// FQ: the terminal weight QN is a full symmetric 3 x 3 matrix (src/MPC.py:150,154 use the whole matrix).  Its three
+// off-diagonal entries exist on the lane of stage N only (pod), and so do the off-diagonals of the inverse of that
+// stage's 3 x 3 Hessian block (hod): the terminal state enters the equality rows through -I alone, so the Schur
+// complement keeps its block-tridiagonal structure and only the diagonal block of stage N, the products with P and
+// the products with inv(H) gain terms.  With FQ = false (the reference's own weights are diagonal) none of this
+// code exists in the kernel.
+template <class L, bool FQ = false>
 struct Solver {
   using R = typename L::real;
   using Mk = typename L::mask;
@@ -228,6 +236,8 @@ struct Solver {
   // ---- where this lane's stage fields live (the unscaled bounds are re-read for the certificate)
   // ---- scaled problem
   R mI[3], a[6], b[2], g[5], p[5], q[5], D[5], Eeq[3], Eb[5], c;
+  R pod[3], hod[3];      // FQ: off-diagonals (01, 02, 12) of the terminal cost block and of the terminal inv(H) block
+  Mk term;               // this lane holds stage N
   R leq[3], lb[5], ub[5];
   // ---- linear algebra
   R hinv[5], Li[6], Gin[9], Gout[9];          // Li, Gin, Gout in chain layout (see factor)
@@ -289,6 +299,29 @@ struct Solver {
     return L::gmax(m);
   }
 
+  // ---- full terminal weight (FQ)
+  // v += offdiag(M) w over the three states, M given by its off-diagonals od = (01, 02, 12)
+  MPMPC_HD static void od_mul_add(const R od[3], const R* w, R* v) {
+    v[0] = fma_(od[1], w[2], fma_(od[0], w[1], v[0]));
+    v[1] = fma_(od[2], w[2], fma_(od[0], w[0], v[1]));
+    v[2] = fma_(od[2], w[1], fma_(od[1], w[0], v[2]));
+  }
+  // Hd: diagonal of the Hessian block whose inverse h the caller has just formed entry by entry.  On the terminal lane
+  // the block is dense (Hd on the diagonal, pod off it): replace h[0..2] by the diagonal of its inverse, keep the rest in hod.
+  template <bool USE = true>
+  MPMPC_HD void dense_terminal(const R* Hd, R* h) {
+    if constexpr (FQ && USE) {
+      const R c00 = fma_(Hd[1], Hd[2], -(pod[2] * pod[2])), c01 = fma_(pod[1], pod[2], -(pod[0] * Hd[2])),
+              c02 = fma_(pod[0], pod[2], -(pod[1] * Hd[1])), c11 = fma_(Hd[0], Hd[2], -(pod[1] * pod[1])),
+              c12 = fma_(pod[0], pod[1], -(Hd[0] * pod[2])), c22 = fma_(Hd[0], Hd[1], -(pod[0] * pod[0]));
+      const R idet = R(1.0) / fma_(pod[1], c02, fma_(pod[0], c01, Hd[0] * c00));
+      h[0] = sel(term, c00 * idet, h[0]); h[1] = sel(term, c11 * idet, h[1]); h[2] = sel(term, c22 * idet, h[2]);
+      hod[0] = sel(term, c01 * idet, R(0.0)); hod[1] = sel(term, c02 * idet, R(0.0)); hod[2] = sel(term, c12 * idet, R(0.0));
+    } else if constexpr (FQ) {
+      hod[0] = hod[1] = hod[2] = R(0.0);
+    }
+  }
+
   // ======================================================================== setup
   // field f of this lane's stage, straight from the stage-blocked QP; bounds clipped like OSQP does
   // (the unscaled offsets and bounds are needed again after the Ruiz passes and in the certificate: they wait in
@@ -306,7 +339,8 @@ struct Solver {
   }
 
   // fields: the 27 stage fields of this lane's (instance, stage) - assemble_fields, or fetch_fields
-  MPMPC_HD void load(const R* fields, int B, const I& inst, const I& k, int N_) {
+  // qn_off: off-diagonals (01, 02, 12) of QN (FQ only; mpmpc_config::QN_offdiag)
+  MPMPC_HD void load(const R* fields, int B, const I& inst, const I& k, int N_, const double* qn_off = nullptr) {
     N = N_;
     n_inst = B;
     live = inst < B;
@@ -330,6 +364,11 @@ struct Solver {
     }
     valid[0] = valid[1] = valid[2] = vx;
     valid[3] = valid[4] = vu;
+    term = live & (k == N);
+    if constexpr (FQ) {
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) { pod[i] = sel(term, R(qn_off ? qn_off[i] : 0.0), R(0.0)); hod[i] = R(0.0); }
+    }
     auto fld = [&](int f, double dflt) { return sel(vx, fields[f], R(dflt)); };
     MPMPC_UNROLL
     for (int i = 0; i < 3; ++i) L::cold_put(COLD_RAW + i, fld(F_BEQ + i, 0.0));
@@ -363,6 +402,11 @@ struct Solver {
       cn[0] = max_(max_(max_(abs_(p[0]), abs_(mI[0])), max_(abs_(a[0]), abs_(a[2]))), max_(abs_(a[4]), abs_(g[0])));
       cn[1] = max_(max_(abs_(p[1]), abs_(mI[1])), max_(max_(abs_(a[1]), abs_(a[3])), abs_(g[1])));
       cn[2] = max_(max_(abs_(p[2]), abs_(mI[2])), max_(abs_(a[5]), abs_(g[2])));
+      if constexpr (FQ) {
+        cn[0] = max_(cn[0], max_(abs_(pod[0]), abs_(pod[1])));
+        cn[1] = max_(cn[1], max_(abs_(pod[0]), abs_(pod[2])));
+        cn[2] = max_(cn[2], max_(abs_(pod[1]), abs_(pod[2])));
+      }
       cn[3] = max_(max_(abs_(p[3]), abs_(b[1])), abs_(g[3]));
       cn[4] = max_(max_(abs_(p[4]), abs_(b[0])), abs_(g[4]));
       r_own[0] = max_(abs_(a[0]), abs_(a[1]));
@@ -388,6 +432,9 @@ struct Solver {
         D[j] = D[j] * Dt[j];
         Eb[j] = Eb[j] * Etb[j];
       }
+      if constexpr (FQ) {
+        pod[0] = (Dt[0] * pod[0]) * Dt[1]; pod[1] = (Dt[0] * pod[1]) * Dt[2]; pod[2] = (Dt[1] * pod[2]) * Dt[2];
+      }
       MPMPC_UNROLL
       for (int i = 0; i < 3; ++i) { mI[i] = (Et[i] * mI[i]) * Dt[i]; Eeq[i] = Eeq[i] * Et[i]; }
       a[0] = (Etd[0] * a[0]) * Dt[0]; a[1] = (Etd[0] * a[1]) * Dt[1];
@@ -398,7 +445,13 @@ struct Solver {
       R s(0.0), mq(0.0);
       MPMPC_UNROLL
       for (int j = 0; j < 5; ++j) {
-        s = s + sel(valid[j], abs_(p[j]), R(0.0));
+        R colmax = abs_(p[j]);                      // inf-norm of column j of P
+        if constexpr (FQ) {
+          if (j == 0) colmax = max_(colmax, max_(abs_(pod[0]), abs_(pod[1])));
+          if (j == 1) colmax = max_(colmax, max_(abs_(pod[0]), abs_(pod[2])));
+          if (j == 2) colmax = max_(colmax, max_(abs_(pod[1]), abs_(pod[2])));
+        }
+        s = s + sel(valid[j], colmax, R(0.0));
         mq = max_(mq, sel(valid[j], abs_(q[j]), R(0.0)));
       }
       R ct = L::gsum(s) / n_total;
@@ -406,6 +459,7 @@ struct Solver {
       ct = keep(on, R(1.0) / limit(max_(ct, nq)), R(1.0));
       MPMPC_UNROLL
       for (int j = 0; j < 5; ++j) { p[j] = p[j] * ct; q[j] = q[j] * ct; }
+      if constexpr (FQ) { pod[0] = pod[0] * ct; pod[1] = pod[1] * ct; pod[2] = pod[2] * ct; }
       c = c * ct;
     }
     MPMPC_UNROLL
@@ -471,6 +525,11 @@ struct Solver {
     Dg[0] = Dg[0] + fma_(mI[0] * mI[0], h[0], r);
     Dg[2] = Dg[2] + fma_(mI[1] * mI[1], h[1], r);
     Dg[5] = Dg[5] + fma_(mI[2] * mI[2], h[2], r);
+    if constexpr (FQ) {       // -I inv(H_N) -I' of the terminal stage is dense
+      Dg[1] = fma_(mI[0] * mI[1], hod[0], Dg[1]);
+      Dg[3] = fma_(mI[0] * mI[2], hod[1], Dg[3]);
+      Dg[4] = fma_(mI[1] * mI[2], hod[2], Dg[4]);
+    }
     // coupling handed on: S_{k+1,k} = T going up, S_{k-1,k} = T_{k-1}' going down, nothing from mid
     {
       R Tu[6];
@@ -641,13 +700,15 @@ struct Solver {
     R t[5], bv[3], s[5];
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) t[j] = hinv[j] * rx[j];
+    if constexpr (FQ) od_mul_add(hod, rx, t);
     Aeq_mul(t, bv);
     MPMPC_UNROLL
     for (int i = 0; i < 3; ++i) bv[i] = bv[i] - req[i];
     s_solve(bv, nu);
     AeqT_mul(nu, s);
     MPMPC_UNROLL
-    for (int j = 0; j < 5; ++j) xt[j] = hinv[j] * (rx[j] - s[j]);
+    for (int j = 0; j < 5; ++j) { s[j] = rx[j] - s[j]; xt[j] = hinv[j] * s[j]; }
+    if constexpr (FQ) od_mul_add(hod, s, xt);
   }
 
   // ---- the same operators on the split layout (S = true: 3 entries per lane, see kSplit) or the plain one
@@ -707,19 +768,22 @@ struct Solver {
     R t[E], bv[3], s[E];
     MPMPC_UNROLL
     for (int j = 0; j < E; ++j) t[j] = hinv[j] * rx[j];
+    if constexpr (FQ) od_mul_add(hod, rx, t);
     Aeq_mul_t<S>(t, bv);
     MPMPC_UNROLL
     for (int i = 0; i < 3; ++i) bv[i] = bv[i] - req[i];
     s_solve(bv, nu);
     AeqT_mul_t<S>(nu, s);
     MPMPC_UNROLL
-    for (int j = 0; j < E; ++j) xt[j] = hinv[j] * (rx[j] - s[j]);
+    for (int j = 0; j < E; ++j) { s[j] = rx[j] - s[j]; xt[j] = hinv[j] * s[j]; }
+    if constexpr (FQ) od_mul_add(hod, s, xt);
   }
 
   MPMPC_HD void admm_factor(double sigma) {
-    R h[5];
+    R h[5], Hd[5];
     MPMPC_UNROLL
-    for (int j = 0; j < 5; ++j) h[j] = R(1.0) / (p[j] + R(sigma) + (g[j] * g[j]) * rb[j]);
+    for (int j = 0; j < 5; ++j) { Hd[j] = p[j] + R(sigma) + (g[j] * g[j]) * rb[j]; h[j] = R(1.0) / Hd[j]; }
+    dense_terminal(Hd, h);
     factor(h, rinv_eq);
   }
 
@@ -745,6 +809,8 @@ struct Solver {
       sAx = max_(sAx, sel(vx, abs_(Axe[i]), R(0.0)));
     }
     R dua(0.0), nq(0.0), nAty(0.0), nPx(0.0), srd(0.0), sq(0.0), sAty(0.0), sPx(0.0);
+    R Pod[3] = {R(0.0), R(0.0), R(0.0)};          // off-diagonal part of P x (FQ)
+    if constexpr (FQ) od_mul_add(pod, x, Pod);
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) {
       R ei = R(1.0) / Eb[j], di = R(1.0) / D[j];
@@ -758,6 +824,7 @@ struct Solver {
       sAx = max_(sAx, sel(valid[j], abs_(Axb), R(0.0)));
       R aty = fma_(g[j], yb[j], Aty[j]);
       R Px = p[j] * x[j];
+      if constexpr (FQ) { if (j < 3) Px = Px + Pod[j]; }
       R rd = Px + q[j] + aty;
       dua = max_(dua, sel(valid[j], abs_(di * rd), R(0.0)));
       nq = max_(nq, sel(valid[j], abs_(di * q[j]), R(0.0)));
@@ -820,11 +887,16 @@ struct Solver {
   MPMPC_HD Mk dual_infeasible(double eps) const {
     R dx[5], nrm(0.0), qdx(0.0), pm(0.0);
     MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) dx[j] = x[j] - L::cold_get(COLD_XPREV + j);
+    R Pdx[5];
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) Pdx[j] = p[j] * dx[j];
+    if constexpr (FQ) od_mul_add(pod, dx, Pdx);
+    MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) {
-      dx[j] = x[j] - L::cold_get(COLD_XPREV + j);
       nrm = max_(nrm, sel(valid[j], abs_(D[j] * dx[j]), R(0.0)));
       qdx = qdx + sel(valid[j], q[j] * dx[j], R(0.0));
-      pm = max_(pm, sel(valid[j], abs_((p[j] * dx[j]) / D[j]), R(0.0)));
+      pm = max_(pm, sel(valid[j], abs_(Pdx[j] / D[j]), R(0.0)));
     }
     nrm = L::gmax(nrm); qdx = L::gsum(qdx); pm = L::gmax(pm);
     R Adx[3];
@@ -1051,12 +1123,17 @@ struct Solver {
       AeqT_mul_t<S>(s.nu, At);
       Aeq_mul_t<S>(s.x, rp);
       R res(0.0), msum(0.0);
+      [[maybe_unused]] R Pod[3] = {zero, zero, zero};          // off-diagonal part of P x (FQ, not in phase 1)
+      if constexpr (FQ && !SOFT) od_mul_add(pod, s.x, Pod);
       MPMPC_UNROLL
       for (int i = 0; i < 3; ++i) { rp[i] = rp[i] - leq[i]; res = max_(res, sel(vx, abs_(rp[i]), zero)); }
       MPMPC_UNROLL
       for (int j = 0; j < E; ++j) {
         if constexpr (SOFT) rd[j] = At[j] - s.zl[j] + s.zu[j] + s.pi[j];
-        else rd[j] = fma_(pp[j], s.x[j], qq[j]) + At[j] - s.zl[j] + s.zu[j] + s.pi[j];
+        else {
+          rd[j] = fma_(pp[j], s.x[j], qq[j]) + At[j] - s.zl[j] + s.zu[j] + s.pi[j];
+          if constexpr (FQ) { if (j < 3) rd[j] = rd[j] + Pod[j]; }
+        }
         res = max_(res, sel(vm[j], max_(max_(abs_(rd[j]), abs_(rpin_of(j))), max_(abs_(rl_of(j)), abs_(ru_of(j)))), zero));
         msum = msum + sel(bx.Lm[j], s.sl[j] * s.zl[j], zero) + sel(bx.Um[j], s.su[j] * s.zu[j], zero);
       }
@@ -1110,8 +1187,10 @@ struct Solver {
                  sel(bx.pin[j], ireg, zero);
         }
       };
+      [[maybe_unused]] R Hd[E];
       MPMPC_UNROLL
-      for (int j = 0; j < E; ++j) h[j] = rcp_(H_of(j));
+      for (int j = 0; j < E; ++j) { const R Hj = H_of(j); if constexpr (FQ) Hd[j] = Hj; h[j] = rcp_(Hj); }
+      dense_terminal<!SOFT>(Hd, h);
       factor_t<S>(h, reg);
       MPMPC_TICK_END(11);
       // ---- predictor and corrector share the factorisation.  (No iterative refinement of the directions: over
@@ -1219,14 +1298,16 @@ struct Solver {
     Mk todo = run, okm = L::mfalse();
     for (int rnd = 0; rnd < st.as_rounds; ++rnd) {
       if (!L::wany(todo)) break;
-      R h[5], bound[5];
+      R h[5], Hd[5], bound[5];
       Mk act[5];
       MPMPC_UNROLL
       for (int j = 0; j < 5; ++j) {
         act[j] = aL[j] | aU[j] | bx.pin[j];
         bound[j] = sel(aU[j], bx.hi[j], bx.lo[j]);
-        h[j] = one / (p[j] + delta + sel(act[j], idelta, zero));
+        Hd[j] = p[j] + delta + sel(act[j], idelta, zero);
+        h[j] = one / Hd[j];
       }
+      dense_terminal(Hd, h);
       MPMPC_TICK_COUNT(17);
       MPMPC_TICK_BEGIN(13);
       factor(h, delta);
@@ -1241,9 +1322,12 @@ struct Solver {
         AeqT_mul(nn, At);
         Aeq_mul(xn, Ax);
         R rs(0.0);                       // KKT residual of the unregularised system at (xn, nn, ln)
+        R Pod[3] = {zero, zero, zero};
+        if constexpr (FQ) od_mul_add(pod, xn, Pod);
         MPMPC_UNROLL
         for (int j = 0; j < 5; ++j) {
           R r1 = -q[j] - p[j] * xn[j] - At[j] - ln[j];
+          if constexpr (FQ) { if (j < 3) r1 = r1 - Pod[j]; }
           r3[j] = sel(act[j], bound[j] - xn[j], zero);
           rhs[j] = fma_(r3[j], idelta, r1);
           rs = max_(rs, sel(valid[j], max_(abs_(r1), abs_(r3[j])), zero));
@@ -1315,6 +1399,8 @@ struct Solver {
     AeqT_mul(nus, At);
     R pv(0.0), sv(0.0), cv(0.0);
     R cinv = R(1.0) / c;
+    R Pod[3] = {R(0.0), R(0.0), R(0.0)};
+    if constexpr (FQ) od_mul_add(pod, xs, Pod);
     MPMPC_UNROLL
     for (int i = 0; i < 3; ++i) pv = max_(pv, sel(vx, abs_((Ax[i] - leq[i]) / Eeq[i]), R(0.0)));
     MPMPC_UNROLL
@@ -1324,6 +1410,7 @@ struct Solver {
       R viol = max_(max_(lo0 - xu, xu - hi0), R(0.0));
       pv = max_(pv, sel(valid[j], viol, R(0.0)));
       R rd = fma_(p[j], xs[j], q[j]) + At[j] + lam[j];
+      if constexpr (FQ) { if (j < 3) rd = rd + Pod[j]; }
       sv = max_(sv, sel(valid[j], abs_(rd / D[j]) * cinv, R(0.0)));
       R yu = (lam[j] / D[j]) * cinv;                      // multiplier of the unscaled box row
       Mk fu = hi0 < R(INF_BOUND), fl = lo0 > R(-INF_BOUND);
@@ -1696,9 +1783,9 @@ struct Solver {
   //     one-instance-per-wave launch, mode 2, and that is where phase 1 runs)
   template <bool WARM = false, bool P1 = true>
   MPMPC_HD void run(const R* fields, int B, const I& inst, const I& k, int N_, const SolverParams& st,
-                    int mode = 0, const I& guess = I(0), const I& base_ipm = I(0)) {
+                    int mode = 0, const I& guess = I(0), const I& base_ipm = I(0), const double* qn_off = nullptr) {
     MPMPC_TICK_BEGIN(0);
-    load(fields, B, inst, k, N_);
+    load(fields, B, inst, k, N_, qn_off);
     MPMPC_TICK_END(0);
     // The polish does not need a converged ADMM point, only a reasonable one: with early_polish > 0
     // it is first tried after that many iterations, on a problem that has seen early_scaling of the

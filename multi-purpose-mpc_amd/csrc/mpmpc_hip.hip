@@ -84,7 +84,7 @@ struct AssembleIn {
   const int* wp_id;
   const double *x0, *cc, *lb, *ub;
 };
-template <int G, int C, bool WARM>
+template <int G, int C, bool WARM, bool FQ = false>
 __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, SolverParams st, int B, int ld,
                                                          AssembleIn ain, double* __restrict__ z,
                                                          double* __restrict__ u0, int* __restrict__ status,
@@ -107,10 +107,10 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
   MPMPC_TICK_BEGIN(8);
   double fields[MPMPC_NUM_FIELDS];
   assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
-  Solver<L> s;
+  Solver<L, FQ> s;
   // (second launch of a packed batch: the interior-point iterations the first launch spent on this instance)
   const int base_ipm = (mode == 2 && iters) ? iters[inst * 2 + 1] : 0;
-  s.template run<WARM, (G == 64)>(fields, B, inst, k, cfg.N, st, mode, guess, base_ipm);
+  s.template run<WARM, (G == 64)>(fields, B, inst, k, cfg.N, st, mode, guess, base_ipm, cfg.QN_offdiag);
   MPMPC_TICK_BEGIN(7);
   s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y, WARM ? act : nullptr, ld);
   MPMPC_TICK_END(7);
@@ -538,6 +538,16 @@ int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_
   if (!(cfg->wheelbase > 0)) return fail(MPMPC_E_ARG, "wheelbase must be > 0");
   for (int i = 0; i < 3; ++i)
     if (!(cfg->Q[i] >= 0) || !(cfg->QN[i] >= 0)) return fail(MPMPC_E_ARG, "Q, QN diagonals must be >= 0");
+  {
+    // QN positive semidefinite: leading principal minors of the symmetric 3 x 3 (with a rounding allowance)
+    const double a = cfg->QN[0], b = cfg->QN[1], c = cfg->QN[2], d = cfg->QN_offdiag[0], e = cfg->QN_offdiag[1], f = cfg->QN_offdiag[2];
+    if (!std::isfinite(d) || !std::isfinite(e) || !std::isfinite(f)) return fail(MPMPC_E_ARG, "QN must be finite");
+    const double tol = 1e-12 * (1.0 + a * a + b * b + c * c);
+    const double m2a = a * b - d * d, m2b = a * c - e * e, m2c = b * c - f * f;
+    const double det = a * (b * c - f * f) - d * (d * c - f * e) + e * (d * f - b * e);
+    if (m2a < -tol || m2b < -tol || m2c < -tol || det < -tol * (1.0 + a + b + c))
+      return fail(MPMPC_E_ARG, "QN must be positive semidefinite");
+  }
   for (int i = 0; i < 2; ++i) {
     if (!(cfg->R[i] >= 0)) return fail(MPMPC_E_ARG, "R diagonal must be >= 0");
     if (!std::isfinite(cfg->umin[i]) || !std::isfinite(cfg->umax[i]) || cfg->umin[i] > cfg->umax[i])
@@ -917,6 +927,10 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y) {
   if (N + 1 <= 32 && B > 1024) G = 32;
   if (N + 1 <= 16 && B > 2048) G = 16;
   if (h->force_lanes && N + 1 <= h->force_lanes) G = h->force_lanes;      // mpmpc_set_packing
+  // a full terminal weight (QN with off-diagonal entries) runs one instance per wave: only those kernels carry the
+  // code of the dense terminal block
+  const bool fullqn = h->cfg.QN_offdiag[0] != 0.0 || h->cfg.QN_offdiag[1] != 0.0 || h->cfg.QN_offdiag[2] != 0.0;
+  if (fullqn) G = 64;
   // closed loop: the previous step's active sets as a first guess.  A launch with one instance per wave ends with
   // its slowest car, and with more than a handful of cars one of them always misses its guess (hit rate 91-93 %
   // per car and step: the miss pays for the attempt AND the normal path, 1024 cars -7 %), so "auto" warm-starts the
@@ -929,13 +943,16 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y) {
   const SolverParams prm = make_params(h->st);
   const bool early = prm.polish && prm.early_polish > 0 && prm.early_polish < prm.max_iter;
   const int first_mode = (G < 64 && early) ? 1 : 0;      // packed launches hand their tail to a second one
-#define LAUNCH_W(GG, CC, WW, MODE, BLOCKS)                                                                            \
-  hipLaunchKernelGGL((mpmpc_solve_kernel<GG, CC, WW>), dim3(BLOCKS), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, \
+#define LAUNCH_W(GG, CC, WW, FF, MODE, BLOCKS)                                                                            \
+  hipLaunchKernelGGL((mpmpc_solve_kernel<GG, CC, WW, FF>), dim3(BLOCKS), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, \
                      ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, MODE, h->tail, warm_act, warm_shift)
-#define LAUNCH(GG, CC, MODE, BLOCKS)                                \
-  do {                                                              \
-    if (warm_act) LAUNCH_W(GG, CC, true, MODE, BLOCKS);             \
-    else LAUNCH_W(GG, CC, false, MODE, BLOCKS);                     \
+#define LAUNCH(GG, CC, MODE, BLOCKS)                                              \
+  do {                                                                            \
+    if (GG == 64 && fullqn) {                                                     \
+      if (warm_act) LAUNCH_W(GG, CC, true, (GG == 64), MODE, BLOCKS);             \
+      else LAUNCH_W(GG, CC, false, (GG == 64), MODE, BLOCKS);                     \
+    } else if (warm_act) LAUNCH_W(GG, CC, true, false, MODE, BLOCKS);             \
+    else LAUNCH_W(GG, CC, false, false, MODE, BLOCKS);                            \
   } while (0)
   if (first_mode == 1) HIP_TRY(hipMemsetAsync(h->tail, 0, sizeof(int), h->stream));
   const int C = lane_split(G, N);        // where the two elimination chains of the factorisation meet

@@ -15,7 +15,7 @@ using namespace mpmpc;
 
 // mode / tail as in mpmpc_solve_kernel: mode 1 appends the instances it leaves UNSOLVED to tail[1..] (tail[0] counts),
 // mode 2 runs one wave per listed instance
-template <int G, int C>
+template <int G, int C, bool FQ = false>
 static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z,
                     double* u0, int* status, int* iters, double* resid, double* y, const int* guess = nullptr,
                     int* act = nullptr, int mode = 0, int* tail = nullptr) {
@@ -33,13 +33,13 @@ static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const dou
       gs.v[i] = (guess && in < B && kk >= 0 && kk <= cfg->N) ? guess[in * ld + kk] : 0;
       if (mode == 2) base.v[i] = iters[in * 2 + 1];
     }
-    Solver<L> s;
+    Solver<L, FQ> s;
     typename L::real fields[MPMPC_NUM_FIELDS];
-    Solver<L>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    Solver<L, FQ>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
     // (like the device: the packed kernels carry no phase-1 code when they run as the first of two launches)
-    if (guess) s.template run<true>(fields, B, inst, k, cfg->N, make_params(*st), mode, gs, base);
-    else if (mode == 1) s.template run<false, (G == 64)>(fields, B, inst, k, cfg->N, make_params(*st), mode, VI(0), base);
-    else s.run(fields, B, inst, k, cfg->N, make_params(*st), mode, VI(0), base);
+    if (guess) s.template run<true>(fields, B, inst, k, cfg->N, make_params(*st), mode, gs, base, cfg->QN_offdiag);
+    else if (mode == 1) s.template run<false, (G == 64)>(fields, B, inst, k, cfg->N, make_params(*st), mode, VI(0), base, cfg->QN_offdiag);
+    else s.template run<false, true>(fields, B, inst, k, cfg->N, make_params(*st), mode, VI(0), base, cfg->QN_offdiag);
     s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y, act, ld);
     if (mode == 1)
       for (int i = 0; i < EMU_W; ++i)
@@ -51,7 +51,11 @@ extern "C" int emu_solve(const mpmpc_config* cfg, const mpmpc_settings* st, int 
                          double* z, double* u0, int* status, int* iters, double* resid, double* y) {
   if (cfg->N + 1 > G) return -1;
   const int C = lane_split(G, cfg->N);       // same variant as the launcher picks
-  if (G == 64 && C == 16) solve_g<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y);
+  const bool fullqn = cfg->QN_offdiag[0] != 0.0 || cfg->QN_offdiag[1] != 0.0 || cfg->QN_offdiag[2] != 0.0;
+  if (fullqn && G != 64) return -1;          // the launcher gives such instances a wave each
+  if (fullqn && C == 16) solve_g<64, 16, true>(cfg, st, qp, B, z, u0, status, iters, resid, y);
+  else if (fullqn) solve_g<64, 32, true>(cfg, st, qp, B, z, u0, status, iters, resid, y);
+  else if (G == 64 && C == 16) solve_g<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y);
   else if (G == 64) solve_g<64, 32>(cfg, st, qp, B, z, u0, status, iters, resid, y);
   else if (G == 32) solve_g<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y);
   else if (G == 16) solve_g<16, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y);

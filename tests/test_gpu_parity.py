@@ -567,3 +567,31 @@ def test_speed_profile_on_device():
                                    border_ub=g1["border_ub"], border_lb=g1["border_lb"])
     rp.compute_speed_profile(dict(zip(('a_min', 'a_max', 'v_min', 'v_max', 'ay_max'), g2["constraints"])))
     assert np.max(np.abs(np.array([w_.v_ref for w_ in rp.waypoints]) - g2["v_ref"])) < 1e-9
+
+
+@pytest.mark.parametrize("cfgid,N,B", [(2, 30, 48), (4, 30, 1500), (3, 50, 12)])
+def test_full_terminal_weight_on_device(cfgid, N, B, track, emu):
+    """QN with off-diagonal entries (src/MPC.py:150,154 use the whole matrix) through libmpmpc.so: the device agrees with
+    the lock-step emulation of the same lane code (which the CPU suite checks against the numpy restatement of the
+    reference's full-QN assembly and the dense oracle), every solved instance passes the KKT certificate on the QP with
+    the dense terminal block, and a batch beyond 1024 still runs (one instance per wave: the packed kernels have no
+    dense-block code)."""
+    from test_emul_parity import QN_FULL, _dense_with_qn
+    sc = scenarios.make(cfgid, track, B=B, N=N)
+    Q, R, _ = scenarios.WEIGHTS[sc.weights]
+    cfg = mpmpc.make_config(N, Q, R, QN_FULL, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX,
+                            scenarios.AY_MAX, scenarios.CAR_LENGTH, max_batch=B)
+    h = mpmpc.Handle(cfg)
+    h.set_path(track.kappa, track.v_ref, track.ds_next)
+    qp = h.assemble(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    sol = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+    h.close()
+    n = min(B, 96)
+    ref = emu.solve(cfg, mpmpc.default_settings(), np.ascontiguousarray(qp[:, :n, :]), G=64)
+    assert np.array_equal(sol.status[:n], ref.status) and np.array_equal(sol.iters[:n, 0], ref.iters[:, 0])
+    ok = ref.status == 1
+    assert ok.sum() >= n // 2 and np.max(np.abs(sol.z[:n][ok] - ref.z[ok])) <= 1e-9
+    for i in np.flatnonzero(ok)[:24]:
+        P, q, A, l, u = _dense_with_qn(qp[:, i, :], N, QN_FULL)
+        assert O.kkt_certificate(P, q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8)
+    assert set(np.unique(sol.status)) <= {1, -3}
