@@ -40,7 +40,7 @@ def test_struct_layouts_match_header(lib):
     d = mpmpc.default_settings()
     for name, _ in mpmpc.Settings._fields_:
         assert getattr(s, name) == getattr(d, name), name
-    assert C.sizeof(mpmpc.Config) == 4 * 4 + 8 * (3 + 2 + 3 + 3 + 3 + 2 + 2 + 2)
+    assert C.sizeof(mpmpc.Config) == 4 * 4 + 8 * (3 + 2 + 3 + 3 + 3 + 2 + 2 + 2 + 3)
     assert lib.mpmpc_stage_ld(30) == 32 and lib.mpmpc_stage_ld(10) == 16 and lib.mpmpc_stage_ld(50) == 64
     assert b"gfx950" in lib.mpmpc_version()
 
