@@ -100,6 +100,14 @@ typedef struct {
                             ray satisfies |A'y| <= 1e-7 |y|, so the test can be sharper: an instance whose corridor
                             cannot be met by a few tenths of a millimetre is still proved infeasible instead of being
                             handed to the ADMM iteration (which calls it "solved" at eps = 1e-3; status 2). */
+  int32_t reduce;        /* 1 (default): when the time state carries neither cost nor bound (Q[2] = QN[2] = 0, QN_offdiag
+                            without t, xmin[2] = -inf, xmax[2] = +inf, R[0] > 0 - the reference's own tracking weights,
+                            src/simulation.py:101-111) the certified polish and phase 1 solve the REDUCED problem: t enters
+                            no other state's dynamics and the speed v drives t alone, so the QP separates into
+                            v_k = clip(v_ref_k) in closed form, the roll-forward of t, and the QP in (e_y, e_psi, kappa) with
+                            2 x 2 blocks - the same optimum (the KKT certificate is evaluated on the FULL problem) for about
+                            half the arithmetic.  0: always the full 3-state polish.  The ADMM stage always runs on the
+                            full problem (it reproduces OSQP's iterates). */
 } mpmpc_settings;
 
 const char* mpmpc_version(void);

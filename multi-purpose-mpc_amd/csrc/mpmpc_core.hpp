@@ -199,6 +199,13 @@ inline SolverParams make_params(const mpmpc_settings& st) {
   return p;
 }
 
+// May the certified polish solve the reduced (e_y, e_psi, kappa) problem?  (mpmpc_settings::reduce, layouts table
+// in the Solver: the time state must carry neither cost nor bound, the speed must have its own strictly convex cost.)
+inline bool reducible(const mpmpc_config& c, const mpmpc_settings& st) {
+  return st.reduce != 0 && st.polish != 0 && c.Q[2] == 0.0 && c.QN[2] == 0.0 && c.QN_offdiag[0] == 0.0 &&
+         c.QN_offdiag[1] == 0.0 && c.QN_offdiag[2] == 0.0 && c.R[0] > 0.0 && !(c.xmin[2] > -INFTY) && !(c.xmax[2] < INFTY);
+}
+
 // Lane split of the twisted factorisation for G lanes per instance and horizon N (shared by the
 // launcher and the emulation): the chains meet at lane C - 1.
 inline int lane_split(int G, int N) { return G == 16 ? 16 : (G == 32 ? 16 : (N + 1 <= 32 ? 16 : 32)); }
@@ -215,8 +222,9 @@ MPMPC_HOST_DEVICE inline int lane_offset(int G, int C, int N) {
 // complement keeps its block-tridiagonal structure and only the diagonal block of stage N, the products with P and
 // the products with inv(H) gain terms.  With FQ = false (the reference's own weights are diagonal) none of this
 // code exists in the kernel.
-template <class L, bool FQ = false>
+template <class L, bool FQ = false, bool RED = false>
 struct Solver {
+  static_assert(!(FQ && RED), "the reduced problem needs a diagonal terminal weight");
   using R = typename L::real;
   using Mk = typename L::mask;
   using I = typename L::ival;
@@ -712,20 +720,106 @@ struct Solver {
   }
 
   // ---- the same operators on the split layout (S = true: 3 entries per lane, see kSplit) or the plain one
-  template <bool S> static constexpr int EN = S ? 3 : 5;
-  MPMPC_HD void to3(const R v[5], R o[3]) const {          // stage vector -> split layout
-    R t3 = L::from_lower(v[3]), t4 = L::from_lower(v[4]);
-    o[0] = sel(sU, t3, v[0]); o[1] = sel(sU, t4, v[1]); o[2] = sel(sU, R(0.0), v[2]);
-  }
-  MPMPC_HD void from3(const R v3[3], R o[5]) const {       // back: the lower lanes get all five entries
-    o[0] = v3[0]; o[1] = v3[1]; o[2] = v3[2];
-    o[3] = L::from_upper(v3[0]); o[4] = L::from_upper(v3[1]);
-  }
-  template <bool S>
-  MPMPC_HD void Aeq_mul_t(const R* v, R r[3]) const {
-    if constexpr (!S) {
-      Aeq_mul(v, r);
+  // ---- layouts of the certified polish (interior point, active set, phase 1)
+  //   LAY_FULL      5 entries per lane: e_y, e_psi, t, v, kappa of the lane's stage; 3 equality rows
+  //   LAY_SPLIT     kSplit (G = 64, N + 1 <= 32): lane k keeps the three states, lane k + 32 the two inputs (v, kappa, -)
+  //   LAY_RED       REDUCED problem, 3 entries per lane: e_y, e_psi, kappa; 2 equality rows
+  //   LAY_REDSPLIT  reduced and split: lane k keeps (e_y, e_psi), lane k + 32 keeps (kappa, -)
+  // The reduced problem (template flag RED of the Solver): the time state t enters no other state's dynamics (column 2
+  // of A_k is the unit vector) and the speed v drives t alone (column 0 of B_k), so when t carries neither cost nor
+  // bound - Q[2] = QN[2] = 0, xmin[2] = -inf, xmax[2] = +inf: the reference's own tracking weights,
+  // src/simulation.py:101-103,110-111 - the QP separates into  v_k = clip(v_ref_k, umin, hi_v_k)  in closed form, the
+  // roll-forward of t, and the QP in (e_y, e_psi, kappa) with 2 x 2 blocks: the same optimum (the certificate and the
+  // tests check the FULL problem's KKT conditions on the reassembled point) for about half the arithmetic.
+  static constexpr int LAY_FULL = 0, LAY_SPLIT = 1, LAY_RED = 2, LAY_REDSPLIT = 3;
+  template <int LAY> static constexpr int EN = LAY == LAY_FULL ? 5 : (LAY == LAY_REDSPLIT ? 2 : 3);   // entries per lane
+  template <int LAY> static constexpr int NR = LAY >= LAY_RED ? 2 : 3;                                 // equality rows per lane
+  template <int LAY> static constexpr bool SPL = (LAY == LAY_SPLIT || LAY == LAY_REDSPLIT);
+  // stage vector (5 entries) -> layout
+  template <int LAY>
+  MPMPC_HD void to_lay(const R v[5], R* o) const {
+    if constexpr (LAY == LAY_FULL) {
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) o[j] = v[j];
+    } else if constexpr (LAY == LAY_SPLIT) {
+      R t3 = L::from_lower(v[3]), t4 = L::from_lower(v[4]);
+      o[0] = sel(sU, t3, v[0]); o[1] = sel(sU, t4, v[1]); o[2] = sel(sU, R(0.0), v[2]);
+    } else if constexpr (LAY == LAY_RED) {
+      o[0] = v[0]; o[1] = v[1]; o[2] = v[4];
     } else {
+      R t4 = L::from_lower(v[4]);
+      o[0] = sel(sU, t4, v[0]); o[1] = sel(sU, R(0.0), v[1]);
+    }
+  }
+  // layout -> stage vector on the lanes that hold a stage; the entries a reduced layout does not carry (t, v) keep
+  // what o[] holds already
+  template <int LAY>
+  MPMPC_HD void from_lay(const R* v, R o[5]) const {
+    if constexpr (LAY == LAY_FULL) {
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) o[j] = v[j];
+    } else if constexpr (LAY == LAY_SPLIT) {
+      o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+      o[3] = L::from_upper(v[0]); o[4] = L::from_upper(v[1]);
+    } else if constexpr (LAY == LAY_RED) {
+      o[0] = v[0]; o[1] = v[1]; o[4] = v[2];
+    } else {
+      o[0] = v[0]; o[1] = v[1]; o[4] = L::from_upper(v[0]);
+    }
+  }
+  // the same for masks (through 0 / 1 values: the exchange between the half-waves moves numbers)
+  template <int LAY>
+  MPMPC_HD void mask_to_lay(const Mk m[5], Mk* o) const {
+    if constexpr (LAY == LAY_FULL) {
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) o[j] = m[j];
+    } else if constexpr (LAY == LAY_RED) {
+      o[0] = m[0]; o[1] = m[1]; o[2] = m[4];
+    } else {
+      R v[5], w[EN<LAY>];
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) v[j] = sel(m[j], R(1.0), R(0.0));
+      to_lay<LAY>(v, w);
+      MPMPC_UNROLL
+      for (int e = 0; e < EN<LAY>; ++e) o[e] = w[e] > R(0.5);
+    }
+  }
+  template <int LAY>
+  MPMPC_HD void mask_from_lay(const Mk* m, Mk o[5]) const {
+    if constexpr (LAY == LAY_FULL) {
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) o[j] = m[j];
+    } else if constexpr (LAY == LAY_RED) {
+      o[0] = m[0]; o[1] = m[1]; o[4] = m[2];
+    } else {
+      R w[EN<LAY>], v[5] = {R(0.0), R(0.0), R(0.0), R(0.0), R(0.0)};
+      MPMPC_UNROLL
+      for (int e = 0; e < EN<LAY>; ++e) w[e] = sel(m[e], R(1.0), R(0.0));
+      from_lay<LAY>(w, v);
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) o[j] = v[j] > R(0.5);
+    }
+  }
+  // which of the lane's entries exist in the layout
+  template <int LAY>
+  MPMPC_HD void valid_lay(Mk* vm) const {
+    if constexpr (LAY == LAY_FULL) {
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) vm[j] = valid[j];
+    } else if constexpr (LAY == LAY_SPLIT) {
+      vm[0] = val3[0]; vm[1] = val3[1]; vm[2] = val3[2];
+    } else if constexpr (LAY == LAY_RED) {
+      vm[0] = vx; vm[1] = vx; vm[2] = vu;
+    } else {
+      vm[0] = val3[0]; vm[1] = val3[2];          // upper lanes: kappa, nothing;  lower lanes: e_y, e_psi
+    }
+  }
+
+  template <int LAY>
+  MPMPC_HD void Aeq_mul_t(const R* v, R* r) const {
+    if constexpr (LAY == LAY_FULL) {
+      Aeq_mul(v, r);
+    } else if constexpr (LAY == LAY_SPLIT) {
       // upper lanes form B u of their stage and hand it to the lower lane, which adds A x
       R c1 = L::from_upper(bU[0] * v[1]), c2 = L::from_upper(bU[1] * v[0]);
       R w[3];
@@ -734,13 +828,24 @@ struct Solver {
       w[2] = fma_(a[5], v[2], a[4] * v[0]) + c2;
       MPMPC_UNROLL
       for (int i = 0; i < 3; ++i) r[i] = fma_(mI[i], v[i], L::up(w[i]));
+    } else if constexpr (LAY == LAY_RED) {
+      R w0 = fma_(a[1], v[1], a[0] * v[0]);
+      R w1 = fma_(b[0], v[2], fma_(a[3], v[1], a[2] * v[0]));
+      r[0] = fma_(mI[0], v[0], L::up(w0));
+      r[1] = fma_(mI[1], v[1], L::up(w1));
+    } else {
+      R c1 = L::from_upper(bU[0] * v[0]);
+      R w0 = fma_(a[1], v[1], a[0] * v[0]);
+      R w1 = fma_(a[3], v[1], a[2] * v[0]) + c1;
+      r[0] = fma_(mI[0], v[0], L::up(w0));
+      r[1] = fma_(mI[1], v[1], L::up(w1));
     }
   }
-  template <bool S>
-  MPMPC_HD void AeqT_mul_t(const R nu[3], R* t) const {
-    if constexpr (!S) {
+  template <int LAY>
+  MPMPC_HD void AeqT_mul_t(const R* nu, R* t) const {
+    if constexpr (LAY == LAY_FULL) {
       AeqT_mul(nu, t);
-    } else {
+    } else if constexpr (LAY == LAY_SPLIT) {
       R nd[3];
       MPMPC_UNROLL
       for (int i = 0; i < 3; ++i) nd[i] = L::down(nu[i]);
@@ -748,35 +853,203 @@ struct Solver {
       t[0] = fma_(bU[1], u2, fma_(a[4], nd[2], fma_(a[2], nd[1], fma_(a[0], nd[0], mI[0] * nu[0]))));
       t[1] = fma_(bU[0], u1, fma_(a[3], nd[1], fma_(a[1], nd[0], mI[1] * nu[1])));
       t[2] = fma_(a[5], nd[2], mI[2] * nu[2]);
+    } else if constexpr (LAY == LAY_RED) {
+      R nd0 = L::down(nu[0]), nd1 = L::down(nu[1]);
+      t[0] = fma_(a[2], nd1, fma_(a[0], nd0, mI[0] * nu[0]));
+      t[1] = fma_(a[3], nd1, fma_(a[1], nd0, mI[1] * nu[1]));
+      t[2] = b[0] * nd1;
+    } else {
+      R nd0 = L::down(nu[0]), nd1 = L::down(nu[1]);
+      R u1 = L::from_lower(nd1);
+      t[0] = fma_(bU[0], u1, fma_(a[2], nd1, fma_(a[0], nd0, mI[0] * nu[0])));       // (bU = 0 on the lower lanes, a = mI = 0 on the upper ones)
+      t[1] = fma_(a[3], nd1, fma_(a[1], nd0, mI[1] * nu[1]));
     }
   }
-  template <bool S>
+  template <int LAY>
   MPMPC_HD void factor_t(const R* h, const R& r) {
-    if constexpr (!S) {
+    if constexpr (LAY == LAY_FULL) {
       factor(h, r);
-    } else {
+    } else if constexpr (LAY == LAY_SPLIT) {
       MPMPC_UNROLL
       for (int e = 0; e < 3; ++e) hinv[e] = h[e];
       R w2b = L::from_upper((bU[0] * bU[0]) * h[1]), w5b = L::from_upper((bU[1] * bU[1]) * h[0]);
       w2b = sel(sU, R(0.0), w2b); w5b = sel(sU, R(0.0), w5b);
       factor_core(h, w2b, w5b, r);
+    } else if constexpr (LAY == LAY_RED) {
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) hinv[e] = h[e];
+      factor_core2(h, (b[0] * b[0]) * h[2], r);
+    } else {
+      hinv[0] = h[0]; hinv[1] = h[1];
+      R wb = L::from_upper((bU[0] * bU[0]) * h[0]);
+      factor_core2(h, sel(sU, R(0.0), wb), r);
     }
   }
-  template <bool S>
-  MPMPC_HD void kkt_solve_t(const R* rx, const R req[3], R* xt, R nu[3]) const {
-    constexpr int E = EN<S>;
-    R t[E], bv[3], s[E];
+  template <int LAY>
+  MPMPC_HD void kkt_solve_t(const R* rx, const R* req, R* xt, R* nu) const {
+    constexpr int E = EN<LAY>, NQ = NR<LAY>;
+    R t[E], bv[NQ], s[E];
     MPMPC_UNROLL
     for (int j = 0; j < E; ++j) t[j] = hinv[j] * rx[j];
     if constexpr (FQ) od_mul_add(hod, rx, t);
-    Aeq_mul_t<S>(t, bv);
+    Aeq_mul_t<LAY>(t, bv);
     MPMPC_UNROLL
-    for (int i = 0; i < 3; ++i) bv[i] = bv[i] - req[i];
-    s_solve(bv, nu);
-    AeqT_mul_t<S>(nu, s);
+    for (int i = 0; i < NQ; ++i) bv[i] = bv[i] - req[i];
+    if constexpr (NQ == 3) s_solve(bv, nu); else s_solve2(bv, nu);
+    AeqT_mul_t<LAY>(nu, s);
     MPMPC_UNROLL
     for (int j = 0; j < E; ++j) { s[j] = rx[j] - s[j]; xt[j] = hinv[j] * s[j]; }
     if constexpr (FQ) od_mul_add(hod, s, xt);
+  }
+
+  // ---- the reduced problem's block-tridiagonal Cholesky: factor_core / s_solve with 2 x 2 blocks (rows e_y, e_psi).
+  // Same twisted elimination, same chain layout, same junction steps; Li = (i00, i10, i11), Gin / Gout 2 x 2 in the
+  // first entries of the member arrays.
+  //   A_k = [[a0, a1], [a2, a3]],  B_k = [0; b0]:   W = A H A' + B h_kappa B',   T = S_{k+1,k} = A H (-I)'
+  MPMPC_HD void factor_core2(const R hx[2], const R& wb, const R& r) {
+    const R* h = hx;
+    R W[3], T[4], Dg[3], To[4];
+    {
+      R a0h = a[0] * h[0], a2h = a[2] * h[0], a1h = a[1] * h[1], a3h = a[3] * h[1];
+      W[0] = fma_(a[1], a1h, a[0] * a0h);
+      W[1] = fma_(a[3], a1h, a[2] * a0h);
+      W[2] = fma_(a[3], a3h, a[2] * a2h) + wb;
+      T[0] = a0h * mI[0]; T[1] = a1h * mI[1];
+      T[2] = a2h * mI[0]; T[3] = a3h * mI[1];
+    }
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) Dg[i] = L::up(W[i]);
+    Dg[0] = Dg[0] + fma_(mI[0] * mI[0], h[0], r);
+    Dg[2] = Dg[2] + fma_(mI[1] * mI[1], h[1], r);
+    {
+      R Tu[4];
+      MPMPC_UNROLL
+      for (int i = 0; i < 4; ++i) Tu[i] = L::up(T[i]);
+      const R zero(0.0);
+      // coupling handed on: S_{k+1,k} = T going up, S_{k-1,k} = T_{k-1}' going down, nothing from mid
+      To[0] = sel(down_chain, Tu[0], T[0]); To[1] = sel(down_chain, Tu[2], T[1]);
+      To[2] = sel(down_chain, Tu[1], T[2]); To[3] = sel(down_chain, Tu[3], T[3]);
+      MPMPC_UNROLL
+      for (int i = 0; i < 4; ++i) To[i] = sel(is_mid, zero, To[i]);
+    }
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) Dg[i] = L::mirror(Dg[i]);
+    MPMPC_UNROLL
+    for (int i = 0; i < 4; ++i) To[i] = L::mirror(To[i]);
+    R M[4], Ls[4];
+    MPMPC_UNROLL
+    for (int i = 0; i < 4; ++i) M[i] = R(0.0);
+    const int last = chain_steps();
+    auto fstep = [&](bool junction) {
+      R Mr[4];
+      MPMPC_UNROLL
+      for (int i = 0; i < 4; ++i) Mr[i] = L::cup(M[i]);
+      R S00 = fma_(-Mr[1], Mr[1], fma_(-Mr[0], Mr[0], Dg[0]));
+      R S10 = fma_(-Mr[3], Mr[1], fma_(-Mr[2], Mr[0], Dg[1]));
+      R S11 = fma_(-Mr[3], Mr[3], fma_(-Mr[2], Mr[2], Dg[2]));
+      if (junction) {
+        R Mx[4];
+        MPMPC_UNROLL
+        for (int i = 0; i < 4; ++i) Mx[i] = sel(is_mid, L::down(L::mirror(M[i])), R(0.0));
+        S00 = fma_(-Mx[1], Mx[1], fma_(-Mx[0], Mx[0], S00));
+        S10 = fma_(-Mx[3], Mx[1], fma_(-Mx[2], Mx[0], S10));
+        S11 = fma_(-Mx[3], Mx[3], fma_(-Mx[2], Mx[2], S11));
+      }
+      R i00 = rsqrt_(S00);
+      R l10 = S10 * i00;
+      R i11 = rsqrt_(fma_(-l10, l10, S11));
+      R i10 = -(l10 * i00) * i11;
+      Li[0] = i00; Li[1] = i10; Li[2] = i11;
+      MPMPC_UNROLL
+      for (int i = 0; i < 4; ++i) Ls[i] = Mr[i];
+      // M = To * inv(L_kk)'
+      M[0] = To[0] * i00; M[1] = fma_(To[1], i11, To[0] * i10);
+      M[2] = To[2] * i00; M[3] = fma_(To[3], i11, To[2] * i10);
+    };
+    {
+      MPMPC_SERIAL_BEGIN();
+      int s = 0;
+      for (; s + 2 <= last; s += 2) { fstep(false); fstep(false); }
+      for (; s < last; ++s) fstep(false);
+      fstep(true);
+      MPMPC_SERIAL_END(last + 1);
+    }
+    //   inward    y_k  = inv(L_kk) b_k + Gin_k y_pred,        Gin_k  = -inv(L_kk) M_in
+    //   outward   nu_k = inv(L_kk)' y_k + Gout_k nu_succ,     Gout_k = -inv(L_kk)' M_own'
+    MPMPC_UNROLL
+    for (int j = 0; j < 2; ++j) {
+      Gin[0 + j] = -(Li[0] * Ls[0 + j]);
+      Gin[2 + j] = -fma_(Li[2], Ls[2 + j], Li[1] * Ls[0 + j]);
+    }
+    MPMPC_UNROLL
+    for (int j = 0; j < 2; ++j) {                                // Gout[i][j] = -sum_m Li[m][i] * M[j][m]
+      R g0 = -fma_(Li[1], M[2 * j + 1], Li[0] * M[2 * j + 0]);
+      R g1 = -(Li[2] * M[2 * j + 1]);
+      Gout[0 + j] = sel(is_end, M[0 + j], g0);
+      Gout[2 + j] = sel(is_end, M[2 + j], g1);
+    }
+  }
+  MPMPC_HD void s_solve2(const R bv[2], R nu[2]) const {
+    R b0 = sel(vxc, L::mirror(bv[0]), R(0.0)), b1 = sel(vxc, L::mirror(bv[1]), R(0.0));
+    R c0 = Li[0] * b0;
+    R c1 = fma_(Li[2], b1, Li[1] * b0);
+    const int last = chain_steps();
+    R y0(0.0), y1(0.0);
+    auto in_step = [&]() {
+      R p0 = L::cup(y0), p1 = L::cup(y1);
+      y0 = fma_(Gin[1], p1, fma_(Gin[0], p0, c0));
+      y1 = fma_(Gin[3], p1, fma_(Gin[2], p0, c1));
+    };
+    {
+      MPMPC_SERIAL_BEGIN();
+      int s = 0;
+      for (; s + 4 <= last; s += 4) { in_step(); in_step(); in_step(); in_step(); }
+      for (; s < last; ++s) in_step();
+      MPMPC_SERIAL_END(last);
+    }
+    {
+      // inward junction: the end lane forms M_own y, mid takes it on top of its chain input
+      MPMPC_SERIAL_BEGIN();
+      R t0 = fma_(Gout[1], y1, Gout[0] * y0);
+      R t1 = fma_(Gout[3], y1, Gout[2] * y0);
+      const R zero(0.0);
+      t0 = sel(is_mid, L::down(L::mirror(t0)), zero);
+      t1 = sel(is_mid, L::down(L::mirror(t1)), zero);
+      R e0 = c0 - Li[0] * t0;
+      R e1 = c1 - fma_(Li[2], t1, Li[1] * t0);
+      R p0 = L::cup(y0), p1 = L::cup(y1);
+      y0 = fma_(Gin[1], p1, fma_(Gin[0], p0, e0));
+      y1 = fma_(Gin[3], p1, fma_(Gin[2], p0, e1));
+      MPMPC_SERIAL_END(N + 1);
+    }
+    R d0 = fma_(Li[1], y1, Li[0] * y0);
+    R d1 = Li[2] * y1;
+    {
+      // outward junction: nu of mid is final; the end lane takes it through M_own'
+      MPMPC_SERIAL_BEGIN();
+      const R zero(0.0);
+      R m0 = sel(is_end, L::mirror(L::up(d0)), zero);
+      R m1 = sel(is_end, L::mirror(L::up(d1)), zero);
+      R w0 = fma_(Gout[2], m1, Gout[0] * m0);
+      R w1 = fma_(Gout[3], m1, Gout[1] * m0);
+      d0 = d0 - fma_(Li[1], w1, Li[0] * w0);
+      d1 = d1 - Li[2] * w1;
+      MPMPC_SERIAL_END(N + 1);
+    }
+    R n0(0.0), n1(0.0);
+    auto out_step = [&]() {
+      R p0 = L::cdown(n0), p1 = L::cdown(n1);
+      n0 = fma_(Gout[1], p1, fma_(Gout[0], p0, d0));
+      n1 = fma_(Gout[3], p1, fma_(Gout[2], p0, d1));
+    };
+    {
+      MPMPC_SERIAL_BEGIN();
+      int s = 0;
+      for (; s + 4 <= last + 1; s += 4) { out_step(); out_step(); out_step(); out_step(); }
+      for (; s <= last; ++s) out_step();
+      MPMPC_SERIAL_END(last + 1);
+    }
+    nu[0] = L::mirror(n0); nu[1] = L::mirror(n1);
   }
 
   MPMPC_HD void admm_factor(double sigma) {
@@ -1063,12 +1336,12 @@ struct Solver {
 
   // ======================================================================== certified polish
   // Variable-space view of the box rows: g x in [lb, ub]  <=>  x in [lo, hi].
-  template <bool S>
+  template <int LAY>
   struct BoxT {
-    R lo[EN<S>], hi[EN<S>];
-    Mk Lm[EN<S>], Um[EN<S>], pin[EN<S>];
+    R lo[EN<LAY>], hi[EN<LAY>];
+    Mk Lm[EN<LAY>], Um[EN<LAY>], pin[EN<LAY>];
   };
-  using Box = BoxT<false>;
+  using Box = BoxT<LAY_FULL>;
   MPMPC_HD void make_box(Box& bx) const {
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) {
@@ -1084,11 +1357,11 @@ struct Solver {
 
   // Regularised Mehrotra predictor-corrector, warm started at (xw, nuw, ybw).  Linear systems
   // go through the same block-tridiagonal Schur factorisation as the ADMM step.
-  template <bool S>
+  template <int LAY>
   struct IpmT {
-    R x[EN<S>], nu[3], sl[EN<S>], su[EN<S>], zl[EN<S>], zu[EN<S>], pi[EN<S>];
+    R x[EN<LAY>], nu[NR<LAY>], sl[EN<LAY>], su[EN<LAY>], zl[EN<LAY>], zu[EN<LAY>], pi[EN<LAY>];
   };
-  using Ipm = IpmT<false>;
+  using Ipm = IpmT<LAY_FULL>;
   // pp, qq, vm: cost diagonal, cost vector and validity masks of the lane's entries in the layout S
   //
   // SOFT = true is PHASE 1 (see phase1()): every box entry j with a finite side reads  lo <= x_j + w_j <= hi  with
@@ -1098,11 +1371,11 @@ struct Solver {
   // of th on the diagonal and  k (cu - cl)  in place of  cu - cl  on the right-hand side.  Pinned entries stay hard.
   // The loop also ends for an instance as soon as its multipliers pass the Farkas test in the scaled problem
   // (|A'y| <= eps |y|, support <= -eps |y|): what is asked of phase 1 is a ray, not a converged point.
-  template <bool S, bool SOFT = false>
-  MPMPC_HD Mk ipm(const BoxT<S>& bx, IpmT<S>& s, const R* pp, const R* qq, const Mk* vm, const SolverParams& st,
+  template <int LAY, bool SOFT = false>
+  MPMPC_HD Mk ipm(const BoxT<LAY>& bx, IpmT<LAY>& s, const R* pp, const R* qq, const Mk* vm, const SolverParams& st,
                   double tol, const Mk& run) {
-    constexpr int E = EN<S>;
-    MPMPC_COUNT_CONTEXT(S ? 1 : 0);
+    constexpr int E = EN<LAY>, NQ = NR<LAY>;
+    MPMPC_COUNT_CONTEXT(SPL<LAY> ? 1 : 0);
     const R reg(st.ipm_reg), ireg(st.inv_ipm_reg), one(1.0), zero(0.0);
     Mk active = run, conv = L::mfalse();
     R cnt(0.0);
@@ -1119,14 +1392,14 @@ struct Solver {
       auto ru_of = [&](int j) { return sel(bx.Um[j], bx.hi[j] - s.x[j] - w_of(j) - s.su[j], zero); };
       auto rpin_of = [&](int j) { return sel(bx.pin[j], s.x[j] - bx.lo[j], zero); };
       MPMPC_TICK_BEGIN(10);
-      R At[E], rp[3], rd[E];
-      AeqT_mul_t<S>(s.nu, At);
-      Aeq_mul_t<S>(s.x, rp);
+      R At[E], rp[NQ], rd[E];
+      AeqT_mul_t<LAY>(s.nu, At);
+      Aeq_mul_t<LAY>(s.x, rp);
       R res(0.0), msum(0.0);
       [[maybe_unused]] R Pod[3] = {zero, zero, zero};          // off-diagonal part of P x (FQ, not in phase 1)
       if constexpr (FQ && !SOFT) od_mul_add(pod, s.x, Pod);
       MPMPC_UNROLL
-      for (int i = 0; i < 3; ++i) { rp[i] = rp[i] - leq[i]; res = max_(res, sel(vx, abs_(rp[i]), zero)); }
+      for (int i = 0; i < NQ; ++i) { rp[i] = rp[i] - leq[i]; res = max_(res, sel(vx, abs_(rp[i]), zero)); }
       MPMPC_UNROLL
       for (int j = 0; j < E; ++j) {
         if constexpr (SOFT) rd[j] = At[j] - s.zl[j] + s.zu[j] + s.pi[j];
@@ -1144,7 +1417,7 @@ struct Solver {
         // Farkas test on the multipliers y = (nu, zu - zl + pi) in the scaled problem: A'y is the dual residual rd itself
         R ny(0.0), na(0.0), sup(0.0);
         MPMPC_UNROLL
-        for (int i = 0; i < 3; ++i) { ny = max_(ny, sel(vx, abs_(s.nu[i]), zero)); sup = sup + sel(vx, leq[i] * s.nu[i], zero); }
+        for (int i = 0; i < NQ; ++i) { ny = max_(ny, sel(vx, abs_(s.nu[i]), zero)); sup = sup + sel(vx, leq[i] * s.nu[i], zero); }
         MPMPC_UNROLL
         for (int j = 0; j < E; ++j) {
           R lam = s.zu[j] - s.zl[j] + s.pi[j];
@@ -1191,18 +1464,18 @@ struct Solver {
       MPMPC_UNROLL
       for (int j = 0; j < E; ++j) { const R Hj = H_of(j); if constexpr (FQ) Hd[j] = Hj; h[j] = rcp_(Hj); }
       dense_terminal<!SOFT>(Hd, h);
-      factor_t<S>(h, reg);
+      factor_t<LAY>(h, reg);
       MPMPC_TICK_END(11);
       // ---- predictor and corrector share the factorisation.  (No iterative refinement of the directions: over
       //      thousands of instances of every configuration it changed neither an iteration count nor a status -
       //      the answer is made by the active-set solve that follows, which does refine.)
-      R dx[E], dnu[3], dsl[E], dsu[E], dzl[E], dzu[E], dpi[E];
+      R dx[E], dnu[NQ], dsl[E], dsu[E], dzl[E], dzu[E], dpi[E];
       R rcl[E], rcu[E];
       MPMPC_UNROLL
       for (int j = 0; j < E; ++j) { rcl[j] = s.sl[j] * s.zl[j]; rcu[j] = s.su[j] * s.zu[j]; }
       R alpha_aff(1.0);
       for (int pass = 0; pass < 2; ++pass) {
-        R rhs[E], nreq[3];
+        R rhs[E], nreq[NQ];
         [[maybe_unused]] R cul[E];          // phase 1: cu - cl of the entry
         MPMPC_UNROLL
         for (int j = 0; j < E; ++j) {
@@ -1216,25 +1489,25 @@ struct Solver {
           }
         }
         MPMPC_UNROLL
-        for (int i = 0; i < 3; ++i) nreq[i] = -rp[i];
+        for (int i = 0; i < NQ; ++i) nreq[i] = -rp[i];
         MPMPC_TICK_BEGIN(12);
-        kkt_solve_t<S>(rhs, nreq, dx, dnu);
+        kkt_solve_t<LAY>(rhs, nreq, dx, dnu);
         if constexpr (SOFT) {
           // One refinement step against the UN-regularised Newton matrix (phase 1 only: it is rare, and what it is
           // asked for is a clean ray - |A'y| / |y| drops from ~1e-6 to ~1e-9, far below the margin phase1_eps asks
           // of the support; the optimum of the hard problem is made by the refining active-set solve instead).
-          R Ad[3], Atd[E], r1[E], r2[3], ddx[E], ddn[3];
-          Aeq_mul_t<S>(dx, Ad);
-          AeqT_mul_t<S>(dnu, Atd);
+          R Ad[NQ], Atd[E], r1[E], r2[NQ], ddx[E], ddn[NQ];
+          Aeq_mul_t<LAY>(dx, Ad);
+          AeqT_mul_t<LAY>(dnu, Atd);
           MPMPC_UNROLL
           for (int j = 0; j < E; ++j) r1[j] = rhs[j] - fma_(rcp_(h[j]) - reg, dx[j], Atd[j]);
           MPMPC_UNROLL
-          for (int i = 0; i < 3; ++i) r2[i] = nreq[i] - Ad[i];
-          kkt_solve_t<S>(r1, r2, ddx, ddn);
+          for (int i = 0; i < NQ; ++i) r2[i] = nreq[i] - Ad[i];
+          kkt_solve_t<LAY>(r1, r2, ddx, ddn);
           MPMPC_UNROLL
           for (int j = 0; j < E; ++j) dx[j] = dx[j] + sel(vm[j], ddx[j], zero);
           MPMPC_UNROLL
-          for (int i = 0; i < 3; ++i) dnu[i] = dnu[i] + sel(vx, ddn[i], zero);
+          for (int i = 0; i < NQ; ++i) dnu[i] = dnu[i] + sel(vx, ddn[i], zero);
         }
         MPMPC_TICK_END(12);
         // largest step that keeps slacks and multipliers positive: 1 / max(-ds/s, -dz/z)
@@ -1282,7 +1555,7 @@ struct Solver {
             s.pi[j] = sel(active, fma_(al, dpi[j], s.pi[j]), s.pi[j]);
           }
           MPMPC_UNROLL
-          for (int i = 0; i < 3; ++i) s.nu[i] = sel(active, fma_(al, dnu[i], s.nu[i]), s.nu[i]);
+          for (int i = 0; i < NQ; ++i) s.nu[i] = sel(active, fma_(al, dnu[i], s.nu[i]), s.nu[i]);
           active = active & (stall < 3);      // steps collapsed: infeasible or hopelessly degenerate
         }
       }
@@ -1291,64 +1564,67 @@ struct Solver {
   }
 
   // OSQP's polish solve on a given active set, iterated with primal-dual active-set updates.
-  // On success (xs, nus, lam) is a KKT point of the scaled problem.
-  MPMPC_HD Mk active_set(const Box& bx, Mk aL[5], Mk aU[5], R xs[5], R nus[3], R lam[5],
+  // On success (xs, nus, lam) is a KKT point of the scaled problem.  LAY: LAY_FULL, or LAY_RED for the reduced
+  // problem (entries e_y, e_psi, kappa; pp, qq: cost diagonal and vector in that layout).
+  template <int LAY>
+  MPMPC_HD Mk active_set(const BoxT<LAY>& bx, const R* pp, const R* qq, const Mk* vm, Mk* aL, Mk* aU, R* xs, R* nus, R* lam,
                          const SolverParams& st, const Mk& run) {
+    constexpr int E = EN<LAY>, NQ = NR<LAY>;
     const R delta(st.as_delta), idelta(st.inv_as_delta), zero(0.0), one(1.0), tol(1e-9);
     Mk todo = run, okm = L::mfalse();
     for (int rnd = 0; rnd < st.as_rounds; ++rnd) {
       if (!L::wany(todo)) break;
-      R h[5], Hd[5], bound[5];
-      Mk act[5];
+      R h[E], Hd[E], bound[E];
+      Mk act[E];
       MPMPC_UNROLL
-      for (int j = 0; j < 5; ++j) {
+      for (int j = 0; j < E; ++j) {
         act[j] = aL[j] | aU[j] | bx.pin[j];
         bound[j] = sel(aU[j], bx.hi[j], bx.lo[j]);
-        Hd[j] = p[j] + delta + sel(act[j], idelta, zero);
+        Hd[j] = pp[j] + delta + sel(act[j], idelta, zero);
         h[j] = one / Hd[j];
       }
       dense_terminal(Hd, h);
       MPMPC_TICK_COUNT(17);
       MPMPC_TICK_BEGIN(13);
-      factor(h, delta);
+      factor_t<LAY>(h, delta);
       MPMPC_TICK_END(13);
-      R xn[5], nn[3], ln[5];
+      R xn[E], nn[NQ], ln[E];
       MPMPC_UNROLL
-      for (int j = 0; j < 5; ++j) xn[j] = ln[j] = zero;
+      for (int j = 0; j < E; ++j) xn[j] = ln[j] = zero;
       MPMPC_UNROLL
-      for (int i = 0; i < 3; ++i) nn[i] = zero;
+      for (int i = 0; i < NQ; ++i) nn[i] = zero;
       for (int rf = 0; rf <= st.as_refine; ++rf) {
-        R At[5], Ax[3], rhs[5], r2[3], r3[5], dx[5], dnu[3];
-        AeqT_mul(nn, At);
-        Aeq_mul(xn, Ax);
+        R At[E], Ax[NQ], rhs[E], r2[NQ], r3[E], dx[E], dnu[NQ];
+        AeqT_mul_t<LAY>(nn, At);
+        Aeq_mul_t<LAY>(xn, Ax);
         R rs(0.0);                       // KKT residual of the unregularised system at (xn, nn, ln)
-        R Pod[3] = {zero, zero, zero};
+        [[maybe_unused]] R Pod[3] = {zero, zero, zero};
         if constexpr (FQ) od_mul_add(pod, xn, Pod);
         MPMPC_UNROLL
-        for (int j = 0; j < 5; ++j) {
-          R r1 = -q[j] - p[j] * xn[j] - At[j] - ln[j];
+        for (int j = 0; j < E; ++j) {
+          R r1 = -qq[j] - pp[j] * xn[j] - At[j] - ln[j];
           if constexpr (FQ) { if (j < 3) r1 = r1 - Pod[j]; }
           r3[j] = sel(act[j], bound[j] - xn[j], zero);
           rhs[j] = fma_(r3[j], idelta, r1);
-          rs = max_(rs, sel(valid[j], max_(abs_(r1), abs_(r3[j])), zero));
+          rs = max_(rs, sel(vm[j], max_(abs_(r1), abs_(r3[j])), zero));
         }
         MPMPC_UNROLL
-        for (int i = 0; i < 3; ++i) { r2[i] = leq[i] - Ax[i]; rs = max_(rs, sel(vx, abs_(r2[i]), zero)); }
+        for (int i = 0; i < NQ; ++i) { r2[i] = leq[i] - Ax[i]; rs = max_(rs, sel(vx, abs_(r2[i]), zero)); }
         // the point already satisfies the system to rounding level (1e-15) for every instance in the wave: no further solve
         if (rf >= 1 && !L::wany(todo & (L::gmax(rs) > R(1e-15)))) break;
         MPMPC_TICK_COUNT(18);
         MPMPC_TICK_BEGIN(14);
-        kkt_solve(rhs, r2, dx, dnu);
+        kkt_solve_t<LAY>(rhs, r2, dx, dnu);
         MPMPC_TICK_END(14);
         R big(0.0);
         MPMPC_UNROLL
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < E; ++j) {
           ln[j] = ln[j] + sel(act[j], (dx[j] - r3[j]) * idelta, zero);
           xn[j] = xn[j] + dx[j];
-          big = max_(big, sel(valid[j], abs_(dx[j]) - R(1e-14) * abs_(xn[j]), zero));
+          big = max_(big, sel(vm[j], abs_(dx[j]) - R(1e-14) * abs_(xn[j]), zero));
         }
         MPMPC_UNROLL
-        for (int i = 0; i < 3; ++i) nn[i] = nn[i] + dnu[i];
+        for (int i = 0; i < NQ; ++i) nn[i] = nn[i] + dnu[i];
         // refinement has converged for every instance in the wave: stop early
         if (rf >= 1 && !L::wany(todo & (L::gmax(big) > R(1e-15)))) break;
         // ... or every instance still in the wave has a violation far beyond what refinement can still move
@@ -1358,38 +1634,63 @@ struct Solver {
           const R far(1e-6);
           Mk clear = L::mfalse();
           MPMPC_UNROLL
-          for (int j = 0; j < 5; ++j)
+          for (int j = 0; j < E; ++j)
             clear = clear | (bx.Lm[j] & !aL[j] & (xn[j] < bx.lo[j] - far)) | (bx.Um[j] & !aU[j] & (xn[j] > bx.hi[j] + far)) |
                     (aL[j] & (ln[j] > far)) | (aU[j] & (ln[j] < -far));
           if (!L::wany(todo & !L::gany(clear))) break;
         }
       }
       Mk anybad = L::mfalse();
-      Mk vL[5], vU[5], bL[5], bU[5];
+      Mk vL[E], vU[E], bL[E], bU_[E];
       MPMPC_UNROLL
-      for (int j = 0; j < 5; ++j) {
+      for (int j = 0; j < E; ++j) {
         vL[j] = bx.Lm[j] & !aL[j] & (xn[j] < bx.lo[j] - tol);
         vU[j] = bx.Um[j] & !aU[j] & (xn[j] > bx.hi[j] + tol);
         bL[j] = aL[j] & (ln[j] > tol);
-        bU[j] = aU[j] & (ln[j] < -tol);
-        anybad = anybad | vL[j] | vU[j] | bL[j] | bU[j];
+        bU_[j] = aU[j] & (ln[j] < -tol);
+        anybad = anybad | vL[j] | vU[j] | bL[j] | bU_[j];
       }
       anybad = L::gany(anybad);
       MPMPC_UNROLL
-      for (int j = 0; j < 5; ++j) {
+      for (int j = 0; j < E; ++j) {
         xs[j] = sel(todo, xn[j], xs[j]);
         lam[j] = sel(todo, ln[j], lam[j]);
         Mk nL = (aL[j] & !bL[j]) | vL[j];
-        Mk nU = ((aU[j] & !bU[j]) | vU[j]) & !nL;
+        Mk nU = ((aU[j] & !bU_[j]) | vU[j]) & !nL;
         aL[j] = selb(todo & anybad, nL, aL[j]);
         aU[j] = selb(todo & anybad, nU, aU[j]);
       }
       MPMPC_UNROLL
-      for (int i = 0; i < 3; ++i) nus[i] = sel(todo, nn[i], nus[i]);
+      for (int i = 0; i < NQ; ++i) nus[i] = sel(todo, nn[i], nus[i]);
       okm = okm | (todo & !anybad);
       todo = todo & anybad;
     }
     return okm;
+  }
+
+  // ---- reduced problem: the closed-form part.  Given the solution of the (e_y, e_psi, kappa) problem in xs[0], xs[1],
+  // xs[4] (scaled), fill in the speed v_k = argmin over its box of its own separable cost (xs[3], with its multiplier
+  // lam[3]) and roll the time state forward through its equality rows (xs[2]); the multipliers of the time rows and
+  // of the time boxes are zero.  All in the scaled problem, so that certificate() checks the FULL KKT system.
+  MPMPC_HD void reduced_complete(const Box& bx, R xs[5], R nus[3], R lam[5]) const {
+    const R zero(0.0);
+    // v: minimise 1/2 p3 x^2 + q3 x on [lo, hi]  (p3 > 0: the launcher takes the reduced path only then)
+    R xv = -q[3] / p[3];
+    xv = sel(bx.Um[3] & (xv > bx.hi[3]), bx.hi[3], xv);
+    xv = sel((bx.Lm[3] | bx.pin[3]) & (xv < bx.lo[3]), bx.lo[3], xv);
+    xv = sel(bx.pin[3], bx.lo[3], xv);
+    xs[3] = sel(valid[3], xv, zero);
+    lam[3] = sel(valid[3], -fma_(p[3], xs[3], q[3]), zero);
+    nus[2] = zero;
+    lam[2] = zero;
+    // t: row 2 of equality block k:  mI2 t_k + (a4 e_y + a5 t + b1 v)_{k-1} = leq2_k, a forward recurrence along the
+    // stages (once per solve: N steps of one fused multiply-add and one lane shift each)
+    R t = leq[2] / mI[2];                         // stage 0; later stages are overwritten step by step
+    for (int it = 0; it < N; ++it) {
+      const R inflow = L::up(fma_(b[1], xs[3], fma_(a[5], t, a[4] * xs[0])));
+      t = sel(first, t, (leq[2] - inflow) / mI[2]);
+    }
+    xs[2] = sel(vx, t, zero);
   }
 
   // KKT certificate in the UNSCALED problem: primal violation, stationarity, complementarity
@@ -1462,6 +1763,67 @@ struct Solver {
     for (int j = 0; j < 5; ++j) v = v + seli(aL[j], I(1 << j), I(0)) + seli(aU[j], I(32 << j), I(0));
     return v;
   }
+  // ---- the layouts the polish runs in (RED: template flag of the Solver, see the layout table above)
+  static constexpr int LAY_AS = RED ? LAY_RED : LAY_FULL;                                           // active-set rounds
+  static constexpr int LAY_IP = RED ? (kSplit ? LAY_REDSPLIT : LAY_RED) : (kSplit ? LAY_SPLIT : LAY_FULL);   // interior point
+
+  // the box, the cost and the validity masks of the lane's entries in layout LAY (from the 5-entry box bx)
+  template <int LAY>
+  MPMPC_HD void problem_in_layout(const Box& bx, BoxT<LAY>& bi, R* pp, R* qq, Mk* vm) {
+    constexpr int E = EN<LAY>;
+    const R one(1.0), zero(0.0);
+    if constexpr (SPL<LAY>) {
+      MPMPC_UNROLL
+      for (int i = 0; i < 2; ++i) bU[i] = sel(sU, L::from_lower(b[i]), zero);
+    }
+    to_lay<LAY>(bx.lo, bi.lo); to_lay<LAY>(bx.hi, bi.hi); to_lay<LAY>(p, pp); to_lay<LAY>(q, qq);
+    mask_to_lay<LAY>(bx.Lm, bi.Lm); mask_to_lay<LAY>(bx.Um, bi.Um); mask_to_lay<LAY>(bx.pin, bi.pin);
+    valid_lay<LAY>(vm);
+    // an entry the upper lanes do not have: unit cost keeps its arithmetic finite
+    if constexpr (LAY == LAY_SPLIT) pp[2] = sel(sU, one, pp[2]);
+    if constexpr (LAY == LAY_REDSPLIT) pp[1] = sel(sU, one, pp[1]);
+    (void)E;
+  }
+  template <int LAY>
+  MPMPC_HD void iterate_to_layout(const Ipm& s, IpmT<LAY>& si) const {
+    const R one(1.0);
+    to_lay<LAY>(s.x, si.x); to_lay<LAY>(s.sl, si.sl); to_lay<LAY>(s.su, si.su);
+    to_lay<LAY>(s.zl, si.zl); to_lay<LAY>(s.zu, si.zu); to_lay<LAY>(s.pi, si.pi);
+    if constexpr (LAY == LAY_SPLIT) { si.sl[2] = sel(sU, one, si.sl[2]); si.su[2] = sel(sU, one, si.su[2]); }
+    if constexpr (LAY == LAY_REDSPLIT) { si.sl[1] = sel(sU, one, si.sl[1]); si.su[1] = sel(sU, one, si.su[1]); }
+    MPMPC_UNROLL
+    for (int i = 0; i < NR<LAY>; ++i) si.nu[i] = s.nu[i];
+  }
+
+  // One active-set attempt from the guess (aL5, aU5) in the 5-entry view, in the layout LAY_AS.  On return (xs, nus,
+  // lam) hold the full point (reduced problem: completed by reduced_complete), aL5 / aU5 the final active set.
+  MPMPC_HD Mk active_set_full(const Box& bx, Mk aL5[5], Mk aU5[5], R xs[5], R nus[3], R lam[5], const SolverParams& st,
+                              const Mk& run) {
+    constexpr int LAY = LAY_AS;
+    constexpr int E = EN<LAY>, NQ = NR<LAY>;
+    BoxT<LAY> ba;
+    R pp[E], qq[E], xa[E], la[E], na[NQ];
+    Mk vm[E], aL[E], aU[E];
+    problem_in_layout<LAY>(bx, ba, pp, qq, vm);
+    mask_to_lay<LAY>(aL5, aL); mask_to_lay<LAY>(aU5, aU);
+    to_lay<LAY>(xs, xa); to_lay<LAY>(lam, la);
+    MPMPC_UNROLL
+    for (int i = 0; i < NQ; ++i) na[i] = nus[i];
+    Mk okm = active_set<LAY>(ba, pp, qq, vm, aL, aU, xa, na, la, st, run);
+    from_lay<LAY>(xa, xs); from_lay<LAY>(la, lam);
+    MPMPC_UNROLL
+    for (int i = 0; i < NQ; ++i) nus[i] = na[i];
+    mask_from_lay<LAY>(aL, aL5); mask_from_lay<LAY>(aU, aU5);
+    if constexpr (RED) {
+      reduced_complete(bx, xs, nus, lam);
+      // the speed's own activity, for the warm start of the next closed-loop step
+      aL5[2] = aU5[2] = L::mfalse();
+      aL5[3] = bx.Lm[3] & (lam[3] < R(0.0)) & valid[3];
+      aU5[3] = bx.Um[3] & (lam[3] > R(0.0)) & valid[3] & !aL5[3];
+    }
+    return okm;
+  }
+
   // Warm start (closed loop): `guess` is the active set of the previous step's certified plan, already shifted to
   // this step's stages.  One or two active-set rounds from it usually reproduce the optimum; whatever they
   // cannot certify goes through the normal path.  Runs on the scaled problem, before any ADMM.
@@ -1484,7 +1846,7 @@ struct Solver {
     // the batch decides the step)
     SolverParams sw = st;
     sw.as_rounds = st.as_rounds < 2 ? st.as_rounds : 2;
-    Mk okm = active_set(bx, aL, aU, xs, nus, lam, sw, run);
+    Mk okm = active_set_full(bx, aL, aU, xs, nus, lam, sw, run);
     R prim, stat;
     Mk cert = certificate(xs, nus, lam, st.cert_tol, prim, stat);
     Mk good = run & okm & cert;
@@ -1526,81 +1888,42 @@ struct Solver {
       s.zu[j] = sel(bx.Um[j], max_(yv, theta), zero);
       s.pi[j] = sel(bx.pin[j], yv, zero);
     }
-    // the interior-point stage runs in the split layout where the upper half-wave is free (kSplit)
-    constexpr bool S = kSplit;
-    constexpr int E = EN<S>;
-    BoxT<S> bi;
-    IpmT<S> si;
+    // the interior-point stage runs in the split layout where the upper half-wave is free (kSplit), and on the
+    // reduced problem where the time state separates (RED)
+    constexpr int LAY = LAY_IP;
+    constexpr int E = EN<LAY>;
+    BoxT<LAY> bi;
+    IpmT<LAY> si;
     R pp[E], qq[E];
     Mk vm[E];
-    if constexpr (S) {
-      MPMPC_UNROLL
-      for (int i = 0; i < 2; ++i) bU[i] = sel(sU, L::from_lower(b[i]), zero);
-      to3(bx.lo, bi.lo); to3(bx.hi, bi.hi); to3(p, pp); to3(q, qq);
-      to3(s.x, si.x); to3(s.sl, si.sl); to3(s.su, si.su); to3(s.zl, si.zl); to3(s.zu, si.zu); to3(s.pi, si.pi);
-      R mL[5], mU[5], mP[5], m3[3];
-      MPMPC_UNROLL
-      for (int j = 0; j < 5; ++j) { mL[j] = sel(bx.Lm[j], one, zero); mU[j] = sel(bx.Um[j], one, zero); mP[j] = sel(bx.pin[j], one, zero); }
-      to3(mL, m3);
-      MPMPC_UNROLL
-      for (int e = 0; e < 3; ++e) bi.Lm[e] = m3[e] > R(0.5);
-      to3(mU, m3);
-      MPMPC_UNROLL
-      for (int e = 0; e < 3; ++e) bi.Um[e] = m3[e] > R(0.5);
-      to3(mP, m3);
-      MPMPC_UNROLL
-      for (int e = 0; e < 3; ++e) { bi.pin[e] = m3[e] > R(0.5); vm[e] = val3[e]; }
-      // the third entry of the upper lanes does not exist: a unit slack pair keeps its arithmetic finite
-      si.sl[2] = sel(sU, one, si.sl[2]); si.su[2] = sel(sU, one, si.su[2]);
-      pp[2] = sel(sU, one, pp[2]);
-      MPMPC_UNROLL
-      for (int i = 0; i < 3; ++i) si.nu[i] = s.nu[i];
-    } else {
-      MPMPC_UNROLL
-      for (int j = 0; j < 5; ++j) {
-        bi.lo[j] = bx.lo[j]; bi.hi[j] = bx.hi[j]; bi.Lm[j] = bx.Lm[j]; bi.Um[j] = bx.Um[j]; bi.pin[j] = bx.pin[j];
-        si.x[j] = s.x[j]; si.sl[j] = s.sl[j]; si.su[j] = s.su[j]; si.zl[j] = s.zl[j]; si.zu[j] = s.zu[j]; si.pi[j] = s.pi[j];
-        pp[j] = p[j]; qq[j] = q[j]; vm[j] = valid[j];
-      }
-      MPMPC_UNROLL
-      for (int i = 0; i < 3; ++i) si.nu[i] = s.nu[i];
-    }
+    problem_in_layout<LAY>(bx, bi, pp, qq, vm);
+    iterate_to_layout<LAY>(s, si);
     double tol = st.ipm_tol;
     Mk todo = run;
     for (int attempt = 0; attempt < 2; ++attempt) {
       stash();
       MPMPC_TICK_BEGIN(4);
-      Mk conv = ipm<S>(bi, si, pp, qq, vm, st, tol, todo);
+      Mk conv = ipm<LAY>(bi, si, pp, qq, vm, st, tol, todo);
       MPMPC_TICK_END(4);
-      Mk aL[5], aU[5];
+      // active-set guess of the interior point: multiplier above slack
+      Mk gL[E], gU[E], aL[5], aU[5];
+      MPMPC_UNROLL
+      for (int e = 0; e < E; ++e) { gL[e] = bi.Lm[e] & (si.zl[e] > si.sl[e]); gU[e] = bi.Um[e] & (si.zu[e] > si.su[e]); }
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) aL[j] = aU[j] = L::mfalse();
+      mask_from_lay<LAY>(gL, aL); mask_from_lay<LAY>(gU, aU);
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) { aL[j] = bx.Lm[j] & aL[j]; aU[j] = bx.Um[j] & aU[j] & !aL[j]; }
       R xs[5], nus[3], lam[5];
-      if constexpr (S) {
-        R g3[3], g5[5];
-        MPMPC_UNROLL
-        for (int e = 0; e < 3; ++e) g3[e] = sel(bi.Lm[e] & (si.zl[e] > si.sl[e]), one, zero);
-        from3(g3, g5);
-        MPMPC_UNROLL
-        for (int j = 0; j < 5; ++j) aL[j] = bx.Lm[j] & (g5[j] > R(0.5));
-        MPMPC_UNROLL
-        for (int e = 0; e < 3; ++e) g3[e] = sel(bi.Um[e] & (si.zu[e] > si.su[e]), one, zero);
-        from3(g3, g5);
-        MPMPC_UNROLL
-        for (int j = 0; j < 5; ++j) aU[j] = bx.Um[j] & (g5[j] > R(0.5)) & !aL[j];
-        from3(si.x, xs);
-      } else {
-        MPMPC_UNROLL
-        for (int j = 0; j < 5; ++j) {
-          aL[j] = bx.Lm[j] & (si.zl[j] > si.sl[j]);
-          aU[j] = bx.Um[j] & (si.zu[j] > si.su[j]) & !aL[j];
-          xs[j] = si.x[j];
-        }
-      }
       MPMPC_UNROLL
-      for (int j = 0; j < 5; ++j) lam[j] = zero;
+      for (int j = 0; j < 5; ++j) { xs[j] = zero; lam[j] = zero; }
+      from_lay<LAY>(si.x, xs);
       MPMPC_UNROLL
-      for (int i = 0; i < 3; ++i) nus[i] = si.nu[i];
+      for (int i = 0; i < 3; ++i) nus[i] = zero;
+      MPMPC_UNROLL
+      for (int i = 0; i < NR<LAY>; ++i) nus[i] = si.nu[i];
       MPMPC_TICK_BEGIN(5);
-      Mk okm = active_set(bx, aL, aU, xs, nus, lam, st, todo & conv);
+      Mk okm = active_set_full(bx, aL, aU, xs, nus, lam, st, todo & conv);
       MPMPC_TICK_END(5);
       unstash();
       R prim, stat;
@@ -1637,6 +1960,8 @@ struct Solver {
   // reached in 5-10 interior-point iterations instead of the hundreds or thousands of ADMM iterations OSQP needs.
   // Certified instances: status PRIMAL_INFEASIBLE, x = least-violation point, (yeq, yb) = the ray, pri_res = largest
   // bound violation of x (unscaled).  Everything else is left untouched (status stays UNSOLVED).
+  // Reduced problem (RED): the speed boxes are consistent by construction and the time state is free, so feasibility
+  // is decided by the (e_y, e_psi, kappa) system alone; its ray has zero entries on the time rows and the speed boxes.
   MPMPC_HD void phase1(const SolverParams& st, const Mk& run) {
     if (!L::wany(run)) return;
     Box bx;
@@ -1657,68 +1982,44 @@ struct Solver {
       s.zu[j] = sel(bx.Um[j], theta * g[j], zero);
       s.pi[j] = zero;
     }
-    constexpr bool S = kSplit;
-    constexpr int E = EN<S>;
-    BoxT<S> bi;
-    IpmT<S> si;
+    constexpr int LAY = LAY_IP;
+    constexpr int E = EN<LAY>;
+    BoxT<LAY> bi;
+    IpmT<LAY> si;
     R pp[E], qq[E];
     Mk vm[E];
-    if constexpr (S) {
-      MPMPC_UNROLL
-      for (int i = 0; i < 2; ++i) bU[i] = sel(sU, L::from_lower(b[i]), zero);
-      to3(bx.lo, bi.lo); to3(bx.hi, bi.hi);
-      to3(s.x, si.x); to3(s.sl, si.sl); to3(s.su, si.su); to3(s.zl, si.zl); to3(s.zu, si.zu); to3(s.pi, si.pi);
-      R mL[5], mU[5], mP[5], m3[3];
-      MPMPC_UNROLL
-      for (int j = 0; j < 5; ++j) { mL[j] = sel(bx.Lm[j], one, zero); mU[j] = sel(bx.Um[j], one, zero); mP[j] = sel(bx.pin[j], one, zero); }
-      to3(mL, m3);
-      MPMPC_UNROLL
-      for (int e = 0; e < 3; ++e) bi.Lm[e] = m3[e] > R(0.5);
-      to3(mU, m3);
-      MPMPC_UNROLL
-      for (int e = 0; e < 3; ++e) bi.Um[e] = m3[e] > R(0.5);
-      to3(mP, m3);
-      MPMPC_UNROLL
-      for (int e = 0; e < 3; ++e) { bi.pin[e] = m3[e] > R(0.5); vm[e] = val3[e]; pp[e] = qq[e] = zero; }
-      si.sl[2] = sel(sU, one, si.sl[2]); si.su[2] = sel(sU, one, si.su[2]);
-      MPMPC_UNROLL
-      for (int i = 0; i < 3; ++i) si.nu[i] = s.nu[i];
-    } else {
-      MPMPC_UNROLL
-      for (int j = 0; j < 5; ++j) {
-        bi.lo[j] = bx.lo[j]; bi.hi[j] = bx.hi[j]; bi.Lm[j] = bx.Lm[j]; bi.Um[j] = bx.Um[j]; bi.pin[j] = bx.pin[j];
-        si.x[j] = s.x[j]; si.sl[j] = s.sl[j]; si.su[j] = s.su[j]; si.zl[j] = s.zl[j]; si.zu[j] = s.zu[j]; si.pi[j] = s.pi[j];
-        pp[j] = qq[j] = zero; vm[j] = valid[j];
-      }
-      MPMPC_UNROLL
-      for (int i = 0; i < 3; ++i) si.nu[i] = s.nu[i];
-    }
+    problem_in_layout<LAY>(bx, bi, pp, qq, vm);
+    iterate_to_layout<LAY>(s, si);
     stash();
     // phase 1 has no use for the cost: it waits in cold storage as well (slots COLD_COST ..)
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) { L::cold_put(COLD_COST + j, p[j]); L::cold_put(COLD_COST + 5 + j, q[j]); }
     L::fence();
     MPMPC_TICK_BEGIN(9);
-    ipm<S, true>(bi, si, pp, qq, vm, st, st.ipm_tol, run);
+    ipm<LAY, true>(bi, si, pp, qq, vm, st, st.ipm_tol, run);
     MPMPC_TICK_END(9);
     L::fence();
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) { p[j] = L::cold_get(COLD_COST + j); q[j] = L::cold_get(COLD_COST + 5 + j); }
     // back to five entries per lane: point and ray (lam = zu - zl + pi in variable space, yb = lam / g in row space)
-    R xs[5], lam[5], nus[3];
-    if constexpr (S) {
-      R l3[3];
-      MPMPC_UNROLL
-      for (int e = 0; e < 3; ++e) l3[e] = si.zu[e] - si.zl[e] + si.pi[e];
-      from3(l3, lam);
-      from3(si.x, xs);
-    } else {
-      MPMPC_UNROLL
-      for (int j = 0; j < 5; ++j) { lam[j] = si.zu[j] - si.zl[j] + si.pi[j]; xs[j] = si.x[j]; }
-    }
+    R xs[5], lam[5], nus[3], l3[E];
     MPMPC_UNROLL
-    for (int i = 0; i < 3; ++i) nus[i] = si.nu[i];
+    for (int j = 0; j < 5; ++j) { xs[j] = zero; lam[j] = zero; }
+    MPMPC_UNROLL
+    for (int e = 0; e < E; ++e) l3[e] = si.zu[e] - si.zl[e] + si.pi[e];
+    from_lay<LAY>(l3, lam);
+    from_lay<LAY>(si.x, xs);
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) nus[i] = zero;
+    MPMPC_UNROLL
+    for (int i = 0; i < NR<LAY>; ++i) nus[i] = si.nu[i];
     unstash();
+    if constexpr (RED) {
+      // a point of the full problem: any speed inside its box (its lower end), the time state rolled forward;
+      // the ray gets no entry from either (lam[3] must stay zero: reduced_complete would put the cost gradient there)
+      reduced_complete(bx, xs, nus, lam);
+      lam[3] = zero;
+    }
     // OSQP's test reads its ray from the cold slots of the last dual step
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) L::cold_put(COLD_DYB + j, sel(valid[j], lam[j] / g[j], zero));

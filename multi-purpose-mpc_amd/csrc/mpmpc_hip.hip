@@ -84,7 +84,8 @@ struct AssembleIn {
   const int* wp_id;
   const double *x0, *cc, *lb, *ub;
 };
-template <int G, int C, bool WARM, bool FQ = false>
+// VAR: 0 = the full problem with a diagonal terminal weight, 1 = full terminal weight (FQ), 2 = reduced polish (RED)
+template <int G, int C, bool WARM, int VAR = 0>
 __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, SolverParams st, int B, int ld,
                                                          AssembleIn ain, double* __restrict__ z,
                                                          double* __restrict__ u0, int* __restrict__ status,
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
   MPMPC_TICK_BEGIN(8);
   double fields[MPMPC_NUM_FIELDS];
   assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
-  Solver<L, FQ> s;
+  Solver<L, VAR == 1, VAR == 2> s;
   // (second launch of a packed batch: the interior-point iterations the first launch spent on this instance)
   const int base_ipm = (mode == 2 && iters) ? iters[inst * 2 + 1] : 0;
   s.template run<WARM, (G == 64)>(fields, B, inst, k, cfg.N, st, mode, guess, base_ipm, cfg.QN_offdiag);
@@ -425,6 +426,7 @@ static int check_settings(const mpmpc_settings* s) {
   if (s->polish == 2 && (!(s->ipm_reg > 0) || !(s->as_delta > 0) || !(s->ipm_tol > 0)))
     return fail(MPMPC_E_ARG, "polish needs ipm_reg, ipm_tol, as_delta > 0");
   if (s->phase1 != 0 && s->phase1 != 1) return fail(MPMPC_E_ARG, "phase1 must be 0 or 1");
+  if (s->reduce != 0 && s->reduce != 1) return fail(MPMPC_E_ARG, "reduce must be 0 or 1");
   if (!(s->ipm_diverged > 1) || !(s->phase1_theta > 0) || !(s->phase1_eps > 0))
     return fail(MPMPC_E_ARG, "need ipm_diverged > 1, phase1_theta > 0, phase1_eps > 0");
   return MPMPC_OK;
@@ -467,6 +469,7 @@ void mpmpc_default_settings(mpmpc_settings* s) {
   s->ipm_diverged = 1e3;
   s->phase1_theta = 1.0;
   s->phase1_eps = 1e-6;
+  s->reduce = 1;
 }
 
 int32_t mpmpc_stage_ld(int32_t N) { return host_stage_ld(N); }
@@ -931,6 +934,7 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y) {
   // code of the dense terminal block
   const bool fullqn = h->cfg.QN_offdiag[0] != 0.0 || h->cfg.QN_offdiag[1] != 0.0 || h->cfg.QN_offdiag[2] != 0.0;
   if (fullqn) G = 64;
+  const bool red = reducible(h->cfg, h->st);      // the polish may work on the (e_y, e_psi, kappa) problem
   // closed loop: the previous step's active sets as a first guess.  A launch with one instance per wave ends with
   // its slowest car, and with more than a handful of cars one of them always misses its guess (hit rate 91-93 %
   // per car and step: the miss pays for the attempt AND the normal path, 1024 cars -7 %), so "auto" warm-starts the
@@ -949,10 +953,13 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y) {
 #define LAUNCH(GG, CC, MODE, BLOCKS)                                              \
   do {                                                                            \
     if (GG == 64 && fullqn) {                                                     \
-      if (warm_act) LAUNCH_W(GG, CC, true, (GG == 64), MODE, BLOCKS);             \
-      else LAUNCH_W(GG, CC, false, (GG == 64), MODE, BLOCKS);                     \
-    } else if (warm_act) LAUNCH_W(GG, CC, true, false, MODE, BLOCKS);             \
-    else LAUNCH_W(GG, CC, false, false, MODE, BLOCKS);                            \
+      if (warm_act) LAUNCH_W(GG, CC, true, (GG == 64 ? 1 : 0), MODE, BLOCKS);     \
+      else LAUNCH_W(GG, CC, false, (GG == 64 ? 1 : 0), MODE, BLOCKS);             \
+    } else if (red) {                                                             \
+      if (warm_act) LAUNCH_W(GG, CC, true, 2, MODE, BLOCKS);                      \
+      else LAUNCH_W(GG, CC, false, 2, MODE, BLOCKS);                              \
+    } else if (warm_act) LAUNCH_W(GG, CC, true, 0, MODE, BLOCKS);                 \
+    else LAUNCH_W(GG, CC, false, 0, MODE, BLOCKS);                                \
   } while (0)
   if (first_mode == 1) HIP_TRY(hipMemsetAsync(h->tail, 0, sizeof(int), h->stream));
   const int C = lane_split(G, N);        // where the two elimination chains of the factorisation meet

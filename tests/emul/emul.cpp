@@ -15,7 +15,7 @@ using namespace mpmpc;
 
 // mode / tail as in mpmpc_solve_kernel: mode 1 appends the instances it leaves UNSOLVED to tail[1..] (tail[0] counts),
 // mode 2 runs one wave per listed instance
-template <int G, int C, bool FQ = false>
+template <int G, int C, bool FQ = false, bool RED = false>
 static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z,
                     double* u0, int* status, int* iters, double* resid, double* y, const int* guess = nullptr,
                     int* act = nullptr, int mode = 0, int* tail = nullptr) {
@@ -33,9 +33,9 @@ static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const dou
       gs.v[i] = (guess && in < B && kk >= 0 && kk <= cfg->N) ? guess[in * ld + kk] : 0;
       if (mode == 2) base.v[i] = iters[in * 2 + 1];
     }
-    Solver<L, FQ> s;
+    Solver<L, FQ, RED> s;
     typename L::real fields[MPMPC_NUM_FIELDS];
-    Solver<L, FQ>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    Solver<L, FQ, RED>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
     // (like the device: the packed kernels carry no phase-1 code when they run as the first of two launches)
     if (guess) s.template run<true>(fields, B, inst, k, cfg->N, make_params(*st), mode, gs, base, cfg->QN_offdiag);
     else if (mode == 1) s.template run<false, (G == 64)>(fields, B, inst, k, cfg->N, make_params(*st), mode, VI(0), base, cfg->QN_offdiag);
@@ -47,6 +47,13 @@ static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const dou
   }
 }
 
+// the variant the launcher would pick: reduced polish where the configuration allows it
+#define SOLVE_G(GG, CC, ...)                                                          \
+  do {                                                                                \
+    if (reducible(*cfg, *st)) solve_g<GG, CC, false, true>(__VA_ARGS__);              \
+    else solve_g<GG, CC>(__VA_ARGS__);                                                \
+  } while (0)
+
 extern "C" int emu_solve(const mpmpc_config* cfg, const mpmpc_settings* st, int G, const double* qp, int B,
                          double* z, double* u0, int* status, int* iters, double* resid, double* y) {
   if (cfg->N + 1 > G) return -1;
@@ -55,10 +62,10 @@ extern "C" int emu_solve(const mpmpc_config* cfg, const mpmpc_settings* st, int 
   if (fullqn && G != 64) return -1;          // the launcher gives such instances a wave each
   if (fullqn && C == 16) solve_g<64, 16, true>(cfg, st, qp, B, z, u0, status, iters, resid, y);
   else if (fullqn) solve_g<64, 32, true>(cfg, st, qp, B, z, u0, status, iters, resid, y);
-  else if (G == 64 && C == 16) solve_g<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y);
-  else if (G == 64) solve_g<64, 32>(cfg, st, qp, B, z, u0, status, iters, resid, y);
-  else if (G == 32) solve_g<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y);
-  else if (G == 16) solve_g<16, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y);
+  else if (G == 64 && C == 16) SOLVE_G(64, 16, cfg, st, qp, B, z, u0, status, iters, resid, y);
+  else if (G == 64) SOLVE_G(64, 32, cfg, st, qp, B, z, u0, status, iters, resid, y);
+  else if (G == 32) SOLVE_G(32, 16, cfg, st, qp, B, z, u0, status, iters, resid, y);
+  else if (G == 16) SOLVE_G(16, 16, cfg, st, qp, B, z, u0, status, iters, resid, y);
   else return -1;
   return 0;
 }
@@ -72,12 +79,12 @@ extern "C" int emu_solve_launch(const mpmpc_config* cfg, const mpmpc_settings* s
   if (n_tail) *n_tail = 0;
   if (G == 64 || !early) return emu_solve(cfg, st, G, qp, B, z, u0, status, iters, resid, y);
   std::vector<int> tail(B + 1, 0);
-  if (G == 32) solve_g<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 1, tail.data());
-  else if (G == 16) solve_g<16, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 1, tail.data());
+  if (G == 32) SOLVE_G(32, 16, cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 1, tail.data());
+  else if (G == 16) SOLVE_G(16, 16, cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 1, tail.data());
   else return -1;
   if (n_tail) *n_tail = tail[0];
-  if (lane_split(64, cfg->N) == 16) solve_g<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 2, tail.data());
-  else solve_g<64, 32>(cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 2, tail.data());
+  if (lane_split(64, cfg->N) == 16) SOLVE_G(64, 16, cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 2, tail.data());
+  else SOLVE_G(64, 32, cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 2, tail.data());
   return 0;
 }
 
@@ -88,10 +95,10 @@ extern "C" int emu_solve_warm(const mpmpc_config* cfg, const mpmpc_settings* st,
                               double* y, int* act) {
   if (cfg->N + 1 > G) return -1;
   const int C = lane_split(G, cfg->N);
-  if (G == 64 && C == 16) solve_g<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, guess, act);
-  else if (G == 64) solve_g<64, 32>(cfg, st, qp, B, z, u0, status, iters, resid, y, guess, act);
-  else if (G == 32) solve_g<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, guess, act);
-  else if (G == 16) solve_g<16, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, guess, act);
+  if (G == 64 && C == 16) SOLVE_G(64, 16, cfg, st, qp, B, z, u0, status, iters, resid, y, guess, act);
+  else if (G == 64) SOLVE_G(64, 32, cfg, st, qp, B, z, u0, status, iters, resid, y, guess, act);
+  else if (G == 32) SOLVE_G(32, 16, cfg, st, qp, B, z, u0, status, iters, resid, y, guess, act);
+  else if (G == 16) SOLVE_G(16, 16, cfg, st, qp, B, z, u0, status, iters, resid, y, guess, act);
   else return -1;
   return 0;
 }
