@@ -244,6 +244,7 @@ struct Solver {
   // ---- where this lane's stage fields live (the unscaled bounds are re-read for the certificate)
   // ---- scaled problem
   R mI[3], a[6], b[2], g[5], p[5], q[5], D[5], Eeq[3], Eb[5], c;
+  Mk p1_converged;       // phase 1 ended at its converged optimum (not at an earlier iterate that already passed the ray test)
   R pod[3], hod[3];      // FQ: off-diagonals (01, 02, 12) of the terminal cost block and of the terminal inv(H) block
   Mk term;               // this lane holds stage N
   R leq[3], lb[5], ub[5];
@@ -1128,6 +1129,13 @@ struct Solver {
 
   // OSQP is_primal_infeasible() on the last dual step
   MPMPC_HD Mk primal_infeasible(double eps) const {
+    R nrm, lhs, m;
+    farkas_values(nrm, lhs, m);
+    return (nrm > R(eps)) & (lhs < R(-eps) * nrm) & (m < R(eps) * nrm);
+  }
+  // the three numbers of that test for the ray in the cold slots COLD_DYEQ / COLD_DYB: |E dy|_inf, the support
+  // u'max(dy,0) + l'min(dy,0), and |inv(D) A'dy|_inf
+  MPMPC_HD void farkas_values(R& nrm_out, R& lhs_out, R& m_out) const {
     R nrm(0.0), lhs(0.0), pd[5], dyeq[3];
     MPMPC_UNROLL
     for (int i = 0; i < 3; ++i) dyeq[i] = L::cold_get(COLD_DYEQ + i);
@@ -1153,7 +1161,7 @@ struct Solver {
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) m = max_(m, sel(valid[j], abs_(fma_(g[j], pd[j], At[j]) / D[j]), R(0.0)));
     m = L::gmax(m);
-    return (nrm > R(eps)) & (lhs < R(-eps) * nrm) & (m < R(eps) * nrm);
+    nrm_out = nrm; lhs_out = lhs; m_out = m;
   }
 
   // OSQP is_dual_infeasible() on the last primal step
@@ -1413,6 +1421,7 @@ struct Solver {
       res = L::gmax(res);
       R mu = L::gsum(msum) / nb;
       Mk ok = (res < R(tol)) & (mu < R(tol));
+      if constexpr (SOFT) p1_converged = selb(active, ok, p1_converged);
       if constexpr (SOFT) {
         // Farkas test on the multipliers y = (nu, zu - zl + pi) in the scaled problem: A'y is the dual residual rd itself
         R ny(0.0), na(0.0), sup(0.0);
@@ -1990,6 +1999,7 @@ struct Solver {
     Mk vm[E];
     problem_in_layout<LAY>(bx, bi, pp, qq, vm);
     iterate_to_layout<LAY>(s, si);
+    p1_converged = L::mfalse();
     stash();
     // phase 1 has no use for the cost: it waits in cold storage as well (slots COLD_COST ..)
     MPMPC_UNROLL
@@ -2026,9 +2036,19 @@ struct Solver {
     MPMPC_UNROLL
     for (int i = 0; i < 3; ++i) L::cold_put(COLD_DYEQ + i, sel(vx, nus[i], zero));
     L::fence();
-    Mk cert = run & primal_infeasible(st.phase1_eps);
-    R prim, stat;
+    // Two ways to a verdict.  (A) OSQP's test at phase1_eps - any iterate whose ray passes is a certificate, the loop
+    // stops at the first one.  (B) phase 1 ran to its converged optimum and that optimum still violates a bound by
+    // more than cert_tol: the least violation is positive, the problem is infeasible however small the margin - taken
+    // when the ray's support is negative by at least a hundred times its own residual |A'y| (at convergence the
+    // residual is at the 1e-9 level, so this decides instances infeasible by well under a micrometre, which (A) at any
+    // fixed eps leaves to hundreds of ADMM iterations that end in "solved inaccurate").
+    R f_nrm, f_lhs, f_m, prim, stat;
+    farkas_values(f_nrm, f_lhs, f_m);
     certificate(xs, nus, lam, st.cert_tol, prim, stat);
+    const R eps1(st.phase1_eps);
+    Mk certA = (f_nrm > eps1) & (f_lhs < -eps1 * f_nrm) & (f_m < eps1 * f_nrm);
+    Mk certB = p1_converged & (prim > R(st.cert_tol)) & (f_nrm > R(0.0)) & (f_lhs < R(-100.0) * f_m) & (f_lhs < R(0.0));
+    Mk cert = run & (certA | certB);
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) { x[j] = sel(cert, xs[j], x[j]); yb[j] = sel(cert, lam[j] / g[j], yb[j]); }
     MPMPC_UNROLL

@@ -574,15 +574,37 @@ def farkas_certificate(A, l, u, y, eps=1e-4):
     return dict(ok=bool(support < -eps and aty < eps), support=support, aty=aty, norm=nrm)
 
 
+def _farkas_values(w: Workspace, dy):
+    """the three numbers of OSQP's primal-infeasibility test: |E dy|_inf, u'max(dy,0) + l'min(dy,0), |inv(D) A'dy|_inf"""
+    lo_inf = w.l < -OSQP_INFTY * MIN_SCALING
+    up_inf = w.u > OSQP_INFTY * MIN_SCALING
+    dy = np.where(up_inf & lo_inf, 0.0,
+                  np.where(up_inf, np.minimum(dy, 0.0), np.where(lo_inf, np.maximum(dy, 0.0), dy)))
+    return (_ninf(w.E * dy), float(np.sum(w.u * np.maximum(dy, 0.0) + w.l * np.minimum(dy, 0.0))),
+            _ninf(w.Dinv * (w.A.T @ dy)))
+
+
 def _phase1(w: Workspace, st: Settings, x0=None):
-    """Phase 1 on the scaled problem of `w`.  -> (x, y, iterations, certified): certified means (x, y) passed OSQP's
-    primal-infeasibility test (unscaled norms, eps_prim_inf) with y as the ray."""
+    """Phase 1 on the scaled problem of `w`.  -> (x, y, iterations, certified).  Two ways to a verdict:
+    (A) OSQP's primal-infeasibility test (unscaled norms) at phase1_eps: any iterate whose ray passes is a
+        certificate, the iteration stops at the first one;
+    (B) the iteration ran to its converged optimum and that optimum violates a bound by more than cert_tol: the least
+        violation is positive, so the problem is infeasible however small the margin - taken when the ray's support is
+        negative by at least a hundred times its own residual |A'y|."""
     n, m = w.n, w.m
     soft = np.max(np.abs(w.A), axis=1) ** 2
     stop = lambda x, y: _primal_infeasible(w, y, st.phase1_eps)
     x, y, it, conv, _ = _ipm_refine(w, np.zeros(n) if x0 is None else x0, np.zeros(m), st, st.ipm_tol, st.phase1_theta,
                                     soft=soft, stop=stop)
-    return x, y, it, bool(_primal_infeasible(w, y, st.phase1_eps))
+    if _primal_infeasible(w, y, st.phase1_eps):
+        return x, y, it, True
+    if conv:            # the ray test failed on the final iterate: the iteration ended at its converged optimum
+        nrm, lhs, res = _farkas_values(w, y)
+        xs, ys = w.unscale(x, y)
+        prim = kkt_certificate(w.P0, w.q0, w.A0, w.l0, w.u0, xs, ys)["prim"]
+        if prim > st.cert_tol and nrm > 0.0 and lhs < 0.0 and lhs < -100.0 * res:
+            return x, y, it, True
+    return x, y, it, False
 
 
 # ---------------------------------------------------------------------------

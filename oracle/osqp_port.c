@@ -757,17 +757,38 @@ static int phase1(work_t* w, double* x_out, double* y_out, oracle_info* info) {
   double *tn = (double*)malloc(sizeof(double) * n), *tm = (double*)malloc(sizeof(double) * m);
   int *low = (int*)calloc(m, sizeof(int)), *upp = (int*)calloc(m, sizeof(int));
   int nit = 0;
-  ipm_refine(w, w->K, w->F, &cl, x, y, st->ipm_tol, st->phase1_theta, &nit, low, upp, soft);
+  int conv = ipm_refine(w, w->K, w->F, &cl, x, y, st->ipm_tol, st->phase1_theta, &nit, low, upp, soft);
   info->ipm_iters += nit;
+  /* (A) OSQP's test at phase1_eps: any iterate whose ray passes is a certificate */
   int cert = primal_infeasible(w, y, st->phase1_eps, tn, tm);
   memcpy(w->P.x, Psave, sizeof(double) * pnnz); memcpy(w->q, qsave, sizeof(double) * n);
+  double *xs = (double*)malloc(sizeof(double) * n), *ys = (double*)malloc(sizeof(double) * m);
+  for (int j = 0; j < n; ++j) xs[j] = w->D[j] * x[j];
+  for (int r = 0; r < m; ++r) ys[r] = w->E[r] * y[r] * w->cinv;
+  double pv, sv;
+  certificate(w, xs, ys, st->cert_tol, &pv, &sv);
+  if (!cert && conv) {
+    /* (B) the iteration ran to its converged optimum (it did not stop at the ray test) and that optimum still violates
+       a bound by more than cert_tol: infeasible however small the margin - taken when the ray's support is negative by
+       at least a hundred times its own residual |A'y| */
+    double nrm = 0, lhs = 0;
+    for (int r = 0; r < m; ++r) {
+      int lo_inf = w->l[r] < -INF_BOUND, up_inf = w->u[r] > INF_BOUND;
+      double d = y[r];
+      if (up_inf && lo_inf) d = 0; else if (up_inf) d = dmin(d, 0); else if (lo_inf) d = dmax(d, 0);
+      tm[r] = d;
+      nrm = dmax(nrm, fabs(w->E[r] * d));
+      lhs += w->u[r] * dmax(d, 0) + w->l[r] * dmin(d, 0);
+    }
+    csc_tmul(&w->A, tm, tn);
+    double res = ninf_s(w->Dinv, tn, n);
+    if (pv > st->cert_tol && nrm > 0.0 && lhs < 0.0 && lhs < -100.0 * res) cert = 1;
+  }
   if (cert) {
-    for (int j = 0; j < n; ++j) x_out[j] = w->D[j] * x[j];
-    for (int r = 0; r < m; ++r) y_out[r] = w->E[r] * y[r] * w->cinv;
-    double pv, sv;
-    certificate(w, x_out, y_out, st->cert_tol, &pv, &sv);
+    memcpy(x_out, xs, sizeof(double) * n); memcpy(y_out, ys, sizeof(double) * m);
     info->status = PRIMAL_INFEASIBLE; info->polished = 0; info->pri_res = pv; info->dua_res = 0.0;
   }
+  free(xs); free(ys);
   free(cl.eq); free(cl.L); free(cl.U); free(soft); free(Psave); free(qsave); free(x); free(y); free(tn); free(tm); free(low); free(upp);
   return cert;
 }
