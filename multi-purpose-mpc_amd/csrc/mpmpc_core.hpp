@@ -2006,7 +2006,9 @@ struct Solver {
     for (int j = 0; j < 5; ++j) { L::cold_put(COLD_COST + j, p[j]); L::cold_put(COLD_COST + 5 + j, q[j]); }
     L::fence();
     MPMPC_TICK_BEGIN(9);
-    ipm<LAY, true>(bi, si, pp, qq, vm, st, st.ipm_tol, run);
+    // (phase 1 converges two digits further than the polish: for an instance infeasible by a tenth of a millimetre the
+    //  quantities of the verdict - the ray's support - are themselves at the 1e-9 level)
+    ipm<LAY, true>(bi, si, pp, qq, vm, st, st.ipm_tol * 1e-2, run);
     MPMPC_TICK_END(9);
     L::fence();
     MPMPC_UNROLL
@@ -2049,6 +2051,10 @@ struct Solver {
     Mk certA = (f_nrm > eps1) & (f_lhs < -eps1 * f_nrm) & (f_m < eps1 * f_nrm);
     Mk certB = p1_converged & (prim > R(st.cert_tol)) & (f_nrm > R(0.0)) & (f_lhs < R(-100.0) * f_m) & (f_lhs < R(0.0));
     Mk cert = run & (certA | certB);
+#ifdef MPMPC_EMU_DEBUG
+    std::fprintf(stderr, "phase1: nrm %.3e lhs %.3e m %.3e prim %.3e converged %d A %d B %d ipm_iters %d\n", f_nrm.v[16], f_lhs.v[16], f_m.v[16],
+                 prim.v[16], (int)p1_converged.v[16], (int)certA.v[16], (int)certB.v[16], ipm_iters.v[16]);
+#endif
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) { x[j] = sel(cert, xs[j], x[j]); yb[j] = sel(cert, lam[j] / g[j], yb[j]); }
     MPMPC_UNROLL

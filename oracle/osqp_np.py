@@ -594,7 +594,9 @@ def _phase1(w: Workspace, st: Settings, x0=None):
     n, m = w.n, w.m
     soft = np.max(np.abs(w.A), axis=1) ** 2
     stop = lambda x, y: _primal_infeasible(w, y, st.phase1_eps)
-    x, y, it, conv, _ = _ipm_refine(w, np.zeros(n) if x0 is None else x0, np.zeros(m), st, st.ipm_tol, st.phase1_theta,
+    # (two digits beyond the polish's tolerance: for an instance infeasible by a tenth of a millimetre the quantities of
+    #  the verdict - the ray's support - are themselves at the 1e-9 level)
+    x, y, it, conv, _ = _ipm_refine(w, np.zeros(n) if x0 is None else x0, np.zeros(m), st, st.ipm_tol * 1e-2, st.phase1_theta,
                                     soft=soft, stop=stop)
     if _primal_infeasible(w, y, st.phase1_eps):
         return x, y, it, True

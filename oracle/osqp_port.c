@@ -757,7 +757,8 @@ static int phase1(work_t* w, double* x_out, double* y_out, oracle_info* info) {
   double *tn = (double*)malloc(sizeof(double) * n), *tm = (double*)malloc(sizeof(double) * m);
   int *low = (int*)calloc(m, sizeof(int)), *upp = (int*)calloc(m, sizeof(int));
   int nit = 0;
-  int conv = ipm_refine(w, w->K, w->F, &cl, x, y, st->ipm_tol, st->phase1_theta, &nit, low, upp, soft);
+  /* (two digits beyond the polish's tolerance: the quantities of a marginal verdict are themselves at the 1e-9 level) */
+  int conv = ipm_refine(w, w->K, w->F, &cl, x, y, st->ipm_tol * 1e-2, st->phase1_theta, &nit, low, upp, soft);
   info->ipm_iters += nit;
   /* (A) OSQP's test at phase1_eps: any iterate whose ray passes is a certificate */
   int cert = primal_infeasible(w, y, st->phase1_eps, tn, tm);
