@@ -1444,11 +1444,16 @@ struct Solver {
       active = active & !ok;
       MPMPC_TICK_END(10);
       if (it == st.ipm_max_iter || !L::wany(active)) break;
+#ifdef MPMPC_EMU_DEBUG
+      std::fprintf(stderr, "  ipm%s it %2d res %.3e mu %.3e mu_min %.3e active %d\n", SOFT ? "(p1)" : "", it, res.v[16], mu.v[16], mu_min.v[16], (int)active.v[16]);
+#endif
       if constexpr (!SOFT) {
         // the complementarity measure of a feasible problem falls (nearly) monotonically; on an infeasible one the
         // multipliers blow up within a few iterations (mu jumps by 4-5 orders of magnitude): give up at once, phase 1
         // is what can decide such an instance
-        active = active & !(mu > R(st.ipm_diverged) * mu_min);
+        // ... and so is a complementarity measure that has collapsed far below the tolerance while the residual
+        // has not moved: the iterate sits on the boundary of an empty set
+        active = active & !(mu > R(st.ipm_diverged) * mu_min) & !((mu < R(tol * 1e-3)) & (res > R(1e-5)));
         mu_min = min_(mu_min, mu);
         if (!L::wany(active)) break;
       }

@@ -466,7 +466,7 @@ void mpmpc_default_settings(mpmpc_settings* s) {
   s->early_polish = 1;
   s->early_scaling = 2;
   s->phase1 = 1;
-  s->ipm_diverged = 1e3;
+  s->ipm_diverged = 1e2;
   s->phase1_theta = 1.0;
   s->phase1_eps = 1e-6;
   s->reduce = 1;

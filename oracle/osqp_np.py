@@ -77,7 +77,7 @@ class Settings:
     ipm_tol: float = 1e-9
     ipm_reg: float = 1e-8
     ipm_max_iter: int = 30
-    ipm_diverged: float = 1e3    # interior point stops when mu exceeds this multiple of its smallest value so far
+    ipm_diverged: float = 1e2    # interior point stops when mu exceeds this multiple of its smallest value so far
     as_delta: float = 1e-9      # (the device uses 1e-10: fewer refinement solves; a general LDL of this KKT matrix loses
                                 #  accuracy there - the plan moves by 1e-5 - so the checker keeps OSQP-polish-like 1e-9)
     as_refine: int = 5
@@ -493,8 +493,8 @@ def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, 
         # the complementarity measure of a feasible problem falls (nearly) monotonically; on an infeasible one the
         # multipliers blow up within a few iterations (mu jumps by 4-5 orders of magnitude): give up at once, the
         # phase-1 test is the one that can decide such an instance
-        if soft is None and mu > st.ipm_diverged * mu_min:
-            break
+        if soft is None and (mu > st.ipm_diverged * mu_min or (mu < tol * 1e-3 and res > 1e-5)):
+            break           # (... or mu has collapsed far below the tolerance while the residual has not moved)
         mu_min = min(mu_min, mu)
         wt = np.where(L, zl / sl, 0.0) + np.where(U, zu / su, 0.0)
         d = np.where(eq, reg, np.where(L | U, 1.0 / np.maximum(wt, 1e-300), 1e30))

@@ -537,7 +537,7 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
     if (it == st->ipm_max_iter) break;
     /* mu of a feasible problem falls (nearly) monotonically; on an infeasible one the multipliers blow up within a few
        iterations: give up at once, phase 1 is what can decide such an instance */
-    if (!soft && mu > st->ipm_diverged * mu_min) break;
+    if (!soft && (mu > st->ipm_diverged * mu_min || (mu < tol * 1e-3 && res > 1e-5))) break;   /* ... or mu collapsed while the residual stands */
     mu_min = dmin(mu_min, mu);
     for (int r = 0; r < m; ++r) {
       double wt = (cl->L[r] ? zl[r] / sl[r] : 0.0) + (cl->U[r] ? zu[r] / su[r] : 0.0);
