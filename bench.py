@@ -58,15 +58,24 @@ def k1_bytes_per_solve(N):
 #   step per stage (per stage: factor 180 flops, KKT solve 110).
 # "executed": every wave instruction times the N + 1 stage-holding lanes, serial steps as often as they are executed
 #   (round 1's figure).
-# key: (one lane per stage with the split interior-point layout, i.e. N + 1 <= 32;  certified optimal / Farkas-certified)
+# key: (N + 1 <= 32, i.e. one lane per stage with the split interior-point layout;  reduced polish (mpmpc_settings::reduce
+#       applies: t carries neither cost nor bound);  certified optimal / Farkas-certified)
 _FLOPS = {
-    (True, 1): dict(algorithmic=(81447.0, 40273.0), executed=(300857.0, 96760.0), N=30),
-    (True, -3): dict(algorithmic=(132612.0, 42339.0), executed=(318920.0, 104347.0), N=30),
-    (False, 1): dict(algorithmic=(47970.0, 64030.0), executed=(215726.0, 288391.0), N=50),
+    (True, True, 1): dict(algorithmic=(64063.0, 24032.0), executed=(183696.0, 42909.0), N=30),
+    (True, True, -3): dict(algorithmic=(51230.0, 30599.0), executed=(99037.0, 57290.0), N=30),
+    (True, False, 1): dict(algorithmic=(81447.0, 40273.0), executed=(300857.0, 96760.0), N=30),
+    (True, False, -3): dict(algorithmic=(132612.0, 42339.0), executed=(318920.0, 104347.0), N=30),
+    (False, False, 1): dict(algorithmic=(47970.0, 64030.0), executed=(215726.0, 288391.0), N=50),
 }
 
 
-def k2_flops(N, status, ipm_iters, kind):
+def reduced_polish(cfg, settings):
+    """mirror of mpmpc::reducible (csrc/mpmpc_core.hpp): may the polish solve the (e_y, e_psi, kappa) problem?"""
+    return bool(settings.reduce and settings.polish and cfg.Q[2] == 0.0 and cfg.QN[2] == 0.0 and not any(cfg.QN_offdiag)
+                and cfg.R[0] > 0.0 and cfg.xmin[2] <= -1e30 and cfg.xmax[2] >= 1e30)
+
+
+def k2_flops(N, status, ipm_iters, kind, reduced):
     """flops of a batch by the fit above, scaled linearly in the number of stages away from the fitted horizon"""
     total = 0.0
     split = N + 1 <= 32
@@ -74,7 +83,7 @@ def k2_flops(N, status, ipm_iters, kind):
         m = (status == stt) if stt == -3 else (status != -3)
         if not m.any():
             continue
-        f = _FLOPS.get((split, stt)) or _FLOPS[(split, 1)]
+        f = _FLOPS.get((split, reduced, stt)) or _FLOPS.get((split, False, stt)) or _FLOPS[(split, False, 1)]
         c0, c1 = f[kind]
         total += float(np.sum(c0 + c1 * ipm_iters[m].astype(float))) * (N + 1) / (f["N"] + 1)
     return total
@@ -290,12 +299,14 @@ def main():
                                    "(mpmpc_set_outputs(0)).  K2 is FP64-VALU / dependency-chain bound, not HBM bound (DESIGN.md "
                                    "section 5): see roofline_fp64"}
         ipm = sol.iters[:, 1]
-        fa, fe = k2_flops(N, sol.status, ipm, "algorithmic"), k2_flops(N, sol.status, ipm, "executed")
+        red = reduced_polish(cfg, settings)
+        fa, fe = k2_flops(N, sol.status, ipm, "algorithmic", red), k2_flops(N, sol.status, ipm, "executed", red)
         out["roofline_fp64"] = {"bound": "fp64-valu", "kernel": "mpmpc_solve_kernel", "peak": FP64_VALU_PEAK / 1e12, "unit": "TFLOP/s",
                                 "achieved": fa / (ms_k2 * 1e-3) / 1e12, "frac": fa / (ms_k2 * 1e-3) / FP64_VALU_PEAK,
                                 "frac_algorithmic": fa / (ms_k2 * 1e-3) / FP64_VALU_PEAK,
                                 "frac_executed": fe / (ms_k2 * 1e-3) / FP64_VALU_PEAK,
                                 "flops_per_solve_algorithmic": fa / B, "flops_per_solve_executed": fe / B,
+                                "reduced_polish": red,
                                 "note": "algorithmic = structure-exploiting count of the implemented recurrence (one step per stage "
                                         "and serial sweep; per stage: factor 180, KKT solve 110 flops); executed = wave "
                                         "instructions x stage-holding lanes; both fitted on the census of the emulated lane "

@@ -59,6 +59,13 @@ def default_settings(**kw) -> Settings:
     return s
 
 
+def stock_settings(**kw) -> Settings:
+    """The reference's own solver call (src/MPC.py:158-159,183): OSQP at its defaults and nothing else - no polish, no
+    phase 1; statuses and iterates are those of the restated OSQP (eps = 1e-3: up to ~1 rad away from the optimum in
+    delta_0 on this problem family)."""
+    return default_settings(polish=0, early_polish=0, phase1=0, reduce=0, **kw)
+
+
 def make_config(N, Q, R, QN, xmin, xmax, umin, umax, ay_max, wheelbase, circular=True, max_batch=1,
                 device=0) -> Config:
     if not 3 <= int(N) <= MAX_HORIZON:

@@ -19,7 +19,7 @@ import mpmpc      # noqa: E402
 import scenarios  # noqa: E402
 
 NAMES = {0: "load", 1: "ruiz scaling", 2: "admm", 3: "polish (all)", 4: "  interior point", 5: "  active set",
-         6: "  certificate", 7: "store", 8: "kernel body", 10: "    ipm residuals", 11: "    ipm rcp + factor",
+         6: "  certificate", 9: "phase 1", 7: "store", 8: "kernel body", 10: "    ipm residuals", 11: "    ipm rcp + factor",
          12: "    ipm kkt solves", 13: "    as factor", 14: "    as kkt solves"}
 COUNTS = {16: "ipm iterations", 17: "as rounds", 18: "as solves"}
 
