@@ -72,7 +72,7 @@ _FLOPS = {
 def reduced_polish(cfg, settings):
     """mirror of mpmpc::reducible (csrc/mpmpc_core.hpp): may the polish solve the (e_y, e_psi, kappa) problem?"""
     return bool(settings.reduce and settings.polish and cfg.Q[2] == 0.0 and cfg.QN[2] == 0.0 and not any(cfg.QN_offdiag)
-                and cfg.R[0] > 0.0 and cfg.xmin[2] <= -1e30 and cfg.xmax[2] >= 1e30)
+                and cfg.R[0] > 0.0 and cfg.xmin[2] <= -1e30 and cfg.xmax[2] >= 1e30 and cfg.xmin[1] <= -1e30 and cfg.xmax[1] >= 1e30)
 
 
 def k2_flops(N, status, ipm_iters, kind, reduced):

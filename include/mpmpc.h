@@ -101,7 +101,7 @@ typedef struct {
                             cannot be met by a few tenths of a millimetre is still proved infeasible instead of being
                             handed to the ADMM iteration (which calls it "solved" at eps = 1e-3; status 2). */
   int32_t reduce;        /* 1 (default): when the time state carries neither cost nor bound (Q[2] = QN[2] = 0, QN_offdiag
-                            without t, xmin[2] = -inf, xmax[2] = +inf, R[0] > 0 - the reference's own tracking weights,
+                            without t, xmin[1..2] = -inf, xmax[1..2] = +inf, R[0] > 0 - the reference's own tracking weights,
                             src/simulation.py:101-111) the certified polish and phase 1 solve the REDUCED problem: t enters
                             no other state's dynamics and the speed v drives t alone, so the QP separates into
                             v_k = clip(v_ref_k) in closed form, the roll-forward of t, and the QP in (e_y, e_psi, kappa) with

@@ -203,7 +203,8 @@ inline SolverParams make_params(const mpmpc_settings& st) {
 // in the Solver: the time state must carry neither cost nor bound, the speed must have its own strictly convex cost.)
 inline bool reducible(const mpmpc_config& c, const mpmpc_settings& st) {
   return st.reduce != 0 && st.polish != 0 && c.Q[2] == 0.0 && c.QN[2] == 0.0 && c.QN_offdiag[0] == 0.0 &&
-         c.QN_offdiag[1] == 0.0 && c.QN_offdiag[2] == 0.0 && c.R[0] > 0.0 && !(c.xmin[2] > -INFTY) && !(c.xmax[2] < INFTY);
+         c.QN_offdiag[1] == 0.0 && c.QN_offdiag[2] == 0.0 && c.R[0] > 0.0 && !(c.xmin[2] > -INFTY) && !(c.xmax[2] < INFTY) &&
+         !(c.xmin[1] > -INFTY) && !(c.xmax[1] < INFTY);      // (and e_psi unbounded: the reduced layouts carry no slack for it)
 }
 
 // Lane split of the twisted factorisation for G lanes per instance and horizon N (shared by the
@@ -1383,12 +1384,16 @@ struct Solver {
   MPMPC_HD Mk ipm(const BoxT<LAY>& bx, IpmT<LAY>& s, const R* pp, const R* qq, const Mk* vm, const SolverParams& st,
                   double tol, const Mk& run) {
     constexpr int E = EN<LAY>, NQ = NR<LAY>;
+    // In the reduced layouts entry 1 is e_psi (lower lanes) or nothing (upper lanes): never boxed - the reduced
+    // polish is only taken when e_psi has no bound (reducible()) - so all of its slack arithmetic is left out at
+    // compile time (the loops below are unrolled: boxed(j) is a constant in every copy).
+    auto boxed = [](int j) constexpr { return !(LAY >= LAY_RED && j == 1); };
     MPMPC_COUNT_CONTEXT(SPL<LAY> ? 1 : 0);
     const R reg(st.ipm_reg), ireg(st.inv_ipm_reg), one(1.0), zero(0.0);
     Mk active = run, conv = L::mfalse();
     R cnt(0.0);
     MPMPC_UNROLL
-    for (int j = 0; j < E; ++j) cnt = cnt + sel(bx.Lm[j], one, zero) + sel(bx.Um[j], one, zero);
+    for (int j = 0; j < E; ++j) if (boxed(j)) cnt = cnt + sel(bx.Lm[j], one, zero) + sel(bx.Um[j], one, zero);
     R nb = max_(L::gsum(cnt), one);
     I stall(0);
     R mu_min(1e300);
@@ -1415,6 +1420,7 @@ struct Solver {
           rd[j] = fma_(pp[j], s.x[j], qq[j]) + At[j] - s.zl[j] + s.zu[j] + s.pi[j];
           if constexpr (FQ) { if (j < 3) rd[j] = rd[j] + Pod[j]; }
         }
+        if (!boxed(j)) { res = max_(res, sel(vm[j], abs_(rd[j]), zero)); continue; }
         res = max_(res, sel(vm[j], max_(max_(abs_(rd[j]), abs_(rpin_of(j))), max_(abs_(rl_of(j)), abs_(ru_of(j)))), zero));
         msum = msum + sel(bx.Lm[j], s.sl[j] * s.zl[j], zero) + sel(bx.Um[j], s.su[j] * s.zu[j], zero);
       }
@@ -1429,9 +1435,10 @@ struct Solver {
         for (int i = 0; i < NQ; ++i) { ny = max_(ny, sel(vx, abs_(s.nu[i]), zero)); sup = sup + sel(vx, leq[i] * s.nu[i], zero); }
         MPMPC_UNROLL
         for (int j = 0; j < E; ++j) {
+          na = max_(na, sel(vm[j], abs_(rd[j]), zero));
+          if (!boxed(j)) continue;
           R lam = s.zu[j] - s.zl[j] + s.pi[j];
           ny = max_(ny, sel(vm[j], abs_(lam), zero));
-          na = max_(na, sel(vm[j], abs_(rd[j]), zero));
           // hi max(lam, 0) + lo min(lam, 0); an infinite side carries no multiplier (zl / zu are zero there)
           sup = sup + sel(vm[j] & (lam > zero) & (bx.Um[j] | bx.pin[j]), sel(bx.pin[j], bx.lo[j], bx.hi[j]) * lam, zero) +
                 sel(vm[j] & (lam < zero) & (bx.Lm[j] | bx.pin[j]), bx.lo[j] * lam, zero);
@@ -1463,9 +1470,10 @@ struct Solver {
       // ---- factor.  Every division by a slack below is a product with its reciprocal, taken once.
       R isl[E], isu[E], h[E];
       MPMPC_UNROLL
-      for (int j = 0; j < E; ++j) { isl[j] = rcp_(s.sl[j]); isu[j] = rcp_(s.su[j]); }
+      for (int j = 0; j < E; ++j) if (boxed(j)) { isl[j] = rcp_(s.sl[j]); isu[j] = rcp_(s.su[j]); }
       [[maybe_unused]] R kap[E];        // phase 1: k = 1 / (1 + th) of the soft entries, th = zl / sl + zu / su
       auto H_of = [&](int j) {
+        if (!boxed(j)) return SOFT ? reg : pp[j] + reg;
         if constexpr (SOFT) {
           kap[j] = rcp_(one + sel(bx.Lm[j], s.zl[j] * isl[j], zero) + sel(bx.Um[j], s.zu[j] * isu[j], zero));
           return (reg + one) - kap[j] + sel(bx.pin[j], ireg, zero);          // k th = 1 - k
@@ -1486,13 +1494,14 @@ struct Solver {
       R dx[E], dnu[NQ], dsl[E], dsu[E], dzl[E], dzu[E], dpi[E];
       R rcl[E], rcu[E];
       MPMPC_UNROLL
-      for (int j = 0; j < E; ++j) { rcl[j] = s.sl[j] * s.zl[j]; rcu[j] = s.su[j] * s.zu[j]; }
+      for (int j = 0; j < E; ++j) if (boxed(j)) { rcl[j] = s.sl[j] * s.zl[j]; rcu[j] = s.su[j] * s.zu[j]; }
       R alpha_aff(1.0);
       for (int pass = 0; pass < 2; ++pass) {
         R rhs[E], nreq[NQ];
         [[maybe_unused]] R cul[E];          // phase 1: cu - cl of the entry
         MPMPC_UNROLL
         for (int j = 0; j < E; ++j) {
+          if (!boxed(j)) { rhs[j] = -rd[j]; continue; }
           if constexpr (SOFT) {
             cul[j] = sel(bx.Um[j], fma_(s.zu[j], ru_of(j), rcu[j]) * isu[j], zero) -
                      sel(bx.Lm[j], fma_(s.zl[j], rl_of(j), rcl[j]) * isl[j], zero);
@@ -1528,6 +1537,7 @@ struct Solver {
         R blk(0.0);
         MPMPC_UNROLL
         for (int j = 0; j < E; ++j) {
+          if (!boxed(j)) continue;
           R ex = dx[j];                     // step of x + w:  dx + k ((cu - cl) - th dx) = k (dx + cu - cl)
           if constexpr (SOFT) ex = kap[j] * (dx[j] + cul[j]);
           dsl[j] = sel(bx.Lm[j], ex + rl_of(j), zero);
@@ -1545,14 +1555,16 @@ struct Solver {
           R ms(0.0);
           MPMPC_UNROLL
           for (int j = 0; j < E; ++j)
-            ms = ms + sel(bx.Lm[j], fma_(alpha_aff, dsl[j], s.sl[j]) * fma_(alpha_aff, dzl[j], s.zl[j]), zero) +
-                 sel(bx.Um[j], fma_(alpha_aff, dsu[j], s.su[j]) * fma_(alpha_aff, dzu[j], s.zu[j]), zero);
+            if (boxed(j))
+              ms = ms + sel(bx.Lm[j], fma_(alpha_aff, dsl[j], s.sl[j]) * fma_(alpha_aff, dzl[j], s.zl[j]), zero) +
+                   sel(bx.Um[j], fma_(alpha_aff, dsu[j], s.su[j]) * fma_(alpha_aff, dzu[j], s.zu[j]), zero);
           R mu_aff = L::gsum(ms) / nb;
           R sg = mu_aff / max_(mu, R(1e-300));
           sg = sg * sg * sg;
           const R sgmu = sg * mu;
           MPMPC_UNROLL
           for (int j = 0; j < E; ++j) {
+            if (!boxed(j)) continue;
             rcl[j] = fma_(dsl[j], dzl[j], fma_(s.sl[j], s.zl[j], -sgmu));
             rcu[j] = fma_(dsu[j], dzu[j], fma_(s.su[j], s.zu[j], -sgmu));
           }
@@ -1562,6 +1574,7 @@ struct Solver {
           MPMPC_UNROLL
           for (int j = 0; j < E; ++j) {
             s.x[j] = sel(active, fma_(al, dx[j], s.x[j]), s.x[j]);
+            if (!boxed(j)) continue;
             s.sl[j] = sel(active, fma_(al, dsl[j], s.sl[j]), s.sl[j]);
             s.su[j] = sel(active, fma_(al, dsu[j], s.su[j]), s.su[j]);
             s.zl[j] = sel(active, fma_(al, dzl[j], s.zl[j]), s.zl[j]);
