@@ -594,3 +594,40 @@ def test_full_terminal_weight_on_device(cfgid, N, B, track, emu):
         P, q, A, l, u = _dense_with_qn(qp[:, i, :], N, QN_FULL)
         assert O.kkt_certificate(P, q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8)
     assert set(np.unique(sol.status)) <= {1, -3}
+
+
+def test_paths_longer_than_the_lds_staging_of_k1(emu):
+    """K1 stages the three path tables in LDS when the path has at most 1 024 waypoints and reads them from memory
+    otherwise (the limit's far side was untested): a 1 500-waypoint synthetic path, assembly bit for bit and
+    solves to 1e-9 against the emulation of the same lane code, horizon windows wrapping around the end of the path."""
+    rng = np.random.default_rng(5)
+    n_wp, N, B = 1500, 30, 96
+    kappa = 3.0 * np.sin(np.arange(n_wp) * 0.021) * (rng.uniform(0, 1, n_wp) < 0.8)
+    v_ref = rng.uniform(0.6, 1.0, n_wp)
+    ds = rng.uniform(0.03, 0.05, n_wp)
+
+    class Tr:
+        pass
+    tr = Tr()
+    tr.kappa, tr.v_ref, tr.ds_next = kappa, v_ref, ds
+    tr.ub_free = tr.lb_free = tr.ub_obstacles = tr.lb_obstacles = np.zeros((2, N))
+    wp = np.concatenate([rng.integers(0, n_wp, B - 4), [n_wp - 1, n_wp - 2, n_wp - N, 0]]).astype(np.int32)
+    x0 = np.stack([rng.uniform(-0.02, 0.02, B), rng.uniform(-0.2, 0.2, B), np.zeros(B)], axis=1)
+    cc = np.zeros((B, 2 * N))
+    cc[B // 2:, 0::2] = 0.8
+    cc[B // 2:, 1::2] = rng.uniform(-0.3, 0.3, (B - B // 2, N))
+    lb, ub = np.full((B, N), -0.15) + rng.uniform(0, 0.05, (B, N)), np.full((B, N), 0.15) - rng.uniform(0, 0.05, (B, N))
+    cfg = T.stock_config(N, max_batch=B)
+    h = mpmpc.Handle(cfg)
+    h.set_path(kappa, v_ref, ds)
+    qp = h.assemble(wp, x0, cc, lb, ub)
+    sol = h.solve(wp, x0, cc, lb, ub)
+    h.close()
+    qp_e = emu.assemble(cfg, tr, (wp, x0, cc, lb, ub))
+    cap = 15                                   # the speed cap goes through tan(): device libm vs the host's, a few ulp
+    other = np.delete(np.arange(mpmpc.NUM_FIELDS), cap)
+    assert np.array_equal(qp[other], qp_e[other])
+    assert np.max(np.abs(qp[cap] - qp_e[cap])) <= 8 * np.finfo(float).eps
+    ref = emu.solve(cfg, mpmpc.default_settings(), qp_e, G=64)
+    assert np.array_equal(sol.status, ref.status) and np.all(sol.status == 1)
+    assert np.max(np.abs(sol.z - ref.z)) <= 1e-9
