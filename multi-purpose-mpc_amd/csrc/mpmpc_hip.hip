@@ -464,7 +464,7 @@ void mpmpc_default_settings(mpmpc_settings* s) {
   s->polish = 2; s->ipm_max_iter = 30; s->ipm_tol = 1e-9; s->ipm_reg = 1e-8;
   s->as_delta = 1e-10; s->as_refine = 5; s->as_rounds = 4; s->cert_tol = 1e-8;
   s->early_polish = 1;
-  s->early_scaling = 2;
+  s->early_scaling = 1;
   s->phase1 = 1;
   s->ipm_diverged = 1e2;
   s->phase1_theta = 1.0;

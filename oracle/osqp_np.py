@@ -84,7 +84,7 @@ class Settings:
     as_rounds: int = 4
     cert_tol: float = 1e-8
     early_polish: int = 1       # polish=2 only: try the polish after this many ADMM iterations (0 = off)
-    early_scaling: int = 2      # Ruiz passes before that attempt; the rest precede the full ADMM run
+    early_scaling: int = 1      # Ruiz passes before that attempt; the rest precede the full ADMM run
     phase1: int = 1             # polish=2: what the early attempt cannot certify is first tested for infeasibility
                                 # (least-squares phase 1 -> Farkas ray -> PRIMAL_INFEASIBLE) before any full ADMM run
     phase1_theta: float = 1.0   # start value of its slacks / multipliers
