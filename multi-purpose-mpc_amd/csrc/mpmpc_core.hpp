@@ -1343,6 +1343,54 @@ struct Solver {
     }
   }
 
+  // The start of the early polish attempt on the reduced problem: OSQP's FIRST iterate from its cold start - the
+  // regularised least-squares point KKT^-1 (-q) relaxed by alpha, its projection and the dual step - computed for the
+  // (e_y, e_psi, kappa) system with the 2 x 2 factorisation; the speed's own (decoupled) entry in closed form, nothing
+  // for the time state.  Same point as admm(st, which, 1) up to the sigma-sized coupling through the time row, for the
+  // 2 x 2 instead of the 3 x 3 factorisation.
+  MPMPC_HD void reduced_start(const SolverParams& st, const Mk& which) {
+    const R zero(0.0), alpha(st.alpha), sigma(st.sigma);
+    status = keepi(which, I(MPMPC_UNSOLVED), status);
+    iters = keepi(which, I(1), iters);
+    ipm_iters = keepi(which, I(0), ipm_iters);
+    polished = keepi(which, I(0), polished);
+    set_rho(R(st.rho));
+    R h5[5], h3[3], rx[3], req[2] = {zero, zero}, xt[3], nu[2];
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) h5[j] = R(1.0) / (p[j] + sigma + (g[j] * g[j]) * rb[j]);
+    h3[0] = h5[0]; h3[1] = h5[1]; h3[2] = h5[4];
+    factor_t<LAY_RED>(h3, rinv_eq);
+    rx[0] = -q[0]; rx[1] = -q[1]; rx[2] = -q[4];
+    kkt_solve_t<LAY_RED>(rx, req, xt, nu);
+    R xt5[5] = {xt[0], xt[1], zero, h5[3] * (-q[3]), xt[2]};
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) {
+      const R xn = alpha * xt5[j];
+      const R zr = alpha * (g[j] * xt5[j]);
+      const R zn = min_(max_(zr, lb[j]), ub[j]);
+      x[j] = keep(which, xn, x[j]);
+      zb[j] = keep(which, zn, zb[j]);
+      yb[j] = keep(which, rb[j] * (zr - zn), yb[j]);
+    }
+    MPMPC_UNROLL
+    for (int i = 0; i < 2; ++i) {
+      const R zr = alpha * (nu[i] * rinv_eq);
+      zeq[i] = keep(which, leq[i], zeq[i]);
+      yeq[i] = keep(which, rho_eq * (zr - leq[i]), yeq[i]);
+    }
+    zeq[2] = keep(which, leq[2], zeq[2]);
+    yeq[2] = keep(which, zero, yeq[2]);
+    // unscaled primal residual of the rows the reduced problem has (the floor of the polish's warm start)
+    R x3[3] = {x[0], x[1], x[4]}, Ax[2], pri(0.0);
+    Aeq_mul_t<LAY_RED>(x3, Ax);
+    MPMPC_UNROLL
+    for (int i = 0; i < 2; ++i) pri = max_(pri, sel(vx, abs_((R(1.0) / Eeq[i]) * (Ax[i] - zeq[i])), zero));
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) if (j != 2) pri = max_(pri, sel(valid[j], abs_((R(1.0) / Eb[j]) * (g[j] * x[j] - zb[j])), zero));
+    pri_res = keep(which, L::gmax(pri), pri_res);
+    dua_res = keep(which, zero, dua_res);
+  }
+
   // ======================================================================== certified polish
   // Variable-space view of the box rows: g x in [lb, ub]  <=>  x in [lo, hi].
   template <int LAY>
@@ -2173,7 +2221,8 @@ struct Solver {
         for (int i = 0; i < 3; ++i) yeq[i] = R(0.0);
       } else {
         MPMPC_TICK_BEGIN(2);
-        admm(st, which, limit);
+        if (RED && early && limit == 1) reduced_start(st, which);
+        else admm(st, which, limit);
         MPMPC_TICK_END(2);
         MPMPC_TICK_BEGIN(3);
         if (st.polish) polish(st, early);
