@@ -1760,10 +1760,11 @@ struct Solver {
     lam[2] = zero;
     // t: row 2 of equality block k:  mI2 t_k + (a4 e_y + a5 t + b1 v)_{k-1} = leq2_k, a forward recurrence along the
     // stages (once per solve: N steps of one fused multiply-add and one lane shift each)
-    R t = leq[2] / mI[2];                         // stage 0; later stages are overwritten step by step
+    const R imI = R(1.0) / mI[2], t0 = leq[2] * imI, drive = fma_(b[1], xs[3], a[4] * xs[0]);
+    R t = t0;                                     // stage 0; later stages are overwritten step by step
     for (int it = 0; it < N; ++it) {
-      const R inflow = L::up(fma_(b[1], xs[3], fma_(a[5], t, a[4] * xs[0])));
-      t = sel(first, t, (leq[2] - inflow) / mI[2]);
+      const R inflow = L::up(fma_(a[5], t, drive));
+      t = sel(first, t0, (leq[2] - inflow) * imI);
     }
     xs[2] = sel(vx, t, zero);
   }
