@@ -61,8 +61,8 @@ def k1_bytes_per_solve(N):
 # key: (N + 1 <= 32, i.e. one lane per stage with the split interior-point layout;  reduced polish (mpmpc_settings::reduce
 #       applies: t carries neither cost nor bound);  certified optimal / Farkas-certified)
 _FLOPS = {
-    (True, True, 1): dict(algorithmic=(64063.0, 24032.0), executed=(183696.0, 42909.0), N=30),
-    (True, True, -3): dict(algorithmic=(51230.0, 30599.0), executed=(99037.0, 57290.0), N=30),
+    (True, True, 1): dict(algorithmic=(48860.0, 17438.0), executed=(133972.0, 38826.0), N=30),
+    (True, True, -3): dict(algorithmic=(32771.0, 23308.0), executed=(45245.0, 52866.0), N=30),
     (True, False, 1): dict(algorithmic=(81447.0, 40273.0), executed=(300857.0, 96760.0), N=30),
     (True, False, -3): dict(algorithmic=(132612.0, 42339.0), executed=(318920.0, 104347.0), N=30),
     (False, False, 1): dict(algorithmic=(47970.0, 64030.0), executed=(215726.0, 288391.0), N=50),
