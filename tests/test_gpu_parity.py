@@ -631,3 +631,31 @@ def test_paths_longer_than_the_lds_staging_of_k1(emu):
     ref = emu.solve(cfg, mpmpc.default_settings(), qp_e, G=64)
     assert np.array_equal(sol.status, ref.status) and np.all(sol.status == 1)
     assert np.max(np.abs(sol.z - ref.z)) <= 1e-9
+
+
+@pytest.mark.parametrize("cfgid,B", [(2, 1024), (4, 4096)])
+def test_reduced_polish_gives_the_full_polish_answers(cfgid, B, track):
+    """reduce = 1 (default: interior point / active set / phase 1 on the (e_y, e_psi, kappa) problem, v in closed form, t
+    rolled forward) against reduce = 0 (the full 3-state polish) on the same batches: same verdicts, the same optimum
+    to 1e-9 in every entry of z that the cost determines, and every point of the reduced path passes the KKT
+    certificate of the FULL problem (numpy on K1's output)."""
+    sc = scenarios.make(cfgid, track, B=B)
+    out = {}
+    for red in (1, 0):
+        h = _handle(track, sc.N, sc.weights, B, mpmpc.default_settings(reduce=red))
+        qp = h.assemble(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+        out[red] = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+        h.close()
+    a, b = out[1], out[0]
+    assert np.array_equal(a.status, b.status) and np.all(a.iters[:, 0] == 1) and np.all(b.iters[:, 0] == 1)
+    ok = a.status == 1
+    keep = np.ones(5 * sc.N + 3, bool)
+    keep[[3 * sc.N + 1, 5 * sc.N + 2]] = False              # e_psi_N and kappa_{N-1} are cost free
+    assert np.max(np.abs(a.z[ok][:, keep] - b.z[ok][:, keep])) <= 1e-9
+    prim, stat, comp = T.kkt_batch(qp[:, ok, :], sc.N, a.z[ok], a.y[ok])
+    assert max(prim.max(), stat.max(), comp.max()) <= 1e-8
+    inf = ~ok
+    if inf.any():
+        fk, _, _ = T.farkas_batch(qp[:, inf, :], sc.N, a.y[inf])
+        assert fk.all()
+    assert a.iters[ok, 1].mean() <= b.iters[ok, 1].mean() + 0.2
