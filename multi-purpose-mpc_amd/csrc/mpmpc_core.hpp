@@ -207,6 +207,11 @@ inline bool reducible(const mpmpc_config& c, const mpmpc_settings& st) {
          !(c.xmin[1] > -INFTY) && !(c.xmax[1] < INFTY);      // (and e_psi unbounded: the reduced layouts carry no slack for it)
 }
 
+// Are e_psi and t free of bounds (the interior point of the full problem may then skip their slack arithmetic)?
+inline bool free_states(const mpmpc_config& c) {
+  return !(c.xmin[1] > -INFTY) && !(c.xmax[1] < INFTY) && !(c.xmin[2] > -INFTY) && !(c.xmax[2] < INFTY);
+}
+
 // Lane split of the twisted factorisation for G lanes per instance and horizon N (shared by the
 // launcher and the emulation): the chains meet at lane C - 1.
 inline int lane_split(int G, int N) { return G == 16 ? 16 : (G == 32 ? 16 : (N + 1 <= 32 ? 16 : 32)); }
@@ -223,7 +228,10 @@ MPMPC_HOST_DEVICE inline int lane_offset(int G, int C, int N) {
 // complement keeps its block-tridiagonal structure and only the diagonal block of stage N, the products with P and
 // the products with inv(H) gain terms.  With FQ = false (the reference's own weights are diagonal) none of this
 // code exists in the kernel.
-template <class L, bool FQ = false, bool RED = false>
+// FREEX: the states e_psi and t are never boxed (xmin[1..2] = -inf, xmax[1..2] = +inf: the reference's own constraints,
+// src/simulation.py:110-111) - the interior point of the FULL problem then carries no slack arithmetic for them
+// (left out at compile time, like e_psi in the reduced layouts).
+template <class L, bool FQ = false, bool RED = false, bool FREEX = false>
 struct Solver {
   static_assert(!(FQ && RED), "the reduced problem needs a diagonal terminal weight");
   using R = typename L::real;
@@ -1435,7 +1443,11 @@ struct Solver {
     // In the reduced layouts entry 1 is e_psi (lower lanes) or nothing (upper lanes): never boxed - the reduced
     // polish is only taken when e_psi has no bound (reducible()) - so all of its slack arithmetic is left out at
     // compile time (the loops below are unrolled: boxed(j) is a constant in every copy).
-    auto boxed = [](int j) constexpr { return !(LAY >= LAY_RED && j == 1); };
+    auto boxed = [](int j) constexpr {
+      if (LAY >= LAY_RED) return j != 1;
+      if (FREEX) return LAY == LAY_FULL ? (j != 1 && j != 2) : j != 2;      // split: entry 2 is t below, nothing above
+      return true;
+    };
     MPMPC_COUNT_CONTEXT(SPL<LAY> ? 1 : 0);
     const R reg(st.ipm_reg), ireg(st.inv_ipm_reg), one(1.0), zero(0.0);
     Mk active = run, conv = L::mfalse();

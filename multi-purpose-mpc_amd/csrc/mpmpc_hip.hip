@@ -84,7 +84,8 @@ struct AssembleIn {
   const int* wp_id;
   const double *x0, *cc, *lb, *ub;
 };
-// VAR: 0 = the full problem with a diagonal terminal weight, 1 = full terminal weight (FQ), 2 = reduced polish (RED)
+// VAR: 0 = the full problem with a diagonal terminal weight, 1 = full terminal weight (FQ), 2 = reduced polish (RED),
+//      3 = the full problem whose states e_psi and t have no bounds (FREEX; one-instance-per-wave kernels only)
 template <int G, int C, bool WARM, int VAR = 0>
 __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, SolverParams st, int B, int ld,
                                                          AssembleIn ain, double* __restrict__ z,
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
   MPMPC_TICK_BEGIN(8);
   double fields[MPMPC_NUM_FIELDS];
   assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
-  Solver<L, VAR == 1, VAR == 2> s;
+  Solver<L, VAR == 1, VAR == 2, VAR == 3> s;
   // (second launch of a packed batch: the interior-point iterations the first launch spent on this instance)
   const int base_ipm = (mode == 2 && iters) ? iters[inst * 2 + 1] : 0;
   s.template run<WARM, (G == 64)>(fields, B, inst, k, cfg.N, st, mode, guess, base_ipm, cfg.QN_offdiag);
@@ -935,6 +936,7 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y) {
   const bool fullqn = h->cfg.QN_offdiag[0] != 0.0 || h->cfg.QN_offdiag[1] != 0.0 || h->cfg.QN_offdiag[2] != 0.0;
   if (fullqn) G = 64;
   const bool red = reducible(h->cfg, h->st);      // the polish may work on the (e_y, e_psi, kappa) problem
+  const bool freex = !fullqn && !red && free_states(h->cfg);
   // closed loop: the previous step's active sets as a first guess.  A launch with one instance per wave ends with
   // its slowest car, and with more than a handful of cars one of them always misses its guess (hit rate 91-93 %
   // per car and step: the miss pays for the attempt AND the normal path, 1024 cars -7 %), so "auto" warm-starts the
@@ -958,6 +960,9 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y) {
     } else if (red) {                                                             \
       if (warm_act) LAUNCH_W(GG, CC, true, 2, MODE, BLOCKS);                      \
       else LAUNCH_W(GG, CC, false, 2, MODE, BLOCKS);                              \
+    } else if (GG == 64 && freex) {                                               \
+      if (warm_act) LAUNCH_W(GG, CC, true, (GG == 64 ? 3 : 0), MODE, BLOCKS);     \
+      else LAUNCH_W(GG, CC, false, (GG == 64 ? 3 : 0), MODE, BLOCKS);             \
     } else if (warm_act) LAUNCH_W(GG, CC, true, 0, MODE, BLOCKS);                 \
     else LAUNCH_W(GG, CC, false, 0, MODE, BLOCKS);                                \
   } while (0)

@@ -15,7 +15,7 @@ using namespace mpmpc;
 
 // mode / tail as in mpmpc_solve_kernel: mode 1 appends the instances it leaves UNSOLVED to tail[1..] (tail[0] counts),
 // mode 2 runs one wave per listed instance
-template <int G, int C, bool FQ = false, bool RED = false>
+template <int G, int C, bool FQ = false, bool RED = false, bool FREEX = false>
 static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z,
                     double* u0, int* status, int* iters, double* resid, double* y, const int* guess = nullptr,
                     int* act = nullptr, int mode = 0, int* tail = nullptr) {
@@ -33,9 +33,9 @@ static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const dou
       gs.v[i] = (guess && in < B && kk >= 0 && kk <= cfg->N) ? guess[in * ld + kk] : 0;
       if (mode == 2) base.v[i] = iters[in * 2 + 1];
     }
-    Solver<L, FQ, RED> s;
+    Solver<L, FQ, RED, FREEX> s;
     typename L::real fields[MPMPC_NUM_FIELDS];
-    Solver<L, FQ, RED>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    Solver<L, FQ, RED, FREEX>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
     // (like the device: the packed kernels carry no phase-1 code when they run as the first of two launches)
     if (guess) s.template run<true>(fields, B, inst, k, cfg->N, make_params(*st), mode, gs, base, cfg->QN_offdiag);
     else if (mode == 1) s.template run<false, (G == 64)>(fields, B, inst, k, cfg->N, make_params(*st), mode, VI(0), base, cfg->QN_offdiag);
@@ -51,6 +51,7 @@ static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const dou
 #define SOLVE_G(GG, CC, ...)                                                          \
   do {                                                                                \
     if (reducible(*cfg, *st)) solve_g<GG, CC, false, true>(__VA_ARGS__);              \
+    else if (GG == 64 && free_states(*cfg)) solve_g<GG, CC, false, false, (GG == 64)>(__VA_ARGS__);   \
     else solve_g<GG, CC>(__VA_ARGS__);                                                \
   } while (0)
 
