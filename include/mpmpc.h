@@ -34,7 +34,9 @@ extern "C" {
 #define MPMPC_SOLVED 1
 #define MPMPC_SOLVED_INACCURATE 2
 #define MPMPC_MAX_ITER_REACHED (-2)
-#define MPMPC_PRIMAL_INFEASIBLE (-3)
+#define MPMPC_PRIMAL_INFEASIBLE (-3) /* default settings: with a Farkas ray in y; an EMPTY box (lower bound above upper bound,
+                                        e.g. the speed cap of src/MPC.py:111-113 below umin[0]) is reported as -3 with a
+                                        zero ray - stock OSQP refuses such data at setup */
 #define MPMPC_DUAL_INFEASIBLE (-4)
 #define MPMPC_UNSOLVED (-10) /* no verdict: the iterate is not finite (NaN / Inf in the inputs) */
 

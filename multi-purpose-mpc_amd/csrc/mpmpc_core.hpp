@@ -2256,6 +2256,23 @@ struct Solver {
       early = false;
       limit = st.max_iter;
     }
+    // An EMPTY box - a lower bound above its upper bound, e.g. the curvature-dependent speed cap of src/MPC.py:111-113
+    // below umin[0] - makes the QP trivially infeasible.  OSQP refuses such data at setup (the reference would raise
+    // there); here the instance is reported infeasible, with a zero ray (no Farkas ray exists for a single empty
+    // interval row) and the width of the gap as its violation.
+    {
+      R gap(0.0);
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) gap = max_(gap, sel(valid[j], lo_raw(j) - hi_raw(j), R(0.0)));
+      gap = L::gmax(gap);
+      Mk empty = live & (gap > R(0.0));
+      status = seli(empty, I(MPMPC_PRIMAL_INFEASIBLE), status);
+      pri_res = sel(empty, gap, pri_res);
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) yb[j] = sel(empty, R(0.0), yb[j]);
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) yeq[i] = sel(empty, R(0.0), yeq[i]);
+    }
     // non-finite data (a NaN pose, say) must not come back as a "solved" plan: no verdict at all, so
     // that the caller takes its fallback branch (src/MPC.py:208-220) instead of driving NaN controls
     Mk bad = L::mfalse();

@@ -200,6 +200,12 @@ def solve(P, q, A, l, u, settings: Settings | None = None, trace=None) -> Result
     come first; what the attempt cannot certify is solved again from a cold start on the problem with
     all `scaling` passes, exactly as OSQP would."""
     st = settings or Settings()
+    lo_, up_ = np.asarray(l, float), np.asarray(u, float)
+    if np.any(lo_ > up_):
+        # an empty interval row: trivially infeasible.  Stock OSQP refuses such data at setup; the build reports it as
+        # primal infeasible with a zero ray and the width of the gap as the violation (mpmpc_core.hpp, Solver::run)
+        return Result(np.zeros(lo_.size and np.asarray(q).size), np.zeros(lo_.size), PRIMAL_INFEASIBLE, 0,
+                      float(np.max(lo_ - up_)), 0.0, 0.0)
     if st.polish == 2 and 0 < st.early_polish < st.max_iter and 0 < st.early_scaling < st.scaling:
         first = _solve(P, q, A, l, u, dataclasses.replace(st, scaling=st.early_scaling, early_scaling=0), trace,
                        stop_after_early=True)

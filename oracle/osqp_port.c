@@ -798,6 +798,17 @@ static int phase1(work_t* w, double* x_out, double* y_out, oracle_info* info) {
 int oracle_solve_csc(int n, int m, const int* Pp, const int* Pi, const double* Px, const double* q, const int* Ap, const int* Ai,
                      const double* Ax_, const double* l, const double* u, const oracle_settings* st, const int* perm_in,
                      double* x_out, double* y_out, oracle_info* info) {
+  {
+    /* an empty interval row: trivially infeasible (stock OSQP refuses such data at setup); zero ray, the gap as violation */
+    double gap = 0;
+    for (int r = 0; r < m; ++r) if (l[r] > u[r]) gap = dmax(gap, l[r] - u[r]);
+    if (gap > 0) {
+      memset(x_out, 0, sizeof(double) * n); memset(y_out, 0, sizeof(double) * m);
+      memset(info, 0, sizeof(*info));
+      info->status = PRIMAL_INFEASIBLE; info->pri_res = gap;
+      return 0;
+    }
+  }
   csc P0 = {n, n, (int*)Pp, (int*)Pi, (double*)Px}, A0 = {m, n, (int*)Ap, (int*)Ai, (double*)Ax_};
   work_t w; memset(&w, 0, sizeof(w));
   w.n = n; w.m = m; w.st = st; w.P0 = &P0; w.A0 = &A0; w.q0 = q;

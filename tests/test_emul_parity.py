@@ -327,3 +327,28 @@ def test_full_terminal_weight_matches_oracle(cfgid, N, B, emu, track, otrack):
     with pytest.raises(ValueError):
         mpmpc.make_config(N, Q, R, np.array([[1.0, 0.2, 0], [0.1, 1, 0], [0, 0, 1]]), scenarios.XMIN, scenarios.XMAX,
                           scenarios.UMIN, scenarios.UMAX, scenarios.AY_MAX, scenarios.CAR_LENGTH)
+
+
+def test_empty_speed_box_is_reported_infeasible(emu, track):
+    """umin[0] above the curvature-dependent speed cap (src/MPC.py:111-113): an empty interval row.  Stock OSQP refuses
+    such data at setup; the build reports the instance infeasible (zero ray, the gap as violation) - device code and
+    oracle alike - and leaves the other instances of the batch alone."""
+    sc = scenarios.make(2, track, B=8)
+    Q, R, QN = scenarios.WEIGHTS["stock"]
+    umin = scenarios.UMIN.copy()
+    umin[0] = 0.9
+    cfg = mpmpc.make_config(sc.N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, umin, scenarios.UMAX, scenarios.AY_MAX,
+                            scenarios.CAR_LENGTH)
+    cc = sc.cc_prev.copy()
+    cc[:4, 1::2], cc[:4, 0::2] = 0.6, 1.0            # large predicted steering: speed cap 0.12 < umin 0.9
+    cc[4:] = 0.0                                     # cold plan: no cap
+    qp = emu.assemble(cfg, track, (sc.wp_id, sc.x0, cc, sc.lb, sc.ub))
+    assert qp[15, :4, :sc.N].min() < 0.9 and qp[15, 4:, :sc.N].min() >= 0.9
+    for G in (64, 32):
+        sol = emu.solve(cfg, mpmpc.default_settings(), qp, G=G)
+        assert np.all(sol.status[:4] == mpmpc.PRIMAL_INFEASIBLE) and np.all(sol.y[:4] == 0.0)
+        assert np.all(sol.resid[:4, 0] > 0.5)
+        assert np.all(sol.status[4:] == 1)
+    Pd, q, A, l, u = T.qp_to_dense(qp[:, 0, :], sc.N)
+    r = O.solve(np.diag(Pd), q, A, l, u, O.Settings(polish=2))
+    assert r.status == O.PRIMAL_INFEASIBLE and r.pri_res > 0.5
