@@ -348,7 +348,7 @@ def _main(real_stdout):
             h.solve(wp, x0, cc, lb, ub)
         out["host_buffers"] = {"value": 5 * B / (time.perf_counter() - t1), "unit": "solves/s",
                                "note": "PCIe-inclusive rate of mpmpc_solve on one GPU (pageable numpy buffers)"}
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:        # (the CPU baseline and the parity legs run on rank 0 at N = 1 only)
             sc_rank = scenarios.Scenario(sc_all.name, N, sc_all.weights, sc_all.obstacles, wp, x0, cc, lb, ub)
             base, ref = cpu_baseline(tr, sc_rank)
             out["cpu_baseline"] = base
