@@ -21,7 +21,7 @@ worst, n_inst, bad = 0.0, 0, 0
 for trial in range(40):
     N = int(rng.choice([3, 4, 7, 10, 15, 16, 17, 24, 30, 31, 32, 33, 40, 45, 50]))
     cfg_id = int(rng.choice([2, 3, 4]))
-    B = int(rng.integers(1, 40))
+    B = int(rng.integers(1, 200))
     weights = scenarios.CONFIGS[cfg_id]["weights"]
     sc = scenarios.make(cfg_id, tr, B=B, N=N)
     # shuffle the instances so that every trial sees other poses
@@ -32,18 +32,28 @@ for trial in range(40):
     Q, R, QN = scenarios.WEIGHTS[weights]
     h = mpmpc.Handle(cfg)
     h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
-    dev = h.solve(wp, x0, cc, lb, ub, want_y=True)
     qp = em.assemble(cfg, tr, (wp, x0, cc, lb, ub))
     for G in sorted({64, 32 if N + 1 <= 32 else 64, 16 if N + 1 <= 16 else 64}):
-        emu = em.solve(cfg, mpmpc.default_settings(), qp, G=G)
+        h.set_packing(G)                       # the device runs THIS packing (packed early pass + tail launch)
+        dev = h.solve(wp, x0, cc, lb, ub, want_y=True)
+        emu, _ = em.solve_launch(cfg, mpmpc.default_settings(), qp, G=G)
         same = np.array_equal(dev.status, emu.status) and np.array_equal(dev.iters, emu.iters)
         ok = dev.status == 1
         dz = float(np.abs(dev.z[ok] - emu.z[ok]).max()) if ok.any() else 0.0
         du = float(np.abs(dev.u0[ok] - emu.u0[ok]).max()) if ok.any() else 0.0
         worst = max(worst, dz, du)
-        if not same or dz > 1e-9 or du > 1e-9:
+        # independent certificates on the device's own outputs: KKT for every 1, Farkas ray for every -3
+        cert = True
+        if ok.any():
+            prim, stat, comp = T.kkt_batch(qp[:, ok, :], N, dev.z[ok], dev.y[ok])
+            cert = cert and max(prim.max(), stat.max(), comp.max()) <= 1e-8
+        inf = dev.status == -3
+        if inf.any():
+            cert = cert and bool(T.farkas_batch(qp[:, inf, :], N, dev.y[inf])[0].all())
+        cert = cert and set(np.unique(dev.status)) <= {1, -3}
+        if not same or dz > 1e-9 or du > 1e-9 or not cert:
             bad += 1
-            print("MISMATCH trial %d N=%d cfg=%d B=%d G=%d: status/iters equal %s, dz %.2e du %.2e" % (trial, N, cfg_id, B, G, same, dz, du))
+            print("MISMATCH trial %d N=%d cfg=%d B=%d G=%d: status/iters equal %s, dz %.2e du %.2e, certificates %s" % (trial, N, cfg_id, B, G, same, dz, du, cert))
     n_inst += B
     h.close()
 print("trials 40, instances %d, mismatches %d, worst |device - emulation| %.2e" % (n_inst, bad, worst))
