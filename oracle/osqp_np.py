@@ -258,8 +258,14 @@ def _solve(P, q, A, l, u, st: Settings, trace=None, stop_after_early=False):
                 return early
             if st.phase1:
                 # not certified: before any long ADMM run, ask whether the problem is infeasible at all
-                px, py, pit, cert = _phase1(w, st)
+                px, py, pit, cert, feasible = _phase1(w, st)
                 early.ipm_iters += pit
+                if feasible and _certified_polish(w, px, np.zeros(m), st, early, 3e-3):
+                    # phase 1 found the problem FEASIBLE: a second polish attempt from its point (inside every box,
+                    # well centred) - the warm-started interior point of the first attempt occasionally jams next to a
+                    # degenerate vertex
+                    early.x_admm, early.y_admm = w.unscale(x, y)
+                    return early
                 if cert:
                     early.x, early.y = w.unscale(px, py)          # least-violation point, Farkas ray
                     early.status, early.polished = PRIMAL_INFEASIBLE, 0
@@ -591,7 +597,8 @@ def _farkas_values(w: Workspace, dy):
 
 
 def _phase1(w: Workspace, st: Settings, x0=None):
-    """Phase 1 on the scaled problem of `w`.  -> (x, y, iterations, certified).  Two ways to a verdict:
+    """Phase 1 on the scaled problem of `w`.  -> (x, y, iterations, certified infeasible, found feasible).  Two ways to
+    an infeasibility verdict:
     (A) OSQP's primal-infeasibility test (unscaled norms) at phase1_eps: any iterate whose ray passes is a
         certificate, the iteration stops at the first one;
     (B) the iteration ran to its converged optimum and that optimum violates a bound by more than cert_tol: the least
@@ -605,14 +612,16 @@ def _phase1(w: Workspace, st: Settings, x0=None):
     x, y, it, conv, _ = _ipm_refine(w, np.zeros(n) if x0 is None else x0, np.zeros(m), st, st.ipm_tol * 1e-2, st.phase1_theta,
                                     soft=soft, stop=stop)
     if _primal_infeasible(w, y, st.phase1_eps):
-        return x, y, it, True
+        return x, y, it, True, False
     if conv:            # the ray test failed on the final iterate: the iteration ended at its converged optimum
         nrm, lhs, res = _farkas_values(w, y)
         xs, ys = w.unscale(x, y)
         prim = kkt_certificate(w.P0, w.q0, w.A0, w.l0, w.u0, xs, ys)["prim"]
         if prim > st.cert_tol and nrm > 0.0 and lhs < 0.0 and lhs < -100.0 * res:
-            return x, y, it, True
-    return x, y, it, False
+            return x, y, it, True, False
+        if not prim > st.cert_tol:
+            return x, y, it, False, True          # feasible to tolerance
+    return x, y, it, False, False
 
 
 # ---------------------------------------------------------------------------

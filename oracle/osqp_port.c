@@ -736,6 +736,10 @@ static int certified_polish(work_t* w, const double* x, const double* y, double 
  * Always feasible when the equality rows are; optimum 0 iff the QP is feasible; at its optimum the multipliers y satisfy
  * A'y = 0 and u'max(y,0) + l'min(y,0) = -|w|^2 < 0: a Farkas ray, put to OSQP's own primal-infeasibility test.
  * gamma_r = max |A_r.| of the scaled row.  Returns 1 when certified; x_out: least-violation point, y_out: the ray. */
+static int certified_polish(work_t* w, const double* x, const double* y, double theta, double* x_out, double* y_out, oracle_info* info);
+/* returns 1: certified infeasible, 2: found FEASIBLE and certified optimal by a second polish attempt from phase 1's
+ * point (inside every box, well centred: the warm-started interior point of the first attempt occasionally jams next to
+ * a degenerate vertex), 0: neither */
 static int phase1(work_t* w, double* x_out, double* y_out, oracle_info* info) {
   const oracle_settings* st = w->st;
   int n = w->n, m = w->m;
@@ -788,6 +792,10 @@ static int phase1(work_t* w, double* x_out, double* y_out, oracle_info* info) {
   if (cert) {
     memcpy(x_out, xs, sizeof(double) * n); memcpy(y_out, ys, sizeof(double) * m);
     info->status = PRIMAL_INFEASIBLE; info->polished = 0; info->pri_res = pv; info->dua_res = 0.0;
+  } else if (conv && !(pv > st->cert_tol)) {
+    double* y0 = (double*)calloc(m, sizeof(double));
+    if (certified_polish(w, x, y0, 3e-3, x_out, y_out, info)) cert = 2;
+    free(y0);
   }
   free(xs); free(ys);
   free(cl.eq); free(cl.L); free(cl.U); free(soft); free(Psave); free(qsave); free(x); free(y); free(tn); free(tm); free(low); free(upp);

@@ -54,6 +54,9 @@ for trial in range(40):
         if not same or dz > 1e-9 or du > 1e-9 or not cert:
             bad += 1
             print("MISMATCH trial %d N=%d cfg=%d B=%d G=%d: status/iters equal %s, dz %.2e du %.2e, certificates %s" % (trial, N, cfg_id, B, G, same, dz, du, cert))
+            d = np.flatnonzero((dev.status != emu.status) | (dev.iters != emu.iters).any(axis=1))
+            for i in d[:4]:
+                print("   instance %d: device status %d iters %s | emulation status %d iters %s" % (i, dev.status[i], dev.iters[i], emu.status[i], emu.iters[i]))
     n_inst += B
     h.close()
 print("trials 40, instances %d, mismatches %d, worst |device - emulation| %.2e" % (n_inst, bad, worst))

@@ -1,5 +1,7 @@
 """CPU lock-step emulation of the HIP kernels (same source, lane = 64-wide vector) vs the oracle.
 This is how the kernel ALGORITHM is checked without a GPU; the -m gpu tests repeat it on hardware."""
+import os
+
 import numpy as np
 import pytest
 
@@ -275,6 +277,27 @@ def test_phase1_leaves_feasible_batches_alone(emu, track):
         a = emu.solve(cfg, mpmpc.default_settings(), qp, G=64)
         b = emu.solve(cfg, mpmpc.default_settings(phase1=0), qp, G=64)
         assert np.all(a.status == 1) and np.array_equal(a.z, b.z) and np.array_equal(a.iters, b.iters)
+
+
+def test_second_polish_attempt_from_phase1s_point(emu, track):
+    """tests/golden/p1_retry_N3.npy: the assembled stage fields of ONE feasible N = 3 instance of config 4 (found by
+    profiles/stress.py, seed 1, trial 13, instance 16) on which the warm-started interior point of the first polish
+    attempt jams next to a degenerate vertex.  Phase 1 finds it feasible; the second attempt from phase 1's point
+    certifies the optimum with no ADMM iteration beyond the first.  Without phase 1 the instance goes the long way."""
+    qp = np.load(os.path.join(os.path.dirname(__file__), "golden", "p1_retry_N3.npy"))
+    cfg = T.stock_config(3, scenarios.CONFIGS[4]["weights"])
+    Pd, q, A, l, u = T.qp_to_dense(qp[:, 0, :], 3)
+    ref = O.solve(np.diag(Pd), q, A, l, u, O.Settings(polish=2))
+    assert ref.status == 1 and ref.iters == 1
+    for G in (64, 32, 16):
+        s = emu.solve(cfg, mpmpc.default_settings(), qp, G=G)
+        if G == 64:
+            assert s.status[0] == 1 and s.iters[0, 0] == 1
+            np.testing.assert_allclose(s.z[0], ref.x, atol=1e-7)
+        else:       # packed kernels carry no phase 1: the instance is handed to the tail launch (status 0 here)
+            assert s.status[0] in (0, 1)
+    off = emu.solve(cfg, mpmpc.default_settings(phase1=0), qp, G=64)
+    assert off.iters[0, 0] > 25
 
 
 # ---------------------------------------------------------------------------------------------------------------
