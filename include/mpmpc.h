@@ -110,6 +110,12 @@ typedef struct {
                             2 x 2 blocks - the same optimum (the KKT certificate is evaluated on the FULL problem) for about
                             half the arithmetic.  0: always the full 3-state polish.  The ADMM stage always runs on the
                             full problem (it reproduces OSQP's iterates). */
+  double ipm_start_slack; /* the polish attempt that follows the early_polish ADMM iterations (and the retry from phase 1's */
+  double ipm_start_mu;    /* point) starts the interior point CENTRED: slacks max(distance to the bound, ipm_start_slack),
+                            multipliers ipm_start_mu / slack (row space of the scaled problem) - after one ADMM iteration
+                            the multipliers carry no information and small slacks cost 5-7 blocked steps.  ipm_start_mu = 0:
+                            warm start from the ADMM multipliers, as the polish after a full ADMM run always does.
+                            Defaults 0.1, 0.01. */
 } mpmpc_settings;
 
 const char* mpmpc_version(void);

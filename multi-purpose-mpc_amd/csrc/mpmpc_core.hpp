@@ -1977,6 +1977,20 @@ struct Solver {
       s.zu[j] = sel(bx.Um[j], max_(yv, theta), zero);
       s.pi[j] = sel(bx.pin[j], yv, zero);
     }
+    if (early && st.ipm_start_mu > 0.0) {
+      // After early_polish (= 1) ADMM iterations the multipliers carry no information and the point violates every
+      // speed bound: floors of 3e-3 cost 5-7 blocked steps.  Centred start instead (mpmpc_settings::ipm_start_*, row
+      // space of the scaled problem: the slack of row g x is g times the slack of x, its multiplier 1 / g times).
+      const R ths(st.ipm_start_slack), mu0(st.ipm_start_mu);
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) {
+        const R fl = ths / g[j];
+        s.sl[j] = sel(bx.Lm[j], max_(x[j] - bx.lo[j], fl), one);
+        s.su[j] = sel(bx.Um[j], max_(bx.hi[j] - x[j], fl), one);
+        s.zl[j] = sel(bx.Lm[j], mu0 / s.sl[j], zero);
+        s.zu[j] = sel(bx.Um[j], mu0 / s.su[j], zero);
+      }
+    }
     // the interior-point stage runs in the split layout where the upper half-wave is free (kSplit), and on the
     // reduced problem where the time state separates (RED)
     constexpr int LAY = LAY_IP;

@@ -428,6 +428,7 @@ static int check_settings(const mpmpc_settings* s) {
     return fail(MPMPC_E_ARG, "polish needs ipm_reg, ipm_tol, as_delta > 0");
   if (s->phase1 != 0 && s->phase1 != 1) return fail(MPMPC_E_ARG, "phase1 must be 0 or 1");
   if (s->reduce != 0 && s->reduce != 1) return fail(MPMPC_E_ARG, "reduce must be 0 or 1");
+  if (!(s->ipm_start_mu >= 0) || !(s->ipm_start_slack > 0)) return fail(MPMPC_E_ARG, "need ipm_start_mu >= 0, ipm_start_slack > 0");
   if (!(s->ipm_diverged > 1) || !(s->phase1_theta > 0) || !(s->phase1_eps > 0))
     return fail(MPMPC_E_ARG, "need ipm_diverged > 1, phase1_theta > 0, phase1_eps > 0");
   return MPMPC_OK;
@@ -471,6 +472,8 @@ void mpmpc_default_settings(mpmpc_settings* s) {
   s->phase1_theta = 1.0;
   s->phase1_eps = 1e-6;
   s->reduce = 1;
+  s->ipm_start_slack = 0.1;
+  s->ipm_start_mu = 0.01;
 }
 
 int32_t mpmpc_stage_ld(int32_t N) { return host_stage_ld(N); }

@@ -88,6 +88,10 @@ class Settings:
     phase1: int = 1             # polish=2: what the early attempt cannot certify is first tested for infeasibility
                                 # (least-squares phase 1 -> Farkas ray -> PRIMAL_INFEASIBLE) before any full ADMM run
     phase1_theta: float = 1.0   # start value of its slacks / multipliers
+    ipm_start_slack: float = 0.1    # the attempt after early_polish ADMM iterations (and the retry from phase 1's
+    ipm_start_mu: float = 0.01      # point) starts the interior point CENTRED: slacks max(distance to the bound,
+                                    # ipm_start_slack), multipliers ipm_start_mu / slack (row space of the scaled
+                                    # problem); ipm_start_mu = 0: warm start from the ADMM multipliers as after a full run
     phase1_eps: float = 1e-6    # OSQP's primal-infeasibility test on phase 1's ray uses this eps: the interior-point ray is
                                 # accurate to ~1e-7 (|A'y| / |y|), so the test can be much sharper than eps_prim_inf = 1e-4,
                                 # which is calibrated for ADMM's slowly converging dual steps
@@ -252,7 +256,9 @@ def _solve(P, q, A, l, u, st: Settings, trace=None, stop_after_early=False):
             # the polish only needs a reasonable starting point: try it now; if it cannot certify,
             # the ADMM iteration simply goes on
             early = Result(None, None, UNSOLVED, it, 0.0, 0.0, 0.0, 0, rho_updates, w.rho)
-            if _certified_polish(w, x, y, st, early, _warm_start_floor(_info(w, x, z, y)["pri_res"])):
+            centred = st.ipm_start_mu > 0.0
+            th0 = st.ipm_start_slack if centred else _warm_start_floor(_info(w, x, z, y)["pri_res"])
+            if _certified_polish(w, x, y, st, early, th0, st.ipm_start_mu):
                 xa, ya = w.unscale(x, y)
                 early.x_admm, early.y_admm = xa, ya
                 return early
@@ -260,7 +266,8 @@ def _solve(P, q, A, l, u, st: Settings, trace=None, stop_after_early=False):
                 # not certified: before any long ADMM run, ask whether the problem is infeasible at all
                 px, py, pit, cert, feasible = _phase1(w, st)
                 early.ipm_iters += pit
-                if feasible and _certified_polish(w, px, np.zeros(m), st, early, 3e-3):
+                if feasible and _certified_polish(w, px, np.zeros(m), st, early, st.ipm_start_slack if centred else 3e-3,
+                                                      st.ipm_start_mu):
                     # phase 1 found the problem FEASIBLE: a second polish attempt from its point (inside every box,
                     # well centred) - the warm-started interior point of the first attempt occasionally jams next to a
                     # degenerate vertex
@@ -323,13 +330,13 @@ def _warm_start_floor(pri_res):
     return min(3e-3, max(3e-4, 0.0125 * pri_res))
 
 
-def _certified_polish(w, x, y, st, res, theta=3e-3) -> bool:
+def _certified_polish(w, x, y, st, res, theta=3e-3, mu0=0.0) -> bool:
     """Interior-point refinement from the scaled point (x, y), iterated active-set solve, KKT
     certificate.  On success writes the certified point into `res` and returns True."""
     ipm_tol = st.ipm_tol
     xi, yi = x, y
     for attempt in range(2):
-        xi, yi, nit, conv, act = _ipm_refine(w, xi, yi, st, ipm_tol, theta)
+        xi, yi, nit, conv, act = _ipm_refine(w, xi, yi, st, ipm_tol, theta, mu0=mu0 if attempt == 0 else 0.0)
         res.ipm_iters += nit
         if not conv:
             break
@@ -462,7 +469,7 @@ def _row_classes(w: Workspace):
     return eq, L, U
 
 
-def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, stop=None):
+def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, stop=None, mu0=0.0):
     """`soft` (phase 1, see _phase1): per-row gamma^2 >= 0.  A soft row r reads  l <= (Ax)_r + gamma_r w_r <= u  with
     the cost 1/2 w_r^2 and NO other cost (P, q are taken as zero); w_r = gamma_r (zl_r - zu_r) is eliminated, which
     leaves the same iteration with  (Ax)_r - gamma_r^2 y_r  in place of (Ax)_r in the slack equations and
@@ -479,6 +486,9 @@ def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, 
     su = np.where(U, np.maximum(w.u - Ax, theta), 1.0)
     zl = np.where(L, np.maximum(-y0, theta), 0.0)
     zu = np.where(U, np.maximum(y0, theta), 0.0)
+    if mu0 > 0.0:           # centred start: every complementarity product equals mu0
+        zl = np.where(L, mu0 / sl, 0.0)
+        zu = np.where(U, mu0 / su, 0.0)
     nb = max(int(L.sum() + U.sum()), 1)
     reg = st.ipm_reg
     conv = False

@@ -45,6 +45,7 @@ typedef struct {
   double cert_tol;
   int32_t early_polish, early_scaling, phase1;
   double ipm_diverged, phase1_theta, phase1_eps;
+  double ipm_start_slack, ipm_start_mu;    /* centred start of the early interior-point attempt (see osqp_np.Settings) */
 } oracle_settings;
 
 typedef struct {
@@ -486,7 +487,7 @@ typedef struct { int *eq, *L, *U; } classes_t;
  * (Ax)_r in the slack equations and gamma_r^2 is added to the row's diagonal entry of the reduced KKT matrix.  In that
  * mode the loop also ends as soon as the multipliers pass OSQP's primal-infeasibility test. */
 static int primal_infeasible(const work_t* w, const double* dy, double eps, double* tn, double* tm);
-static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double* x, double* y, double tol, double theta, int* iters_out, int* low, int* upp, const double* soft) {
+static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double* x, double* y, double tol, double theta, int* iters_out, int* low, int* upp, const double* soft, double mu0) {
   const oracle_settings* st = w->st;
   int n = w->n, m = w->m, N = n + m;
   const double reg = st->ipm_reg;
@@ -509,6 +510,7 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
     su[r] = cl->U[r] ? dmax(w->u[r] - Ax[r], theta) : 1.0;
     zl[r] = cl->L[r] ? dmax(-y[r], theta) : 0.0;
     zu[r] = cl->U[r] ? dmax(y[r], theta) : 0.0;
+    if (mu0 > 0.0) { zl[r] = cl->L[r] ? mu0 / sl[r] : 0.0; zu[r] = cl->U[r] ? mu0 / su[r] : 0.0; }
     nb += cl->L[r] + cl->U[r];
   }
   if (nb < 1) nb = 1;
@@ -691,7 +693,7 @@ static int active_set_polish(work_t* w, const classes_t* cl, int* low, int* upp,
 /* floor of the warm-started slacks / multipliers: pri_res / 80 in [3e-4, 3e-3] (closer ADMM point, smaller floor) */
 static double warm_start_floor(double pri_res) { return dmin(3e-3, dmax(3e-4, 0.0125 * pri_res)); }
 
-static int certified_polish(work_t* w, const double* x, const double* y, double theta, double* x_out, double* y_out, oracle_info* info) {
+static int certified_polish(work_t* w, const double* x, const double* y, double theta, double mu0, double* x_out, double* y_out, oracle_info* info) {
   const oracle_settings* st = w->st;
   int n = w->n, m = w->m;
   classes_t cl; cl.eq = (int*)malloc(sizeof(int) * m); cl.L = (int*)malloc(sizeof(int) * m); cl.U = (int*)malloc(sizeof(int) * m);
@@ -709,7 +711,7 @@ static int certified_polish(work_t* w, const double* x, const double* y, double 
   int good = 0;
   for (int attempt = 0; attempt < 2 && !good; ++attempt) {
     int nit = 0;
-    int conv = ipm_refine(w, w->K, w->F, &cl, xi, yi, tol, theta, &nit, low, upp, NULL);
+    int conv = ipm_refine(w, w->K, w->F, &cl, xi, yi, tol, theta, &nit, low, upp, NULL, attempt == 0 ? mu0 : 0.0);
     info->ipm_iters += nit;
     if (!conv) break;
     int rounds = 0;
@@ -736,7 +738,7 @@ static int certified_polish(work_t* w, const double* x, const double* y, double 
  * Always feasible when the equality rows are; optimum 0 iff the QP is feasible; at its optimum the multipliers y satisfy
  * A'y = 0 and u'max(y,0) + l'min(y,0) = -|w|^2 < 0: a Farkas ray, put to OSQP's own primal-infeasibility test.
  * gamma_r = max |A_r.| of the scaled row.  Returns 1 when certified; x_out: least-violation point, y_out: the ray. */
-static int certified_polish(work_t* w, const double* x, const double* y, double theta, double* x_out, double* y_out, oracle_info* info);
+static int certified_polish(work_t* w, const double* x, const double* y, double theta, double mu0, double* x_out, double* y_out, oracle_info* info);
 /* returns 1: certified infeasible, 2: found FEASIBLE and certified optimal by a second polish attempt from phase 1's
  * point (inside every box, well centred: the warm-started interior point of the first attempt occasionally jams next to
  * a degenerate vertex), 0: neither */
@@ -762,7 +764,7 @@ static int phase1(work_t* w, double* x_out, double* y_out, oracle_info* info) {
   int *low = (int*)calloc(m, sizeof(int)), *upp = (int*)calloc(m, sizeof(int));
   int nit = 0;
   /* (two digits beyond the polish's tolerance: the quantities of a marginal verdict are themselves at the 1e-9 level) */
-  int conv = ipm_refine(w, w->K, w->F, &cl, x, y, st->ipm_tol * 1e-2, st->phase1_theta, &nit, low, upp, soft);
+  int conv = ipm_refine(w, w->K, w->F, &cl, x, y, st->ipm_tol * 1e-2, st->phase1_theta, &nit, low, upp, soft, 0.0);
   info->ipm_iters += nit;
   /* (A) OSQP's test at phase1_eps: any iterate whose ray passes is a certificate */
   int cert = primal_infeasible(w, y, st->phase1_eps, tn, tm);
@@ -794,7 +796,7 @@ static int phase1(work_t* w, double* x_out, double* y_out, oracle_info* info) {
     info->status = PRIMAL_INFEASIBLE; info->polished = 0; info->pri_res = pv; info->dua_res = 0.0;
   } else if (conv && !(pv > st->cert_tol)) {
     double* y0 = (double*)calloc(m, sizeof(double));
-    if (certified_polish(w, x, y0, 3e-3, x_out, y_out, info)) cert = 2;
+    if (certified_polish(w, x, y0, st->ipm_start_mu > 0.0 ? st->ipm_start_slack : 3e-3, st->ipm_start_mu, x_out, y_out, info)) cert = 2;
     free(y0);
   }
   free(xs); free(ys);
@@ -877,7 +879,7 @@ int oracle_solve_csc(int n, int m, const int* Pp, const int* Pi, const double* P
       /* the polish only needs a reasonable starting point: try it now; if it cannot certify, ADMM goes on */
       info->status = UNSOLVED; info->iters = it; info->rho_updates = rho_updates; info->ipm_iters = 0; info->as_rounds = 0; info->polished = 0;
       compute_info(&w, x, z, y, &o);
-      if (certified_polish(&w, x, y, warm_start_floor(o.pri), x_out, y_out, info)) { early_done = 1; break; }
+      if (certified_polish(&w, x, y, st->ipm_start_mu > 0.0 ? st->ipm_start_slack : warm_start_floor(o.pri), st->ipm_start_mu, x_out, y_out, info)) { early_done = 1; break; }
       /* not certified: before any long ADMM run, ask whether the problem is infeasible at all */
       if (st->phase1 && phase1(&w, x_out, y_out, info)) { early_done = 1; break; }
       if (passes_done < st->scaling) {
@@ -927,7 +929,7 @@ int oracle_solve_csc(int n, int m, const int* Pp, const int* Pi, const double* P
   info->polished = 0;
 
   if (st->polish == 2 && (status == SOLVED || status == SOLVED_INACCURATE || status == MAX_ITER_REACHED)) {
-    if (!certified_polish(&w, x, y, warm_start_floor(o.pri), x_out, y_out, info)) { info->status = SOLVED_INACCURATE; info->polished = -1; }
+    if (!certified_polish(&w, x, y, warm_start_floor(o.pri), 0.0, x_out, y_out, info)) { info->status = SOLVED_INACCURATE; info->polished = -1; }
   }
 finish:
   /* objective of the returned point */

@@ -281,23 +281,27 @@ def test_phase1_leaves_feasible_batches_alone(emu, track):
 
 def test_second_polish_attempt_from_phase1s_point(emu, track):
     """tests/golden/p1_retry_N3.npy: the assembled stage fields of ONE feasible N = 3 instance of config 4 (found by
-    profiles/stress.py, seed 1, trial 13, instance 16) on which the warm-started interior point of the first polish
-    attempt jams next to a degenerate vertex.  Phase 1 finds it feasible; the second attempt from phase 1's point
-    certifies the optimum with no ADMM iteration beyond the first.  Without phase 1 the instance goes the long way."""
+    profiles/stress.py, seed 1, trial 13, instance 16) on which the WARM-started interior point (ipm_start_mu = 0: start
+    from the multipliers of the one ADMM iteration) jams next to a degenerate vertex.  Phase 1 finds it feasible; the
+    second attempt from phase 1's point certifies the optimum with no ADMM iteration beyond the first.  Without phase 1
+    the instance goes the long way.  The default, centred start does not jam on it in the first place."""
     qp = np.load(os.path.join(os.path.dirname(__file__), "golden", "p1_retry_N3.npy"))
     cfg = T.stock_config(3, scenarios.CONFIGS[4]["weights"])
     Pd, q, A, l, u = T.qp_to_dense(qp[:, 0, :], 3)
-    ref = O.solve(np.diag(Pd), q, A, l, u, O.Settings(polish=2))
-    assert ref.status == 1 and ref.iters == 1
+    ref = O.solve(np.diag(Pd), q, A, l, u, O.Settings(polish=2, ipm_start_mu=0.0))
+    assert ref.status == 1 and ref.iters == 1       # (the oracle's full-problem iteration does not jam on it)
     for G in (64, 32, 16):
-        s = emu.solve(cfg, mpmpc.default_settings(), qp, G=G)
+        s = emu.solve(cfg, mpmpc.default_settings(ipm_start_mu=0.0), qp, G=G)
         if G == 64:
-            assert s.status[0] == 1 and s.iters[0, 0] == 1
+            assert s.status[0] == 1 and s.iters[0, 0] == 1 and s.iters[0, 1] > 30      # 30 jammed, phase 1, retry
             np.testing.assert_allclose(s.z[0], ref.x, atol=1e-7)
         else:       # packed kernels carry no phase 1: the instance is handed to the tail launch (status 0 here)
             assert s.status[0] in (0, 1)
-    off = emu.solve(cfg, mpmpc.default_settings(phase1=0), qp, G=64)
+    off = emu.solve(cfg, mpmpc.default_settings(phase1=0, ipm_start_mu=0.0), qp, G=64)
     assert off.iters[0, 0] > 25
+    dflt = emu.solve(cfg, mpmpc.default_settings(), qp, G=64)
+    assert dflt.status[0] == 1 and dflt.iters[0, 0] == 1 and dflt.iters[0, 1] < 15
+    np.testing.assert_allclose(dflt.z[0], ref.x, atol=1e-7)
 
 
 # ---------------------------------------------------------------------------------------------------------------
