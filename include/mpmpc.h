@@ -116,6 +116,9 @@ typedef struct {
                             the multipliers carry no information and small slacks cost 5-7 blocked steps.  ipm_start_mu = 0:
                             warm start from the ADMM multipliers, as the polish after a full ADMM run always does.
                             Defaults 0.1, 0.01. */
+  double as_add_fraction; /* active-set rounds add only the bounds violated by at least this fraction of the round's worst
+                            violation (measured on the scaled variable); 0: every violated bound, the plain primal-dual
+                            active-set update; the retry after a failed attempt uses at least 0.5.  Default 0.25. */
 } mpmpc_settings;
 
 const char* mpmpc_version(void);

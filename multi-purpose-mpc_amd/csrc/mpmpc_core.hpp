@@ -1487,7 +1487,9 @@ struct Solver {
       }
       res = L::gmax(res);
       R mu = L::gsum(msum) / nb;
-      Mk ok = (res < R(tol)) & (mu < R(tol));
+      // (the residual of a converged iterate sits at ~1e-13 in double precision: the retry at ipm_tol x 1e-4 asks the
+      //  complementarity for its tolerance - that is what identifies a weakly active bound - and the residual for 1e-11)
+      Mk ok = (res < R(tol > 1e-11 ? tol : 1e-11)) & (mu < R(tol));
       if constexpr (SOFT) p1_converged = selb(active, ok, p1_converged);
       if constexpr (SOFT) {
         // Farkas test on the multipliers y = (nu, zu - zl + pi) in the scaled problem: A'y is the dual residual rd itself
@@ -1656,7 +1658,7 @@ struct Solver {
   // problem (entries e_y, e_psi, kappa; pp, qq: cost diagonal and vector in that layout).
   template <int LAY>
   MPMPC_HD Mk active_set(const BoxT<LAY>& bx, const R* pp, const R* qq, const Mk* vm, Mk* aL, Mk* aU, R* xs, R* nus, R* lam,
-                         const SolverParams& st, const Mk& run) {
+                         const SolverParams& st, const Mk& run, double add_fraction) {
     constexpr int E = EN<LAY>, NQ = NR<LAY>;
     const R delta(st.as_delta), idelta(st.inv_as_delta), zero(0.0), one(1.0), tol(1e-9);
     Mk todo = run, okm = L::mfalse();
@@ -1730,6 +1732,7 @@ struct Solver {
       }
       Mk anybad = L::mfalse();
       Mk vL[E], vU[E], bL[E], bU_[E];
+      R worst(0.0);
       MPMPC_UNROLL
       for (int j = 0; j < E; ++j) {
         vL[j] = bx.Lm[j] & !aL[j] & (xn[j] < bx.lo[j] - tol);
@@ -1737,8 +1740,20 @@ struct Solver {
         bL[j] = aL[j] & (ln[j] > tol);
         bU_[j] = aU[j] & (ln[j] < -tol);
         anybad = anybad | vL[j] | vU[j] | bL[j] | bU_[j];
+        worst = max_(worst, max_(sel(vL[j], bx.lo[j] - xn[j], zero), sel(vU[j], xn[j] - bx.hi[j], zero)));
       }
       anybad = L::gany(anybad);
+      // Only the violations within as_add_fraction of the worst one enter the active set: the small ones are mostly
+      // consequences of the large ones (a missed weakly active bound pushes its neighbours out by a fraction of its own
+      // violation), and adding them all at once makes the primal-dual iteration cycle on long horizons.
+      {
+        const R thr = R(add_fraction) * L::gmax(worst);
+        MPMPC_UNROLL
+        for (int j = 0; j < E; ++j) {
+          vL[j] = vL[j] & !(bx.lo[j] - xn[j] < thr);
+          vU[j] = vU[j] & !(xn[j] - bx.hi[j] < thr);
+        }
+      }
       MPMPC_UNROLL
       for (int j = 0; j < E; ++j) {
         xs[j] = sel(todo, xn[j], xs[j]);
@@ -1886,7 +1901,7 @@ struct Solver {
 
   // One active-set attempt from the guess (aL5, aU5) in the 5-entry view, in the layout LAY_AS.  On return (xs, nus,
   // lam) hold the full point (reduced problem: completed by reduced_complete), aL5 / aU5 the final active set.
-  MPMPC_HD Mk active_set_full(const Box& bx, Mk aL5[5], Mk aU5[5], R xs[5], R nus[3], R lam[5], const SolverParams& st,
+  MPMPC_HD Mk active_set_full(const Box& bx, Mk aL5[5], Mk aU5[5], R xs[5], R nus[3], R lam[5], const SolverParams& st, double add_fraction,
                               const Mk& run) {
     constexpr int LAY = LAY_AS;
     constexpr int E = EN<LAY>, NQ = NR<LAY>;
@@ -1898,7 +1913,7 @@ struct Solver {
     to_lay<LAY>(xs, xa); to_lay<LAY>(lam, la);
     MPMPC_UNROLL
     for (int i = 0; i < NQ; ++i) na[i] = nus[i];
-    Mk okm = active_set<LAY>(ba, pp, qq, vm, aL, aU, xa, na, la, st, run);
+    Mk okm = active_set<LAY>(ba, pp, qq, vm, aL, aU, xa, na, la, st, run, add_fraction);
     from_lay<LAY>(xa, xs); from_lay<LAY>(la, lam);
     MPMPC_UNROLL
     for (int i = 0; i < NQ; ++i) nus[i] = na[i];
@@ -1935,7 +1950,7 @@ struct Solver {
     // the batch decides the step)
     SolverParams sw = st;
     sw.as_rounds = st.as_rounds < 2 ? st.as_rounds : 2;
-    Mk okm = active_set_full(bx, aL, aU, xs, nus, lam, sw, run);
+    Mk okm = active_set_full(bx, aL, aU, xs, nus, lam, sw, st.as_add_fraction, run);
     R prim, stat;
     Mk cert = certificate(xs, nus, lam, st.cert_tol, prim, stat);
     Mk good = run & okm & cert;
@@ -2026,7 +2041,9 @@ struct Solver {
       MPMPC_UNROLL
       for (int i = 0; i < NR<LAY>; ++i) nus[i] = si.nu[i];
       MPMPC_TICK_BEGIN(5);
-      Mk okm = active_set_full(bx, aL, aU, xs, nus, lam, st, todo & conv);
+      // (the retry is more careful: only the upper half of the violations enters per round)
+      const double frac = attempt == 0 ? st.as_add_fraction : (st.as_add_fraction > 0.5 ? st.as_add_fraction : 0.5);
+      Mk okm = active_set_full(bx, aL, aU, xs, nus, lam, st, frac, todo & conv);
       MPMPC_TICK_END(5);
       unstash();
       R prim, stat;

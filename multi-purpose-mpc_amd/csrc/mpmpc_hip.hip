@@ -429,6 +429,7 @@ static int check_settings(const mpmpc_settings* s) {
   if (s->phase1 != 0 && s->phase1 != 1) return fail(MPMPC_E_ARG, "phase1 must be 0 or 1");
   if (s->reduce != 0 && s->reduce != 1) return fail(MPMPC_E_ARG, "reduce must be 0 or 1");
   if (!(s->ipm_start_mu >= 0) || !(s->ipm_start_slack > 0)) return fail(MPMPC_E_ARG, "need ipm_start_mu >= 0, ipm_start_slack > 0");
+  if (!(s->as_add_fraction >= 0) || !(s->as_add_fraction <= 1)) return fail(MPMPC_E_ARG, "need 0 <= as_add_fraction <= 1");
   if (!(s->ipm_diverged > 1) || !(s->phase1_theta > 0) || !(s->phase1_eps > 0))
     return fail(MPMPC_E_ARG, "need ipm_diverged > 1, phase1_theta > 0, phase1_eps > 0");
   return MPMPC_OK;
@@ -474,6 +475,7 @@ void mpmpc_default_settings(mpmpc_settings* s) {
   s->reduce = 1;
   s->ipm_start_slack = 0.1;
   s->ipm_start_mu = 0.01;
+  s->as_add_fraction = 0.25;
 }
 
 int32_t mpmpc_stage_ld(int32_t N) { return host_stage_ld(N); }

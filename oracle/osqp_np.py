@@ -92,6 +92,8 @@ class Settings:
     ipm_start_mu: float = 0.01      # point) starts the interior point CENTRED: slacks max(distance to the bound,
                                     # ipm_start_slack), multipliers ipm_start_mu / slack (row space of the scaled
                                     # problem); ipm_start_mu = 0: warm start from the ADMM multipliers as after a full run
+    as_add_fraction: float = 0.25   # active-set rounds add only the rows violated by at least this fraction of the worst
+                                    # violation (row violation / max |A_r.|: the violation of the scaled variable)
     phase1_eps: float = 1e-6    # OSQP's primal-infeasibility test on phase 1's ray uses this eps: the interior-point ray is
                                 # accurate to ~1e-7 (|A'y| / |y|), so the test can be much sharper than eps_prim_inf = 1e-4,
                                 # which is calibrated for ADMM's slowly converging dual steps
@@ -336,11 +338,14 @@ def _certified_polish(w, x, y, st, res, theta=3e-3, mu0=0.0) -> bool:
     ipm_tol = st.ipm_tol
     xi, yi = x, y
     for attempt in range(2):
-        xi, yi, nit, conv, act = _ipm_refine(w, xi, yi, st, ipm_tol, theta, mu0=mu0 if attempt == 0 else 0.0)
+        # (the retry at the tighter tolerance CONTINUES the iteration: slacks and multipliers are kept)
+        xi, yi, nit, conv, act = _ipm_refine(w, xi, yi, st, ipm_tol, theta, mu0=mu0 if attempt == 0 else 0.0,
+                                             state=act["state"] if attempt else None)
         res.ipm_iters += nit
         if not conv:
             break
-        out = _active_set_polish(w, act, st)
+        # (the retry is more careful: only the upper half of the violations enters per round)
+        out = _active_set_polish(w, act, st, add_fraction=st.as_add_fraction if attempt == 0 else max(st.as_add_fraction, 0.5))
         res.as_rounds += out[3]
         if out[2]:
             xs, ys = w.unscale(out[0], out[1])
@@ -469,7 +474,7 @@ def _row_classes(w: Workspace):
     return eq, L, U
 
 
-def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, stop=None, mu0=0.0):
+def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, stop=None, mu0=0.0, state=None):
     """`soft` (phase 1, see _phase1): per-row gamma^2 >= 0.  A soft row r reads  l <= (Ax)_r + gamma_r w_r <= u  with
     the cost 1/2 w_r^2 and NO other cost (P, q are taken as zero); w_r = gamma_r (zl_r - zu_r) is eliminated, which
     leaves the same iteration with  (Ax)_r - gamma_r^2 y_r  in place of (Ax)_r in the slack equations and
@@ -489,6 +494,8 @@ def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, 
     if mu0 > 0.0:           # centred start: every complementarity product equals mu0
         zl = np.where(L, mu0 / sl, 0.0)
         zu = np.where(U, mu0 / su, 0.0)
+    if state is not None:
+        sl, su, zl, zu = (a.copy() for a in state)
     nb = max(int(L.sum() + U.sum()), 1)
     reg = st.ipm_reg
     conv = False
@@ -504,8 +511,8 @@ def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, 
         ru = np.where(U, w.u - Ax + g2 * (zu - zl) - su, 0.0)
         mu = (np.sum(sl * zl * L) + np.sum(su * zu * U)) / nb
         res = max(_ninf(rd), _ninf(req), _ninf(rl), _ninf(ru))
-        if res < tol and mu < tol:
-            conv = True
+        if res < max(tol, 1e-11) and mu < tol:      # (residual floor of double precision: ~1e-13; the retry at
+            conv = True                             #  ipm_tol * 1e-4 needs its tolerance on mu only)
             break
         if stop is not None and stop(x, y):
             conv = True
@@ -564,7 +571,7 @@ def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, 
         nu = nu + a * dnu
         sl, su, zl, zu = sl + a * dsl, su + a * dsu, zl + a * dzl, zu + a * dzu
     y = nu + zu - zl
-    act = dict(eq=eq, low=L & (zl > sl), upp=U & (zu > su) & ~(L & (zl > sl)), L=L, U=U)
+    act = dict(eq=eq, low=L & (zl > sl), upp=U & (zu > su) & ~(L & (zl > sl)), L=L, U=U, state=(sl, su, zl, zu))
     return x, y, it, conv, act
 
 
@@ -638,11 +645,13 @@ def _phase1(w: Workspace, st: Settings, x0=None):
 # polish=2, stage 2: OSQP's active-set solve, iterated (primal-dual active-set
 # updates) with residuals accumulated in extended precision.
 # ---------------------------------------------------------------------------
-def _active_set_polish(w: Workspace, act, st: Settings, tol=1e-9):
+def _active_set_polish(w: Workspace, act, st: Settings, tol=1e-9, add_fraction=None):
+    add_fraction = st.as_add_fraction if add_fraction is None else add_fraction
     n, m = w.n, w.m
     eq, low, upp, L, U = act["eq"], act["low"].copy(), act["upp"].copy(), act["L"], act["U"]
     x = np.zeros(n)
     y = np.zeros(m)
+    gr = np.maximum(np.max(np.abs(w.A), axis=1), 1e-300) if m else np.ones(0)
     for rnd in range(1, st.as_rounds + 1):
         rows = np.flatnonzero(eq | low | upp)
         k = rows.size
@@ -672,6 +681,12 @@ def _active_set_polish(w: Workspace, act, st: Settings, tol=1e-9):
         bad_u = upp & (y < -tol)
         if not (viol_l.any() or viol_u.any() or bad_l.any() or bad_u.any()):
             return x, y, True, rnd
+        # only the violations within as_add_fraction of the worst one are added (see mpmpc_settings::as_add_fraction)
+        vl = np.where(viol_l, (w.l - Ax) / gr, 0.0)
+        vu = np.where(viol_u, (Ax - w.u) / gr, 0.0)
+        thr = add_fraction * max(vl.max(initial=0.0), vu.max(initial=0.0))
+        viol_l &= ~(vl < thr)
+        viol_u &= ~(vu < thr)
         low = (low & ~bad_l) | viol_l
         upp = ((upp & ~bad_u) | viol_u) & ~low
     return x, y, False, st.as_rounds

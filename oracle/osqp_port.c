@@ -46,6 +46,7 @@ typedef struct {
   int32_t early_polish, early_scaling, phase1;
   double ipm_diverged, phase1_theta, phase1_eps;
   double ipm_start_slack, ipm_start_mu;    /* centred start of the early interior-point attempt (see osqp_np.Settings) */
+  double as_add_fraction;                  /* active-set rounds add only violations >= this fraction of the worst */
 } oracle_settings;
 
 typedef struct {
@@ -487,7 +488,9 @@ typedef struct { int *eq, *L, *U; } classes_t;
  * (Ax)_r in the slack equations and gamma_r^2 is added to the row's diagonal entry of the reduced KKT matrix.  In that
  * mode the loop also ends as soon as the multipliers pass OSQP's primal-infeasibility test. */
 static int primal_infeasible(const work_t* w, const double* dy, double eps, double* tn, double* tm);
-static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double* x, double* y, double tol, double theta, int* iters_out, int* low, int* upp, const double* soft, double mu0) {
+static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double* x, double* y, double tol, double theta, int* iters_out, int* low, int* upp, const double* soft, double mu0, double* keep, int resume) {
+  /* keep (4 m doubles or NULL): the slacks and multipliers (sl, su, zl, zu) at exit; resume != 0: start from them and
+   * from (x, y) instead of flooring afresh - the retry at a tighter tolerance CONTINUES the iteration */
   const oracle_settings* st = w->st;
   int n = w->n, m = w->m, N = n + m;
   const double reg = st->ipm_reg;
@@ -511,6 +514,7 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
     zl[r] = cl->L[r] ? dmax(-y[r], theta) : 0.0;
     zu[r] = cl->U[r] ? dmax(y[r], theta) : 0.0;
     if (mu0 > 0.0) { zl[r] = cl->L[r] ? mu0 / sl[r] : 0.0; zu[r] = cl->U[r] ? mu0 / su[r] : 0.0; }
+    if (resume && keep) { sl[r] = keep[r]; su[r] = keep[m + r]; zl[r] = keep[2 * m + r]; zu[r] = keep[3 * m + r]; }
     nb += cl->L[r] + cl->U[r];
   }
   if (nb < 1) nb = 1;
@@ -534,7 +538,7 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
       if (cl->U[r]) mu += su[r] * zu[r];
     }
     mu /= nb;
-    if (res < tol && mu < tol) { conv = 1; break; }
+    if (res < dmax(tol, 1e-11) && mu < tol) { conv = 1; break; }
     if (soft && primal_infeasible(w, yy, st->phase1_eps, tn, tm)) { conv = 1; break; }
     if (it == st->ipm_max_iter) break;
     /* mu of a feasible problem falls (nearly) monotonically; on an infeasible one the multipliers blow up within a few
@@ -602,6 +606,7 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
     y[r] = nu[r] + zu[r] - zl[r];
     low[r] = cl->L[r] && zl[r] > sl[r];
     upp[r] = cl->U[r] && zu[r] > su[r] && !low[r];
+    if (keep) { keep[r] = sl[r]; keep[m + r] = su[r]; keep[2 * m + r] = zl[r]; keep[3 * m + r] = zu[r]; }
   }
   *iters_out = it;
   free(Ax); free(nu); free(sl); free(su); free(zl); free(zu); free(rd); free(req); free(rl); free(ru); free(d); free(rhs); free(sol);
@@ -611,12 +616,16 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
 }
 
 /* ------------------------------------------------------------------ polish stage 2: iterated active-set solve */
-static int active_set_polish(work_t* w, const classes_t* cl, int* low, int* upp, double* x, double* y, int* rounds_out) {
+static int active_set_polish(work_t* w, const classes_t* cl, int* low, int* upp, double* x, double* y, int* rounds_out, double add_fraction) {
   const oracle_settings* st = w->st;
   int n = w->n, m = w->m;
   const double tol = 1e-9;
   int* rows = (int*)malloc(sizeof(int) * (m > 0 ? m : 1));
   double* Ax = (double*)malloc(sizeof(double) * m);
+  double* rowmax = (double*)calloc(m > 0 ? m : 1, sizeof(double));
+  for (int j = 0; j < n; ++j)
+    for (int p = w->A.p[j]; p < w->A.p[j + 1]; ++p) rowmax[w->A.i[p]] = dmax(rowmax[w->A.i[p]], fabs(w->A.x[p]));
+  for (int r = 0; r < m; ++r) if (!(rowmax[r] > 0.0)) rowmax[r] = 1e-300;
   int ok = 0, rnd = 0;
   for (rnd = 1; rnd <= st->as_rounds; ++rnd) {
     int k = 0;
@@ -671,11 +680,19 @@ static int active_set_polish(work_t* w, const classes_t* cl, int* low, int* upp,
     csc_mul(&w->A, x, Ax);
     int any = 0;
     int *nl = (int*)malloc(sizeof(int) * (m > 0 ? m : 1)), *nu_ = (int*)malloc(sizeof(int) * (m > 0 ? m : 1));
+    double worst = 0.0;           /* worst violation of a scaled variable: row violation / max |A_r.| */
+    for (int r = 0; r < m; ++r) {
+      if (cl->L[r] && !low[r] && Ax[r] < w->l[r] - tol) worst = dmax(worst, (w->l[r] - Ax[r]) / rowmax[r]);
+      if (cl->U[r] && !upp[r] && Ax[r] > w->u[r] + tol) worst = dmax(worst, (Ax[r] - w->u[r]) / rowmax[r]);
+    }
+    const double thr = add_fraction * worst;
     for (int r = 0; r < m; ++r) {
       int vl = cl->L[r] && !low[r] && Ax[r] < w->l[r] - tol;
       int vu = cl->U[r] && !upp[r] && Ax[r] > w->u[r] + tol;
       int bl = low[r] && y[r] > tol, bu = upp[r] && y[r] < -tol;
       if (vl || vu || bl || bu) any = 1;
+      vl = vl && !((w->l[r] - Ax[r]) / rowmax[r] < thr);       /* only the violations near the worst one are added */
+      vu = vu && !((Ax[r] - w->u[r]) / rowmax[r] < thr);
       nl[r] = (low[r] && !bl) || vl;
       nu_[r] = ((upp[r] && !bu) || vu) && !nl[r];
     }
@@ -684,7 +701,7 @@ static int active_set_polish(work_t* w, const classes_t* cl, int* low, int* upp,
     if (!any) { ok = 1; break; }
   }
   *rounds_out = rnd > st->as_rounds ? st->as_rounds : rnd;
-  free(rows); free(Ax);
+  free(rows); free(Ax); free(rowmax);
   return ok;
 }
 
@@ -708,14 +725,16 @@ static int certified_polish(work_t* w, const double* x, const double* y, double 
   double *xs = (double*)malloc(sizeof(double) * n), *ys = (double*)malloc(sizeof(double) * m);
   memcpy(xi, x, sizeof(double) * n); memcpy(yi, y, sizeof(double) * m);
   double tol = st->ipm_tol;
+  double* keep = (double*)malloc(sizeof(double) * 4 * (m > 0 ? m : 1));
   int good = 0;
   for (int attempt = 0; attempt < 2 && !good; ++attempt) {
     int nit = 0;
-    int conv = ipm_refine(w, w->K, w->F, &cl, xi, yi, tol, theta, &nit, low, upp, NULL, attempt == 0 ? mu0 : 0.0);
+    int conv = ipm_refine(w, w->K, w->F, &cl, xi, yi, tol, theta, &nit, low, upp, NULL, attempt == 0 ? mu0 : 0.0, keep, attempt);
     info->ipm_iters += nit;
     if (!conv) break;
     int rounds = 0;
-    int okm = active_set_polish(w, &cl, low, upp, xa, ya, &rounds);
+    /* (the retry is more careful: only the upper half of the violations) */
+    int okm = active_set_polish(w, &cl, low, upp, xa, ya, &rounds, attempt == 0 ? st->as_add_fraction : dmax(st->as_add_fraction, 0.5));
     info->as_rounds += rounds;
     if (okm) {
       for (int j = 0; j < n; ++j) xs[j] = w->D[j] * xa[j];
@@ -729,7 +748,7 @@ static int certified_polish(work_t* w, const double* x, const double* y, double 
     }
     tol *= 1e-4;
   }
-  free(cl.eq); free(cl.L); free(cl.U); free(low); free(upp); free(xi); free(yi); free(xa); free(ya); free(xs); free(ys);
+  free(cl.eq); free(cl.L); free(cl.U); free(low); free(upp); free(xi); free(yi); free(xa); free(ya); free(xs); free(ys); free(keep);
   return good;
 }
 
@@ -764,7 +783,7 @@ static int phase1(work_t* w, double* x_out, double* y_out, oracle_info* info) {
   int *low = (int*)calloc(m, sizeof(int)), *upp = (int*)calloc(m, sizeof(int));
   int nit = 0;
   /* (two digits beyond the polish's tolerance: the quantities of a marginal verdict are themselves at the 1e-9 level) */
-  int conv = ipm_refine(w, w->K, w->F, &cl, x, y, st->ipm_tol * 1e-2, st->phase1_theta, &nit, low, upp, soft, 0.0);
+  int conv = ipm_refine(w, w->K, w->F, &cl, x, y, st->ipm_tol * 1e-2, st->phase1_theta, &nit, low, upp, soft, 0.0, NULL, 0);
   info->ipm_iters += nit;
   /* (A) OSQP's test at phase1_eps: any iterate whose ray passes is a certificate */
   int cert = primal_infeasible(w, y, st->phase1_eps, tn, tm);

@@ -116,6 +116,41 @@ def kkt_batch(qp, N, z, y):
     return prim, stat, np.maximum(comp(x, lo_x, hi_x, yx), comp(u, lo_u, hi_u, yu))
 
 
+def objective_batch(qp, N, z):
+    """1/2 z'Pz + q'z per instance from the stage fields (diagonal weights)."""
+    B = qp.shape[1]
+    f = qp[:, :, :N + 1]
+    ne = 3 * (N + 1)
+    x = z[:, :ne].reshape(B, N + 1, 3)
+    u = z[:, ne:].reshape(B, N, 2)
+    Px, qx = np.moveaxis(f[22:25], 0, -1), np.moveaxis(f[17:20], 0, -1)
+    Pu, qu = np.moveaxis(f[25:27, :, :N], 0, -1), np.moveaxis(f[20:22, :, :N], 0, -1)
+    return (0.5 * Px * x * x + qx * x).sum(axis=(1, 2)) + (0.5 * Pu * u * u + qu * u).sum(axis=(1, 2))
+
+
+def controls_vs_reference(qp, N, sol, ref, tol=1e-6):
+    """Controls of the device against the oracle's on the instances both solved.  The reference's stock weights put NO
+    cost on the steering input (R = diag(0.5, 0), src/simulation.py:104) and none on e_psi and t: the QP is positive
+    SEMI-definite, and where a corridor bound is weakly active (zero multiplier) its optimum is a face, not a point -
+    two correct solvers may return different points of it.  Such an instance counts as an ALTERNATIVE OPTIMUM when
+    both points carry a KKT certificate (1e-8) and their objectives agree to 1e-9 relative; everything else must agree
+    to `tol`.  -> (worst |u - u_ref| over the rest, indices of the alternative optima)"""
+    both = (sol.status == 1) & (ref["status"] == 1)
+    d = np.abs(sol.u0 - ref["u0"]).max(axis=1)
+    far = np.flatnonzero(both & (d > tol))
+    alt = []
+    if far.size:
+        q = qp[:, far, :]
+        od, orf = objective_batch(q, N, sol.z[far]), objective_batch(q, N, ref["z"][far])
+        cd = np.max(kkt_batch(q, N, sol.z[far], sol.y[far]), axis=0)
+        cr = np.max(kkt_batch(q, N, ref["z"][far], ref["y"][far]), axis=0)
+        same = (np.abs(od - orf) <= 1e-9 * np.maximum(1.0, np.abs(orf))) & (cd <= 1e-8) & (cr <= 1e-8)
+        alt = far[same]
+    rest = both.copy()
+    rest[alt] = False
+    return (float(d[rest].max()) if rest.any() else 0.0), np.asarray(alt, int)
+
+
 def farkas_batch(qp, N, y, eps=1e-6):
     """Vectorised check that the rays y [B, 8N+6] prove their QPs infeasible (OSQP's primal-infeasibility criterion,
     plain numpy on K1's stage fields qp [27, B, LD]; eps = the library's phase1_eps; rows [dynamics; state boxes; input boxes] as in
