@@ -494,8 +494,9 @@ def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, 
     if mu0 > 0.0:           # centred start: every complementarity product equals mu0
         zl = np.where(L, mu0 / sl, 0.0)
         zu = np.where(U, mu0 / su, 0.0)
+    tap_l, tap_u = L & (zl > sl), U & (zu > su)         # (before any step: multiplier above slack)
     if state is not None:
-        sl, su, zl, zu = (a.copy() for a in state)
+        sl, su, zl, zu, tap_l, tap_u = (a.copy() for a in state)
     nb = max(int(L.sum() + U.sum()), 1)
     reg = st.ipm_reg
     conv = False
@@ -569,9 +570,11 @@ def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, 
             break
         x = x + a * dx
         nu = nu + a * dnu
+        # active-set indicators of this step (Tapia): the slack of an active bound shrinks faster than its multiplier
+        tap_l, tap_u = L & (dsl * zl < dzl * sl), U & (dsu * zu < dzu * su)
         sl, su, zl, zu = sl + a * dsl, su + a * dsu, zl + a * dzl, zu + a * dzu
     y = nu + zu - zl
-    act = dict(eq=eq, low=L & (zl > sl), upp=U & (zu > su) & ~(L & (zl > sl)), L=L, U=U, state=(sl, su, zl, zu))
+    act = dict(eq=eq, low=tap_l, upp=tap_u & ~tap_l, L=L, U=U, state=(sl, su, zl, zu, tap_l, tap_u))
     return x, y, it, conv, act
 
 

@@ -515,6 +515,7 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
     zu[r] = cl->U[r] ? dmax(y[r], theta) : 0.0;
     if (mu0 > 0.0) { zl[r] = cl->L[r] ? mu0 / sl[r] : 0.0; zu[r] = cl->U[r] ? mu0 / su[r] : 0.0; }
     if (resume && keep) { sl[r] = keep[r]; su[r] = keep[m + r]; zl[r] = keep[2 * m + r]; zu[r] = keep[3 * m + r]; }
+    else { low[r] = cl->L[r] && zl[r] > sl[r]; upp[r] = cl->U[r] && zu[r] > su[r]; }   /* (before any step) */
     nb += cl->L[r] + cl->U[r];
   }
   if (nb < 1) nb = 1;
@@ -596,6 +597,9 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
         for (int j = 0; j < n; ++j) x[j] += a * sol[j];
         for (int r = 0; r < m; ++r) {
           if (cl->eq[r]) nu[r] += a * sol[n + r];
+          /* active-set indicators of this step (Tapia): the slack of an active bound shrinks faster than its multiplier */
+          low[r] = cl->L[r] && dsl[r] * zl[r] < dzl[r] * sl[r];
+          upp[r] = cl->U[r] && dsu[r] * zu[r] < dzu[r] * su[r];
           sl[r] += a * dsl[r]; su[r] += a * dsu[r]; zl[r] += a * dzl[r]; zu[r] += a * dzu[r];
         }
       }
@@ -604,8 +608,7 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
   }
   for (int r = 0; r < m; ++r) {
     y[r] = nu[r] + zu[r] - zl[r];
-    low[r] = cl->L[r] && zl[r] > sl[r];
-    upp[r] = cl->U[r] && zu[r] > su[r] && !low[r];
+    upp[r] = upp[r] && !low[r];
     if (keep) { keep[r] = sl[r]; keep[m + r] = su[r]; keep[2 * m + r] = zl[r]; keep[3 * m + r] = zu[r]; }
   }
   *iters_out = it;
