@@ -2008,6 +2008,8 @@ struct Solver {
       // space of the scaled problem: the slack of row g x is g times the slack of x, its multiplier 1 / g times).
       const R ths(st.ipm_start_slack), mu0(st.ipm_start_mu);
       MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) s.nu[i] = zero;       // (the equality multipliers of that one iteration: worse than none)
+      MPMPC_UNROLL
       for (int j = 0; j < 5; ++j) {
         const R fl = ths / g[j];
         s.sl[j] = sel(bx.Lm[j], max_(x[j] - bx.lo[j], fl), one);
@@ -2134,7 +2136,7 @@ struct Solver {
     MPMPC_TICK_BEGIN(9);
     // (phase 1 converges two digits further than the polish: for an instance infeasible by a tenth of a millimetre the
     //  quantities of the verdict - the ray's support - are themselves at the 1e-9 level)
-    ipm<LAY, true>(bi, si, pp, qq, vm, st, st.ipm_tol * 1e-2, run);
+    ipm<LAY, true>(bi, si, pp, qq, vm, st, st.ipm_tol * 1e-2 < 1e-11 ? st.ipm_tol * 1e-2 : 1e-11, run);
     MPMPC_TICK_END(9);
     L::fence();
     MPMPC_UNROLL

@@ -464,7 +464,7 @@ void mpmpc_default_settings(mpmpc_settings* s) {
   s->eps_abs = 1e-3; s->eps_rel = 1e-3; s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4;
   s->max_iter = 4000; s->check_termination = 25; s->scaling = 10;
   s->adaptive_rho = 1; s->adaptive_rho_interval = 50; s->adaptive_rho_tolerance = 5.0;
-  s->polish = 2; s->ipm_max_iter = 30; s->ipm_tol = 1e-9; s->ipm_reg = 1e-8;
+  s->polish = 2; s->ipm_max_iter = 30; s->ipm_tol = 1e-8; s->ipm_reg = 1e-8;
   s->as_delta = 1e-10; s->as_refine = 5; s->as_rounds = 4; s->cert_tol = 1e-8;
   s->early_polish = 1;
   s->early_scaling = 1;

@@ -52,7 +52,7 @@ def default_settings(**kw) -> Settings:
     s = Settings(rho=0.1, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, eps_prim_inf=1e-4,
                  eps_dual_inf=1e-4, max_iter=4000, check_termination=25, scaling=10, adaptive_rho=1,
                  adaptive_rho_interval=50, adaptive_rho_tolerance=5.0, polish=2, ipm_max_iter=30,
-                 ipm_tol=1e-9, ipm_reg=1e-8, as_delta=1e-10, as_refine=5, as_rounds=4, cert_tol=1e-8, early_polish=1,
+                 ipm_tol=1e-8, ipm_reg=1e-8, as_delta=1e-10, as_refine=5, as_rounds=4, cert_tol=1e-8, early_polish=1,
                  early_scaling=1, phase1=1, ipm_diverged=1e2, phase1_theta=1.0, phase1_eps=1e-6, reduce=1,
                  ipm_start_slack=0.1, ipm_start_mu=0.01, as_add_fraction=0.25)
     for k, v in kw.items():

@@ -74,7 +74,7 @@ class Settings:
     delta: float = 1e-6          # stock polish regularisation
     polish_refine_iter: int = 3
     # polish=2 parameters
-    ipm_tol: float = 1e-9
+    ipm_tol: float = 1e-8
     ipm_reg: float = 1e-8
     ipm_max_iter: int = 30
     ipm_diverged: float = 1e2    # interior point stops when mu exceeds this multiple of its smallest value so far
@@ -491,7 +491,8 @@ def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, 
     su = np.where(U, np.maximum(w.u - Ax, theta), 1.0)
     zl = np.where(L, np.maximum(-y0, theta), 0.0)
     zu = np.where(U, np.maximum(y0, theta), 0.0)
-    if mu0 > 0.0:           # centred start: every complementarity product equals mu0
+    if mu0 > 0.0:           # centred start: every complementarity product equals mu0, no equality multipliers
+        nu = np.zeros(m)
         zl = np.where(L, mu0 / sl, 0.0)
         zu = np.where(U, mu0 / su, 0.0)
     tap_l, tap_u = L & (zl > sl), U & (zu > su)         # (before any step: multiplier above slack)
@@ -629,7 +630,7 @@ def _phase1(w: Workspace, st: Settings, x0=None):
     stop = lambda x, y: _primal_infeasible(w, y, st.phase1_eps)
     # (two digits beyond the polish's tolerance: for an instance infeasible by a tenth of a millimetre the quantities of
     #  the verdict - the ray's support - are themselves at the 1e-9 level)
-    x, y, it, conv, _ = _ipm_refine(w, np.zeros(n) if x0 is None else x0, np.zeros(m), st, st.ipm_tol * 1e-2, st.phase1_theta,
+    x, y, it, conv, _ = _ipm_refine(w, np.zeros(n) if x0 is None else x0, np.zeros(m), st, min(st.ipm_tol * 1e-2, 1e-11), st.phase1_theta,
                                     soft=soft, stop=stop)
     if _primal_infeasible(w, y, st.phase1_eps):
         return x, y, it, True, False

@@ -513,7 +513,7 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
     su[r] = cl->U[r] ? dmax(w->u[r] - Ax[r], theta) : 1.0;
     zl[r] = cl->L[r] ? dmax(-y[r], theta) : 0.0;
     zu[r] = cl->U[r] ? dmax(y[r], theta) : 0.0;
-    if (mu0 > 0.0) { zl[r] = cl->L[r] ? mu0 / sl[r] : 0.0; zu[r] = cl->U[r] ? mu0 / su[r] : 0.0; }
+    if (mu0 > 0.0) { nu[r] = 0.0; zl[r] = cl->L[r] ? mu0 / sl[r] : 0.0; zu[r] = cl->U[r] ? mu0 / su[r] : 0.0; }
     if (resume && keep) { sl[r] = keep[r]; su[r] = keep[m + r]; zl[r] = keep[2 * m + r]; zu[r] = keep[3 * m + r]; }
     else { low[r] = cl->L[r] && zl[r] > sl[r]; upp[r] = cl->U[r] && zu[r] > su[r]; }   /* (before any step) */
     nb += cl->L[r] + cl->U[r];
@@ -786,7 +786,7 @@ static int phase1(work_t* w, double* x_out, double* y_out, oracle_info* info) {
   int *low = (int*)calloc(m, sizeof(int)), *upp = (int*)calloc(m, sizeof(int));
   int nit = 0;
   /* (two digits beyond the polish's tolerance: the quantities of a marginal verdict are themselves at the 1e-9 level) */
-  int conv = ipm_refine(w, w->K, w->F, &cl, x, y, st->ipm_tol * 1e-2, st->phase1_theta, &nit, low, upp, soft, 0.0, NULL, 0);
+  int conv = ipm_refine(w, w->K, w->F, &cl, x, y, dmin(st->ipm_tol * 1e-2, 1e-11), st->phase1_theta, &nit, low, upp, soft, 0.0, NULL, 0);
   info->ipm_iters += nit;
   /* (A) OSQP's test at phase1_eps: any iterate whose ray passes is a certificate */
   int cert = primal_infeasible(w, y, st->phase1_eps, tn, tm);
