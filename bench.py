@@ -52,7 +52,7 @@ def k1_bytes_per_solve(N):
 
 # FP64 flops of one solve at the default settings, fitted on the instruction census of the lock-step emulation of the
 # SAME lane code (profiles/census.py; FMA = 2, other arithmetic = 1, compares / selects / lane moves = 0) as
-#     flops = c0 + c1 * interior-point iterations      (rms error 2.5-5 %)
+#     flops = c0 + c1 * interior-point iterations      (rms error below 2 %: one active-set round almost always)
 # "algorithmic": the structure-exploiting count of the implemented recurrence - lane-parallel instructions
 #   count for the lanes that hold a stage, every serial sweep of the twisted factorisation / substitutions counts ONE
 #   step per stage (per stage: factor 180 flops, KKT solve 110).
@@ -61,11 +61,11 @@ def k1_bytes_per_solve(N):
 # key: (N + 1 <= 32, i.e. one lane per stage with the split interior-point layout;  reduced polish (mpmpc_settings::reduce
 #       applies: t carries neither cost nor bound);  certified optimal / Farkas-certified)
 _FLOPS = {
-    (True, True, 1): dict(algorithmic=(48860.0, 17438.0), executed=(133972.0, 38826.0), N=30),
-    (True, True, -3): dict(algorithmic=(32771.0, 23308.0), executed=(45245.0, 52866.0), N=30),
-    (True, False, 1): dict(algorithmic=(81447.0, 40273.0), executed=(300857.0, 96760.0), N=30),
-    (True, False, -3): dict(algorithmic=(132612.0, 42339.0), executed=(318920.0, 104347.0), N=30),
-    (False, False, 1): dict(algorithmic=(47970.0, 64030.0), executed=(215726.0, 288391.0), N=50),
+    (True, True, 1): dict(algorithmic=(40708.0, 18134.0), executed=(98084.0, 40982.0), N=30),
+    (True, True, -3): dict(algorithmic=(48823.0, 22075.0), executed=(80271.0, 49912.0), N=30),
+    (True, False, 1): dict(algorithmic=(60242.0, 34985.0), executed=(207452.0, 97650.0), N=30),
+    (True, False, -3): dict(algorithmic=(59657.0, 41835.0), executed=(141472.0, 116563.0), N=30),
+    (False, False, 1): dict(algorithmic=(105506.0, 46289.0), executed=(544228.0, 246133.0), N=50),
 }
 
 

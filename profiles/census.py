@@ -14,7 +14,7 @@ Two counts per solve, both from the SAME executed code (mpmpc_core.hpp marks the
 Fitted per solve at the default settings as  flops = c0 + c1 * ipm_iters  (the one ADMM iteration, the Ruiz passes,
 the active-set rounds and the certificate are in c0 / amortised in c1) and printed with the per-stage cost of the two
 linear-algebra pieces (factor, KKT solve).  bench.py carries the fitted constants.  Runs in the authoring container:
-    python profiles/census.py [config] [instances]"""
+    python profiles/census.py [config] [instances] [reduce (1 | 0)]"""
 import ctypes as C
 import os
 import sys
@@ -37,7 +37,7 @@ tr = scenarios.sim_track()
 sc = scenarios.make(config, tr, B)
 N = sc.N
 cfg = tl.stock_config(N, weights=sc.weights)
-st = mpmpc.default_settings()
+st = mpmpc.default_settings(reduce=int(sys.argv[3]) if len(sys.argv) > 3 else 1)
 out = (C.c_double * 4)()
 rows = []
 for i in range(B):
