@@ -69,6 +69,18 @@ _FLOPS = {
 }
 
 
+def qp_objective(qp, N, z):
+    """1/2 z'Pz + q'z per instance from the stage-blocked fields of mpmpc_assemble (diagonal weights: fields 22-26 the
+    cost diagonal, 17-21 the cost vector; include/mpmpc.h)"""
+    B = qp.shape[1]
+    f = qp[:, :, :N + 1]
+    ne = 3 * (N + 1)
+    x, u = z[:, :ne].reshape(B, N + 1, 3), z[:, ne:].reshape(B, N, 2)
+    Px, qx = np.moveaxis(f[22:25], 0, -1), np.moveaxis(f[17:20], 0, -1)
+    Pu, qu = np.moveaxis(f[25:27, :, :N], 0, -1), np.moveaxis(f[20:22, :, :N], 0, -1)
+    return (0.5 * Px * x * x + qx * x).sum(axis=(1, 2)) + (0.5 * Pu * u * u + qu * u).sum(axis=(1, 2))
+
+
 def reduced_polish(cfg, settings):
     """mirror of mpmpc::reducible (csrc/mpmpc_core.hpp): may the polish solve the (e_y, e_psi, kappa) problem?"""
     return bool(settings.reduce and settings.polish and cfg.Q[2] == 0.0 and cfg.QN[2] == 0.0 and not any(cfg.QN_offdiag)
@@ -354,7 +366,23 @@ def _main(real_stdout):
             out["cpu_baseline"] = base
             ns = ref["status"].size
             both = (ref["status"] == 1) & (sol.status[:ns] == 1)
-            out["max_abs_u_minus_uref"] = float(np.max(np.abs(sol.u0[:ns][both] - ref["u0"][both]))) if both.any() else None
+            # The stock weights put no cost on the steering input, on e_psi and on t (src/simulation.py:101-111): the QP is
+            # positive SEMI-definite, and where a corridor bound is weakly active its optimum is a face, not a point.  An
+            # instance whose control differs by more than the tolerance while both solvers hold a certificate and the
+            # objectives agree to 1e-9 relative is an alternative optimum: counted, not compared.
+            du = np.abs(sol.u0[:ns] - ref["u0"]).max(axis=1)
+            far = np.flatnonzero(both & (du > 1e-6))
+            alt = np.zeros(ns, bool)
+            if far.size:
+                qf = h.assemble(wp[far], x0[far], cc[far], lb[far], ub[far])
+                od, orf = qp_objective(qf, N, sol.z[:ns][far]), qp_objective(qf, N, ref["z"][far])
+                alt[far[np.abs(od - orf) <= 1e-9 * np.maximum(1.0, np.abs(orf))]] = True
+            out["alternative_optima"] = {"count": int(alt.sum()), "max_abs_u_diff": float(du[alt].max()) if alt.any() else 0.0,
+                                         "note": "both certified (KKT 1e-8), objectives equal to 1e-9 relative, controls differ by "
+                                                 "more than 1e-6: the QP is only positive semi-definite (no cost on the steering "
+                                                 "input); excluded from max_abs_u_minus_uref / max_abs_plan_minus_ref"}
+            both = both & ~alt
+            out["max_abs_u_minus_uref"] = float(np.max(du[both])) if both.any() else None
             out["status_agreement"] = float(np.mean(ref["status"] == sol.status[:ns]))
             # whole plan (z without the cost-free kappa_{N-1} and e_psi_N) against the certified optimum
             keep = np.ones(5 * N + 3, bool)
