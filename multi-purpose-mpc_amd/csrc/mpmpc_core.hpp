@@ -593,17 +593,12 @@ struct Solver {
         S22 = fma_(-Mx[8], Mx[8], fma_(-Mx[7], Mx[7], fma_(-Mx[6], Mx[6], S22)));
       }
       // 3x3 Cholesky through reciprocal square roots: i_jj = 1 / l_jj
-      // (the first two reciprocal square roots are independent of each other, as in factor_core2:
-      //  1 / l11 = sqrt(S00) / sqrt(S00 S11 - S10^2);  l21 = (S00 S21 - S20 S10) / S00 / l11)
       R i00 = rsqrt_(S00);
-      R rdet = rsqrt_(fma_(S00, S11, -(S10 * S10)));
-      R c21 = fma_(S00, S21, -(S20 * S10));
-      R q00 = i00 * i00;
       R l10 = S10 * i00, l20 = S20 * i00;
-      R i11 = rdet * (S00 * i00);
-      R l21 = (c21 * q00) * i11;
+      R i11 = rsqrt_(fma_(-l10, l10, S11));
+      R l21 = fma_(-l20, l10, S21) * i11;
       R i22 = rsqrt_(fma_(-l21, l21, fma_(-l20, l20, S22)));
-      R i10 = -((S10 * q00) * i11);
+      R i10 = -(l10 * i00) * i11;
       R i21 = -(l21 * i11) * i22;
       R i20 = -(fma_(l21, i10, l20 * i00)) * i22;
       Li[0] = i00; Li[1] = i10; Li[2] = i11; Li[3] = i20; Li[4] = i21; Li[5] = i22;
@@ -971,13 +966,10 @@ struct Solver {
         S10 = fma_(-Mx[3], Mx[1], fma_(-Mx[2], Mx[0], S10));
         S11 = fma_(-Mx[3], Mx[3], fma_(-Mx[2], Mx[2], S11));
       }
-      // inv(L) of the 2 x 2 pivot with its two reciprocal square roots INDEPENDENT of each other (the step is a chain of
-      // dependent instructions at one wave per SIMD):  1 / l11 = 1 / sqrt(S11 - S10^2 / S00) = sqrt(S00) / sqrt(det)
-      // - the same cancellation as the textbook order, three dependent instructions fewer per step
       R i00 = rsqrt_(S00);
-      R rdet = rsqrt_(fma_(S00, S11, -(S10 * S10)));
-      R i11 = rdet * (S00 * i00);
-      R i10 = -((S10 * (i00 * i00)) * i11);
+      R l10 = S10 * i00;
+      R i11 = rsqrt_(fma_(-l10, l10, S11));
+      R i10 = -(l10 * i00) * i11;
       Li[0] = i00; Li[1] = i10; Li[2] = i11;
       MPMPC_UNROLL
       for (int i = 0; i < 4; ++i) Ls[i] = Mr[i];
