@@ -429,6 +429,32 @@ def test_default_path_does_not_depend_on_adaptive_rho_interval(track):
     assert np.mean(usable[0] == usable[1]) >= 0.99 and np.mean(usable[2] == usable[1]) >= 0.99
 
 
+@pytest.mark.parametrize("cfgid,B", [(2, 512), (4, 1024), (3, 256)])
+def test_the_polish_settings_change_the_route_not_the_answer(cfgid, B, track):
+    """The knobs of the certified polish - centred or warm start, step indicators' tolerance, selective active-set
+    additions, reduced or full problem - decide how many iterations an instance takes, never what it returns: every
+    variant ends with the same status and, where solved, the same certified optimum (1e-8 in u; both certified)."""
+    sc = scenarios.make(cfgid, track, B=B)
+    variants = [dict(), dict(ipm_start_mu=0.0), dict(ipm_tol=1e-9), dict(ipm_tol=1e-7), dict(as_add_fraction=0.0),
+                dict(ipm_start_slack=0.3, ipm_start_mu=0.1), dict(reduce=0)]
+    outs = []
+    for kw in variants:
+        h = _handle(track, sc.N, sc.weights, B, mpmpc.default_settings(**kw))
+        if not outs:
+            qp = h.assemble(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+        outs.append(h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True))
+        h.close()
+    ref = outs[0]
+    ok = ref.status == 1
+    assert set(np.unique(ref.status)) <= {1, mpmpc.PRIMAL_INFEASIBLE} and ok.mean() > 0.85
+    for kw, o in zip(variants[1:], outs[1:]):
+        assert np.array_equal(o.status, ref.status), kw
+        worst, alt = T.controls_vs_reference(qp, sc.N, o, dict(status=ref.status, u0=ref.u0, z=ref.z, y=ref.y), 1e-8)
+        assert worst <= 1e-8 and alt.size <= 1, (kw, worst, alt)
+        prim, stat, comp = T.kkt_batch(qp[:, ok, :], sc.N, o.z[ok], o.y[ok])
+        assert max(prim.max(), stat.max(), comp.max()) <= 1e-8, kw
+
+
 @pytest.mark.parametrize("cfgid,B", [(5, 65536), (2, 65536)])
 def test_baseline_batch_sizes_carry_kkt_certificates(cfgid, B, track):
     """BASELINE.json's largest batches (config 5: 65 536 obstacle-course instances; config 2's poses at
