@@ -92,6 +92,8 @@ def make(config: int, track: Track | None = None, B: int | None = None, N: int |
     rng = np.random.default_rng(spec["seed"])
     ubT, lbT = (tr.ub_obstacles, tr.lb_obstacles) if spec["obstacles"] else (tr.ub_free, tr.lb_free)
     wp = rng.integers(0, tr.n_wp, B)
+    if N > ubT.shape[1]:
+        raise ValueError("the corridor tables of the golden track hold %d stages; N = %d needs its own tables" % (ubT.shape[1], N))
     ub, lb = ubT[wp, :N], lbT[wp, :N]
     u1, u2 = rng.uniform(-1.0, 1.0, B), rng.uniform(-0.2, 0.2, B)
     if spec["obstacles"]:      # offset inside the first horizon corridor: most, not all, feasible
