@@ -116,6 +116,10 @@ typedef struct {
                             the multipliers carry no information and small slacks cost 5-7 blocked steps.  ipm_start_mu = 0:
                             warm start from the ADMM multipliers, as the polish after a full ADMM run always does.
                             Defaults 0.1, 0.01. */
+  double ipm_start_dual;  /* > 0: the centred start uses mu0 = max(ipm_start_mu, ipm_start_dual x ipm_start_slack x |P x + q|_inf)
+                            (scaled problem, start point x): start multipliers commensurate with the dual residual they
+                            have to balance (config 3, time-optimal weights: 12.6 -> 11.4 iterations; the stock weights sit on the
+                            ipm_start_mu floor).  0: ipm_start_mu alone.  Default 0.2. */
   double as_add_fraction; /* active-set rounds add only the bounds violated by at least this fraction of the round's worst
                             violation (measured on the scaled variable); 0: every violated bound, the plain primal-dual
                             active-set update; the retry after a failed attempt uses at least 0.5.  Default 0.25. */

@@ -2006,7 +2006,22 @@ struct Solver {
       // After early_polish (= 1) ADMM iterations the multipliers carry no information and the point violates every
       // speed bound: floors of 3e-3 cost 5-7 blocked steps.  Centred start instead (mpmpc_settings::ipm_start_*, row
       // space of the scaled problem: the slack of row g x is g times the slack of x, its multiplier 1 / g times).
-      const R ths(st.ipm_start_slack), mu0(st.ipm_start_mu);
+      const R ths(st.ipm_start_slack);
+      R mu0(st.ipm_start_mu);
+      if (st.ipm_start_dual > 0.0) {
+        // ... and multipliers commensurate with the dual residual they will have to balance: mu0 at least
+        // ipm_start_dual x slack floor x |P x + q|_inf of the start point
+        R rd0(0.0);
+        [[maybe_unused]] R Pod[3] = {zero, zero, zero};
+        if constexpr (FQ) od_mul_add(pod, x, Pod);
+        MPMPC_UNROLL
+        for (int j = 0; j < 5; ++j) {
+          R v = fma_(p[j], x[j], q[j]);
+          if constexpr (FQ) { if (j < 3) v = v + Pod[j]; }
+          rd0 = max_(rd0, sel(valid[j], abs_(v), zero));
+        }
+        mu0 = max_(mu0, (R(st.ipm_start_dual) * ths) * L::gmax(rd0));
+      }
       MPMPC_UNROLL
       for (int i = 0; i < 3; ++i) s.nu[i] = zero;       // (the equality multipliers of that one iteration: worse than none)
       MPMPC_UNROLL

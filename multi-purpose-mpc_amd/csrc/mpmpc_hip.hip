@@ -428,6 +428,7 @@ static int check_settings(const mpmpc_settings* s) {
     return fail(MPMPC_E_ARG, "polish needs ipm_reg, ipm_tol, as_delta > 0");
   if (s->phase1 != 0 && s->phase1 != 1) return fail(MPMPC_E_ARG, "phase1 must be 0 or 1");
   if (s->reduce != 0 && s->reduce != 1) return fail(MPMPC_E_ARG, "reduce must be 0 or 1");
+  if (!(s->ipm_start_dual >= 0)) return fail(MPMPC_E_ARG, "need ipm_start_dual >= 0");
   if (!(s->ipm_start_mu >= 0) || !(s->ipm_start_slack > 0)) return fail(MPMPC_E_ARG, "need ipm_start_mu >= 0, ipm_start_slack > 0");
   if (!(s->as_add_fraction >= 0) || !(s->as_add_fraction <= 1)) return fail(MPMPC_E_ARG, "need 0 <= as_add_fraction <= 1");
   if (!(s->ipm_diverged > 1) || !(s->phase1_theta > 0) || !(s->phase1_eps > 0))
@@ -475,6 +476,7 @@ void mpmpc_default_settings(mpmpc_settings* s) {
   s->reduce = 1;
   s->ipm_start_slack = 0.1;
   s->ipm_start_mu = 0.01;
+  s->ipm_start_dual = 0.2;
   s->as_add_fraction = 0.25;
 }
 

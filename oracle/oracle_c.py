@@ -30,7 +30,8 @@ class Settings(C.Structure):
                 ("as_refine", C.c_int32), ("as_rounds", C.c_int32), ("cert_tol", C.c_double),
                 ("early_polish", C.c_int32), ("early_scaling", C.c_int32), ("phase1", C.c_int32),
                 ("ipm_diverged", C.c_double), ("phase1_theta", C.c_double), ("phase1_eps", C.c_double),
-                ("ipm_start_slack", C.c_double), ("ipm_start_mu", C.c_double), ("as_add_fraction", C.c_double)]
+                ("ipm_start_slack", C.c_double), ("ipm_start_mu", C.c_double), ("ipm_start_dual", C.c_double),
+                ("as_add_fraction", C.c_double)]
 
 
 class Info(C.Structure):
@@ -51,7 +52,7 @@ def settings(polish=2, **kw):
                  max_iter=4000, check_termination=25, scaling=10, adaptive_rho=1, adaptive_rho_interval=50,
                  adaptive_rho_tolerance=5.0, polish=polish, ipm_max_iter=30, ipm_tol=1e-8, ipm_reg=1e-8,
                  as_delta=1e-9, as_refine=5, as_rounds=4, cert_tol=1e-8, early_polish=1, early_scaling=1,
-                 phase1=1, ipm_diverged=1e2, phase1_theta=1.0, phase1_eps=1e-6, ipm_start_slack=0.1, ipm_start_mu=0.01, as_add_fraction=0.25)
+                 phase1=1, ipm_diverged=1e2, phase1_theta=1.0, phase1_eps=1e-6, ipm_start_slack=0.1, ipm_start_mu=0.01, ipm_start_dual=0.2, as_add_fraction=0.25)
     for k, v in kw.items():
         setattr(s, k, v)
     return s

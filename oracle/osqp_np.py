@@ -89,6 +89,7 @@ class Settings:
                                 # (least-squares phase 1 -> Farkas ray -> PRIMAL_INFEASIBLE) before any full ADMM run
     phase1_theta: float = 1.0   # start value of its slacks / multipliers
     ipm_start_slack: float = 0.1    # the attempt after early_polish ADMM iterations (and the retry from phase 1's
+    ipm_start_dual: float = 0.2     # ... mu0 = max(ipm_start_mu, ipm_start_dual * ipm_start_slack * |P x + q|_inf)
     ipm_start_mu: float = 0.01      # point) starts the interior point CENTRED: slacks max(distance to the bound,
                                     # ipm_start_slack), multipliers ipm_start_mu / slack (row space of the scaled
                                     # problem); ipm_start_mu = 0: warm start from the ADMM multipliers as after a full run
@@ -492,6 +493,8 @@ def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, 
     zl = np.where(L, np.maximum(-y0, theta), 0.0)
     zu = np.where(U, np.maximum(y0, theta), 0.0)
     if mu0 > 0.0:           # centred start: every complementarity product equals mu0, no equality multipliers
+        if st.ipm_start_dual > 0.0:     # multipliers commensurate with the dual residual they will have to balance
+            mu0 = max(mu0, st.ipm_start_dual * theta * _ninf(w.P @ x + w.q))
         nu = np.zeros(m)
         zl = np.where(L, mu0 / sl, 0.0)
         zu = np.where(U, mu0 / su, 0.0)

@@ -46,6 +46,7 @@ typedef struct {
   int32_t early_polish, early_scaling, phase1;
   double ipm_diverged, phase1_theta, phase1_eps;
   double ipm_start_slack, ipm_start_mu;    /* centred start of the early interior-point attempt (see osqp_np.Settings) */
+  double ipm_start_dual;                   /* mu0 = max(ipm_start_mu, ipm_start_dual * ipm_start_slack * |P x + q|_inf) */
   double as_add_fraction;                  /* active-set rounds add only violations >= this fraction of the worst */
 } oracle_settings;
 
@@ -506,6 +507,12 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
   double *dzl = (double*)malloc(sizeof(double) * m), *dzu = (double*)malloc(sizeof(double) * m);
   double *tn = (double*)malloc(sizeof(double) * n), *tm = (double*)malloc(sizeof(double) * m), *yy = (double*)malloc(sizeof(double) * m);
   csc_mul(&w->A, x, Ax);
+  if (mu0 > 0.0 && st->ipm_start_dual > 0.0) {      /* multipliers commensurate with the dual residual of the start */
+    sym_mul(&w->P, x, tn);
+    double r0 = 0.0;
+    for (int j = 0; j < n; ++j) r0 = dmax(r0, fabs(tn[j] + w->q[j]));
+    mu0 = dmax(mu0, st->ipm_start_dual * theta * r0);
+  }
   int nb = 0;
   for (int r = 0; r < m; ++r) {
     nu[r] = cl->eq[r] ? y[r] : 0.0;
