@@ -1584,7 +1584,8 @@ struct Solver {
         for (int i = 0; i < NQ; ++i) nreq[i] = -rp[i];
         MPMPC_TICK_BEGIN(12);
         kkt_solve_t<LAY>(rhs, nreq, dx, dnu);
-        if constexpr (SOFT) {
+        if (SOFT && pass == 1) {
+          // (the predictor only supplies the centring parameter and the second-order term: not refined)
           // One refinement step against the UN-regularised Newton matrix (phase 1 only: it is rare, and what it is
           // asked for is a clean ray - |A'y| / |y| drops from ~1e-6 to ~1e-9, far below the margin phase1_eps asks
           // of the support; the optimum of the hard problem is made by the refining active-set solve instead).
