@@ -76,11 +76,13 @@ typedef struct {
   int32_t adaptive_rho, adaptive_rho_interval;
   double adaptive_rho_tolerance;
   int32_t polish;   /* 0: ADMM only (stock OSQP behaviour); 2: interior-point refine + active-set polish + certificate */
-  int32_t ipm_max_iter;
-  double ipm_tol, ipm_reg;
-  double as_delta;
-  int32_t as_refine, as_rounds;
-  double cert_tol;
+  int32_t ipm_max_iter;  /* interior-point iterations per attempt (30) */
+  double ipm_tol, ipm_reg; /* the interior point stops at residual, complementarity < ipm_tol (1e-8: it only has to identify the
+                            active set, which it reads off its last step; a failed active-set attempt continues it to
+                            ipm_tol x 1e-4); primal / dual regularisation of its Newton systems (1e-8) */
+  double as_delta;       /* regularisation of the active-set KKT solve, removed by as_refine refinement steps (1e-10, 5) */
+  int32_t as_refine, as_rounds;   /* ...; primal-dual active-set rounds per attempt (4) */
+  double cert_tol;       /* KKT certificate (unscaled problem): primal violation, stationarity, complementarity <= 1e-8 */
   int32_t early_polish; /* > 0: try the polish after this many ADMM iterations; instances it cannot certify
                            run the full ADMM (to max_iter / termination / infeasibility) and are polished
                            again.  0: polish only after ADMM has terminated (OSQP's order). */
