@@ -18,6 +18,7 @@ BENCH_ARGS="--steps 5 --warmup 1" prof pmc_fetch --pmc FETCH_SIZE
 BENCH_ARGS="--steps 5 --warmup 1" prof pmc_write --pmc WRITE_SIZE
 BENCH_ARGS="--steps 5 --warmup 1" prof pmc_sq1 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 BENCH_ARGS="--steps 5 --warmup 1" prof pmc_sq2 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_FLAT
+BENCH_ARGS="--config 3 --steps 20 --warmup 2" prof trace_cfg3 --kernel-trace --stats
 BENCH_ARGS="--config 4 --steps 20 --warmup 2" prof trace_cfg4 --kernel-trace --stats
 BENCH_ARGS="--config 5 --steps 20 --warmup 2" prof trace_cfg5 --kernel-trace --stats
 BENCH_ARGS="--batch 65536 --steps 5 --warmup 1" prof trace_b65536 --kernel-trace --stats

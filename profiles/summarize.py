@@ -18,7 +18,7 @@ for name in ("bench_cfg2.json", "bench_cfg3.json", "bench_cfg4.json", "bench_cfg
 if os.path.exists(os.path.join(O, "trace_b65536.json")):
     shutil.copy(os.path.join(O, "trace_b65536.json"), os.path.join(P, "bench_cfg2_b65536.json"))
 for src, dst in (("trace", "bench_cfg2_kernel_stats.csv"), ("trace_b65536", "bench_cfg2_b65536_kernel_stats.csv"),
-                 ("trace_cfg4", "bench_cfg4_kernel_stats.csv"), ("trace_cfg5", "bench_cfg5_kernel_stats.csv")):
+                 ("trace_cfg3", "bench_cfg3_kernel_stats.csv"), ("trace_cfg4", "bench_cfg4_kernel_stats.csv"), ("trace_cfg5", "bench_cfg5_kernel_stats.csv")):
     fs = glob.glob(os.path.join(O, src, "*", "*kernel_stats.csv"))
     if fs:                                   # gpurun merges runs into the same directory: newest wins
         shutil.copy(max(fs, key=os.path.getmtime), os.path.join(P, dst))
