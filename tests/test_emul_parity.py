@@ -304,6 +304,24 @@ def test_second_polish_attempt_from_phase1s_point(emu, track):
     np.testing.assert_allclose(dflt.z[0], ref.x, atol=1e-7)
 
 
+def test_controls_vs_reference_counts_only_certified_equal_objective_points_as_alternatives(emu, track):
+    """The comparison helper of the full-batch parity tests: identical answers -> nothing to report; a reference whose
+    control is off and whose plan is NOT an optimum (objective differs, no certificate) is a disagreement, not an
+    "alternative optimum"."""
+    sc = scenarios.make(4, track, B=48)
+    cfg = T.stock_config(sc.N, sc.weights)
+    qp = emu.assemble(cfg, track, _inputs(sc))
+    sol = emu.solve(cfg, mpmpc.default_settings(), qp, G=64)
+    ref = dict(status=sol.status.copy(), u0=sol.u0.copy(), z=sol.z.copy(), y=sol.y.copy())
+    worst, alt = T.controls_vs_reference(qp, sc.N, sol, ref, 1e-6)
+    assert worst == 0.0 and alt.size == 0
+    i = int(np.flatnonzero(sol.status == 1)[0])
+    ref["u0"][i, 1] += 1e-3
+    ref["z"][i, 3 * (sc.N + 1) + 1] += 1e-3            # kappa_0 of the reference plan moved: no longer a KKT point
+    worst, alt = T.controls_vs_reference(qp, sc.N, sol, ref, 1e-6)
+    assert alt.size == 0 and worst >= 0.9e-3
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # full terminal weight QN (src/MPC.py:150,154 use the whole matrix)
 # ---------------------------------------------------------------------------------------------------------------
