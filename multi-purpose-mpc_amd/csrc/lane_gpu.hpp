@@ -172,7 +172,7 @@ struct LaneGpu {
   // "cold" per-lane storage in LDS (one wavefront per block, slot-major: a wave access is 64
   // consecutive doubles, conflict free) for values only needed at termination checks and in the
   // certificate, so that they do not occupy registers - or worse, scratch - inside the loops
-  static constexpr int cold_slots = 66;          // 28 KB per wave
+  static constexpr int cold_slots = 66;          // 66 x 512 B = 33 KB per wave
   static __device__ __forceinline__ double* cold() {
     __shared__ double buf[cold_slots * 64];
     return buf;

@@ -259,6 +259,7 @@ __global__ __launch_bounds__(64) void mpmpc_free_segments_kernel(MapView map, Pa
   __shared__ int cells[COR_CELL_CAP];
   __shared__ unsigned char occ[COR_CELL_CAP];
   __shared__ int s_n;
+  __shared__ double seg[4 * COR_MAXSEG];      // lane 0's segment list (in LDS: a per-lane array would live in scratch)
   const int i = blockIdx.x, lane = threadIdx.x;
   int ux, uy, lx, ly;
   cor_w2m(map, bub[2 * i], bub[2 * i + 1], ux, uy);
@@ -277,7 +278,6 @@ __global__ __launch_bounds__(64) void mpmpc_free_segments_kernel(MapView map, Pa
     }
     __syncthreads();
     if (lane != 0) return;
-    double seg[4 * COR_MAXSEG];
     cnt = cor_scan_cells(map, ux, uy, lx, ly, min_width, n, [&](int c, int& x, int& y) { cor_unpack_cell(cells[c], x, y); },
                          [&](int c) { return occ[c] != 0; }, seg);
     for (int k = 0; k < 4 * COR_MAXSEG; ++k) segs[(long)i * 4 * COR_MAXSEG + k] = (cnt > 0 && k < 4 * cnt) ? seg[k] : 0.0;

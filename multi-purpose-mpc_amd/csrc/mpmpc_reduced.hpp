@@ -1,0 +1,449 @@
+// Reduced-NATIVE solver of the batch path: a lane never holds the 3-state problem.
+//
+// Where the reduction of mpmpc_core.hpp applies (reducible(): the time state t carries neither cost nor bound, e_psi has
+// no bound, R[0] > 0 - the reference's own tracking weights, src/simulation.py:101-111) the QP of src/MPC.py:61-155
+// separates EXACTLY into
+//     v_k = clip(v_ref_k, umin[0], min(umax[0], vmax_k))     closed form, in the unscaled problem, done at load time
+//     t_k                                                      roll-forward through its own equality rows, after the solve
+//     the QP in (e_y, e_psi, kappa)                            2 x 2 blocks, 2 equality rows and 3 entries per stage
+// The general kernels (Solver::run) assemble, scale and start on the FULL problem and only run the polish on the reduced
+// one - they carry the OSQP iteration, phase 1 and the 5-entry problem through the whole solve: 440-512 registers, a
+// 120 KB kernel, one wavefront per SIMD.  This solver keeps ONLY the reduced problem: own Ruiz pass on its 3 columns /
+// 2 + 3 rows, own start (OSQP's first iterate of the reduced system from the 2 x 2 factorisation), the interior point
+// and the active-set rounds of Solver (ipm<LAY_RED / LAY_REDSPLIT>, active_set<LAY_RED>: the same code), a KKT certificate
+// of the reduced problem in unscaled units - the separated parts satisfy their KKT rows by construction: the speed's
+// multiplier is -(R0 v + q_v) with the sign its clip gives it, the time rows hold to rounding with zero multipliers, and
+// tests/ check every answer against the FULL problem's KKT system with numpy (mpmpc_testlib.kkt_batch).
+// What it cannot certify - infeasible and very hard instances - keeps status UNSOLVED: the launcher appends it to the
+// tail list, and the general one-instance-per-wave kernel (mode 2: phase 1, full OSQP run) decides it.
+//
+// Replaces, per instance: MPC._init_problem + osqp setup/solve (src/MPC.py:61-159,183) for the default settings.
+#pragma once
+#include "mpmpc_core.hpp"
+
+namespace mpmpc {
+
+// May the batch path run this solver?  (the launcher and the emulation ask the same question)
+inline bool reduced_native(const mpmpc_config& c, const mpmpc_settings& st) {
+  return st.native != 0 && reducible(c, st) && st.early_polish == 1 && st.max_iter > 1 && st.ipm_start_mu > 0.0 &&
+         st.early_scaling >= 0 && st.scaling > 0;
+}
+
+template <class L>
+struct ReducedSolver : Solver<L, false, true, false> {
+  using S = Solver<L, false, true, false>;
+  using R = typename L::real;
+  using Mk = typename L::mask;
+  using I = typename L::ival;
+  using S::N; using S::n_inst; using S::off_; using S::vx; using S::vu; using S::first; using S::down_chain; using S::is_mid;
+  using S::is_end; using S::vxc; using S::sU; using S::val3; using S::bU; using S::live; using S::a; using S::b; using S::mI;
+  using S::leq; using S::status; using S::iters; using S::ipm_iters; using S::polished; using S::pri_res; using S::dua_res;
+  static constexpr bool kSplit = S::kSplit;
+  static constexpr int LAY_RED = S::LAY_RED, LAY_REDSPLIT = S::LAY_REDSPLIT;
+  static constexpr int LAY_IP = kSplit ? LAY_REDSPLIT : LAY_RED;
+  static constexpr int EI = kSplit ? 2 : 3;                    // entries per lane in the interior point's layout
+  using Box3 = typename S::template BoxT<LAY_RED>;
+  using BoxI = typename S::template BoxT<LAY_IP>;
+  using IpmI = typename S::template IpmT<LAY_IP>;
+
+  // ---- cold storage (LDS), 512 B per slot: what only setup, the certificate and the store need
+  enum { C_D = 0, C_E = 3, C_C = 5, C_LOE = 6, C_HIE = 7, C_LOK = 8, C_HIK = 9, C_V = 10, C_LAMV = 11, C_A20 = 12, C_BV = 13, C_BEQ2 = 14,
+         C_G = 15, C_PI = 18, COLD_USED = 19 };
+  static_assert(COLD_USED <= L::cold_slots, "lane backend has too few cold slots");
+
+  // ---- the reduced problem, scaled; entries e = (e_y, e_psi, kappa)
+  R P3[3], Q3[3];
+  R x3[3];               // start point, then the certified point (scaled)
+  R nu2[2], lam3[3];     // multipliers of the certified point (scaled)
+  Mk val[3];             // entry exists: (vx, vx, vu)
+  Mk solvable, empty;    // instance exists and no box of it is empty; instance exists and a box is empty
+
+  // ================================================================================ setup: load + Ruiz + cold
+  MPMPC_HD void setup(const R* fields, int B, const I& inst, const I& k, int N_, const SolverParams& st) {
+    N = N_;
+    n_inst = B;
+    live = inst < B;
+    vx = live & within_(k, 0, N);
+    vu = live & within_(k, 0, N - 1);
+    first = (k == 0);
+    {
+      const int C = L::split;
+      off_ = lane_offset(L::group, C, N);
+      I kl = k + off_;
+      down_chain = (kl >= C);
+      is_mid = (kl == C - 1);
+      is_end = (kl == 2 * C - 1);
+      I kc = seli(down_chain & (kl < 2 * C), kl * (-1) + (3 * C - 1), kl) - off_;
+      vxc = live & within_(kc, 0, N);
+      if constexpr (kSplit) {
+        sU = (kl >= 32);
+        Mk vU = live & within_(kl, 32 + off_, N + 31 + off_);
+        val3[0] = selb(sU, vU, vx); val3[1] = selb(sU, vU, vx); val3[2] = vx & !sU;
+      }
+    }
+    val[0] = vx; val[1] = vx; val[2] = vu;
+    auto fld = [&](int f, double dflt) { return sel(vx, fields[f], R(dflt)); };
+    const R zero(0.0), onec(1.0);
+    // ---- the separated parts, in the UNSCALED problem
+    const R lo_v = max_(fld(F_LO + 3, -INFTY), R(-INFTY)), hi_v = min_(fld(F_HI + 3, INFTY), R(INFTY));
+    const R p_v = fld(F_P + 3, 1.0), q_v = fld(F_Q + 3, 0.0);
+    R v = -q_v / p_v;                                   // minimiser of 1/2 p v^2 + q v  (= v_ref: src/MPC.py:155)
+    v = sel((hi_v < R(INF_BOUND)) & (v > hi_v), hi_v, v);
+    v = sel((lo_v > R(-INF_BOUND)) & (v < lo_v), lo_v, v);
+    v = sel(vu, v, zero);
+    L::cold_put(C_V, v);
+    L::cold_put(C_LAMV, sel(vu, -fma_(p_v, v, q_v), zero));        // multiplier of the speed's box row
+    L::cold_put(C_A20, fld(F_A20, 0.0));
+    L::cold_put(C_BV, fld(F_B20, 0.0) * v);
+    L::cold_put(C_BEQ2, fld(F_BEQ + 2, 0.0));
+    // ---- the (e_y, e_psi, kappa) problem
+    const R lo_e = max_(fld(F_LO + 0, -INFTY), R(-INFTY)), hi_e = min_(fld(F_HI + 0, INFTY), R(INFTY));
+    const R lo_k = max_(fld(F_LO + 4, -INFTY), R(-INFTY)), hi_k = min_(fld(F_HI + 4, INFTY), R(INFTY));
+    L::cold_put(C_LOE, lo_e); L::cold_put(C_HIE, hi_e); L::cold_put(C_LOK, lo_k); L::cold_put(C_HIK, hi_k);
+    {
+      // an EMPTY box makes the QP trivially infeasible (Solver::run has the same rule): reported at once, never solved
+      R gap = max_(max_(sel(vx, lo_e - hi_e, zero), sel(vu, lo_k - hi_k, zero)), sel(vu, lo_v - hi_v, zero));
+      gap = L::gmax(gap);
+      empty = live & (gap > zero);
+      solvable = live & !empty;
+      pri_res = gap;
+    }
+    const R ds = fld(F_DS, 0.0), one = sel(vu, onec, zero);
+    a[0] = one; a[1] = ds; a[2] = fld(F_A10, 0.0); a[3] = one;
+    b[0] = ds;
+    mI[0] = mI[1] = R(-1.0);
+    P3[0] = fld(F_P + 0, 1.0); P3[1] = fld(F_P + 1, 1.0); P3[2] = fld(F_P + 4, 1.0);
+    Q3[0] = fld(F_Q + 0, 0.0); Q3[1] = fld(F_Q + 1, 0.0); Q3[2] = fld(F_Q + 4, 0.0);
+    R D3[3] = {onec, onec, onec}, G3[3] = {onec, onec, onec}, Eb[3] = {onec, onec, onec}, E2[2] = {onec, onec}, c3(1.0);
+    // OSQP scale_data() on the reduced problem: Ruiz passes over the columns (e_y, e_psi, kappa) and the rows (2 dynamics
+    // rows, 3 box rows), each with the cost normalisation
+    const int passes = st.early_scaling > 0 && st.early_scaling < st.scaling ? st.early_scaling : st.scaling;
+    const R n_total(double(3 * N + 2));
+    for (int it = 0; it < passes; ++it) {
+      R cn[3], rn[2], r_own[2];
+      cn[0] = max_(max_(max_(abs_(P3[0]), abs_(mI[0])), max_(abs_(a[0]), abs_(a[2]))), abs_(G3[0]));
+      cn[1] = max_(max_(max_(abs_(P3[1]), abs_(mI[1])), max_(abs_(a[1]), abs_(a[3]))), abs_(G3[1]));
+      cn[2] = max_(max_(abs_(P3[2]), abs_(b[0])), abs_(G3[2]));
+      r_own[0] = max_(abs_(a[0]), abs_(a[1]));
+      r_own[1] = max_(max_(abs_(a[2]), abs_(a[3])), abs_(b[0]));
+      R Dt[3], Et[2], Etb[3], Etd[2];
+      MPMPC_UNROLL
+      for (int i = 0; i < 2; ++i) {
+        rn[i] = max_(abs_(mI[i]), L::up(r_own[i]));
+        Et[i] = R(1.0) / sqrt_(S::limit(rn[i]));
+        Etd[i] = L::down(Et[i]);
+      }
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) {
+        Dt[e] = R(1.0) / sqrt_(S::limit(cn[e]));
+        Etb[e] = R(1.0) / sqrt_(S::limit(abs_(G3[e])));
+        P3[e] = (Dt[e] * P3[e]) * Dt[e];
+        G3[e] = (Etb[e] * G3[e]) * Dt[e];
+        Q3[e] = Dt[e] * Q3[e];
+        D3[e] = D3[e] * Dt[e];
+        Eb[e] = Eb[e] * Etb[e];
+      }
+      MPMPC_UNROLL
+      for (int i = 0; i < 2; ++i) { mI[i] = (Et[i] * mI[i]) * Dt[i]; E2[i] = E2[i] * Et[i]; }
+      a[0] = (Etd[0] * a[0]) * Dt[0]; a[1] = (Etd[0] * a[1]) * Dt[1];
+      a[2] = (Etd[1] * a[2]) * Dt[0]; a[3] = (Etd[1] * a[3]) * Dt[1];
+      b[0] = (Etd[1] * b[0]) * Dt[2];
+      R s(0.0), mq(0.0);
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) {
+        s = s + sel(val[e], abs_(P3[e]), zero);
+        mq = max_(mq, sel(val[e], abs_(Q3[e]), zero));
+      }
+      R ct = L::gsum(s) / n_total;
+      const R nq = S::limit(L::gmax(mq));
+      ct = R(1.0) / S::limit(max_(ct, nq));
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) { P3[e] = P3[e] * ct; Q3[e] = Q3[e] * ct; }
+      c3 = c3 * ct;
+    }
+    leq[0] = E2[0] * fld(F_BEQ + 0, 0.0);
+    leq[1] = E2[1] * fld(F_BEQ + 1, 0.0);
+    MPMPC_UNROLL
+    for (int e = 0; e < 3; ++e) { L::cold_put(C_D + e, D3[e]); L::cold_put(C_G + e, G3[e]); }
+    L::cold_put(C_E, E2[0]); L::cold_put(C_E + 1, E2[1]);
+    L::cold_put(C_C, c3);
+    // ---- OSQP's FIRST iterate of the reduced system from its cold start (Solver::reduced_start): per-row step sizes by
+    // constraint type, x = alpha KKT^-1 (-q); for the pinned entries the multiplier of that iterate (the interior
+    // point starts its pin multipliers there)
+    const R sigma(st.sigma), alpha(st.alpha), rho(st.rho), rho_eq = R(RHO_EQ_FACTOR) * rho, rinv_eq = R(1.0) / rho_eq;
+    const R lo_r[3] = {lo_e, R(-INFTY), lo_k}, hi_r[3] = {hi_e, R(INFTY), hi_k};
+    R h3[3], rbv[3], lbs[3];
+    MPMPC_UNROLL
+    for (int e = 0; e < 3; ++e) {
+      lbs[e] = Eb[e] * lo_r[e];
+      const R ubs = Eb[e] * hi_r[e];
+      const Mk freerow = (lbs[e] < R(-INF_BOUND)) & (ubs > R(INF_BOUND));
+      const Mk eqrow = (ubs - lbs[e]) < R(RHO_TOL);
+      rbv[e] = sel(freerow, R(RHO_MIN), sel(eqrow, rho_eq, rho));
+      h3[e] = R(1.0) / (P3[e] + sigma + (G3[e] * G3[e]) * rbv[e]);
+    }
+    this->template factor_t<LAY_RED>(h3, rinv_eq);
+    R rx[3] = {-Q3[0], -Q3[1], -Q3[2]}, req[2] = {zero, zero}, xt[3], nu[2];
+    this->template kkt_solve_t<LAY_RED>(rx, req, xt, nu);
+    MPMPC_UNROLL
+    for (int e = 0; e < 3; ++e) {
+      x3[e] = alpha * xt[e];
+      // pinned entry (lower = upper bound): zr - zn = alpha g xt - lb, multiplier rb (zr - zn), in variable space x g
+      const Mk pn = (lo_r[e] > R(-INF_BOUND)) & (hi_r[e] < R(INF_BOUND)) & ((hi_r[e] - lo_r[e]) <= R(1e-12) * max_(R(1.0), abs_(lo_r[e])));
+      L::cold_put(C_PI + e, sel(pn & val[e], (rbv[e] * (alpha * (G3[e] * xt[e]) - lbs[e])) * G3[e], zero));
+    }
+    L::fence();
+  }
+
+  // ================================================================================ layouts
+  // 3 entries per lane (e_y, e_psi, kappa)  <->  the interior point's layout (split: lane k keeps (e_y, e_psi), lane
+  // k + 32 keeps (kappa, -); `fill` = value of the entry the upper lanes do not have)
+  MPMPC_HD void to_ip(const R v[3], R* o, double fill = 0.0) const {
+    if constexpr (kSplit) {
+      o[0] = sel(sU, L::from_lower(v[2]), v[0]);
+      o[1] = sel(sU, R(fill), v[1]);
+    } else {
+      o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+    }
+  }
+  MPMPC_HD void from_ip(const R* v, R o[3]) const {
+    if constexpr (kSplit) {
+      o[0] = v[0]; o[1] = v[1]; o[2] = L::from_upper(v[0]);
+    } else {
+      o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+    }
+  }
+  MPMPC_HD void mask_to_ip(const Mk m[3], Mk* o) const {
+    if constexpr (kSplit) {
+      R v[3], w[2];
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) v[e] = sel(m[e], R(1.0), R(0.0));
+      to_ip(v, w);
+      o[0] = w[0] > R(0.5); o[1] = w[1] > R(0.5);
+    } else {
+      o[0] = m[0]; o[1] = m[1]; o[2] = m[2];
+    }
+  }
+  MPMPC_HD void mask_from_ip(const Mk* m, Mk o[3]) const {
+    if constexpr (kSplit) {
+      R w[2] = {sel(m[0], R(1.0), R(0.0)), sel(m[1], R(1.0), R(0.0))}, v[3];
+      from_ip(w, v);
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) o[e] = v[e] > R(0.5);
+    } else {
+      o[0] = m[0]; o[1] = m[1]; o[2] = m[2];
+    }
+  }
+
+  // ================================================================================ certificate (reduced problem, unscaled)
+  MPMPC_HD Mk certificate3(const R xs[3], const R nus[2], const R lam[3], double tol, R& prim, R& stat) const {
+    const R zero(0.0);
+    R Ax[2], At[3];
+    this->template Aeq_mul_t<LAY_RED>(xs, Ax);
+    this->template AeqT_mul_t<LAY_RED>(nus, At);
+    const R cinv = R(1.0) / L::cold_get(C_C);
+    R pv(0.0), sv(0.0), cv(0.0);
+    MPMPC_UNROLL
+    for (int i = 0; i < 2; ++i) pv = max_(pv, sel(vx, abs_((Ax[i] - leq[i]) / L::cold_get(C_E + i)), zero));
+    Mk bad = L::mfalse();
+    MPMPC_UNROLL
+    for (int e = 0; e < 3; ++e) {
+      const R De = L::cold_get(C_D + e);
+      const R xu = De * xs[e];
+      const R lo0 = e == 0 ? L::cold_get(C_LOE) : (e == 2 ? L::cold_get(C_LOK) : R(-INFTY));
+      const R hi0 = e == 0 ? L::cold_get(C_HIE) : (e == 2 ? L::cold_get(C_HIK) : R(INFTY));
+      pv = max_(pv, sel(val[e], max_(max_(lo0 - xu, xu - hi0), zero), zero));
+      const R rd = fma_(P3[e], xs[e], Q3[e]) + At[e] + lam[e];
+      sv = max_(sv, sel(val[e], abs_(rd / De) * cinv, zero));
+      const R yu = (lam[e] / De) * cinv;                  // multiplier of the unscaled box row
+      const Mk fu = hi0 < R(INF_BOUND), fl = lo0 > R(-INF_BOUND);
+      const R cu = sel(fu, max_(yu, zero) * abs_(hi0 - xu), sel(yu > zero, R(1e300), zero));
+      const R cl = sel(fl, max_(-yu, zero) * abs_(xu - lo0), sel(yu < zero, R(1e300), zero));
+      cv = max_(cv, sel(val[e], max_(cu, cl), zero));
+      bad = bad | (val[e] & !((abs_(xs[e]) < R(1e300)) & (abs_(lam[e]) < R(1e300))));     // a NaN must never pass
+    }
+    MPMPC_UNROLL
+    for (int i = 0; i < 2; ++i) bad = bad | (vx & !(abs_(nus[i]) < R(1e300)));
+    bad = L::gany(bad);
+    prim = L::gmax(pv);
+    stat = L::gmax(sv);
+    cv = L::gmax(cv);
+    return (prim <= R(tol)) & (stat <= R(tol)) & (cv <= R(tol)) & !bad;
+  }
+
+  // ================================================================================ the solve
+  MPMPC_HD void run(const R* fields, int B, const I& inst, const I& k, int N_, const SolverParams& st) {
+    MPMPC_TICK_BEGIN(0);
+    setup(fields, B, inst, k, N_, st);
+    MPMPC_TICK_END(0);
+    const R zero(0.0), one(1.0);
+    status = I(MPMPC_UNSOLVED);
+    iters = I(1);
+    ipm_iters = I(0);
+    polished = I(0);
+    dua_res = zero;
+    MPMPC_UNROLL
+    for (int e = 0; e < 3; ++e) lam3[e] = zero;
+    nu2[0] = nu2[1] = zero;
+    this->act_bits = I(0);
+    Mk todo = solvable;
+    if (L::wany(todo)) {
+      // ---- box rows in the scaled variable space:  g x in [lb, ub]  <=>  x in [lo, hi] = [lo_raw, hi_raw] / D
+      Box3 b3;
+      {
+        const R lo_r[3] = {L::cold_get(C_LOE), R(-INFTY), L::cold_get(C_LOK)}, hi_r[3] = {L::cold_get(C_HIE), R(INFTY), L::cold_get(C_HIK)};
+        MPMPC_UNROLL
+        for (int e = 0; e < 3; ++e) {
+          const R iD = R(1.0) / L::cold_get(C_D + e);
+          const Mk fl = lo_r[e] > R(-INF_BOUND), fu = hi_r[e] < R(INF_BOUND);
+          const Mk pn = fl & fu & ((hi_r[e] - lo_r[e]) <= R(1e-12) * max_(one, abs_(lo_r[e])));
+          b3.lo[e] = lo_r[e] * iD;
+          b3.hi[e] = hi_r[e] * iD;
+          b3.pin[e] = pn & val[e];
+          b3.Lm[e] = fl & !pn & val[e];
+          b3.Um[e] = fu & !pn & val[e];
+        }
+      }
+      // ---- centred start of the interior point (Solver::polish, early attempt): slacks max(distance to the bound,
+      // ipm_start_slack in row space), multipliers mu0 / slack, no equality multipliers
+      R sl[3], su[3], zl[3], zu[3], pi[3];
+      {
+        const R ths(st.ipm_start_slack);
+        R mu0(st.ipm_start_mu);
+        if (st.ipm_start_dual > 0.0) {
+          R rd0(0.0);
+          MPMPC_UNROLL
+          for (int e = 0; e < 3; ++e) rd0 = max_(rd0, sel(val[e], abs_(fma_(P3[e], x3[e], Q3[e])), zero));
+          mu0 = max_(mu0, (R(st.ipm_start_dual) * ths) * L::gmax(rd0));
+        }
+        MPMPC_UNROLL
+        for (int e = 0; e < 3; ++e) {
+          const R fl = ths / L::cold_get(C_G + e);
+          sl[e] = sel(b3.Lm[e], max_(x3[e] - b3.lo[e], fl), one);
+          su[e] = sel(b3.Um[e], max_(b3.hi[e] - x3[e], fl), one);
+          zl[e] = sel(b3.Lm[e], mu0 / sl[e], zero);
+          zu[e] = sel(b3.Um[e], mu0 / su[e], zero);
+          pi[e] = L::cold_get(C_PI + e);
+        }
+      }
+      // ---- the interior point's own layout
+      BoxI bi;
+      IpmI si;
+      R pp[EI], qq[EI];
+      Mk vm[EI];
+      if constexpr (kSplit) {
+        bU[0] = sel(sU, L::from_lower(b[0]), zero);
+        bU[1] = zero;
+        vm[0] = val3[0]; vm[1] = val3[2];
+      } else {
+        vm[0] = val[0]; vm[1] = val[1]; vm[2] = val[2];
+      }
+      to_ip(b3.lo, bi.lo); to_ip(b3.hi, bi.hi); to_ip(P3, pp, 1.0); to_ip(Q3, qq);
+      mask_to_ip(b3.Lm, bi.Lm); mask_to_ip(b3.Um, bi.Um); mask_to_ip(b3.pin, bi.pin);
+      to_ip(x3, si.x); to_ip(sl, si.sl, 1.0); to_ip(su, si.su, 1.0); to_ip(zl, si.zl); to_ip(zu, si.zu); to_ip(pi, si.pi);
+      si.nu[0] = si.nu[1] = zero;
+      MPMPC_UNROLL
+      for (int e = 0; e < EI; ++e) {
+        si.tL[e] = bi.Lm[e] & (si.zl[e] > si.sl[e]);
+        si.tU[e] = bi.Um[e] & (si.zu[e] > si.su[e]);
+      }
+      double tol = st.ipm_tol;
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        MPMPC_TICK_BEGIN(4);
+        const Mk conv = this->template ipm<LAY_IP>(bi, si, pp, qq, vm, st, tol, todo);
+        MPMPC_TICK_END(4);
+        // active-set guess: the indicators of the interior point's last step
+        Mk gL[EI], gU[EI], aL[3], aU[3];
+        MPMPC_UNROLL
+        for (int e = 0; e < EI; ++e) { gL[e] = bi.Lm[e] & si.tL[e]; gU[e] = bi.Um[e] & si.tU[e]; }
+        mask_from_ip(gL, aL); mask_from_ip(gU, aU);
+        MPMPC_UNROLL
+        for (int e = 0; e < 3; ++e) { aL[e] = b3.Lm[e] & aL[e]; aU[e] = b3.Um[e] & aU[e] & !aL[e]; }
+        R xa[3], la[3] = {zero, zero, zero}, na[2] = {si.nu[0], si.nu[1]};
+        from_ip(si.x, xa);
+        MPMPC_TICK_BEGIN(5);
+        const double frac = attempt == 0 ? st.as_add_fraction : (st.as_add_fraction > 0.5 ? st.as_add_fraction : 0.5);
+        const Mk okm = this->template active_set<LAY_RED>(b3, P3, Q3, val, aL, aU, xa, na, la, st, todo & conv, frac);
+        MPMPC_TICK_END(5);
+        R prim, stat;
+        MPMPC_TICK_BEGIN(6);
+        const Mk cert = certificate3(xa, na, la, st.cert_tol, prim, stat);
+        MPMPC_TICK_END(6);
+        const Mk good = todo & conv & okm & cert;
+        MPMPC_UNROLL
+        for (int e = 0; e < 3; ++e) { x3[e] = sel(good, xa[e], x3[e]); lam3[e] = sel(good, la[e], lam3[e]); }
+        nu2[0] = sel(good, na[0], nu2[0]); nu2[1] = sel(good, na[1], nu2[1]);
+        pri_res = sel(good, prim, pri_res);
+        dua_res = sel(good, stat, dua_res);
+        status = seli(good, I(MPMPC_SOLVED), status);
+        polished = seli(good, I(1), polished);
+        todo = todo & conv & !good;          // a diverged interior-point run is not retried
+        if (!L::wany(todo)) break;
+        tol *= 1e-4;
+      }
+    }
+    // empty box: infeasible, zero ray, the width of the gap in resid[0] (set in setup)
+    status = seli(empty, I(MPMPC_PRIMAL_INFEASIBLE), status);
+    const Mk keepx = live & (status == MPMPC_SOLVED);
+    MPMPC_UNROLL
+    for (int e = 0; e < 3; ++e) { x3[e] = sel(keepx, x3[e], zero); lam3[e] = sel(keepx, lam3[e], zero); }
+    nu2[0] = sel(keepx, nu2[0], zero); nu2[1] = sel(keepx, nu2[1], zero);
+    pri_res = sel(live & !keepx & !empty, zero, pri_res);
+  }
+
+  // ================================================================================ output
+  // z in the reference's ordering, u0 = (v_0, delta_0), multipliers in the reference's row order; the separated parts
+  // (v, its multiplier, the roll-forward of t) are put together here, in the unscaled problem
+  MPMPC_HD void store(const I& inst, const I& k, double wheelbase, double* z, double* u0, int* st_out, int* it_out,
+                      double* resid, double* y) const {
+    const int n = 5 * N + 3, m = 8 * N + 6;
+    const R zero(0.0);
+    const Mk ok = live & (status == MPMPC_SOLVED);
+    const R cinv = R(1.0) / L::cold_get(C_C);
+    R D3[3];
+    MPMPC_UNROLL
+    for (int e = 0; e < 3; ++e) D3[e] = L::cold_get(C_D + e);
+    const R e_y = D3[0] * x3[0], e_psi = D3[1] * x3[1], kap = D3[2] * x3[2];
+    const R v = sel(ok, L::cold_get(C_V), zero), lam_v = sel(ok, L::cold_get(C_LAMV), zero);
+    // t: row 2 of equality block k is  -t_k + a20 e_y_{k-1} + t_{k-1} + b20 v_{k-1} = beq2_k  (block 0: -t_0 = -x0[2]),
+    // a running sum along the stages
+    const R drive = fma_(L::cold_get(C_A20), e_y, L::cold_get(C_BV)), beq2 = L::cold_get(C_BEQ2);
+    const R t0 = -beq2;
+    R t = t0;
+    for (int it = 0; it < N; ++it) t = sel(first, t0, L::up(t + drive) - beq2);
+    t = sel(ok & vx, t, zero);
+    const R E2[2] = {L::cold_get(C_E), L::cold_get(C_E + 1)};
+    L::fence();
+    if (z) {
+      L::rows(z, n, inst, n_inst, [&](auto put) {
+        put(k * 3, vx, e_y);
+        put(k * 3 + 1, vx, e_psi);
+        put(k * 3 + 2, vx, t);
+        put(k * 2 + (3 * (N + 1)), vu, v);
+        put(k * 2 + (3 * (N + 1) + 1), vu, kap);
+      });
+    }
+    if (y) {
+      L::rows(y, m, inst, n_inst, [&](auto put) {
+        put(k * 3, vx, (E2[0] * nu2[0]) * cinv);
+        put(k * 3 + 1, vx, (E2[1] * nu2[1]) * cinv);
+        put(k * 3 + 2, vx, zero);
+        put(k * 3 + (3 * (N + 1)), vx, (lam3[0] / D3[0]) * cinv);
+        put(k * 3 + (3 * (N + 1) + 1), vx, (lam3[1] / D3[1]) * cinv);
+        put(k * 3 + (3 * (N + 1) + 2), vx, zero);
+        put(k * 2 + (6 * (N + 1)), vu, lam_v);
+        put(k * 2 + (6 * (N + 1) + 1), vu, (lam3[2] / D3[2]) * cinv);
+      });
+    }
+    const Mk lead = live & first;
+    if (u0) {
+      L::store(u0, inst * 2, lead, v);
+      L::store(u0, inst * 2 + 1, lead, atan_(kap * R(wheelbase)));        // src/MPC.py:188-189
+    }
+    if (st_out) L::storei(st_out, inst, lead, status);
+    if (it_out) { L::storei(it_out, inst * 2, lead, iters); L::storei(it_out, inst * 2 + 1, lead, ipm_iters); }
+    if (resid) { L::store(resid, inst * 2, lead, pri_res); L::store(resid, inst * 2 + 1, lead, dua_res); }
+  }
+};
+
+}  // namespace mpmpc

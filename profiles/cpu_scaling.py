@@ -4,7 +4,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for d in ("multi-purpose-mpc_amd", "oracle", "tests"):
+for d in ("multi-purpose-mpc_amd", "oracle", "tests", "."):
     sys.path.insert(0, os.path.join(ROOT, d))
 import oracle_c     # noqa: E402
 import scenarios    # noqa: E402

@@ -1,7 +1,7 @@
 """Latency of one controller instance (the drop-in case: MPC.get_control for a single car): mpmpc_solve with
 B = 1 from host buffers, and the two kernels by HIP events.  python profiles/latency_b1.py  (on the GPU box)"""
 import sys, time, numpy as np
-sys.path[:0]=["multi-purpose-mpc_amd","tests","oracle"]
+sys.path[:0]=["multi-purpose-mpc_amd","tests","oracle","."]
 import mpmpc, scenarios
 tr=scenarios.sim_track(); sc=scenarios.make(2,tr,B=1)
 Q,R,QN=scenarios.WEIGHTS["stock"]

@@ -10,7 +10,7 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [os.path.join(ROOT, "multi-purpose-mpc_amd"), os.path.join(ROOT, "tests")]
+sys.path[:0] = [os.path.join(ROOT, "multi-purpose-mpc_amd"), os.path.join(ROOT, "tests"), ROOT]
 import mpmpc            # noqa: E402
 import mpmpc_testlib as T   # noqa: E402
 import scenarios        # noqa: E402

@@ -15,6 +15,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "multi-purpose-mpc_amd"))
+sys.path.insert(0, ROOT)
 import mpmpc      # noqa: E402
 import scenarios  # noqa: E402
 

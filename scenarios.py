@@ -5,6 +5,9 @@ Each scenario is a batch of independent controller instances on Sim_Track
 (turned into the spatial state the way MPC.get_control does, src/MPC.py:171-177) and a previous
 plan `cc_prev` (MPC.current_control).  Track tables come from the committed fixtures that the
 reference itself produced (tests/golden/make_golden.py).
+
+This is the workload generator of bench.py, the tests and the profiling scripts: it lives beside bench.py, NOT in the
+product package (multi-purpose-mpc_amd/ imports nothing from the test tree).
 """
 from __future__ import annotations
 
@@ -14,7 +17,7 @@ import os
 
 import numpy as np
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
 
 CAR_LENGTH, CAR_WIDTH, TS = 0.12, 0.06, 0.05            # simulation.py:53-54
 UMIN = np.array([0.0, -math.tan(0.66) / CAR_LENGTH])      # simulation.py:108-109

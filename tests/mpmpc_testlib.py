@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "multi-purpose-mpc_amd")
-for p in (PKG, os.path.join(ROOT, "oracle")):
+for p in (PKG, os.path.join(ROOT, "oracle"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 

@@ -5,7 +5,7 @@ ADMM fallback, no alternative optimum.  Not collected by pytest (minutes per hun
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [os.path.join(ROOT, d) for d in ("tests", "oracle", "multi-purpose-mpc_amd")]
+sys.path[:0] = [os.path.join(ROOT, d) for d in ("tests", "oracle", "multi-purpose-mpc_amd")] + [ROOT]
 import numpy as np
 import mpmpc, mpmpc_testlib as T, scenarios, oracle_c
 tr = scenarios.sim_track()
