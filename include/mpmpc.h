@@ -125,6 +125,14 @@ typedef struct {
   double as_add_fraction; /* active-set rounds add only the bounds violated by at least this fraction of the round's worst
                             violation (measured on the scaled variable); 0: every violated bound, the plain primal-dual
                             active-set update; the retry after a failed attempt uses at least 0.5.  Default 0.25. */
+  int32_t native;        /* 1 (default): where `reduce` applies and the settings are the defaults of the early attempt
+                            (early_polish = 1, ipm_start_mu > 0) the batch launches run the REDUCED-NATIVE kernels: a lane
+                            never holds the 3-state problem - v in closed form at load time, own Ruiz pass / start / interior
+                            point / active-set rounds / KKT certificate on the (e_y, e_psi, kappa) problem, the roll-forward
+                            of t at the store - about half the registers of the general kernels, so two wavefronts share a
+                            SIMD.  What they cannot certify (infeasible or very hard instances) goes to the general
+                            one-instance-per-wave kernel (phase 1, full OSQP run) exactly like the tail of a packed launch.
+                            0: the general kernels only.  The closed loop's warm-started launches use the general kernels. */
 } mpmpc_settings;
 
 const char* mpmpc_version(void);

@@ -64,7 +64,9 @@ __device__ __forceinline__ double dpp_merge(double keep, double a) {
 // G lanes per instance; C = split of the twisted factorisation (mpmpc_core.hpp, factor): in chain
 // layout the lanes [C, 2C) of an instance are reversed.  Supported: <64,16> (N + 1 <= 32), <64,32>,
 // <32,16>, <16,16> (no second chain).
-template <int G, int C = G / 2>
+// SLOTS: 512-byte slots of per-wave LDS ("cold" storage + staging of the output rows): 66 for the general solver (33 KB: four
+// waves per CU, one per SIMD), 24 for the reduced-native one (12 KB: eight waves per CU, two per SIMD, fit the 160 KB).
+template <int G, int C = G / 2, int SLOTS = 66>
 struct LaneGpu {
   static_assert((G == 64 && (C == 16 || C == 32)) || (G == 32 && C == 16) || (G == 16 && C == 16), "unsupported lane split");
   static constexpr int split = C;
@@ -172,7 +174,7 @@ struct LaneGpu {
   // "cold" per-lane storage in LDS (one wavefront per block, slot-major: a wave access is 64
   // consecutive doubles, conflict free) for values only needed at termination checks and in the
   // certificate, so that they do not occupy registers - or worse, scratch - inside the loops
-  static constexpr int cold_slots = 66;          // 66 x 512 B = 33 KB per wave
+  static constexpr int cold_slots = SLOTS;       // x 512 B per wave
   static __device__ __forceinline__ double* cold() {
     __shared__ double buf[cold_slots * 64];
     return buf;

@@ -34,6 +34,7 @@ __device__ long long g_phase[4096 * 32];
 #endif
 #include "lane_gpu.hpp"
 #include "mpmpc_core.hpp"
+#include "mpmpc_reduced.hpp"
 #include "corridor_core.hpp"
 #include "rollout_core.hpp"
 #include "speed_core.hpp"
@@ -118,6 +119,32 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
   MPMPC_TICK_END(7);
   MPMPC_TICK_END(8);
   if (mode == 1 && k == 0 && inst < B && s.status == MPMPC_UNSOLVED) tail[1 + atomicAdd(tail, 1)] = inst;
+}
+
+// K2r: the reduced-native solve kernel (mpmpc_reduced.hpp) - the batch path of every configuration whose time state
+// separates (the reference's own weights).  One launch assembles (K1's code, in registers), solves and stores; the ids of
+// the instances it cannot certify are appended to tail[1..] (tail[0] counts) for the general kernel in mode 2.
+// 24 LDS slots (12 KB) and at most 256 registers: two wavefronts per SIMD.
+constexpr int RN_SLOTS = 37;
+template <int G, int C>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void mpmpc_reduced_kernel(mpmpc_config cfg, SolverParams st, int B, AssembleIn ain,
+                                                           double* __restrict__ z, double* __restrict__ u0,
+                                                           int* __restrict__ status, int* __restrict__ iters,
+                                                           double* __restrict__ resid, double* __restrict__ y,
+                                                           int* __restrict__ tail) {
+  using L = LaneGpu<G, C, RN_SLOTS>;
+  const int inst = blockIdx.x * L::per_wave + L::slot();
+  const int k = L::stage() - lane_offset(G, C, cfg.N);
+  MPMPC_TICK_BEGIN(8);
+  double fields[MPMPC_NUM_FIELDS];
+  assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
+  ReducedSolver<L> s;
+  s.run(fields, B, inst, k, cfg.N, st);
+  MPMPC_TICK_BEGIN(7);
+  s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y);
+  MPMPC_TICK_END(7);
+  MPMPC_TICK_END(8);
+  if (k == 0 && inst < B && s.status == MPMPC_UNSOLVED) tail[1 + atomicAdd(tail, 1)] = inst;
 }
 
 // K4: speed profile.  The kernel of choice is mpmpc_speed_profile_wave_kernel below (one wavefront per path); these
@@ -428,6 +455,7 @@ static int check_settings(const mpmpc_settings* s) {
     return fail(MPMPC_E_ARG, "polish needs ipm_reg, ipm_tol, as_delta > 0");
   if (s->phase1 != 0 && s->phase1 != 1) return fail(MPMPC_E_ARG, "phase1 must be 0 or 1");
   if (s->reduce != 0 && s->reduce != 1) return fail(MPMPC_E_ARG, "reduce must be 0 or 1");
+  if (s->native != 0 && s->native != 1) return fail(MPMPC_E_ARG, "native must be 0 or 1");
   if (!(s->ipm_start_dual >= 0)) return fail(MPMPC_E_ARG, "need ipm_start_dual >= 0");
   if (!(s->ipm_start_mu >= 0) || !(s->ipm_start_slack > 0)) return fail(MPMPC_E_ARG, "need ipm_start_mu >= 0, ipm_start_slack > 0");
   if (!(s->as_add_fraction >= 0) || !(s->as_add_fraction <= 1)) return fail(MPMPC_E_ARG, "need 0 <= as_add_fraction <= 1");
@@ -478,6 +506,7 @@ void mpmpc_default_settings(mpmpc_settings* s) {
   s->ipm_start_mu = 0.01;
   s->ipm_start_dual = 0.2;
   s->as_add_fraction = 0.25;
+  s->native = 1;
 }
 
 int32_t mpmpc_stage_ld(int32_t N) { return host_stage_ld(N); }
@@ -954,6 +983,11 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y) {
   const int per = 64 / G;
   const int blocks = (B + per - 1) / per;
   const SolverParams prm = make_params(h->st);
+  const int C = lane_split(G, N);        // where the two elimination chains of the factorisation meet
+  // (a tail launch has one block per instance of the batch: blocks beyond the list's length return at once - 0.25 us per
+  //  1024 of them; a grid-stride loop over the list around the solver costs the general kernels 70 registers and
+  //  puts 148-544 B of scratch into kernels that have none: measured on the code object, not kept)
+  const int tail_grid = B;
   const bool early = prm.polish && prm.early_polish > 0 && prm.early_polish < prm.max_iter;
   const int first_mode = (G < 64 && early) ? 1 : 0;      // packed launches hand their tail to a second one
 #define LAUNCH_W(GG, CC, WW, FF, MODE, BLOCKS)                                                                            \
@@ -973,17 +1007,32 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y) {
     } else if (warm_act) LAUNCH_W(GG, CC, true, 0, MODE, BLOCKS);                 \
     else LAUNCH_W(GG, CC, false, 0, MODE, BLOCKS);                                \
   } while (0)
-  if (first_mode == 1) HIP_TRY(hipMemsetAsync(h->tail, 0, sizeof(int), h->stream));
-  const int C = lane_split(G, N);        // where the two elimination chains of the factorisation meet
-  if (G == 64 && C == 16) LAUNCH(64, 16, first_mode, blocks);
+  // The reduced-native kernels (mpmpc_reduced.hpp) take the batch path of every configuration they apply to; the
+  // general kernel then only sees their tail.  (Warm-started closed-loop launches keep the general kernels.)
+  const bool rn = !warm && reduced_native(h->cfg, h->st);
+  // (knob of the occupancy experiment, profiles/r3/occupancy.txt: MPMPC_RN_OCC=1 pads every block with 20 KB of unused
+  //  dynamic LDS - 38.9 KB per wave, four waves per CU, ONE per SIMD - so that the same code object can be timed at one
+  //  and at two waves per SIMD)
+  static const int rn_pad = (std::getenv("MPMPC_RN_OCC") && std::atoi(std::getenv("MPMPC_RN_OCC")) == 1) ? 20 * 1024 : 0;
+#define LAUNCH_RN(GG, CC)                                                                                              \
+  hipLaunchKernelGGL((mpmpc_reduced_kernel<GG, CC>), dim3(blocks), dim3(64), rn_pad, h->stream, h->cfg, prm, B, ain,  \
+                     h->z, h->u0, h->status, h->iters, h->resid, y_out, h->tail)
+  if (rn || first_mode == 1) HIP_TRY(hipMemsetAsync(h->tail, 0, sizeof(int), h->stream));
+  if (rn) {
+    if (G == 64 && C == 16) LAUNCH_RN(64, 16);
+    else if (G == 64) LAUNCH_RN(64, 32);
+    else if (G == 32) LAUNCH_RN(32, 16);
+    else LAUNCH_RN(16, 16);
+  } else if (G == 64 && C == 16) LAUNCH(64, 16, first_mode, blocks);
   else if (G == 64) LAUNCH(64, 32, first_mode, blocks);
   else if (G == 32) LAUNCH(32, 16, first_mode, blocks);
   else LAUNCH(16, 16, first_mode, blocks);
-  if (first_mode == 1) {
+  if (rn || first_mode == 1) {
     // the tail is short (infeasible / very hard instances); waves beyond its length return at once
-    if (lane_split(64, N) == 16) LAUNCH(64, 16, 2, B);
-    else LAUNCH(64, 32, 2, B);
+    if (lane_split(64, N) == 16) LAUNCH(64, 16, 2, tail_grid);
+    else LAUNCH(64, 32, 2, tail_grid);
   }
+#undef LAUNCH_RN
 #undef LAUNCH_W
 #undef LAUNCH
   HIP_TRY(hipGetLastError());

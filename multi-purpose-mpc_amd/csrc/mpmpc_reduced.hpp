@@ -47,14 +47,23 @@ struct ReducedSolver : Solver<L, false, true, false> {
   using IpmI = typename S::template IpmT<LAY_IP>;
 
   // ---- cold storage (LDS), 512 B per slot: what only setup, the certificate and the store need
-  enum { C_D = 0, C_E = 3, C_C = 5, C_LOE = 6, C_HIE = 7, C_LOK = 8, C_HIK = 9, C_V = 10, C_LAMV = 11, C_A20 = 12, C_BV = 13, C_BEQ2 = 14,
-         C_G = 15, C_PI = 18, COLD_USED = 19 };
+  //   C_D, C_E, C_C        scalings D (3 columns), E (2 dynamics rows), cost scaling c
+  //   K_LO0 .. K_HI2       box of e_y and kappa in the scaled variable space (lo_raw / D, hi_raw / D)
+  //   C_V .. C_BEQ2        the separated parts: v, its multiplier, a20, b20 v, rhs of the time row
+  //   C_GAP                width of an empty box (resid[0] of such an instance)
+  //   C_G, C_PI            box-row scaling and pin multipliers of the start; later (same slots) C_XS, C_LAM: the certified point
+  //   C_NUS                its equality multipliers
+  //   K_PP .. K_RP         the packed interior point (ipm3): cost, equality offsets, residuals of the iteration
+  enum { C_D = 0, C_E = 3, C_C = 5, K_LO0 = 6, K_HI0 = 7, K_LO2 = 8, K_HI2 = 9, C_V = 10, C_LAMV = 11, C_A20 = 12, C_BV = 13, C_BEQ2 = 14,
+         C_G = 15, C_PI = 18, C_XS = 15, C_LAM = 18, C_NUS = 21, C_GAP = 23,
+         K_PP = 24, K_QQ = 27, K_LEQ = 30, K_RD = 32, K_RP = 35, COLD_USED = 37 };
   static_assert(COLD_USED <= L::cold_slots, "lane backend has too few cold slots");
+  // a scaled bound beyond this is "infinite" (raw infinities are +-1e30, the Ruiz factors stay within [1e-4, 1e4] per pass)
+  static constexpr double BOX_INF = 1e20;
 
   // ---- the reduced problem, scaled; entries e = (e_y, e_psi, kappa)
   R P3[3], Q3[3];
-  R x3[3];               // start point, then the certified point (scaled)
-  R nu2[2], lam3[3];     // multipliers of the certified point (scaled)
+  R x3[3];               // start point (the certified point and its multipliers wait in cold storage: C_XS, C_LAM, C_NUS)
   Mk val[3];             // entry exists: (vx, vx, vu)
   Mk solvable, empty;    // instance exists and no box of it is empty; instance exists and a box is empty
 
@@ -99,14 +108,13 @@ struct ReducedSolver : Solver<L, false, true, false> {
     // ---- the (e_y, e_psi, kappa) problem
     const R lo_e = max_(fld(F_LO + 0, -INFTY), R(-INFTY)), hi_e = min_(fld(F_HI + 0, INFTY), R(INFTY));
     const R lo_k = max_(fld(F_LO + 4, -INFTY), R(-INFTY)), hi_k = min_(fld(F_HI + 4, INFTY), R(INFTY));
-    L::cold_put(C_LOE, lo_e); L::cold_put(C_HIE, hi_e); L::cold_put(C_LOK, lo_k); L::cold_put(C_HIK, hi_k);
     {
       // an EMPTY box makes the QP trivially infeasible (Solver::run has the same rule): reported at once, never solved
       R gap = max_(max_(sel(vx, lo_e - hi_e, zero), sel(vu, lo_k - hi_k, zero)), sel(vu, lo_v - hi_v, zero));
       gap = L::gmax(gap);
       empty = live & (gap > zero);
       solvable = live & !empty;
-      pri_res = gap;
+      L::cold_put(C_GAP, gap);
     }
     const R ds = fld(F_DS, 0.0), one = sel(vu, onec, zero);
     a[0] = one; a[1] = ds; a[2] = fld(F_A10, 0.0); a[3] = one;
@@ -167,6 +175,8 @@ struct ReducedSolver : Solver<L, false, true, false> {
     for (int e = 0; e < 3; ++e) { L::cold_put(C_D + e, D3[e]); L::cold_put(C_G + e, G3[e]); }
     L::cold_put(C_E, E2[0]); L::cold_put(C_E + 1, E2[1]);
     L::cold_put(C_C, c3);
+    // box in the scaled variable space:  g x in [lb, ub]  <=>  x in [lo_raw, hi_raw] / D
+    L::cold_put(K_LO0, lo_e / D3[0]); L::cold_put(K_HI0, hi_e / D3[0]); L::cold_put(K_LO2, lo_k / D3[2]); L::cold_put(K_HI2, hi_k / D3[2]);
     // ---- OSQP's FIRST iterate of the reduced system from its cold start (Solver::reduced_start): per-row step sizes by
     // constraint type, x = alpha KKT^-1 (-q); for the pinned entries the multiplier of that iterate (the interior
     // point starts its pin multipliers there)
@@ -235,8 +245,158 @@ struct ReducedSolver : Solver<L, false, true, false> {
     }
   }
 
+  // ================================================================================ interior point, 3 entries per lane
+  // Solver::ipm<LAY_RED> (same iteration, same constants, same operation order) written for a small register footprint:
+  // two wavefronts share a SIMD only if a wave stays within 256 registers, and the general routine keeps ~390 live
+  // around its two KKT solves.  Here the loop invariants (box, cost, equality offsets) and the residuals of the iteration
+  // wait in LDS and are re-read where they are used (~40 LDS reads and 5 writes per iteration, 2 % of its instructions);
+  // across a factorisation or a KKT solve a lane holds the iterate, the slack reciprocals and the complementarity
+  // targets - nothing else.  Entry 1 (e_psi) is never boxed (reducible()).
+  MPMPC_HD Mk ipm3(const Box3& bx, typename S::template IpmT<LAY_RED>& s, const SolverParams& st, double tol, const Mk& run) {
+    const R reg(st.ipm_reg), ireg(st.inv_ipm_reg), one(1.0), zero(0.0);
+    constexpr int JB[2] = {0, 2};                       // the boxed entries: e_y, kappa
+    Mk active = run, conv = L::mfalse();
+    R cnt(0.0);
+    MPMPC_UNROLL
+    for (int b = 0; b < 2; ++b) cnt = cnt + sel(bx.Lm[JB[b]], one, zero) + sel(bx.Um[JB[b]], one, zero);
+    const R nb = max_(L::gsum(cnt), one);
+    I stall(0);
+    R mu_min(1e300);
+    auto lo_of = [&](int b) { return L::cold_get(b == 0 ? K_LO0 : K_LO2); };
+    auto hi_of = [&](int b) { return L::cold_get(b == 0 ? K_HI0 : K_HI2); };
+    // slack residuals of boxed entry b (cheap functions of the iterate and the box)
+    auto rl_of = [&](int b) { const int j = JB[b]; return sel(bx.Lm[j], s.x[j] - lo_of(b) - s.sl[j], zero); };
+    auto ru_of = [&](int b) { const int j = JB[b]; return sel(bx.Um[j], hi_of(b) - s.x[j] - s.su[j], zero); };
+    auto rpin_of = [&](int b) { const int j = JB[b]; return sel(bx.pin[j], s.x[j] - lo_of(b), zero); };
+    for (int it = 0; it <= st.ipm_max_iter; ++it) {
+      R mu;
+      {
+        // ---- residuals -> LDS
+        L::fence();
+        R At[3], rp[2], rd[3];
+        this->template AeqT_mul_t<LAY_RED>(s.nu, At);
+        this->template Aeq_mul_t<LAY_RED>(s.x, rp);
+        R res(0.0), msum(0.0);
+        MPMPC_UNROLL
+        for (int i = 0; i < 2; ++i) { rp[i] = rp[i] - L::cold_get(K_LEQ + i); res = max_(res, sel(vx, abs_(rp[i]), zero)); }
+        MPMPC_UNROLL
+        for (int j = 0; j < 3; ++j) rd[j] = fma_(L::cold_get(K_PP + j), s.x[j], L::cold_get(K_QQ + j)) + At[j] - s.zl[j] + s.zu[j] + s.pi[j];
+        res = max_(res, sel(val[1], abs_(rd[1]), zero));
+        MPMPC_UNROLL
+        for (int b = 0; b < 2; ++b) {
+          const int j = JB[b];
+          res = max_(res, sel(val[j], max_(max_(abs_(rd[j]), abs_(rpin_of(b))), max_(abs_(rl_of(b)), abs_(ru_of(b)))), zero));
+          msum = msum + sel(bx.Lm[j], s.sl[j] * s.zl[j], zero) + sel(bx.Um[j], s.su[j] * s.zu[j], zero);
+        }
+        MPMPC_UNROLL
+        for (int j = 0; j < 3; ++j) L::cold_put(K_RD + j, rd[j]);
+        L::cold_put(K_RP, rp[0]); L::cold_put(K_RP + 1, rp[1]);
+        res = L::gmax(res);
+        mu = L::gsum(msum) / nb;
+        const Mk ok = (res < R(tol > 1e-11 ? tol : 1e-11)) & (mu < R(tol));
+        conv = conv | (active & ok);
+        active = active & !ok;
+        if (it == st.ipm_max_iter || !L::wany(active)) break;
+        active = active & !(mu > R(st.ipm_diverged) * mu_min) & !((mu < R(tol * 1e-3)) & (res > R(1e-5)));
+        mu_min = min_(mu_min, mu);
+        if (!L::wany(active)) break;
+      }
+      ipm_iters = seli(active, ipm_iters + I(1), ipm_iters);
+      // ---- factor
+      R isl[2], isu[2], rcl[2], rcu[2];
+      {
+        L::fence();
+        R h[3];
+        h[1] = rcp_(L::cold_get(K_PP + 1) + reg);
+        MPMPC_UNROLL
+        for (int b = 0; b < 2; ++b) {
+          const int j = JB[b];
+          isl[b] = rcp_(s.sl[j]); isu[b] = rcp_(s.su[j]);
+          h[j] = rcp_(L::cold_get(K_PP + j) + reg + sel(bx.Lm[j], s.zl[j] * isl[b], zero) + sel(bx.Um[j], s.zu[j] * isu[b], zero) +
+                      sel(bx.pin[j], ireg, zero));
+          rcl[b] = s.sl[j] * s.zl[j]; rcu[b] = s.su[j] * s.zu[j];
+        }
+        this->template factor_t<LAY_RED>(h, reg);
+      }
+      R alpha_aff(1.0);
+      for (int pass = 0; pass < 2; ++pass) {
+        R dx[3], dnu[2];
+        {
+          L::fence();
+          R rhs[3], nreq[2];
+          rhs[1] = -L::cold_get(K_RD + 1);
+          MPMPC_UNROLL
+          for (int b = 0; b < 2; ++b) {
+            const int j = JB[b];
+            rhs[j] = -L::cold_get(K_RD + j) - sel(bx.Lm[j], fma_(s.zl[j], rl_of(b), rcl[b]) * isl[b], zero) +
+                     sel(bx.Um[j], fma_(s.zu[j], ru_of(b), rcu[b]) * isu[b], zero) - sel(bx.pin[j], rpin_of(b) * ireg, zero);
+          }
+          nreq[0] = -L::cold_get(K_RP); nreq[1] = -L::cold_get(K_RP + 1);
+          this->template kkt_solve_t<LAY_RED>(rhs, nreq, dx, dnu);
+        }
+        L::fence();
+        // largest step that keeps slacks and multipliers positive: 1 / max(-ds/s, -dz/z)
+        R dsl[2], dsu[2], dzl[2], dzu[2], dpi[2];
+        R blk(0.0);
+        MPMPC_UNROLL
+        for (int b = 0; b < 2; ++b) {
+          const int j = JB[b];
+          dsl[b] = sel(bx.Lm[j], dx[j] + rl_of(b), zero);
+          dsu[b] = sel(bx.Um[j], -dx[j] + ru_of(b), zero);
+          dzl[b] = sel(bx.Lm[j], -fma_(s.zl[j], dsl[b], rcl[b]) * isl[b], zero);
+          dzu[b] = sel(bx.Um[j], -fma_(s.zu[j], dsu[b], rcu[b]) * isu[b], zero);
+          dpi[b] = sel(bx.pin[j], (rpin_of(b) + dx[j]) * ireg, zero);
+          blk = max_(blk, max_(sel(bx.Lm[j], -dsl[b] * isl[b], zero), sel(bx.Um[j], -dsu[b] * isu[b], zero)));
+          blk = max_(blk, max_(sel(bx.Lm[j], -dzl[b] * rcp_(s.zl[j]), zero), sel(bx.Um[j], -dzu[b] * rcp_(s.zu[j]), zero)));
+        }
+        blk = L::gmax(blk);
+        const R ratio = sel(blk > zero, rcp_(blk), R(1e300));
+        if (pass == 0) {
+          alpha_aff = min_(one, ratio);
+          R ms(0.0);
+          MPMPC_UNROLL
+          for (int b = 0; b < 2; ++b) {
+            const int j = JB[b];
+            ms = ms + sel(bx.Lm[j], fma_(alpha_aff, dsl[b], s.sl[j]) * fma_(alpha_aff, dzl[b], s.zl[j]), zero) +
+                 sel(bx.Um[j], fma_(alpha_aff, dsu[b], s.su[j]) * fma_(alpha_aff, dzu[b], s.zu[j]), zero);
+          }
+          const R mu_aff = L::gsum(ms) / nb;
+          R sg = mu_aff / max_(mu, R(1e-300));
+          sg = sg * sg * sg;
+          const R sgmu = sg * mu;
+          MPMPC_UNROLL
+          for (int b = 0; b < 2; ++b) {
+            const int j = JB[b];
+            rcl[b] = fma_(dsl[b], dzl[b], fma_(s.sl[j], s.zl[j], -sgmu));
+            rcu[b] = fma_(dsu[b], dzu[b], fma_(s.su[j], s.zu[j], -sgmu));
+          }
+        } else {
+          const R al = min_(one, R(0.995) * ratio);
+          stall = seli(active & (al < R(1e-6)), stall + I(1), I(0));
+          s.x[1] = sel(active, fma_(al, dx[1], s.x[1]), s.x[1]);
+          MPMPC_UNROLL
+          for (int b = 0; b < 2; ++b) {
+            const int j = JB[b];
+            s.x[j] = sel(active, fma_(al, dx[j], s.x[j]), s.x[j]);
+            s.tL[j] = selb(active, bx.Lm[j] & (dsl[b] * s.zl[j] < dzl[b] * s.sl[j]), s.tL[j]);
+            s.tU[j] = selb(active, bx.Um[j] & (dsu[b] * s.zu[j] < dzu[b] * s.su[j]), s.tU[j]);
+            s.sl[j] = sel(active, fma_(al, dsl[b], s.sl[j]), s.sl[j]);
+            s.su[j] = sel(active, fma_(al, dsu[b], s.su[j]), s.su[j]);
+            s.zl[j] = sel(active, fma_(al, dzl[b], s.zl[j]), s.zl[j]);
+            s.zu[j] = sel(active, fma_(al, dzu[b], s.zu[j]), s.zu[j]);
+            s.pi[j] = sel(active, fma_(al, dpi[b], s.pi[j]), s.pi[j]);
+          }
+          s.nu[0] = sel(active, fma_(al, dnu[0], s.nu[0]), s.nu[0]);
+          s.nu[1] = sel(active, fma_(al, dnu[1], s.nu[1]), s.nu[1]);
+          active = active & (stall < 3);
+        }
+      }
+    }
+    return conv;
+  }
+
   // ================================================================================ certificate (reduced problem, unscaled)
-  MPMPC_HD Mk certificate3(const R xs[3], const R nus[2], const R lam[3], double tol, R& prim, R& stat) const {
+  MPMPC_HD Mk certificate3(const R* pp, const R* qq, const R xs[3], const R nus[2], const R lam[3], double tol, R& prim, R& stat) const {
     const R zero(0.0);
     R Ax[2], At[3];
     this->template Aeq_mul_t<LAY_RED>(xs, Ax);
@@ -249,16 +409,17 @@ struct ReducedSolver : Solver<L, false, true, false> {
     MPMPC_UNROLL
     for (int e = 0; e < 3; ++e) {
       const R De = L::cold_get(C_D + e);
-      const R xu = De * xs[e];
-      const R lo0 = e == 0 ? L::cold_get(C_LOE) : (e == 2 ? L::cold_get(C_LOK) : R(-INFTY));
-      const R hi0 = e == 0 ? L::cold_get(C_HIE) : (e == 2 ? L::cold_get(C_HIK) : R(INFTY));
-      pv = max_(pv, sel(val[e], max_(max_(lo0 - xu, xu - hi0), zero), zero));
-      const R rd = fma_(P3[e], xs[e], Q3[e]) + At[e] + lam[e];
+      // (the box in scaled units; distances go back to the unscaled problem through D)
+      const R lo0 = e == 0 ? L::cold_get(K_LO0) : (e == 2 ? L::cold_get(K_LO2) : R(-INFTY));
+      const R hi0 = e == 0 ? L::cold_get(K_HI0) : (e == 2 ? L::cold_get(K_HI2) : R(INFTY));
+      const Mk fu = hi0 < R(BOX_INF), fl = lo0 > R(-BOX_INF);
+      const R dlo = sel(fl, De * (xs[e] - lo0), R(INFTY)), dhi = sel(fu, De * (hi0 - xs[e]), R(INFTY));   // unscaled distances to the bounds
+      pv = max_(pv, sel(val[e], max_(max_(-dlo, -dhi), zero), zero));
+      const R rd = fma_(pp[e], xs[e], qq[e]) + At[e] + lam[e];
       sv = max_(sv, sel(val[e], abs_(rd / De) * cinv, zero));
       const R yu = (lam[e] / De) * cinv;                  // multiplier of the unscaled box row
-      const Mk fu = hi0 < R(INF_BOUND), fl = lo0 > R(-INF_BOUND);
-      const R cu = sel(fu, max_(yu, zero) * abs_(hi0 - xu), sel(yu > zero, R(1e300), zero));
-      const R cl = sel(fl, max_(-yu, zero) * abs_(xu - lo0), sel(yu < zero, R(1e300), zero));
+      const R cu = sel(fu, max_(yu, zero) * abs_(dhi), sel(yu > zero, R(1e300), zero));
+      const R cl = sel(fl, max_(-yu, zero) * abs_(dlo), sel(yu < zero, R(1e300), zero));
       cv = max_(cv, sel(val[e], max_(cu, cl), zero));
       bad = bad | (val[e] & !((abs_(xs[e]) < R(1e300)) & (abs_(lam[e]) < R(1e300))));     // a NaN must never pass
     }
@@ -281,24 +442,20 @@ struct ReducedSolver : Solver<L, false, true, false> {
     iters = I(1);
     ipm_iters = I(0);
     polished = I(0);
-    dua_res = zero;
-    MPMPC_UNROLL
-    for (int e = 0; e < 3; ++e) lam3[e] = zero;
-    nu2[0] = nu2[1] = zero;
+    pri_res = dua_res = zero;
     this->act_bits = I(0);
     Mk todo = solvable;
     if (L::wany(todo)) {
       // ---- box rows in the scaled variable space:  g x in [lb, ub]  <=>  x in [lo, hi] = [lo_raw, hi_raw] / D
       Box3 b3;
       {
-        const R lo_r[3] = {L::cold_get(C_LOE), R(-INFTY), L::cold_get(C_LOK)}, hi_r[3] = {L::cold_get(C_HIE), R(INFTY), L::cold_get(C_HIK)};
+        const R lo_s[3] = {L::cold_get(K_LO0), R(-INFTY), L::cold_get(K_LO2)}, hi_s[3] = {L::cold_get(K_HI0), R(INFTY), L::cold_get(K_HI2)};
         MPMPC_UNROLL
         for (int e = 0; e < 3; ++e) {
-          const R iD = R(1.0) / L::cold_get(C_D + e);
-          const Mk fl = lo_r[e] > R(-INF_BOUND), fu = hi_r[e] < R(INF_BOUND);
-          const Mk pn = fl & fu & ((hi_r[e] - lo_r[e]) <= R(1e-12) * max_(one, abs_(lo_r[e])));
-          b3.lo[e] = lo_r[e] * iD;
-          b3.hi[e] = hi_r[e] * iD;
+          const Mk fl = lo_s[e] > R(-BOX_INF), fu = hi_s[e] < R(BOX_INF);
+          const Mk pn = fl & fu & ((hi_s[e] - lo_s[e]) <= R(1e-12) * max_(one, abs_(lo_s[e])));
+          b3.lo[e] = lo_s[e];
+          b3.hi[e] = hi_s[e];
           b3.pin[e] = pn & val[e];
           b3.Lm[e] = fl & !pn & val[e];
           b3.Um[e] = fu & !pn & val[e];
@@ -347,10 +504,29 @@ struct ReducedSolver : Solver<L, false, true, false> {
         si.tL[e] = bi.Lm[e] & (si.zl[e] > si.sl[e]);
         si.tU[e] = bi.Um[e] & (si.zu[e] > si.su[e]);
       }
+      if constexpr (!kSplit) {
+        MPMPC_UNROLL
+        for (int e = 0; e < 3; ++e) { L::cold_put(K_PP + e, P3[e]); L::cold_put(K_QQ + e, Q3[e]); }
+        L::cold_put(K_LEQ, leq[0]); L::cold_put(K_LEQ + 1, leq[1]);
+        L::fence();
+      }
       double tol = st.ipm_tol;
       for (int attempt = 0; attempt < 2; ++attempt) {
         MPMPC_TICK_BEGIN(4);
-        const Mk conv = this->template ipm<LAY_IP>(bi, si, pp, qq, vm, st, tol, todo);
+        Mk conv;
+        if constexpr (kSplit) {
+          conv = this->template ipm<LAY_IP>(bi, si, pp, qq, vm, st, tol, todo);
+        } else {
+          conv = ipm3(bi, si, st, tol, todo);
+          // the packed interior point read its invariants from LDS; what follows takes them from there as well, so that
+          // no copy of them had to stay in registers across the loop
+          L::fence();
+          MPMPC_UNROLL
+          for (int e = 0; e < 3; ++e) { P3[e] = L::cold_get(K_PP + e); Q3[e] = L::cold_get(K_QQ + e); }
+          leq[0] = L::cold_get(K_LEQ); leq[1] = L::cold_get(K_LEQ + 1);
+          b3.lo[0] = bi.lo[0] = L::cold_get(K_LO0); b3.hi[0] = bi.hi[0] = L::cold_get(K_HI0);
+          b3.lo[2] = bi.lo[2] = L::cold_get(K_LO2); b3.hi[2] = bi.hi[2] = L::cold_get(K_HI2);
+        }
         MPMPC_TICK_END(4);
         // active-set guess: the indicators of the interior point's last step
         Mk gL[EI], gU[EI], aL[3], aU[3];
@@ -367,12 +543,24 @@ struct ReducedSolver : Solver<L, false, true, false> {
         MPMPC_TICK_END(5);
         R prim, stat;
         MPMPC_TICK_BEGIN(6);
-        const Mk cert = certificate3(xa, na, la, st.cert_tol, prim, stat);
+        const Mk cert = certificate3(P3, Q3, xa, na, la, st.cert_tol, prim, stat);
         MPMPC_TICK_END(6);
         const Mk good = todo & conv & okm & cert;
-        MPMPC_UNROLL
-        for (int e = 0; e < 3; ++e) { x3[e] = sel(good, xa[e], x3[e]); lam3[e] = sel(good, la[e], lam3[e]); }
-        nu2[0] = sel(good, na[0], nu2[0]); nu2[1] = sel(good, na[1], nu2[1]);
+        // the certified point goes to cold storage (the slots of the start's G and pin multipliers, which are done with);
+        // a packed wave's second attempt must not disturb what its partner instance has committed
+        if (attempt == 0) {
+          MPMPC_UNROLL
+          for (int e = 0; e < 3; ++e) { L::cold_put(C_XS + e, xa[e]); L::cold_put(C_LAM + e, la[e]); }
+          L::cold_put(C_NUS, na[0]); L::cold_put(C_NUS + 1, na[1]);
+        } else {
+          MPMPC_UNROLL
+          for (int e = 0; e < 3; ++e) {
+            L::cold_put(C_XS + e, sel(good, xa[e], L::cold_get(C_XS + e)));
+            L::cold_put(C_LAM + e, sel(good, la[e], L::cold_get(C_LAM + e)));
+          }
+          L::cold_put(C_NUS, sel(good, na[0], L::cold_get(C_NUS))); L::cold_put(C_NUS + 1, sel(good, na[1], L::cold_get(C_NUS + 1)));
+        }
+        L::fence();
         pri_res = sel(good, prim, pri_res);
         dua_res = sel(good, stat, dua_res);
         status = seli(good, I(MPMPC_SOLVED), status);
@@ -382,13 +570,9 @@ struct ReducedSolver : Solver<L, false, true, false> {
         tol *= 1e-4;
       }
     }
-    // empty box: infeasible, zero ray, the width of the gap in resid[0] (set in setup)
+    // empty box: infeasible, zero ray, the width of the gap in resid[0]
     status = seli(empty, I(MPMPC_PRIMAL_INFEASIBLE), status);
-    const Mk keepx = live & (status == MPMPC_SOLVED);
-    MPMPC_UNROLL
-    for (int e = 0; e < 3; ++e) { x3[e] = sel(keepx, x3[e], zero); lam3[e] = sel(keepx, lam3[e], zero); }
-    nu2[0] = sel(keepx, nu2[0], zero); nu2[1] = sel(keepx, nu2[1], zero);
-    pri_res = sel(live & !keepx & !empty, zero, pri_res);
+    pri_res = sel(empty, L::cold_get(C_GAP), pri_res);
   }
 
   // ================================================================================ output
@@ -403,7 +587,12 @@ struct ReducedSolver : Solver<L, false, true, false> {
     R D3[3];
     MPMPC_UNROLL
     for (int e = 0; e < 3; ++e) D3[e] = L::cold_get(C_D + e);
-    const R e_y = D3[0] * x3[0], e_psi = D3[1] * x3[1], kap = D3[2] * x3[2];
+    // the certified point (cold storage; zeros for an instance that has none: tail or empty box)
+    R xs[3], lam3[3], nu2[2];
+    MPMPC_UNROLL
+    for (int e = 0; e < 3; ++e) { xs[e] = sel(ok, L::cold_get(C_XS + e), zero); lam3[e] = sel(ok, L::cold_get(C_LAM + e), zero); }
+    nu2[0] = sel(ok, L::cold_get(C_NUS), zero); nu2[1] = sel(ok, L::cold_get(C_NUS + 1), zero);
+    const R e_y = D3[0] * xs[0], e_psi = D3[1] * xs[1], kap = D3[2] * xs[2];
     const R v = sel(ok, L::cold_get(C_V), zero), lam_v = sel(ok, L::cold_get(C_LAMV), zero);
     // t: row 2 of equality block k is  -t_k + a20 e_y_{k-1} + t_{k-1} + b20 v_{k-1} = beq2_k  (block 0: -t_0 = -x0[2]),
     // a running sum along the stages

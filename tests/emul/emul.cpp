@@ -6,6 +6,7 @@
 #include <initializer_list>
 #include "lane_emu.hpp"
 #include "mpmpc_core.hpp"
+#include "mpmpc_reduced.hpp"
 #include "corridor_core.hpp"
 #include "rollout_core.hpp"
 #include <limits>
@@ -47,6 +48,36 @@ static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const dou
   }
 }
 
+// mpmpc_reduced_kernel: the reduced-native solver; instances it leaves UNSOLVED are appended to tail[1..]
+template <int G, int C>
+static void solve_rn(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
+                     int* status, int* iters, double* resid, double* y, int* tail) {
+  using L = LaneEmu<G, C>;
+  const int ld = stage_ld(cfg->N);
+  const int per = L::per_wave;
+  for (int w = 0; w < (B + per - 1) / per; ++w) {
+    VI inst = L::slot() + w * per;
+    VI k = L::stage() - lane_offset(G, C, cfg->N);
+    ReducedSolver<L> s;
+    typename L::real fields[MPMPC_NUM_FIELDS];
+    ReducedSolver<L>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    s.run(fields, B, inst, k, cfg->N, make_params(*st));
+    s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y);
+    for (int i = 0; i < EMU_W; ++i)
+      if (k.v[i] == 0 && inst.v[i] < B && s.status.v[i] == MPMPC_UNSOLVED) tail[1 + tail[0]++] = inst.v[i];
+  }
+}
+static int solve_rn_g(int G, const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
+                      int* status, int* iters, double* resid, double* y, int* tail) {
+  const int C = lane_split(G, cfg->N);
+  if (G == 64 && C == 16) solve_rn<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
+  else if (G == 64) solve_rn<64, 32>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
+  else if (G == 32) solve_rn<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
+  else if (G == 16) solve_rn<16, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
+  else return -1;
+  return 0;
+}
+
 // the variant the launcher would pick: reduced polish where the configuration allows it
 #define SOLVE_G(GG, CC, ...)                                                          \
   do {                                                                                \
@@ -78,8 +109,16 @@ extern "C" int emu_solve_launch(const mpmpc_config* cfg, const mpmpc_settings* s
   if (cfg->N + 1 > G) return -1;
   const bool early = st->polish && st->early_polish > 0 && st->early_polish < st->max_iter;
   if (n_tail) *n_tail = 0;
-  if (G == 64 || !early) return emu_solve(cfg, st, G, qp, B, z, u0, status, iters, resid, y);
   std::vector<int> tail(B + 1, 0);
+  if (reduced_native(*cfg, *st)) {
+    // the reduced-native kernel for the whole batch (any packing), then the general kernel on its tail
+    if (solve_rn_g(G, cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data())) return -1;
+    if (n_tail) *n_tail = tail[0];
+    if (lane_split(64, cfg->N) == 16) SOLVE_G(64, 16, cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 2, tail.data());
+    else SOLVE_G(64, 32, cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 2, tail.data());
+    return 0;
+  }
+  if (G == 64 || !early) return emu_solve(cfg, st, G, qp, B, z, u0, status, iters, resid, y);
   if (G == 32) SOLVE_G(32, 16, cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 1, tail.data());
   else if (G == 16) SOLVE_G(16, 16, cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 1, tail.data());
   else return -1;
@@ -88,6 +127,17 @@ extern "C" int emu_solve_launch(const mpmpc_config* cfg, const mpmpc_settings* s
   else SOLVE_G(64, 32, cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 2, tail.data());
   return 0;
 }
+
+// the reduced-native kernel alone: what it cannot certify stays UNSOLVED and is counted in *n_tail
+extern "C" int emu_solve_rn(const mpmpc_config* cfg, const mpmpc_settings* st, int G, const double* qp, int B,
+                            double* z, double* u0, int* status, int* iters, double* resid, double* y, int* n_tail) {
+  if (cfg->N + 1 > G || !reducible(*cfg, *st)) return -1;
+  std::vector<int> tail(B + 1, 0);
+  if (solve_rn_g(G, cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data())) return -1;
+  if (n_tail) *n_tail = tail[0];
+  return 0;
+}
+extern "C" int emu_reduced_native(const mpmpc_config* cfg, const mpmpc_settings* st) { return reduced_native(*cfg, *st) ? 1 : 0; }
 
 // the closed-loop variant: `guess` [B x ld] = active sets to start from (bit 30 = valid), `act` [B x ld] <- the
 // active sets of the certified points (what mpmpc_solve_kernel<..., true> reads and writes in a rollout)

@@ -138,7 +138,8 @@ def test_full_size_against_emulation_and_certificates(cfgid, B, track, emu):
     h = _handle(track, sc.N, sc.weights, B)
     qp = h.assemble(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
     sol = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
-    ref = emu.solve(T.stock_config(sc.N, sc.weights), h.settings, qp, G=64)
+    # (solve_launch: what the launcher runs - the reduced-native kernel, then the general kernel on its tail)
+    ref, _ = emu.solve_launch(T.stock_config(sc.N, sc.weights), h.settings, qp, G=64)
     assert np.array_equal(sol.status, ref.status)
     assert np.array_equal(sol.iters[:, 0], ref.iters[:, 0])
     ok = sol.status == 1
@@ -185,7 +186,7 @@ def test_randomised_horizons_weights_and_batches_against_emulation(seed, track, 
         cfg = T.stock_config(N, weights, max_batch=B)
         qp = emu.assemble(cfg, track, (wp, x0, cc, lb, ub))
         for G in sorted({64, 32 if N + 1 <= 32 else 64, 16 if N + 1 <= 16 else 64}):
-            ref = emu.solve(cfg, mpmpc.default_settings(), qp, G=G)
+            ref, _ = emu.solve_launch(cfg, mpmpc.default_settings(), qp, G=G)      # the launcher's own sequence of kernels
             assert np.array_equal(dev.status, ref.status) and np.array_equal(dev.iters, ref.iters), (N, cfg_id, B, G)
             ok = dev.status == 1
             if ok.any():
@@ -655,7 +656,7 @@ def test_paths_longer_than_the_lds_staging_of_k1(emu):
     other = np.delete(np.arange(mpmpc.NUM_FIELDS), cap)
     assert np.array_equal(qp[other][:, :, :N + 1], qp_e[other][:, :, :N + 1])        # (the padding stage is never written)
     assert np.max(np.abs(qp[cap, :, :N + 1] - qp_e[cap, :, :N + 1])) <= 8 * np.finfo(float).eps
-    ref = emu.solve(cfg, mpmpc.default_settings(), qp_e, G=64)
+    ref, _ = emu.solve_launch(cfg, mpmpc.default_settings(), qp_e, G=64)
     assert np.array_equal(sol.status, ref.status) and np.all(sol.status == 1)
     assert np.max(np.abs(sol.z - ref.z)) <= 1e-9
 
