@@ -113,7 +113,8 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
   Solver<L, VAR == 1, VAR == 2, VAR == 3> s;
   // (second launch of a packed batch: the interior-point iterations the first launch spent on this instance)
   const int base_ipm = (mode == 2 && iters) ? iters[inst * 2 + 1] : 0;
-  s.template run<WARM, (G == 64)>(fields, B, inst, k, cfg.N, st, mode, guess, base_ipm, cfg.QN_offdiag);
+  static_assert(G == 64, "the general kernels run one instance per wave (only the reduced-native kernels pack)");
+  s.template run<WARM, true>(fields, B, inst, k, cfg.N, st, mode, guess, base_ipm, cfg.QN_offdiag);
   MPMPC_TICK_BEGIN(7);
   s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y, WARM ? act : nullptr, ld);
   MPMPC_TICK_END(7);
@@ -126,22 +127,30 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
 // the instances it cannot certify are appended to tail[1..] (tail[0] counts) for the general kernel in mode 2.
 // 24 LDS slots (12 KB) and at most 256 registers: two wavefronts per SIMD.
 constexpr int RN_SLOTS = 37;
-template <int G, int C>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void mpmpc_reduced_kernel(mpmpc_config cfg, SolverParams st, int B, AssembleIn ain,
+// WARM (closed loop): act [B x ld] holds the active sets the previous step certified, shift [B] the waypoints each car has
+// advanced since; the kernel starts from them and leaves this step's sets in act.
+template <int G, int C, bool WARM>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void mpmpc_reduced_kernel(mpmpc_config cfg, SolverParams st, int B, int ld, AssembleIn ain,
                                                            double* __restrict__ z, double* __restrict__ u0,
                                                            int* __restrict__ status, int* __restrict__ iters,
                                                            double* __restrict__ resid, double* __restrict__ y,
-                                                           int* __restrict__ tail) {
+                                                           int* __restrict__ tail, int* __restrict__ act,
+                                                           const int* __restrict__ shift) {
   using L = LaneGpu<G, C, RN_SLOTS>;
   const int inst = blockIdx.x * L::per_wave + L::slot();
   const int k = L::stage() - lane_offset(G, C, cfg.N);
+  int guess = 0;
+  if (WARM && inst < B && k >= 0 && k <= cfg.N) {
+    const int kk = k + shift[inst];
+    guess = act[inst * ld + (kk > cfg.N ? cfg.N : kk)];
+  }
   MPMPC_TICK_BEGIN(8);
   double fields[MPMPC_NUM_FIELDS];
   assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
   ReducedSolver<L> s;
-  s.run(fields, B, inst, k, cfg.N, st);
+  s.template run<WARM>(fields, B, inst, k, cfg.N, st, guess);
   MPMPC_TICK_BEGIN(7);
-  s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y);
+  s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y, WARM ? act : nullptr, ld);
   MPMPC_TICK_END(7);
   MPMPC_TICK_END(8);
   if (k == 0 && inst < B && s.status == MPMPC_UNSOLVED) tail[1 + atomicAdd(tail, 1)] = inst;
@@ -960,19 +969,22 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y) {
   ain.tab = PathTables{h->kappa, h->v_ref, h->ds_next, h->n_wp, h->ub_tab, h->lb_tab, h->n_cols};
   ain.wp_id = h->wp_id; ain.x0 = h->x0; ain.cc = h->cc;
   ain.lb = h->have_rows ? h->lb : nullptr; ain.ub = h->have_rows ? h->ub : nullptr;
-  // lanes per instance: one instance per wave while there are no more instances than SIMDs (1024);
-  // beyond that the smallest power of two holding N+1 stages, so that a wave carries 2 or 4 instances
-  // (measured at N = 30: B = 2048 takes 0.28 ms with 32 lanes per instance, 0.47 ms with 64)
-  int G = 64;
-  if (N + 1 <= 32 && B > 1024) G = 32;
-  if (N + 1 <= 16 && B > 2048) G = 16;
-  if (h->force_lanes && N + 1 <= h->force_lanes) G = h->force_lanes;      // mpmpc_set_packing
-  // a full terminal weight (QN with off-diagonal entries) runs one instance per wave: only those kernels carry the
-  // code of the dense terminal block
+  // A full terminal weight (QN with off-diagonal entries), bounds on e_psi / t or a cost on t rule the reduction out:
+  // such configurations run the general kernels, one instance per wave.
   const bool fullqn = h->cfg.QN_offdiag[0] != 0.0 || h->cfg.QN_offdiag[1] != 0.0 || h->cfg.QN_offdiag[2] != 0.0;
-  if (fullqn) G = 64;
   const bool red = reducible(h->cfg, h->st);      // the polish may work on the (e_y, e_psi, kappa) problem
   const bool freex = !fullqn && !red && free_states(h->cfg);
+  // The reduced-native kernels (mpmpc_reduced.hpp) take the batch path of every configuration they apply to - cold and
+  // warm-started - and only they pack several instances into a wave; the general kernel then sees their tail.
+  const bool rn = reduced_native(h->cfg, h->st);
+  // lanes per instance: one instance per wave while there are no more instances than SIMDs (1024); beyond that the
+  // smallest power of two holding N + 1 stages, so that a wave carries 2 or 4 instances and a SIMD two such waves
+  int G = 64;
+  if (rn) {
+    if (N + 1 <= 32 && B > 1024) G = 32;
+    if (N + 1 <= 16 && B > 2048) G = 16;
+    if (h->force_lanes && N + 1 <= h->force_lanes) G = h->force_lanes;      // mpmpc_set_packing
+  }
   // closed loop: the previous step's active sets as a first guess.  A launch with one instance per wave ends with
   // its slowest car, and with more than a handful of cars one of them always misses its guess (hit rate 91-93 %
   // per car and step: the miss pays for the attempt AND the normal path, 1024 cars -7 %), so "auto" warm-starts the
@@ -984,55 +996,52 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y) {
   const int blocks = (B + per - 1) / per;
   const SolverParams prm = make_params(h->st);
   const int C = lane_split(G, N);        // where the two elimination chains of the factorisation meet
-  // (a tail launch has one block per instance of the batch: blocks beyond the list's length return at once - 0.25 us per
-  //  1024 of them; a grid-stride loop over the list around the solver costs the general kernels 70 registers and
-  //  puts 148-544 B of scratch into kernels that have none: measured on the code object, not kept)
-  const int tail_grid = B;
-  const bool early = prm.polish && prm.early_polish > 0 && prm.early_polish < prm.max_iter;
-  const int first_mode = (G < 64 && early) ? 1 : 0;      // packed launches hand their tail to a second one
-#define LAUNCH_W(GG, CC, WW, FF, MODE, BLOCKS)                                                                            \
-  hipLaunchKernelGGL((mpmpc_solve_kernel<GG, CC, WW, FF>), dim3(BLOCKS), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, \
-                     ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, MODE, h->tail, warm_act, warm_shift)
-#define LAUNCH(GG, CC, MODE, BLOCKS)                                              \
-  do {                                                                            \
-    if (GG == 64 && fullqn) {                                                     \
-      if (warm_act) LAUNCH_W(GG, CC, true, (GG == 64 ? 1 : 0), MODE, BLOCKS);     \
-      else LAUNCH_W(GG, CC, false, (GG == 64 ? 1 : 0), MODE, BLOCKS);             \
-    } else if (red) {                                                             \
-      if (warm_act) LAUNCH_W(GG, CC, true, 2, MODE, BLOCKS);                      \
-      else LAUNCH_W(GG, CC, false, 2, MODE, BLOCKS);                              \
-    } else if (GG == 64 && freex) {                                               \
-      if (warm_act) LAUNCH_W(GG, CC, true, (GG == 64 ? 3 : 0), MODE, BLOCKS);     \
-      else LAUNCH_W(GG, CC, false, (GG == 64 ? 3 : 0), MODE, BLOCKS);             \
-    } else if (warm_act) LAUNCH_W(GG, CC, true, 0, MODE, BLOCKS);                 \
-    else LAUNCH_W(GG, CC, false, 0, MODE, BLOCKS);                                \
+#define LAUNCH_W(CC, WW, FF, MODE, BLOCKS)                                                                                \
+  hipLaunchKernelGGL((mpmpc_solve_kernel<64, CC, WW, FF>), dim3(BLOCKS), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, \
+                     ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, MODE, h->tail, WW ? warm_act : nullptr,    \
+                     WW ? warm_shift : nullptr)
+#define LAUNCH_V(CC, WW, MODE, BLOCKS)                  \
+  do {                                                  \
+    if (fullqn) LAUNCH_W(CC, WW, 1, MODE, BLOCKS);      \
+    else if (red) LAUNCH_W(CC, WW, 2, MODE, BLOCKS);    \
+    else if (freex) LAUNCH_W(CC, WW, 3, MODE, BLOCKS);  \
+    else LAUNCH_W(CC, WW, 0, MODE, BLOCKS);             \
   } while (0)
-  // The reduced-native kernels (mpmpc_reduced.hpp) take the batch path of every configuration they apply to; the
-  // general kernel then only sees their tail.  (Warm-started closed-loop launches keep the general kernels.)
-  const bool rn = !warm && reduced_native(h->cfg, h->st);
+  // the general kernel, one instance per wave: the whole solve (mode 0), or the tail of a reduced-native launch (mode 2)
+#define LAUNCH(CC, WW, MODE, BLOCKS)                    \
+  do {                                                  \
+    if (WW) LAUNCH_V(CC, true, MODE, BLOCKS);           \
+    else LAUNCH_V(CC, false, MODE, BLOCKS);             \
+  } while (0)
   // (knob of the occupancy experiment, profiles/r3/occupancy.txt: MPMPC_RN_OCC=1 pads every block with 20 KB of unused
   //  dynamic LDS - 38.9 KB per wave, four waves per CU, ONE per SIMD - so that the same code object can be timed at one
   //  and at two waves per SIMD)
   static const int rn_pad = (std::getenv("MPMPC_RN_OCC") && std::atoi(std::getenv("MPMPC_RN_OCC")) == 1) ? 20 * 1024 : 0;
-#define LAUNCH_RN(GG, CC)                                                                                              \
-  hipLaunchKernelGGL((mpmpc_reduced_kernel<GG, CC>), dim3(blocks), dim3(64), rn_pad, h->stream, h->cfg, prm, B, ain,  \
-                     h->z, h->u0, h->status, h->iters, h->resid, y_out, h->tail)
-  if (rn || first_mode == 1) HIP_TRY(hipMemsetAsync(h->tail, 0, sizeof(int), h->stream));
+#define LAUNCH_RN_W(GG, CC, WW)                                                                                             \
+  hipLaunchKernelGGL((mpmpc_reduced_kernel<GG, CC, WW>), dim3(blocks), dim3(64), rn_pad, h->stream, h->cfg, prm, B, h->ld, \
+                     ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, h->tail, warm_act, warm_shift)
+#define LAUNCH_RN(GG, CC)                       \
+  do {                                          \
+    if (warm) LAUNCH_RN_W(GG, CC, true);        \
+    else LAUNCH_RN_W(GG, CC, false);            \
+  } while (0)
   if (rn) {
+    HIP_TRY(hipMemsetAsync(h->tail, 0, sizeof(int), h->stream));
     if (G == 64 && C == 16) LAUNCH_RN(64, 16);
     else if (G == 64) LAUNCH_RN(64, 32);
     else if (G == 32) LAUNCH_RN(32, 16);
     else LAUNCH_RN(16, 16);
-  } else if (G == 64 && C == 16) LAUNCH(64, 16, first_mode, blocks);
-  else if (G == 64) LAUNCH(64, 32, first_mode, blocks);
-  else if (G == 32) LAUNCH(32, 16, first_mode, blocks);
-  else LAUNCH(16, 16, first_mode, blocks);
-  if (rn || first_mode == 1) {
-    // the tail is short (infeasible / very hard instances); waves beyond its length return at once
-    if (lane_split(64, N) == 16) LAUNCH(64, 16, 2, tail_grid);
-    else LAUNCH(64, 32, 2, tail_grid);
-  }
+    // The tail is short (infeasible / very hard instances).  One block per instance of the batch: blocks beyond the
+    // list's length return at once (0.25 us per 1024 of them; a grid-stride loop over the list around the solver costs
+    // the general kernels 70 registers and puts 148-544 B of scratch into kernels that have none: measured on the code
+    // object, not kept).  Its instances carry no guess for the next closed-loop step (act stays 0 from the first launch).
+    if (lane_split(64, N) == 16) LAUNCH(16, false, 2, B);
+    else LAUNCH(32, false, 2, B);
+  } else if (C == 16) LAUNCH(16, warm, 0, blocks);
+  else LAUNCH(32, warm, 0, blocks);
 #undef LAUNCH_RN
+#undef LAUNCH_RN_W
+#undef LAUNCH_V
 #undef LAUNCH_W
 #undef LAUNCH
   HIP_TRY(hipGetLastError());

@@ -433,7 +433,43 @@ struct ReducedSolver : Solver<L, false, true, false> {
   }
 
   // ================================================================================ the solve
-  MPMPC_HD void run(const R* fields, int B, const I& inst, const I& k, int N_, const SolverParams& st) {
+  // the certified point goes to cold storage (the slots of the start's G and pin multipliers, which are done with); with
+  // `merge` a packed wave's later commit does not disturb what its partner instance has committed before
+  MPMPC_HD void commit(const Mk& good, bool merge, const R xa[3], const R na[2], const R la[3], const R& prim, const R& stat) {
+    if (!merge) {
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) { L::cold_put(C_XS + e, xa[e]); L::cold_put(C_LAM + e, la[e]); }
+      L::cold_put(C_NUS, na[0]); L::cold_put(C_NUS + 1, na[1]);
+    } else {
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) {
+        L::cold_put(C_XS + e, sel(good, xa[e], L::cold_get(C_XS + e)));
+        L::cold_put(C_LAM + e, sel(good, la[e], L::cold_get(C_LAM + e)));
+      }
+      L::cold_put(C_NUS, sel(good, na[0], L::cold_get(C_NUS))); L::cold_put(C_NUS + 1, sel(good, na[1], L::cold_get(C_NUS + 1)));
+    }
+    L::fence();
+    pri_res = sel(good, prim, pri_res);
+    dua_res = sel(good, stat, dua_res);
+    status = seli(good, I(MPMPC_SOLVED), status);
+    polished = seli(good, I(1), polished);
+  }
+  // active set of a certified point in the closed loop's format (Solver::pack_active: bit j lower, bit 5 + j upper over
+  // (e_y, e_psi, t, v, kappa), bit 30 = valid); the speed's own activity from the sign of its multiplier
+  MPMPC_HD I pack_active3(const Mk aL[3], const Mk aU[3]) const {
+    const R lam_v = L::cold_get(C_LAMV), zero(0.0);
+    I v(1 << 30);
+    v = v + seli(aL[0], I(1 << 0), I(0)) + seli(aU[0], I(32 << 0), I(0)) + seli(aL[1], I(1 << 1), I(0)) + seli(aU[1], I(32 << 1), I(0)) +
+        seli(aL[2], I(1 << 4), I(0)) + seli(aU[2], I(32 << 4), I(0));
+    v = v + seli(vu & (lam_v < zero), I(1 << 3), I(0)) + seli(vu & (lam_v > zero), I(32 << 3), I(0));
+    return v;
+  }
+
+  // WARM (closed loop): `guess` = active set of the previous step's certified plan, already shifted to this step's stages
+  // (bit 30 set where there is one).  One or two active-set rounds from it usually reproduce the optimum
+  // (Solver::warm_polish); what they cannot certify takes the normal path.
+  template <bool WARM = false>
+  MPMPC_HD void run(const R* fields, int B, const I& inst, const I& k, int N_, const SolverParams& st, const I& guess = I(0)) {
     MPMPC_TICK_BEGIN(0);
     setup(fields, B, inst, k, N_, st);
     MPMPC_TICK_END(0);
@@ -447,6 +483,7 @@ struct ReducedSolver : Solver<L, false, true, false> {
     Mk todo = solvable;
     if (L::wany(todo)) {
       // ---- box rows in the scaled variable space:  g x in [lb, ub]  <=>  x in [lo, hi] = [lo_raw, hi_raw] / D
+      bool committed = false;
       Box3 b3;
       {
         const R lo_s[3] = {L::cold_get(K_LO0), R(-INFTY), L::cold_get(K_LO2)}, hi_s[3] = {L::cold_get(K_HI0), R(INFTY), L::cold_get(K_HI2)};
@@ -461,6 +498,32 @@ struct ReducedSolver : Solver<L, false, true, false> {
           b3.Um[e] = fu & !pn & val[e];
         }
       }
+      if constexpr (WARM) {
+        const Mk warm = L::gany(todo & bit_(guess, 30));
+        if (L::wany(warm)) {
+          Mk aL[3], aU[3];
+          constexpr int J5[3] = {0, 1, 4};
+          MPMPC_UNROLL
+          for (int e = 0; e < 3; ++e) {
+            aL[e] = b3.Lm[e] & bit_(guess, J5[e]);
+            aU[e] = b3.Um[e] & bit_(guess, 5 + J5[e]) & !aL[e];
+          }
+          R xa[3] = {zero, zero, zero}, la[3] = {zero, zero, zero}, na[2] = {zero, zero};
+          SolverParams sw = st;
+          sw.as_rounds = st.as_rounds < 2 ? st.as_rounds : 2;      // a guess that needs more is not worth more than the normal path
+          const Mk okm = this->template active_set<LAY_RED>(b3, P3, Q3, val, aL, aU, xa, na, la, sw, warm, st.as_add_fraction);
+          R prim, stat;
+          const Mk cert = certificate3(P3, Q3, xa, na, la, st.cert_tol, prim, stat);
+          const Mk good = warm & okm & cert;
+          // (merge: the lanes that missed their guess still need the start's G / pin multipliers, which share the slots)
+          commit(good, true, xa, na, la, prim, stat);
+          committed = true;
+          iters = seli(good, I(0), iters);
+          this->act_bits = seli(good, pack_active3(aL, aU), this->act_bits);
+          todo = todo & !good;
+        }
+      }
+      if (L::wany(todo)) {
       // ---- centred start of the interior point (Solver::polish, early attempt): slacks max(distance to the bound,
       // ipm_start_slack in row space), multipliers mu0 / slack, no equality multipliers
       R sl[3], su[3], zl[3], zu[3], pi[3];
@@ -546,28 +609,13 @@ struct ReducedSolver : Solver<L, false, true, false> {
         const Mk cert = certificate3(P3, Q3, xa, na, la, st.cert_tol, prim, stat);
         MPMPC_TICK_END(6);
         const Mk good = todo & conv & okm & cert;
-        // the certified point goes to cold storage (the slots of the start's G and pin multipliers, which are done with);
-        // a packed wave's second attempt must not disturb what its partner instance has committed
-        if (attempt == 0) {
-          MPMPC_UNROLL
-          for (int e = 0; e < 3; ++e) { L::cold_put(C_XS + e, xa[e]); L::cold_put(C_LAM + e, la[e]); }
-          L::cold_put(C_NUS, na[0]); L::cold_put(C_NUS + 1, na[1]);
-        } else {
-          MPMPC_UNROLL
-          for (int e = 0; e < 3; ++e) {
-            L::cold_put(C_XS + e, sel(good, xa[e], L::cold_get(C_XS + e)));
-            L::cold_put(C_LAM + e, sel(good, la[e], L::cold_get(C_LAM + e)));
-          }
-          L::cold_put(C_NUS, sel(good, na[0], L::cold_get(C_NUS))); L::cold_put(C_NUS + 1, sel(good, na[1], L::cold_get(C_NUS + 1)));
-        }
-        L::fence();
-        pri_res = sel(good, prim, pri_res);
-        dua_res = sel(good, stat, dua_res);
-        status = seli(good, I(MPMPC_SOLVED), status);
-        polished = seli(good, I(1), polished);
+        commit(good, committed, xa, na, la, prim, stat);
+        committed = true;
+        if constexpr (WARM) this->act_bits = seli(good, pack_active3(aL, aU), this->act_bits);
         todo = todo & conv & !good;          // a diverged interior-point run is not retried
         if (!L::wany(todo)) break;
         tol *= 1e-4;
+      }
       }
     }
     // empty box: infeasible, zero ray, the width of the gap in resid[0]
@@ -579,7 +627,8 @@ struct ReducedSolver : Solver<L, false, true, false> {
   // z in the reference's ordering, u0 = (v_0, delta_0), multipliers in the reference's row order; the separated parts
   // (v, its multiplier, the roll-forward of t) are put together here, in the unscaled problem
   MPMPC_HD void store(const I& inst, const I& k, double wheelbase, double* z, double* u0, int* st_out, int* it_out,
-                      double* resid, double* y) const {
+                      double* resid, double* y, int* act = nullptr, int ld = 0) const {
+    if (act) L::storei(act, inst * ld + k, vx, this->act_bits);
     const int n = 5 * N + 3, m = 8 * N + 6;
     const R zero(0.0);
     const Mk ok = live & (status == MPMPC_SOLVED);

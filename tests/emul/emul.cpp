@@ -51,29 +51,35 @@ static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const dou
 // mpmpc_reduced_kernel: the reduced-native solver; instances it leaves UNSOLVED are appended to tail[1..]
 template <int G, int C>
 static void solve_rn(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
-                     int* status, int* iters, double* resid, double* y, int* tail) {
+                     int* status, int* iters, double* resid, double* y, int* tail, const int* guess = nullptr, int* act = nullptr) {
   using L = LaneEmu<G, C>;
   const int ld = stage_ld(cfg->N);
   const int per = L::per_wave;
   for (int w = 0; w < (B + per - 1) / per; ++w) {
     VI inst = L::slot() + w * per;
     VI k = L::stage() - lane_offset(G, C, cfg->N);
+    VI gs(0);
+    for (int i = 0; i < EMU_W; ++i) {
+      const int in = inst.v[i], kk = k.v[i];
+      gs.v[i] = (guess && in < B && kk >= 0 && kk <= cfg->N) ? guess[in * ld + kk] : 0;
+    }
     ReducedSolver<L> s;
     typename L::real fields[MPMPC_NUM_FIELDS];
     ReducedSolver<L>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
-    s.run(fields, B, inst, k, cfg->N, make_params(*st));
-    s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y);
+    if (guess) s.template run<true>(fields, B, inst, k, cfg->N, make_params(*st), gs);
+    else s.template run<false>(fields, B, inst, k, cfg->N, make_params(*st));
+    s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y, act, ld);
     for (int i = 0; i < EMU_W; ++i)
       if (k.v[i] == 0 && inst.v[i] < B && s.status.v[i] == MPMPC_UNSOLVED) tail[1 + tail[0]++] = inst.v[i];
   }
 }
 static int solve_rn_g(int G, const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
-                      int* status, int* iters, double* resid, double* y, int* tail) {
+                      int* status, int* iters, double* resid, double* y, int* tail, const int* guess = nullptr, int* act = nullptr) {
   const int C = lane_split(G, cfg->N);
-  if (G == 64 && C == 16) solve_rn<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
-  else if (G == 64) solve_rn<64, 32>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
-  else if (G == 32) solve_rn<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
-  else if (G == 16) solve_rn<16, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
+  if (G == 64 && C == 16) solve_rn<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail, guess, act);
+  else if (G == 64) solve_rn<64, 32>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail, guess, act);
+  else if (G == 32) solve_rn<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail, guess, act);
+  else if (G == 16) solve_rn<16, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail, guess, act);
   else return -1;
   return 0;
 }
@@ -146,6 +152,16 @@ extern "C" int emu_solve_warm(const mpmpc_config* cfg, const mpmpc_settings* st,
                               double* y, int* act) {
   if (cfg->N + 1 > G) return -1;
   const int C = lane_split(G, cfg->N);
+  if (reduced_native(*cfg, *st)) {
+    // what the launcher runs in a warm-started closed-loop step: the reduced-native kernel with the guesses, then the
+    // general kernel (no guess) on its tail
+    std::vector<int> tail(B + 1, 0);
+    if (solve_rn_g(G, cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data(), guess, act)) return -1;
+    if (lane_split(64, cfg->N) == 16) SOLVE_G(64, 16, cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 2, tail.data());
+    else SOLVE_G(64, 32, cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 2, tail.data());
+    return 0;
+  }
+  if (G != 64) return -1;          // the general kernels run one instance per wave
   if (G == 64 && C == 16) SOLVE_G(64, 16, cfg, st, qp, B, z, u0, status, iters, resid, y, guess, act);
   else if (G == 64) SOLVE_G(64, 32, cfg, st, qp, B, z, u0, status, iters, resid, y, guess, act);
   else if (G == 32) SOLVE_G(32, 16, cfg, st, qp, B, z, u0, status, iters, resid, y, guess, act);

@@ -71,3 +71,44 @@ def test_argument_validation_without_device(lib):
         mpmpc.default_settings(no_such_setting=1)
     with pytest.raises(ValueError):
         mpmpc.make_config(30, [1, 0], [0.5, 0], [1, 0, 0], [0] * 3, [0] * 3, [0, 0], [1, 1], 4.0, 0.12)
+
+
+# ---- resources of the kernels in the SHIPPED code object (llvm-readelf --notes of libmpmpc.so's gfx950 image)
+def _kernel_rows(lib):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    import kernel_resources
+    return kernel_resources.kernel_table()
+
+
+def test_reduced_native_kernels_fit_two_waves_per_simd(lib):
+    """The batch path of the reference's own weights runs mpmpc_reduced_kernel<G, C>: every instantiation must stay within
+    256 registers (vgpr_count is the unified VGPR + AGPR total on gfx950), 20 KB of LDS and NO scratch - the budget of two
+    wavefronts per SIMD / eight per CU."""
+    rows = [r for r in _kernel_rows(lib) if r["name"].startswith("mpmpc_reduced_kernel")]
+    assert len(rows) >= 8, [r["name"] for r in rows]
+    for r in rows:
+        assert r["scratch"] == 0, r
+        assert r["vgpr"] <= 256 and r["agpr"] == 0, r
+        assert r["lds"] <= 20 * 1024, r
+
+
+def test_no_batch_path_solve_kernel_has_scratch(lib):
+    """private_segment_fixed_size must be 0 for every solve kernel a batch launch can pick: the reduced-native kernels, and
+    the one-instance-per-wave general kernels that take their tail / the configurations the reduction does not apply to.
+    KNOWN_SCRATCH lists the instantiations that still spill - none of them is reachable from BASELINE.json's
+    configurations (N >= 32 with bounded e_psi / t or a full terminal weight) - with the bytes measured when they were
+    listed: the test fails if one of them grows or a new one appears."""
+    KNOWN_SCRATCH = {
+        "mpmpc_solve_kernel<64, 32, false, 0>": 160, "mpmpc_solve_kernel<64, 32, true, 0>": 160,
+        "mpmpc_solve_kernel<64, 32, false, 1>": 208, "mpmpc_solve_kernel<64, 32, true, 1>": 208,
+    }
+    rows = [r for r in _kernel_rows(lib) if "solve_kernel" in r["name"] or "reduced_kernel" in r["name"]]
+    assert rows
+    bad = {r["name"]: r["scratch"] for r in rows if r["scratch"] > KNOWN_SCRATCH.get(r["name"], 0)}
+    assert not bad, bad
+    # the kernels of BASELINE configs 2-5 (N = 30 reduced-native + tail, N = 50 time-optimal) by name
+    by = {r["name"]: r for r in rows}
+    for name in ("mpmpc_reduced_kernel<64, 16, false>", "mpmpc_reduced_kernel<32, 16, false>", "mpmpc_solve_kernel<64, 16, false, 2>",
+                 "mpmpc_solve_kernel<64, 32, false, 3>"):
+        assert by[name]["scratch"] == 0, by[name]

@@ -180,7 +180,7 @@ def test_warm_start_reproduces_the_cold_solution(cfgid, G, emu, track):
     qp = emu.assemble(cfg, track, _inputs(sc), obstacles=sc.obstacles)
     st = mpmpc.default_settings()
     cold, act = emu.solve_warm(cfg, st, qp, np.zeros((sc.B, mpmpc.stage_ld(sc.N)), np.int32), G=G)
-    ref = emu.solve(cfg, st, qp, G=G)
+    ref, _ = emu.solve_launch(cfg, st, qp, G=G)          # the launcher's cold sequence of kernels
     assert np.array_equal(cold.status, ref.status) and np.array_equal(cold.u0, ref.u0)      # no guess: the plain path
     ok = cold.status == 1
     assert np.all((act[ok, 0] >> 30) & 1) and not np.any(act[~ok])
