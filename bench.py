@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """bench.py - MPC QP solves/sec on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-A step = one pass of the hot path (assembly + ADMM / certified polish, one launch of the solve kernel, which
-builds its QP in registers) over one batch of B synthetic controller instances whose inputs are already
-resident in HBM.  N=1 workload: config 2 of
+A step = one pass of the hot path over one batch of B synthetic controller instances whose inputs are already resident
+in HBM: the solve launch assembles its QP in registers (the reference's MPC._init_problem) and solves it.  With the
+reference's own weights that is the reduced-native kernel (closed-form speed, Ruiz pass, OSQP's first iterate as start,
+interior point, active-set round, KKT certificate on the (e_y, e_psi, kappa) problem) plus a tail launch of the general
+kernel for what it cannot certify (phase 1 / Farkas ray; the OSQP ADMM iteration only as the last fallback).  N=1 workload: config 2 of
 BASELINE.json (B=1024 independent initial poses, reference tracking, horizon 30).  With --gpus N
 every rank solves its own batch of the same size (weak scaling, no data-path collective; the
 instances are independent) and `value` is the whole-job rate.
@@ -69,6 +71,13 @@ _FLOPS = {
 }
 
 
+# the reduced-native kernels (mpmpc_settings::native; profiles/census.py through the launcher's sequence of kernels)
+_FLOPS_NATIVE = {
+    1: dict(algorithmic=(32648.0, 18134.0), executed=(90024.0, 40982.0), N=30),
+    -3: dict(algorithmic=(29263.0, 21327.0), executed=(41182.0, 47796.0), N=30),
+}
+
+
 def qp_objective(qp, N, z):
     """1/2 z'Pz + q'z per instance from the stage-blocked fields of mpmpc_assemble (diagonal weights: fields 22-26 the
     cost diagonal, 17-21 the cost vector; include/mpmpc.h)"""
@@ -81,13 +90,60 @@ def qp_objective(qp, N, z):
     return (0.5 * Px * x * x + qx * x).sum(axis=(1, 2)) + (0.5 * Pu * u * u + qu * u).sum(axis=(1, 2))
 
 
+def algorithm_text(cfg, settings):
+    """what the solve launches of this configuration execute, in words (for config.workload)"""
+    if not settings.polish:
+        return "restated OSQP ADMM at the settings given (no polish): the reference's own solver call"
+    if native_path(cfg, settings):
+        return ("reduced-native kernel per instance: speed in closed form, one Ruiz pass + OSQP's first iterate (one 2x2-block KKT solve) "
+                "as start, interior point, active-set round(s), KKT certificate on the (e_y, e_psi, kappa) QP, roll-forward of t; "
+                "uncertified instances go to a tail launch: phase 1 (Farkas ray) and, only if that cannot decide, the OSQP ADMM iteration")
+    red = "reduced 2x2-block" if reduced_polish(cfg, settings) else "full 3x3-block"
+    return ("general kernel per instance: %d Ruiz pass(es), %d OSQP start step(s), %s interior point + active-set round(s) + KKT "
+            "certificate; phase 1 (Farkas ray) and then the full OSQP ADMM run for what that cannot certify" %
+            (settings.early_scaling, settings.early_polish, red))
+
+
+def native_path(cfg, settings):
+    """mirror of mpmpc::reduced_native (csrc/mpmpc_reduced.hpp): do the batch launches run the reduced-native kernels?"""
+    return bool(settings.native and reduced_polish(cfg, settings) and settings.early_polish == 1 and settings.max_iter > 1
+                and settings.ipm_start_mu > 0.0 and settings.scaling > 0)
+
+
+def rocprof_kernel_average(config, B, lib_version):
+    """Average duration [ms] of the solve launches of one step from the committed `rocprofv3 --kernel-trace --stats` of
+    this command (profiles/r3/bench_*_kernel_stats.csv), used for roofline.avg_ms when - and only when - the summary was
+    measured on a library built from the same sources as the one running now (profiles/r3/pmc_summary.json records the
+    hash).  -> (ms or None, source text)"""
+    import csv
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r3", "pmc_summary.json")))
+        src = d.get("library_source_hash", "")
+    except Exception:
+        return None, "no profiles/r3/pmc_summary.json"
+    if not src or src not in lib_version:
+        return None, "profiles/r3 was measured on library sources %s, this run is %s" % (src or "?", lib_version)
+    name = {(2, 1024): "bench_cfg2", (2, 65536): "bench_cfg2_b65536", (3, 4096): "bench_cfg3", (4, 8192): "bench_cfg4", (5, 8192): "bench_cfg5"}.get((config, B))
+    path = os.path.join(ROOT, "profiles", "r3", "%s_kernel_stats.csv" % name) if name else None
+    if not path or not os.path.exists(path):
+        return None, "no kernel trace committed for this workload"
+    total, calls = 0.0, None
+    for r in csv.DictReader(open(path)):
+        if "mpmpc_reduced_kernel" in r["Name"] or "mpmpc_solve_kernel" in r["Name"]:
+            total += float(r["TotalDurationNs"])
+            calls = max(calls or 0, int(r["Calls"]))
+    if not calls:
+        return None, "no solve kernel in %s" % path
+    return total / calls / 1e6, "profiles/r3/%s_kernel_stats.csv (rocprofv3 --kernel-trace --stats, same library sources %s)" % (name, src)
+
+
 def reduced_polish(cfg, settings):
     """mirror of mpmpc::reducible (csrc/mpmpc_core.hpp): may the polish solve the (e_y, e_psi, kappa) problem?"""
     return bool(settings.reduce and settings.polish and cfg.Q[2] == 0.0 and cfg.QN[2] == 0.0 and not any(cfg.QN_offdiag)
                 and cfg.R[0] > 0.0 and cfg.xmin[2] <= -1e30 and cfg.xmax[2] >= 1e30 and cfg.xmin[1] <= -1e30 and cfg.xmax[1] >= 1e30)
 
 
-def k2_flops(N, status, ipm_iters, kind, reduced):
+def k2_flops(N, status, ipm_iters, kind, reduced, native=False):
     """flops of a batch by the fit above, scaled linearly in the number of stages away from the fitted horizon"""
     total = 0.0
     split = N + 1 <= 32
@@ -96,19 +152,23 @@ def k2_flops(N, status, ipm_iters, kind, reduced):
         if not m.any():
             continue
         f = _FLOPS.get((split, reduced, stt)) or _FLOPS.get((split, False, stt)) or _FLOPS[(split, False, 1)]
+        if native:
+            f = _FLOPS_NATIVE[stt]
         c0, c1 = f[kind]
         total += float(np.sum(c0 + c1 * ipm_iters[m].astype(float))) * (N + 1) / (f["N"] + 1)
     return total
 
 
-def cpu_baseline(tr, sc, seconds=10.0):
+def cpu_baseline(tr, sc, seconds=10.0, stock=False):
     """The oracle's C port (oracle/osqp_port.c: own restatement of the reference's assembly + OSQP +
-    certified polish) timed on the host cores of this box, on a bounded sample of the workload."""
+    certified polish) timed on the host cores of this box, on a bounded sample of the workload.
+    stock: the port at polish = 0, early_polish = 0, phase1 = 0 - restated OSQP at its defaults and nothing else, the
+    arithmetic of the reference's own solver call (src/MPC.py:159,183)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_c
     limits = dict(umin=scenarios.UMIN, umax=scenarios.UMAX, xmin=scenarios.XMIN, xmax=scenarios.XMAX,
                   ay_max=scenarios.AY_MAX, wheelbase=scenarios.CAR_LENGTH)
-    return oracle_c.timed_baseline(tr, sc, scenarios.WEIGHTS[sc.weights], limits, seconds)
+    return oracle_c.timed_baseline(tr, sc, scenarios.WEIGHTS[sc.weights], limits, seconds, stock=stock)
 
 
 def stock_osqp_leg(tr, sc, ref, seconds=3.0):
@@ -148,25 +208,25 @@ def stock_osqp_leg(tr, sc, ref, seconds=3.0):
 
 def pmc_traffic_bytes(kernel_prefix, B, lib_version):
     """HBM bytes per launch of one kernel from the committed rocprofv3 PMC summary of THIS command
-    (profiles/r2/pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as
+    (profiles/r3/pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  The summary records the source hash of the library it was measured
     on: the figure is only reported when the library running now was built from the same sources, otherwise None
     (with the reason) - a counter reading of another kernel is not this run's traffic."""
-    path = os.path.join(ROOT, "profiles", "r2", "pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", "r3", "pmc_summary.json")
     key_f, key_w = ("pmc_fetch", "pmc_write") if B == 1024 else ("pmc_fetch_b%d" % B, "pmc_write_b%d" % B)
     try:
         d = json.load(open(path))
     except Exception:
-        return None, "no PMC summary committed (profiles/r2/pmc_summary.json)"
+        return None, "no PMC summary committed (profiles/r3/pmc_summary.json)"
     src = d.get("library_source_hash", "")
     if not src or src not in lib_version:
-        return None, "profiles/r2/pmc_summary.json was measured on library sources %s, this run is %s" % (src or "?", lib_version)
+        return None, "profiles/r3/pmc_summary.json was measured on library sources %s, this run is %s" % (src or "?", lib_version)
     try:
         f = next(v for k, v in d[key_f].items() if k.startswith(kernel_prefix))["FETCH_SIZE"]["mean"]
         w = next(v for k, v in d[key_w].items() if k.startswith(kernel_prefix))["WRITE_SIZE"]["mean"]
-        return (2.0 * f + w) * 1024.0, "profiles/r2/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same library sources %s)" % src
+        return (2.0 * f + w) * 1024.0, "profiles/r3/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same library sources %s)" % src
     except Exception:
-        return None, "profiles/r2/pmc_summary.json has no counters for this kernel at B = %d" % B
+        return None, "profiles/r3/pmc_summary.json has no counters for this kernel at B = %d" % B
 
 
 def main():
@@ -285,21 +345,18 @@ def _main(real_stdout):
     # one result buffer, outside the timed region: the shards' controls gathered on every rank (the only data
     # collective a caller of the sharded path may want), checked on rank 0 against ONE process solving the whole
     # world*B batch of the same seed on its own GPU
-    gather_check = None
-    if dist is not None and world > 1:
-        u_all, s_all = bench_dist.gather_controls(dist, sol.u0, sol.status, B * world, device=dev)
-        if rank == 0:
-            cfg1 = mpmpc.make_config(N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX,
-                                     scenarios.AY_MAX, scenarios.CAR_LENGTH, circular=True, max_batch=B * world,
-                                     device=local_rank)
-            h1 = mpmpc.Handle(cfg1, settings)
-            h1.set_path(tr.kappa, tr.v_ref, tr.ds_next)
-            one = h1.solve(sc_all.wp_id, sc_all.x0, sc_all.cc_prev, sc_all.lb, sc_all.ub)
-            h1.close()
-            okm = (one.status == 1) & (s_all == 1)
-            gather_check = {"instances": int(B * world), "status_equal": bool(np.array_equal(one.status, s_all)),
-                            "max_abs_u_diff": float(np.max(np.abs(one.u0[okm] - u_all[okm]))) if okm.any() else None,
-                            "note": "all-gathered (u0, status) of the %d shards vs one process solving the whole batch" % world}
+    def solve_whole():
+        cfg1 = mpmpc.make_config(N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX,
+                                 scenarios.AY_MAX, scenarios.CAR_LENGTH, circular=True, max_batch=B * world,
+                                 device=local_rank)
+        h1 = mpmpc.Handle(cfg1, settings)
+        h1.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+        one = h1.solve(sc_all.wp_id, sc_all.x0, sc_all.cc_prev, sc_all.lb, sc_all.ub)
+        h1.close()
+        return one
+
+    gather_check = bench_dist.gather_check(dist, rank, sol.u0, sol.status, B * world, solve_whole, device=dev)
+    ranks = bench_dist.rank_reports(dist, cfg.device, sol.status, device=dev)
 
     if rank == 0:
         value = world * B * args.steps / dt
@@ -310,29 +367,38 @@ def _main(real_stdout):
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "world_size": int(dist.get_world_size()) if dist is not None else 1,
             "ms_per_step_by_rank": [1e3 * t / args.steps for t in dt_ranks],
-            "config": {"workload": "config%d: batch=%d independent poses per GPU, %s weights, N=%d, %s corridor, "
-                                   "OSQP-default ADMM, certified polish tried after %d iterations" %
+            "config": {"workload": "config%d: batch=%d independent poses per GPU, %s weights, N=%d, %s corridor; %s" %
                                    (args.config, B, sc_all.weights, N, "obstacle" if sc_all.obstacles else "free",
-                                    settings.early_polish),
+                                    algorithm_text(cfg, settings)),
                        "batch_per_gpu": B, "horizon": N, "parallelism": "batch-shard x%d" % world},
         }
-        if gather_check is not None:
+        out["rccl_world_size"] = int(dist.get_world_size()) if dist is not None else 0      # 0: no process group (one process, no launcher)
+        out["ranks"] = ranks              # per rank: HIP device ordinal of its handle, status counts of its shard
+        if gather_check:
             out["gather_check"] = gather_check
         lib_version = h.lib.mpmpc_version().decode()
         out["library"] = lib_version
         bytes_k2 = algorithmic_bytes_per_solve(N) * B
-        traffic, traffic_src = pmc_traffic_bytes("mpmpc_solve_kernel", B, lib_version) if args.config == 2 else (None, "PMC passes are collected for config 2 only")
-        out["roofline"] = {"bound": "hbm", "kernel": "mpmpc_solve_kernel", "achieved": bytes_k2 / (ms_k2 * 1e-3) / 1e9,
+        nat = native_path(cfg, settings)
+        k2_name = "mpmpc_reduced_kernel" if nat else "mpmpc_solve_kernel"
+        traffic, traffic_src = pmc_traffic_bytes(k2_name, B, lib_version) if args.config == 2 else (None, "PMC passes are collected for config 2 only")
+        ms_events = ms_k2
+        ms_prof, ms_src = rocprof_kernel_average(args.config, B, lib_version)
+        if ms_prof is not None:
+            ms_k2 = ms_prof          # the committed rocprofv3 kernel average of the same library
+        out["roofline"] = {"bound": "hbm", "kernel": k2_name + (" (+ tail launch of mpmpc_solve_kernel)" if nat else ""),
+                           "achieved": bytes_k2 / (ms_k2 * 1e-3) / 1e9,
                            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bytes_k2 / (ms_k2 * 1e-3) / HBM_PEAK,
                            "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes": bytes_k2, "bytes_per_solve": algorithmic_bytes_per_solve(N), "avg_ms": ms_k2,
+                           "avg_ms_hip_events": ms_events, "avg_ms_source": ms_src if ms_prof is not None else "HIP events on the library's stream in this run (%s)" % ms_src,
                            "note": "SURVEY 8(d) bytes: 8(7N+3) in + 8(5N+5)+8 out per solve; the launch writes no multipliers here "
                                    "(mpmpc_set_outputs(0)).  K2 is FP64-VALU / dependency-chain bound, not HBM bound (DESIGN.md "
                                    "section 5): see roofline_fp64"}
         ipm = sol.iters[:, 1]
         red = reduced_polish(cfg, settings)
-        fa, fe = k2_flops(N, sol.status, ipm, "algorithmic", red), k2_flops(N, sol.status, ipm, "executed", red)
-        out["roofline_fp64"] = {"bound": "fp64-valu", "kernel": "mpmpc_solve_kernel", "peak": FP64_VALU_PEAK / 1e12, "unit": "TFLOP/s",
+        fa, fe = k2_flops(N, sol.status, ipm, "algorithmic", red, nat), k2_flops(N, sol.status, ipm, "executed", red, nat)
+        out["roofline_fp64"] = {"bound": "fp64-valu", "kernel": k2_name, "peak": FP64_VALU_PEAK / 1e12, "unit": "TFLOP/s",
                                 "achieved": fa / (ms_k2 * 1e-3) / 1e12, "frac": fa / (ms_k2 * 1e-3) / FP64_VALU_PEAK,
                                 "frac_algorithmic": fa / (ms_k2 * 1e-3) / FP64_VALU_PEAK,
                                 "frac_executed": fe / (ms_k2 * 1e-3) / FP64_VALU_PEAK,
@@ -351,7 +417,12 @@ def _main(real_stdout):
                                             "launch; the solve launch assembles its own QP in registers"}
         st, cnt = np.unique(sol.status, return_counts=True)
         out["status_counts"] = {int(s): int(c) for s, c in zip(st, cnt)}
-        out["iters"] = {"admm_mean": float(sol.iters[:, 0].mean()), "admm_max": int(sol.iters[:, 0].max()),
+        # iters[:, 0] is OSQP's iteration counter: 1 = the start step alone (OSQP's first iterate, one KKT solve, no
+        # iteration of the ADMM loop); only an instance that fell back to the full OSQP run reports more
+        adm = np.where(sol.iters[:, 0] > settings.early_polish, sol.iters[:, 0], 0) if settings.polish and settings.early_polish > 0 else sol.iters[:, 0]
+        out["iters"] = {"start_steps_per_instance": int(settings.early_polish) if settings.polish else 0,
+                        "admm_loop_iterations_mean": float(adm.mean()), "admm_loop_iterations_max": int(adm.max()),
+                        "instances_in_admm_fallback": int(np.sum(adm > 0)),
                         "ipm_mean": float(sol.iters[:, 1].mean()), "ipm_max": int(sol.iters[:, 1].max()),
                         "ipm_histogram": {int(k): int(v) for k, v in zip(*np.unique(sol.iters[:, 1], return_counts=True))}}
         # the same step from HOST buffers (mpmpc_solve: upload + assembly and solve in one launch + download): reported, never `value`
@@ -364,6 +435,9 @@ def _main(real_stdout):
             sc_rank = scenarios.Scenario(sc_all.name, N, sc_all.weights, sc_all.obstacles, wp, x0, cc, lb, ub)
             base, ref = cpu_baseline(tr, sc_rank)
             out["cpu_baseline"] = base
+            # ... and the arithmetic the reference's own call performs (src/MPC.py:159,183: OSQP at its defaults, no polish,
+            # no phase 1) through the same C port, on the same sample
+            out["cpu_baseline_stock"] = cpu_baseline(tr, sc_rank, seconds=6.0, stock=True)[0]
             ns = ref["status"].size
             both = (ref["status"] == 1) & (sol.status[:ns] == 1)
             # The stock weights put no cost on the steering input, on e_psi and on t (src/simulation.py:101-111): the QP is

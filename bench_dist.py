@@ -56,3 +56,36 @@ def gather_controls(dist, u0: np.ndarray, status: np.ndarray, total: int, device
         out_u[lo:hi] = block[:, :2]
         out_s[lo:hi] = block[:, 2].astype(np.int32)
     return out_u, out_s
+
+
+def rank_reports(dist, device_ordinal: int, status: np.ndarray, device=None) -> list:
+    """Per rank, on every rank: the HIP device ordinal its handle is bound to and the status counts of its shard
+    (solved, solved-inaccurate, infeasible, anything else)."""
+    mine = [int(device_ordinal), int(np.sum(status == 1)), int(np.sum(status == 2)), int(np.sum(status == -3)),
+            int(np.sum((status != 1) & (status != 2) & (status != -3)))]
+    if dist is None:
+        rows = [mine]
+    else:
+        import torch
+        t = torch.tensor(mine, dtype=torch.int64, device=device or "cpu")
+        parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, t)
+        rows = [[int(v) for v in p.cpu().tolist()] for p in parts]
+    return [{"rank": r, "device": row[0], "solved": row[1], "solved_inaccurate": row[2], "infeasible": row[3], "other": row[4]}
+            for r, row in enumerate(rows)]
+
+
+def gather_check(dist, rank: int, u0: np.ndarray, status: np.ndarray, total: int, solve_whole, device=None):
+    """One result buffer: the shards' (u0, status) all-gathered on every rank, and - on rank 0 - checked against ONE
+    process solving the whole batch (`solve_whole()` -> object with .u0, .status).  None without a process group of
+    more than one rank; the dict of bench.py's `gather_check` entry on rank 0; {} on the other ranks."""
+    if dist is None or dist.get_world_size() < 2:
+        return None
+    u_all, s_all = gather_controls(dist, u0, status, total, device=device)
+    if rank != 0:
+        return {}
+    one = solve_whole()
+    okm = (one.status == 1) & (s_all == 1)
+    return {"instances": int(total), "status_equal": bool(np.array_equal(one.status, s_all)),
+            "max_abs_u_diff": float(np.max(np.abs(one.u0[okm] - u_all[okm]))) if okm.any() else None,
+            "note": "all-gathered (u0, status) of the %d shards vs one process solving the whole batch" % dist.get_world_size()}

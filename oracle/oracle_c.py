@@ -157,12 +157,15 @@ def usable_cpus():
     return n
 
 
-def timed_baseline(track, sc, weights, limits, seconds=15.0, nthreads=0):
-    """bench.py's cpu_baseline leg: the reference-equivalent CPU path (assembly + fresh setup + ADMM +
-    certified polish per instance) on a bounded sample, all host cores."""
+def timed_baseline(track, sc, weights, limits, seconds=15.0, nthreads=0, stock=False):
+    """bench.py's cpu_baseline legs: per instance assembly + fresh setup (Ruiz scaling, sparse LDL) + solve on a bounded
+    sample, all host cores.  stock = False: the port's certified path (one OSQP start step + interior point + active-set
+    round + KKT certificate, phase 1 for what that cannot certify, OSQP's ADMM as the last fallback) - the CPU twin of the
+    device's default algorithm.  stock = True: restated OSQP at its defaults and nothing else (polish = 0, early_polish = 0,
+    phase1 = 0): what the reference's own call executes (src/MPC.py:159,183)."""
     cfg = mpc_cfg(sc.N, weights, limits["umin"], limits["umax"], limits["xmin"], limits["xmax"], limits["ay_max"],
                   limits["wheelbase"])
-    st = settings()
+    st = settings(polish=0, early_polish=0, phase1=0) if stock else settings()
     args = (cfg, st, track.kappa, track.v_ref, track.ds_next)
 
     def run(n, nt):
@@ -186,8 +189,13 @@ def timed_baseline(track, sc, weights, limits, seconds=15.0, nthreads=0):
             best = (dt_c, nt_c, reps, out_c)
     dt, nt, reps, out = best
     nsamp = sc.B
+    what = ("restated OSQP at its defaults (eps 1e-3, no polish, no phase 1): the arithmetic of the reference's own solver call; "
+            "ADMM iterations mean %.1f / max %d" % (float(np.mean(out["iters"][:, 0])), int(np.max(out["iters"][:, 0])))) if stock else \
+           ("the device's default algorithm on the CPU: one OSQP start step + interior point (mean %.2f iterations) + active-set round + "
+            "KKT certificate, phase 1 for the rest, OSQP ADMM only as fallback (%d of the sample's instances)" %
+            (float(np.mean(out["iters"][:, 1])), int(np.sum(out["iters"][:, 0] > 1))))
     base = dict(value=nsamp / dt, unit="solves/s", cores=nt, kind="port", usable_cpus=usable_cpus(),
                 sample="first %d instances of the workload, %d passes (%.1f s); C restatement (oracle/osqp_port.c): numpy-equivalent "
-                       "assembly + fresh OSQP-style setup (Ruiz scaling, sparse LDL) + ADMM at OSQP defaults + "
-                       "certified polish per instance, OpenMP over instances" % (nsamp, reps, dt * reps))
+                       "assembly + fresh OSQP-style setup (Ruiz scaling, sparse LDL, ordering cached) per instance, OpenMP over "
+                       "instances; %s" % (nsamp, reps, dt * reps, what))
     return base, out

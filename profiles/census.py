@@ -44,7 +44,7 @@ for i in range(B):
     inp = (sc.wp_id[i:i + 1], sc.x0[i:i + 1], sc.cc_prev[i:i + 1], sc.lb[i:i + 1], sc.ub[i:i + 1])
     qp = emu.assemble(cfg, tr, inp, obstacles=sc.obstacles)
     cnt.emu_op_flops(out, 1)
-    sol = emu.solve(cfg, st, qp, G=64)
+    sol, _ = emu.solve_launch(cfg, st, qp, G=64)          # the launcher's own sequence: reduced-native kernel, then its tail
     cnt.emu_op_flops(out, 1)
     par, split, ser_exec, ser_one = out[0], out[1], out[2], out[3]
     algorithmic = (N + 1) * par + ((N + 1) + 2.0 * N / 3.0) * split + (N + 1) * ser_one

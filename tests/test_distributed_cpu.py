@@ -42,6 +42,17 @@ def _worker(rank, world, port, total, N, out_dir):
     sol = backend.solve(wp, x0, cc, lb, ub)
     dt = bench_dist.max_over_ranks(dist, 0.25 * (rank + 1))
     u_all, s_all = bench_dist.gather_controls(dist, sol.u0, sol.status, total)
+    # the two bookkeeping calls of bench.py's multi-rank line, end to end: per-rank device ordinal + status counts, and the
+    # all-gathered result buffer checked on rank 0 against ONE process solving the whole batch
+    def solve_whole():
+        one = T.EmuBackend(cfg, mpmpc.default_settings())
+        one.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+        return one.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    check = bench_dist.gather_check(dist, rank, sol.u0, sol.status, total, solve_whole)
+    ranks = bench_dist.rank_reports(dist, 40 + rank, sol.status)
+    import json
+    with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as f:
+        json.dump({"check": check, "ranks": ranks}, f)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), u=u_all, s=s_all, dt=dt, n_local=wp.size)
     dist.barrier()
     dist.destroy_process_group()
@@ -65,6 +76,18 @@ def test_two_ranks_gloo_match_single_process(tmp_path):
         ok = full.status > 0
         assert np.array_equal(g["u"][ok], full.u0[ok])
         assert float(g["dt"]) == 0.5      # MAX over ranks of (0.25, 0.5)
+    # bench.py's gather_check / ranks entries (bench_dist.gather_check, rank_reports) as the two ranks produced them
+    import json
+    rep = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(world)]
+    assert rep[1]["check"] == {} and rep[0]["check"]["status_equal"] is True and rep[0]["check"]["instances"] == total
+    assert rep[0]["check"]["max_abs_u_diff"] == 0.0
+    for r in rep:
+        assert [x["device"] for x in r["ranks"]] == [40, 41] and [x["rank"] for x in r["ranks"]] == [0, 1]
+        assert sum(x["solved"] + x["solved_inaccurate"] + x["infeasible"] + x["other"] for x in r["ranks"]) == total
+        assert sum(x["solved"] for x in r["ranks"]) == int((full.status == 1).sum())
+    # without a process group: no gather, one report
+    assert bench_dist.gather_check(None, 0, full.u0, full.status, total, None) is None
+    assert bench_dist.rank_reports(None, 3, full.status)[0]["device"] == 3
 
 
 def _run_bench(args, env_extra=None, timeout=300):
