@@ -125,6 +125,13 @@ typedef struct {
   double as_add_fraction; /* active-set rounds add only the bounds violated by at least this fraction of the round's worst
                             violation (measured on the scaled variable); 0: every violated bound, the plain primal-dual
                             active-set update; the retry after a failed attempt uses at least 0.5.  Default 0.25. */
+  int32_t phase1_accept; /* 1 (default): an instance phase 1 proves infeasible by LESS than OSQP's primal termination tolerance
+                            (eps_abs + eps_rel max(|Ax|, |z|) at the least-violation point: millimetres at eps = 1e-3) is not
+                            reported infeasible - the reference's OSQP call accepts such a problem as "solved" and the
+                            reference drives the plan (src/MPC.py:159,183-206).  Its violated boxes are widened to 1.5 times the
+                            least violation, the polish solves that problem, and the plan comes back as MPMPC_SOLVED_INACCURATE
+                            with the violation in resid[0] (a usable status: no fallback step).  0: every proven infeasibility
+                            is reported as MPMPC_PRIMAL_INFEASIBLE however small the margin (batch sweeps that want the verdict). */
   int32_t native;        /* 1 (default): where `reduce` applies and the settings are the defaults of the early attempt
                             (early_polish = 1, ipm_start_mu > 0) the batch launches run the REDUCED-NATIVE kernels: a lane
                             never holds the 3-state problem - v in closed form at load time, own Ruiz pass / start / interior

@@ -255,6 +255,8 @@ struct Solver {
   R mI[3], a[6], b[2], g[5], p[5], q[5], D[5], Eeq[3], Eb[5], c;
   Mk p1_feasible;        // phase 1 converged to a point that violates nothing: the start of a second polish attempt
   Mk p1_converged;       // phase 1 ended at its converged optimum (not at an earlier iterate that already passed the ray test)
+  Mk p1_marginal;        // infeasible by less than OSQP's own primal tolerance: solved on the boxes relaxed by that much (phase1_accept)
+  R p1_viol;             // ... and the violation (unscaled) the plan is allowed
   R pod[3], hod[3];      // FQ: off-diagonals (01, 02, 12) of the terminal cost block and of the terminal inv(H) block
   Mk term;               // this lane holds stage N
   R leq[3], lb[5], ub[5];
@@ -2195,9 +2197,49 @@ struct Solver {
     Mk certA = (f_nrm > eps1) & (f_lhs < -eps1 * f_nrm) & (f_m < eps1 * f_nrm);
     Mk certB = p1_converged & (prim > R(st.cert_tol)) & (f_nrm > R(0.0)) & (f_lhs < R(-100.0) * f_m) & (f_lhs < R(0.0));
     Mk cert = run & (certA | certB);
+    // MARGINALLY infeasible (phase1_accept, default): the least violation is below the primal tolerance at which the
+    // reference's own OSQP call stops and returns a plan - eps_abs + eps_rel max(|Ax|, |z|) at eps = 1e-3, i.e. corridor
+    // violations of millimetres (src/MPC.py:159,183 run OSQP at its defaults; the reference then DRIVES that plan instead
+    // of taking its fallback branch).  Such an instance is not reported infeasible: every box its least-violation point
+    // leaves is widened to 1.5 times that violation, the polish runs once more from that point (pass 1 of run(), like a
+    // feasible instance), and the result is returned as SOLVED_INACCURATE with the violation in resid[0].
+    p1_marginal = L::mfalse();
+    p1_viol = R(0.0);
+    if (st.phase1_accept) {
+      // max(|Ax|, |z|) of OSQP's test: the identity rows make it the largest entry of the plan - where the corridor cannot
+      // be met the steering sits on its bound, so the largest finite box bound of the instance stands for the iterate OSQP
+      // would stop at (stock limits: 1e-3 + 1e-3 x 6.47 = 7.5 mm)
+      R nAx(0.0);
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) {
+        const R lo0 = lo_raw(j), hi0 = hi_raw(j);
+        R m = abs_(D[j] * xs[j]);
+        m = max_(m, sel(lo0 > R(-INF_BOUND), abs_(lo0), R(0.0)));
+        m = max_(m, sel(hi0 < R(INF_BOUND), abs_(hi0), R(0.0)));
+        nAx = max_(nAx, sel(valid[j], m, R(0.0)));
+      }
+      nAx = L::gmax(nAx);
+      p1_marginal = cert & !(prim > fma_(R(st.eps_rel), nAx, R(st.eps_abs)));
+      cert = cert & !p1_marginal;
+      if (L::wany(p1_marginal)) {
+        p1_viol = sel(p1_marginal, prim, R(0.0));
+        MPMPC_UNROLL
+        for (int j = 0; j < 5; ++j) {
+          const R xu = D[j] * xs[j], lo0 = lo_raw(j), hi0 = hi_raw(j);
+          const R wl = sel(p1_marginal & valid[j] & (lo0 > R(-INF_BOUND)), max_(lo0 - xu, R(0.0)), R(0.0));
+          const R wh = sel(p1_marginal & valid[j] & (hi0 < R(INF_BOUND)), max_(xu - hi0, R(0.0)), R(0.0));
+          const R lo1 = fma_(R(-1.5), wl, lo0), hi1 = fma_(R(1.5), wh, hi0);
+          L::cold_put(COLD_RAW + 3 + j, lo1);
+          L::cold_put(COLD_RAW + 8 + j, hi1);
+          lb[j] = sel(p1_marginal, Eb[j] * lo1, lb[j]);
+          ub[j] = sel(p1_marginal, Eb[j] * hi1, ub[j]);
+        }
+        L::fence();
+      }
+    }
     // FEASIBLE to tolerance: phase 1 converged and its point violates nothing.  That point - inside every box, well
     // centred by the barrier - is handed back as the start of a second polish attempt (Solver::run, pass 1).
-    p1_feasible = run & !cert & p1_converged & !(prim > R(st.cert_tol));
+    p1_feasible = run & !cert & ((p1_converged & !(prim > R(st.cert_tol))) | p1_marginal);
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) { x[j] = sel(p1_feasible, xs[j], x[j]); yb[j] = sel(p1_feasible, zero, yb[j]); }
     MPMPC_UNROLL
@@ -2286,6 +2328,8 @@ struct Solver {
     // central path; seen once in 12 000 randomised instances, at N = 3): ~10 interior-point iterations instead of the
     // hundreds of ADMM iterations plus a polish that jams again.  Pass 2: the remaining Ruiz passes and the full OSQP run.
     Mk retry = L::mfalse();
+    p1_marginal = L::mfalse();
+    p1_viol = R(0.0);
     _Pragma("nounroll")
     for (int pass = 0; pass < 3; ++pass) {
       if (pass == 1 && !L::wany(retry)) continue;
@@ -2325,6 +2369,15 @@ struct Solver {
         MPMPC_TICK_BEGIN(3);
         if (st.polish) polish(st, attempt);
         MPMPC_TICK_END(3);
+        if constexpr (P1) {
+          if (pass == 1) {
+            // a marginally infeasible instance (phase1_accept) ends here: the optimum over the relaxed boxes, or - if the
+            // polish could not certify that - phase 1's least-violation point itself; either way a usable, inaccurate plan
+            const Mk mg = live & p1_marginal & ((status == MPMPC_SOLVED) | (status == MPMPC_UNSOLVED));
+            status = seli(mg, I(MPMPC_SOLVED_INACCURATE), status);
+            pri_res = sel(mg, p1_viol, pri_res);
+          }
+        }
         which = live & (status == MPMPC_UNSOLVED);
         if (!attempt || mode == 1 || !L::wany(which)) break;
       }

@@ -272,6 +272,47 @@ def stage_loop():
         print("G6 N=%d: %d steps, infeasible %d, final s %.4f, exit(1) %s" % (N, st.size, (st < 0).sum(), car.s, exited))
 
 
+def stage_loop_stock():
+    """G6s: the SAME closed loop with the stand-in in STOCK mode - the restated OSQP at its defaults and nothing else
+    (osqp_np.Settings(polish=0): eps 1e-3, no polish, no phase 1), i.e. the arithmetic of the reference's own solver call
+    (src/MPC.py:159,183).  Recorded per step: the inputs (teacher forcing), OSQP's verdict and which branch of
+    src/MPC.py:185-220 the reference took (fresh plan / fallback).  ADVICE r2: the default path of the build must take
+    the same branch (tests/test_emul_parity.py, tests/test_gpu_parity.py)."""
+    import osqp_np
+    saved = osqp.SETTINGS
+    osqp.SETTINGS = osqp_np.Settings(polish=0)
+    try:
+        for N in (10, 30):
+            m, rp = build_track()
+            add_obstacles(m)
+            car, mpc = make_controller(rp, N, "stock")
+            rp.compute_speed_profile(dict(SPEED))
+            rec = {k: [] for k in ("s", "pose", "cc_prev", "wp_id", "x0", "lb", "ub", "status", "iters", "u", "counter", "pri_res")}
+            exited = False
+            while car.s < rp.length:
+                s, pose = car.s, [car.temporal_state.x, car.temporal_state.y, car.temporal_state.psi]
+                cc_prev = mpc.current_control.copy()
+                osqp.CAPTURES.clear()
+                try:
+                    u = mpc.get_control()
+                except SystemExit:
+                    exited = True
+                    break
+                res = osqp.CAPTURES[-1]["res"]
+                ub, lb, _ = rp.update_path_constraints(car.wp_id + 1, N, 2 * car.safety_margin, car.safety_margin)
+                for k, v in (("s", s), ("pose", pose), ("cc_prev", cc_prev), ("wp_id", car.wp_id), ("x0", car.spatial_state[:]),
+                             ("lb", lb), ("ub", ub), ("status", res.status), ("iters", res.iters), ("u", np.array(u, float)),
+                             ("counter", mpc.infeasibility_counter), ("pri_res", res.pri_res)):
+                    rec[k].append(v)
+                car.drive(u)
+            np.savez_compressed(os.path.join(HERE, "g6s_stock_loop_N%d.npz" % N), **{k: np.array(v) for k, v in rec.items()},
+                                N=np.array([N]), final_s=np.array([car.s]), exited=np.array([exited]))
+            st = np.array(rec["status"])
+            print("G6s N=%d: %d steps, statuses %s, final s %.4f, exit(1) %s" % (N, st.size, dict(zip(*np.unique(st, return_counts=True))), car.s, exited))
+    finally:
+        osqp.SETTINGS = saved
+
+
 def stage_raster():
     """G7: skimage.draw.line_aa cell sequences (order matters to _compute_free_segments)."""
     from skimage.draw import line_aa
@@ -295,7 +336,7 @@ def stage_raster():
 
 
 STAGES = dict(raster=stage_raster, path=stage_path, speed=stage_speed, corridor=stage_corridor, assembly=stage_assembly,
-              loop=stage_loop)
+              loop=stage_loop, loop_stock=stage_loop_stock)
 
 if __name__ == "__main__":
     assert os.getcwd().rstrip("/") == "/root/reference/src", "run with cwd=/root/reference/src"

@@ -140,7 +140,7 @@ def test_c_port_agrees_with_emulation_on_a_larger_sample(emu, track):
     sc = scenarios.make(4, track, B=256)
     cfg = T.stock_config(sc.N, sc.weights)
     qp = emu.assemble(cfg, track, _inputs(sc))
-    sol = emu.solve(cfg, mpmpc.default_settings(), qp, G=64)
+    sol = emu.solve(cfg, mpmpc.default_settings(phase1_accept=0), qp, G=64)
     ocfg = OC.mpc_cfg(sc.N, scenarios.WEIGHTS[sc.weights], scenarios.UMIN, scenarios.UMAX, scenarios.XMIN,
                       scenarios.XMAX, 4.0, 0.12)
     ref = OC.mpc_batch(ocfg, OC.settings(), track.kappa, track.v_ref, track.ds_next, sc.wp_id, sc.x0, sc.cc_prev,
@@ -227,7 +227,7 @@ def test_phase1_certifies_every_infeasible_instance_without_admm(G, emu, track):
     sc = scenarios.make(4, track, B=512)
     cfg = T.stock_config(sc.N, sc.weights)
     qp = emu.assemble(cfg, track, _inputs(sc))
-    sol, n_tail = emu.solve_launch(cfg, mpmpc.default_settings(), qp, G=G)
+    sol, n_tail = emu.solve_launch(cfg, mpmpc.default_settings(phase1_accept=0), qp, G=G)
     ocfg = OC.mpc_cfg(sc.N, scenarios.WEIGHTS[sc.weights], scenarios.UMIN, scenarios.UMAX, scenarios.XMIN,
                       scenarios.XMAX, 4.0, 0.12)
     ref = OC.mpc_batch(ocfg, OC.settings(), track.kappa, track.v_ref, track.ds_next, sc.wp_id, sc.x0, sc.cc_prev,
@@ -255,7 +255,7 @@ def test_phase1_off_restores_osqps_own_verdicts(emu, track):
     sc = scenarios.make(4, track, B=96)
     cfg = T.stock_config(sc.N, sc.weights)
     qp = emu.assemble(cfg, track, _inputs(sc))
-    on = emu.solve(cfg, mpmpc.default_settings(), qp, G=64)
+    on = emu.solve(cfg, mpmpc.default_settings(phase1_accept=0), qp, G=64)
     off = emu.solve(cfg, mpmpc.default_settings(phase1=0), qp, G=64)
     solved = on.status == 1
     assert np.array_equal(off.status[solved], on.status[solved]) and np.array_equal(off.u0[solved], on.u0[solved])
