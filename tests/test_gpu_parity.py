@@ -11,6 +11,11 @@ import scenarios
 pytestmark = pytest.mark.gpu
 
 
+# verdict semantics of the oracle and of the certified-mode goldens (G5, G6): every proven infeasibility is reported.  The
+# library's default hands marginal ones back as usable plans (mpmpc_settings::phase1_accept), pinned by golden G6s.
+STRICT = dict(phase1_accept=0)
+
+
 def _handle(track, N, weights, max_batch, settings=None, table=None):
     cfg = T.stock_config(N, weights, max_batch=max_batch)
     h = mpmpc.Handle(cfg, settings or mpmpc.default_settings())
@@ -310,6 +315,28 @@ def test_device_corridor_in_the_single_car_loop():
     assert t_dev < t_host
 
 
+@pytest.mark.parametrize("N", [10, 30])
+def test_default_path_takes_the_branch_stock_osqp_takes_on_device(N, track):
+    """ADVICE r2 (high), on the device: golden G6s is the reference's own loop run with the restated OSQP at ITS DEFAULTS
+    (eps 1e-3, no polish, no phase 1 - the arithmetic of src/MPC.py:159,183).  Every recorded step through libmpmpc.so
+    with the DEFAULT settings takes the branch the reference took: a usable plan (status 1 or 2) exactly where OSQP
+    returned one, a refusal exactly where OSQP refused.  With phase1_accept = 0 the same batch refuses the marginal
+    steps too - the behaviour ADVICE r2 objected to."""
+    g = np.load(M.GOLDEN + "/g6s_stock_loop_N%d.npz" % N)
+    B = g["s"].size
+    h = _handle(track, N, "stock", B)
+    sol = h.solve(g["wp_id"].astype(np.int32), g["x0"], g["cc_prev"], g["lb"], g["ub"])
+    h.close()
+    usable = (sol.status == 1) | (sol.status == 2)
+    assert np.array_equal(usable, g["status"] > 0), np.flatnonzero(usable != (g["status"] > 0))
+    assert (sol.status == 2).sum() >= 5
+    assert np.max(np.abs(sol.u0[usable, 0] - g["u"][usable, 0])) <= 5e-3          # speed channel: OSQP at 1e-3 has it
+    hs = _handle(track, N, "stock", B, mpmpc.default_settings(**STRICT))
+    strict = hs.solve(g["wp_id"].astype(np.int32), g["x0"], g["cc_prev"], g["lb"], g["ub"])
+    hs.close()
+    assert (strict.status == -3).sum() >= (sol.status == -3).sum() + 5
+
+
 def test_batch_mpc_matches_single_controller():
     import test_host_mpc as H
     from MPC import BatchMPC
@@ -320,7 +347,7 @@ def test_batch_mpc_matches_single_controller():
     ic = {'umin': np.array([0.0, -np.tan(0.66) / car.length]), 'umax': np.array([1.0, np.tan(0.66) / car.length])}
     sc = {'xmin': np.array([-np.inf] * 3), 'xmax': np.array([np.inf] * 3)}
     idx = np.arange(0, 200, 5)
-    bm = BatchMPC(car, 30, Q, R, QN, sc, ic, 4.0, max_batch=idx.size)
+    bm = BatchMPC(car, 30, Q, R, QN, sc, ic, 4.0, max_batch=idx.size, settings=mpmpc.default_settings(**STRICT))
     wp, x0 = bm.spatial_states(g["s"][idx], g["pose"][idx])
     assert np.array_equal(wp, g["wp_id"][idx]) and np.allclose(x0, g["x0"][idx], atol=1e-13)
     u, plan, status, sol = bm.get_control_batch(wp, x0, g["cc_prev"][idx], g["lb"][idx], g["ub"][idx])
@@ -360,7 +387,7 @@ def test_full_batches_against_c_oracle(cfgid, B, track):
     beyond the one iteration of the early attempt."""
     import oracle_c as OC
     sc = scenarios.make(cfgid, track, B=B)
-    h = _handle(track, sc.N, sc.weights, B)
+    h = _handle(track, sc.N, sc.weights, B, mpmpc.default_settings(**STRICT))
     qp = h.assemble(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
     sol = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
     ocfg = OC.mpc_cfg(sc.N, scenarios.WEIGHTS[sc.weights], scenarios.UMIN, scenarios.UMAX, scenarios.XMIN,
@@ -440,7 +467,7 @@ def test_the_polish_settings_change_the_route_not_the_answer(cfgid, B, track):
                 dict(ipm_start_slack=0.3, ipm_start_mu=0.1), dict(ipm_start_dual=0.0), dict(reduce=0)]
     outs = []
     for kw in variants:
-        h = _handle(track, sc.N, sc.weights, B, mpmpc.default_settings(**kw))
+        h = _handle(track, sc.N, sc.weights, B, mpmpc.default_settings(**STRICT, **kw))
         if not outs:
             qp = h.assemble(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
         outs.append(h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True))
@@ -474,15 +501,30 @@ def test_baseline_batch_sizes_carry_kkt_certificates(cfgid, B, track):
     # nobody needs OSQP's ADMM beyond the one iteration of the early attempt: every instance is certified optimal or
     # proved infeasible - including the fifteen of config 5 whose corridor cannot be met by a tenth of a millimetre
     # (phase 1's converged optimum, criterion B)
-    assert set(np.unique(sol.status)) <= {1, -3}
+    # ... or, infeasible by less than OSQP's own primal tolerance, handed back as a usable plan (status 2, phase1_accept)
+    assert set(np.unique(sol.status)) <= {1, 2, -3}
     assert np.all(sol.iters[:, 0] == 1)
     if cfgid == 2:
         assert ok.all()
     else:
-        assert 0.85 < ok.mean() < 0.95 and (sol.status == -3).mean() > 0.05
+        assert 0.85 < ok.mean() < 0.95 and (sol.status == -3).mean() > 0.03
         inf = sol.status == -3
         fk, support, aty = T.farkas_batch(qp[:, inf, :], sc.N, sol.y[inf])
         assert fk.all(), (support.max(), aty.max())
+        # the marginal ones: the plan keeps the dynamics exactly and leaves its boxes by at most 1.5 x the least violation
+        # reported in resid[0], which is below OSQP's tolerance eps_abs + eps_rel |kappa_max|; the strict setting
+        # reports exactly these instances (and the -3 ones) infeasible
+        mg = sol.status == 2
+        assert 0 < mg.sum() < 0.06 * B
+        eps_osqp = 1e-3 + 1e-3 * float(np.max(np.abs(scenarios.UMAX)))
+        assert sol.resid[mg, 0].max() <= eps_osqp and sol.resid[mg, 0].min() > 1e-8
+        prim_m, _, _ = T.kkt_batch(qp[:, mg, :], sc.N, sol.z[mg], sol.y[mg])
+        assert np.all(prim_m <= 1.5 * sol.resid[mg, 0] + 1e-8) and np.all(prim_m > 1e-7)
+        hs = _handle(track, sc.N, sc.weights, B, mpmpc.default_settings(**STRICT))
+        strict = hs.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+        hs.close()
+        assert np.array_equal(strict.status == -3, mg | inf) and np.array_equal(strict.status == 1, ok)
+        assert np.array_equal(strict.u0[ok], sol.u0[ok])
     perm = np.random.default_rng(0).permutation(B)
     sol2 = h.solve(sc.wp_id[perm], sc.x0[perm], sc.cc_prev[perm], sc.lb[perm], sc.ub[perm])
     assert np.array_equal(sol2.status, sol.status[perm]) and np.array_equal(sol2.iters, sol.iters[perm])
@@ -621,7 +663,7 @@ def test_full_terminal_weight_on_device(cfgid, N, B, track, emu):
     for i in np.flatnonzero(ok)[:24]:
         P, q, A, l, u = _dense_with_qn(qp[:, i, :], N, QN_FULL)
         assert O.kkt_certificate(P, q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8)
-    assert set(np.unique(sol.status)) <= {1, -3}
+    assert set(np.unique(sol.status)) <= {1, 2, -3}
 
 
 def test_paths_longer_than_the_lds_staging_of_k1(emu):
@@ -670,7 +712,7 @@ def test_reduced_polish_gives_the_full_polish_answers(cfgid, B, track):
     sc = scenarios.make(cfgid, track, B=B)
     out = {}
     for red in (1, 0):
-        h = _handle(track, sc.N, sc.weights, B, mpmpc.default_settings(reduce=red))
+        h = _handle(track, sc.N, sc.weights, B, mpmpc.default_settings(reduce=red, **STRICT))
         qp = h.assemble(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
         out[red] = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
         h.close()

@@ -151,11 +151,12 @@ def test_rollout_warm_start_default_is_used_where_it_pays():
         assert (hits > 0.5) if expect_warm else (hits == 0.0), (B, hits)
 
 
-def _g6_handle(N, B):
+def _g6_handle(N, B, settings=None):
     g1 = np.load(M.GOLDEN + "/g1_path_sim_track.npz")
     g3 = np.load(M.GOLDEN + "/g3_corridor.npz")
     tr = __import__("scenarios").sim_track()
-    h = mpmpc.Handle(T.stock_config(N, max_batch=B))
+    # (golden G6 was recorded with a solver that reports every proven infeasibility: phase1_accept = 0)
+    h = mpmpc.Handle(T.stock_config(N, max_batch=B), settings or mpmpc.default_settings(phase1_accept=0))
     h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
     h.set_corridor(g3["ub_obstacles"], g3["lb_obstacles"])
     h.set_path_geometry(g1["x"], g1["y"], g1["psi"], g1["border_ub"], g1["border_lb"])
