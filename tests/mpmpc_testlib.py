@@ -294,3 +294,41 @@ class EmuBackend:
     def solve(self, wp_id, x0, cc_prev, lb=None, ub=None, want_y=False):
         qp = self.emu.assemble(self.cfg, self.t, (np.asarray(wp_id, np.int32), x0, cc_prev, lb, ub))
         return self.emu.solve(self.cfg, self.settings, qp, G=64, want_y=want_y)
+
+
+# ---- the independent leg (oracle/independent.py, golden G8): nothing below shares code with the device algorithm
+def g8(name):
+    return np.load(os.path.join(ROOT, "tests", "golden", "g8_independent_%s.npz" % name))
+
+
+def compare_with_independent(sol, g, N, tol=1e-6):
+    """Device / emulation answers against golden G8 (restated OSQP ADMM to 1e-10 + ONE stock polish; never touched by a
+    device commit).  Compared where the independent leg certified ITS OWN point (polished = 1: KKT <= 1e-8): the first
+    control to `tol` in (v_0, kappa_0 -> delta_0 through atan), the plan without the cost-free kappa_{N-1} / e_psi_N to
+    `tol`.  -> dict(compared, worst_u0, worst_plan, verdict_disagreements)"""
+    import independent as I
+    keep, u0c = I.compared_coordinates(N)
+    n = g["x"].shape[0]
+    both = (g["polished"] == 1) & (sol.status[:n] == 1)
+    du = np.abs(sol.z[:n][both][:, u0c] - g["x"][both][:, u0c])
+    dp = np.abs(sol.z[:n][both][:, keep] - g["x"][both][:, keep])
+    # verdicts: the ADMM leg's own infeasibility verdict (-3) against a usable / refused answer of the device
+    dev_refused = (sol.status[:n] == -3)
+    ind_refused = (g["status"] == -3)
+    return dict(compared=int(both.sum()), worst_u0=float(du.max()) if both.any() else 0.0, worst_plan=float(dp.max()) if both.any() else 0.0,
+                refused_by_both=int((dev_refused & ind_refused).sum()), refused_by_device_only=int((dev_refused & ~ind_refused).sum()),
+                refused_by_independent_only=int((~dev_refused & ind_refused).sum()))
+
+
+def uniqueness_count(qp, N, z, y, idx):
+    """oracle/independent.py:uniqueness_certificate on the device's (z, y) of the instances `idx`, on the coordinates the
+    parity statements compare.  -> (number certified unique, number checked, worst coordinate freedom)"""
+    import independent as I
+    keep, _ = I.compared_coordinates(N)
+    good, worst = 0, 0.0
+    for i in idx:
+        Pd, q, A, l, u = qp_to_dense(qp[:, i, :], N)
+        c = I.uniqueness_certificate(Pd, A, l, u, z[i], y[i], keep)
+        good += int(c["unique"])
+        worst = max(worst, c["worst"])
+    return good, len(idx), worst

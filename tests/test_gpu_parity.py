@@ -315,6 +315,46 @@ def test_device_corridor_in_the_single_car_loop():
     assert t_dev < t_host
 
 
+@pytest.mark.parametrize("cfgid", [2, 3, 4])
+def test_device_against_the_independent_leg_and_uniqueness(cfgid, track):
+    """VERDICT r2 item 3, on the device.  (a) The uniqueness certificate (oracle/independent.py: null([P; A_S]) vanishes on
+    the compared coordinates - plain numpy, no solver) on the DEVICE's own (z, y) of 256 instances of configs 2 / 3 / 4: a
+    KKT point of this positive SEMI-definite QP is then THE optimum where it is compared; the count that fails is asserted,
+    not excused.  (b) The first 128 instances against golden G8 - restated OSQP ADMM to 1e-10 + ONE stock polish, no code
+    shared with the device algorithm, never touched by a device commit: first control and plan to 1e-6."""
+    B = 256
+    sc = scenarios.make(cfgid, track, B=B)
+    h = _handle(track, sc.N, sc.weights, B)
+    qp = h.assemble(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    sol = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+    h.close()
+    solved = np.flatnonzero(sol.status == 1)
+    good, n, worst = T.uniqueness_count(qp, sc.N, sol.z, sol.y, solved)
+    print("config %d: %d of %d certified optima unique on the compared coordinates (worst freedom %.1e)" % (cfgid, good, n, worst))
+    assert n >= 200 and good == n, (good, n, worst)
+    g = T.g8("cfg%d" % cfgid)
+    r = T.compare_with_independent(sol, g, sc.N)
+    print("config %d against G8:" % cfgid, r)
+    assert r["compared"] >= (100 if cfgid != 3 else 30), r
+    assert r["worst_u0"] <= 1e-6 and r["worst_plan"] <= 1e-6, r
+    assert r["refused_by_device_only"] == 0, r
+
+
+@pytest.mark.parametrize("N", [3, 10, 30, 50])
+def test_device_against_the_independent_leg_on_the_reference_captures(N, track):
+    """The reference's own captured inputs (G4) through libmpmpc.so against golden G8 (independent leg) on the QPs the
+    reference assembled from them: same refusals, first control and plan to 1e-6 where G8 certified its own point."""
+    g4 = np.load(M.GOLDEN + "/g4_assembly_N%d.npz" % N)
+    g = T.g8("g4_N%d" % N)
+    h = _handle(track, N, str(g4["weights"][0]), g4["s"].size)
+    sol = h.solve(g4["wp_id"].astype(np.int32), g4["x0"], g4["cc_prev"], g4["lb"], g4["ub"])
+    h.close()
+    r = T.compare_with_independent(sol, g, N)
+    assert r["compared"] >= (20 if N != 50 else 10), r
+    assert r["worst_u0"] <= 1e-6 and r["worst_plan"] <= 1e-6, r
+    assert r["refused_by_device_only"] == 0 and r["refused_by_independent_only"] == 0, r
+
+
 @pytest.mark.parametrize("N", [10, 30])
 def test_default_path_takes_the_branch_stock_osqp_takes_on_device(N, track):
     """ADVICE r2 (high), on the device: golden G6s is the reference's own loop run with the restated OSQP at ITS DEFAULTS
