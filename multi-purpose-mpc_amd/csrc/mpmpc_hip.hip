@@ -93,10 +93,13 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
                                                          double* __restrict__ u0, int* __restrict__ status,
                                                          int* __restrict__ iters, double* __restrict__ resid,
                                                          double* __restrict__ y, int mode, int* __restrict__ tail,
-                                                         int* __restrict__ act, const int* __restrict__ shift) {
+                                                         int* __restrict__ act, const int* __restrict__ shift,
+                                                         int* __restrict__ tail_reset) {
   using L = LaneGpu<G, C>;
   int inst = blockIdx.x * L::per_wave + L::slot();
   if (mode == 2) {
+    // the list the NEXT launch on this handle will fill starts empty (two lists, used in turn: no memset between launches)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *tail_reset = 0;
     if ((int)blockIdx.x >= tail[0]) return;       // wave-uniform: G = 64 here
     inst = tail[1 + blockIdx.x];
   }
@@ -443,6 +446,7 @@ struct mpmpc_handle_s {
   size_t stage_in_bytes = 0, stage_out_bytes = 0;
   // instances the early pass of a packed (2 or 4 per wave) launch could not certify: [0] = count, [1..] = ids
   int* tail = nullptr;
+  int tail_flip = 0;          // which of the two lists the next reduced-native launch fills
   int force_lanes = 0;      // mpmpc_set_packing: 0 = chosen from the batch size
   bool resident_y = true;   // mpmpc_set_outputs: do resident launches store the multipliers y (46 % of the output bytes)?
   bool y_valid = false;     // the last solve launch stored y
@@ -633,7 +637,8 @@ int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_
   ALLOC(h->out_block, lay.out_end);
   lay_out(h, cfg->max_batch);
   ALLOC(h->qp, (size_t)MPMPC_NUM_FIELDS * B * h->ld);
-  ALLOC(h->tail, B + 1);
+  ALLOC(h->tail, 2 * (B + 1));
+  (void)hipMemset(h->tail, 0, 2 * (B + 1) * sizeof(int));
 #undef ALLOC
   {
     const size_t STAGE_LIMIT = 64u << 20;
@@ -998,10 +1003,15 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y) {
   const int blocks = (B + per - 1) / per;
   const SolverParams prm = make_params(h->st);
   const int C = lane_split(G, N);        // where the two elimination chains of the factorisation meet
+  // tail lists ([0] = count, [1..] = instance ids), two of them used in turn: the tail launch of this step empties the
+  // list of the next one, so that no memset has to sit between the launches of consecutive steps
+  int* tail_cur = h->tail + (size_t)h->tail_flip * (h->cfg.max_batch + 1);
+  int* tail_next = h->tail + (size_t)(1 - h->tail_flip) * (h->cfg.max_batch + 1);
+  if (rn) h->tail_flip = 1 - h->tail_flip;
 #define LAUNCH_W(CC, WW, FF, MODE, BLOCKS)                                                                                \
   hipLaunchKernelGGL((mpmpc_solve_kernel<64, CC, WW, FF>), dim3(BLOCKS), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, \
-                     ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, MODE, h->tail, WW ? warm_act : nullptr,    \
-                     WW ? warm_shift : nullptr)
+                     ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, MODE, tail_cur, WW ? warm_act : nullptr,   \
+                     WW ? warm_shift : nullptr, tail_next)
 #define LAUNCH_V(CC, WW, MODE, BLOCKS)                  \
   do {                                                  \
     if (fullqn) LAUNCH_W(CC, WW, 1, MODE, BLOCKS);      \
@@ -1021,14 +1031,13 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y) {
   static const int rn_pad = (std::getenv("MPMPC_RN_OCC") && std::atoi(std::getenv("MPMPC_RN_OCC")) == 1) ? 20 * 1024 : 0;
 #define LAUNCH_RN_W(GG, CC, WW)                                                                                             \
   hipLaunchKernelGGL((mpmpc_reduced_kernel<GG, CC, WW>), dim3(blocks), dim3(64), rn_pad, h->stream, h->cfg, prm, B, h->ld, \
-                     ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, h->tail, warm_act, warm_shift)
+                     ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, tail_cur, warm_act, warm_shift)
 #define LAUNCH_RN(GG, CC)                       \
   do {                                          \
     if (warm) LAUNCH_RN_W(GG, CC, true);        \
     else LAUNCH_RN_W(GG, CC, false);            \
   } while (0)
   if (rn) {
-    HIP_TRY(hipMemsetAsync(h->tail, 0, sizeof(int), h->stream));
     if (G == 64 && C == 16) LAUNCH_RN(64, 16);
     else if (G == 64) LAUNCH_RN(64, 32);
     else if (G == 32) LAUNCH_RN(32, 16);

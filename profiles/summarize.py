@@ -8,14 +8,15 @@ import os
 import shutil
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r1"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r3"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O, P = os.path.join(root, "gpurun_out", rnd), os.path.join(root, "profiles", rnd)
 os.makedirs(P, exist_ok=True)
-for name in ("bench_cfg2.json", "bench_cfg3.json", "bench_cfg4.json", "bench_cfg5.json", "host.txt"):
+for name in ("bench_cfg2.json", "bench_cfg3.json", "bench_cfg4.json", "bench_cfg5.json", "bench_cfg4_strict.json", "bench_cfg5_strict.json",
+             "bench_cfg2_b65536.json", "host.txt"):
     if os.path.exists(os.path.join(O, name)):
         shutil.copy(os.path.join(O, name), os.path.join(P, name))
-if os.path.exists(os.path.join(O, "trace_b65536.json")):
+if os.path.exists(os.path.join(O, "trace_b65536.json")) and not os.path.exists(os.path.join(O, "bench_cfg2_b65536.json")):
     shutil.copy(os.path.join(O, "trace_b65536.json"), os.path.join(P, "bench_cfg2_b65536.json"))
 for src, dst in (("trace", "bench_cfg2_kernel_stats.csv"), ("trace_b65536", "bench_cfg2_b65536_kernel_stats.csv"),
                  ("trace_cfg3", "bench_cfg3_kernel_stats.csv"), ("trace_cfg4", "bench_cfg4_kernel_stats.csv"), ("trace_cfg5", "bench_cfg5_kernel_stats.csv")):
@@ -30,7 +31,8 @@ try:
     out["library_source_hash"] = ver.split("src ")[1].rstrip(")")
 except Exception as e:
     print("no library version in the profiled bench line:", e)
-for name in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_fetch_b65536", "pmc_write_b65536"):
+for name in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_fetch_b65536", "pmc_write_b65536", "pmc_sq1_cfg4", "pmc_sq2_cfg4",
+             "pmc_sq1_b65536", "pmc_sq2_b65536"):
     fs = glob.glob(os.path.join(O, name, "*", "*counter_collection.csv"))
     if not fs:
         continue
