@@ -60,6 +60,7 @@ struct ReducedSolver : Solver<L, false, true, false> {
   static_assert(COLD_USED <= L::cold_slots, "lane backend has too few cold slots");
   // a scaled bound beyond this is "infinite" (raw infinities are +-1e30, the Ruiz factors stay within [1e-4, 1e4] per pass)
   static constexpr double BOX_INF = 1e20;
+  static constexpr int RN_IPM_CAP = 16;       // interior-point iterations of the attempt (see run())
 
   // ---- the reduced problem, scaled; entries e = (e_y, e_psi, kappa)
   R P3[3], Q3[3];
@@ -573,14 +574,19 @@ struct ReducedSolver : Solver<L, false, true, false> {
         L::cold_put(K_LEQ, leq[0]); L::cold_put(K_LEQ + 1, leq[1]);
         L::fence();
       }
+      // A launch ends with its slowest wave, and a packed wave with its slower instance: feasible instances of this problem
+      // family converge in 5 - 11 iterations, so the attempt gives up after RN_IPM_CAP - what is still running by then
+      // (marginally infeasible instances: they would use all ipm_max_iter iterations) belongs to the tail launch anyway.
+      SolverParams sc = st;
+      sc.ipm_max_iter = st.ipm_max_iter < RN_IPM_CAP ? st.ipm_max_iter : RN_IPM_CAP;
       double tol = st.ipm_tol;
       for (int attempt = 0; attempt < 2; ++attempt) {
         MPMPC_TICK_BEGIN(4);
         Mk conv;
         if constexpr (kSplit) {
-          conv = this->template ipm<LAY_IP>(bi, si, pp, qq, vm, st, tol, todo);
+          conv = this->template ipm<LAY_IP>(bi, si, pp, qq, vm, sc, tol, todo);
         } else {
-          conv = ipm3(bi, si, st, tol, todo);
+          conv = ipm3(bi, si, sc, tol, todo);
           // the packed interior point read its invariants from LDS; what follows takes them from there as well, so that
           // no copy of them had to stay in registers across the loop
           L::fence();
