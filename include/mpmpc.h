@@ -50,10 +50,12 @@ typedef struct mpmpc_handle_s* mpmpc_handle;
 
 /* Controller constants: what MPC.__init__ stores (src/MPC.py:15-59) plus the model's wheelbase
  * (src/spatial_bicycle_models.py:130) and the path's `circular` flag (src/reference_path.py:96).
- * Q, R are the DIAGONALS of the reference's weight matrices (its cost vector only ever uses diag(Q), diag(R),
- * src/MPC.py:153-155); QN is used as a whole by the reference (src/MPC.py:150,154): its diagonal goes into QN, its
- * off-diagonal entries (symmetric) into QN_offdiag.  With a non-zero QN_offdiag the solve launches give every instance
- * its own wavefront (the packed kernels carry no code for the dense terminal block). */
+ * Q, R are the DIAGONALS of the reference's weight matrices.  RESTRICTION: the reference puts the whole Q and R into the
+ * Hessian (src/MPC.py:150) although its cost vector only ever uses diag(Q), diag(R) (src/MPC.py:153-155); this library
+ * supports diagonal stage weights only (what src/simulation.py:101-103 builds) - the host class raises ValueError for
+ * anything else.  QN is used as a whole (src/MPC.py:150,154): its diagonal goes into QN, its off-diagonal entries
+ * (symmetric) into QN_offdiag; such a configuration, like one with bounds on e_psi / t or a cost on t, runs the general
+ * kernels, one instance per wavefront.  HORIZON: 3 <= N <= 63 (one wavefront lane per stage; the reference has no upper limit). */
 typedef struct {
   int32_t N;          /* horizon, 3 <= N <= MPMPC_MAX_HORIZON (the kappa_pred quirk of MPC.py:86 needs N >= 3) */
   int32_t max_batch;  /* largest B of any later call */
