@@ -140,6 +140,14 @@ struct LaneEmu {
   static VD cup(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) { int l = i % G; r.v[i] = (l == 0 || (l == C && C != 32) || (C == 16 && l % 16 == 0)) ? 0.0 : a.v[i - 1]; } return r; }
   static VD cdown(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) { int l = i % G; r.v[i] = ((l == C - 1 && C != 32) || l == 2 * C - 1 || l == G - 1 || (C == 16 && l % 16 == 15)) ? 0.0 : a.v[i + 1]; } return r; }
 
+  // shifts by D lanes inside each row of 16 lanes, zero inflow (see lane_gpu.hpp)
+  template <int D>
+  static VD rshr(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (i % 16 >= D) ? a.v[i - D] : 0.0; return r; }
+  template <int D>
+  static VD rshl(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (i % 16 + D < 16) ? a.v[i + D] : 0.0; return r; }
+  template <int D>
+  static VB cr_elim() { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (((i % 16) + D + 1) & (2 * D - 1)) == 0; return r; }
+
   // half-wave exchange (see lane_gpu.hpp)
   static VD from_upper(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i | 32]; return r; }
   static VD from_lower(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i & 31]; return r; }

@@ -79,6 +79,16 @@ struct LaneGpu {
   static __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
   static __device__ __forceinline__ int stage() { return (threadIdx.x & 63) % G; }
   static __device__ __forceinline__ int slot() { return (threadIdx.x & 63) / G; }
+  // The lane's number formed anew (blocks are one wavefront): a kernel that needs stage() / slot() once at its start and
+  // once at its very end asks again there instead of carrying a register through everything in between.  (The opaque
+  // zero keeps the compiler from merging this with the first computation.)
+  static __device__ __forceinline__ int lane_again() {
+    int z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+  }
+  static __device__ __forceinline__ int stage_again() { return lane_again() % G; }
+  static __device__ __forceinline__ int slot_again() { return lane_again() / G; }
   static __device__ __forceinline__ bool mtrue() { return true; }
   static __device__ __forceinline__ bool mfalse() { return false; }
 
@@ -126,6 +136,17 @@ struct LaneGpu {
       return dpp_shift<DPP_WAVE_SHL1>(a);
     }
   }
+
+  // ---- shifts by D lanes inside each row of 16 lanes, zero inflow (the cyclic-reduction levels of the chain factorisation:
+  //      one DPP move per dword, like the one-lane shifts)
+  template <int D>
+  static __device__ __forceinline__ double rshr(double a) { return dpp_shift<0x110 + D>(a); }      // lane i <- lane i - D
+  template <int D>
+  static __device__ __forceinline__ double rshl(double a) { return dpp_shift<0x100 + D>(a); }      // lane i <- lane i + D
+  // position p of the lane in its row is eliminated at the cyclic-reduction level of distance D (1, 2, 4, 8) iff
+  // p = 15 - D mod 2D: level by level the odd positions counted from the row's END go, position 15 survives them all
+  template <int D>
+  static __device__ __forceinline__ bool cr_elim() { return (((threadIdx.x & 15) + D + 1) & (2 * D - 1)) == 0; }
 
   // ---- half-wave exchange (G = 64, N + 1 <= 32: lanes 32..63 carry the inputs of the stage on lane - 32)
   // from_upper(a): every lane gets a of lane | 32;  from_lower(a): every lane gets a of lane & 31.

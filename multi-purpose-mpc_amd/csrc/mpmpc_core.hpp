@@ -231,9 +231,13 @@ MPMPC_HOST_DEVICE inline int lane_offset(int G, int C, int N) {
 // FREEX: the states e_psi and t are never boxed (xmin[1..2] = -inf, xmax[1..2] = +inf: the reference's own constraints,
 // src/simulation.py:110-111) - the interior point of the FULL problem then carries no slack arithmetic for them
 // (left out at compile time, like e_psi in the reduced layouts).
-template <class L, bool FQ = false, bool RED = false, bool FREEX = false>
+// CR: the two elimination chains of the reduced problem's factorisation (2 x 2 blocks, L::split == 16: each chain is one
+// row of 16 lanes) are eliminated by CYCLIC REDUCTION IN CHOLESKY FORM - four lane-parallel levels of distance 1, 2, 4, 8
+// inside the row instead of 15 dependent steps (factor_cr2 / s_solve_cr2 below).
+template <class L, bool FQ = false, bool RED = false, bool FREEX = false, bool CR = false>
 struct Solver {
   static_assert(!(FQ && RED), "the reduced problem needs a diagonal terminal weight");
+  static constexpr bool kCR = CR && L::split == 16;
   using R = typename L::real;
   using Mk = typename L::mask;
   using I = typename L::ival;
@@ -949,6 +953,7 @@ struct Solver {
     for (int i = 0; i < 3; ++i) Dg[i] = L::mirror(Dg[i]);
     MPMPC_UNROLL
     for (int i = 0; i < 4; ++i) To[i] = L::mirror(To[i]);
+    if constexpr (kCR) { factor_cr2(Dg, To); return; }
     R M[4], Ls[4];
     MPMPC_UNROLL
     for (int i = 0; i < 4; ++i) M[i] = R(0.0);
@@ -1002,7 +1007,173 @@ struct Solver {
       Gout[2 + j] = sel(is_end, M[2 + j], g1);
     }
   }
+  // ---- cyclic reduction in Cholesky form (kCR).  In chain layout every chain is one row of 16 lanes, position p = 0 .. 15
+  // along the chain, position 15 next to the meeting stage (row 0: mid itself; row 1: the end lane).  A Cholesky
+  // factorisation may eliminate the stages of an SPD block-tridiagonal matrix in ANY order (a symmetric permutation): level
+  // D = 1, 2, 4, 8 eliminates the positions p = 15 - D mod 2D - every second stage of what is left, counted from the row's
+  // end - all at once.  Eliminating stage e with the current neighbours a = e - D, b = e + D:
+  //     L_e L_e' = D_e,   Ua = inv(L_e) S_ea,   Ub = inv(L_e) S_eb,
+  //     D_a -= Ua'Ua,   D_b -= Ub'Ub,   S_ba = -Ub'Ua   (a and b become neighbours at distance 2D),
+  // so the blocks stay 2 x 2 and every lane is eliminated exactly once: it keeps inv(L_e) in Li and Ua, Ub in Gin, Gout.
+  // After the four levels position 15 of each row holds the Schur complement of its chain; the end lane is eliminated, the
+  // meeting stage takes its update (the junction of the sequential scheme), and is factored last.  The data exchanges are
+  // in-row DPP shifts by D (one move per dword).  Backward stable like any Cholesky factorisation (it IS one) - unlike the
+  // inverse-based parallel cyclic reduction of DESIGN.md 6a.  Depth 4 levels + junction instead of 16 dependent steps.
+  // Cm: coupling of the lane's stage with its current LOWER neighbour, S_{p, p - D} (row-major 2 x 2).
+  template <int D>
+  MPMPC_HD void cr_level(R Dg[3], R Cm[4]) {
+    // (written in the order that keeps the fewest blocks alive at once: the kernel lives on a 256-register budget)
+    const Mk E = L::template cr_elim<D>();
+    const R zero(0.0);
+    // Cholesky of the own block on every lane (used where the lane is eliminated at this level)
+    const R i00 = rsqrt_(Dg[0]);
+    const R l10 = Dg[1] * i00;
+    const R i11 = rsqrt_(fma_(-l10, l10, Dg[2]));
+    const R i10 = -(l10 * i00) * i11;
+    Li[0] = sel(E, i00, Li[0]); Li[1] = sel(E, i10, Li[1]); Li[2] = sel(E, i11, Li[2]);
+    // Ub = inv(L) S_eb = inv(L) Cb',  Cb = S_be = the coupling lane e + D holds with its lower neighbour e
+    R gb[4];
+    {
+      R Cb[4], Ub[4];
+      MPMPC_UNROLL
+      for (int i = 0; i < 4; ++i) Cb[i] = L::template rshl<D>(Cm[i]);
+      Ub[0] = sel(E, i00 * Cb[0], zero); Ub[1] = sel(E, i00 * Cb[2], zero);
+      Ub[2] = sel(E, fma_(i11, Cb[1], i10 * Cb[0]), zero); Ub[3] = sel(E, fma_(i11, Cb[3], i10 * Cb[2]), zero);
+      MPMPC_UNROLL
+      for (int i = 0; i < 4; ++i) { Gout[i] = sel(E, Ub[i], Gout[i]); gb[i] = L::template rshr<D>(Ub[i]); }
+    }
+    // to the upper neighbour b (lane e + D):  D_b -= Ub'Ub
+    Dg[0] = fma_(-gb[2], gb[2], fma_(-gb[0], gb[0], Dg[0]));
+    Dg[1] = fma_(-gb[3], gb[2], fma_(-gb[1], gb[0], Dg[1]));
+    Dg[2] = fma_(-gb[3], gb[3], fma_(-gb[1], gb[1], Dg[2]));
+    // Ua = inv(L) S_ea = inv(L) Cm
+    R ga[4];
+    {
+      R Ua[4];
+      Ua[0] = sel(E, i00 * Cm[0], zero); Ua[1] = sel(E, i00 * Cm[1], zero);
+      Ua[2] = sel(E, fma_(i11, Cm[2], i10 * Cm[0]), zero); Ua[3] = sel(E, fma_(i11, Cm[3], i10 * Cm[1]), zero);
+      MPMPC_UNROLL
+      for (int i = 0; i < 4; ++i) Gin[i] = sel(E, Ua[i], Gin[i]);
+      // to the lower neighbour a (lane e - D):  D_a -= Ua'Ua
+      {
+        R fa[4];
+        MPMPC_UNROLL
+        for (int i = 0; i < 4; ++i) fa[i] = L::template rshl<D>(Ua[i]);
+        Dg[0] = fma_(-fa[2], fa[2], fma_(-fa[0], fa[0], Dg[0]));
+        Dg[1] = fma_(-fa[3], fa[2], fma_(-fa[1], fa[0], Dg[1]));
+        Dg[2] = fma_(-fa[3], fa[3], fma_(-fa[1], fa[1], Dg[2]));
+      }
+      MPMPC_UNROLL
+      for (int i = 0; i < 4; ++i) ga[i] = L::template rshr<D>(Ua[i]);
+    }
+    // ... and S_ba = -Ub'Ua: the coupling of b with its new lower neighbour a (a lane that survives this level has the
+    // eliminated lane p - D below it: its old coupling is consumed)
+    Cm[0] = sel(E, Cm[0], -fma_(gb[2], ga[2], gb[0] * ga[0]));
+    Cm[1] = sel(E, Cm[1], -fma_(gb[2], ga[3], gb[0] * ga[1]));
+    Cm[2] = sel(E, Cm[2], -fma_(gb[3], ga[2], gb[1] * ga[0]));
+    Cm[3] = sel(E, Cm[3], -fma_(gb[3], ga[3], gb[1] * ga[1]));
+  }
+  // Dg: diagonal blocks, To: coupling S_{succ(p), p} with the chain successor, both in chain layout
+  MPMPC_HD void factor_cr2(R Dg[3], const R To[4]) {
+    const R zero(0.0);
+    R Cm[4];
+    MPMPC_UNROLL
+    for (int i = 0; i < 4; ++i) Cm[i] = L::cup(To[i]);            // S_{p, p-1}: the predecessor's hand-on (zero at the chain heads)
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) Li[i] = zero;
+    // (position 15 is never eliminated by a level, so its Gout is free until the junction: the end lane's hand-on to the
+    //  meeting stage waits there instead of in four more registers)
+    MPMPC_UNROLL
+    for (int i = 0; i < 4; ++i) { Gin[i] = zero; Gout[i] = To[i]; }
+    cr_level<1>(Dg, Cm);
+    cr_level<2>(Dg, Cm);
+    cr_level<4>(Dg, Cm);
+    cr_level<8>(Dg, Cm);
+    // position 15 of each row: the end lane (row 1) is eliminated, its block M = S_{mid,end} inv(L_end)' goes to the meeting
+    // stage (row 0), which is factored last.  (Chains shorter than a row: the positions without a stage carry identity-like
+    // blocks and zero couplings, they factor harmlessly.)
+    const Mk last = is_mid | is_end;
+    {
+      const R i00 = rsqrt_(Dg[0]);
+      const R l10 = Dg[1] * i00;
+      const R i11 = rsqrt_(fma_(-l10, l10, Dg[2]));
+      const R i10 = -(l10 * i00) * i11;
+      R M[4];
+      M[0] = Gout[0] * i00; M[1] = fma_(Gout[1], i11, Gout[0] * i10);
+      M[2] = Gout[2] * i00; M[3] = fma_(Gout[3], i11, Gout[2] * i10);
+      Li[0] = sel(is_end, i00, Li[0]); Li[1] = sel(is_end, i10, Li[1]); Li[2] = sel(is_end, i11, Li[2]);
+      MPMPC_UNROLL
+      for (int i = 0; i < 4; ++i) Gout[i] = sel(is_end, M[i], Gout[i]);          // the end lane keeps M_own (as in the sequential scheme)
+      R Mx[4];
+      MPMPC_UNROLL
+      for (int i = 0; i < 4; ++i) Mx[i] = sel(is_mid, L::down(L::mirror(sel(is_end, M[i], zero))), zero);
+      Dg[0] = fma_(-Mx[1], Mx[1], fma_(-Mx[0], Mx[0], Dg[0]));
+      Dg[1] = fma_(-Mx[3], Mx[1], fma_(-Mx[2], Mx[0], Dg[1]));
+      Dg[2] = fma_(-Mx[3], Mx[3], fma_(-Mx[2], Mx[2], Dg[2]));
+    }
+    {
+      const R i00 = rsqrt_(Dg[0]);
+      const R l10 = Dg[1] * i00;
+      const R i11 = rsqrt_(fma_(-l10, l10, Dg[2]));
+      const R i10 = -(l10 * i00) * i11;
+      Li[0] = sel(is_mid, i00, Li[0]); Li[1] = sel(is_mid, i10, Li[1]); Li[2] = sel(is_mid, i11, Li[2]);
+    }
+    (void)last;
+  }
+  // forward / backward substitution of one cyclic-reduction level
+  template <int D>
+  MPMPC_HD void cr_forward(R& b0, R& b1, R& y0, R& y1) const {
+    const Mk E = L::template cr_elim<D>();
+    const R zero(0.0);
+    const R t0 = Li[0] * b0, t1 = fma_(Li[2], b1, Li[1] * b0);            // y = inv(L) b
+    y0 = sel(E, t0, y0); y1 = sel(E, t1, y1);
+    const R e0 = sel(E, t0, zero), e1 = sel(E, t1, zero);
+    // b_a -= Ua' y,  b_b -= Ub' y
+    const R pa0 = fma_(Gin[2], e1, Gin[0] * e0), pa1 = fma_(Gin[3], e1, Gin[1] * e0);
+    const R pb0 = fma_(Gout[2], e1, Gout[0] * e0), pb1 = fma_(Gout[3], e1, Gout[1] * e0);
+    b0 = b0 - L::template rshl<D>(pa0) - L::template rshr<D>(pb0);
+    b1 = b1 - L::template rshl<D>(pa1) - L::template rshr<D>(pb1);
+  }
+  template <int D>
+  MPMPC_HD void cr_backward(const R& y0, const R& y1, R& n0, R& n1) const {
+    const Mk E = L::template cr_elim<D>();
+    // nu_e = inv(L_e)' (y_e - Ua nu_a - Ub nu_b),  nu_a from lane e - D, nu_b from lane e + D
+    const R a0 = L::template rshr<D>(n0), a1 = L::template rshr<D>(n1), c0 = L::template rshl<D>(n0), c1 = L::template rshl<D>(n1);
+    const R r0 = y0 - fma_(Gin[1], a1, Gin[0] * a0) - fma_(Gout[1], c1, Gout[0] * c0);
+    const R r1 = y1 - fma_(Gin[3], a1, Gin[2] * a0) - fma_(Gout[3], c1, Gout[2] * c0);
+    n0 = sel(E, fma_(Li[1], r1, Li[0] * r0), n0);
+    n1 = sel(E, Li[2] * r1, n1);
+  }
+  MPMPC_HD void s_solve_cr2(const R bv[2], R nu[2]) const {
+    const R zero(0.0);
+    R b0 = sel(vxc, L::mirror(bv[0]), zero), b1 = sel(vxc, L::mirror(bv[1]), zero);
+    R y0(0.0), y1(0.0);
+    cr_forward<1>(b0, b1, y0, y1);
+    cr_forward<2>(b0, b1, y0, y1);
+    cr_forward<4>(b0, b1, y0, y1);
+    cr_forward<8>(b0, b1, y0, y1);
+    // junction: y_end = inv(L_end) b_end;  b_mid -= M y_end;  y_mid = inv(L_mid) b_mid;  nu_mid = inv(L_mid)' y_mid;
+    //           nu_end = inv(L_end)' (y_end - M' nu_mid)
+    const R ye0 = Li[0] * b0, ye1 = fma_(Li[2], b1, Li[1] * b0);                   // valid on the end lane (and, pre-update, on mid)
+    const R q0 = fma_(Gout[1], ye1, Gout[0] * ye0), q1 = fma_(Gout[3], ye1, Gout[2] * ye0);      // M y_end on the end lane
+    const R qm0 = sel(is_mid, L::down(L::mirror(sel(is_end, q0, zero))), zero), qm1 = sel(is_mid, L::down(L::mirror(sel(is_end, q1, zero))), zero);
+    const R bm0 = b0 - qm0, bm1 = b1 - qm1;
+    const R ym0 = Li[0] * bm0, ym1 = fma_(Li[2], bm1, Li[1] * bm0);
+    const R nm0 = fma_(Li[1], ym1, Li[0] * ym0), nm1 = Li[2] * ym1;               // nu of the meeting stage (on mid)
+    // to the end lane: M' nu_mid
+    const R me0 = sel(is_end, L::mirror(L::up(sel(is_mid, nm0, zero))), zero), me1 = sel(is_end, L::mirror(L::up(sel(is_mid, nm1, zero))), zero);
+    const R re0 = ye0 - fma_(Gout[2], me1, Gout[0] * me0), re1 = ye1 - fma_(Gout[3], me1, Gout[1] * me0);
+    const R ne0 = fma_(Li[1], re1, Li[0] * re0), ne1 = Li[2] * re1;
+    R n0 = sel(is_mid, nm0, sel(is_end, ne0, zero)), n1 = sel(is_mid, nm1, sel(is_end, ne1, zero));
+    cr_backward<8>(y0, y1, n0, n1);
+    cr_backward<4>(y0, y1, n0, n1);
+    cr_backward<2>(y0, y1, n0, n1);
+    cr_backward<1>(y0, y1, n0, n1);
+    nu[0] = L::mirror(n0); nu[1] = L::mirror(n1);
+  }
+
   MPMPC_HD void s_solve2(const R bv[2], R nu[2]) const {
+    if constexpr (kCR) { s_solve_cr2(bv, nu); return; }
     R b0 = sel(vxc, L::mirror(bv[0]), R(0.0)), b1 = sel(vxc, L::mirror(bv[1]), R(0.0));
     R c0 = Li[0] * b0;
     R c1 = fma_(Li[2], b1, Li[1] * b0);
@@ -1677,20 +1848,26 @@ struct Solver {
     Mk todo = run, okm = L::mfalse();
     for (int rnd = 0; rnd < st.as_rounds; ++rnd) {
       if (!L::wany(todo)) break;
-      R h[E], Hd[E], bound[E];
+      R bound[E];
       Mk act[E];
       MPMPC_UNROLL
-      for (int j = 0; j < E; ++j) {
-        act[j] = aL[j] | aU[j] | bx.pin[j];
-        bound[j] = sel(aU[j], bx.hi[j], bx.lo[j]);
-        Hd[j] = pp[j] + delta + sel(act[j], idelta, zero);
-        h[j] = one / Hd[j];
+      for (int j = 0; j < E; ++j) act[j] = aL[j] | aU[j] | bx.pin[j];
+      {
+        R h[E], Hd[E];
+        MPMPC_UNROLL
+        for (int j = 0; j < E; ++j) {
+          Hd[j] = pp[j] + delta + sel(act[j], idelta, zero);
+          h[j] = one / Hd[j];
+        }
+        dense_terminal(Hd, h);
+        MPMPC_TICK_COUNT(17);
+        MPMPC_TICK_BEGIN(13);
+        factor_t<LAY>(h, delta);
+        MPMPC_TICK_END(13);
       }
-      dense_terminal(Hd, h);
-      MPMPC_TICK_COUNT(17);
-      MPMPC_TICK_BEGIN(13);
-      factor_t<LAY>(h, delta);
-      MPMPC_TICK_END(13);
+      L::fence();          // (a scheduling fence: what follows is formed after the factorisation, not carried through it)
+      MPMPC_UNROLL
+      for (int j = 0; j < E; ++j) bound[j] = sel(aU[j], bx.hi[j], bx.lo[j]);
       R xn[E], nn[NQ], ln[E];
       MPMPC_UNROLL
       for (int j = 0; j < E; ++j) xn[j] = ln[j] = zero;

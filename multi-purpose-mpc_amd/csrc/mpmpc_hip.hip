@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
 // separates (the reference's own weights).  One launch assembles (K1's code, in registers), solves and stores; the ids of
 // the instances it cannot certify are appended to tail[1..] (tail[0] counts) for the general kernel in mode 2.
 // 24 LDS slots (12 KB) and at most 256 registers: two wavefronts per SIMD.
-constexpr int RN_SLOTS = 37;
+constexpr int RN_SLOTS = 40;
 // WARM (closed loop): act [B x ld] holds the active sets the previous step certified, shift [B] the waypoints each car has
 // advanced since; the kernel starts from them and leaves this step's sets in act.
 template <int G, int C, bool WARM>
@@ -153,10 +153,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   ReducedSolver<L> s;
   s.template run<WARM>(fields, B, inst, k, cfg.N, st, guess);
   MPMPC_TICK_BEGIN(7);
-  s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y, WARM ? act : nullptr, ld);
+  // (instance and stage are formed again rather than kept in registers through the solve)
+  const int inst_o = blockIdx.x * L::per_wave + L::slot_again();
+  const int k_o = L::stage_again() - lane_offset(G, C, cfg.N);
+  s.store(inst_o, k_o, cfg.wheelbase, z, u0, status, iters, resid, y, WARM ? act : nullptr, ld);
   MPMPC_TICK_END(7);
   MPMPC_TICK_END(8);
-  if (k == 0 && inst < B && s.status == MPMPC_UNSOLVED) tail[1 + atomicAdd(tail, 1)] = inst;
+  if (k_o == 0 && inst_o < B && s.status == MPMPC_UNSOLVED) tail[1 + atomicAdd(tail, 1)] = inst_o;
 }
 
 // K4: speed profile.  The kernel of choice is mpmpc_speed_profile_wave_kernel below (one wavefront per path); these

@@ -29,9 +29,10 @@ inline bool reduced_native(const mpmpc_config& c, const mpmpc_settings& st) {
          st.early_scaling >= 0 && st.scaling > 0;
 }
 
-template <class L>
-struct ReducedSolver : Solver<L, false, true, false> {
-  using S = Solver<L, false, true, false>;
+// CR: cyclic-reduction elimination of the factorisation's chains (Solver::kCR; on for the shipped kernels)
+template <class L, bool CR = true>
+struct ReducedSolver : Solver<L, false, true, false, CR> {
+  using S = Solver<L, false, true, false, CR>;
   using R = typename L::real;
   using Mk = typename L::mask;
   using I = typename L::ival;
@@ -54,9 +55,11 @@ struct ReducedSolver : Solver<L, false, true, false> {
   //   C_G, C_PI            box-row scaling and pin multipliers of the start; later (same slots) C_XS, C_LAM: the certified point
   //   C_NUS                its equality multipliers
   //   K_PP .. K_RP         the packed interior point (ipm3): cost, equality offsets, residuals of the iteration
+  //   K_PARK .. +7         the interior point's slacks and bound multipliers while the active-set rounds run (the iteration's
+  //                        residual slots are idle then): they are needed again only by a second attempt
   enum { C_D = 0, C_E = 3, C_C = 5, K_LO0 = 6, K_HI0 = 7, K_LO2 = 8, K_HI2 = 9, C_V = 10, C_LAMV = 11, C_A20 = 12, C_BV = 13, C_BEQ2 = 14,
          C_G = 15, C_PI = 18, C_XS = 15, C_LAM = 18, C_NUS = 21, C_GAP = 23,
-         K_PP = 24, K_QQ = 27, K_LEQ = 30, K_RD = 32, K_RP = 35, COLD_USED = 37 };
+         K_PP = 24, K_QQ = 27, K_LEQ = 30, K_RD = 32, K_RP = 35, K_PARK = 32, COLD_USED = 40 };
   static_assert(COLD_USED <= L::cold_slots, "lane backend has too few cold slots");
   // a scaled bound beyond this is "infinite" (raw infinities are +-1e30, the Ruiz factors stay within [1e-4, 1e4] per pass)
   static constexpr double BOX_INF = 1e20;
@@ -312,12 +315,20 @@ struct ReducedSolver : Solver<L, false, true, false> {
         MPMPC_UNROLL
         for (int b = 0; b < 2; ++b) {
           const int j = JB[b];
-          isl[b] = rcp_(s.sl[j]); isu[b] = rcp_(s.su[j]);
-          h[j] = rcp_(L::cold_get(K_PP + j) + reg + sel(bx.Lm[j], s.zl[j] * isl[b], zero) + sel(bx.Um[j], s.zu[j] * isu[b], zero) +
+          const R il = rcp_(s.sl[j]), iu = rcp_(s.su[j]);
+          h[j] = rcp_(L::cold_get(K_PP + j) + reg + sel(bx.Lm[j], s.zl[j] * il, zero) + sel(bx.Um[j], s.zu[j] * iu, zero) +
                       sel(bx.pin[j], ireg, zero));
-          rcl[b] = s.sl[j] * s.zl[j]; rcu[b] = s.su[j] * s.zu[j];
         }
         this->template factor_t<LAY_RED>(h, reg);
+        // (the slack reciprocals and complementarity products are formed AFTER the factorisation: four reciprocals twice are
+        //  cheaper than eight registers across the factorisation's levels)
+        L::fence();
+        MPMPC_UNROLL
+        for (int b = 0; b < 2; ++b) {
+          const int j = JB[b];
+          isl[b] = rcp_(s.sl[j]); isu[b] = rcp_(s.su[j]);
+          rcl[b] = s.sl[j] * s.zl[j]; rcu[b] = s.su[j] * s.zu[j];
+        }
       }
       R alpha_aff(1.0);
       for (int pass = 0; pass < 2; ++pass) {
@@ -433,6 +444,45 @@ struct ReducedSolver : Solver<L, false, true, false> {
     return (prim <= R(tol)) & (stat <= R(tol)) & (cv <= R(tol)) & !bad;
   }
 
+  // The active-set rounds are the register peak of the kernel (their factorisation on top of the caller's state); the boxed
+  // entries' slacks and multipliers of the interior point wait in LDS meanwhile.
+  MPMPC_HD void park_ip(const IpmI& s) {
+    L::fence();
+    MPMPC_UNROLL
+    for (int b = 0; b < 2; ++b) {
+      const int j = kSplit ? b : (b == 0 ? 0 : 2);
+      L::cold_put(K_PARK + 4 * b + 0, s.sl[j]); L::cold_put(K_PARK + 4 * b + 1, s.su[j]);
+      L::cold_put(K_PARK + 4 * b + 2, s.zl[j]); L::cold_put(K_PARK + 4 * b + 3, s.zu[j]);
+      L::cold_put(K_QQ + b, s.pi[j]);
+    }
+    // (the packed interior point's copies of cost and offsets are in registers again by now: their slots take the iterate)
+    MPMPC_UNROLL
+    for (int j = 0; j < EI; ++j) L::cold_put(K_PP + j, s.x[j]);
+    L::cold_put(K_LEQ, s.nu[0]); L::cold_put(K_LEQ + 1, s.nu[1]);
+    L::fence();
+  }
+  MPMPC_HD void unpark_ip(IpmI& s) {
+    L::fence();
+    MPMPC_UNROLL
+    for (int b = 0; b < 2; ++b) {
+      const int j = kSplit ? b : (b == 0 ? 0 : 2);
+      s.sl[j] = L::cold_get(K_PARK + 4 * b + 0); s.su[j] = L::cold_get(K_PARK + 4 * b + 1);
+      s.zl[j] = L::cold_get(K_PARK + 4 * b + 2); s.zu[j] = L::cold_get(K_PARK + 4 * b + 3);
+      s.pi[j] = L::cold_get(K_QQ + b);
+    }
+    MPMPC_UNROLL
+    for (int j = 0; j < EI; ++j) s.x[j] = L::cold_get(K_PP + j);
+    s.nu[0] = L::cold_get(K_LEQ); s.nu[1] = L::cold_get(K_LEQ + 1);
+    if constexpr (!kSplit) {
+      s.sl[1] = s.su[1] = R(1.0); s.zl[1] = s.zu[1] = s.pi[1] = R(0.0);
+      L::fence();
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) { L::cold_put(K_PP + e, P3[e]); L::cold_put(K_QQ + e, Q3[e]); }
+      L::cold_put(K_LEQ, leq[0]); L::cold_put(K_LEQ + 1, leq[1]);
+      L::fence();
+    }
+  }
+
   // ================================================================================ the solve
   // the certified point goes to cold storage (the slots of the start's G and pin multipliers, which are done with); with
   // `merge` a packed wave's later commit does not disturb what its partner instance has committed before
@@ -519,8 +569,8 @@ struct ReducedSolver : Solver<L, false, true, false> {
           // (merge: the lanes that missed their guess still need the start's G / pin multipliers, which share the slots)
           commit(good, true, xa, na, la, prim, stat);
           committed = true;
-          iters = seli(good, I(0), iters);
-          this->act_bits = seli(good, pack_active3(aL, aU), this->act_bits);
+          // (bit 29: certified from the guess - "iters = 0" rides in a register that lives through the solve anyway)
+          this->act_bits = seli(good, pack_active3(aL, aU) + I(1 << 29), this->act_bits);
           todo = todo & !good;
         }
       }
@@ -604,8 +654,10 @@ struct ReducedSolver : Solver<L, false, true, false> {
         mask_from_ip(gL, aL); mask_from_ip(gU, aU);
         MPMPC_UNROLL
         for (int e = 0; e < 3; ++e) { aL[e] = b3.Lm[e] & aL[e]; aU[e] = b3.Um[e] & aU[e] & !aL[e]; }
-        R xa[3], la[3] = {zero, zero, zero}, na[2] = {si.nu[0], si.nu[1]};
-        from_ip(si.x, xa);
+        // (the rounds overwrite the point on every lane they run on and nothing reads it elsewhere: no copy of the interior
+        //  point's iterate has to live through them)
+        R xa[3] = {zero, zero, zero}, la[3] = {zero, zero, zero}, na[2] = {zero, zero};
+        park_ip(si);
         MPMPC_TICK_BEGIN(5);
         const double frac = attempt == 0 ? st.as_add_fraction : (st.as_add_fraction > 0.5 ? st.as_add_fraction : 0.5);
         const Mk okm = this->template active_set<LAY_RED>(b3, P3, Q3, val, aL, aU, xa, na, la, st, todo & conv, frac);
@@ -620,9 +672,18 @@ struct ReducedSolver : Solver<L, false, true, false> {
         if constexpr (WARM) this->act_bits = seli(good, pack_active3(aL, aU), this->act_bits);
         todo = todo & conv & !good;          // a diverged interior-point run is not retried
         if (!L::wany(todo)) break;
+        unpark_ip(si);
+        if constexpr (kSplit) {          // (re-formed rather than carried through the rounds)
+          to_ip(b3.lo, bi.lo); to_ip(b3.hi, bi.hi); to_ip(P3, pp, 1.0); to_ip(Q3, qq);
+        }
         tol *= 1e-4;
       }
       }
+    }
+    {
+      const Mk warm_hit = bit_(this->act_bits, 29);
+      iters = seli(warm_hit, I(0), I(1));
+      this->act_bits = seli(warm_hit, this->act_bits - (1 << 29), this->act_bits);
     }
     // empty box: infeasible, zero ray, the width of the gap in resid[0]
     status = seli(empty, I(MPMPC_PRIMAL_INFEASIBLE), status);

@@ -49,7 +49,7 @@ static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const dou
 }
 
 // mpmpc_reduced_kernel: the reduced-native solver; instances it leaves UNSOLVED are appended to tail[1..]
-template <int G, int C>
+template <int G, int C, bool CR = true>
 static void solve_rn(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
                      int* status, int* iters, double* resid, double* y, int* tail, const int* guess = nullptr, int* act = nullptr) {
   using L = LaneEmu<G, C>;
@@ -63,9 +63,9 @@ static void solve_rn(const mpmpc_config* cfg, const mpmpc_settings* st, const do
       const int in = inst.v[i], kk = k.v[i];
       gs.v[i] = (guess && in < B && kk >= 0 && kk <= cfg->N) ? guess[in * ld + kk] : 0;
     }
-    ReducedSolver<L> s;
+    ReducedSolver<L, CR> s;
     typename L::real fields[MPMPC_NUM_FIELDS];
-    ReducedSolver<L>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    ReducedSolver<L, CR>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
     if (guess) s.template run<true>(fields, B, inst, k, cfg->N, make_params(*st), gs);
     else s.template run<false>(fields, B, inst, k, cfg->N, make_params(*st));
     s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y, act, ld);
@@ -140,6 +140,19 @@ extern "C" int emu_solve_rn(const mpmpc_config* cfg, const mpmpc_settings* st, i
   if (cfg->N + 1 > G || !reducible(*cfg, *st)) return -1;
   std::vector<int> tail(B + 1, 0);
   if (solve_rn_g(G, cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data())) return -1;
+  if (n_tail) *n_tail = tail[0];
+  return 0;
+}
+// the same kernel with the SEQUENTIAL elimination of the chains (the cyclic-reduction form is what ships): A/B in the tests
+extern "C" int emu_solve_rn_sequential(const mpmpc_config* cfg, const mpmpc_settings* st, int G, const double* qp, int B,
+                                       double* z, double* u0, int* status, int* iters, double* resid, double* y, int* n_tail) {
+  if (cfg->N + 1 > G || !reducible(*cfg, *st)) return -1;
+  std::vector<int> tail(B + 1, 0);
+  const int C = lane_split(G, cfg->N);
+  if (G == 64 && C == 16) solve_rn<64, 16, false>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data());
+  else if (G == 32) solve_rn<32, 16, false>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data());
+  else if (G == 16) solve_rn<16, 16, false>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data());
+  else return -1;
   if (n_tail) *n_tail = tail[0];
   return 0;
 }

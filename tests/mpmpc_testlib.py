@@ -243,6 +243,21 @@ class Emul:
         assert rc == 0
         return mpmpc.Solution(z, u0, st, it, rs, y), nt.value
 
+    def solve_rn(self, cfg, settings, qp, G=64, sequential=False):
+        """the reduced-native kernel alone (no tail launch); sequential = True: the same kernel with the chain-sequential
+        factorisation in place of the cyclic reduction (Solver<..., CR = false>).  -> (Solution, instances left unsolved)"""
+        B = qp.shape[1]
+        N = cfg.N
+        n, m = 5 * N + 3, 8 * N + 6
+        z, u0, y = np.zeros((B, n)), np.zeros((B, 2)), np.zeros((B, m))
+        st, it, rs = np.zeros(B, np.int32), np.zeros((B, 2), np.int32), np.zeros((B, 2))
+        nt = C.c_int(0)
+        fn = self.lib.emu_solve_rn_sequential if sequential else self.lib.emu_solve_rn
+        rc = fn(C.byref(cfg), C.byref(settings), C.c_int(G), _d(np.ascontiguousarray(qp)), C.c_int(B), _d(z), _d(u0), _i(st), _i(it),
+                _d(rs), _d(y), C.byref(nt))
+        assert rc == 0
+        return mpmpc.Solution(z, u0, st, it, rs, y), nt.value
+
     def solve_warm(self, cfg, settings, qp, guess, G=64):
         """closed-loop variant: start from the active sets `guess` [B, ld]; -> (Solution, act [B, ld])"""
         B = qp.shape[1]

@@ -398,3 +398,28 @@ def test_empty_speed_box_is_reported_infeasible(emu, track):
     Pd, q, A, l, u = T.qp_to_dense(qp[:, 0, :], sc.N)
     r = O.solve(np.diag(Pd), q, A, l, u, O.Settings(polish=2))
     assert r.status == O.PRIMAL_INFEASIBLE and r.pri_res > 0.5
+
+
+@pytest.mark.parametrize("cfgid,B,N,Gs", [(2, 96, 30, (64, 32)), (4, 128, 30, (64, 32)), (2, 48, 10, (64, 32, 16)), (4, 48, 3, (64, 32, 16)),
+                                          (2, 48, 15, (64, 32, 16)), (4, 64, 20, (64, 32))])
+def test_cyclic_reduction_factorisation_agrees_with_the_sequential_one(cfgid, B, N, Gs, emu, track):
+    """The reduced-native kernels factor the chains of the Schur complement by cyclic reduction in Cholesky form
+    (mpmpc_core.hpp, factor_cr2 / s_solve_cr2: a different elimination ORDER of the same SPD block-tridiagonal matrix).
+    Against the same kernel with the chain-sequential elimination (CR = false): same verdicts, same hand-overs to the tail,
+    the same interior-point iteration counts instance by instance, the same controls to rounding - and the points pass the
+    plain-numpy KKT test."""
+    sc = scenarios.make(cfgid, track, B=B, N=N)
+    cfg = T.stock_config(N, sc.weights)
+    st = mpmpc.default_settings()
+    qp = emu.assemble(cfg, track, _inputs(sc))
+    for G in Gs:
+        a, ta = emu.solve_rn(cfg, st, qp, G)
+        b, tb = emu.solve_rn(cfg, st, qp, G, sequential=True)
+        assert np.array_equal(a.status, b.status) and ta == tb
+        ok = a.status == 1
+        assert ok.sum() >= B // 2
+        assert np.array_equal(a.iters[ok], b.iters[ok])
+        assert np.max(np.abs(a.u0[ok] - b.u0[ok])) <= 1e-13
+        assert np.max(np.abs(a.z[ok] - b.z[ok])) <= 1e-11
+        prim, stat, comp = T.kkt_batch(qp[:, ok], N, a.z[ok], a.y[ok])
+        assert max(prim.max(), stat.max(), comp.max()) <= 1e-9
