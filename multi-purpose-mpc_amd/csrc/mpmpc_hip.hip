@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
   MPMPC_TICK_BEGIN(8);
   double fields[MPMPC_NUM_FIELDS];
   assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
-  Solver<L, VAR == 1, VAR == 2, VAR == 3> s;
+  Solver<L, VAR == 1, VAR == 2, VAR == 3, VAR == 2> s;   // (the reduced variant factors its 16-lane chains by cyclic reduction, like the reduced-native kernels)
   // (second launch of a packed batch: the interior-point iterations the first launch spent on this instance)
   const int base_ipm = (mode == 2 && iters) ? iters[inst * 2 + 1] : 0;
   static_assert(G == 64, "the general kernels run one instance per wave (only the reduced-native kernels pack)");

@@ -34,9 +34,9 @@ static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const dou
       gs.v[i] = (guess && in < B && kk >= 0 && kk <= cfg->N) ? guess[in * ld + kk] : 0;
       if (mode == 2) base.v[i] = iters[in * 2 + 1];
     }
-    Solver<L, FQ, RED, FREEX> s;
+    Solver<L, FQ, RED, FREEX, RED> s;
     typename L::real fields[MPMPC_NUM_FIELDS];
-    Solver<L, FQ, RED, FREEX>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    Solver<L, FQ, RED, FREEX, RED>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
     // (like the device: the packed kernels carry no phase-1 code when they run as the first of two launches)
     if (guess) s.template run<true>(fields, B, inst, k, cfg->N, make_params(*st), mode, gs, base, cfg->QN_offdiag);
     else if (mode == 1) s.template run<false, (G == 64)>(fields, B, inst, k, cfg->N, make_params(*st), mode, VI(0), base, cfg->QN_offdiag);
