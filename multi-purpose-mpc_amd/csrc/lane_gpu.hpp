@@ -212,13 +212,16 @@ struct LaneGpu {
   static __device__ __forceinline__ void rows(double* dst, int rowlen, int inst, int n_inst, F fill) {
     double* buf = cold();
     __syncthreads();                              // one wave per block: orders the LDS accesses only
-    const int mine = slot() * rowlen;
+    // (rows are written at the very end of a kernel: the lane number is formed again here, so that nothing derived from
+    //  threadIdx has to stay in a register through the solve for it)
+    const int lane = lane_again(), sl = lane / G;
+    const int mine = sl * rowlen;
     fill([&](int idx, bool ok, double v) { if (ok) buf[mine + idx] = v; });
     __syncthreads();
-    const int inst0 = inst - slot();              // first instance of this wave
+    const int inst0 = inst - sl;                  // first instance of this wave
     const int cnt = (n_inst - inst0 < per_wave ? n_inst - inst0 : per_wave) * rowlen;
     double* out = dst + (long)inst0 * rowlen;
-    for (int i = lane_id(); i < cnt; i += 64) out[i] = buf[i];
+    for (int i = lane; i < cnt; i += 64) out[i] = buf[i];
   }
 
   static __device__ __forceinline__ double load(const double* p, int idx, bool ok, double dflt) {

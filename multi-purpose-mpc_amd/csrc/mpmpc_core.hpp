@@ -241,6 +241,10 @@ struct Solver {
   using R = typename L::real;
   using Mk = typename L::mask;
   using I = typename L::ival;
+  // An instance-wide condition is wave-wide when the wave holds ONE instance, and the loops below leave as soon as it is false:
+  // inside them "update where the instance is still running" needs no select (two v_cndmask per double otherwise).
+  MPMPC_HD static R updw(const Mk& m, const R& a, const R& b) { if constexpr (L::per_wave == 1) { (void)m; (void)b; return a; } else return sel(m, a, b); }
+  MPMPC_HD static Mk updwb(const Mk& m, const Mk& a, const Mk& b) { if constexpr (L::per_wave == 1) { (void)m; (void)b; return a; } else return selb(m, a, b); }
 
   // ---- lane context
   int N, n_inst, off_;    // off_: lane of stage 0 inside the group (lane_offset)
@@ -1022,25 +1026,29 @@ struct Solver {
   // Cm: coupling of the lane's stage with its current LOWER neighbour, S_{p, p - D} (row-major 2 x 2).
   template <int D>
   MPMPC_HD void cr_level(R Dg[3], R Cm[4]) {
-    // (written in the order that keeps the fewest blocks alive at once: the kernel lives on a 256-register budget)
+    // (written in the order that keeps the fewest blocks alive at once: the kernel lives on a 256-register budget.  inv(L) is
+    //  masked ONCE - zero on the lanes that are not eliminated at this level - so that Ua, Ub come out zero there without a
+    //  select each, and since every lane is eliminated at exactly one level the kept blocks are ACCUMULATED by exact additions
+    //  of those zeros: one v_add_f64 per entry instead of two v_cndmask)
     const Mk E = L::template cr_elim<D>();
     const R zero(0.0);
     // Cholesky of the own block on every lane (used where the lane is eliminated at this level)
-    const R i00 = rsqrt_(Dg[0]);
+    R i00 = rsqrt_(Dg[0]);
     const R l10 = Dg[1] * i00;
-    const R i11 = rsqrt_(fma_(-l10, l10, Dg[2]));
-    const R i10 = -(l10 * i00) * i11;
-    Li[0] = sel(E, i00, Li[0]); Li[1] = sel(E, i10, Li[1]); Li[2] = sel(E, i11, Li[2]);
+    R i11 = rsqrt_(fma_(-l10, l10, Dg[2]));
+    R i10 = -(l10 * i00) * i11;
+    i00 = sel(E, i00, zero); i10 = sel(E, i10, zero); i11 = sel(E, i11, zero);
+    Li[0] = Li[0] + i00; Li[1] = Li[1] + i10; Li[2] = Li[2] + i11;
     // Ub = inv(L) S_eb = inv(L) Cb',  Cb = S_be = the coupling lane e + D holds with its lower neighbour e
     R gb[4];
     {
       R Cb[4], Ub[4];
       MPMPC_UNROLL
       for (int i = 0; i < 4; ++i) Cb[i] = L::template rshl<D>(Cm[i]);
-      Ub[0] = sel(E, i00 * Cb[0], zero); Ub[1] = sel(E, i00 * Cb[2], zero);
-      Ub[2] = sel(E, fma_(i11, Cb[1], i10 * Cb[0]), zero); Ub[3] = sel(E, fma_(i11, Cb[3], i10 * Cb[2]), zero);
+      Ub[0] = i00 * Cb[0]; Ub[1] = i00 * Cb[2];
+      Ub[2] = fma_(i11, Cb[1], i10 * Cb[0]); Ub[3] = fma_(i11, Cb[3], i10 * Cb[2]);
       MPMPC_UNROLL
-      for (int i = 0; i < 4; ++i) { Gout[i] = sel(E, Ub[i], Gout[i]); gb[i] = L::template rshr<D>(Ub[i]); }
+      for (int i = 0; i < 4; ++i) { Gout[i] = Gout[i] + Ub[i]; gb[i] = L::template rshr<D>(Ub[i]); }
     }
     // to the upper neighbour b (lane e + D):  D_b -= Ub'Ub
     Dg[0] = fma_(-gb[2], gb[2], fma_(-gb[0], gb[0], Dg[0]));
@@ -1050,10 +1058,10 @@ struct Solver {
     R ga[4];
     {
       R Ua[4];
-      Ua[0] = sel(E, i00 * Cm[0], zero); Ua[1] = sel(E, i00 * Cm[1], zero);
-      Ua[2] = sel(E, fma_(i11, Cm[2], i10 * Cm[0]), zero); Ua[3] = sel(E, fma_(i11, Cm[3], i10 * Cm[1]), zero);
+      Ua[0] = i00 * Cm[0]; Ua[1] = i00 * Cm[1];
+      Ua[2] = fma_(i11, Cm[2], i10 * Cm[0]); Ua[3] = fma_(i11, Cm[3], i10 * Cm[1]);
       MPMPC_UNROLL
-      for (int i = 0; i < 4; ++i) Gin[i] = sel(E, Ua[i], Gin[i]);
+      for (int i = 0; i < 4; ++i) Gin[i] = Gin[i] + Ua[i];
       // to the lower neighbour a (lane e - D):  D_a -= Ua'Ua
       {
         R fa[4];
@@ -1084,7 +1092,7 @@ struct Solver {
     // (position 15 is never eliminated by a level, so its Gout is free until the junction: the end lane's hand-on to the
     //  meeting stage waits there instead of in four more registers)
     MPMPC_UNROLL
-    for (int i = 0; i < 4; ++i) { Gin[i] = zero; Gout[i] = To[i]; }
+    for (int i = 0; i < 4; ++i) { Gin[i] = zero; Gout[i] = sel(is_end, To[i], zero); }
     cr_level<1>(Dg, Cm);
     cr_level<2>(Dg, Cm);
     cr_level<4>(Dg, Cm);
@@ -1126,8 +1134,8 @@ struct Solver {
     const Mk E = L::template cr_elim<D>();
     const R zero(0.0);
     const R t0 = Li[0] * b0, t1 = fma_(Li[2], b1, Li[1] * b0);            // y = inv(L) b
-    y0 = sel(E, t0, y0); y1 = sel(E, t1, y1);
     const R e0 = sel(E, t0, zero), e1 = sel(E, t1, zero);
+    y0 = y0 + e0; y1 = y1 + e1;                                            // (each lane is eliminated once: an exact accumulation)
     // b_a -= Ua' y,  b_b -= Ub' y
     const R pa0 = fma_(Gin[2], e1, Gin[0] * e0), pa1 = fma_(Gin[3], e1, Gin[1] * e0);
     const R pb0 = fma_(Gout[2], e1, Gout[0] * e0), pb1 = fma_(Gout[3], e1, Gout[1] * e0);
@@ -1946,15 +1954,15 @@ struct Solver {
       }
       MPMPC_UNROLL
       for (int j = 0; j < E; ++j) {
-        xs[j] = sel(todo, xn[j], xs[j]);
-        lam[j] = sel(todo, ln[j], lam[j]);
+        xs[j] = updw(todo, xn[j], xs[j]);
+        lam[j] = updw(todo, ln[j], lam[j]);
         Mk nL = (aL[j] & !bL[j]) | vL[j];
         Mk nU = ((aU[j] & !bU_[j]) | vU[j]) & !nL;
         aL[j] = selb(todo & anybad, nL, aL[j]);
         aU[j] = selb(todo & anybad, nU, aU[j]);
       }
       MPMPC_UNROLL
-      for (int i = 0; i < NQ; ++i) nus[i] = sel(todo, nn[i], nus[i]);
+      for (int i = 0; i < NQ; ++i) nus[i] = updw(todo, nn[i], nus[i]);
       okm = okm | (todo & !anybad);
       todo = todo & anybad;
     }
