@@ -72,9 +72,11 @@ _FLOPS = {
 
 
 # the reduced-native kernels (mpmpc_settings::native; profiles/census.py through the launcher's sequence of kernels)
+# (cyclic-reduction factorisation of the 16-lane chains: every stage is eliminated at one of the four levels, so a level's
+#  work counts once per stage in "algorithmic" - like one step per stage of a serial sweep - and four times in "executed")
 _FLOPS_NATIVE = {
-    1: dict(algorithmic=(32648.0, 18134.0), executed=(90024.0, 40982.0), N=30),
-    -3: dict(algorithmic=(29263.0, 21327.0), executed=(41182.0, 47796.0), N=30),
+    1: dict(algorithmic=(37091.0, 19396.0), executed=(71260.0, 30855.0), N=30),
+    -3: dict(algorithmic=(37714.0, 22145.0), executed=(48264.0, 35098.0), N=30),
 }
 
 
@@ -405,7 +407,8 @@ def _main(real_stdout):
                                 "flops_per_solve_algorithmic": fa / B, "flops_per_solve_executed": fe / B,
                                 "reduced_polish": red,
                                 "note": "algorithmic = structure-exploiting count of the implemented recurrence (one step per stage "
-                                        "and serial sweep; per stage: factor 180, KKT solve 110 flops); executed = wave "
+                                        "and serial sweep, one level per stage of a cyclic-reduction factorisation; 3x3 chains: "
+                                        "factor 180, KKT solve 110 flops per stage); executed = wave "
                                         "instructions x stage-holding lanes; both fitted on the census of the emulated lane "
                                         "code (profiles/census.py, bench.py:_FLOPS)"}
         bytes_k1 = k1_bytes_per_solve(N) * B

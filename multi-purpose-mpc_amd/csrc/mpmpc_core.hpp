@@ -1093,14 +1093,21 @@ struct Solver {
     //  meeting stage waits there instead of in four more registers)
     MPMPC_UNROLL
     for (int i = 0; i < 4; ++i) { Gin[i] = zero; Gout[i] = sel(is_end, To[i], zero); }
-    cr_level<1>(Dg, Cm);
-    cr_level<2>(Dg, Cm);
-    cr_level<4>(Dg, Cm);
-    cr_level<8>(Dg, Cm);
+    {
+      // (census: every stage is eliminated at exactly ONE of the four levels - its factorisation and the updates it sends
+      //  are one level's work - although all lanes execute all four: like one step per stage of a serial sweep)
+      MPMPC_SERIAL_BEGIN();
+      cr_level<1>(Dg, Cm);
+      cr_level<2>(Dg, Cm);
+      cr_level<4>(Dg, Cm);
+      cr_level<8>(Dg, Cm);
+      MPMPC_SERIAL_END(4);
+    }
     // position 15 of each row: the end lane (row 1) is eliminated, its block M = S_{mid,end} inv(L_end)' goes to the meeting
     // stage (row 0), which is factored last.  (Chains shorter than a row: the positions without a stage carry identity-like
     // blocks and zero couplings, they factor harmlessly.)
     const Mk last = is_mid | is_end;
+    MPMPC_SERIAL_BEGIN();                  // (census: the junction is useful on its two lanes only)
     {
       const R i00 = rsqrt_(Dg[0]);
       const R l10 = Dg[1] * i00;
@@ -1126,6 +1133,7 @@ struct Solver {
       const R i10 = -(l10 * i00) * i11;
       Li[0] = sel(is_mid, i00, Li[0]); Li[1] = sel(is_mid, i10, Li[1]); Li[2] = sel(is_mid, i11, Li[2]);
     }
+    MPMPC_SERIAL_END(N + 1);
     (void)last;
   }
   // forward / backward substitution of one cyclic-reduction level
@@ -1156,12 +1164,17 @@ struct Solver {
     const R zero(0.0);
     R b0 = sel(vxc, L::mirror(bv[0]), zero), b1 = sel(vxc, L::mirror(bv[1]), zero);
     R y0(0.0), y1(0.0);
-    cr_forward<1>(b0, b1, y0, y1);
-    cr_forward<2>(b0, b1, y0, y1);
-    cr_forward<4>(b0, b1, y0, y1);
-    cr_forward<8>(b0, b1, y0, y1);
+    {
+      MPMPC_SERIAL_BEGIN();
+      cr_forward<1>(b0, b1, y0, y1);
+      cr_forward<2>(b0, b1, y0, y1);
+      cr_forward<4>(b0, b1, y0, y1);
+      cr_forward<8>(b0, b1, y0, y1);
+      MPMPC_SERIAL_END(4);
+    }
     // junction: y_end = inv(L_end) b_end;  b_mid -= M y_end;  y_mid = inv(L_mid) b_mid;  nu_mid = inv(L_mid)' y_mid;
     //           nu_end = inv(L_end)' (y_end - M' nu_mid)
+    MPMPC_SERIAL_BEGIN();                                                           // (census: useful on the two lanes of the junction only)
     const R ye0 = Li[0] * b0, ye1 = fma_(Li[2], b1, Li[1] * b0);                   // valid on the end lane (and, pre-update, on mid)
     const R q0 = fma_(Gout[1], ye1, Gout[0] * ye0), q1 = fma_(Gout[3], ye1, Gout[2] * ye0);      // M y_end on the end lane
     const R qm0 = sel(is_mid, L::down(L::mirror(sel(is_end, q0, zero))), zero), qm1 = sel(is_mid, L::down(L::mirror(sel(is_end, q1, zero))), zero);
@@ -1173,10 +1186,15 @@ struct Solver {
     const R re0 = ye0 - fma_(Gout[2], me1, Gout[0] * me0), re1 = ye1 - fma_(Gout[3], me1, Gout[1] * me0);
     const R ne0 = fma_(Li[1], re1, Li[0] * re0), ne1 = Li[2] * re1;
     R n0 = sel(is_mid, nm0, sel(is_end, ne0, zero)), n1 = sel(is_mid, nm1, sel(is_end, ne1, zero));
-    cr_backward<8>(y0, y1, n0, n1);
-    cr_backward<4>(y0, y1, n0, n1);
-    cr_backward<2>(y0, y1, n0, n1);
-    cr_backward<1>(y0, y1, n0, n1);
+    MPMPC_SERIAL_END(N + 1);
+    {
+      MPMPC_SERIAL_BEGIN();
+      cr_backward<8>(y0, y1, n0, n1);
+      cr_backward<4>(y0, y1, n0, n1);
+      cr_backward<2>(y0, y1, n0, n1);
+      cr_backward<1>(y0, y1, n0, n1);
+      MPMPC_SERIAL_END(4);
+    }
     nu[0] = L::mirror(n0); nu[1] = L::mirror(n1);
   }
 
