@@ -385,7 +385,10 @@ def _main(real_stdout):
         k2_name = "mpmpc_reduced_kernel" if nat else "mpmpc_solve_kernel"
         traffic, traffic_src = pmc_traffic_bytes(k2_name, B, lib_version) if args.config == 2 else (None, "PMC passes are collected for config 2 only")
         ms_events = ms_k2
-        ms_prof, ms_src = rocprof_kernel_average(args.config, B, lib_version)
+        if args.set or args.lanes or os.environ.get("MPMPC_RN_OCC"):
+            ms_prof, ms_src = None, "non-default settings: the committed kernel trace is of the default command"
+        else:
+            ms_prof, ms_src = rocprof_kernel_average(args.config, B, lib_version)
         if ms_prof is not None:
             ms_k2 = ms_prof          # the committed rocprofv3 kernel average of the same library
         out["roofline"] = {"bound": "hbm", "kernel": k2_name + (" (+ tail launch of mpmpc_solve_kernel)" if nat else ""),
