@@ -138,8 +138,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                            int* __restrict__ status, int* __restrict__ iters,
                                                            double* __restrict__ resid, double* __restrict__ y,
                                                            int* __restrict__ tail, int* __restrict__ act,
-                                                           const int* __restrict__ shift) {
+                                                           const int* __restrict__ shift, int* __restrict__ tail_reset,
+                                                           unsigned* __restrict__ tail_flag, unsigned seq) {
   using L = LaneGpu<G, C, RN_SLOTS>;
+  // (the list of the NEXT launch is emptied here as well: the tail launch, which does it too, may be deferred - see
+  //  launch_solve)
+  if (blockIdx.x == 0 && threadIdx.x == 0) *tail_reset = 0;
   const int inst = blockIdx.x * L::per_wave + L::slot();
   const int k = L::stage() - lane_offset(G, C, cfg.N);
   int guess = 0;
@@ -159,7 +163,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   s.store(inst_o, k_o, cfg.wheelbase, z, u0, status, iters, resid, y, WARM ? act : nullptr, ld);
   MPMPC_TICK_END(7);
   MPMPC_TICK_END(8);
-  if (k_o == 0 && inst_o < B && s.status == MPMPC_UNSOLVED) tail[1 + atomicAdd(tail, 1)] = inst_o;
+  if (k_o == 0 && inst_o < B && s.status == MPMPC_UNSOLVED) {
+    tail[1 + atomicAdd(tail, 1)] = inst_o;
+    // "this launch left a tail": the launch's sequence number, in host memory the device writes through (read by the host
+    // after the stream has drained: observe_tail)
+    __hip_atomic_store(tail_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // K4: speed profile.  The kernel of choice is mpmpc_speed_profile_wave_kernel below (one wavefront per path); these
@@ -450,12 +459,36 @@ struct mpmpc_handle_s {
   // instances the early pass of a packed (2 or 4 per wave) launch could not certify: [0] = count, [1..] = ids
   int* tail = nullptr;
   int tail_flip = 0;          // which of the two lists the next reduced-native launch fills
+  // Deferred tail (batch launches of the reduced-native kernels, not the closed loop).  Launching the tail kernel costs
+  // 4.8 us even when its list is empty - 10 % of a 1 024-instance step - so when the last launch whose outcome the host
+  // has SEEN left no tail, the next launches do not enqueue one: the reduced-native kernel stamps its sequence number into
+  // tail_flag (host memory) if it appends anything, and every entry point through which results or state can be observed
+  // or changed (sync, download, upload, set_*, rollout, timed launches) first drains the stream, looks at the stamp and
+  // runs the tail of the LAST launch if it left one (observe_tail).  A launch that is followed by another launch without
+  // such a call in between has unobservable results either way (same output buffers).
+  unsigned* tail_flag = nullptr;      // hipHostMalloc'ed, device-visible
+  unsigned seq = 0;                   // sequence number of the last reduced-native launch
+  bool tail_expect_empty = false;     // the last observed launch left no tail
+  bool pend = false;                  // the last launch's tail launch was not enqueued
+  bool tail_ran_late = false;         // the last observe_tail had to run a deferred tail
+  int pend_B = 0;
+  bool pend_y = false;
+  int *pend_cur = nullptr, *pend_next = nullptr;
   int force_lanes = 0;      // mpmpc_set_packing: 0 = chosen from the batch size
   bool resident_y = true;   // mpmpc_set_outputs: do resident launches store the multipliers y (46 % of the output bytes)?
   bool y_valid = false;     // the last solve launch stored y
 };
 
 static int host_stage_ld(int N) { return N + 1 <= 16 ? 16 : (N + 1 <= 32 ? 32 : 64); }
+
+static int observe_tail(mpmpc_handle h);
+// first statement of every entry point that reads results or changes what a deferred tail launch would work on
+#define MPMPC_SETTLE(h)                            \
+  do {                                             \
+    if ((h)->pend) {                               \
+      if (int rc_ = observe_tail(h)) return rc_;   \
+    }                                              \
+  } while (0)
 
 static int check_settings(const mpmpc_settings* s) {
   if (!s) return fail(MPMPC_E_ARG, "settings is NULL");
@@ -482,7 +515,7 @@ static int check_settings(const mpmpc_settings* s) {
 }
 
 static int launch_assemble(mpmpc_handle h, int B);
-static int launch_solve(mpmpc_handle h, int B, bool closed_loop = false, bool want_y = true);
+static int launch_solve(mpmpc_handle h, int B, bool closed_loop = false, bool want_y = true, bool tail_only = false);
 
 extern "C" {
 
@@ -579,6 +612,7 @@ int mpmpc_destroy(mpmpc_handle h) {
     if (p) (void)hipFree(p);
   if (h->stage_in) (void)hipHostFree(h->stage_in);
   if (h->stage_out) (void)hipHostFree(h->stage_out);
+  if (h->tail_flag) (void)hipHostFree(h->tail_flag);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   if (h->ev_in) (void)hipEventDestroy(h->ev_in);
@@ -642,6 +676,12 @@ int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_
   ALLOC(h->qp, (size_t)MPMPC_NUM_FIELDS * B * h->ld);
   ALLOC(h->tail, 2 * (B + 1));
   (void)hipMemset(h->tail, 0, 2 * (B + 1) * sizeof(int));
+  if (hipHostMalloc(reinterpret_cast<void**>(&h->tail_flag), sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
+    h->tail_flag = nullptr;
+    mpmpc_destroy(h);
+    return fail(MPMPC_E_HIP, "hipHostMalloc tail_flag");
+  }
+  *h->tail_flag = 0u;
 #undef ALLOC
   {
     const size_t STAGE_LIMIT = 64u << 20;
@@ -664,6 +704,7 @@ int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_
 
 int mpmpc_set_packing(mpmpc_handle h, int32_t lanes_per_instance) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  MPMPC_SETTLE(h);
   const int g = lanes_per_instance;
   if (g != 0 && g != 16 && g != 32 && g != 64) return fail(MPMPC_E_ARG, "lanes_per_instance must be 0 (auto), 16, 32 or 64");
   if (g != 0 && h->cfg.N + 1 > g) return fail(MPMPC_E_ARG, "lanes_per_instance must hold the N + 1 stages of an instance");
@@ -673,6 +714,7 @@ int mpmpc_set_packing(mpmpc_handle h, int32_t lanes_per_instance) {
 
 int mpmpc_set_settings(mpmpc_handle h, const mpmpc_settings* settings) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  MPMPC_SETTLE(h);
   if (int rc = check_settings(settings)) return rc;
   h->st = *settings;
   return MPMPC_OK;
@@ -687,6 +729,7 @@ static int upload_table(mpmpc_handle h, double** dst, const double* src, size_t 
 
 int mpmpc_set_path(mpmpc_handle h, int32_t n_wp, const double* kappa, const double* v_ref, const double* ds_next) {
   if (!h || !kappa || !v_ref || !ds_next) return fail(MPMPC_E_ARG, "NULL argument");
+  MPMPC_SETTLE(h);
   if (n_wp < 2) return fail(MPMPC_E_ARG, "need at least 2 waypoints");
   for (int i = 0; i < n_wp; ++i)
     if (!(v_ref[i] > 0) || !std::isfinite(kappa[i]) || !(ds_next[i] >= 0))
@@ -703,6 +746,7 @@ int mpmpc_set_path(mpmpc_handle h, int32_t n_wp, const double* kappa, const doub
 
 int mpmpc_set_corridor(mpmpc_handle h, int32_t n_wp, int32_t n_cols, const double* ub, const double* lb) {
   if (!h || !ub || !lb) return fail(MPMPC_E_ARG, "NULL argument");
+  MPMPC_SETTLE(h);
   if (h->n_wp == 0 || n_wp != h->n_wp) return fail(MPMPC_E_STATE, "set the path first; n_wp must match it");
   if (n_cols < h->cfg.N) return fail(MPMPC_E_ARG, "corridor table needs n_cols >= N");
   HIP_TRY(hipSetDevice(h->cfg.device));
@@ -716,6 +760,7 @@ int mpmpc_set_corridor(mpmpc_handle h, int32_t n_wp, int32_t n_cols, const doubl
 int mpmpc_set_map(mpmpc_handle h, int32_t height, int32_t width, const int8_t* data, double origin_x,
                   double origin_y, double resolution) {
   if (!h || !data) return fail(MPMPC_E_ARG, "NULL argument");
+  MPMPC_SETTLE(h);
   if (height < 1 || width < 1 || !(resolution > 0)) return fail(MPMPC_E_ARG, "map needs positive size and resolution");
   if (height > COR_MAX_SIDE || width > COR_MAX_SIDE) return fail(MPMPC_E_ARG, "map sides are limited to 65534 cells");
   HIP_TRY(hipSetDevice(h->cfg.device));
@@ -730,6 +775,7 @@ int mpmpc_set_map(mpmpc_handle h, int32_t height, int32_t width, const int8_t* d
 int mpmpc_set_path_geometry(mpmpc_handle h, int32_t n_wp, const double* x, const double* y, const double* psi,
                             const double* border_ub, const double* border_lb) {
   if (!h || !x || !y || !psi || !border_ub || !border_lb) return fail(MPMPC_E_ARG, "NULL argument");
+  MPMPC_SETTLE(h);
   if (h->n_wp == 0 || n_wp != h->n_wp) return fail(MPMPC_E_STATE, "set the path first; n_wp must match it");
   HIP_TRY(hipSetDevice(h->cfg.device));
   if (int rc = upload_table(h, &h->gx, x, n_wp)) return rc;
@@ -760,6 +806,7 @@ int mpmpc_set_path_geometry(mpmpc_handle h, int32_t n_wp, const double* x, const
 int mpmpc_build_corridor(mpmpc_handle h, int32_t n_cols, double min_width, double safety_margin, double* ub_out,
                          double* lb_out, int32_t* bad_rows) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  MPMPC_SETTLE(h);
   if (!h->map || h->geom_n == 0 || h->geom_n != h->n_wp)
     return fail(MPMPC_E_STATE, "needs mpmpc_set_path, mpmpc_set_map and mpmpc_set_path_geometry first");
   if (n_cols < h->cfg.N) return fail(MPMPC_E_ARG, "corridor table needs n_cols >= N");
@@ -809,6 +856,7 @@ int mpmpc_build_corridor(mpmpc_handle h, int32_t n_cols, double min_width, doubl
 int mpmpc_rollout_init(mpmpc_handle h, int32_t B, double Ts, const double* cum_lengths, const double* s,
                        const double* pose, const double* cc0) {
   if (!h || !cum_lengths || !s || !pose) return fail(MPMPC_E_ARG, "NULL argument");
+  MPMPC_SETTLE(h);
   if (B < 1 || B > h->cfg.max_batch) return fail(MPMPC_E_ARG, "B must be in [1, max_batch]");
   if (!(Ts > 0)) return fail(MPMPC_E_ARG, "Ts must be > 0");
   if (h->n_wp == 0 || h->geom_n != h->n_wp) return fail(MPMPC_E_STATE, "needs mpmpc_set_path and mpmpc_set_path_geometry");
@@ -852,6 +900,7 @@ int mpmpc_rollout_init(mpmpc_handle h, int32_t B, double Ts, const double* cum_l
 
 int mpmpc_rollout_set_counters(mpmpc_handle h, int32_t B, const int32_t* counter) {
   if (!h || !counter) return fail(MPMPC_E_ARG, "NULL argument");
+  MPMPC_SETTLE(h);
   if (B < 1 || B > h->ro_B || !h->ro_valid) return fail(MPMPC_E_STATE, "call mpmpc_rollout_init for at least B cars first");
   for (int i = 0; i < B; ++i)
     if (counter[i] < 0 || counter[i] >= h->cfg.N - 1) return fail(MPMPC_E_ARG, "infeasibility counters must be in [0, N - 2]");
@@ -863,6 +912,7 @@ int mpmpc_rollout_set_counters(mpmpc_handle h, int32_t B, const int32_t* counter
 
 int mpmpc_rollout_step(mpmpc_handle h, int32_t B, int32_t n_steps) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  MPMPC_SETTLE(h);
   if (B < 1 || B > h->ro_B) return fail(MPMPC_E_STATE, "call mpmpc_rollout_init for at least B cars first");
   if (!h->ro_valid)
     return fail(MPMPC_E_STATE, "the rollout's state was overwritten by an upload / solve / assemble on this handle: "
@@ -891,6 +941,7 @@ int mpmpc_rollout_warm_start(mpmpc_handle h, int32_t enable) {
 int mpmpc_rollout_state(mpmpc_handle h, int32_t B, double* s, double* pose, double* cc, int32_t* wp_id, double* x0,
                         double* u_last, int32_t* status, int32_t* counter, int32_t* alive) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  MPMPC_SETTLE(h);
   if (B < 1 || B > h->ro_B) return fail(MPMPC_E_STATE, "call mpmpc_rollout_init for at least B cars first");
   if (!h->ro_valid)
     return fail(MPMPC_E_STATE, "the rollout's state was overwritten by an upload / solve / assemble on this handle: "
@@ -915,6 +966,7 @@ int mpmpc_rollout_state(mpmpc_handle h, int32_t B, double* s, double* pose, doub
 int mpmpc_upload(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x0, const double* cc_prev,
                  const double* lb, const double* ub) {
   if (!h || !wp_id || !x0 || !cc_prev) return fail(MPMPC_E_ARG, "NULL argument");
+  MPMPC_SETTLE(h);
   if (B < 1 || B > h->cfg.max_batch) return fail(MPMPC_E_ARG, "B must be in [1, max_batch]");
   if (h->n_wp == 0) return fail(MPMPC_E_STATE, "no path set (mpmpc_set_path)");
   if ((lb == nullptr) != (ub == nullptr)) return fail(MPMPC_E_ARG, "lb and ub must both be given or both NULL");
@@ -971,7 +1023,8 @@ static int launch_assemble(mpmpc_handle h, int B) {
   return MPMPC_OK;
 }
 
-static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y) {
+// tail_only: the deferred tail launch of the last reduced-native launch (observe_tail), nothing else
+static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, bool tail_only) {
   const int N = h->cfg.N;
   double* y_out = want_y ? h->y : nullptr;        // nobody wants the multipliers: the kernel skips their stores
   h->y_valid = want_y;
@@ -1010,7 +1063,8 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y) {
   // list of the next one, so that no memset has to sit between the launches of consecutive steps
   int* tail_cur = h->tail + (size_t)h->tail_flip * (h->cfg.max_batch + 1);
   int* tail_next = h->tail + (size_t)(1 - h->tail_flip) * (h->cfg.max_batch + 1);
-  if (rn) h->tail_flip = 1 - h->tail_flip;
+  if (tail_only) { tail_cur = h->pend_cur; tail_next = h->pend_next; }
+  else if (rn) { h->tail_flip = 1 - h->tail_flip; h->seq += 1; }
 #define LAUNCH_W(CC, WW, FF, MODE, BLOCKS)                                                                                \
   hipLaunchKernelGGL((mpmpc_solve_kernel<64, CC, WW, FF>), dim3(BLOCKS), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, \
                      ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, MODE, tail_cur, WW ? warm_act : nullptr,   \
@@ -1034,22 +1088,30 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y) {
   static const int rn_pad = (std::getenv("MPMPC_RN_OCC") && std::atoi(std::getenv("MPMPC_RN_OCC")) == 1) ? 20 * 1024 : 0;
 #define LAUNCH_RN_W(GG, CC, WW)                                                                                             \
   hipLaunchKernelGGL((mpmpc_reduced_kernel<GG, CC, WW>), dim3(blocks), dim3(64), rn_pad, h->stream, h->cfg, prm, B, h->ld, \
-                     ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, tail_cur, warm_act, warm_shift)
+                     ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, tail_cur, warm_act, warm_shift, tail_next,      \
+                     h->tail_flag, h->seq)
 #define LAUNCH_RN(GG, CC)                       \
   do {                                          \
     if (warm) LAUNCH_RN_W(GG, CC, true);        \
     else LAUNCH_RN_W(GG, CC, false);            \
   } while (0)
   if (rn) {
-    if (G == 64 && C == 16) LAUNCH_RN(64, 16);
-    else if (G == 64) LAUNCH_RN(64, 32);
-    else if (G == 32) LAUNCH_RN(32, 16);
-    else LAUNCH_RN(16, 16);
+    if (!tail_only) {
+      if (G == 64 && C == 16) LAUNCH_RN(64, 16);
+      else if (G == 64) LAUNCH_RN(64, 32);
+      else if (G == 32) LAUNCH_RN(32, 16);
+      else LAUNCH_RN(16, 16);
+    }
     // The tail is short (infeasible / very hard instances).  One block per instance of the batch: blocks beyond the
     // list's length return at once (0.25 us per 1024 of them; a grid-stride loop over the list around the solver costs
     // the general kernels 70 registers and puts 148-544 B of scratch into kernels that have none: measured on the code
     // object, not kept).  Its instances carry no guess for the next closed-loop step (act stays 0 from the first launch).
-    if (lane_split(64, N) == 16) LAUNCH(16, false, 2, B);
+    // Deferred (see the handle): no tail launch is enqueued while the launches the host has seen leave none; the closed
+    // loop consumes its results on the device and always launches it.
+    h->pend = !tail_only && !closed_loop && h->tail_expect_empty;
+    if (h->pend) {
+      h->pend_B = B; h->pend_y = want_y; h->pend_cur = tail_cur; h->pend_next = tail_next;
+    } else if (lane_split(64, N) == 16) LAUNCH(16, false, 2, B);
     else LAUNCH(32, false, 2, B);
   } else if (C == 16) LAUNCH(16, warm, 0, blocks);
   else LAUNCH(32, warm, 0, blocks);
@@ -1059,6 +1121,25 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y) {
 #undef LAUNCH_W
 #undef LAUNCH
   HIP_TRY(hipGetLastError());
+  return MPMPC_OK;
+}
+
+// Drain the stream, see whether the last reduced-native launch left a tail, run it if its launch was deferred.
+static int observe_tail(mpmpc_handle h) {
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->seq == 0) return MPMPC_OK;
+  const bool left = *static_cast<volatile unsigned*>(h->tail_flag) == h->seq;
+  h->tail_ran_late = false;
+  if (h->pend) {
+    h->pend = false;
+    if (left) {
+      h->tail_ran_late = true;
+      if (int rc = launch_solve(h, h->pend_B, false, h->pend_y, true)) return rc;
+      HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+  }
+  h->tail_expect_empty = !left;
   return MPMPC_OK;
 }
 
@@ -1088,6 +1169,16 @@ int mpmpc_solve_resident_timed(mpmpc_handle h, int32_t B, float* ms_assemble, fl
   float a = 0.f, s = 0.f;
   HIP_TRY(hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
   HIP_TRY(hipEventElapsedTime(&s, h->ev[1], h->ev[2]));
+  // a deferred tail this launch turns out to need runs now, and its time counts
+  HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+  if (int rc = observe_tail(h)) return rc;
+  if (h->tail_ran_late) {
+    HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev[2]));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, h->ev[1], h->ev[2]));
+    s += t;
+  }
   if (ms_assemble) *ms_assemble = a;
   if (ms_solve) *ms_solve = s;
   return MPMPC_OK;
@@ -1162,14 +1253,13 @@ int mpmpc_speed_profile(int32_t device, int32_t B, int32_t n, const double* li, 
 
 int mpmpc_sync(mpmpc_handle h) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
-  HIP_TRY(hipSetDevice(h->cfg.device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return MPMPC_OK;
+  return observe_tail(h);
 }
 
 int mpmpc_download(mpmpc_handle h, int32_t B, double* z, double* u0, int32_t* status, int32_t* iters,
                    double* resid, double* y) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  if (int rc = observe_tail(h)) return rc;        // (also how the single-call path learns that its launches leave no tail)
   if (B < 1 || B > h->uploaded) return fail(MPMPC_E_STATE, "B exceeds the uploaded batch");
   if (y && !h->y_valid)
     return fail(MPMPC_E_STATE, "the last solve launch did not store the multipliers (mpmpc_set_outputs(h, 0) / closed loop)");

@@ -773,3 +773,59 @@ def test_reduced_polish_gives_the_full_polish_answers(cfgid, B, track):
         fk, _, _ = T.farkas_batch(qp[:, inf, :], sc.N, a.y[inf])
         assert fk.all()
     assert a.iters[ok, 1].mean() <= b.iters[ok, 1].mean() + 0.2
+
+
+def test_deferred_tail_launch_gives_the_same_results(track):
+    """The launcher stops enqueueing the (4.8 us, usually empty) tail launch of the reduced-native kernels once a launch it
+    has seen the outcome of left no tail, and runs it late - at the next sync / download / upload - when a launch does
+    leave one (mpmpc_hip.hip, observe_tail).  Whatever the history of the handle, the answers are those of a fresh one."""
+    N, B = 30, 512
+    feas = scenarios.make(2, track, B=B, N=N)             # every instance certified by the first kernel: no tail
+    hard = scenarios.make(4, track, B=B, N=N)             # ~9 % infeasible: a tail of ~45 instances
+    assert feas.weights == hard.weights
+
+    def fresh(sc):
+        h = _handle(track, N, sc.weights, B)
+        return h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+
+    ref_f, ref_h = fresh(feas), fresh(hard)
+    assert (ref_h.status == mpmpc.PRIMAL_INFEASIBLE).sum() >= 10 and (ref_f.status == mpmpc.SOLVED).all()
+
+    def same(a, b):
+        assert np.array_equal(a.status, b.status) and np.array_equal(a.iters, b.iters)
+        assert np.array_equal(a.z, b.z) and np.array_equal(a.u0, b.u0) and np.array_equal(a.resid, b.resid)
+
+    h = _handle(track, N, feas.weights, B)
+    h.set_outputs(True)
+    # 1. learn "no tail" on the feasible batch, then meet the hard one with the tail launch deferred: resident path
+    h.upload(feas.wp_id, feas.x0, feas.cc_prev, feas.lb, feas.ub)
+    for _ in range(3):
+        h.solve_resident(B)
+        h.sync()
+    same(h.download(B, want_y=True), ref_f)
+    h.upload(hard.wp_id, hard.x0, hard.cc_prev, hard.lb, hard.ub)
+    h.solve_resident(B)                                   # deferred: the handle expects no tail
+    got = h.download(B, want_y=True)                      # ... and runs it here
+    same(got, ref_h)
+    assert np.array_equal(got.y, ref_h.y)
+    # 2. now the handle launches the tail eagerly again; several launches in a row, one sync
+    for _ in range(3):
+        h.solve_resident(B)
+    h.sync()
+    same(h.download(B), ref_h)
+    # 3. back to the feasible batch (eager, then deferred again), then the hard one through the host-buffer call
+    h.upload(feas.wp_id, feas.x0, feas.cc_prev, feas.lb, feas.ub)
+    for _ in range(2):
+        h.solve_resident(B)
+        h.sync()
+    same(h.download(B), ref_f)
+    same(h.solve(hard.wp_id, hard.x0, hard.cc_prev, hard.lb, hard.ub), ref_h)
+    same(h.solve(feas.wp_id, feas.x0, feas.cc_prev, feas.lb, feas.ub), ref_f)
+    # 4. a timed launch that turns out to need its deferred tail
+    h.upload(feas.wp_id, feas.x0, feas.cc_prev, feas.lb, feas.ub)
+    h.solve_resident(B)
+    h.sync()
+    h.upload(hard.wp_id, hard.x0, hard.cc_prev, hard.lb, hard.ub)
+    ms = h.solve_resident_timed(B)
+    assert ms[1] > 0
+    same(h.download(B), ref_h)
