@@ -243,6 +243,11 @@ int mpmpc_solve(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x
  * transfer itself is ordered before everything launched after it on the handle's stream. */
 int mpmpc_upload(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x0,
                  const double* cc_prev, const double* lb, const double* ub);
+/* The outputs of a resident launch are defined after the next mpmpc_sync / mpmpc_download on the handle (the only ways to
+ * read them), and only for the LAST launch before it: launches share the handle's output block.  The library uses that
+ * freedom: the second kernel of a launch (the tail: instances the first kernel could not certify, usually none) is not
+ * enqueued while the launches whose outcome the host has seen left no tail; a launch that does leave one has it run inside
+ * the next mpmpc_sync / mpmpc_download / mpmpc_upload / mpmpc_set_* call, before that call does anything else. */
 int mpmpc_solve_resident(mpmpc_handle h, int32_t B);
 /* Do resident launches store the multipliers y (46 % of a solve's output bytes)?  Default 1.  mpmpc_solve decides per
  * call (y == NULL: not stored), the closed-loop rollout never stores them.  mpmpc_download refuses a y the last launch
