@@ -17,7 +17,7 @@ import scenarios        # noqa: E402
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 tr = scenarios.sim_track()
 em = T.Emul()
-worst, n_inst, bad = 0.0, 0, 0
+worst, n_inst, bad, notes = 0.0, 0, 0, 0
 for trial in range(40):
     N = int(rng.choice([3, 4, 7, 10, 15, 16, 17, 24, 30, 31, 32, 33, 40, 45, 50]))
     cfg_id = int(rng.choice([2, 3, 4]))
@@ -30,14 +30,21 @@ for trial in range(40):
     x0 = x0 + rng.normal(0, 0.01, x0.shape) * np.array([1.0, 1.0, 0.0])
     cfg = T.stock_config(N, weights, max_batch=B)
     Q, R, QN = scenarios.WEIGHTS[weights]
-    h = mpmpc.Handle(cfg)
+    # odd trials: every proven infeasibility reported (phase1_accept = 0: statuses 1 / -3 only, each with its certificate);
+    # even trials: the default verdicts (marginal instances come back with status 2)
+    st = mpmpc.default_settings(phase1_accept=trial % 2)
+    h = mpmpc.Handle(cfg, st)
     h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
     qp = em.assemble(cfg, tr, (wp, x0, cc, lb, ub))
     for G in sorted({64, 32 if N + 1 <= 32 else 64, 16 if N + 1 <= 16 else 64}):
         h.set_packing(G)                       # the device runs THIS packing (packed early pass + tail launch)
         dev = h.solve(wp, x0, cc, lb, ub, want_y=True)
-        emu, _ = em.solve_launch(cfg, mpmpc.default_settings(), qp, G=G)
-        same = np.array_equal(dev.status, emu.status) and np.array_equal(dev.iters, emu.iters)
+        emu, _ = em.solve_launch(cfg, st, qp, G=G)
+        # (phase 1 of an infeasible instance may stop one iteration apart: the device's reciprocals are 1-ulp seeds + Newton,
+        #  the emulation divides; the verdict and its certificate are what must agree)
+        it_ok = (dev.iters == emu.iters).all(axis=1) | ((dev.status == -3) & (np.abs(dev.iters - emu.iters).max(axis=1) <= 1))
+        same = np.array_equal(dev.status, emu.status) and bool(it_ok.all())
+        notes += int((~(dev.iters == emu.iters).all(axis=1)).sum())
         ok = dev.status == 1
         dz = float(np.abs(dev.z[ok] - emu.z[ok]).max()) if ok.any() else 0.0
         du = float(np.abs(dev.u0[ok] - emu.u0[ok]).max()) if ok.any() else 0.0
@@ -50,7 +57,7 @@ for trial in range(40):
         inf = dev.status == -3
         if inf.any():
             cert = cert and bool(T.farkas_batch(qp[:, inf, :], N, dev.y[inf])[0].all())
-        cert = cert and set(np.unique(dev.status)) <= {1, -3}
+        cert = cert and set(np.unique(dev.status)) <= ({1, -3} if st.phase1_accept == 0 else {1, 2, -3})
         if not same or dz > 1e-9 or du > 1e-9 or not cert:
             bad += 1
             print("MISMATCH trial %d N=%d cfg=%d B=%d G=%d: status/iters equal %s, dz %.2e du %.2e, certificates %s" % (trial, N, cfg_id, B, G, same, dz, du, cert))
@@ -59,5 +66,5 @@ for trial in range(40):
                 print("   instance %d: device status %d iters %s | emulation status %d iters %s" % (i, dev.status[i], dev.iters[i], emu.status[i], emu.iters[i]))
     n_inst += B
     h.close()
-print("trials 40, instances %d, mismatches %d, worst |device - emulation| %.2e" % (n_inst, bad, worst))
+print("trials 40, instances %d, mismatches %d, worst |device - emulation| %.2e, phase-1 iteration counts one apart: %d" % (n_inst, bad, worst, notes))
 sys.exit(1 if bad else 0)
