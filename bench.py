@@ -99,7 +99,9 @@ def algorithm_text(cfg, settings):
     if native_path(cfg, settings):
         return ("reduced-native kernel per instance: speed in closed form, one Ruiz pass + OSQP's first iterate (one 2x2-block KKT solve) "
                 "as start, interior point, active-set round(s), KKT certificate on the (e_y, e_psi, kappa) QP, roll-forward of t; "
-                "uncertified instances go to a tail launch: phase 1 (Farkas ray) and, only if that cannot decide, the OSQP ADMM iteration")
+                "uncertified instances go to a tail launch: phase 1 (Farkas ray) and, only if that cannot decide, the OSQP ADMM iteration "
+                "(the tail launch is enqueued with the step while the launches seen so far leave a tail, otherwise only when a launch "
+                "turns out to need it - checked at every sync, inside the timed region)")
     red = "reduced 2x2-block" if reduced_polish(cfg, settings) else "full 3x3-block"
     return ("general kernel per instance: %d Ruiz pass(es), %d OSQP start step(s), %s interior point + active-set round(s) + KKT "
             "certificate; phase 1 (Farkas ray) and then the full OSQP ADMM run for what that cannot certify" %
@@ -391,7 +393,7 @@ def _main(real_stdout):
             ms_prof, ms_src = rocprof_kernel_average(args.config, B, lib_version)
         if ms_prof is not None:
             ms_k2 = ms_prof          # the committed rocprofv3 kernel average of the same library
-        out["roofline"] = {"bound": "hbm", "kernel": k2_name + (" (+ tail launch of mpmpc_solve_kernel)" if nat else ""),
+        out["roofline"] = {"bound": "hbm", "kernel": k2_name + (" (+ tail launch of mpmpc_solve_kernel where a launch leaves a tail)" if nat else ""),
                            "achieved": bytes_k2 / (ms_k2 * 1e-3) / 1e9,
                            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bytes_k2 / (ms_k2 * 1e-3) / HBM_PEAK,
                            "traffic": traffic, "traffic_source": traffic_src,
