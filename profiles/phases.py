@@ -35,7 +35,12 @@ def main():
     Q, R, QN = scenarios.WEIGHTS[scenarios.CONFIGS[cfg_id]["weights"]]
     cfg = mpmpc.make_config(sc.N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX,
                             scenarios.AY_MAX, scenarios.CAR_LENGTH, max_batch=sc.B)
-    h = mpmpc.Handle(cfg)
+    # MPMPC_PHASES_SET="key=value,key=value": solver settings away from the defaults (tolerance sweeps)
+    over = {}
+    for kv in filter(None, os.environ.get("MPMPC_PHASES_SET", "").split(",")):
+        k, v = kv.split("=")
+        over[k] = float(v) if any(c in v for c in ".eE") else int(v)
+    h = mpmpc.Handle(cfg, mpmpc.default_settings(**over))
     h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
     h.upload(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
     for _ in range(3):
