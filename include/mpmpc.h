@@ -262,6 +262,17 @@ int mpmpc_set_outputs(mpmpc_handle h, int32_t want_y);
 int mpmpc_sync(mpmpc_handle h);
 int mpmpc_download(mpmpc_handle h, int32_t B, double* z, double* u0, int32_t* status,
                    int32_t* iters, double* resid, double* y);
+/* Zero-copy host path.  mpmpc_solve copies the caller's (pageable) arrays into page-locked staging blocks and the results back
+ * out of them - at B = 1 024 those host-side copies are two thirds of the call.  A caller that can build its inputs in place
+ * and read the results in place asks for the blocks themselves: mpmpc_staging gives pointers into them, laid out for a batch
+ * of B (same shapes as mpmpc_solve's arguments; any out-pointer may be NULL; the pointers stay valid until the handle is
+ * destroyed, the layout until a call with another B), mpmpc_solve_staged runs upload + solve + download on them and returns
+ * when the outputs are there: u0, status, iters, resid always, z if want_z, z and y if want_y.  with_rows = 0: lb / ub are not
+ * read, the corridor table (mpmpc_set_corridor) applies.  Handles whose max_batch needs more than 64 MiB per block have no
+ * staging blocks (MPMPC_E_STATE). */
+int mpmpc_staging(mpmpc_handle h, int32_t B, int32_t** wp_id, double** x0, double** cc_prev, double** lb, double** ub,
+                  double** z, double** u0, int32_t** status, int32_t** iters, double** resid, double** y);
+int mpmpc_solve_staged(mpmpc_handle h, int32_t B, int32_t with_rows, int32_t want_z, int32_t want_y);
 /* one resident pass with HIP events around each kernel on the handle's stream (ms) */
 int mpmpc_solve_resident_timed(mpmpc_handle h, int32_t B, float* ms_assemble, float* ms_solve);
 

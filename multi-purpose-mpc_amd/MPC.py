@@ -245,6 +245,19 @@ class BatchMPC:
         self.handle.rollout_step(n_steps)
         return self.handle.rollout_state()
 
+    def staging(self, B):
+        """numpy views of the handle's page-locked staging blocks for a batch of B (mpmpc.Handle.staging): a caller that builds
+        wp_id / x0 / cc_prev (/ lb / ub) in place and reads u0 / status / z in place skips the host-side copies, which are two
+        thirds of get_control_batch at B = 1 024."""
+        return self.handle.staging(B)
+
+    def get_control_staged(self, B, with_rows=True, want_plan=True):
+        """get_control_batch on the staging views: -> (u [B,2] = (v, delta), status [B]) as views into the staging block; the
+        plan is in staging(B)["z"] (kappa entries, not yet delta) when want_plan."""
+        self.handle.solve_staged(B, with_rows=with_rows, want_z=want_plan, want_y=False)
+        st = self.handle.staging(B)
+        return st["u0"], st["status"]
+
     def get_control_batch(self, wp_id, x0, cc_prev, lb=None, ub=None):
         """-> (u [B,2] = (v, delta), plan [B,2N] with delta entries, status [B], Solution)."""
         sol = self.handle.solve(wp_id, x0, cc_prev, lb, ub)

@@ -1300,6 +1300,60 @@ int mpmpc_download(mpmpc_handle h, int32_t B, double* z, double* u0, int32_t* st
   return MPMPC_OK;
 }
 
+// ---- zero-copy host path: the caller works in the handle's own page-locked staging blocks
+int mpmpc_staging(mpmpc_handle h, int32_t B, int32_t** wp_id, double** x0, double** cc_prev, double** lb, double** ub,
+                  double** z, double** u0, int32_t** status, int32_t** iters, double** resid, double** y) {
+  if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  if (B < 1 || B > h->cfg.max_batch) return fail(MPMPC_E_ARG, "B must be in [1, max_batch]");
+  if (!h->stage_in || !h->stage_out) return fail(MPMPC_E_STATE, "this handle has no staging blocks (max_batch above the staging limit)");
+  const BlockLayout L = block_layout(h->cfg.N, B);
+  char *si = h->stage_in, *so = h->stage_out;
+  if (wp_id) *wp_id = reinterpret_cast<int32_t*>(si + L.wp_id);
+  if (x0) *x0 = reinterpret_cast<double*>(si + L.x0);
+  if (cc_prev) *cc_prev = reinterpret_cast<double*>(si + L.cc);
+  if (lb) *lb = reinterpret_cast<double*>(si + L.lb);
+  if (ub) *ub = reinterpret_cast<double*>(si + L.ub);
+  if (u0) *u0 = reinterpret_cast<double*>(so + L.u0);
+  if (resid) *resid = reinterpret_cast<double*>(so + L.resid);
+  if (status) *status = reinterpret_cast<int32_t*>(so + L.status);
+  if (iters) *iters = reinterpret_cast<int32_t*>(so + L.iters);
+  if (z) *z = reinterpret_cast<double*>(so + L.z);
+  if (y) *y = reinterpret_cast<double*>(so + L.y);
+  return MPMPC_OK;
+}
+
+int mpmpc_solve_staged(mpmpc_handle h, int32_t B, int32_t with_rows, int32_t want_z, int32_t want_y) {
+  if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  MPMPC_SETTLE(h);
+  if (B < 1 || B > h->cfg.max_batch) return fail(MPMPC_E_ARG, "B must be in [1, max_batch]");
+  if (!h->stage_in || !h->stage_out) return fail(MPMPC_E_STATE, "this handle has no staging blocks (max_batch above the staging limit)");
+  if (h->n_wp == 0) return fail(MPMPC_E_STATE, "no path set (mpmpc_set_path)");
+  if (!with_rows && h->n_cols == 0) return fail(MPMPC_E_STATE, "no corridor rows given and no corridor table set");
+  const int N = h->cfg.N;
+  const BlockLayout L = block_layout(N, B);
+  const int32_t* wp = reinterpret_cast<const int32_t*>(h->stage_in + L.wp_id);
+  for (int i = 0; i < B; ++i) {
+    if (wp[i] < 0 || wp[i] >= h->n_wp) return fail(MPMPC_E_ARG, "wp_id out of range");
+    if (!h->cfg.circular && wp[i] + N >= h->n_wp) return fail(MPMPC_E_ARG, "Reached end of path!");
+  }
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (h->in_flight) { HIP_TRY(hipEventSynchronize(h->ev_in)); h->in_flight = false; }
+  h->ro_valid = false;
+  if (B != h->laid_out) lay_out(h, B);
+  HIP_TRY(hipMemcpyAsync(h->in_block, h->stage_in, with_rows ? L.in_end : L.in_end_cc, hipMemcpyHostToDevice, h->stream));
+  h->have_rows = with_rows != 0;
+  h->uploaded = B;
+  if (int rc = launch_solve(h, B, false, want_y != 0)) return rc;
+  const size_t out_bytes = want_y ? L.out_end : (want_z ? L.out_end_z : L.z);
+  HIP_TRY(hipMemcpyAsync(h->stage_out, h->out_block, out_bytes, hipMemcpyDeviceToHost, h->stream));
+  if (int rc = observe_tail(h)) return rc;          // drains the stream; a launch that left a deferred tail has it run now
+  if (h->tail_ran_late) {
+    HIP_TRY(hipMemcpyAsync(h->stage_out, h->out_block, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  return MPMPC_OK;
+}
+
 int mpmpc_assemble(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x0, const double* cc_prev,
                    const double* lb, const double* ub, double* qp_out) {
   if (int rc = mpmpc_upload(h, B, wp_id, x0, cc_prev, lb, ub)) return rc;

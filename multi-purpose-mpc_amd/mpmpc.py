@@ -151,6 +151,9 @@ def load_library(path: str | None = None):
     lib.mpmpc_download.argtypes = [h, C.c_int32, _dp, _dp, _ip, _ip, _dp, _dp]
     lib.mpmpc_solve_resident_timed.argtypes = [h, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.mpmpc_speed_profile.argtypes = [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_double, _dp, _ip, _ip]
+    _ipp, _dpp = C.POINTER(_ip), C.POINTER(_dp)
+    lib.mpmpc_staging.argtypes = [h, C.c_int32, _ipp, _dpp, _dpp, _dpp, _dpp, _dpp, _dpp, _ipp, _ipp, _dpp, _dpp]
+    lib.mpmpc_solve_staged.argtypes = [h, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     if path is None:
         _lib = lib
     return lib
@@ -160,7 +163,8 @@ EXPORTS = ["mpmpc_version", "mpmpc_last_error", "mpmpc_device_count", "mpmpc_def
            "mpmpc_create", "mpmpc_destroy", "mpmpc_set_settings", "mpmpc_set_packing", "mpmpc_set_path", "mpmpc_set_corridor",
            "mpmpc_set_map", "mpmpc_set_path_geometry", "mpmpc_build_corridor", "mpmpc_rollout_init",
            "mpmpc_rollout_step", "mpmpc_rollout_set_counters", "mpmpc_rollout_warm_start", "mpmpc_rollout_state", "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident", "mpmpc_set_outputs",
-           "mpmpc_sync", "mpmpc_download", "mpmpc_solve_resident_timed", "mpmpc_speed_profile"]
+           "mpmpc_sync", "mpmpc_download", "mpmpc_solve_resident_timed", "mpmpc_speed_profile", "mpmpc_staging",
+           "mpmpc_solve_staged"]
 
 
 class MpmpcError(RuntimeError):
@@ -320,6 +324,24 @@ class Handle:
         self._check(self.lib.mpmpc_solve(self._h, B, _i(wp), _d(x0), _d(cc), _d(lb), _d(ub), _d(z), _d(u0),
                                          _i(st), _i(it), _d(rs), _d(y)))
         return Solution(z, u0, st, it, rs, y)
+
+    # --- zero-copy host form: numpy views of the handle's page-locked staging blocks
+    def staging(self, B):
+        """-> dict of numpy views (wp_id [B], x0 [B,3], cc_prev [B,2N], lb / ub [B,N]; z [B,n], u0 [B,2], status [B], iters [B,2],
+        resid [B,2], y [B,m]) laid out for a batch of B: fill the inputs in place, call solve_staged(B), read the outputs."""
+        N = self.cfg.N
+        pi, pd = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+        wp, st, it = pi(), pi(), pi()
+        x0, cc, lb, ub, z, u0, rs, y = (pd() for _ in range(8))
+        self._check(self.lib.mpmpc_staging(self._h, B, C.byref(wp), C.byref(x0), C.byref(cc), C.byref(lb), C.byref(ub), C.byref(z),
+                                           C.byref(u0), C.byref(st), C.byref(it), C.byref(rs), C.byref(y)))
+        view = lambda p, shape: np.ctypeslib.as_array(p, shape=shape)
+        return dict(wp_id=view(wp, (B,)), x0=view(x0, (B, 3)), cc_prev=view(cc, (B, 2 * N)), lb=view(lb, (B, N)), ub=view(ub, (B, N)),
+                    z=view(z, (B, self.n)), u0=view(u0, (B, 2)), status=view(st, (B,)), iters=view(it, (B, 2)), resid=view(rs, (B, 2)),
+                    y=view(y, (B, self.m)))
+
+    def solve_staged(self, B, with_rows=True, want_z=True, want_y=False):
+        self._check(self.lib.mpmpc_solve_staged(self._h, B, int(with_rows), int(want_z), int(want_y)))
 
     # --- resident (benchmark / closed loop) form
     def upload(self, wp_id, x0, cc_prev, lb=None, ub=None):

@@ -829,3 +829,50 @@ def test_deferred_tail_launch_gives_the_same_results(track):
     ms = h.solve_resident_timed(B)
     assert ms[1] > 0
     same(h.download(B), ref_h)
+
+
+def test_staged_host_path_is_the_host_buffer_path_without_its_copies(track):
+    """mpmpc_staging / mpmpc_solve_staged: the caller fills the handle's page-locked staging blocks and reads the results
+    there.  Same answers as mpmpc_solve, bit for bit - with corridor rows and with the corridor table, with and without z / y,
+    and through a deferred tail launch."""
+    N, B = 30, 300
+    hard = scenarios.make(4, track, B=B, N=N)
+    feas = scenarios.make(2, track, B=B, N=N)
+    h = _handle(track, N, hard.weights, B, table="obstacles")
+    ref = {}
+    for name, sc in (("hard", hard), ("feas", feas)):
+        ref[name] = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+    ref_tab = h.solve(hard.wp_id, hard.x0, hard.cc_prev, want_y=True)               # rows from the corridor table
+    assert (ref["hard"].status == mpmpc.PRIMAL_INFEASIBLE).sum() >= 5
+
+    g = _handle(track, N, hard.weights, B, table="obstacles")
+    v = g.staging(B)
+
+    def fill(sc, rows=True):
+        v["wp_id"][:] = sc.wp_id; v["x0"][:] = sc.x0; v["cc_prev"][:] = sc.cc_prev
+        if rows:
+            v["lb"][:] = sc.lb; v["ub"][:] = sc.ub
+
+    def same(r, z=True, y=True):
+        assert np.array_equal(v["status"], r.status) and np.array_equal(v["iters"], r.iters)
+        assert np.array_equal(v["u0"], r.u0) and np.array_equal(v["resid"], r.resid)
+        if z:
+            assert np.array_equal(v["z"], r.z)
+        if y:
+            assert np.array_equal(v["y"], r.y)
+
+    fill(hard)
+    g.solve_staged(B, want_z=True, want_y=True)
+    same(ref["hard"])
+    fill(feas)
+    for _ in range(2):                                   # the handle learns "no tail" ...
+        g.solve_staged(B, want_z=True, want_y=False)
+    same(ref["feas"], y=False)
+    fill(hard)                                           # ... and meets a batch that leaves one
+    g.solve_staged(B, want_z=False, want_y=False)
+    same(ref["hard"], z=False, y=False)
+    g.solve_staged(B, with_rows=False, want_z=True, want_y=True)
+    same(ref_tab)
+    v["wp_id"][0] = -1
+    with pytest.raises(mpmpc.MpmpcError):
+        g.solve_staged(B)
