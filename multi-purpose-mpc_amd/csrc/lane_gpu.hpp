@@ -65,7 +65,7 @@ __device__ __forceinline__ double dpp_merge(double keep, double a) {
 // layout the lanes [C, 2C) of an instance are reversed.  Supported: <64,16> (N + 1 <= 32), <64,32>,
 // <32,16>, <16,16> (no second chain).
 // SLOTS: 512-byte slots of per-wave LDS ("cold" storage + staging of the output rows): 66 for the general solver (33 KB: four
-// waves per CU, one per SIMD), 24 for the reduced-native one (12 KB: eight waves per CU, two per SIMD, fit the 160 KB).
+// waves per CU, one per SIMD), 40 for the reduced-native one (20 KB: eight waves per CU, two per SIMD, exactly the 160 KB).
 template <int G, int C = G / 2, int SLOTS = 66>
 struct LaneGpu {
   static_assert((G == 64 && (C == 16 || C == 32)) || (G == 32 && C == 16) || (G == 16 && C == 16), "unsupported lane split");

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
 // K2r: the reduced-native solve kernel (mpmpc_reduced.hpp) - the batch path of every configuration whose time state
 // separates (the reference's own weights).  One launch assembles (K1's code, in registers), solves and stores; the ids of
 // the instances it cannot certify are appended to tail[1..] (tail[0] counts) for the general kernel in mode 2.
-// 24 LDS slots (12 KB) and at most 256 registers: two wavefronts per SIMD.
+// 40 LDS slots (20 KB) and at most 256 registers: two wavefronts per SIMD.
 constexpr int RN_SLOTS = 40;
 // WARM (closed loop): act [B x ld] holds the active sets the previous step certified, shift [B] the waypoints each car has
 // advanced since; the kernel starts from them and leaves this step's sets in act.
@@ -1085,7 +1085,7 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, bo
     else LAUNCH_V(CC, false, MODE, BLOCKS);             \
   } while (0)
   // (knob of the occupancy experiment, profiles/r3/occupancy.txt: MPMPC_RN_OCC=1 pads every block with 20 KB of unused
-  //  dynamic LDS - 38.9 KB per wave, four waves per CU, ONE per SIMD - so that the same code object can be timed at one
+  //  dynamic LDS - 40 KB per wave, four waves per CU, ONE per SIMD - so that the same code object can be timed at one
   //  and at two waves per SIMD)
   static const int rn_pad = (std::getenv("MPMPC_RN_OCC") && std::atoi(std::getenv("MPMPC_RN_OCC")) == 1) ? 20 * 1024 : 0;
 #define LAUNCH_RN_W(GG, CC, WW)                                                                                             \
@@ -1105,7 +1105,8 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, bo
       else LAUNCH_RN(16, 16);
     }
     // The tail is short (infeasible / very hard instances).  One block per instance of the batch: blocks beyond the
-    // list's length return at once (0.25 us per 1024 of them; a grid-stride loop over the list around the solver costs
+    // list's length return at once (an all-empty launch takes 4.8 us at 1 024 blocks, 15 us at 65 536: rocprofv3 kernel
+    // trace - which is why it is not enqueued when no tail is expected, below; a grid-stride loop over the list around the solver costs
     // the general kernels 70 registers and puts 148-544 B of scratch into kernels that have none: measured on the code
     // object, not kept).  Its instances carry no guess for the next closed-loop step (act stays 0 from the first launch).
     // Deferred (see the handle): no tail launch is enqueued while the launches the host has seen leave none; the closed
