@@ -76,7 +76,7 @@ def test_certified_matches_oracle(cfgid, B, N, G, emu, track):
     qp = emu.assemble(cfg, track, _inputs(sc))
     sol = emu.solve(cfg, mpmpc.default_settings(), qp, G=G)
     L = scenarios.CAR_LENGTH
-    n_cert = 0
+    n_cert = n_inf = n_skip = 0
     for i in range(B):
         Pd, q, A, l, u = T.qp_to_dense(qp[:, i, :], N)
         r = O.solve(np.diag(Pd), q, A, l, u, O.Settings(polish=2))
@@ -84,11 +84,13 @@ def test_certified_matches_oracle(cfgid, B, N, G, emu, track):
             # the dense oracle interior point gave up where the kernel did not: the kernel's point
             # must then carry its own certificate
             assert O.kkt_certificate(np.diag(Pd), q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8)
+            n_skip += 1
             continue
         assert sol.status[i] == r.status
         # same ADMM iteration count, unless exactly one side certified at the early-polish attempt
         # (the dense numpy interior point is less robust than the kernel's / the C port's)
         assert sol.iters[i, 0] == r.iters or 1 in (sol.iters[i, 0], r.iters)
+        n_inf += int(r.status == O.PRIMAL_INFEASIBLE)
         if r.status == O.SOLVED:
             n_cert += 1
             uref = np.array([r.x[3 * (N + 1)], np.arctan(r.x[3 * (N + 1) + 1] * L)])
@@ -98,7 +100,9 @@ def test_certified_matches_oracle(cfgid, B, N, G, emu, track):
             e[3 * N + 1] = 0.0          # ... and so is the e_psi_N it alone drives
             assert e.max() <= 1e-6
             assert O.kkt_certificate(np.diag(Pd), q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8)
-    assert n_cert >= B // 2
+    # every instance is accounted for: compared with the oracle's certified optimum, or infeasible on both sides; on these
+    # batches the dense numpy oracle never gives up ("weak" 4: the test used to ask for half)
+    assert n_skip == 0 and n_cert + n_inf == B, (n_cert, n_inf, n_skip)
 
 
 def test_ragged_batch_and_group_packing(emu, track):

@@ -111,17 +111,19 @@ def test_certified_matches_oracle(cfgid, B, N, track):
     qp = h.assemble(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
     sol = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
     L = scenarios.CAR_LENGTH
-    n_cert = 0
+    n_cert = n_inf = n_skip = 0
     for i in range(B):
         Pd, q, A, l, u = T.qp_to_dense(qp[:, i, :], N)
         r = O.solve(np.diag(Pd), q, A, l, u, O.Settings(polish=2))
         if r.polished != 1 and sol.status[i] == 1:
             assert O.kkt_certificate(np.diag(Pd), q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8)
+            n_skip += 1
             continue
         assert sol.status[i] == r.status
         # same ADMM iteration count, unless exactly one side certified at the early-polish attempt
         # (the dense numpy interior point is less robust than the kernel's / the C port's)
         assert sol.iters[i, 0] == r.iters or 1 in (sol.iters[i, 0], r.iters)
+        n_inf += int(r.status == O.PRIMAL_INFEASIBLE)
         if r.status == O.SOLVED:
             n_cert += 1
             uref = np.array([r.x[3 * (N + 1)], np.arctan(r.x[3 * (N + 1) + 1] * L)])
@@ -131,7 +133,9 @@ def test_certified_matches_oracle(cfgid, B, N, track):
             e[3 * N + 1] = 0.0
             assert e.max() <= 1e-6
             assert O.kkt_certificate(np.diag(Pd), q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8)
-    assert n_cert >= B // 2
+    # every instance is accounted for: compared with the oracle's certified optimum, or infeasible on both sides; on these
+    # batches the dense numpy oracle never gives up ("weak" 4: the test used to ask for half)
+    assert n_skip == 0 and n_cert + n_inf == B, (n_cert, n_inf, n_skip)
     h.close()
 
 
@@ -278,18 +282,22 @@ def test_mpc_get_control_replays_reference_lap_on_gpu():
 
 
 def test_free_running_lap_on_gpu():
-    """src/simulation.py's while-loop (simulation.py:134-148) with our classes, plotting off."""
+    """src/simulation.py's while-loop (simulation.py:134-148) with our classes, plotting off.  With the verdict semantics of
+    the solver golden G6 was driven by (every proven infeasibility reported) the free-running lap has the reference lap's
+    length to the step; with the default verdicts (marginal instances come back as plans, like the reference's OSQP call) the
+    car takes other branches at the marginal steps and the lap may differ by a few steps."""
     import test_host_mpc as H
     g = np.load(M.GOLDEN + "/g6_closed_loop_N30.npz")
-    m, rp, car = H.build_world()
-    mpc = H.make_mpc(car, 30)
-    steps = 0
-    while car.s < rp.length and steps < 400:
-        u = mpc.get_control()
-        car.drive(u)
-        steps += 1
-    assert car.s >= rp.length
-    assert abs(steps - g["s"].size) <= 10           # the reference's lap: 210 steps
+    for settings, slack in ((mpmpc.default_settings(phase1_accept=0), 0), (None, 10)):
+        m, rp, car = H.build_world()
+        mpc = H.make_mpc(car, 30, settings=settings)
+        steps = 0
+        while car.s < rp.length and steps < 400:
+            u = mpc.get_control()
+            car.drive(u)
+            steps += 1
+        assert car.s >= rp.length
+        assert abs(steps - g["s"].size) <= slack, (steps, g["s"].size)           # the reference's lap: 210 steps
 
 
 def test_device_corridor_in_the_single_car_loop():

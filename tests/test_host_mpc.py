@@ -38,7 +38,7 @@ def make_mpc(car, N, backend=None, corridor="host", settings=None):
     if backend == "emu":
         cfg = T.stock_config(N)
         backend = T.EmuBackend(cfg, settings or mpmpc.default_settings())
-    return MPC(car, N, Q, R, QN, sc, ic, 4.0, backend=backend, corridor=corridor)
+    return MPC(car, N, Q, R, QN, sc, ic, 4.0, settings=settings, backend=backend, corridor=corridor)
 
 
 @pytest.mark.parametrize("N,stride", [(10, 1), (30, 3)])
