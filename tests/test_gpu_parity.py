@@ -516,7 +516,8 @@ def test_the_polish_settings_change_the_route_not_the_answer(cfgid, B, track):
     variant ends with the same status and, where solved, the same certified optimum (1e-8 in u; both certified)."""
     sc = scenarios.make(cfgid, track, B=B)
     variants = [dict(), dict(ipm_start_mu=0.0), dict(ipm_tol=1e-9), dict(ipm_tol=1e-7), dict(as_add_fraction=0.0),
-                dict(ipm_start_slack=0.3, ipm_start_mu=0.1), dict(ipm_start_dual=0.0), dict(reduce=0)]
+                dict(ipm_start_slack=0.3, ipm_start_mu=0.1), dict(ipm_start_dual=0.0), dict(reduce=0), dict(native=0),
+                dict(native_ipm_tol=1e-8), dict(native_ipm_tol=1e-6)]
     outs = []
     for kw in variants:
         h = _handle(track, sc.N, sc.weights, B, mpmpc.default_settings(**STRICT, **kw))
