@@ -17,7 +17,7 @@ for trial in range(int(sys.argv[2])):
     sc = scenarios.make(cid, tr, B=B, N=N)
     cfg = T.stock_config(N, sc.weights, max_batch=B)
     qp = emu.assemble(cfg, tr, (sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub))
-    sol, n_tail = emu.solve_launch(cfg, mpmpc.default_settings(), qp, G=G)
+    sol, n_tail = emu.solve_launch(cfg, mpmpc.default_settings(phase1_accept=0), qp, G=G)      # (the oracle reports every proven infeasibility)
     cfgc = oracle_c.mpc_cfg(N, scenarios.WEIGHTS[sc.weights], scenarios.UMIN, scenarios.UMAX, scenarios.XMIN, scenarios.XMAX, scenarios.AY_MAX, scenarios.CAR_LENGTH)
     out = oracle_c.mpc_batch(cfgc, oracle_c.settings(), tr.kappa, tr.v_ref, tr.ds_next, sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, 8, want_y=True)
     tot += B
