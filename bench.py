@@ -259,6 +259,7 @@ def _main(real_stdout):
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--no-pipelined", dest="pipelined", action="store_false", help="skip the two-batches-in-flight measurement")
     ap.add_argument("--prewarm", type=int, default=300, help="untimed launches before the W warm-up steps (clock ramp)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--lanes", type=int, default=0, help="force 64 / 32 / 16 lanes per instance (tuning; 0 = automatic)")
@@ -352,6 +353,35 @@ def _main(real_stdout):
     ms_k1, ms_k2 = float(np.mean(ka)), float(np.mean(ks))
     sol = h.download(B, want_y=False)
 
+    # Two batches in flight (reported beside `value`, never as it): a second handle - its own stream, its own copy of the batch -
+    # and the K steps go to the two handles in turn, as a serving loop that double-buffers its batches would issue them.  The
+    # launches of the two streams share the chip: where a launch leaves SIMDs or issue slots idle (one wave per SIMD at
+    # B = 1 024; the tail launch of configs 4 / 5) the other one's waves run there.
+    pipelined = None
+    if args.pipelined and B <= 16384:
+        h2 = mpmpc.Handle(cfg, settings)
+        h2.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+        h2.set_packing(args.lanes)
+        h2.set_outputs(want_y=False)
+        h2.upload(wp, x0, cc, lb, ub)
+        pair = (h, h2)
+        for i in range(2 * max(args.warmup, 10)):
+            pair[i & 1].solve_resident(B)
+        h2.sync()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            pair[i & 1].solve_resident(B)
+        h2.sync()
+        barrier()
+        dt2 = bench_dist.max_over_ranks(dist, time.perf_counter() - t0, device=dev)
+        sol2 = h2.download(B, want_y=False)
+        pipelined = {"value": world * B * args.steps / dt2, "unit": "solves/s", "ms_per_step": 1e3 * dt2 / args.steps, "handles": 2,
+                     "same_answers": bool(np.array_equal(sol2.status, sol.status) and np.array_equal(sol2.u0, sol.u0)),
+                     "note": "the same K steps issued to two handles in turn (two batches of the configuration in flight, each "
+                             "launch still one batch): what a double-buffered serving loop gets; `value` above is ONE batch in flight"}
+        h2.close()
+
     # one result buffer, outside the timed region: the shards' controls gathered on every rank (the only data
     # collective a caller of the sharded path may want), checked on rank 0 against ONE process solving the whole
     # world*B batch of the same seed on its own GPU
@@ -382,6 +412,8 @@ def _main(real_stdout):
                                     algorithm_text(cfg, settings)),
                        "batch_per_gpu": B, "horizon": N, "parallelism": "batch-shard x%d" % world},
         }
+        if pipelined:
+            out["pipelined_two_handles"] = pipelined
         out["rccl_world_size"] = int(dist.get_world_size()) if dist is not None else 0      # 0: no process group (one process, no launcher)
         out["ranks"] = ranks              # per rank: HIP device ordinal of its handle, status counts of its shard
         if gather_check:
