@@ -259,7 +259,9 @@ def _main(real_stdout):
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--no-pipelined", dest="pipelined", action="store_false", help="skip the two-batches-in-flight measurement")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="also measure two batches in flight (two handles fed in turn); off by default so that a profile of the "
+                         "default command holds the launches of the timed loop only")
     ap.add_argument("--prewarm", type=int, default=300, help="untimed launches before the W warm-up steps (clock ramp)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--lanes", type=int, default=0, help="force 64 / 32 / 16 lanes per instance (tuning; 0 = automatic)")
