@@ -273,6 +273,12 @@ int mpmpc_download(mpmpc_handle h, int32_t B, double* z, double* u0, int32_t* st
 int mpmpc_staging(mpmpc_handle h, int32_t B, int32_t** wp_id, double** x0, double** cc_prev, double** lb, double** ub,
                   double** z, double** u0, int32_t** status, int32_t** iters, double** resid, double** y);
 int mpmpc_solve_staged(mpmpc_handle h, int32_t B, int32_t with_rows, int32_t want_z, int32_t want_y);
+/* The same call in two halves, for a loop that keeps several handles busy: mpmpc_staged_begin enqueues upload, solve and
+ * download on the handle's stream and returns; mpmpc_staged_end waits for them (and runs the rarely needed second kernel of the
+ * launch if it turns out to be needed).  Between the two the staging block belongs to the device: do not touch it.  Every other
+ * call on the handle ends a begun call first. */
+int mpmpc_staged_begin(mpmpc_handle h, int32_t B, int32_t with_rows, int32_t want_z, int32_t want_y);
+int mpmpc_staged_end(mpmpc_handle h);
 /* one resident pass with HIP events around each kernel on the handle's stream (ms) */
 int mpmpc_solve_resident_timed(mpmpc_handle h, int32_t B, float* ms_assemble, float* ms_solve);
 

@@ -471,6 +471,7 @@ struct mpmpc_handle_s {
   bool tail_expect_empty = false;     // the last observed launch left no tail
   bool pend = false;                  // the last launch's tail launch was not enqueued
   bool tail_ran_late = false;         // the last observe_tail had to run a deferred tail
+  size_t staged_bytes = 0;            // mpmpc_staged_begin without its mpmpc_staged_end: bytes of the output block on their way back
   int pend_B = 0;
   bool pend_y = false;
   int *pend_cur = nullptr, *pend_next = nullptr;
@@ -483,11 +484,14 @@ static int host_stage_ld(int N) { return N + 1 <= 16 ? 16 : (N + 1 <= 32 ? 32 : 
 
 static int observe_tail(mpmpc_handle h);
 // first statement of every entry point that reads results or changes what a deferred tail launch would work on
-#define MPMPC_SETTLE(h)                            \
-  do {                                             \
-    if ((h)->pend) {                               \
-      if (int rc_ = observe_tail(h)) return rc_;   \
-    }                                              \
+#define MPMPC_SETTLE(h)                                 \
+  do {                                                  \
+    if ((h)->staged_bytes) {                            \
+      if (int rc_ = mpmpc_staged_end(h)) return rc_;    \
+    }                                                   \
+    if ((h)->pend) {                                    \
+      if (int rc_ = observe_tail(h)) return rc_;        \
+    }                                                   \
   } while (0)
 
 static int check_settings(const mpmpc_settings* s) {
@@ -1256,12 +1260,16 @@ int mpmpc_speed_profile(int32_t device, int32_t B, int32_t n, const double* li, 
 
 int mpmpc_sync(mpmpc_handle h) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  if (h->staged_bytes) return mpmpc_staged_end(h);
   return observe_tail(h);
 }
 
 int mpmpc_download(mpmpc_handle h, int32_t B, double* z, double* u0, int32_t* status, int32_t* iters,
                    double* resid, double* y) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  if (h->staged_bytes) {
+    if (int rc = mpmpc_staged_end(h)) return rc;
+  }
   if (int rc = observe_tail(h)) return rc;        // (also how the single-call path learns that its launches leave no tail)
   if (B < 1 || B > h->uploaded) return fail(MPMPC_E_STATE, "B exceeds the uploaded batch");
   if (y && !h->y_valid)
@@ -1323,8 +1331,27 @@ int mpmpc_staging(mpmpc_handle h, int32_t B, int32_t** wp_id, double** x0, doubl
   return MPMPC_OK;
 }
 
-int mpmpc_solve_staged(mpmpc_handle h, int32_t B, int32_t with_rows, int32_t want_z, int32_t want_y) {
+int mpmpc_staged_end(mpmpc_handle h) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  if (!h->staged_bytes) return MPMPC_OK;
+  const size_t out_bytes = h->staged_bytes;
+  h->staged_bytes = 0;
+  if (int rc = observe_tail(h)) return rc;          // drains the stream; a launch that left a deferred tail has it run now
+  if (h->tail_ran_late) {
+    HIP_TRY(hipMemcpyAsync(h->stage_out, h->out_block, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  return MPMPC_OK;
+}
+
+int mpmpc_solve_staged(mpmpc_handle h, int32_t B, int32_t with_rows, int32_t want_z, int32_t want_y) {
+  if (int rc = mpmpc_staged_begin(h, B, with_rows, want_z, want_y)) return rc;
+  return mpmpc_staged_end(h);
+}
+
+int mpmpc_staged_begin(mpmpc_handle h, int32_t B, int32_t with_rows, int32_t want_z, int32_t want_y) {
+  if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  if (h->staged_bytes) return fail(MPMPC_E_STATE, "mpmpc_staged_begin: the previous one has not been ended");
   MPMPC_SETTLE(h);
   if (B < 1 || B > h->cfg.max_batch) return fail(MPMPC_E_ARG, "B must be in [1, max_batch]");
   if (!h->stage_in || !h->stage_out) return fail(MPMPC_E_STATE, "this handle has no staging blocks (max_batch above the staging limit)");
@@ -1347,11 +1374,7 @@ int mpmpc_solve_staged(mpmpc_handle h, int32_t B, int32_t with_rows, int32_t wan
   if (int rc = launch_solve(h, B, false, want_y != 0)) return rc;
   const size_t out_bytes = want_y ? L.out_end : (want_z ? L.out_end_z : L.z);
   HIP_TRY(hipMemcpyAsync(h->stage_out, h->out_block, out_bytes, hipMemcpyDeviceToHost, h->stream));
-  if (int rc = observe_tail(h)) return rc;          // drains the stream; a launch that left a deferred tail has it run now
-  if (h->tail_ran_late) {
-    HIP_TRY(hipMemcpyAsync(h->stage_out, h->out_block, out_bytes, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-  }
+  h->staged_bytes = out_bytes;
   return MPMPC_OK;
 }
 

@@ -154,6 +154,8 @@ def load_library(path: str | None = None):
     _ipp, _dpp = C.POINTER(_ip), C.POINTER(_dp)
     lib.mpmpc_staging.argtypes = [h, C.c_int32, _ipp, _dpp, _dpp, _dpp, _dpp, _dpp, _dpp, _ipp, _ipp, _dpp, _dpp]
     lib.mpmpc_solve_staged.argtypes = [h, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.mpmpc_staged_begin.argtypes = [h, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.mpmpc_staged_end.argtypes = [h]
     if path is None:
         _lib = lib
     return lib
@@ -164,7 +166,7 @@ EXPORTS = ["mpmpc_version", "mpmpc_last_error", "mpmpc_device_count", "mpmpc_def
            "mpmpc_set_map", "mpmpc_set_path_geometry", "mpmpc_build_corridor", "mpmpc_rollout_init",
            "mpmpc_rollout_step", "mpmpc_rollout_set_counters", "mpmpc_rollout_warm_start", "mpmpc_rollout_state", "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident", "mpmpc_set_outputs",
            "mpmpc_sync", "mpmpc_download", "mpmpc_solve_resident_timed", "mpmpc_speed_profile", "mpmpc_staging",
-           "mpmpc_solve_staged"]
+           "mpmpc_solve_staged", "mpmpc_staged_begin", "mpmpc_staged_end"]
 
 
 class MpmpcError(RuntimeError):
@@ -342,6 +344,13 @@ class Handle:
 
     def solve_staged(self, B, with_rows=True, want_z=True, want_y=False):
         self._check(self.lib.mpmpc_solve_staged(self._h, B, int(with_rows), int(want_z), int(want_y)))
+
+    def staged_begin(self, B, with_rows=True, want_z=True, want_y=False):
+        """solve_staged in two halves (a loop that keeps several handles busy): enqueue, return; staged_end() waits."""
+        self._check(self.lib.mpmpc_staged_begin(self._h, B, int(with_rows), int(want_z), int(want_y)))
+
+    def staged_end(self):
+        self._check(self.lib.mpmpc_staged_end(self._h))
 
     # --- resident (benchmark / closed loop) form
     def upload(self, wp_id, x0, cc_prev, lb=None, ub=None):

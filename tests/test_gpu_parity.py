@@ -882,6 +882,22 @@ def test_staged_host_path_is_the_host_buffer_path_without_its_copies(track):
     same(ref["hard"], z=False, y=False)
     g.solve_staged(B, with_rows=False, want_z=True, want_y=True)
     same(ref_tab)
+    # the two halves, two handles in flight: begin / begin / end / end
+    g2 = _handle(track, N, hard.weights, B, table="obstacles")
+    v2 = g2.staging(B)
+    fill(feas)
+    v2["wp_id"][:] = hard.wp_id; v2["x0"][:] = hard.x0; v2["cc_prev"][:] = hard.cc_prev; v2["lb"][:] = hard.lb; v2["ub"][:] = hard.ub
+    g.staged_begin(B, want_z=True, want_y=False)
+    g2.staged_begin(B, want_z=True, want_y=True)
+    with pytest.raises(mpmpc.MpmpcError):
+        g.staged_begin(B)                                # one at a time per handle
+    g.staged_end()
+    g2.staged_end()
+    same(ref["feas"], y=False)
+    assert np.array_equal(v2["status"], ref["hard"].status) and np.array_equal(v2["z"], ref["hard"].z) and np.array_equal(v2["y"], ref["hard"].y)
+    g2.staged_begin(B, want_z=False)
+    g2.sync()                                            # any other call ends a begun one
+    assert np.array_equal(v2["u0"], ref["hard"].u0)
     v["wp_id"][0] = -1
     with pytest.raises(mpmpc.MpmpcError):
         g.solve_staged(B)
