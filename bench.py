@@ -3,8 +3,8 @@
 
 A step = one pass of the hot path over one batch of B synthetic controller instances whose inputs are already resident
 in HBM: the solve launch assembles its QP in registers (the reference's MPC._init_problem) and solves it.  With the
-reference's own weights that is the reduced-native kernel (closed-form speed, Ruiz pass, OSQP's first iterate as start,
-interior point, active-set round, KKT certificate on the (e_y, e_psi, kappa) problem) plus a tail launch of the general
+reference's own weights that is the reduced-native kernel (closed-form speed, Ruiz pass, interior point from x = 0,
+active-set round, KKT certificate on the (e_y, e_psi, kappa) problem) plus a tail launch of the general
 kernel for what it cannot certify (phase 1 / Farkas ray; the OSQP ADMM iteration only as the last fallback).  N=1 workload: config 2 of
 BASELINE.json (B=1024 independent initial poses, reference tracking, horizon 30).  With --gpus N
 every rank solves its own batch of the same size (weak scaling, no data-path collective; the
@@ -97,8 +97,8 @@ def algorithm_text(cfg, settings):
     if not settings.polish:
         return "restated OSQP ADMM at the settings given (no polish): the reference's own solver call"
     if native_path(cfg, settings):
-        return ("reduced-native kernel per instance: speed in closed form, one Ruiz pass + OSQP's first iterate (one 2x2-block KKT solve) "
-                "as start, interior point, active-set round(s), KKT certificate on the (e_y, e_psi, kappa) QP, roll-forward of t; "
+        return ("reduced-native kernel per instance: speed in closed form, one Ruiz pass, interior point from x = 0 (no OSQP iterate "
+                "is computed: iters[:, 0] = 1 marks the attempt), active-set round(s), KKT certificate on the (e_y, e_psi, kappa) QP, roll-forward of t; "
                 "uncertified instances go to a tail launch: phase 1 (Farkas ray) and, only if that cannot decide, the OSQP ADMM iteration "
                 "(the tail launch is enqueued with the step while the launches seen so far leave a tail, otherwise only when a launch "
                 "turns out to need it - checked at every sync, inside the timed region)")
@@ -468,10 +468,11 @@ def _main(real_stdout):
                                             "launch; the solve launch assembles its own QP in registers"}
         st, cnt = np.unique(sol.status, return_counts=True)
         out["status_counts"] = {int(s): int(c) for s, c in zip(st, cnt)}
-        # iters[:, 0] is OSQP's iteration counter: 1 = the start step alone (OSQP's first iterate, one KKT solve, no
-        # iteration of the ADMM loop); only an instance that fell back to the full OSQP run reports more
+        # iters[:, 0] is OSQP's iteration counter: 1 = the early attempt alone (general kernels: OSQP's first iterate, one KKT
+        # solve, as its start; reduced-native kernels: no OSQP iterate at all, the 1 marks the attempt); only an instance that
+        # fell back to the full OSQP run reports more
         adm = np.where(sol.iters[:, 0] > settings.early_polish, sol.iters[:, 0], 0) if settings.polish and settings.early_polish > 0 else sol.iters[:, 0]
-        out["iters"] = {"start_steps_per_instance": int(settings.early_polish) if settings.polish else 0,
+        out["iters"] = {"start_steps_per_instance": 0 if native_path(cfg, settings) else (int(settings.early_polish) if settings.polish else 0),
                         "admm_loop_iterations_mean": float(adm.mean()), "admm_loop_iterations_max": int(adm.max()),
                         "instances_in_admm_fallback": int(np.sum(adm > 0)),
                         "ipm_mean": float(sol.iters[:, 1].mean()), "ipm_max": int(sol.iters[:, 1].max()),

@@ -237,7 +237,9 @@ int32_t mpmpc_stage_ld(int32_t N);
 /* replaces _init_problem + osqp setup/solve + solution extraction (src/MPC.py:180-194) for B
  * instances.  Outputs (any may be NULL): z[B*(5N+3)] primal solution (dec.x), u0[B*2] = (v_0,
  * delta_0 = arctan(kappa_0 * wheelbase)) as returned by get_control, status[B], iters[B*2]
- * (ADMM iterations, interior-point iterations), resid[B*2] (primal, dual residual, unscaled),
+ * (OSQP's iteration counter: 0 = certified from the closed loop's warm-start guess, 1 = the early attempt alone - the general
+ * kernels start it from OSQP's first iterate, the reduced-native kernels from x = 0 without any OSQP iterate -, more = the ADMM
+ * loop ran; interior-point iterations), resid[B*2] (primal, dual residual, unscaled),
  * y[B*(8N+6)] multipliers in the reference's row order. */
 int mpmpc_solve(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x0,
                 const double* cc_prev, const double* lb, const double* ub, double* z, double* u0,

@@ -9,7 +9,7 @@
 // The general kernels (Solver::run) assemble, scale and start on the FULL problem and only run the polish on the reduced
 // one - they carry the OSQP iteration, phase 1 and the 5-entry problem through the whole solve: 440-512 registers, a
 // 120 KB kernel, one wavefront per SIMD.  This solver keeps ONLY the reduced problem: own Ruiz pass on its 3 columns /
-// 2 + 3 rows, own start (OSQP's first iterate of the reduced system from the 2 x 2 factorisation), the interior point
+// 2 + 3 rows, the interior point from x = 0 (no OSQP iterate: measured, the start from OSQP's first iterate cost more than it saved),
 // and the active-set rounds of Solver (ipm<LAY_RED / LAY_REDSPLIT>, active_set<LAY_RED>: the same code), a KKT certificate
 // of the reduced problem in unscaled units - the separated parts satisfy their KKT rows by construction: the speed's
 // multiplier is -(R0 v + q_v) with the sign its clip gives it, the time rows hold to rounding with zero multipliers, and
@@ -187,30 +187,14 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
     L::cold_put(C_C, c3);
     // box in the scaled variable space:  g x in [lb, ub]  <=>  x in [lo_raw, hi_raw] / D
     L::cold_put(K_LO0, lo_e / D3[0]); L::cold_put(K_HI0, hi_e / D3[0]); L::cold_put(K_LO2, lo_k / D3[2]); L::cold_put(K_HI2, hi_k / D3[2]);
-    // ---- OSQP's FIRST iterate of the reduced system from its cold start (Solver::reduced_start): per-row step sizes by
-    // constraint type, x = alpha KKT^-1 (-q); for the pinned entries the multiplier of that iterate (the interior
-    // point starts its pin multipliers there)
-    const R sigma(st.sigma), alpha(st.alpha), rho(st.rho), rho_eq = R(RHO_EQ_FACTOR) * rho, rinv_eq = R(1.0) / rho_eq;
-    const R lo_r[3] = {lo_e, R(-INFTY), lo_k}, hi_r[3] = {hi_e, R(INFTY), hi_k};
-    R h3[3], rbv[3], lbs[3];
+    // ---- start of the interior point: x = 0, no pin multipliers.  (The first reduced-native build started from OSQP's first
+    // iterate of the reduced system - one factorisation + one KKT solve, like Solver::reduced_start: 0.25 interior-point
+    // iterations fewer on config 2, none fewer on config 4, for the price of 0.4 iterations; measured without it: config 2
+    // 23.8 -> 25.1 M solves/s, config 4 30.1 -> 31.6 M, B = 4 096 45.4 -> 53.6 M)
     MPMPC_UNROLL
     for (int e = 0; e < 3; ++e) {
-      lbs[e] = Eb[e] * lo_r[e];
-      const R ubs = Eb[e] * hi_r[e];
-      const Mk freerow = (lbs[e] < R(-INF_BOUND)) & (ubs > R(INF_BOUND));
-      const Mk eqrow = (ubs - lbs[e]) < R(RHO_TOL);
-      rbv[e] = sel(freerow, R(RHO_MIN), sel(eqrow, rho_eq, rho));
-      h3[e] = R(1.0) / (P3[e] + sigma + (G3[e] * G3[e]) * rbv[e]);
-    }
-    this->template factor_t<LAY_RED>(h3, rinv_eq);
-    R rx[3] = {-Q3[0], -Q3[1], -Q3[2]}, req[2] = {zero, zero}, xt[3], nu[2];
-    this->template kkt_solve_t<LAY_RED>(rx, req, xt, nu);
-    MPMPC_UNROLL
-    for (int e = 0; e < 3; ++e) {
-      x3[e] = alpha * xt[e];
-      // pinned entry (lower = upper bound): zr - zn = alpha g xt - lb, multiplier rb (zr - zn), in variable space x g
-      const Mk pn = (lo_r[e] > R(-INF_BOUND)) & (hi_r[e] < R(INF_BOUND)) & ((hi_r[e] - lo_r[e]) <= R(1e-12) * max_(R(1.0), abs_(lo_r[e])));
-      L::cold_put(C_PI + e, sel(pn & val[e], (rbv[e] * (alpha * (G3[e] * xt[e]) - lbs[e])) * G3[e], zero));
+      x3[e] = zero;
+      L::cold_put(C_PI + e, zero);
     }
     L::fence();
   }
