@@ -75,8 +75,8 @@ _FLOPS = {
 # (cyclic-reduction factorisation of the 16-lane chains: every stage is eliminated at one of the four levels, so a level's
 #  work counts once per stage in "algorithmic" - like one step per stage of a serial sweep - and four times in "executed")
 _FLOPS_NATIVE = {
-    1: dict(algorithmic=(37091.0, 19396.0), executed=(71260.0, 30855.0), N=30),
-    -3: dict(algorithmic=(37714.0, 22145.0), executed=(48264.0, 35098.0), N=30),
+    1: dict(algorithmic=(33932.0, 18809.0), executed=(60563.0, 29529.0), N=30),
+    -3: dict(algorithmic=(30153.0, 22195.0), executed=(28018.0, 35176.0), N=30),
 }
 
 
