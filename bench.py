@@ -103,9 +103,10 @@ def algorithm_text(cfg, settings):
                 "(the tail launch is enqueued with the step while the launches seen so far leave a tail, otherwise only when a launch "
                 "turns out to need it - checked at every sync, inside the timed region)")
     red = "reduced 2x2-block" if reduced_polish(cfg, settings) else "full 3x3-block"
-    return ("general kernel per instance: %d Ruiz pass(es), %d OSQP start step(s), %s interior point + active-set round(s) + KKT "
+    return ("general kernel per instance: %d Ruiz pass(es), %s, %s interior point + active-set round(s) + KKT "
             "certificate; phase 1 (Farkas ray) and then the full OSQP ADMM run for what that cannot certify" %
-            (settings.early_scaling, settings.early_polish, red))
+            (settings.early_scaling, ("%d OSQP start step(s)" % settings.early_polish) if settings.early_start else
+             "start from x = 0 (no OSQP iterate is computed: iters[:, 0] = 1 marks the attempt)", red))
 
 
 def native_path(cfg, settings):
@@ -472,7 +473,7 @@ def _main(real_stdout):
         # solve, as its start; reduced-native kernels: no OSQP iterate at all, the 1 marks the attempt); only an instance that
         # fell back to the full OSQP run reports more
         adm = np.where(sol.iters[:, 0] > settings.early_polish, sol.iters[:, 0], 0) if settings.polish and settings.early_polish > 0 else sol.iters[:, 0]
-        out["iters"] = {"start_steps_per_instance": 0 if native_path(cfg, settings) else (int(settings.early_polish) if settings.polish else 0),
+        out["iters"] = {"start_steps_per_instance": 0 if (native_path(cfg, settings) or not settings.early_start) else (int(settings.early_polish) if settings.polish else 0),
                         "admm_loop_iterations_mean": float(adm.mean()), "admm_loop_iterations_max": int(adm.max()),
                         "instances_in_admm_fallback": int(np.sum(adm > 0)),
                         "ipm_mean": float(sol.iters[:, 1].mean()), "ipm_max": int(sol.iters[:, 1].max()),
