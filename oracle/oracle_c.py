@@ -191,7 +191,8 @@ def timed_baseline(track, sc, weights, limits, seconds=15.0, nthreads=0, stock=F
     nsamp = sc.B
     what = ("restated OSQP at its defaults (eps 1e-3, no polish, no phase 1): the arithmetic of the reference's own solver call; "
             "ADMM iterations mean %.1f / max %d" % (float(np.mean(out["iters"][:, 0])), int(np.max(out["iters"][:, 0])))) if stock else \
-           ("the device's default algorithm on the CPU: one OSQP start step + interior point (mean %.2f iterations) + active-set round + "
+           ("the device's certified algorithm on the CPU (the device's default differs in one point: its interior point starts from x = 0, "
+            "this port from OSQP's first iterate): one OSQP start step + interior point (mean %.2f iterations) + active-set round + "
             "KKT certificate, phase 1 for the rest, OSQP ADMM only as fallback (%d of the sample's instances)" %
             (float(np.mean(out["iters"][:, 1])), int(np.sum(out["iters"][:, 0] > 1))))
     base = dict(value=nsamp / dt, unit="solves/s", cores=nt, kind="port", usable_cpus=usable_cpus(),
