@@ -20,9 +20,10 @@ G_ICACHE="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUP
 G_ICACHE2="SQC_ICACHE_BUSY_CYCLES SQC_ICACHE_INPUT_VALID_READYB SQC_DCACHE_REQ SQ_INSTS_BRANCH"
 G_MIX="SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_ACTIVE_INST_VALU2 SQ_THREAD_CYCLES_VALU"
 G_MEM="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"
-for wl in cfg2 cfg4 big; do
+for wl in cfg2 cfg3 cfg4 big; do
   case $wl in
     cfg2) A="--steps 5 --warmup 1" ;;
+    cfg3) A="--config 3 --steps 5 --warmup 1" ;;
     cfg4) A="--config 4 --steps 5 --warmup 1" ;;
     big)  A="--batch 65536 --steps 3 --warmup 1" ;;
   esac
