@@ -63,6 +63,11 @@ def test_argument_validation_without_device(lib):
     bad = mpmpc.default_settings(alpha=2.5)
     assert lib.mpmpc_create(C.byref(cfg), C.byref(bad), C.byref(h)) == -1
     assert b"alpha" in lib.mpmpc_last_error()
+    for kw, word in ((dict(early_start=2), b"early_start"), (dict(native_ipm_tol=0.0), b"native_ipm_tol"), (dict(native=3), b"native"),
+                     (dict(phase1_accept=-1), b"phase1_accept")):
+        bad = mpmpc.default_settings(**kw)
+        assert lib.mpmpc_create(C.byref(cfg), C.byref(bad), C.byref(h)) == -1, kw
+        assert word in lib.mpmpc_last_error(), (kw, lib.mpmpc_last_error())
     if mpmpc.device_count() == 0:
         # no HIP device here: creation must fail loudly, never fall back to a CPU path
         assert lib.mpmpc_create(C.byref(T.stock_config(30)), None, C.byref(h)) == -2
