@@ -2540,7 +2540,26 @@ struct Solver {
     bool early = two_stage && mode != 2;
     int limit = early ? st.early_polish : st.max_iter;
     int passes = two_stage && st.early_scaling > 0 && st.early_scaling < st.scaling ? st.early_scaling : st.scaling;
-    Mk which = live;
+    // An EMPTY box - a lower bound above its upper bound, e.g. the curvature-dependent speed cap of src/MPC.py:111-113
+    // below umin[0] - makes the QP trivially infeasible.  OSQP refuses such data at setup (the reference would raise
+    // there); here the instance is reported infeasible (verdict written at the end of run) and takes no part in the solve:
+    // the polish cannot certify it and phase 1's reduced ray has no speed entry, so it would sit through the whole ADMM run
+    // and hold its wave for it.
+    auto box_gap = [&]() {
+      R gap(0.0);
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) gap = max_(gap, sel(valid[j], lo_raw(j) - hi_raw(j), R(0.0)));
+      return L::gmax(gap);
+    };
+    const Mk solvable = live & !(box_gap() > R(0.0));      // (one mask lives through the solve; the gap itself is formed again at the end)
+    Mk which = solvable;
+    // (an instance that takes no part keeps a defined point: zero)
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) { x[j] = R(0.0); zb[j] = R(0.0); yb[j] = R(0.0); }
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) { zeq[i] = R(0.0); yeq[i] = R(0.0); }
+    status = I(MPMPC_UNSOLVED); iters = I(0); ipm_iters = I(0); polished = I(0);
+    pri_res = R(0.0); dua_res = R(0.0);
     act_bits = I(0);
     Mk warm = L::mfalse();
     if constexpr (WARM) warm = L::gany(live & bit_(guess, 30));
@@ -2569,7 +2588,7 @@ struct Solver {
         MPMPC_UNROLL
         for (int i = 0; i < 3; ++i) yeq[i] = R(0.0);
         warm_polish(st, guess, warm);
-        which = live & (status == MPMPC_UNSOLVED);
+        which = solvable & (status == MPMPC_UNSOLVED);
         if (!L::wany(which)) break;
       }
       if (pass == 0 && mode == 2 && two_stage) {
@@ -2601,7 +2620,7 @@ struct Solver {
             pri_res = sel(mg, p1_viol, pri_res);
           }
         }
-        which = live & (status == MPMPC_UNSOLVED);
+        which = solvable & (status == MPMPC_UNSOLVED);
         if (!attempt || mode == 1 || !L::wany(which)) break;
       }
       if (pass == 1) { early = false; limit = st.max_iter; continue; }
@@ -2612,25 +2631,19 @@ struct Solver {
           phase1(st, which);
           // (what phase 1 certifies keeps the ADMM iteration count of the early attempt it followed)
           iters = seli(which & (status == MPMPC_PRIMAL_INFEASIBLE), I(st.early_polish), iters);
-          which = live & (status == MPMPC_UNSOLVED);
+          which = solvable & (status == MPMPC_UNSOLVED);
           if (!L::wany(which)) break;
           retry = which & p1_feasible;
         }
       }
       if (!L::wany(retry)) { early = false; limit = st.max_iter; }
     }
-    // An EMPTY box - a lower bound above its upper bound, e.g. the curvature-dependent speed cap of src/MPC.py:111-113
-    // below umin[0] - makes the QP trivially infeasible.  OSQP refuses such data at setup (the reference would raise
-    // there); here the instance is reported infeasible, with a zero ray (no Farkas ray exists for a single empty
-    // interval row) and the width of the gap as its violation.
+    // the empty-box verdict: a zero ray (no Farkas ray exists for a single empty interval row) and the width of the gap as
+    // its violation
     {
-      R gap(0.0);
-      MPMPC_UNROLL
-      for (int j = 0; j < 5; ++j) gap = max_(gap, sel(valid[j], lo_raw(j) - hi_raw(j), R(0.0)));
-      gap = L::gmax(gap);
-      Mk empty = live & (gap > R(0.0));
+      const Mk empty = live & !solvable;
       status = seli(empty, I(MPMPC_PRIMAL_INFEASIBLE), status);
-      pri_res = sel(empty, gap, pri_res);
+      pri_res = sel(empty, box_gap(), pri_res);
       MPMPC_UNROLL
       for (int j = 0; j < 5; ++j) yb[j] = sel(empty, R(0.0), yb[j]);
       MPMPC_UNROLL
