@@ -2551,8 +2551,11 @@ struct Solver {
       for (int j = 0; j < 5; ++j) gap = max_(gap, sel(valid[j], lo_raw(j) - hi_raw(j), R(0.0)));
       return L::gmax(gap);
     };
-    const Mk solvable = live & !(box_gap() > R(0.0));      // (one mask lives through the solve; the gap itself is formed again at the end)
-    Mk which = solvable;
+    // (`live` itself is narrowed for the duration of the solve, so that every stage of it - the polish and phase 1 form
+    //  their own masks from it - leaves the instance alone; one mask lives through the solve, the gap is formed again at the end)
+    const Mk live_all = live;
+    live = live_all & !(box_gap() > R(0.0));
+    Mk which = live;
     // (an instance that takes no part keeps a defined point: zero)
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) { x[j] = R(0.0); zb[j] = R(0.0); yb[j] = R(0.0); }
@@ -2588,7 +2591,7 @@ struct Solver {
         MPMPC_UNROLL
         for (int i = 0; i < 3; ++i) yeq[i] = R(0.0);
         warm_polish(st, guess, warm);
-        which = solvable & (status == MPMPC_UNSOLVED);
+        which = live & (status == MPMPC_UNSOLVED);
         if (!L::wany(which)) break;
       }
       if (pass == 0 && mode == 2 && two_stage) {
@@ -2620,7 +2623,7 @@ struct Solver {
             pri_res = sel(mg, p1_viol, pri_res);
           }
         }
-        which = solvable & (status == MPMPC_UNSOLVED);
+        which = live & (status == MPMPC_UNSOLVED);
         if (!attempt || mode == 1 || !L::wany(which)) break;
       }
       if (pass == 1) { early = false; limit = st.max_iter; continue; }
@@ -2631,7 +2634,7 @@ struct Solver {
           phase1(st, which);
           // (what phase 1 certifies keeps the ADMM iteration count of the early attempt it followed)
           iters = seli(which & (status == MPMPC_PRIMAL_INFEASIBLE), I(st.early_polish), iters);
-          which = solvable & (status == MPMPC_UNSOLVED);
+          which = live & (status == MPMPC_UNSOLVED);
           if (!L::wany(which)) break;
           retry = which & p1_feasible;
         }
@@ -2641,7 +2644,8 @@ struct Solver {
     // the empty-box verdict: a zero ray (no Farkas ray exists for a single empty interval row) and the width of the gap as
     // its violation
     {
-      const Mk empty = live & !solvable;
+      const Mk empty = live_all & !live;
+      live = live_all;
       status = seli(empty, I(MPMPC_PRIMAL_INFEASIBLE), status);
       pri_res = sel(empty, box_gap(), pri_res);
       MPMPC_UNROLL

@@ -901,3 +901,28 @@ def test_staged_host_path_is_the_host_buffer_path_without_its_copies(track):
     v["wp_id"][0] = -1
     with pytest.raises(mpmpc.MpmpcError):
         g.solve_staged(B)
+
+
+@pytest.mark.parametrize("native", [1, 0])
+def test_empty_speed_box_is_reported_at_once_on_device(native, track):
+    """umin[0] above the curvature-dependent speed cap (src/MPC.py:111-113): an empty interval row.  The instance is reported
+    infeasible (zero ray, the gap as violation) by the reduced-native kernels and by the general ones alike, it spends no
+    iteration on it (it used to sit through the whole ADMM run in the general kernels), and its neighbours in the
+    batch are solved as if it were not there."""
+    sc = scenarios.make(2, track, B=8)
+    Q, R, QN = scenarios.WEIGHTS["stock"]
+    umin = scenarios.UMIN.copy()
+    umin[0] = 0.9
+    cfg = mpmpc.make_config(sc.N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, umin, scenarios.UMAX, scenarios.AY_MAX,
+                            scenarios.CAR_LENGTH, max_batch=8)
+    cc = sc.cc_prev.copy()
+    cc[:4, 1::2], cc[:4, 0::2] = 0.6, 1.0            # large predicted steering: speed cap 0.12 < umin 0.9
+    cc[4:] = 0.0
+    h = mpmpc.Handle(cfg, mpmpc.default_settings(native=native))
+    h.set_path(track.kappa, track.v_ref, track.ds_next)
+    sol = h.solve(sc.wp_id, sc.x0, cc, sc.lb, sc.ub, want_y=True)
+    assert np.all(sol.status[:4] == mpmpc.PRIMAL_INFEASIBLE) and np.all(sol.y[:4] == 0.0) and np.all(sol.resid[:4, 0] > 0.5)
+    assert np.all(sol.iters[:4, 1] == 0) and np.all(sol.iters[:4, 0] <= 1)
+    assert np.all(sol.status[4:] == 1)
+    alone = h.solve(sc.wp_id[4:], sc.x0[4:], cc[4:], sc.lb[4:], sc.ub[4:])
+    assert np.array_equal(alone.status, sol.status[4:]) and np.max(np.abs(alone.u0 - sol.u0[4:])) <= 1e-12
