@@ -270,6 +270,10 @@ struct Solver {
   R leq[3], lb[5], ub[5];
   // ---- linear algebra
   R hinv[5], Li[6], Gin[9], Gout[9];          // Li, Gin, Gout in chain layout (see factor)
+  // LAY_RED4: the rank-one term of the cost, rk_c = its vector on the entries e_y (0) and v (1) - zero on every other entry
+  // and on lanes without a stage; rk_u / rk_un = inv(K0) [rk_c; 0] of the current factorisation (K0: the KKT matrix without
+  // the rank-one term), rk_g = 1 / (1 + rk_c' rk_u)
+  R rk_c[2], rk_u[4], rk_un[2], rk_g;
   // ---- ADMM state
   R x[5], zeq[3], zb[5], yeq[3], yb[5];
   R rho, rb[5], rbinv[5], rho_eq, rinv_eq;
@@ -752,8 +756,12 @@ struct Solver {
   // src/simulation.py:101-103,110-111 - the QP separates into  v_k = clip(v_ref_k, umin, hi_v_k)  in closed form, the
   // roll-forward of t, and the QP in (e_y, e_psi, kappa) with 2 x 2 blocks: the same optimum (the certificate and the
   // tests check the FULL problem's KKT conditions on the reassembled point) for about half the arithmetic.
-  static constexpr int LAY_FULL = 0, LAY_SPLIT = 1, LAY_RED = 2, LAY_REDSPLIT = 3;
-  template <int LAY> static constexpr int EN = LAY == LAY_FULL ? 5 : (LAY == LAY_REDSPLIT ? 2 : 3);   // entries per lane
+  //   LAY_RED4      reduced problem PLUS the speed, 4 entries per lane: e_y, e_psi, kappa, v; 2 equality rows; the cost
+  //                 carries ONE rank-one term  1/2 (rk_c' x)^2  on top of its diagonal (the terminal cost on the time state,
+  //                 t_N being a linear functional of e_y and v: mpmpc_reduced_t.hpp) - every KKT solve is the reduced
+  //                 2 x 2-block solve, a diagonal solve for the speeds and a Sherman-Morrison correction
+  static constexpr int LAY_FULL = 0, LAY_SPLIT = 1, LAY_RED = 2, LAY_REDSPLIT = 3, LAY_RED4 = 4;
+  template <int LAY> static constexpr int EN = LAY == LAY_FULL ? 5 : (LAY == LAY_REDSPLIT ? 2 : (LAY == LAY_RED4 ? 4 : 3));   // entries per lane
   template <int LAY> static constexpr int NR = LAY >= LAY_RED ? 2 : 3;                                 // equality rows per lane
   template <int LAY> static constexpr bool SPL = (LAY == LAY_SPLIT || LAY == LAY_REDSPLIT);
   // stage vector (5 entries) -> layout
@@ -849,7 +857,7 @@ struct Solver {
       w[2] = fma_(a[5], v[2], a[4] * v[0]) + c2;
       MPMPC_UNROLL
       for (int i = 0; i < 3; ++i) r[i] = fma_(mI[i], v[i], L::up(w[i]));
-    } else if constexpr (LAY == LAY_RED) {
+    } else if constexpr (LAY == LAY_RED || LAY == LAY_RED4) {      // (the speed, entry 3 of LAY_RED4, is in no equality row)
       R w0 = fma_(a[1], v[1], a[0] * v[0]);
       R w1 = fma_(b[0], v[2], fma_(a[3], v[1], a[2] * v[0]));
       r[0] = fma_(mI[0], v[0], L::up(w0));
@@ -874,11 +882,12 @@ struct Solver {
       t[0] = fma_(bU[1], u2, fma_(a[4], nd[2], fma_(a[2], nd[1], fma_(a[0], nd[0], mI[0] * nu[0]))));
       t[1] = fma_(bU[0], u1, fma_(a[3], nd[1], fma_(a[1], nd[0], mI[1] * nu[1])));
       t[2] = fma_(a[5], nd[2], mI[2] * nu[2]);
-    } else if constexpr (LAY == LAY_RED) {
+    } else if constexpr (LAY == LAY_RED || LAY == LAY_RED4) {
       R nd0 = L::down(nu[0]), nd1 = L::down(nu[1]);
       t[0] = fma_(a[2], nd1, fma_(a[0], nd0, mI[0] * nu[0]));
       t[1] = fma_(a[3], nd1, fma_(a[1], nd0, mI[1] * nu[1]));
       t[2] = b[0] * nd1;
+      if constexpr (LAY == LAY_RED4) t[3] = R(0.0);
     } else {
       R nd0 = L::down(nu[0]), nd1 = L::down(nu[1]);
       R u1 = L::from_lower(nd1);
@@ -900,14 +909,37 @@ struct Solver {
       MPMPC_UNROLL
       for (int e = 0; e < 3; ++e) hinv[e] = h[e];
       factor_core2(h, (b[0] * b[0]) * h[2], r);
+    } else if constexpr (LAY == LAY_RED4) {
+      MPMPC_UNROLL
+      for (int e = 0; e < 4; ++e) hinv[e] = h[e];
+      factor_core2(h, (b[0] * b[0]) * h[2], r);
+      // Sherman-Morrison: one extra right-hand side per factorisation, u = inv(K0) [rk_c; 0], and 1 / (1 + rk_c'u)
+      const R zero(0.0);
+      const R rc[4] = {rk_c[0], zero, zero, rk_c[1]}, rq[2] = {zero, zero};
+      kkt_solve_base<LAY_RED4>(rc, rq, rk_u, rk_un);
+      rk_g = R(1.0) / (R(1.0) + L::gsum(fma_(rk_c[1], rk_u[3], rk_c[0] * rk_u[0])));
     } else {
       hinv[0] = h[0]; hinv[1] = h[1];
       R wb = L::from_upper((bU[0] * bU[0]) * h[0]);
       factor_core2(h, sel(sU, R(0.0), wb), r);
     }
   }
+  // [diag(1/hinv) + rank-one, Aeq'; Aeq, -r I] [xt; nu] = [rx; req]  in the layout LAY
   template <int LAY>
   MPMPC_HD void kkt_solve_t(const R* rx, const R* req, R* xt, R* nu) const {
+    kkt_solve_base<LAY>(rx, req, xt, nu);
+    if constexpr (LAY == LAY_RED4) {
+      // inv(K0 + c c') r = s - u (c's) / (1 + c'u)
+      const R beta = rk_g * L::gsum(fma_(rk_c[1], xt[3], rk_c[0] * xt[0]));
+      MPMPC_UNROLL
+      for (int j = 0; j < 4; ++j) xt[j] = fma_(-beta, rk_u[j], xt[j]);
+      nu[0] = fma_(-beta, rk_un[0], nu[0]); nu[1] = fma_(-beta, rk_un[1], nu[1]);
+    }
+  }
+  // rk_c' x over the instance (LAY_RED4; x in that layout)
+  MPMPC_HD R rank_one_dot(const R* x) const { return L::gsum(fma_(rk_c[1], x[3], rk_c[0] * x[0])); }
+  template <int LAY>
+  MPMPC_HD void kkt_solve_base(const R* rx, const R* req, R* xt, R* nu) const {
     constexpr int E = EN<LAY>, NQ = NR<LAY>;
     R t[E], bv[NQ], s[E];
     MPMPC_UNROLL
@@ -1694,6 +1726,8 @@ struct Solver {
       R res(0.0), msum(0.0);
       [[maybe_unused]] R Pod[3] = {zero, zero, zero};          // off-diagonal part of P x (FQ, not in phase 1)
       if constexpr (FQ && !SOFT) od_mul_add(pod, s.x, Pod);
+      [[maybe_unused]] R rk_dot(0.0);                          // rank-one part of P x: rk_c (rk_c' x)   (LAY_RED4)
+      if constexpr (LAY == LAY_RED4 && !SOFT) rk_dot = rank_one_dot(s.x);
       MPMPC_UNROLL
       for (int i = 0; i < NQ; ++i) { rp[i] = rp[i] - leq[i]; res = max_(res, sel(vx, abs_(rp[i]), zero)); }
       MPMPC_UNROLL
@@ -1702,6 +1736,7 @@ struct Solver {
         else {
           rd[j] = fma_(pp[j], s.x[j], qq[j]) + At[j] - s.zl[j] + s.zu[j] + s.pi[j];
           if constexpr (FQ) { if (j < 3) rd[j] = rd[j] + Pod[j]; }
+          if constexpr (LAY == LAY_RED4) { if (j == 0 || j == 3) rd[j] = fma_(rk_c[j == 0 ? 0 : 1], rk_dot, rd[j]); }
         }
         if (!boxed(j)) { res = max_(res, sel(vm[j], abs_(rd[j]), zero)); continue; }
         res = max_(res, sel(vm[j], max_(max_(abs_(rd[j]), abs_(rpin_of(j))), max_(abs_(rl_of(j)), abs_(ru_of(j)))), zero));
@@ -1923,10 +1958,13 @@ struct Solver {
         R rs(0.0);                       // KKT residual of the unregularised system at (xn, nn, ln)
         [[maybe_unused]] R Pod[3] = {zero, zero, zero};
         if constexpr (FQ) od_mul_add(pod, xn, Pod);
+        [[maybe_unused]] R rk_dot(0.0);
+        if constexpr (LAY == LAY_RED4) rk_dot = rank_one_dot(xn);
         MPMPC_UNROLL
         for (int j = 0; j < E; ++j) {
           R r1 = -qq[j] - pp[j] * xn[j] - At[j] - ln[j];
           if constexpr (FQ) { if (j < 3) r1 = r1 - Pod[j]; }
+          if constexpr (LAY == LAY_RED4) { if (j == 0 || j == 3) r1 = fma_(-rk_c[j == 0 ? 0 : 1], rk_dot, r1); }
           r3[j] = sel(act[j], bound[j] - xn[j], zero);
           rhs[j] = fma_(r3[j], idelta, r1);
           rs = max_(rs, sel(vm[j], max_(abs_(r1), abs_(r3[j])), zero));

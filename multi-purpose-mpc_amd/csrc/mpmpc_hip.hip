@@ -35,6 +35,7 @@ __device__ long long g_phase[4096 * 32];
 #include "lane_gpu.hpp"
 #include "mpmpc_core.hpp"
 #include "mpmpc_reduced.hpp"
+#include "mpmpc_reduced_t.hpp"
 #include "corridor_core.hpp"
 #include "rollout_core.hpp"
 #include "speed_core.hpp"
@@ -167,6 +168,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     tail[1 + atomicAdd(tail, 1)] = inst_o;
     // "this launch left a tail": the launch's sequence number, in host memory the device writes through (read by the host
     // after the stream has drained: observe_tail)
+    __hip_atomic_store(tail_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// K2t: the reduced-native kernel of the weightings with a TERMINAL cost on the time state (mpmpc_reduced_t.hpp; BASELINE
+// config 3): the (e_y, e_psi, kappa) problem plus the speeds plus one rank-one term, Sherman-Morrison on the 2 x 2-block
+// solves.  Same launch contract as K2r (cold starts only: a warm-started closed loop of such weights starts cold here).
+template <int G, int C>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void mpmpc_reduced_t_kernel(mpmpc_config cfg, SolverParams st, int B, AssembleIn ain,
+                                                           double* __restrict__ z, double* __restrict__ u0,
+                                                           int* __restrict__ status, int* __restrict__ iters,
+                                                           double* __restrict__ resid, double* __restrict__ y,
+                                                           int* __restrict__ tail, int* __restrict__ tail_reset,
+                                                           unsigned* __restrict__ tail_flag, unsigned seq) {
+  using L = LaneGpu<G, C, RN_SLOTS>;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *tail_reset = 0;
+  const int inst = blockIdx.x * L::per_wave + L::slot();
+  const int k = L::stage() - lane_offset(G, C, cfg.N);
+  MPMPC_TICK_BEGIN(8);
+  double fields[MPMPC_NUM_FIELDS];
+  assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
+  ReducedTSolver<L> s;
+  s.run(fields, B, inst, k, cfg.N, st, cfg.QN[2]);
+  MPMPC_TICK_BEGIN(7);
+  const int inst_o = blockIdx.x * L::per_wave + L::slot_again();
+  const int k_o = L::stage_again() - lane_offset(G, C, cfg.N);
+  s.store(inst_o, k_o, cfg.wheelbase, z, u0, status, iters, resid, y);
+  MPMPC_TICK_END(7);
+  MPMPC_TICK_END(8);
+  if (k_o == 0 && inst_o < B && s.status == MPMPC_UNSOLVED) {
+    tail[1 + atomicAdd(tail, 1)] = inst_o;
     __hip_atomic_store(tail_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
@@ -1047,7 +1079,8 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, bo
   const bool freex = !fullqn && !red && free_states(h->cfg);
   // The reduced-native kernels (mpmpc_reduced.hpp) take the batch path of every configuration they apply to - cold and
   // warm-started - and only they pack several instances into a wave; the general kernel then sees their tail.
-  const bool rn = reduced_native(h->cfg, h->st);
+  const bool rnt = reduced_native_tt(h->cfg, h->st);      // ... or their twin for a terminal cost on the time state
+  const bool rn = rnt || reduced_native(h->cfg, h->st);
   // lanes per instance: one instance per wave while there are no more instances than SIMDs (1024); beyond that the
   // smallest power of two holding N + 1 stages, so that a wave carries 2 or 4 instances and a SIMD two such waves
   int G = 64;
@@ -1060,7 +1093,7 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, bo
   // its slowest car, and with more than a handful of cars one of them always misses its guess (hit rate 91-93 %
   // per car and step: the miss pays for the attempt AND the normal path, 1024 cars -7 %), so "auto" warm-starts the
   // packed launches (x1.5 at 8192 cars) and the very small fleets (x1.7 at 8 cars) only.
-  const bool warm = closed_loop && (h->ro_warm == 1 || (h->ro_warm == 2 && (G < 64 || B <= 16)));
+  const bool warm = closed_loop && !rnt && (h->ro_warm == 1 || (h->ro_warm == 2 && (G < 64 || B <= 16)));
   int* warm_act = warm ? h->ro_act : nullptr;
   const int* warm_shift = warm ? h->ro_shift : nullptr;
   const int per = 64 / G;
@@ -1103,8 +1136,16 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, bo
     if (warm) LAUNCH_RN_W(GG, CC, true);        \
     else LAUNCH_RN_W(GG, CC, false);            \
   } while (0)
+#define LAUNCH_RNT(GG, CC)                                                                                               \
+  hipLaunchKernelGGL((mpmpc_reduced_t_kernel<GG, CC>), dim3(blocks), dim3(64), rn_pad, h->stream, h->cfg, prm, B, ain, \
+                     h->z, h->u0, h->status, h->iters, h->resid, y_out, tail_cur, tail_next, h->tail_flag, h->seq)
   if (rn) {
-    if (!tail_only) {
+    if (!tail_only && rnt) {
+      if (G == 64 && C == 16) LAUNCH_RNT(64, 16);
+      else if (G == 64) LAUNCH_RNT(64, 32);
+      else if (G == 32) LAUNCH_RNT(32, 16);
+      else LAUNCH_RNT(16, 16);
+    } else if (!tail_only) {
       if (G == 64 && C == 16) LAUNCH_RN(64, 16);
       else if (G == 64) LAUNCH_RN(64, 32);
       else if (G == 32) LAUNCH_RN(32, 16);
@@ -1124,6 +1165,7 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, bo
     else LAUNCH(32, false, 2, B);
   } else if (C == 16) LAUNCH(16, warm, 0, blocks);
   else LAUNCH(32, warm, 0, blocks);
+#undef LAUNCH_RNT
 #undef LAUNCH_RN
 #undef LAUNCH_RN_W
 #undef LAUNCH_V

@@ -7,6 +7,7 @@
 #include "lane_emu.hpp"
 #include "mpmpc_core.hpp"
 #include "mpmpc_reduced.hpp"
+#include "mpmpc_reduced_t.hpp"
 #include "corridor_core.hpp"
 #include "rollout_core.hpp"
 #include <limits>
@@ -73,6 +74,35 @@ static void solve_rn(const mpmpc_config* cfg, const mpmpc_settings* st, const do
       if (k.v[i] == 0 && inst.v[i] < B && s.status.v[i] == MPMPC_UNSOLVED) tail[1 + tail[0]++] = inst.v[i];
   }
 }
+// mpmpc_reduced_t_kernel: the reduced-native solver of the weightings with a terminal cost on the time state
+template <int G, int C>
+static void solve_rnt(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
+                      int* status, int* iters, double* resid, double* y, int* tail) {
+  using L = LaneEmu<G, C>;
+  const int ld = stage_ld(cfg->N);
+  const int per = L::per_wave;
+  for (int w = 0; w < (B + per - 1) / per; ++w) {
+    VI inst = L::slot() + w * per;
+    VI k = L::stage() - lane_offset(G, C, cfg->N);
+    ReducedTSolver<L> s;
+    typename L::real fields[MPMPC_NUM_FIELDS];
+    ReducedTSolver<L>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    s.run(fields, B, inst, k, cfg->N, make_params(*st), cfg->QN[2]);
+    s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y);
+    for (int i = 0; i < EMU_W; ++i)
+      if (k.v[i] == 0 && inst.v[i] < B && s.status.v[i] == MPMPC_UNSOLVED) tail[1 + tail[0]++] = inst.v[i];
+  }
+}
+static int solve_rnt_g(int G, const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
+                       int* status, int* iters, double* resid, double* y, int* tail) {
+  const int C = lane_split(G, cfg->N);
+  if (G == 64 && C == 16) solve_rnt<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
+  else if (G == 64) solve_rnt<64, 32>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
+  else if (G == 32) solve_rnt<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
+  else if (G == 16) solve_rnt<16, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
+  else return -1;
+  return 0;
+}
 static int solve_rn_g(int G, const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
                       int* status, int* iters, double* resid, double* y, int* tail, const int* guess = nullptr, int* act = nullptr) {
   const int C = lane_split(G, cfg->N);
@@ -116,9 +146,10 @@ extern "C" int emu_solve_launch(const mpmpc_config* cfg, const mpmpc_settings* s
   const bool early = st->polish && st->early_polish > 0 && st->early_polish < st->max_iter;
   if (n_tail) *n_tail = 0;
   std::vector<int> tail(B + 1, 0);
-  if (reduced_native(*cfg, *st)) {
+  if (reduced_native(*cfg, *st) || reduced_native_tt(*cfg, *st)) {
     // the reduced-native kernel for the whole batch (any packing), then the general kernel on its tail
-    if (solve_rn_g(G, cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data())) return -1;
+    if (reduced_native_tt(*cfg, *st) ? solve_rnt_g(G, cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data())
+                                     : solve_rn_g(G, cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data())) return -1;
     if (n_tail) *n_tail = tail[0];
     if (lane_split(64, cfg->N) == 16) SOLVE_G(64, 16, cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 2, tail.data());
     else SOLVE_G(64, 32, cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 2, tail.data());
@@ -137,8 +168,14 @@ extern "C" int emu_solve_launch(const mpmpc_config* cfg, const mpmpc_settings* s
 // the reduced-native kernel alone: what it cannot certify stays UNSOLVED and is counted in *n_tail
 extern "C" int emu_solve_rn(const mpmpc_config* cfg, const mpmpc_settings* st, int G, const double* qp, int B,
                             double* z, double* u0, int* status, int* iters, double* resid, double* y, int* n_tail) {
-  if (cfg->N + 1 > G || !reducible(*cfg, *st)) return -1;
+  if (cfg->N + 1 > G) return -1;
   std::vector<int> tail(B + 1, 0);
+  if (reducible_tt(*cfg, *st)) {
+    if (solve_rnt_g(G, cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data())) return -1;
+    if (n_tail) *n_tail = tail[0];
+    return 0;
+  }
+  if (!reducible(*cfg, *st)) return -1;
   if (solve_rn_g(G, cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data())) return -1;
   if (n_tail) *n_tail = tail[0];
   return 0;
@@ -157,6 +194,7 @@ extern "C" int emu_solve_rn_sequential(const mpmpc_config* cfg, const mpmpc_sett
   return 0;
 }
 extern "C" int emu_reduced_native(const mpmpc_config* cfg, const mpmpc_settings* st) { return reduced_native(*cfg, *st) ? 1 : 0; }
+extern "C" int emu_reduced_native_tt(const mpmpc_config* cfg, const mpmpc_settings* st) { return reduced_native_tt(*cfg, *st) ? 1 : 0; }
 
 // the closed-loop variant: `guess` [B x ld] = active sets to start from (bit 30 = valid), `act` [B x ld] <- the
 // active sets of the certified points (what mpmpc_solve_kernel<..., true> reads and writes in a rollout)
