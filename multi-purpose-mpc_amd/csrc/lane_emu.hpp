@@ -175,6 +175,15 @@ struct LaneEmu {
     }
     return r;
   }
+  static VD gcount(const VB& m) {
+    VD r;
+    for (int g = 0; g < per_wave; ++g) {
+      int c = 0;
+      for (int i = 0; i < G; ++i) c += m.v[g * G + i] ? 1 : 0;
+      for (int i = 0; i < G; ++i) r.v[g * G + i] = double(c);
+    }
+    return r;
+  }
   static bool wany(const VB& m) { for (int i = 0; i < EMU_W; ++i) if (m.v[i]) return true; return false; }
 
   // "cold" per-lane storage (LDS on the GPU) for values that are only needed at termination checks

@@ -191,6 +191,12 @@ struct LaneGpu {
     return mine != 0ull;
   }
   static __device__ __forceinline__ bool wany(bool m) { return __ballot(m) != 0ull; }
+  // number of lanes of the instance on which m holds (scalar unit: ballot + bit count, no lane arithmetic)
+  static __device__ __forceinline__ double gcount(bool m) {
+    unsigned long long b = __ballot(m);
+    if (G < 64) b = (b >> (slot() * G)) & ((1ull << (G & 63)) - 1ull);
+    return double(__popcll(b));
+  }
 
   // "cold" per-lane storage in LDS (one wavefront per block, slot-major: a wave access is 64
   // consecutive doubles, conflict free) for values only needed at termination checks and in the

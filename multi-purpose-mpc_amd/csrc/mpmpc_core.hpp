@@ -234,7 +234,9 @@ MPMPC_HOST_DEVICE inline int lane_offset(int G, int C, int N) {
 // CR: the two elimination chains of the reduced problem's factorisation (2 x 2 blocks, L::split == 16: each chain is one
 // row of 16 lanes) are eliminated by CYCLIC REDUCTION IN CHOLESKY FORM - four lane-parallel levels of distance 1, 2, 4, 8
 // inside the row instead of 15 dependent steps (factor_cr2 / s_solve_cr2 below).
-template <class L, bool FQ = false, bool RED = false, bool FREEX = false, bool CR = false>
+// RKS: LAY_RED4 only - first of the six cold slots that hold the Sherman-Morrison vector of the current factorisation
+// (it is read once per KKT solve: no reason to keep twelve registers for it)
+template <class L, bool FQ = false, bool RED = false, bool FREEX = false, bool CR = false, int RKS = 0>
 struct Solver {
   static_assert(!(FQ && RED), "the reduced problem needs a diagonal terminal weight");
   static constexpr bool kCR = CR && L::split == 16;
@@ -271,9 +273,9 @@ struct Solver {
   // ---- linear algebra
   R hinv[5], Li[6], Gin[9], Gout[9];          // Li, Gin, Gout in chain layout (see factor)
   // LAY_RED4: the rank-one term of the cost, rk_c = its vector on the entries e_y (0) and v (1) - zero on every other entry
-  // and on lanes without a stage; rk_u / rk_un = inv(K0) [rk_c; 0] of the current factorisation (K0: the KKT matrix without
-  // the rank-one term), rk_g = 1 / (1 + rk_c' rk_u)
-  R rk_c[2], rk_u[4], rk_un[2], rk_g;
+  // and on lanes without a stage; u = inv(K0) [rk_c; 0] of the current factorisation (K0: the KKT matrix without the rank-one
+  // term) waits in the cold slots RKS .. RKS + 5 (4 entries, 2 equality rows), rk_g = 1 / (1 + rk_c'u)
+  R rk_c[2], rk_g;
   // ---- ADMM state
   R x[5], zeq[3], zb[5], yeq[3], yb[5];
   R rho, rb[5], rbinv[5], rho_eq, rinv_eq;
@@ -916,8 +918,13 @@ struct Solver {
       // Sherman-Morrison: one extra right-hand side per factorisation, u = inv(K0) [rk_c; 0], and 1 / (1 + rk_c'u)
       const R zero(0.0);
       const R rc[4] = {rk_c[0], zero, zero, rk_c[1]}, rq[2] = {zero, zero};
-      kkt_solve_base<LAY_RED4>(rc, rq, rk_u, rk_un);
-      rk_g = R(1.0) / (R(1.0) + L::gsum(fma_(rk_c[1], rk_u[3], rk_c[0] * rk_u[0])));
+      R u[4], un[2];
+      kkt_solve_base<LAY_RED4>(rc, rq, u, un);
+      rk_g = R(1.0) / (R(1.0) + L::gsum(fma_(rk_c[1], u[3], rk_c[0] * u[0])));
+      MPMPC_UNROLL
+      for (int j = 0; j < 4; ++j) L::cold_put(RKS + j, u[j]);
+      L::cold_put(RKS + 4, un[0]); L::cold_put(RKS + 5, un[1]);
+      L::fence();
     } else {
       hinv[0] = h[0]; hinv[1] = h[1];
       R wb = L::from_upper((bU[0] * bU[0]) * h[0]);
@@ -932,8 +939,8 @@ struct Solver {
       // inv(K0 + c c') r = s - u (c's) / (1 + c'u)
       const R beta = rk_g * L::gsum(fma_(rk_c[1], xt[3], rk_c[0] * xt[0]));
       MPMPC_UNROLL
-      for (int j = 0; j < 4; ++j) xt[j] = fma_(-beta, rk_u[j], xt[j]);
-      nu[0] = fma_(-beta, rk_un[0], nu[0]); nu[1] = fma_(-beta, rk_un[1], nu[1]);
+      for (int j = 0; j < 4; ++j) xt[j] = fma_(-beta, L::cold_get(RKS + j), xt[j]);
+      nu[0] = fma_(-beta, L::cold_get(RKS + 4), nu[0]); nu[1] = fma_(-beta, L::cold_get(RKS + 5), nu[1]);
     }
   }
   // rk_c' x over the instance (LAY_RED4; x in that layout)

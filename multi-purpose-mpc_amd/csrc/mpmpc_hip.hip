@@ -1084,7 +1084,7 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, bo
   // lanes per instance: one instance per wave while there are no more instances than SIMDs (1024); beyond that the
   // smallest power of two holding N + 1 stages, so that a wave carries 2 or 4 instances and a SIMD two such waves
   int G = 64;
-  if (rn) {
+  if (rn && !rnt) {      // (the terminal-time kernels run one instance per wave)
     if (N + 1 <= 32 && B > 1024) G = 32;
     if (N + 1 <= 16 && B > 2048) G = 16;
     if (h->force_lanes && N + 1 <= h->force_lanes) G = h->force_lanes;      // mpmpc_set_packing
@@ -1141,10 +1141,8 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, bo
                      h->z, h->u0, h->status, h->iters, h->resid, y_out, tail_cur, tail_next, h->tail_flag, h->seq)
   if (rn) {
     if (!tail_only && rnt) {
-      if (G == 64 && C == 16) LAUNCH_RNT(64, 16);
-      else if (G == 64) LAUNCH_RNT(64, 32);
-      else if (G == 32) LAUNCH_RNT(32, 16);
-      else LAUNCH_RNT(16, 16);
+      if (C == 16) LAUNCH_RNT(64, 16);
+      else LAUNCH_RNT(64, 32);
     } else if (!tail_only) {
       if (G == 64 && C == 16) LAUNCH_RN(64, 16);
       else if (G == 64) LAUNCH_RN(64, 32);

@@ -33,9 +33,12 @@ inline bool reduced_native_tt(const mpmpc_config& c, const mpmpc_settings& st) {
          st.early_scaling >= 0 && st.scaling > 0;
 }
 
+// One instance per wavefront only (G = 64): the cold slots of the certified point are free until the solve ends and serve as
+// working storage of the loops (a packed wave would hold its partner instance's committed point there).
 template <class L, bool CR = true>
-struct ReducedTSolver : Solver<L, false, true, false, CR> {
-  using S = Solver<L, false, true, false, CR>;
+struct ReducedTSolver : Solver<L, false, true, false, CR, 11> {
+  static_assert(L::per_wave == 1, "the terminal-time kernels run one instance per wavefront");
+  using S = Solver<L, false, true, false, CR, 11>;
   using R = typename L::real;
   using Mk = typename L::mask;
   using I = typename L::ival;
@@ -50,15 +53,17 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
   //   C_D (4), C_E (2), C_C   scalings of the 4 columns, the 2 dynamics rows, the cost
   //   C_A20, C_B20, C_BEQ2    the time row: t_k = t_{k-1} + a20 e_y + b20 v - beq2  (also the unscaled rank-one vector)
   //   C_GAP                   width of an empty box
-  //   C_G (4)                 box-row scaling of the start; later (same slots) C_XS: the certified point
-  //   C_LAM (4), C_NUS (2)    its box and equality multipliers
+  //   C_G (4)                 box-row scaling of the start; at the end (same slots) C_XS: the certified point,
+  //   C_LAM (4), C_NUS (2)    its box and equality multipliers.  Until then these ten slots work for the loops:
+  //     S_U (6)               the Sherman-Morrison vector of the current factorisation (Solver: RKS)
+  //     S_RD (4)              dual residual of the interior point's iteration (S_RP (2), the primal one: two of the free slots)
   //   K_LO* / K_HI*           boxes of e_y, kappa, v in the scaled variable space
   //   K_PP (4), K_QQ (4), K_LEQ (2)   cost and equality offsets of the interior point's loop
   //   K_PARK .. 39            (= K_LO0 ..: box, cost and offsets are in registers while the active-set rounds run, and three
   //                           free slots) the interior point's iterate during the rounds - only a further attempt reads it again
   enum { C_D = 0, C_E = 4, C_C = 6, C_A20 = 7, C_B20 = 8, C_BEQ2 = 9, C_GAP = 10, C_G = 11, C_XS = 11, C_LAM = 15, C_NUS = 19,
-         K_LO0 = 21, K_HI0 = 22, K_LO2 = 23, K_HI2 = 24, K_LO3 = 25, K_HI3 = 26, K_PP = 27, K_QQ = 31, K_LEQ = 35, K_PARK = 21,
-         COLD_USED = 40 };
+         S_U = 11, S_RD = 17, K_LO0 = 21, K_HI0 = 22, K_LO2 = 23, K_HI2 = 24, K_LO3 = 25, K_HI3 = 26, K_PP = 27, K_QQ = 31, K_LEQ = 35,
+         S_RP = 37, S_RES = 37, K_PARK = 21, COLD_USED = 40 };
   static_assert(COLD_USED <= L::cold_slots, "lane backend has too few cold slots");
   static constexpr double BOX_INF = 1e20;
   static constexpr int RN_ATTEMPTS = 3;
@@ -78,8 +83,6 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
     live = inst < B;
     vx = live & within_(k, 0, N);
     vu = live & within_(k, 0, N - 1);
-    first = (k == 0);
-    term = live & (k == N);
     {
       const int C = L::split;
       off_ = lane_offset(L::group, C, N);
@@ -93,16 +96,21 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
     val[0] = vx; val[1] = vx; val[2] = vu; val[3] = vu;
     auto fld = [&](int f, double dflt) { return sel(vx, fields[f], R(dflt)); };
     const R zero(0.0), onec(1.0);
-    const R lo_e = max_(fld(F_LO + 0, -INFTY), R(-INFTY)), hi_e = min_(fld(F_HI + 0, INFTY), R(INFTY));
-    const R lo_k = max_(fld(F_LO + 4, -INFTY), R(-INFTY)), hi_k = min_(fld(F_HI + 4, INFTY), R(INFTY));
-    const R lo_v = max_(fld(F_LO + 3, -INFTY), R(-INFTY)), hi_v = min_(fld(F_HI + 3, INFTY), R(INFTY));
+    // (what the Ruiz passes do not touch goes to its cold slot at once - raw, and is put in scaled form afterwards - so that
+    //  the passes, the register peak of the kernel's start, do not carry it)
     {
+      const R lo_e = max_(fld(F_LO + 0, -INFTY), R(-INFTY)), hi_e = min_(fld(F_HI + 0, INFTY), R(INFTY));
+      const R lo_k = max_(fld(F_LO + 4, -INFTY), R(-INFTY)), hi_k = min_(fld(F_HI + 4, INFTY), R(INFTY));
+      const R lo_v = max_(fld(F_LO + 3, -INFTY), R(-INFTY)), hi_v = min_(fld(F_HI + 3, INFTY), R(INFTY));
       // an EMPTY box makes the QP trivially infeasible (Solver::run has the same rule): reported at once, never solved
       R gap = max_(max_(sel(vx, lo_e - hi_e, zero), sel(vu, lo_k - hi_k, zero)), sel(vu, lo_v - hi_v, zero));
       gap = L::gmax(gap);
       empty = live & (gap > zero);
       solvable = live & !empty;
       L::cold_put(C_GAP, gap);
+      L::cold_put(K_LO0, lo_e); L::cold_put(K_HI0, hi_e); L::cold_put(K_LO2, lo_k); L::cold_put(K_HI2, hi_k);
+      L::cold_put(K_LO3, lo_v); L::cold_put(K_HI3, hi_v);
+      L::cold_put(K_LEQ, fld(F_BEQ + 0, 0.0)); L::cold_put(K_LEQ + 1, fld(F_BEQ + 1, 0.0));
     }
     const R ds = fld(F_DS, 0.0), one = sel(vu, onec, zero);
     a[0] = one; a[1] = ds; a[2] = fld(F_A10, 0.0); a[3] = one;
@@ -112,44 +120,44 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
     Q4[0] = fld(F_Q + 0, 0.0); Q4[1] = fld(F_Q + 1, 0.0); Q4[2] = fld(F_Q + 4, 0.0); Q4[3] = fld(F_Q + 3, 0.0);
     // ---- the time functional  t_N = c'(e_y, v) + d  (unscaled): c = (a20, b20) of the lane's stage (zero on stage N),
     // d = -sum beq2;  its cost 1/2 w t_N^2 adds  w d c  to the cost vector and  w c c'  to the Hessian
-    R cr[2] = {sel(vu, fld(F_A20, 0.0), zero), sel(vu, fld(F_B20, 0.0), zero)};
-    const R beq2 = fld(F_BEQ + 2, 0.0);
-    L::cold_put(C_A20, cr[0]); L::cold_put(C_B20, cr[1]); L::cold_put(C_BEQ2, beq2);
     {
+      const R cr0 = sel(vu, fld(F_A20, 0.0), zero), cr1 = sel(vu, fld(F_B20, 0.0), zero);
+      const R beq2 = fld(F_BEQ + 2, 0.0);
+      L::cold_put(C_A20, cr0); L::cold_put(C_B20, cr1); L::cold_put(C_BEQ2, beq2);
       const R wd = R(w_time) * L::gsum(-beq2);
-      Q4[0] = fma_(wd, cr[0], Q4[0]);
-      Q4[3] = fma_(wd, cr[1], Q4[3]);
+      Q4[0] = fma_(wd, cr0, Q4[0]);
+      Q4[3] = fma_(wd, cr1, Q4[3]);
     }
-    R D4[4] = {onec, onec, onec, onec}, G4[4] = {onec, onec, onec, onec}, Eb[4] = {onec, onec, onec, onec}, E2[2] = {onec, onec}, c4(1.0);
-    // OSQP scale_data() on this problem: Ruiz passes over the columns (e_y, e_psi, kappa, v) and the rows (2 dynamics rows,
+    L::fence();
+    R D4[4] = {onec, onec, onec, onec}, G4[4] = {onec, onec, onec, onec}, E2[2] = {onec, onec}, c4(1.0);
+    // OSQP's scale_data() on this problem: Ruiz passes over the columns (e_y, e_psi, kappa, v) and the rows (2 dynamics rows,
     // 4 box rows), each with the cost normalisation (the rank-one term takes no part in the norms: its entries, w c_i c_j,
-    // stay below the diagonal's for the path's curvatures and speeds)
+    // stay below the diagonal's for the path's curvatures and speeds).  Reciprocal square roots by rsqrt_ (1.2 ulp): this
+    // kernel's scaling is its own, nothing has to reproduce it bit for bit.
     const int passes = st.early_scaling > 0 && st.early_scaling < st.scaling ? st.early_scaling : st.scaling;
     const R n_total(double(4 * N + 2));
     for (int it = 0; it < passes; ++it) {
-      R cn[4], rn[2], r_own[2];
+      R cn[4], r_own[2];
       cn[0] = max_(max_(max_(abs_(P4[0]), abs_(mI[0])), max_(abs_(a[0]), abs_(a[2]))), abs_(G4[0]));
       cn[1] = max_(max_(max_(abs_(P4[1]), abs_(mI[1])), max_(abs_(a[1]), abs_(a[3]))), abs_(G4[1]));
       cn[2] = max_(max_(abs_(P4[2]), abs_(b[0])), abs_(G4[2]));
       cn[3] = max_(abs_(P4[3]), abs_(G4[3]));
       r_own[0] = max_(abs_(a[0]), abs_(a[1]));
       r_own[1] = max_(max_(abs_(a[2]), abs_(a[3])), abs_(b[0]));
-      R Dt[4], Et[2], Etb[4], Etd[2];
+      R Dt[4], Et[2], Etd[2];
       MPMPC_UNROLL
       for (int i = 0; i < 2; ++i) {
-        rn[i] = max_(abs_(mI[i]), L::up(r_own[i]));
-        Et[i] = R(1.0) / sqrt_(S::limit(rn[i]));
+        Et[i] = rsqrt_(S::limit(max_(abs_(mI[i]), L::up(r_own[i]))));
         Etd[i] = L::down(Et[i]);
       }
       MPMPC_UNROLL
       for (int e = 0; e < 4; ++e) {
-        Dt[e] = R(1.0) / sqrt_(S::limit(cn[e]));
-        Etb[e] = R(1.0) / sqrt_(S::limit(abs_(G4[e])));
+        Dt[e] = rsqrt_(S::limit(cn[e]));
+        const R Etb = rsqrt_(S::limit(abs_(G4[e])));
         P4[e] = (Dt[e] * P4[e]) * Dt[e];
-        G4[e] = (Etb[e] * G4[e]) * Dt[e];
+        G4[e] = (Etb * G4[e]) * Dt[e];
         Q4[e] = Dt[e] * Q4[e];
         D4[e] = D4[e] * Dt[e];
-        Eb[e] = Eb[e] * Etb[e];
       }
       MPMPC_UNROLL
       for (int i = 0; i < 2; ++i) { mI[i] = (Et[i] * mI[i]) * Dt[i]; E2[i] = E2[i] * Et[i]; }
@@ -164,55 +172,62 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
       }
       R ct = L::gsum(s) / n_total;
       const R nq = S::limit(L::gmax(mq));
-      ct = R(1.0) / S::limit(max_(ct, nq));
+      ct = rcp_(S::limit(max_(ct, nq)));
       MPMPC_UNROLL
       for (int e = 0; e < 4; ++e) { P4[e] = P4[e] * ct; Q4[e] = Q4[e] * ct; }
       c4 = c4 * ct;
     }
-    leq[0] = E2[0] * fld(F_BEQ + 0, 0.0);
-    leq[1] = E2[1] * fld(F_BEQ + 1, 0.0);
+    L::fence();
+    leq[0] = E2[0] * L::cold_get(K_LEQ);
+    leq[1] = E2[1] * L::cold_get(K_LEQ + 1);
     // the rank-one vector in the scaled problem:  1/2 (c4 w) (c' D x)^2  =  1/2 (rk_c' x)^2
     {
       const R sw = sqrt_(c4 * R(w_time));
-      rk_c[0] = (sw * D4[0]) * cr[0];
-      rk_c[1] = (sw * D4[3]) * cr[1];
+      rk_c[0] = (sw * D4[0]) * L::cold_get(C_A20);
+      rk_c[1] = (sw * D4[3]) * L::cold_get(C_B20);
     }
     MPMPC_UNROLL
     for (int e = 0; e < 4; ++e) { L::cold_put(C_D + e, D4[e]); L::cold_put(C_G + e, G4[e]); }
     L::cold_put(C_E, E2[0]); L::cold_put(C_E + 1, E2[1]);
     L::cold_put(C_C, c4);
     // box in the scaled variable space:  g x in [lb, ub]  <=>  x in [lo_raw, hi_raw] / D
-    L::cold_put(K_LO0, lo_e / D4[0]); L::cold_put(K_HI0, hi_e / D4[0]);
-    L::cold_put(K_LO2, lo_k / D4[2]); L::cold_put(K_HI2, hi_k / D4[2]);
-    L::cold_put(K_LO3, lo_v / D4[3]); L::cold_put(K_HI3, hi_v / D4[3]);
+    {
+      const R i0 = rcp_(D4[0]), i2 = rcp_(D4[2]), i3 = rcp_(D4[3]);
+      L::cold_put(K_LO0, L::cold_get(K_LO0) * i0); L::cold_put(K_HI0, L::cold_get(K_HI0) * i0);
+      L::cold_put(K_LO2, L::cold_get(K_LO2) * i2); L::cold_put(K_HI2, L::cold_get(K_HI2) * i2);
+      L::cold_put(K_LO3, L::cold_get(K_LO3) * i3); L::cold_put(K_HI3, L::cold_get(K_HI3) * i3);
+    }
     L::fence();
   }
 
   // ================================================================================ interior point, 4 entries per lane
-  // Solver::ipm<LAY_RED4> (same iteration, same constants, same operation order) written like ReducedSolver::ipm3 for a small
-  // register footprint: the loop invariants (box, cost, equality offsets) wait in LDS and are re-read where they are used.
-  // Entry 1 (e_psi) is never boxed (reducible_tt()); entries 0, 2, 3 (e_y, kappa, v) are.
+  // The iteration of Solver::ipm (regularised Mehrotra predictor-corrector, same constants and step rules) written like
+  // ReducedSolver::ipm3 for a small register footprint: the loop invariants (box, cost, equality offsets), the residuals of the
+  // iteration and the Sherman-Morrison vector wait in LDS and are re-read where they are used.  Entry 1 (e_psi) is never boxed
+  // (reducible_tt()); entries 0, 2, 3 (e_y, kappa, v) are.  A PINNED entry (lo = hi: e_y of stage 0) is eliminated instead
+  // of being held by a proximal term: it starts on its value and its diagonal inverse is zero, so that no step moves it and
+  // no multiplier has to be carried for it (s.pi is not used; the active-set rounds compute the pin's multiplier).
   MPMPC_HD Mk ipm4(const Box4& bx, Ipm4& s, const SolverParams& st, double tol, const Mk& run) {
-    const R reg(st.ipm_reg), ireg(st.inv_ipm_reg), one(1.0), zero(0.0);
+    const R reg(st.ipm_reg), one(1.0), zero(0.0);
     constexpr int NB = 3;
     constexpr int JB[NB] = {0, 2, 3};
     Mk active = run, conv = L::mfalse();
     R cnt(0.0);
     MPMPC_UNROLL
-    for (int b = 0; b < NB; ++b) cnt = cnt + sel(bx.Lm[JB[b]], one, zero) + sel(bx.Um[JB[b]], one, zero);
-    const R nb = max_(L::gsum(cnt), one);
+    for (int b = 0; b < NB; ++b) cnt = cnt + L::gcount(bx.Lm[JB[b]]) + L::gcount(bx.Um[JB[b]]);
+    const R nb = max_(cnt, one);
     I stall(0);
     R mu_min(1e300);
     auto lo_of = [&](int b) { return L::cold_get(b == 0 ? K_LO0 : (b == 1 ? K_LO2 : K_LO3)); };
     auto hi_of = [&](int b) { return L::cold_get(b == 0 ? K_HI0 : (b == 1 ? K_HI2 : K_HI3)); };
     auto rl_of = [&](int b) { const int j = JB[b]; return sel(bx.Lm[j], s.x[j] - lo_of(b) - s.sl[j], zero); };
     auto ru_of = [&](int b) { const int j = JB[b]; return sel(bx.Um[j], hi_of(b) - s.x[j] - s.su[j], zero); };
-    auto rpin_of = [&](int b) { const int j = JB[b]; return sel(bx.pin[j], s.x[j] - lo_of(b), zero); };
     for (int it = 0; it <= st.ipm_max_iter; ++it) {
-      R mu, rd[4], rp[2];
+      R mu;
       {
+        // ---- residuals -> LDS
         L::fence();
-        R At[4];
+        R At[4], rd[4], rp[2];
         this->template AeqT_mul_t<LAY4>(s.nu, At);
         this->template Aeq_mul_t<LAY4>(s.x, rp);
         const R rk_dot = this->rank_one_dot(s.x);
@@ -221,16 +236,20 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
         for (int i = 0; i < 2; ++i) { rp[i] = rp[i] - L::cold_get(K_LEQ + i); res = max_(res, sel(vx, abs_(rp[i]), zero)); }
         MPMPC_UNROLL
         for (int j = 0; j < 4; ++j) {
-          rd[j] = fma_(L::cold_get(K_PP + j), s.x[j], L::cold_get(K_QQ + j)) + At[j] - s.zl[j] + s.zu[j] + s.pi[j];
+          rd[j] = fma_(L::cold_get(K_PP + j), s.x[j], L::cold_get(K_QQ + j)) + At[j] - s.zl[j] + s.zu[j];
           if (j == 0 || j == 3) rd[j] = fma_(rk_c[j == 0 ? 0 : 1], rk_dot, rd[j]);
+          if (j != 1) rd[j] = sel(bx.pin[j], zero, rd[j]);          // (a pinned entry has no stationarity row)
         }
         res = max_(res, sel(val[1], abs_(rd[1]), zero));
         MPMPC_UNROLL
         for (int b = 0; b < NB; ++b) {
           const int j = JB[b];
-          res = max_(res, sel(val[j], max_(max_(abs_(rd[j]), abs_(rpin_of(b))), max_(abs_(rl_of(b)), abs_(ru_of(b)))), zero));
+          res = max_(res, sel(val[j], max_(abs_(rd[j]), max_(abs_(rl_of(b)), abs_(ru_of(b)))), zero));
           msum = msum + sel(bx.Lm[j], s.sl[j] * s.zl[j], zero) + sel(bx.Um[j], s.su[j] * s.zu[j], zero);
         }
+        MPMPC_UNROLL
+        for (int j = 0; j < 4; ++j) L::cold_put(S_RD + j, rd[j]);
+        L::cold_put(S_RP, rp[0]); L::cold_put(S_RP + 1, rp[1]);
         res = L::gmax(res);
         mu = L::gsum(msum) / nb;
         const Mk ok = (res < R(tol > 1e-11 ? tol : 1e-11)) & (mu < R(tol));
@@ -252,8 +271,7 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
         for (int b = 0; b < NB; ++b) {
           const int j = JB[b];
           const R il = rcp_(s.sl[j]), iu = rcp_(s.su[j]);
-          h[j] = rcp_(L::cold_get(K_PP + j) + reg + sel(bx.Lm[j], s.zl[j] * il, zero) + sel(bx.Um[j], s.zu[j] * iu, zero) +
-                      sel(bx.pin[j], ireg, zero));
+          h[j] = sel(bx.pin[j], zero, rcp_(L::cold_get(K_PP + j) + reg + sel(bx.Lm[j], s.zl[j] * il, zero) + sel(bx.Um[j], s.zu[j] * iu, zero)));
         }
         this->template factor_t<LAY4>(h, reg);
         L::fence();
@@ -270,18 +288,18 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
         {
           L::fence();
           R rhs[4], nreq[2];
-          rhs[1] = -rd[1];
+          rhs[1] = -L::cold_get(S_RD + 1);
           MPMPC_UNROLL
           for (int b = 0; b < NB; ++b) {
             const int j = JB[b];
-            rhs[j] = -rd[j] - sel(bx.Lm[j], fma_(s.zl[j], rl_of(b), rcl[b]) * isl[b], zero) +
-                     sel(bx.Um[j], fma_(s.zu[j], ru_of(b), rcu[b]) * isu[b], zero) - sel(bx.pin[j], rpin_of(b) * ireg, zero);
+            rhs[j] = -L::cold_get(S_RD + j) - sel(bx.Lm[j], fma_(s.zl[j], rl_of(b), rcl[b]) * isl[b], zero) +
+                     sel(bx.Um[j], fma_(s.zu[j], ru_of(b), rcu[b]) * isu[b], zero);
           }
-          nreq[0] = -rp[0]; nreq[1] = -rp[1];
+          nreq[0] = -L::cold_get(S_RP); nreq[1] = -L::cold_get(S_RP + 1);
           this->template kkt_solve_t<LAY4>(rhs, nreq, dx, dnu);
         }
         L::fence();
-        R dsl[NB], dsu[NB], dzl[NB], dzu[NB], dpi[NB];
+        R dsl[NB], dsu[NB], dzl[NB], dzu[NB];
         R blk(0.0);
         MPMPC_UNROLL
         for (int b = 0; b < NB; ++b) {
@@ -290,7 +308,6 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
           dsu[b] = sel(bx.Um[j], -dx[j] + ru_of(b), zero);
           dzl[b] = sel(bx.Lm[j], -fma_(s.zl[j], dsl[b], rcl[b]) * isl[b], zero);
           dzu[b] = sel(bx.Um[j], -fma_(s.zu[j], dsu[b], rcu[b]) * isu[b], zero);
-          dpi[b] = sel(bx.pin[j], (rpin_of(b) + dx[j]) * ireg, zero);
           blk = max_(blk, max_(sel(bx.Lm[j], -dsl[b] * isl[b], zero), sel(bx.Um[j], -dsu[b] * isu[b], zero)));
           blk = max_(blk, max_(sel(bx.Lm[j], -dzl[b] * rcp_(s.zl[j]), zero), sel(bx.Um[j], -dzu[b] * rcp_(s.zu[j]), zero)));
         }
@@ -329,7 +346,6 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
             s.su[j] = sel(active, fma_(al, dsu[b], s.su[j]), s.su[j]);
             s.zl[j] = sel(active, fma_(al, dzl[b], s.zl[j]), s.zl[j]);
             s.zu[j] = sel(active, fma_(al, dzu[b], s.zu[j]), s.zu[j]);
-            s.pi[j] = sel(active, fma_(al, dpi[b], s.pi[j]), s.pi[j]);
           }
           s.nu[0] = sel(active, fma_(al, dnu[0], s.nu[0]), s.nu[0]);
           s.nu[1] = sel(active, fma_(al, dnu[1], s.nu[1]), s.nu[1]);
@@ -377,9 +393,8 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
     return (prim <= R(tol)) & (stat <= R(tol)) & (cv <= R(tol)) & !bad;
   }
 
-  // The active-set rounds are the register peak of the kernel (their factorisation and refinement on top of the caller's
-  // state); the interior point's iterate waits in LDS meanwhile, in the slots of the loop invariants (in registers then).
-  // 19 slots for its 21 numbers: the pin multipliers of kappa and v stay where they are.
+  // While the active-set rounds run (their factorisation and refinement on top of the caller's state), the interior point's
+  // iterate waits in LDS, in the slots of the loop invariants (in registers then): only a further attempt reads it again.
   MPMPC_HD void park_ip(const Ipm4& s) {
     L::fence();
     constexpr int JB[3] = {0, 2, 3};
@@ -392,7 +407,6 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
       L::cold_put(K_PARK + 6 + 4 * b + 0, s.sl[j]); L::cold_put(K_PARK + 6 + 4 * b + 1, s.su[j]);
       L::cold_put(K_PARK + 6 + 4 * b + 2, s.zl[j]); L::cold_put(K_PARK + 6 + 4 * b + 3, s.zu[j]);
     }
-    L::cold_put(K_PARK + 18, s.pi[0]);
     L::fence();
   }
   // ... and back, with the invariants of the loop in their slots again
@@ -408,8 +422,7 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
       s.sl[j] = L::cold_get(K_PARK + 6 + 4 * b + 0); s.su[j] = L::cold_get(K_PARK + 6 + 4 * b + 1);
       s.zl[j] = L::cold_get(K_PARK + 6 + 4 * b + 2); s.zu[j] = L::cold_get(K_PARK + 6 + 4 * b + 3);
     }
-    s.pi[0] = L::cold_get(K_PARK + 18);
-    s.sl[1] = s.su[1] = R(1.0); s.zl[1] = s.zu[1] = s.pi[1] = R(0.0);
+    s.sl[1] = s.su[1] = R(1.0); s.zl[1] = s.zu[1] = R(0.0);
     L::fence();
     MPMPC_UNROLL
     for (int e = 0; e < 4; ++e) { L::cold_put(K_PP + e, P4[e]); L::cold_put(K_QQ + e, Q4[e]); }
@@ -420,24 +433,20 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
     L::fence();
   }
 
-  MPMPC_HD void commit(const Mk& good, bool merge, const R xa[4], const R na[2], const R la[4], const R& prim, const R& stat) {
-    if (!merge) {
-      MPMPC_UNROLL
-      for (int e = 0; e < 4; ++e) { L::cold_put(C_XS + e, xa[e]); L::cold_put(C_LAM + e, la[e]); }
-      L::cold_put(C_NUS, na[0]); L::cold_put(C_NUS + 1, na[1]);
-    } else {
-      MPMPC_UNROLL
-      for (int e = 0; e < 4; ++e) {
-        L::cold_put(C_XS + e, sel(good, xa[e], L::cold_get(C_XS + e)));
-        L::cold_put(C_LAM + e, sel(good, la[e], L::cold_get(C_LAM + e)));
-      }
-      L::cold_put(C_NUS, sel(good, na[0], L::cold_get(C_NUS))); L::cold_put(C_NUS + 1, sel(good, na[1], L::cold_get(C_NUS + 1)));
-    }
+  // the certified point goes to cold storage (the working slots of the loops, which are done with)
+  MPMPC_HD void commit(const Mk& good, const R xa[4], const R na[2], const R la[4], const R& prim, const R& stat) {
     L::fence();
-    pri_res = sel(good, prim, pri_res);
-    dua_res = sel(good, stat, dua_res);
-    status = seli(good, I(MPMPC_SOLVED), status);
-    polished = seli(good, I(1), polished);
+    MPMPC_UNROLL
+    for (int e = 0; e < 4; ++e) { L::cold_put(C_XS + e, xa[e]); L::cold_put(C_LAM + e, la[e]); }
+    L::cold_put(C_NUS, na[0]); L::cold_put(C_NUS + 1, na[1]);
+    L::fence();
+    // (the residuals of the certificate wait for the store in cold slots as well - behind the rows the store stages)
+    const R zero(0.0);
+    L::cold_put(S_RES, sel(good, prim, zero));
+    L::cold_put(S_RES + 1, sel(good, stat, zero));
+    L::fence();
+    status = seli(good, I(MPMPC_SOLVED), I(MPMPC_UNSOLVED));
+    polished = seli(good, I(1), I(0));
   }
 
   // ================================================================================ the solve
@@ -451,11 +460,10 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
     iters = I(1);
     ipm_iters = I(0);
     polished = I(0);
-    pri_res = dua_res = zero;
     this->act_bits = I(0);
+    L::cold_put(S_RES, zero); L::cold_put(S_RES + 1, zero);
     Mk todo = solvable;
     if (L::wany(todo)) {
-      bool committed = false;
       Box4 b4;
       {
         const R lo_s[4] = {L::cold_get(K_LO0), R(-INFTY), L::cold_get(K_LO2), L::cold_get(K_LO3)};
@@ -483,24 +491,24 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
           for (int e = 0; e < 4; ++e) rd0 = max_(rd0, sel(val[e], abs_(Q4[e]), zero));
           mu0 = max_(mu0, (R(st.ipm_start_dual) * ths) * L::gmax(rd0));
         }
+        // (the loop's invariants go to their slots first: cost and offsets are not needed in registers before the rounds)
+        MPMPC_UNROLL
+        for (int e = 0; e < 4; ++e) { L::cold_put(K_PP + e, P4[e]); L::cold_put(K_QQ + e, Q4[e]); }
+        L::cold_put(K_LEQ, leq[0]); L::cold_put(K_LEQ + 1, leq[1]);
+        L::fence();
         MPMPC_UNROLL
         for (int e = 0; e < 4; ++e) {
-          const R fl = ths / L::cold_get(C_G + e);
-          si.x[e] = zero;
+          const R fl = ths * rcp_(L::cold_get(C_G + e));
+          si.x[e] = sel(b4.pin[e], b4.lo[e], zero);          // (a pinned entry sits on its value from the start: ipm4)
           si.sl[e] = sel(b4.Lm[e], max_(-b4.lo[e], fl), one);
           si.su[e] = sel(b4.Um[e], max_(b4.hi[e], fl), one);
-          si.zl[e] = sel(b4.Lm[e], mu0 / si.sl[e], zero);
-          si.zu[e] = sel(b4.Um[e], mu0 / si.su[e], zero);
-          si.pi[e] = zero;
+          si.zl[e] = sel(b4.Lm[e], mu0 * rcp_(si.sl[e]), zero);
+          si.zu[e] = sel(b4.Um[e], mu0 * rcp_(si.su[e]), zero);
           si.tL[e] = b4.Lm[e] & (si.zl[e] > si.sl[e]);
           si.tU[e] = b4.Um[e] & (si.zu[e] > si.su[e]);
         }
         si.nu[0] = si.nu[1] = zero;
       }
-      MPMPC_UNROLL
-      for (int e = 0; e < 4; ++e) { L::cold_put(K_PP + e, P4[e]); L::cold_put(K_QQ + e, Q4[e]); }
-      L::cold_put(K_LEQ, leq[0]); L::cold_put(K_LEQ + 1, leq[1]);
-      L::fence();
       SolverParams sc = st;
       sc.ipm_max_iter = st.ipm_max_iter < RN_IPM_CAP ? st.ipm_max_iter : RN_IPM_CAP;
       double tol = st.native_ipm_tol;
@@ -531,17 +539,18 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
         const Mk cert = certificate4(b4, P4, Q4, xa, na, la, st.cert_tol, prim, stat);
         MPMPC_TICK_END(6);
         const Mk good = todo & conv & okm & cert;
-        commit(good, committed, xa, na, la, prim, stat);
-        committed = true;
         todo = todo & conv & !good;          // a diverged interior-point run is not retried
-        if (!L::wany(todo)) break;
+        if (!L::wany(todo)) {
+          // (one instance per wave: the attempts end here, certified or not - only now do the working slots take the point)
+          commit(good, xa, na, la, prim, stat);
+          break;
+        }
         unpark_ip(si, b4);
         tol *= RN_RETRY;
       }
     }
-    // empty box: infeasible, zero ray, the width of the gap in resid[0]
+    // empty box: infeasible, zero ray, the width of the gap in resid[0] (store)
     status = seli(empty, I(MPMPC_PRIMAL_INFEASIBLE), status);
-    pri_res = sel(empty, L::cold_get(C_GAP), pri_res);
   }
 
   // ================================================================================ output
@@ -551,6 +560,8 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
                       double* resid, double* y) const {
     const int n = 5 * N + 3, m = 8 * N + 6;
     const R zero(0.0);
+    // (the lane masks of the output are formed again from (inst, k) rather than carried through the solve)
+    const Mk live = inst < n_inst, vx = live & within_(k, 0, N), vu = live & within_(k, 0, N - 1), first = (k == 0), term = live & (k == N);
     const Mk ok = live & (status == MPMPC_SOLVED);
     const R cinv = R(1.0) / L::cold_get(C_C);
     R D4[4];
@@ -598,7 +609,13 @@ struct ReducedTSolver : Solver<L, false, true, false, CR> {
     }
     if (st_out) L::storei(st_out, inst, lead, status);
     if (it_out) { L::storei(it_out, inst * 2, lead, iters); L::storei(it_out, inst * 2 + 1, lead, ipm_iters); }
-    if (resid) { L::store(resid, inst * 2, lead, pri_res); L::store(resid, inst * 2 + 1, lead, dua_res); }
+    if (resid) {
+      // (one instance per wave: the rows staged above end below slot 7 - 8 N + 6 <= 510 doubles - and these slots lie behind)
+      L::fence();
+      const R res0 = L::cold_get(S_RES), res1 = L::cold_get(S_RES + 1), gap = L::cold_get(C_GAP);
+      L::store(resid, inst * 2, lead, sel(status == MPMPC_PRIMAL_INFEASIBLE, gap, res0));
+      L::store(resid, inst * 2 + 1, lead, res1);
+    }
   }
 };
 

@@ -95,12 +95,11 @@ static void solve_rnt(const mpmpc_config* cfg, const mpmpc_settings* st, const d
 }
 static int solve_rnt_g(int G, const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
                        int* status, int* iters, double* resid, double* y, int* tail) {
-  const int C = lane_split(G, cfg->N);
-  if (G == 64 && C == 16) solve_rnt<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
-  else if (G == 64) solve_rnt<64, 32>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
-  else if (G == 32) solve_rnt<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
-  else if (G == 16) solve_rnt<16, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
-  else return -1;
+  const int C = lane_split(64, cfg->N);
+  // (one instance per wave whatever packing the caller asked for: the launcher does the same)
+  (void)G;
+  if (C == 16 && lane_split(64, cfg->N) == 16) solve_rnt<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
+  else solve_rnt<64, 32>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
   return 0;
 }
 static int solve_rn_g(int G, const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
