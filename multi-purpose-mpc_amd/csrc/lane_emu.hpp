@@ -148,6 +148,13 @@ struct LaneEmu {
   template <int D>
   static VB cr_elim() { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (((i % 16) + D + 1) & (2 * D - 1)) == 0; return r; }
 
+  // row-pair exchanges and lane roles of the 32-lane chains' cyclic reduction (see lane_gpu.hpp)
+  static VD from_even_row(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i & ~16]; return r; }
+  static VD from_odd_row(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i | 16]; return r; }
+  static VD bcast15(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (i & 16) ? a.v[(i & ~31) | 15] : 0.0; return r; }
+  static VB cr_low15() { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (i & 31) == 15; return r; }
+  static VB cr_special() { VB r; for (int i = 0; i < EMU_W; ++i) { const int p = i & 15; r.v[i] = (i & 16) != 0 && ((p & (p + 1)) == 0) && p != 15; } return r; }
+
   // half-wave exchange (see lane_gpu.hpp)
   static VD from_upper(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i | 32]; return r; }
   static VD from_lower(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i & 31]; return r; }

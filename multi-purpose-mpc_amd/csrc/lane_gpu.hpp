@@ -148,6 +148,33 @@ struct LaneGpu {
   template <int D>
   static __device__ __forceinline__ bool cr_elim() { return (((threadIdx.x & 15) + D + 1) & (2 * D - 1)) == 0; }
 
+  // ---- row-pair exchanges of the 32-lane chains' cyclic reduction (a chain is two rows of 16 lanes: rows 0|1, rows 2|3)
+  // from_odd_row(a): every lane gets a of the same position in the ODD row of its pair; from_even_row(a): ... in the EVEN
+  // row.  v_permlane16_swap on (a, a) produces both at once, one instruction per dword.
+  static __device__ __forceinline__ double from_even_row(double a) {
+    auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(a), false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(a), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]);
+  }
+  static __device__ __forceinline__ double from_odd_row(double a) {
+    auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(a), false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(a), false, false);
+    return __hiloint2double((int)hi[1], (int)lo[1]);
+  }
+  // bcast15(a): the lanes of the odd rows get a of lane 15 of the row below (DPP row_bcast:15, rows 1 and 3), all others 0
+  static __device__ __forceinline__ double bcast15(double a) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(a), 0x142, 0xA, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(a), 0x142, 0xA, 0xf, false);
+    return __hiloint2double(hi, lo);
+  }
+  // lane roles of that scheme: the first row's survivor of each chain (position 15 of rows 0 and 2), and the lanes of the
+  // second rows whose lower neighbour, at the level that eliminates them, is that survivor (positions 0, 1, 3, 7 of rows 1, 3)
+  static __device__ __forceinline__ bool cr_low15() { return (threadIdx.x & 31) == 15; }
+  static __device__ __forceinline__ bool cr_special() {
+    const int p = threadIdx.x & 15;
+    return (threadIdx.x & 16) != 0 && ((p & (p + 1)) == 0) && p != 15;      // p = 2^m - 1: 0, 1, 3, 7
+  }
+
   // ---- half-wave exchange (G = 64, N + 1 <= 32: lanes 32..63 carry the inputs of the stage on lane - 32)
   // from_upper(a): every lane gets a of lane | 32;  from_lower(a): every lane gets a of lane & 31.
   // v_permlane32_swap on (a, a) produces both at once, one instruction per dword, no LDS.

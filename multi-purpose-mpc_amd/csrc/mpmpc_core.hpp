@@ -239,7 +239,8 @@ MPMPC_HOST_DEVICE inline int lane_offset(int G, int C, int N) {
 template <class L, bool FQ = false, bool RED = false, bool FREEX = false, bool CR = false, int RKS = 0>
 struct Solver {
   static_assert(!(FQ && RED), "the reduced problem needs a diagonal terminal weight");
-  static constexpr bool kCR = CR && L::split == 16;
+  static constexpr bool kCR = CR && (L::split == 16 || L::split == 32);
+  static constexpr bool kCR32 = kCR && L::split == 32;      // a chain is TWO rows of 16 lanes (see factor_cr2)
   using R = typename L::real;
   using Mk = typename L::mask;
   using I = typename L::ival;
@@ -1142,6 +1143,41 @@ struct Solver {
       cr_level<8>(Dg, Cm);
       MPMPC_SERIAL_END(4);
     }
+    if constexpr (kCR32) {
+      // ---- 32-lane chains: each chain is two rows.  The four levels have eliminated the interiors of all four rows; the
+      // first row's survivor X (position 15 of rows 0 / 2) is still coupled with the second row's Y (position 31 of the chain:
+      // the meeting stage / the end lane) through the fill S_YX the levels left in Y's Cm, and it has not yet received the
+      // updates of the second row's lanes that were eliminated with X as their lower neighbour (positions 0, 1, 3, 7 of rows
+      // 1 / 3, one per level - their Ua is in their Gin, and the row shift that carries a level's update stops at the row's
+      // edge):  D_X -= sum Ua'Ua, a sum over four lanes of the next row.  Then X is eliminated:  L_X L_X' = D_X,
+      // U = inv(L_X) S_XY waits in X's Gout (free: no level eliminates position 15),  D_Y -= U'U.
+      MPMPC_SERIAL_BEGIN();
+      const Mk spec = L::cr_special(), isX = L::cr_low15(), isY = is_mid | is_end;
+      R w0 = sel(spec, fma_(Gin[2], Gin[2], Gin[0] * Gin[0]), zero), w1 = sel(spec, fma_(Gin[3], Gin[2], Gin[1] * Gin[0]), zero),
+        w2 = sel(spec, fma_(Gin[3], Gin[3], Gin[1] * Gin[1]), zero);
+      // positions 0, 1, 3, 7 summed into position 0 of the row, then one lane down: position 15 of the row below
+      w0 = w0 + L::template rshl<1>(w0); w1 = w1 + L::template rshl<1>(w1); w2 = w2 + L::template rshl<1>(w2);
+      w0 = w0 + L::template rshl<3>(w0); w1 = w1 + L::template rshl<3>(w1); w2 = w2 + L::template rshl<3>(w2);
+      w0 = w0 + L::template rshl<7>(w0); w1 = w1 + L::template rshl<7>(w1); w2 = w2 + L::template rshl<7>(w2);
+      Dg[0] = Dg[0] - sel(isX, L::down(w0), zero); Dg[1] = Dg[1] - sel(isX, L::down(w1), zero); Dg[2] = Dg[2] - sel(isX, L::down(w2), zero);
+      R i00 = rsqrt_(Dg[0]);
+      const R l10 = Dg[1] * i00;
+      R i11 = rsqrt_(fma_(-l10, l10, Dg[2]));
+      R i10 = -(l10 * i00) * i11;
+      i00 = sel(isX, i00, zero); i10 = sel(isX, i10, zero); i11 = sel(isX, i11, zero);
+      Li[0] = Li[0] + i00; Li[1] = Li[1] + i10; Li[2] = Li[2] + i11;
+      R Cb[4], Ub[4], gb[4];
+      MPMPC_UNROLL
+      for (int i = 0; i < 4; ++i) Cb[i] = L::from_odd_row(Cm[i]);
+      Ub[0] = i00 * Cb[0]; Ub[1] = i00 * Cb[2];
+      Ub[2] = fma_(i11, Cb[1], i10 * Cb[0]); Ub[3] = fma_(i11, Cb[3], i10 * Cb[2]);
+      MPMPC_UNROLL
+      for (int i = 0; i < 4; ++i) { Gout[i] = Gout[i] + Ub[i]; gb[i] = sel(isY, L::from_even_row(Ub[i]), zero); }
+      Dg[0] = fma_(-gb[2], gb[2], fma_(-gb[0], gb[0], Dg[0]));
+      Dg[1] = fma_(-gb[3], gb[2], fma_(-gb[1], gb[0], Dg[1]));
+      Dg[2] = fma_(-gb[3], gb[3], fma_(-gb[1], gb[1], Dg[2]));
+      MPMPC_SERIAL_END(N + 1);
+    }
     // position 15 of each row: the end lane (row 1) is eliminated, its block M = S_{mid,end} inv(L_end)' goes to the meeting
     // stage (row 0), which is factored last.  (Chains shorter than a row: the positions without a stage carry identity-like
     // blocks and zero couplings, they factor harmlessly.)
@@ -1211,6 +1247,24 @@ struct Solver {
       cr_forward<8>(b0, b1, y0, y1);
       MPMPC_SERIAL_END(4);
     }
+    [[maybe_unused]] Mk spec = L::mfalse(), isX = L::mfalse();
+    if constexpr (kCR32) {
+      // the first rows' survivors X (see factor_cr2):  b_X -= sum Ua'y over the four lanes of the next row that were eliminated
+      // against X;  y_X = inv(L_X) b_X;  b_Y -= U'y_X
+      MPMPC_SERIAL_BEGIN();
+      spec = L::cr_special(); isX = L::cr_low15();
+      R c0 = sel(spec, fma_(Gin[2], y1, Gin[0] * y0), zero), c1 = sel(spec, fma_(Gin[3], y1, Gin[1] * y0), zero);
+      c0 = c0 + L::template rshl<1>(c0); c1 = c1 + L::template rshl<1>(c1);
+      c0 = c0 + L::template rshl<3>(c0); c1 = c1 + L::template rshl<3>(c1);
+      c0 = c0 + L::template rshl<7>(c0); c1 = c1 + L::template rshl<7>(c1);
+      const R bx0 = b0 - L::down(c0), bx1 = b1 - L::down(c1);
+      const R yx0 = sel(isX, Li[0] * bx0, zero), yx1 = sel(isX, fma_(Li[2], bx1, Li[1] * bx0), zero);
+      y0 = y0 + yx0; y1 = y1 + yx1;
+      const R p0 = fma_(Gout[2], yx1, Gout[0] * yx0), p1 = fma_(Gout[3], yx1, Gout[1] * yx0);      // U'y_X on the X lanes
+      const Mk isY = is_mid | is_end;
+      b0 = b0 - sel(isY, L::from_even_row(p0), zero); b1 = b1 - sel(isY, L::from_even_row(p1), zero);
+      MPMPC_SERIAL_END(N + 1);
+    }
     // junction: y_end = inv(L_end) b_end;  b_mid -= M y_end;  y_mid = inv(L_mid) b_mid;  nu_mid = inv(L_mid)' y_mid;
     //           nu_end = inv(L_end)' (y_end - M' nu_mid)
     MPMPC_SERIAL_BEGIN();                                                           // (census: useful on the two lanes of the junction only)
@@ -1226,6 +1280,19 @@ struct Solver {
     const R ne0 = fma_(Li[1], re1, Li[0] * re0), ne1 = Li[2] * re1;
     R n0 = sel(is_mid, nm0, sel(is_end, ne0, zero)), n1 = sel(is_mid, nm1, sel(is_end, ne1, zero));
     MPMPC_SERIAL_END(N + 1);
+    if constexpr (kCR32) {
+      // nu_X = inv(L_X)' (y_X - U nu_Y);  the second rows' lanes that were eliminated against X take  -Ua nu_X  into their y
+      // before the levels run backwards (each of them is eliminated at exactly one level)
+      MPMPC_SERIAL_BEGIN();
+      const R c0 = L::from_odd_row(n0), c1 = L::from_odd_row(n1);
+      const R r0 = y0 - fma_(Gout[1], c1, Gout[0] * c0), r1 = y1 - fma_(Gout[3], c1, Gout[2] * c0);
+      n0 = sel(isX, fma_(Li[1], r1, Li[0] * r0), n0);
+      n1 = sel(isX, Li[2] * r1, n1);
+      const R x0 = L::bcast15(n0), x1 = L::bcast15(n1);
+      y0 = y0 - sel(spec, fma_(Gin[1], x1, Gin[0] * x0), zero);
+      y1 = y1 - sel(spec, fma_(Gin[3], x1, Gin[2] * x0), zero);
+      MPMPC_SERIAL_END(N + 1);
+    }
     {
       MPMPC_SERIAL_BEGIN();
       cr_backward<8>(y0, y1, n0, n1);

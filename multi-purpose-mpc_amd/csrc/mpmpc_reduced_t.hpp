@@ -224,6 +224,7 @@ struct ReducedTSolver : Solver<L, false, true, false, CR, 11> {
     auto ru_of = [&](int b) { const int j = JB[b]; return sel(bx.Um[j], hi_of(b) - s.x[j] - s.su[j], zero); };
     for (int it = 0; it <= st.ipm_max_iter; ++it) {
       R mu;
+      MPMPC_TICK_BEGIN(10);
       {
         // ---- residuals -> LDS
         L::fence();
@@ -255,14 +256,17 @@ struct ReducedTSolver : Solver<L, false, true, false, CR, 11> {
         const Mk ok = (res < R(tol > 1e-11 ? tol : 1e-11)) & (mu < R(tol));
         conv = conv | (active & ok);
         active = active & !ok;
+        MPMPC_TICK_END(10);
         if (it == st.ipm_max_iter || !L::wany(active)) break;
         active = active & !(mu > R(st.ipm_diverged) * mu_min) & !((mu < R(tol * 1e-3)) & (res > R(1e-5)));
         mu_min = min_(mu_min, mu);
         if (!L::wany(active)) break;
       }
+      MPMPC_TICK_COUNT(16);
       ipm_iters = seli(active, ipm_iters + I(1), ipm_iters);
       // ---- factor (+ the Sherman-Morrison vector of this factorisation)
       R isl[NB], isu[NB], rcl[NB], rcu[NB];
+      MPMPC_TICK_BEGIN(11);
       {
         L::fence();
         R h[4];
@@ -282,6 +286,7 @@ struct ReducedTSolver : Solver<L, false, true, false, CR, 11> {
           rcl[b] = s.sl[j] * s.zl[j]; rcu[b] = s.su[j] * s.zu[j];
         }
       }
+      MPMPC_TICK_END(11);
       R alpha_aff(1.0);
       for (int pass = 0; pass < 2; ++pass) {
         R dx[4], dnu[2];
@@ -296,7 +301,9 @@ struct ReducedTSolver : Solver<L, false, true, false, CR, 11> {
                      sel(bx.Um[j], fma_(s.zu[j], ru_of(b), rcu[b]) * isu[b], zero);
           }
           nreq[0] = -L::cold_get(S_RP); nreq[1] = -L::cold_get(S_RP + 1);
+          MPMPC_TICK_BEGIN(12);
           this->template kkt_solve_t<LAY4>(rhs, nreq, dx, dnu);
+          MPMPC_TICK_END(12);
         }
         L::fence();
         R dsl[NB], dsu[NB], dzl[NB], dzu[NB];
