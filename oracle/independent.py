@@ -121,6 +121,123 @@ def solve_admm_polish(P, q, A, l, u, eps=1e-10, max_iter=400000, cert_tol=1e-8):
     return out
 
 
+def _split_rows(A, l, u):
+    """The reference's QP has A = [dynamics rows ; I] (src/MPC.py:128-147): rows with l = u are equalities E x = e, the
+    identity rows are bounds lo <= x <= hi.  -> (E, e, eq_rows, lo, hi, bound_row_of_variable)"""
+    A = np.asarray(A, float)
+    m, n = A.shape
+    single = (np.count_nonzero(A, axis=1) == 1) & (np.abs(A).max(axis=1) == 1.0) & (A.max(axis=1) == 1.0)
+    brow = np.full(n, -1)
+    for i in np.flatnonzero(single):
+        j = int(np.argmax(A[i]))
+        if brow[j] < 0:
+            brow[j] = i
+    eq_rows = np.array([i for i in range(m) if i not in set(brow[brow >= 0])], int)
+    if np.any(brow < 0) or not np.allclose(l[eq_rows], u[eq_rows]):
+        raise ValueError("not the reference's row structure [equalities ; identity]")
+    lo = np.where(l[brow] > -1e20, l[brow], -np.inf)
+    hi = np.where(u[brow] < 1e20, u[brow], np.inf)
+    return A[eq_rows], l[eq_rows].astype(float), eq_rows, lo, hi, brow
+
+
+def solve_primal_active_set(P, q, A, l, u, x_near=None, tol=1e-9, max_iter=20000):
+    """Textbook PRIMAL ACTIVE-SET method for the convex QP (Nocedal & Wright, Numerical Optimization, Alg. 16.3) in dense numpy,
+    with the null-space solve of every equality-constrained subproblem by SVD and the inertia-controlling rule for a
+    positive SEMI-definite reduced Hessian (a direction of zero curvature with a non-zero gradient is followed to the next
+    bound).  No interior point, no step indicators, no scaling, no regularisation: nothing of the device's algorithm.
+    Start: the feasible point closest (1-norm) to x_near, by HiGHS' LP solver (scipy.optimize.linprog).
+    -> dict(x, y, status (1 solved, -3 infeasible, -2 iteration limit), iters, kkt)"""
+    from scipy.optimize import linprog
+    P = _dense(P)
+    q = np.asarray(q, float)
+    l, u = np.asarray(l, float), np.asarray(u, float)
+    E, e, eq_rows, lo, hi, brow = _split_rows(A, l, u)
+    n, m = q.size, l.size
+    x0 = np.zeros(n) if x_near is None else np.asarray(x_near, float)
+    # phase 1 (LP): min sum w  s.t.  -w <= x - x0 <= w,  E x = e,  lo <= x <= hi
+    I_n = np.eye(n)
+    res = linprog(np.concatenate([np.zeros(n), np.ones(n)]), A_ub=np.block([[I_n, -I_n], [-I_n, -I_n]]), b_ub=np.concatenate([x0, -x0]),
+                  A_eq=np.hstack([E, np.zeros((E.shape[0], n))]), b_eq=e,
+                  bounds=[(a if np.isfinite(a) else None, b if np.isfinite(b) else None) for a, b in zip(lo, hi)] + [(0, None)] * n,
+                  method="highs")
+    if res.status == 2:
+        return dict(x=np.full(n, np.nan), y=np.full(m, np.nan), status=-3, iters=0, kkt=(np.nan,) * 3)
+    if res.status != 0:
+        raise RuntimeError("phase-1 LP: " + res.message)
+    x = np.clip(res.x[:n], lo, hi)
+    fixed = np.isfinite(lo) & np.isfinite(hi) & (hi - lo <= 1e-12 * np.maximum(1.0, np.abs(lo)))
+    scale = 1.0 + np.max(np.abs(x))
+    atl = np.isfinite(lo) & (x - lo <= 1e-9 * scale)
+    atu = np.isfinite(hi) & (hi - x <= 1e-9 * scale) & ~atl
+    W = atl | atu | fixed                     # working set: variables held on a bound
+    side = np.where(atu, 1, -1)               # which bound
+    x = np.where(atl | fixed, lo, np.where(atu, hi, x))
+    out_status, it = -2, 0
+    nu, ybox = np.zeros(E.shape[0]), np.zeros(n)
+    for it in range(1, max_iter + 1):
+        g = P @ x + q
+        F = ~W
+        EF = E[:, F]
+        # null space of E_F
+        if F.any():
+            Uf, sf, Vt = np.linalg.svd(EF, full_matrices=True)
+            rk = int(np.sum(sf > 1e-12 * max(1.0, sf[0]))) if sf.size else 0
+            Z = Vt[rk:].T
+        else:
+            Z = np.zeros((0, 0))
+        p = np.zeros(n)
+        ray = False
+        if Z.shape[1]:
+            H = Z.T @ P[np.ix_(F, F)] @ Z
+            r = Z.T @ g[F]
+            lam, V = np.linalg.eigh(0.5 * (H + H.T))
+            pos = lam > 1e-12 * max(1.0, lam[-1])
+            c = V.T @ r
+            flat = ~pos & (np.abs(c) > 1e-10 * (1.0 + np.abs(r).max()))
+            if flat.any():                    # zero curvature, non-zero slope: a ray of descent
+                pz = -(V[:, flat] @ c[flat])
+                ray = True
+            else:
+                pz = -(V[:, pos] @ (c[pos] / lam[pos]))
+            p[F] = Z @ pz
+        if not ray and np.max(np.abs(p)) <= 1e-11 * scale:
+            # stationary on the working set: multipliers  g + E' nu + ybox = 0,  ybox = 0 on the free variables
+            if F.any():
+                nu = np.linalg.lstsq(EF.T, -g[F], rcond=None)[0]
+            else:
+                nu = np.zeros(E.shape[0])
+            ybox = np.where(W, -(g + E.T @ nu), 0.0)
+            bad = W & ~fixed & (((side > 0) & (ybox < -tol)) | ((side < 0) & (ybox > tol)))
+            if not bad.any():
+                out_status = 1
+                break
+            j = int(np.argmax(np.where(bad, np.abs(ybox), -1.0)))      # drop the most wrongly signed bound
+            W[j] = False
+            continue
+        # longest step inside the box
+        alpha, jblk, sblk = (np.inf if ray else 1.0), -1, 0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tu = np.where(F & (p > 1e-14 * scale), (hi - x) / p, np.inf)
+            tl = np.where(F & (p < -1e-14 * scale), (lo - x) / p, np.inf)
+        ju, jl = int(np.argmin(tu)), int(np.argmin(tl))
+        if tu[ju] < alpha:
+            alpha, jblk, sblk = max(tu[ju], 0.0), ju, 1
+        if tl[jl] < alpha:
+            alpha, jblk, sblk = max(tl[jl], 0.0), jl, -1
+        if not np.isfinite(alpha):
+            raise RuntimeError("the QP is unbounded below along a ray")
+        x = x + alpha * p
+        if jblk >= 0:
+            W[jblk] = True
+            side[jblk] = sblk
+            x[jblk] = hi[jblk] if sblk > 0 else lo[jblk]
+        scale = 1.0 + np.max(np.abs(x))
+    y = np.zeros(m)
+    y[eq_rows] = nu
+    y[brow] = ybox
+    return dict(x=x, y=y, status=out_status, iters=it, kkt=kkt_residuals(P, q, A, l, u, x, y))
+
+
 def highs_solution(P, q, A, l, u, time_limit=10.0):
     """(x, objective) of the QP according to scipy's bundled HiGHS, or (None, nan)."""
     try:

@@ -4,7 +4,9 @@ independent leg of the oracle reaches - oracle/independent.py: restated OSQP ADM
 polish; no interior point, no step indicators, no active-set rounds, no phase 1: nothing of the device's algorithm -
 with its own KKT residuals, and what scipy's bundled HiGHS returns for the same QP (point and objective).
 
-    python tests/golden/make_g8.py [workers]          (system python; needs no reference and no GPU; ~10 min on 8 cores)
+    python tests/golden/make_g8.py [workers] [names]  (system python; needs no reference and no GPU; ~10 min on 8 cores;
+                                                       names: comma-separated subset, e.g. cfg3,g4_N50 - round 4 regenerated
+                                                       exactly these two, with the primal active-set method, see one_active_set)
 
 Writes tests/golden/g8_independent_{g4_N3,g4_N10,g4_N30,g4_N50,cfg2,cfg3,cfg4}.npz.  The tests compare the DEVICE with
 these files (tests/test_gpu_parity.py, tests/test_emul_parity.py); nothing here may be touched by a device commit."""
@@ -22,6 +24,20 @@ import independent as I  # noqa: E402
 import mpc_np as M       # noqa: E402
 
 
+def one_active_set(args):
+    """N = 50 (round 4): the restated ADMM does not reach 1e-10 within 10^6 iterations on most of these
+    QPs, so ONE polish of its iterate certified only 82 / 128 (cfg3) and 32 / 64 (g4_N50).  These two files come from the
+    independent leg's textbook primal active-set method instead (oracle/independent.py:solve_primal_active_set), started at the
+    feasible point nearest to a cheap ADMM iterate (eps = 1e-5, at most 20 000 iterations)."""
+    import oracle_c as OC
+    Pd, q, A, l, u = args
+    st = OC.settings(polish=0, early_polish=0, phase1=0, eps_abs=1e-5, eps_rel=1e-5, max_iter=20000)
+    xa, ya, info = OC.solve(np.diag(Pd), q, A, l, u, st)
+    r = I.solve_primal_active_set(Pd, q, A, l, u, x_near=xa if np.all(np.isfinite(xa)) else None)
+    ok = r["status"] == 1 and max(r["kkt"]) <= 1e-8
+    return (r["x"], r["status"], int(info.iters), int(ok), np.array(r["kkt"]), np.full(q.size, np.nan), np.nan)
+
+
 def one(args):
     Pd, q, A, l, u = args
     r = I.solve_admm_polish(Pd, q, A, l, u, max_iter=1000000)
@@ -31,13 +47,22 @@ def one(args):
     return (r["x"], r["status"], r["admm_iters"], r["polished"], np.array(r["kkt"]), hx if hx is not None else np.full(q.size, np.nan), ho)
 
 
+ACTIVE_SET = ("g4_N50", "cfg3")          # the files produced by the primal active-set method
+ONLY = None                              # names to (re)generate; None = all
+
+
 def run(name, qps, pool, meta):
-    res = pool.map(one, qps, chunksize=1)
+    if ONLY is not None and name not in ONLY:
+        return
+    res = pool.map(one_active_set if name in ACTIVE_SET else one, qps, chunksize=1)
     X = np.array([r[0] for r in res])
     st = np.array([r[1] for r in res], np.int32)
     out = dict(x=X, status=st, admm_iters=np.array([r[2] for r in res], np.int32), polished=np.array([r[3] for r in res], np.int32),
                kkt=np.array([r[4] for r in res]), x_highs=np.array([r[5] for r in res]), obj_highs=np.array([r[6] for r in res]), **meta,
-               note=np.array(["oracle/independent.py: restated OSQP ADMM to 1e-10 (max 1e6 iterations) + ONE stock polish; polished = 1: the "
+               note=np.array(["oracle/independent.py: textbook primal active-set method (solve_primal_active_set) from the feasible point nearest "
+                              "to a restated-OSQP iterate at 1e-5; polished = 1: its point passed the KKT test at 1e-8; admm_iters: iterations of "
+                              "that start; no HiGHS at this horizon" if name in ACTIVE_SET else
+                              "oracle/independent.py: restated OSQP ADMM to 1e-10 (max 1e6 iterations) + ONE stock polish; polished = 1: the "
                               "polished point passed the KKT test at 1e-8 and is stored, else the ADMM iterate is; HiGHS: scipy's bundled QP solver"]))
     np.savez_compressed(os.path.join(HERE, "g8_independent_%s.npz" % name), **out)
     ok = st > 0
@@ -49,7 +74,10 @@ def run(name, qps, pool, meta):
 
 
 def main():
+    global ONLY
     workers = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    if len(sys.argv) > 2:
+        ONLY = tuple(sys.argv[2].split(","))
     with mp.Pool(workers) as pool:
         for N in (3, 10, 30, 50):
             g = np.load(os.path.join(HERE, "g4_assembly_N%d.npz" % N))
