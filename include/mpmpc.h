@@ -257,8 +257,10 @@ int mpmpc_solve(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x
 int mpmpc_upload(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x0,
                  const double* cc_prev, const double* lb, const double* ub);
 /* The outputs of a resident launch are defined after the next mpmpc_sync / mpmpc_download on the handle (the only ways to
- * read them), and only for the LAST launch before it: launches share the handle's output block.  The library uses that
- * freedom: the second kernel of a launch (the tail: instances the first kernel could not certify, usually none) is not
+ * read them), and only for the LAST launch before it.  Resident launches are double-buffered inside the handle (two
+ * streams, two output blocks, used in turn: mpmpc_set_pipeline): launch k + 1 runs beside launch k, whose outputs stay
+ * untouched until launch k + 2; mpmpc_sync / mpmpc_download and every other call on the handle wait for both.  The
+ * library also uses the freedom the first sentence leaves: the second kernel of a launch (the tail: instances the first kernel could not certify, usually none) is not
  * enqueued while the launches whose outcome the host has seen left no tail; a launch that does leave one has it run inside
  * the next mpmpc_sync / mpmpc_download / mpmpc_upload / mpmpc_set_* call, before that call does anything else. */
 int mpmpc_solve_resident(mpmpc_handle h, int32_t B);
@@ -266,6 +268,9 @@ int mpmpc_solve_resident(mpmpc_handle h, int32_t B);
  * call (y == NULL: not stored), the closed-loop rollout never stores them.  mpmpc_download refuses a y the last launch
  * did not produce. */
 int mpmpc_set_outputs(mpmpc_handle h, int32_t want_y);
+/* Resident launches in flight: 2 (default) = double-buffered as described above; 1 = every launch on one stream and one
+ * output block, each waiting for the one before (what every other entry point does anyway). */
+int mpmpc_set_pipeline(mpmpc_handle h, int32_t depth);
 int mpmpc_sync(mpmpc_handle h);
 int mpmpc_download(mpmpc_handle h, int32_t B, double* z, double* u0, int32_t* status,
                    int32_t* iters, double* resid, double* y);
@@ -286,8 +291,12 @@ int mpmpc_solve_staged(mpmpc_handle h, int32_t B, int32_t with_rows, int32_t wan
  * call on the handle ends a begun call first. */
 int mpmpc_staged_begin(mpmpc_handle h, int32_t B, int32_t with_rows, int32_t want_z, int32_t want_y);
 int mpmpc_staged_end(mpmpc_handle h);
-/* one resident pass with HIP events around each kernel on the handle's stream (ms) */
+/* one resident pass with HIP events around each kernel on the handle's stream (ms); the launch runs alone on the chip */
 int mpmpc_solve_resident_timed(mpmpc_handle h, int32_t B, float* ms_assemble, float* ms_solve);
+/* n resident launches issued exactly as mpmpc_solve_resident issues them (double-buffered, see there), each between two
+ * HIP events on its own stream: ms_each[n] = duration of every launch with the other slot's launch beside it on the chip,
+ * *ms_span (may be NULL) = first start to last end.  What rocprofv3 --kernel-trace reports for the same loop. */
+int mpmpc_solve_resident_profile(mpmpc_handle h, int32_t B, int32_t n, float* ms_each, float* ms_span);
 
 /* ---- speed profile (K4): replaces ReferencePath.compute_speed_profile, src/reference_path.py:289-354,
  * the reference's second OSQP call site, for B paths of n + 1 waypoints at once (no handle needed):

@@ -507,6 +507,31 @@ struct mpmpc_handle_s {
   int pend_B = 0;
   bool pend_y = false;
   int *pend_cur = nullptr, *pend_next = nullptr;
+  // ---- second launch slot (double-buffered resident launches, mpmpc_solve_resident): its own stream, output block, tail
+  // lists and deferred-tail state.  The members above are those of the slot of the LAST launch; `alt` holds the other slot's,
+  // and a resident launch swaps the two before it goes out, so that launch k + 1 runs beside launch k (each on its own stream,
+  // writing its own outputs) and everything else in this file keeps working on "the last launch" unchanged.
+  struct Slot {
+    hipStream_t stream = nullptr;
+    char* out_block = nullptr;
+    double *z = nullptr, *u0 = nullptr, *resid = nullptr, *y = nullptr;
+    int *status = nullptr, *iters = nullptr;
+    int* tail = nullptr;
+    int tail_flip = 0;
+    unsigned* tail_flag = nullptr;
+    unsigned seq = 0;
+    bool tail_expect_empty = false, pend = false, tail_ran_late = false;
+    int pend_B = 0;
+    bool pend_y = false;
+    int *pend_cur = nullptr, *pend_next = nullptr;
+    bool y_valid = false;
+    bool busy = false;      // launches in flight on this slot's stream that nothing has waited for yet
+  } alt;
+  bool busy = false;        // ... the same for the slot of the last launch
+  int pipeline = 2;         // mpmpc_set_pipeline: resident launches in flight (1 = one slot only)
+  hipEvent_t ev_order = nullptr;
+  bool order_pending = false;      // asynchronous work other than resident solves is queued on `stream`: the next resident launch
+                                   // on the OTHER stream has to wait for it (uploads, closed-loop steps: they write what solves read)
   int force_lanes = 0;      // mpmpc_set_packing: 0 = chosen from the batch size
   bool resident_y = true;   // mpmpc_set_outputs: do resident launches store the multipliers y (46 % of the output bytes)?
   bool y_valid = false;     // the last solve launch stored y
@@ -515,15 +540,37 @@ struct mpmpc_handle_s {
 static int host_stage_ld(int N) { return N + 1 <= 16 ? 16 : (N + 1 <= 32 ? 32 : 64); }
 
 static int observe_tail(mpmpc_handle h);
-// first statement of every entry point that reads results or changes what a deferred tail launch would work on
-#define MPMPC_SETTLE(h)                                 \
-  do {                                                  \
-    if ((h)->staged_bytes) {                            \
-      if (int rc_ = mpmpc_staged_end(h)) return rc_;    \
-    }                                                   \
-    if ((h)->pend) {                                    \
-      if (int rc_ = observe_tail(h)) return rc_;        \
-    }                                                   \
+static void swap_slots(mpmpc_handle h) {
+  auto& a = h->alt;
+  std::swap(h->stream, a.stream); std::swap(h->out_block, a.out_block);
+  std::swap(h->z, a.z); std::swap(h->u0, a.u0); std::swap(h->resid, a.resid); std::swap(h->y, a.y);
+  std::swap(h->status, a.status); std::swap(h->iters, a.iters);
+  std::swap(h->tail, a.tail); std::swap(h->tail_flip, a.tail_flip); std::swap(h->tail_flag, a.tail_flag); std::swap(h->seq, a.seq);
+  std::swap(h->tail_expect_empty, a.tail_expect_empty); std::swap(h->pend, a.pend); std::swap(h->tail_ran_late, a.tail_ran_late);
+  std::swap(h->pend_B, a.pend_B); std::swap(h->pend_y, a.pend_y); std::swap(h->pend_cur, a.pend_cur); std::swap(h->pend_next, a.pend_next);
+  std::swap(h->y_valid, a.y_valid); std::swap(h->busy, a.busy);
+}
+// The other slot's launches are drained and its deferred tail, if any, is run (the slot of the last launch is left as it is:
+// what follows on its stream is ordered behind it anyway).
+static int settle_other_slot(mpmpc_handle h) {
+  if (!h->alt.busy && !h->alt.pend) return MPMPC_OK;
+  swap_slots(h);
+  const int rc = observe_tail(h);
+  swap_slots(h);
+  return rc;
+}
+// first statement of every entry point that reads results or changes what a launch in flight - or a deferred tail launch -
+// works on
+#define MPMPC_SETTLE(h)                                      \
+  do {                                                       \
+    if ((h)->staged_bytes) {                                 \
+      if (int rc_ = mpmpc_staged_end(h)) return rc_;         \
+    }                                                        \
+    if (int rc_ = settle_other_slot(h)) return rc_;          \
+    if ((h)->pend) {                                         \
+      if (int rc_ = observe_tail(h)) return rc_;             \
+    }                                                        \
+    (h)->order_pending = true;                               \
   } while (0)
 
 static int check_settings(const mpmpc_settings* s) {
@@ -638,6 +685,15 @@ static void lay_out(mpmpc_handle h, int B) {
   h->iters = (int*)(h->out_block + L.iters);
   h->z = (double*)(h->out_block + L.z);
   h->y = (double*)(h->out_block + L.y);
+  if (h->alt.out_block) {
+    auto& a = h->alt;
+    a.u0 = (double*)(a.out_block + L.u0);
+    a.resid = (double*)(a.out_block + L.resid);
+    a.status = (int*)(a.out_block + L.status);
+    a.iters = (int*)(a.out_block + L.iters);
+    a.z = (double*)(a.out_block + L.z);
+    a.y = (double*)(a.out_block + L.y);
+  }
   h->laid_out = B;
 }
 
@@ -650,6 +706,11 @@ int mpmpc_destroy(mpmpc_handle h) {
                   h->ro_u,  h->ro_counter, h->ro_alive, h->tail, h->ro_act, h->ro_shift};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (h->alt.out_block) (void)hipFree(h->alt.out_block);
+  if (h->alt.tail) (void)hipFree(h->alt.tail);
+  if (h->alt.tail_flag) (void)hipHostFree(h->alt.tail_flag);
+  if (h->alt.stream) (void)hipStreamDestroy(h->alt.stream);
+  if (h->ev_order) (void)hipEventDestroy(h->ev_order);
   if (h->stage_in) (void)hipHostFree(h->stage_in);
   if (h->stage_out) (void)hipHostFree(h->stage_out);
   if (h->tail_flag) (void)hipHostFree(h->tail_flag);
@@ -712,16 +773,25 @@ int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_
   const BlockLayout lay = block_layout(cfg->N, cfg->max_batch);
   ALLOC(h->in_block, lay.in_end);
   ALLOC(h->out_block, lay.out_end);
+  ALLOC(h->alt.out_block, lay.out_end);
   lay_out(h, cfg->max_batch);
   ALLOC(h->qp, (size_t)MPMPC_NUM_FIELDS * B * h->ld);
   ALLOC(h->tail, 2 * (B + 1));
+  ALLOC(h->alt.tail, 2 * (B + 1));
   (void)hipMemset(h->tail, 0, 2 * (B + 1) * sizeof(int));
+  (void)hipMemset(h->alt.tail, 0, 2 * (B + 1) * sizeof(int));
   if (hipHostMalloc(reinterpret_cast<void**>(&h->tail_flag), sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
     h->tail_flag = nullptr;
     mpmpc_destroy(h);
     return fail(MPMPC_E_HIP, "hipHostMalloc tail_flag");
   }
   *h->tail_flag = 0u;
+  if (hipHostMalloc(reinterpret_cast<void**>(&h->alt.tail_flag), sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
+    h->alt.tail_flag = nullptr;
+    mpmpc_destroy(h);
+    return fail(MPMPC_E_HIP, "hipHostMalloc tail_flag");
+  }
+  *h->alt.tail_flag = 0u;
 #undef ALLOC
   {
     const size_t STAGE_LIMIT = 64u << 20;
@@ -732,8 +802,10 @@ int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_
     else h->stage_out = nullptr;
   }
   hipError_t e = hipStreamCreate(&h->stream);
+  if (e == hipSuccess) e = hipStreamCreate(&h->alt.stream);
   for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming);
   if (e != hipSuccess) {
     mpmpc_destroy(h);
     return fail(MPMPC_E_HIP, std::string("stream/event creation: ") + hipGetErrorString(e));
@@ -1177,6 +1249,8 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, bo
 static int observe_tail(mpmpc_handle h) {
   HIP_TRY(hipSetDevice(h->cfg.device));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  h->busy = false;
+  h->order_pending = false;
   if (h->seq == 0) return MPMPC_OK;
   const bool left = *static_cast<volatile unsigned*>(h->tail_flag) == h->seq;
   h->tail_ran_late = false;
@@ -1192,21 +1266,47 @@ static int observe_tail(mpmpc_handle h) {
   return MPMPC_OK;
 }
 
+// Resident launches are DOUBLE-BUFFERED: launch k + 1 goes to the other slot (stream, output block, tail lists) and runs
+// beside launch k - a batch launch fills one of the two wave slots of a SIMD (B <= 1 024) or leaves SIMDs idle while its last
+// waves and its tail launch run, and the next batch takes what is idle.  The results of launch k stay where they are until
+// launch k + 2; mpmpc_download / mpmpc_sync and every other call on the handle refer to the LAST launch and wait for both.
 int mpmpc_solve_resident(mpmpc_handle h, int32_t B) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  if (h->staged_bytes) {
+    if (int rc = mpmpc_staged_end(h)) return rc;
+  }
   if (B < 1 || B > h->uploaded) return fail(MPMPC_E_STATE, "B exceeds the uploaded batch");
   HIP_TRY(hipSetDevice(h->cfg.device));
+  if (h->pipeline > 1) {
+    // what this stream still has queued that solves read (an upload, closed-loop steps) must be done before the other one starts
+    const bool order = h->order_pending;
+    if (order) HIP_TRY(hipEventRecord(h->ev_order, h->stream));
+    swap_slots(h);
+    if (order) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_order, 0));
+    h->order_pending = false;
+  }
+  h->busy = true;
   return launch_solve(h, B, false, h->resident_y);      // one launch: the assembly runs inside K2
+}
+
+int mpmpc_set_pipeline(mpmpc_handle h, int32_t depth) {
+  if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  MPMPC_SETTLE(h);
+  if (depth != 1 && depth != 2) return fail(MPMPC_E_ARG, "pipeline depth must be 1 or 2");
+  h->pipeline = depth;
+  return MPMPC_OK;
 }
 
 int mpmpc_set_outputs(mpmpc_handle h, int32_t want_y) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  MPMPC_SETTLE(h);
   h->resident_y = want_y != 0;
   return MPMPC_OK;
 }
 
 int mpmpc_solve_resident_timed(mpmpc_handle h, int32_t B, float* ms_assemble, float* ms_solve) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  MPMPC_SETTLE(h);          // (a timed launch runs alone: nothing of an earlier launch is left on the chip)
   if (B < 1 || B > h->uploaded) return fail(MPMPC_E_STATE, "B exceeds the uploaded batch");
   HIP_TRY(hipSetDevice(h->cfg.device));
   HIP_TRY(hipEventRecord(h->ev[0], h->stream));
@@ -1231,6 +1331,45 @@ int mpmpc_solve_resident_timed(mpmpc_handle h, int32_t B, float* ms_assemble, fl
   if (ms_assemble) *ms_assemble = a;
   if (ms_solve) *ms_solve = s;
   return MPMPC_OK;
+}
+
+// n resident launches exactly as mpmpc_solve_resident issues them (double-buffered unless mpmpc_set_pipeline(h, 1)), each
+// bracketed by HIP events on the stream it goes to: ms_each[i] = duration of launch i (its kernels, with whatever else is on
+// the chip beside it - the other slot's launch), *ms_span = first start to last end.  For bench.py's roofline line: rocprofv3's
+// per-kernel durations of the same loop must agree with ms_each.
+int mpmpc_solve_resident_profile(mpmpc_handle h, int32_t B, int32_t n, float* ms_each, float* ms_span) {
+  if (!h || !ms_each) return fail(MPMPC_E_ARG, "NULL argument");
+  if (n < 1 || n > 4096) return fail(MPMPC_E_ARG, "n must be in [1, 4096]");
+  MPMPC_SETTLE(h);
+  if (B < 1 || B > h->uploaded) return fail(MPMPC_E_STATE, "B exceeds the uploaded batch");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  std::vector<hipEvent_t> ev(2 * (size_t)n, nullptr);
+  int rc = MPMPC_OK;
+  for (auto& e : ev)
+    if (hipEventCreate(&e) != hipSuccess) { rc = fail(MPMPC_E_HIP, "hipEventCreate"); break; }
+  for (int i = 0; i < n && rc == MPMPC_OK; ++i) {
+    if (h->pipeline > 1) swap_slots(h);
+    h->busy = true;
+    if (hipEventRecord(ev[2 * i], h->stream) != hipSuccess) { rc = fail(MPMPC_E_HIP, "hipEventRecord"); break; }
+    rc = launch_solve(h, B, false, h->resident_y);
+    if (rc == MPMPC_OK && hipEventRecord(ev[2 * i + 1], h->stream) != hipSuccess) rc = fail(MPMPC_E_HIP, "hipEventRecord");
+  }
+  if (rc == MPMPC_OK) rc = settle_other_slot(h);
+  if (rc == MPMPC_OK) rc = observe_tail(h);
+  if (rc == MPMPC_OK) {
+    for (int i = 0; i < n; ++i)
+      if (hipEventElapsedTime(&ms_each[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess) { rc = fail(MPMPC_E_HIP, "hipEventElapsedTime"); break; }
+    if (rc == MPMPC_OK && ms_span) {
+      // (the last END is the later of the last two launches' - they run side by side)
+      float a = 0.f, b = 0.f;
+      (void)hipEventElapsedTime(&a, ev[0], ev[2 * n - 1]);
+      if (n > 1) (void)hipEventElapsedTime(&b, ev[0], ev[2 * n - 3]);
+      *ms_span = a > b ? a : b;
+    }
+  }
+  for (auto& e : ev)
+    if (e) (void)hipEventDestroy(e);
+  return rc;
 }
 
 // device scratch of mpmpc_speed_profile, kept between calls (a call is a set-up step, and without this its cost was
@@ -1303,6 +1442,7 @@ int mpmpc_speed_profile(int32_t device, int32_t B, int32_t n, const double* li, 
 int mpmpc_sync(mpmpc_handle h) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
   if (h->staged_bytes) return mpmpc_staged_end(h);
+  if (int rc = settle_other_slot(h)) return rc;
   return observe_tail(h);
 }
 
@@ -1312,6 +1452,7 @@ int mpmpc_download(mpmpc_handle h, int32_t B, double* z, double* u0, int32_t* st
   if (h->staged_bytes) {
     if (int rc = mpmpc_staged_end(h)) return rc;
   }
+  if (int rc = settle_other_slot(h)) return rc;
   if (int rc = observe_tail(h)) return rc;        // (also how the single-call path learns that its launches leave no tail)
   if (B < 1 || B > h->uploaded) return fail(MPMPC_E_STATE, "B exceeds the uploaded batch");
   if (y && !h->y_valid)
@@ -1377,8 +1518,9 @@ int mpmpc_staged_end(mpmpc_handle h) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
   if (!h->staged_bytes) return MPMPC_OK;
   const size_t out_bytes = h->staged_bytes;
-  h->staged_bytes = 0;
+  if (int rc = settle_other_slot(h)) return rc;
   if (int rc = observe_tail(h)) return rc;          // drains the stream; a launch that left a deferred tail has it run now
+  h->staged_bytes = 0;                              // (only now: an error above leaves the call begun)
   if (h->tail_ran_late) {
     HIP_TRY(hipMemcpyAsync(h->stage_out, h->out_block, out_bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));

@@ -130,6 +130,7 @@ def load_library(path: str | None = None):
     lib.mpmpc_destroy.argtypes = [h]
     lib.mpmpc_set_settings.argtypes = [h, C.POINTER(Settings)]
     lib.mpmpc_set_packing.argtypes = [h, C.c_int32]
+    lib.mpmpc_set_pipeline.argtypes = [h, C.c_int32]
     lib.mpmpc_set_path.argtypes = [h, C.c_int32, _dp, _dp, _dp]
     lib.mpmpc_set_corridor.argtypes = [h, C.c_int32, C.c_int32, _dp, _dp]
     lib.mpmpc_set_map.argtypes = [h, C.c_int32, C.c_int32, C.POINTER(C.c_int8), C.c_double, C.c_double, C.c_double]
@@ -150,6 +151,7 @@ def load_library(path: str | None = None):
     lib.mpmpc_sync.argtypes = [h]
     lib.mpmpc_download.argtypes = [h, C.c_int32, _dp, _dp, _ip, _ip, _dp, _dp]
     lib.mpmpc_solve_resident_timed.argtypes = [h, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.mpmpc_solve_resident_profile.argtypes = [h, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.mpmpc_speed_profile.argtypes = [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_double, _dp, _ip, _ip]
     _ipp, _dpp = C.POINTER(_ip), C.POINTER(_dp)
     lib.mpmpc_staging.argtypes = [h, C.c_int32, _ipp, _dpp, _dpp, _dpp, _dpp, _dpp, _dpp, _ipp, _ipp, _dpp, _dpp]
@@ -164,8 +166,8 @@ def load_library(path: str | None = None):
 EXPORTS = ["mpmpc_version", "mpmpc_last_error", "mpmpc_device_count", "mpmpc_default_settings",
            "mpmpc_create", "mpmpc_destroy", "mpmpc_set_settings", "mpmpc_set_packing", "mpmpc_set_path", "mpmpc_set_corridor",
            "mpmpc_set_map", "mpmpc_set_path_geometry", "mpmpc_build_corridor", "mpmpc_rollout_init",
-           "mpmpc_rollout_step", "mpmpc_rollout_set_counters", "mpmpc_rollout_warm_start", "mpmpc_rollout_state", "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident", "mpmpc_set_outputs",
-           "mpmpc_sync", "mpmpc_download", "mpmpc_solve_resident_timed", "mpmpc_speed_profile", "mpmpc_staging",
+           "mpmpc_rollout_step", "mpmpc_rollout_set_counters", "mpmpc_rollout_warm_start", "mpmpc_rollout_state", "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident", "mpmpc_set_outputs", "mpmpc_set_pipeline",
+           "mpmpc_sync", "mpmpc_download", "mpmpc_solve_resident_timed", "mpmpc_solve_resident_profile", "mpmpc_speed_profile", "mpmpc_staging",
            "mpmpc_solve_staged", "mpmpc_staged_begin", "mpmpc_staged_end"]
 
 
@@ -365,6 +367,11 @@ class Handle:
         """resident launches store the multipliers y (default) or skip them (46 % of the output bytes)"""
         self._check(self.lib.mpmpc_set_outputs(self._h, int(bool(want_y))))
 
+    def set_pipeline(self, depth=2):
+        """resident launches in flight: 2 (default) = double-buffered inside the handle (launch k + 1 runs beside launch k,
+        whose results stay readable until launch k + 2), 1 = one stream, one output block"""
+        self._check(self.lib.mpmpc_set_pipeline(self._h, int(depth)))
+
     def sync(self):
         self._check(self.lib.mpmpc_sync(self._h))
 
@@ -377,6 +384,14 @@ class Handle:
         a, s = C.c_float(), C.c_float()
         self._check(self.lib.mpmpc_solve_resident_timed(self._h, B, C.byref(a), C.byref(s)))
         return a.value, s.value
+
+    def solve_resident_profile(self, B, n):
+        """n resident launches as solve_resident issues them (double-buffered), HIP events around each on its own stream
+        -> (durations [n] in ms, span from the first start to the last end in ms)"""
+        each = np.zeros(n, np.float32)
+        span = C.c_float()
+        self._check(self.lib.mpmpc_solve_resident_profile(self._h, B, n, each.ctypes.data_as(C.POINTER(C.c_float)), C.byref(span)))
+        return each.astype(float), span.value
 
 
 def device_count() -> int:

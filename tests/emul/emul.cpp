@@ -4,6 +4,12 @@
 // the oracle in the GPU-less authoring container.  Never loaded by the product.
 #include <cstring>
 #include <initializer_list>
+// event counters of the solver code (the phase-clock build of the library counts the same events per wave):
+// 16 interior-point iterations, 17 active-set rounds, 18 active-set KKT solves - per emulated wave
+static long long g_emu_count[32];
+#define MPMPC_TICK_BEGIN(i) ((void)0)
+#define MPMPC_TICK_END(i) ((void)0)
+#define MPMPC_TICK_COUNT(i) (++g_emu_count[i])
 #include "lane_emu.hpp"
 #include "mpmpc_core.hpp"
 #include "mpmpc_reduced.hpp"
@@ -237,6 +243,9 @@ extern "C" int emu_assemble(const mpmpc_config* cfg, int n_wp, const double* kap
 }
 
 extern "C" int emu_stage_ld(int N) { return stage_ld(N); }
+extern "C" void emu_event_counts(long long* out32, int reset) {
+  for (int i = 0; i < 32; ++i) { out32[i] = g_emu_count[i]; if (reset) g_emu_count[i] = 0; }
+}
 
 // instruction census of everything executed since the last reset (only with -DMPMPC_COUNT_OPS)
 // out7: wave instructions by class, all contexts together

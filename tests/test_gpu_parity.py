@@ -840,6 +840,96 @@ def test_deferred_tail_launch_gives_the_same_results(track):
     same(h.download(B), ref_h)
 
 
+@pytest.mark.parametrize("cfgid,B", [(2, 1024), (4, 2048), (3, 512)])
+def test_double_buffered_resident_launches_give_the_single_buffer_results(cfgid, B, track):
+    """mpmpc_solve_resident alternates between two launch slots of the handle (stream, output block, tail lists): launch k + 1
+    runs beside launch k.  Whatever the number of launches in flight and whatever came before on the handle, the results of
+    the last launch are, bit for bit, those of a handle that runs one launch at a time (mpmpc_set_pipeline(h, 1)) - through
+    tails (config 4), deferred tails, re-uploads between launches and the host-buffer call."""
+    sc = scenarios.make(cfgid, track, B=B)
+    other = scenarios.make(cfgid, track, B=B)
+    perm = np.random.default_rng(cfgid).permutation(B)
+    other.wp_id, other.x0, other.cc_prev, other.lb, other.ub = (a[perm] for a in (sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub))
+
+    def same(a, b):
+        assert np.array_equal(a.status, b.status) and np.array_equal(a.iters, b.iters)
+        assert np.array_equal(a.z, b.z) and np.array_equal(a.u0, b.u0) and np.array_equal(a.resid, b.resid) and np.array_equal(a.y, b.y)
+
+    one = _handle(track, sc.N, sc.weights, B)
+    one.set_pipeline(1)
+    ref, ref_o = [one.solve(x.wp_id, x.x0, x.cc_prev, x.lb, x.ub, want_y=True) for x in (sc, other)]
+    h = _handle(track, sc.N, sc.weights, B)
+    h.set_outputs(True)
+    for n_launch in (1, 2, 3, 6):
+        h.upload(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+        for _ in range(n_launch):
+            h.solve_resident(B)
+        same(h.download(B, want_y=True), ref)                       # (waits for both slots)
+        h.upload(other.wp_id, other.x0, other.cc_prev, other.lb, other.ub)      # the upload waits for what is in flight, too
+        for _ in range(n_launch):
+            h.solve_resident(B)
+        h.sync()
+        same(h.download(B, want_y=True), ref_o)
+    # an odd number of launches leaves the slots swapped: the host-buffer call and the staged call still see "the last launch"
+    h.upload(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    h.solve_resident(B)
+    same(h.solve(other.wp_id, other.x0, other.cc_prev, other.lb, other.ub, want_y=True), ref_o)
+    h.solve_resident(B)                                              # (the batch of the host-buffer call is resident now)
+    h.solve_resident(B)
+    same(h.download(B, want_y=True), ref_o)
+    # one launch at a time on request
+    h.set_pipeline(1)
+    h.upload(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    for _ in range(3):
+        h.solve_resident(B)
+    same(h.download(B, want_y=True), ref)
+    with pytest.raises(mpmpc.MpmpcError):
+        h.set_pipeline(3)
+    h.close()
+    one.close()
+
+
+def test_resident_launch_between_the_halves_of_a_staged_call(track):
+    """a resident (or timed) launch issued between mpmpc_staged_begin and mpmpc_staged_end ends the begun call
+    first - its deferred tail runs and its results are complete in the staging block - instead of overwriting its state."""
+    N, B = 30, 300
+    hard = scenarios.make(4, track, B=B, N=N)
+    feas = scenarios.make(2, track, B=B, N=N)
+    h = _handle(track, N, hard.weights, B, table="obstacles")
+    ref_h = h.solve(hard.wp_id, hard.x0, hard.cc_prev, hard.lb, hard.ub, want_y=True)
+    ref_f = h.solve(feas.wp_id, feas.x0, feas.cc_prev, feas.lb, feas.ub, want_y=True)
+    assert (ref_h.status == mpmpc.PRIMAL_INFEASIBLE).sum() >= 5
+    g = _handle(track, N, hard.weights, B, table="obstacles")
+    v = g.staging(B)
+
+    def fill(sc):
+        v["wp_id"][:] = sc.wp_id; v["x0"][:] = sc.x0; v["cc_prev"][:] = sc.cc_prev; v["lb"][:] = sc.lb; v["ub"][:] = sc.ub
+
+    fill(feas)
+    for _ in range(2):                                   # the handle learns "no tail": the next tail launch is deferred
+        g.solve_staged(B, want_z=True, want_y=True)
+    for launch in ("resident", "timed", "outputs"):
+        fill(hard)
+        g.staged_begin(B, want_z=True, want_y=True)      # leaves a tail whose launch was not enqueued
+        if launch == "resident":
+            g.solve_resident(B)
+        elif launch == "timed":
+            g.solve_resident_timed(B)
+        else:
+            g.set_outputs(True)
+        # the begun call has been ended by the other call: complete results, no MPMPC_UNSOLVED left behind
+        assert np.array_equal(v["status"], ref_h.status) and np.array_equal(v["z"], ref_h.z) and np.array_equal(v["y"], ref_h.y)
+        g.staged_end()                                   # (nothing left to do)
+        got = g.download(B, want_y=True)
+        assert np.array_equal(got.status, ref_h.status) and np.array_equal(got.z, ref_h.z)
+        fill(feas)
+        for _ in range(2):
+            g.solve_staged(B, want_z=True, want_y=True)
+        assert np.array_equal(v["status"], ref_f.status)
+    g.close()
+    h.close()
+
+
 def test_staged_host_path_is_the_host_buffer_path_without_its_copies(track):
     """mpmpc_staging / mpmpc_solve_staged: the caller fills the handle's page-locked staging blocks and reads the results
     there.  Same answers as mpmpc_solve, bit for bit - with corridor rows and with the corridor table, with and without z / y,
