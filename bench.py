@@ -257,6 +257,79 @@ def pmc_traffic_bytes(kernel_prefix, B, lib_version):
         return None, "profiles/r4/pmc_summary.json has no counters for this kernel at B = %d" % B
 
 
+def single_process_bench(args, real_stdout):
+    """--gpus N --single-process: the N shards of a world x B batch on N handles of THIS process (device r for shard r; no
+    torch, no process group, no collective).  A step = one resident launch on every handle; the clock stops when every
+    device is idle.  The line carries the contract's fields; parity legs and rooflines are those of the default run."""
+    import sharded
+    tr = scenarios.sim_track()
+    spec = scenarios.CONFIGS[args.config]
+    B = args.batch or spec.get("B_per_gpu", spec["B"])
+    world = args.gpus
+    n_dev = mpmpc.device_count()
+    if n_dev < 1:
+        sys.exit("bench.py: no HIP device visible")
+    if world > n_dev and not os.environ.get("MPMPC_BENCH_SHARE_DEVICE"):
+        sys.exit("bench.py: --gpus %d --single-process but %d device(s) visible (MPMPC_BENCH_SHARE_DEVICE=1 puts the handles on "
+                 "device 0 for a functional check)" % (world, n_dev))
+    sc_all = scenarios.make(args.config, tr, B=B * world)
+    N = sc_all.N
+    Q, R, QN = scenarios.WEIGHTS[sc_all.weights]
+    settings = mpmpc.default_settings()
+    hs = []
+    for r in range(world):
+        cfg = mpmpc.make_config(N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX, scenarios.AY_MAX,
+                                scenarios.CAR_LENGTH, circular=True, max_batch=B, device=r if world <= n_dev else 0)
+        h = mpmpc.Handle(cfg, settings)
+        h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+        h.set_outputs(want_y=False)
+        h.set_pipeline(args.pipeline)
+        h.upload(*sharding.shard([sc_all.wp_id, sc_all.x0, sc_all.cc_prev, sc_all.lb, sc_all.ub], world, r))
+        hs.append(h)
+
+    def step():
+        for h in hs:
+            h.solve_resident(B)
+
+    def sync():
+        for h in hs:
+            h.sync()
+    for _ in range(args.prewarm + args.warmup):
+        step()
+    dts = []
+    for _ in range(max(1, args.repeats)):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        dts.append(time.perf_counter() - t0)
+    dt = float(np.median(dts))
+    # the shards through the product class against one handle solving the whole batch (outside the timed region)
+    sh = sharded.ShardedHandles(hs)
+    got = sh.solve(sc_all.wp_id, sc_all.x0, sc_all.cc_prev, sc_all.lb, sc_all.ub)
+    cfg1 = mpmpc.make_config(N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX, scenarios.AY_MAX,
+                             scenarios.CAR_LENGTH, circular=True, max_batch=B * world, device=0)
+    h1 = mpmpc.Handle(cfg1, settings)
+    h1.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+    one = h1.solve(sc_all.wp_id, sc_all.x0, sc_all.cc_prev, sc_all.lb, sc_all.ub)
+    h1.close()
+    out = {"metric": "MPC QP solves/sec (batch, horizon N=%d)" % N, "value": world * B * args.steps / dt, "unit": "solves/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "repeats": len(dts), "ms_per_step_min": 1e3 * min(dts) / args.steps, "ms_per_step_max": 1e3 * max(dts) / args.steps,
+           "config": {"workload": "config%d: batch=%d independent poses per GPU, %s weights, N=%d; ONE process, one handle per device "
+                                  "(sharded.ShardedHandles), no process group" % (args.config, B, sc_all.weights, N),
+                      "batch_per_gpu": B, "horizon": N, "parallelism": "single-process batch-shard x%d" % world},
+           "devices": [int(h.cfg.device) for h in hs], "launches_in_flight": int(args.pipeline),
+           "gather_check": {"same_status": bool(np.array_equal(got.status, one.status)), "same_u0": bool(np.array_equal(got.u0, one.u0)),
+                            "instances": int(B * world)},
+           "library": hs[0].lib.mpmpc_version().decode()}
+    real_stdout.write(json.dumps(out) + "\n")
+    real_stdout.flush()
+    sh.close()
+
+
 def main():
     # Only the JSON line may reach stdout: libraries loaded below print banners there (RCCL its version block at
     # communicator creation).  File descriptor 1 points at stderr for the duration of the run; the line is written to
@@ -284,6 +357,9 @@ def _main(real_stdout):
     ap.add_argument("--repeats", type=int, default=25, help="the timed region of K steps is run this many times; value = median repeat")
     ap.add_argument("--pipeline", type=int, default=2, help="resident launches in flight inside the handle (mpmpc_set_pipeline): 2 or 1")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--single-process", action="store_true",
+                    help="with --gpus N: ONE process drives the N devices (one handle per device, multi-purpose-mpc_amd/sharded.py) "
+                         "instead of one rank per GPU under torch.distributed; a second way to run config 5")
     ap.add_argument("--lanes", type=int, default=0, help="force 64 / 32 / 16 lanes per instance (tuning; 0 = automatic)")
     ap.add_argument("--early-polish", type=int, default=None, help="override the early_polish solver setting")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
@@ -292,6 +368,8 @@ def _main(real_stdout):
 
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
+    if args.single_process:
+        return single_process_bench(args, real_stdout)
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not launched:
         # Start the ranks as children of this process, which has made no GPU call (never re-exec a process that has).
@@ -407,11 +485,13 @@ def _main(real_stdout):
         pair = (h, h2)
         for i in range(2 * max(args.warmup, 10)):
             pair[i & 1].solve_resident(B)
+        h.sync()
         h2.sync()
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
             pair[i & 1].solve_resident(B)
+        h.sync()                 # (both handles: ADVICE r3 - the clock used to stop after the second one's sync only)
         h2.sync()
         barrier()
         dt2 = bench_dist.max_over_ranks(dist, time.perf_counter() - t0, device=dev)
@@ -556,7 +636,7 @@ def _main(real_stdout):
             out["cpu_baseline"] = base
             # ... and the arithmetic the reference's own call performs (src/MPC.py:159,183: OSQP at its defaults, no polish,
             # no phase 1) through the same C port, on the same sample
-            out["cpu_baseline_stock"] = cpu_baseline(tr, sc_rank, seconds=6.0, stock=True)[0]
+            out["cpu_baseline_stock"], ref_stock = cpu_baseline(tr, sc_rank, seconds=6.0, stock=True)
             ns = ref["status"].size
             both = (ref["status"] == 1) & (sol.status[:ns] == 1)
             # The stock weights put no cost on the steering input, on e_psi and on t (src/simulation.py:101-111): the QP is
@@ -576,7 +656,21 @@ def _main(real_stdout):
                                                  "input); excluded from max_abs_u_minus_uref / max_abs_plan_minus_ref"}
             both = both & ~alt
             out["max_abs_u_minus_uref"] = float(np.max(du[both])) if both.any() else None
+            # Verdicts, both pairings (VERDICT r3 "weak" 5).  The device's DEFAULT returns a usable plan (status 2) for an instance
+            # infeasible by less than OSQP's own primal tolerance, like the reference's solver call does; the certified C port
+            # reports every proven infeasibility.  `status_agreement` keeps comparing those two semantics (it is < 1 exactly by
+            # the marginal instances); the like-for-like pairings are
+            #   strict:  device with phase1_accept = 0  vs  the certified port          (same semantics: must be 1.0)
+            #   default: device default, usable (status 1 / 2) or refused  vs  the port run as stock OSQP (status > 0 or not)
             out["status_agreement"] = float(np.mean(ref["status"] == sol.status[:ns]))
+            h.set_settings(mpmpc.default_settings(**dict(overrides, phase1_accept=0)))
+            strict = h.solve(wp[:ns], x0[:ns], cc[:ns], lb[:ns], ub[:ns])
+            h.set_settings(settings)
+            n2 = min(ns, ref_stock["status"].size)
+            out["status_agreement_pairings"] = {
+                "strict_device_vs_certified_port": float(np.mean(strict.status == ref["status"])),
+                "default_device_usable_vs_stock_osqp_port_usable": float(np.mean(((sol.status[:n2] == 1) | (sol.status[:n2] == 2)) == (ref_stock["status"][:n2] > 0))),
+                "marginal_instances_status_2": int(np.sum(sol.status[:ns] == 2)), "sample": int(ns), "sample_stock": int(n2)}
             # whole plan (z without the cost-free kappa_{N-1} and e_psi_N) against the certified optimum
             keep = np.ones(5 * N + 3, bool)
             keep[[3 * N + 1, 5 * N + 2]] = False

@@ -133,7 +133,12 @@ typedef struct {
                             reference drives the plan (src/MPC.py:159,183-206).  Its violated boxes are widened to 1.5 times the
                             least violation, the polish solves that problem, and the plan comes back as MPMPC_SOLVED_INACCURATE
                             with the violation in resid[0] (a usable status: no fallback step).  0: every proven infeasibility
-                            is reported as MPMPC_PRIMAL_INFEASIBLE however small the margin (batch sweeps that want the verdict). */
+                            is reported as MPMPC_PRIMAL_INFEASIBLE however small the margin (batch sweeps that want the verdict).
+                            The threshold is a PROXY of OSQP's test, not the test: max(|Ax|, |z|) is taken as the largest
+                            finite box bound (or entry of the least-violation point) of the instance, which stands for the
+                            iterate stock OSQP would stop at; a borderline instance can therefore take the other branch than
+                            stock OSQP would.  Validated on the reference's own laps (golden G6s); mpmpc.stock_settings() runs
+                            the restated OSQP itself. */
   int32_t native;        /* 1 (default): where `reduce` applies and the settings are the defaults of the early attempt
                             (early_polish = 1, ipm_start_mu > 0) the batch launches run the REDUCED-NATIVE kernels: a lane
                             never holds the 3-state problem - v in closed form at load time, own Ruiz pass / start / interior
@@ -141,7 +146,11 @@ typedef struct {
                             of t at the store - about half the registers of the general kernels, so two wavefronts share a
                             SIMD.  What they cannot certify (infeasible or very hard instances) goes to the general
                             one-instance-per-wave kernel (phase 1, full OSQP run) exactly like the tail of a packed launch.
-                            0: the general kernels only.  The closed loop's warm-started launches use the general kernels. */
+                            0: the general kernels only.  The closed loop's warm-started launches run the same kernels
+                            (template flag WARM).  Weightings with a terminal cost on the time state and none else on it
+                            (QN[2] > 0 = Q[2]: BASELINE config 3) have their own reduced-native kernels
+                            (csrc/mpmpc_reduced_t.hpp: the speeds stay in the problem, the time cost is one rank-one term;
+                            one instance per wave, cold starts). */
   double native_ipm_tol; /* interior-point tolerance of the reduced-native kernels' FIRST attempt (ipm_tol is the general
                             kernels').  The interior point only has to identify the active set - the active-set rounds
                             and the KKT certificate (cert_tol) make the answer - and on the reduced problem it has done
@@ -281,7 +290,8 @@ int mpmpc_download(mpmpc_handle h, int32_t B, double* z, double* u0, int32_t* st
  * destroyed, the layout until a call with another B), mpmpc_solve_staged runs upload + solve + download on them and returns
  * when the outputs are there: u0, status, iters, resid always, z if want_z, z and y if want_y.  with_rows = 0: lb / ub are not
  * read, the corridor table (mpmpc_set_corridor) applies.  Handles whose max_batch needs more than 64 MiB per block have no
- * staging blocks (MPMPC_E_STATE). */
+ * staging blocks (MPMPC_E_STATE).  The blocks ARE the ones mpmpc_upload / mpmpc_download / mpmpc_solve stage through: a call
+ * of those overwrites them, and mpmpc_staging itself first waits for an upload that is still leaving the input block. */
 int mpmpc_staging(mpmpc_handle h, int32_t B, int32_t** wp_id, double** x0, double** cc_prev, double** lb, double** ub,
                   double** z, double** u0, int32_t** status, int32_t** iters, double** resid, double** y);
 int mpmpc_solve_staged(mpmpc_handle h, int32_t B, int32_t with_rows, int32_t want_z, int32_t want_y);

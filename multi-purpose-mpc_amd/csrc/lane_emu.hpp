@@ -93,6 +93,7 @@ inline VI operator*(const VI& a, int b) { VI r; for (int i = 0; i < EMU_W; ++i) 
 inline VD fma_(const VD& a, const VD& b, const VD& c) { MPMPC_OP(fma); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::fma(a.v[i], b.v[i], c.v[i]); return r; }
 inline VD sqrt_(const VD& a) { MPMPC_OP(sqrt); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::sqrt(a.v[i]); return r; }
 inline VD rcp_(const VD& a) { MPMPC_OP(div); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = 1.0 / a.v[i]; return r; }
+inline VD rcp_fast_(const VD& a) { MPMPC_OP(div); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = 1.0 / a.v[i]; return r; }
 inline VD rsqrt_(const VD& a) { MPMPC_OP(sqrt); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = 1.0 / std::sqrt(a.v[i]); return r; }
 inline VD abs_(const VD& a) { VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::fabs(a.v[i]); return r; }
 inline VD max_(const VD& a, const VD& b) { MPMPC_OP(cmpsel); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = std::fmax(a.v[i], b.v[i]); return r; }

@@ -63,12 +63,31 @@ __global__ __launch_bounds__(K1_THREADS) void mpmpc_assemble_kernel(
     t.v_ref = s_vref;
     t.ds_next = s_ds;
   }
-  // grid-stride over (instance, stage) pairs, stage fastest: a wavefront writes 64 consecutive
-  // doubles of one field
-  const int total = B * ld;
+  // grid-stride over (instance, PAIR of stages), pair fastest: a thread builds the fields of stages 2j and 2j + 1 and stores
+  // them as one 16-byte word per field, so a wavefront writes 1 KiB of one field per store instruction (16-byte accesses are
+  // what the memory pipeline moves at full rate: MI355X_MICROARCH.md, 8-byte ones 0.54-0.70 x) - non-temporal: the block is
+  // written once and not read by this kernel.  (ld is 16 / 32 / 64: pairs never straddle an instance.)
+  using L = LaneGpu<64>;
+  const int half = ld / 2, total = B * half;
   for (int g = blockIdx.x * K1_THREADS + threadIdx.x; g < total; g += gridDim.x * K1_THREADS) {
-    int inst = g / ld, k = g - inst * ld;
-    assemble_lane<LaneGpu<64>>(cfg, t, B, ld, inst, k, wp_id, x0, cc, lb, ub, qp);
+    const int inst = g / half, k = 2 * (g - inst * half);
+    double f0[MPMPC_NUM_FIELDS], f1[MPMPC_NUM_FIELDS];
+    assemble_fields<L>(cfg, t, B, inst, k, wp_id, x0, cc, lb, ub, f0);
+    assemble_fields<L>(cfg, t, B, inst, k + 1, wp_id, x0, cc, lb, ub, f1);
+    const bool ok0 = k <= cfg.N, ok1 = k + 1 <= cfg.N;
+    double* base = qp + (size_t)inst * ld + k;
+    const size_t stride = (size_t)B * ld;
+    if (ok1) {
+      typedef double v2d __attribute__((ext_vector_type(2)));
+      MPMPC_UNROLL
+      for (int f = 0; f < MPMPC_NUM_FIELDS; ++f) {
+        v2d v = {f0[f], f1[f]};
+        __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(base + f * stride));
+      }
+    } else if (ok0) {
+      MPMPC_UNROLL
+      for (int f = 0; f < MPMPC_NUM_FIELDS; ++f) __builtin_nontemporal_store(f0[f], base + f * stride);
+    }
   }
 }
 
@@ -1046,6 +1065,7 @@ int mpmpc_rollout_step(mpmpc_handle h, int32_t B, int32_t n_steps) {
 
 int mpmpc_rollout_warm_start(mpmpc_handle h, int32_t enable) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  MPMPC_SETTLE(h);
   h->ro_warm = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
   return MPMPC_OK;
 }
@@ -1126,7 +1146,7 @@ int mpmpc_upload(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* 
 
 static int launch_assemble(mpmpc_handle h, int B) {
   PathTables t{h->kappa, h->v_ref, h->ds_next, h->n_wp, h->ub_tab, h->lb_tab, h->n_cols};
-  const int total = B * h->ld;
+  const int total = B * (h->ld / 2);      // one thread per pair of stages
   int blocks = (total + K1_THREADS - 1) / K1_THREADS;
   if (blocks > 2048) blocks = 2048;          // 256 CUs x 8 blocks, grid-stride beyond that
   hipLaunchKernelGGL(mpmpc_assemble_kernel, dim3(blocks), dim3(K1_THREADS), 0, h->stream, h->cfg, t, B, h->ld,
@@ -1498,6 +1518,10 @@ int mpmpc_staging(mpmpc_handle h, int32_t B, int32_t** wp_id, double** x0, doubl
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
   if (B < 1 || B > h->cfg.max_batch) return fail(MPMPC_E_ARG, "B must be in [1, max_batch]");
   if (!h->stage_in || !h->stage_out) return fail(MPMPC_E_STATE, "this handle has no staging blocks (max_batch above the staging limit)");
+  // The blocks are the ones mpmpc_upload / mpmpc_download stage through: an upload still on its way out of the input block
+  // must have left it before the caller may write there, and a begun staged call owns both blocks
+  MPMPC_SETTLE(h);
+  if (h->in_flight) { HIP_TRY(hipEventSynchronize(h->ev_in)); h->in_flight = false; }
   const BlockLayout L = block_layout(h->cfg.N, B);
   char *si = h->stage_in, *so = h->stage_out;
   if (wp_id) *wp_id = reinterpret_cast<int32_t*>(si + L.wp_id);

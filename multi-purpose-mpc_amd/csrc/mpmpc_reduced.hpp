@@ -259,8 +259,12 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
     auto lo_of = [&](int b) { return L::cold_get(b == 0 ? K_LO0 : K_LO2); };
     auto hi_of = [&](int b) { return L::cold_get(b == 0 ? K_HI0 : K_HI2); };
     // slack residuals of boxed entry b (cheap functions of the iterate and the box)
-    auto rl_of = [&](int b) { const int j = JB[b]; return sel(bx.Lm[j], s.x[j] - lo_of(b) - s.sl[j], zero); };
-    auto ru_of = [&](int b) { const int j = JB[b]; return sel(bx.Um[j], hi_of(b) - s.x[j] - s.su[j], zero); };
+    // A side without a bound (infinite, pinned entry, lane without a stage) carries a zero multiplier and - in the products
+    // that eliminate the slack steps - a zero in place of its slack reciprocal (isl / isu below): its multiplier step is then
+    // exactly zero whatever its slack residual is, and that residual (finite: the clipped infinities are 1e30) needs no mask
+    // except where it would enter a norm.  The iterates are bit for bit those of the fully masked form (Solver::ipm<LAY_RED>).
+    auto rl_of = [&](int b) { const int j = JB[b]; return s.x[j] - lo_of(b) - s.sl[j]; };
+    auto ru_of = [&](int b) { const int j = JB[b]; return hi_of(b) - s.x[j] - s.su[j]; };
     auto rpin_of = [&](int b) { const int j = JB[b]; return sel(bx.pin[j], s.x[j] - lo_of(b), zero); };
     for (int it = 0; it <= st.ipm_max_iter; ++it) {
       R mu;
@@ -279,7 +283,7 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
         MPMPC_UNROLL
         for (int b = 0; b < 2; ++b) {
           const int j = JB[b];
-          res = max_(res, sel(val[j], max_(max_(abs_(rd[j]), abs_(rpin_of(b))), max_(abs_(rl_of(b)), abs_(ru_of(b)))), zero));
+          res = max_(res, sel(val[j], max_(max_(abs_(rd[j]), abs_(rpin_of(b))), max_(sel(bx.Lm[j], abs_(rl_of(b)), zero), sel(bx.Um[j], abs_(ru_of(b)), zero))), zero));
           msum = msum + sel(bx.Lm[j], s.sl[j] * s.zl[j], zero) + sel(bx.Um[j], s.su[j] * s.zu[j], zero);
         }
         MPMPC_UNROLL
@@ -316,7 +320,7 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
         MPMPC_UNROLL
         for (int b = 0; b < 2; ++b) {
           const int j = JB[b];
-          isl[b] = rcp_(s.sl[j]); isu[b] = rcp_(s.su[j]);
+          isl[b] = sel(bx.Lm[j], rcp_(s.sl[j]), zero); isu[b] = sel(bx.Um[j], rcp_(s.su[j]), zero);
           rcl[b] = s.sl[j] * s.zl[j]; rcu[b] = s.su[j] * s.zu[j];
         }
       }
@@ -330,8 +334,8 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
           MPMPC_UNROLL
           for (int b = 0; b < 2; ++b) {
             const int j = JB[b];
-            rhs[j] = -L::cold_get(K_RD + j) - sel(bx.Lm[j], fma_(s.zl[j], rl_of(b), rcl[b]) * isl[b], zero) +
-                     sel(bx.Um[j], fma_(s.zu[j], ru_of(b), rcu[b]) * isu[b], zero) - sel(bx.pin[j], rpin_of(b) * ireg, zero);
+            rhs[j] = -L::cold_get(K_RD + j) - fma_(s.zl[j], rl_of(b), rcl[b]) * isl[b] + fma_(s.zu[j], ru_of(b), rcu[b]) * isu[b] -
+                     sel(bx.pin[j], rpin_of(b) * ireg, zero);
           }
           nreq[0] = -L::cold_get(K_RP); nreq[1] = -L::cold_get(K_RP + 1);
           this->template kkt_solve_t<LAY_RED>(rhs, nreq, dx, dnu);
@@ -343,12 +347,12 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
         MPMPC_UNROLL
         for (int b = 0; b < 2; ++b) {
           const int j = JB[b];
-          dsl[b] = sel(bx.Lm[j], dx[j] + rl_of(b), zero);
-          dsu[b] = sel(bx.Um[j], -dx[j] + ru_of(b), zero);
-          dzl[b] = sel(bx.Lm[j], -fma_(s.zl[j], dsl[b], rcl[b]) * isl[b], zero);
-          dzu[b] = sel(bx.Um[j], -fma_(s.zu[j], dsu[b], rcu[b]) * isu[b], zero);
+          dsl[b] = dx[j] + rl_of(b);
+          dsu[b] = -dx[j] + ru_of(b);
+          dzl[b] = -fma_(s.zl[j], dsl[b], rcl[b]) * isl[b];
+          dzu[b] = -fma_(s.zu[j], dsu[b], rcu[b]) * isu[b];
           dpi[b] = sel(bx.pin[j], (rpin_of(b) + dx[j]) * ireg, zero);
-          blk = max_(blk, max_(sel(bx.Lm[j], -dsl[b] * isl[b], zero), sel(bx.Um[j], -dsu[b] * isu[b], zero)));
+          blk = max_(blk, max_(-dsl[b] * isl[b], -dsu[b] * isu[b]));
           blk = max_(blk, max_(sel(bx.Lm[j], -dzl[b] * rcp_(s.zl[j]), zero), sel(bx.Um[j], -dzu[b] * rcp_(s.zu[j]), zero)));
         }
         blk = L::gmax(blk);

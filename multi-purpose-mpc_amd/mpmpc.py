@@ -183,6 +183,14 @@ class Solution:
         self.z, self.u0, self.status, self.iters, self.resid, self.y = z, u0, status, iters, resid, y
 
 
+class _StagingView(np.ndarray):
+    """ndarray view into a handle's staging block; carries a reference to the Handle that owns the memory"""
+    _owner = None
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, "_owner", None)
+
+
 class Handle:
     """One device context: controller constants, path tables, device buffers for max_batch QPs."""
 
@@ -339,7 +347,11 @@ class Handle:
         x0, cc, lb, ub, z, u0, rs, y = (pd() for _ in range(8))
         self._check(self.lib.mpmpc_staging(self._h, B, C.byref(wp), C.byref(x0), C.byref(cc), C.byref(lb), C.byref(ub), C.byref(z),
                                            C.byref(u0), C.byref(st), C.byref(it), C.byref(rs), C.byref(y)))
-        view = lambda p, shape: np.ctypeslib.as_array(p, shape=shape)
+        def view(p, shape):
+            # (the views point into the handle's page-locked blocks: they keep the Handle alive - its close() / __del__ frees them)
+            v = np.ctypeslib.as_array(p, shape=shape).view(_StagingView)
+            v._owner = self
+            return v
         return dict(wp_id=view(wp, (B,)), x0=view(x0, (B, 3)), cc_prev=view(cc, (B, 2 * N)), lb=view(lb, (B, N)), ub=view(ub, (B, N)),
                     z=view(z, (B, self.n)), u0=view(u0, (B, 2)), status=view(st, (B,)), iters=view(it, (B, 2)), resid=view(rs, (B, 2)),
                     y=view(y, (B, self.m)))

@@ -347,3 +347,23 @@ def uniqueness_count(qp, N, z, y, idx):
         good += int(c["unique"])
         worst = max(worst, c["worst"])
     return good, len(idx), worst
+
+
+def relaxed_plan_check(qp_i, N, z, y, viol):
+    """A status-2 plan (mpmpc_settings::phase1_accept: an instance infeasible by less than OSQP's own primal tolerance) is
+    returned as the optimum over boxes widened by 1.5 x the least violation.  Independent statement, plain numpy on K1's
+    stage fields: with every box relaxed to exactly what z itself uses - lo' = min(lo, z), hi' = max(hi, z) - the returned
+    (z, y) is a KKT point of that QP (oracle/independent.py:kkt_residuals), it is unique there on the compared coordinates,
+    and no box was relaxed by more than 1.5 x resid[0].  -> dict(kkt, unique, worst_relaxation / resid0)"""
+    import independent as I
+    Pd, q, A, l, u = qp_to_dense(qp_i, N)
+    Az = A @ z
+    lr, ur = np.minimum(l, Az), np.maximum(u, Az)
+    ne = 3 * (N + 1)
+    lr[:ne], ur[:ne] = l[:ne], u[:ne]                      # (the dynamics rows are not relaxed)
+    with np.errstate(invalid="ignore"):
+        relax = float(max(np.max(np.where(np.isfinite(l), l - lr, 0.0)), np.max(np.where(np.isfinite(u), ur - u, 0.0))))
+    keep, _ = I.compared_coordinates(N)
+    kkt = I.kkt_residuals(Pd, q, A, lr, ur, z, y)
+    uq = I.uniqueness_certificate(Pd, A, lr, ur, z, y, keep)
+    return dict(kkt=max(kkt), unique=bool(uq["unique"]), relaxation=relax, ratio=relax / viol if viol > 0 else np.inf)

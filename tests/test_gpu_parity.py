@@ -347,7 +347,7 @@ def test_device_against_the_independent_leg_and_uniqueness(cfgid, track):
     h.close()
     r = T.compare_with_independent(sol8, g, sc8.N)
     print("config %d against G8:" % cfgid, r)
-    assert r["compared"] >= (100 if cfgid != 3 else 30), r
+    assert r["compared"] >= (100 if cfgid != 3 else 120), r
     assert r["worst_u0"] <= 1e-6 and r["worst_plan"] <= 1e-6, r
     assert r["refused_by_device_only"] == 0, r
 
@@ -362,7 +362,7 @@ def test_device_against_the_independent_leg_on_the_reference_captures(N, track):
     sol = h.solve(g4["wp_id"].astype(np.int32), g4["x0"], g4["cc_prev"], g4["lb"], g4["ub"])
     h.close()
     r = T.compare_with_independent(sol, g, N)
-    assert r["compared"] >= (20 if N != 50 else 10), r
+    assert r["compared"] >= (20 if N != 50 else 52), r
     assert r["worst_u0"] <= 1e-6 and r["worst_plan"] <= 1e-6, r
     assert r["refused_by_device_only"] == 0 and r["refused_by_independent_only"] == 0, r
 
@@ -377,11 +377,17 @@ def test_default_path_takes_the_branch_stock_osqp_takes_on_device(N, track):
     g = np.load(M.GOLDEN + "/g6s_stock_loop_N%d.npz" % N)
     B = g["s"].size
     h = _handle(track, N, "stock", B)
-    sol = h.solve(g["wp_id"].astype(np.int32), g["x0"], g["cc_prev"], g["lb"], g["ub"])
+    sol = h.solve(g["wp_id"].astype(np.int32), g["x0"], g["cc_prev"], g["lb"], g["ub"], want_y=True)
+    qp = h.assemble(g["wp_id"].astype(np.int32), g["x0"], g["cc_prev"], g["lb"], g["ub"])
     h.close()
     usable = (sol.status == 1) | (sol.status == 2)
     assert np.array_equal(usable, g["status"] > 0), np.flatnonzero(usable != (g["status"] > 0))
     assert (sol.status == 2).sum() >= 5
+    # what a status-2 plan IS, checked without the device's code (VERDICT r3 "weak" 3): the unique KKT point of the QP whose
+    # boxes are relaxed to what the plan uses, none of them by more than 1.5 x the violation reported in resid[0]
+    for i in np.flatnonzero(sol.status == 2):
+        c = T.relaxed_plan_check(qp[:, i, :], N, sol.z[i], sol.y[i], sol.resid[i, 0])
+        assert c["kkt"] <= 1e-8 and c["unique"] and 0.0 < c["relaxation"] <= 1.5 * sol.resid[i, 0] * (1 + 1e-6) + 1e-12, (i, c)
     assert np.max(np.abs(sol.u0[usable, 0] - g["u"][usable, 0])) <= 5e-3          # speed channel: OSQP at 1e-3 has it
     hs = _handle(track, N, "stock", B, mpmpc.default_settings(**STRICT))
     strict = hs.solve(g["wp_id"].astype(np.int32), g["x0"], g["cc_prev"], g["lb"], g["ub"])
@@ -447,11 +453,19 @@ def test_full_batches_against_c_oracle(cfgid, B, track):
     ref = OC.mpc_batch(ocfg, OC.settings(), track.kappa, track.v_ref, track.ds_next, sc.wp_id, sc.x0, sc.cc_prev,
                        sc.lb, sc.ub, want_y=True)
     assert np.array_equal(sol.status, ref["status"])
-    assert np.array_equal(sol.iters[:, 0], ref["iters"][:, 0]) and np.all(sol.iters[:, 0] == 1)
+    assert np.array_equal(sol.iters[:, 0], ref["iters"][:, 0])
     both = sol.status == 1
     assert both.mean() > 0.85 and set(np.unique(sol.status)) <= {1, mpmpc.PRIMAL_INFEASIBLE}
     worst, alt = T.controls_vs_reference(qp, sc.N, sol, ref, 1e-6)
-    assert worst <= 1e-6 and alt.size <= 2, (worst, alt)      # (config 4: one weakly active corridor bound in 8 192)
+    assert worst <= 1e-6, (worst, alt)
+    # an instance whose control differs while both points carry a KKT certificate and equal objectives is excused only with
+    # a PROOF that its optimum is not a point: the uniqueness certificate must fail on the compared coordinates
+    # (VERDICT r3 "weak" 4; config 4 has had one weakly active corridor bound in 8 192 instances)
+    import independent as I
+    keep, _ = I.compared_coordinates(sc.N)
+    for i in alt:
+        Pd, q, A, l, u = T.qp_to_dense(qp[:, i, :], sc.N)
+        assert not I.uniqueness_certificate(Pd, A, l, u, sol.z[i], sol.y[i], keep)["unique"], i
     prim, stat, comp = T.kkt_batch(qp[:, both, :], sc.N, sol.z[both], sol.y[both])
     assert max(prim.max(), stat.max(), comp.max()) <= 1e-8
     inf = ~both

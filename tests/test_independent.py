@@ -43,17 +43,20 @@ def test_g5_optima_are_unique_where_they_are_compared(N):
 
 @pytest.mark.parametrize("N", [3, 10, 30, 50])
 def test_independent_leg_reaches_the_g5_optima(N):
-    """G8 (ADMM to 1e-10 + one stock polish) against G5 (the oracle that follows the device algorithm) on the QPs the
+    """G8 (ADMM to 1e-10 + one stock polish; at N = 50 the textbook primal active-set method) against G5 (the oracle that follows the device algorithm) on the QPs the
     REFERENCE assembled: the same verdicts, and the same point to 1e-8 wherever the independent leg certified its own."""
     g5 = np.load(M.GOLDEN + "/g5_solutions_N%d.npz" % N)
     g8 = T.g8("g4_N%d" % N)
     keep, u0c = I.compared_coordinates(N)
     assert np.array_equal(g8["status"] == -3, g5["status"] == -3)           # ADMM's own infeasibility verdict = the Farkas-certified one
     both = (g8["polished"] == 1) & (g5["status"] == 1)
-    assert both.sum() >= 0.9 * (g5["status"] == 1).sum() or N == 50, (both.sum(), (g5["status"] == 1).sum())
+    # (N = 50: the primal active-set method of round 4 - 52 of the 56 feasible captures; before: ADMM + one polish, 32)
+    assert both.sum() >= 0.9 * (g5["status"] == 1).sum(), (both.sum(), (g5["status"] == 1).sum())
     assert np.max(g8["kkt"][both]) <= 1e-8
     assert np.max(np.abs(g8["x"][both][:, keep] - g5["x"][both][:, keep])) <= 1e-8
-    assert np.max(np.abs(g8["x"][both][:, u0c] - g5["x"][both][:, u0c])) <= 1e-9
+    # (N = 50: the active-set method solves the UNregularised KKT system of the final working set exactly, G5's oracle a
+    #  delta = 1e-9 regularised one with refinement - along the nearly flat steering direction the two differ by 2e-9)
+    assert np.max(np.abs(g8["x"][both][:, u0c] - g5["x"][both][:, u0c])) <= (1e-9 if N != 50 else 5e-9)
 
 
 @pytest.mark.parametrize("N", [3, 10, 30])
@@ -89,7 +92,7 @@ def test_emulated_kernels_against_the_independent_leg(cfgid, emu, track):
     qp = emu.assemble(cfg, track, (sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub))
     sol, _ = emu.solve_launch(cfg, mpmpc.default_settings(), qp, G=64)
     r = T.compare_with_independent(sol, g, sc.N)
-    assert r["compared"] >= (100 if cfgid != 3 else 30), r
+    assert r["compared"] >= (100 if cfgid != 3 else 120), r
     assert r["worst_u0"] <= 1e-6 and r["worst_plan"] <= 1e-6, r
     assert r["refused_by_device_only"] == 0, r          # (status 2 plans of marginal instances are usable answers)
     solved = np.flatnonzero(sol.status == 1)[:48]
