@@ -1783,7 +1783,7 @@ struct Solver {
     R cnt(0.0);
     MPMPC_UNROLL
     for (int j = 0; j < E; ++j) if (boxed(j)) cnt = cnt + sel(bx.Lm[j], one, zero) + sel(bx.Um[j], one, zero);
-    R nb = max_(L::gsum(cnt), one);
+    const R inb = rcp_(max_(L::gsum(cnt), one));      // (its reciprocal once: the complementarity measures below are products)
     I stall(0);
     R mu_min(1e300);
     for (int it = 0; it <= st.ipm_max_iter; ++it) {
@@ -1817,7 +1817,7 @@ struct Solver {
         msum = msum + sel(bx.Lm[j], s.sl[j] * s.zl[j], zero) + sel(bx.Um[j], s.su[j] * s.zu[j], zero);
       }
       res = L::gmax(res);
-      R mu = L::gsum(msum) / nb;
+      R mu = L::gsum(msum) * inb;
       // (the residual of a converged iterate sits at ~1e-13 in double precision: the retry at ipm_tol x 1e-4 asks the
       //  complementarity for its tolerance - that is what identifies a weakly active bound - and the residual for 1e-11)
       Mk ok = (res < R(tol > 1e-11 ? tol : 1e-11)) & (mu < R(tol));
@@ -1941,7 +1941,8 @@ struct Solver {
           dzu[j] = sel(bx.Um[j], -fma_(s.zu[j], dsu[j], rcu[j]) * isu[j], zero);
           dpi[j] = sel(bx.pin[j], (rpin_of(j) + dx[j]) * ireg, zero);
           blk = max_(blk, max_(sel(bx.Lm[j], -dsl[j] * isl[j], zero), sel(bx.Um[j], -dsu[j] * isu[j], zero)));
-          blk = max_(blk, max_(sel(bx.Lm[j], -dzl[j] * rcp_(s.zl[j]), zero), sel(bx.Um[j], -dzu[j] * rcp_(s.zu[j]), zero)));
+          // (the ratios -dz / z only size the step, which keeps 0.5 % from the boundary anyway: the reciprocal's seed will do)
+          blk = max_(blk, max_(sel(bx.Lm[j], -dzl[j] * rcp_fast_(s.zl[j]), zero), sel(bx.Um[j], -dzu[j] * rcp_fast_(s.zu[j]), zero)));
         }
         blk = L::gmax(blk);
         R ratio = sel(blk > zero, rcp_(blk), R(1e300));
@@ -1953,8 +1954,8 @@ struct Solver {
             if (boxed(j))
               ms = ms + sel(bx.Lm[j], fma_(alpha_aff, dsl[j], s.sl[j]) * fma_(alpha_aff, dzl[j], s.zl[j]), zero) +
                    sel(bx.Um[j], fma_(alpha_aff, dsu[j], s.su[j]) * fma_(alpha_aff, dzu[j], s.zu[j]), zero);
-          R mu_aff = L::gsum(ms) / nb;
-          R sg = mu_aff / max_(mu, R(1e-300));
+          R mu_aff = L::gsum(ms) * inb;
+          R sg = mu_aff * rcp_(max_(mu, R(1e-300)));
           sg = sg * sg * sg;
           const R sgmu = sg * mu;
           MPMPC_UNROLL

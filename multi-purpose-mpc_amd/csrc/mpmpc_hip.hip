@@ -46,6 +46,12 @@ using namespace mpmpc;
 constexpr int K1_THREADS = 256;
 constexpr int K1_LDS_WP = 1024;   // path tables of up to this many waypoints are staged in LDS
 
+// NT: non-temporal stores.  Measured (profiles/k1_variants.sh, profiles/r4/k1_variants.txt): while the stage-blocked QP of the
+// batch fits the 256 MB Infinity Cache (B = 8 192: 69 MB) plain stores run at 52 % of the HBM peak and non-temporal ones at
+// 38 %; beyond it (B = 65 536: 550 MB) non-temporal stores and a grid of 8 192 blocks reach 58 % (plain: 57 %; with the
+// 2 048-block grid of round 3: 50 %).  Two stages per thread with 16-byte stores were measured too and are not kept (166
+// registers: 43 - 57 %).
+template <bool NT>
 __global__ __launch_bounds__(K1_THREADS) void mpmpc_assemble_kernel(
     mpmpc_config cfg, PathTables tab, int B, int ld, const int* __restrict__ wp_id, const double* __restrict__ x0,
     const double* __restrict__ cc, const double* __restrict__ lb, const double* __restrict__ ub,
@@ -63,30 +69,22 @@ __global__ __launch_bounds__(K1_THREADS) void mpmpc_assemble_kernel(
     t.v_ref = s_vref;
     t.ds_next = s_ds;
   }
-  // grid-stride over (instance, PAIR of stages), pair fastest: a thread builds the fields of stages 2j and 2j + 1 and stores
-  // them as one 16-byte word per field, so a wavefront writes 1 KiB of one field per store instruction (16-byte accesses are
-  // what the memory pipeline moves at full rate: MI355X_MICROARCH.md, 8-byte ones 0.54-0.70 x) - non-temporal: the block is
-  // written once and not read by this kernel.  (ld is 16 / 32 / 64: pairs never straddle an instance.)
+  // grid-stride over (instance, stage) pairs, stage fastest: a wavefront writes 64 consecutive
+  // doubles of one field
   using L = LaneGpu<64>;
-  const int half = ld / 2, total = B * half;
+  const int total = B * ld;
   for (int g = blockIdx.x * K1_THREADS + threadIdx.x; g < total; g += gridDim.x * K1_THREADS) {
-    const int inst = g / half, k = 2 * (g - inst * half);
-    double f0[MPMPC_NUM_FIELDS], f1[MPMPC_NUM_FIELDS];
-    assemble_fields<L>(cfg, t, B, inst, k, wp_id, x0, cc, lb, ub, f0);
-    assemble_fields<L>(cfg, t, B, inst, k + 1, wp_id, x0, cc, lb, ub, f1);
-    const bool ok0 = k <= cfg.N, ok1 = k + 1 <= cfg.N;
-    double* base = qp + (size_t)inst * ld + k;
-    const size_t stride = (size_t)B * ld;
-    if (ok1) {
-      typedef double v2d __attribute__((ext_vector_type(2)));
-      MPMPC_UNROLL
-      for (int f = 0; f < MPMPC_NUM_FIELDS; ++f) {
-        v2d v = {f0[f], f1[f]};
-        __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(base + f * stride));
+    const int inst = g / ld, k = g - inst * ld;
+    if constexpr (!NT) {
+      assemble_lane<L>(cfg, t, B, ld, inst, k, wp_id, x0, cc, lb, ub, qp);
+    } else {
+      double f0[MPMPC_NUM_FIELDS];
+      assemble_fields<L>(cfg, t, B, inst, k, wp_id, x0, cc, lb, ub, f0);
+      if (inst < B && k <= cfg.N) {
+        double* base = qp + (size_t)inst * ld + k;
+        MPMPC_UNROLL
+        for (int f = 0; f < MPMPC_NUM_FIELDS; ++f) __builtin_nontemporal_store(f0[f], base + f * ((size_t)B * ld));
       }
-    } else if (ok0) {
-      MPMPC_UNROLL
-      for (int f = 0; f < MPMPC_NUM_FIELDS; ++f) __builtin_nontemporal_store(f0[f], base + f * stride);
     }
   }
 }
@@ -1146,11 +1144,17 @@ int mpmpc_upload(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* 
 
 static int launch_assemble(mpmpc_handle h, int B) {
   PathTables t{h->kappa, h->v_ref, h->ds_next, h->n_wp, h->ub_tab, h->lb_tab, h->n_cols};
-  const int total = B * (h->ld / 2);      // one thread per pair of stages
+  const int total = B * h->ld;
   int blocks = (total + K1_THREADS - 1) / K1_THREADS;
-  if (blocks > 2048) blocks = 2048;          // 256 CUs x 8 blocks, grid-stride beyond that
-  hipLaunchKernelGGL(mpmpc_assemble_kernel, dim3(blocks), dim3(K1_THREADS), 0, h->stream, h->cfg, t, B, h->ld,
-                     h->wp_id, h->x0, h->cc, h->have_rows ? h->lb : nullptr, h->have_rows ? h->ub : nullptr, h->qp);
+  if (blocks > 8192) blocks = 8192;          // 256 CUs x 8 blocks x 4 rounds, grid-stride beyond that
+  // the QP block of the batch is written once and not read by this kernel: past the Infinity Cache (256 MB) it bypasses it
+  const bool nt = sizeof(double) * MPMPC_NUM_FIELDS * (size_t)B * h->ld > (size_t)256 << 20;
+#define K1_LAUNCH(V)                                                                                                       \
+  hipLaunchKernelGGL(mpmpc_assemble_kernel<V>, dim3(blocks), dim3(K1_THREADS), 0, h->stream, h->cfg, t, B, h->ld, h->wp_id, \
+                     h->x0, h->cc, h->have_rows ? h->lb : nullptr, h->have_rows ? h->ub : nullptr, h->qp)
+  if (nt) K1_LAUNCH(true);
+  else K1_LAUNCH(false);
+#undef K1_LAUNCH
   HIP_TRY(hipGetLastError());
   return MPMPC_OK;
 }

@@ -250,10 +250,12 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
     const R reg(st.ipm_reg), ireg(st.inv_ipm_reg), one(1.0), zero(0.0);
     constexpr int JB[2] = {0, 2};                       // the boxed entries: e_y, kappa
     Mk active = run, conv = L::mfalse();
+    // (number of bounds of the instance by ballot + bit count on the scalar unit; its reciprocal once: the complementarity
+    //  measures below are products)
     R cnt(0.0);
     MPMPC_UNROLL
-    for (int b = 0; b < 2; ++b) cnt = cnt + sel(bx.Lm[JB[b]], one, zero) + sel(bx.Um[JB[b]], one, zero);
-    const R nb = max_(L::gsum(cnt), one);
+    for (int b = 0; b < 2; ++b) cnt = cnt + L::gcount(bx.Lm[JB[b]]) + L::gcount(bx.Um[JB[b]]);
+    const R inb = rcp_(max_(cnt, one));
     I stall(0);
     R mu_min(1e300);
     auto lo_of = [&](int b) { return L::cold_get(b == 0 ? K_LO0 : K_LO2); };
@@ -290,7 +292,7 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
         for (int j = 0; j < 3; ++j) L::cold_put(K_RD + j, rd[j]);
         L::cold_put(K_RP, rp[0]); L::cold_put(K_RP + 1, rp[1]);
         res = L::gmax(res);
-        mu = L::gsum(msum) / nb;
+        mu = L::gsum(msum) * inb;
         const Mk ok = (res < R(tol > 1e-11 ? tol : 1e-11)) & (mu < R(tol));
         conv = conv | (active & ok);
         active = active & !ok;
@@ -353,7 +355,8 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
           dzu[b] = -fma_(s.zu[j], dsu[b], rcu[b]) * isu[b];
           dpi[b] = sel(bx.pin[j], (rpin_of(b) + dx[j]) * ireg, zero);
           blk = max_(blk, max_(-dsl[b] * isl[b], -dsu[b] * isu[b]));
-          blk = max_(blk, max_(sel(bx.Lm[j], -dzl[b] * rcp_(s.zl[j]), zero), sel(bx.Um[j], -dzu[b] * rcp_(s.zu[j]), zero)));
+          // (the ratios -dz / z only size the step, which keeps 0.5 % from the boundary anyway: the reciprocal's seed will do)
+          blk = max_(blk, max_(sel(bx.Lm[j], -dzl[b] * rcp_fast_(s.zl[j]), zero), sel(bx.Um[j], -dzu[b] * rcp_fast_(s.zu[j]), zero)));
         }
         blk = L::gmax(blk);
         const R ratio = sel(blk > zero, rcp_(blk), R(1e300));
@@ -366,8 +369,8 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
             ms = ms + sel(bx.Lm[j], fma_(alpha_aff, dsl[b], s.sl[j]) * fma_(alpha_aff, dzl[b], s.zl[j]), zero) +
                  sel(bx.Um[j], fma_(alpha_aff, dsu[b], s.su[j]) * fma_(alpha_aff, dzu[b], s.zu[j]), zero);
           }
-          const R mu_aff = L::gsum(ms) / nb;
-          R sg = mu_aff / max_(mu, R(1e-300));
+          const R mu_aff = L::gsum(ms) * inb;
+          R sg = mu_aff * rcp_(max_(mu, R(1e-300)));
           sg = sg * sg * sg;
           const R sgmu = sg * mu;
           MPMPC_UNROLL

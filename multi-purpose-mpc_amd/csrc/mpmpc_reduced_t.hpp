@@ -216,7 +216,7 @@ struct ReducedTSolver : Solver<L, false, true, false, CR, 11> {
     R cnt(0.0);
     MPMPC_UNROLL
     for (int b = 0; b < NB; ++b) cnt = cnt + L::gcount(bx.Lm[JB[b]]) + L::gcount(bx.Um[JB[b]]);
-    const R nb = max_(cnt, one);
+    const R inb = rcp_(max_(cnt, one));
     I stall(0);
     R mu_min(1e300);
     auto lo_of = [&](int b) { return L::cold_get(b == 0 ? K_LO0 : (b == 1 ? K_LO2 : K_LO3)); };
@@ -257,7 +257,7 @@ struct ReducedTSolver : Solver<L, false, true, false, CR, 11> {
         for (int j = 0; j < 4; ++j) L::cold_put(S_RD + j, rd[j]);
         L::cold_put(S_RP, rp[0]); L::cold_put(S_RP + 1, rp[1]);
         res = L::gmax(res);
-        mu = L::gsum(msum) / nb;
+        mu = L::gsum(msum) * inb;
         const Mk ok = (res < R(tol > 1e-11 ? tol : 1e-11)) & (mu < R(tol));
         conv = conv | (active & ok);
         active = active & !ok;
@@ -334,8 +334,8 @@ struct ReducedTSolver : Solver<L, false, true, false, CR, 11> {
             ms = ms + sel(bx.Lm[j], fma_(alpha_aff, dsl[b], s.sl[j]) * fma_(alpha_aff, dzl[b], s.zl[j]), zero) +
                  sel(bx.Um[j], fma_(alpha_aff, dsu[b], s.su[j]) * fma_(alpha_aff, dzu[b], s.zu[j]), zero);
           }
-          const R mu_aff = L::gsum(ms) / nb;
-          R sg = mu_aff / max_(mu, R(1e-300));
+          const R mu_aff = L::gsum(ms) * inb;
+          R sg = mu_aff * rcp_(max_(mu, R(1e-300)));
           sg = sg * sg * sg;
           const R sgmu = sg * mu;
           MPMPC_UNROLL

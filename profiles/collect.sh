@@ -4,15 +4,15 @@
 # Raw output lands in gpurun_out/<round>/ (scratch); profiles/summarize.py turns it into the
 # committed summaries under profiles/<round>/.
 set -u
-ROUND=${1:-r3}
+ROUND=${1:-r4}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$ROUND
 mkdir -p "$O"
 cd "$R"
-python bench.py --pipelined > "$O/bench_cfg2.json" 2> "$O/bench_cfg2.err"
-for c in 3 4 5; do python bench.py --pipelined --config $c --steps 20 --warmup 2 > "$O/bench_cfg$c.json" 2>/dev/null; done
+python bench.py > "$O/bench_cfg2.json" 2> "$O/bench_cfg2.err"
+for c in 3 4 5; do python bench.py --config $c --steps 20 --warmup 2 > "$O/bench_cfg$c.json" 2>/dev/null; done
 # the verdict semantics ADVICE r2 asked to see side by side: every proven infeasibility reported (phase1_accept = 0)
-for c in 4 5; do python bench.py --pipelined --config $c --steps 20 --warmup 2 --no-cpu --set phase1_accept=0 > "$O/bench_cfg${c}_strict.json" 2>/dev/null; done
+for c in 4 5; do python bench.py --config $c --steps 20 --warmup 2 --no-cpu --set phase1_accept=0 > "$O/bench_cfg${c}_strict.json" 2>/dev/null; done
 python bench.py --batch 65536 --steps 5 --warmup 1 --no-cpu > "$O/bench_cfg2_b65536.json" 2>/dev/null
 cd /tmp; export TMPDIR=/tmp
 prof() { out=$1; shift; rocprofv3 "$@" --output-format csv -d "$O/$out" -- python3 "$R/bench.py" ${BENCH_ARGS:-} --no-cpu > "$O/$out.json" 2>/dev/null; }

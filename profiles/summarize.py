@@ -8,7 +8,7 @@ import os
 import shutil
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r3"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r4"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O, P = os.path.join(root, "gpurun_out", rnd), os.path.join(root, "profiles", rnd)
 os.makedirs(P, exist_ok=True)
@@ -46,5 +46,39 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_fetch_b65536",
 for src, dst in (("trace_cfg4", "bench_cfg4_profiled.json"), ("trace_cfg5", "bench_cfg5_profiled.json")):
     if os.path.exists(os.path.join(O, src + ".json")):
         shutil.copy(os.path.join(O, src + ".json"), os.path.join(P, dst))
+# ---- the TIMED launches of every traced bench run: rows of the kernel trace in start order, without the
+# prewarm + warm-up launches at the head and the profile / isolated launches bench.py issues after its timed loop; per kernel the
+# average duration and, over the window, the average number of solve kernels on the chip (launches are double-buffered)
+timed = {}
+for src, wl in (("trace", "bench_cfg2"), ("trace_b65536", "bench_cfg2_b65536"), ("trace_cfg3", "bench_cfg3"), ("trace_cfg4", "bench_cfg4"),
+                ("trace_cfg5", "bench_cfg5")):
+    fs = glob.glob(os.path.join(O, src, "*", "*kernel_trace.csv"))
+    try:
+        line = json.load(open(os.path.join(O, src + ".json")))
+    except Exception:
+        continue
+    if not fs:
+        continue
+    rows = [r for r in csv.DictReader(open(max(fs, key=os.path.getmtime)))
+            if "mpmpc_reduced" in r["Kernel_Name"] or "mpmpc_solve_kernel" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    first = [r for r in rows if "mpmpc_reduced" in r["Kernel_Name"]] or rows         # one per step: the step's first kernel
+    skip, n = int(line.get("prewarm", 300)) + int(line["warmup"]), int(line["steps"]) * int(line.get("repeats", 1))
+    win = first[skip:skip + n]
+    if len(win) < n:
+        print("trace of %s too short: %d launches after %d skipped, %d expected" % (wl, len(win), skip, n))
+        continue
+    t0, t1 = int(win[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in win)
+    inside = [r for r in rows if t0 <= int(r["Start_Timestamp"]) <= t1]
+    per = collections.defaultdict(list)
+    for r in inside:
+        per[r["Kernel_Name"].split("(")[0].replace("void ", "")].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
+    busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in inside)
+    timed[wl] = {"library": line.get("library"), "steps": int(line["steps"]), "repeats": int(line.get("repeats", 1)), "launches": n,
+                 "kernels": {k: {"launches": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)} for k, v in per.items()},
+                 "streams": sorted({r["Stream_Id"] for r in inside}), "solve_kernels_in_flight_avg": busy / float(t1 - t0),
+                 "ms_per_step_in_trace": (t1 - t0) * 1e-6 / n, "ms_per_step_reported": line["ms_per_step"]}
+json.dump(timed, open(os.path.join(P, "kernel_timed.json"), "w"), indent=1)
+print("timed launches:", json.dumps(timed, indent=1)[:1500])
 json.dump(out, open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
