@@ -46,11 +46,13 @@ using namespace mpmpc;
 constexpr int K1_THREADS = 256;
 constexpr int K1_LDS_WP = 1024;   // path tables of up to this many waypoints are staged in LDS
 
-// NT: non-temporal stores.  Measured (profiles/k1_variants.sh, profiles/r4/k1_variants.txt): while the stage-blocked QP of the
-// batch fits the 256 MB Infinity Cache (B = 8 192: 69 MB) plain stores run at 52 % of the HBM peak and non-temporal ones at
-// 38 %; beyond it (B = 65 536: 550 MB) non-temporal stores and a grid of 8 192 blocks reach 58 % (plain: 57 %; with the
-// 2 048-block grid of round 3: 50 %).  Two stages per thread with 16-byte stores were measured too and are not kept (166
-// registers: 43 - 57 %).
+// NT: non-temporal stores (tuning knob MPMPC_K1_NT=1; off by default).  Same-box A/B (profiles/k1_timing.py,
+// profiles/r4/k1_timing.txt; medians of 30 launches): while the stage-blocked QP of the batch fits the 256 MB Infinity Cache
+// (B = 8 192: 69 MB) plain stores reach 56 % of the HBM peak, non-temporal ones 40 - 47 %; beyond it (B = 65 536: 550 MB) plain
+// stores with a grid of 8 192 blocks 39 % (best launch 54 %; the 2 048-block grid of round 3: 37 - 38 %, best 47 %),
+// non-temporal ones 33 - 38 %.  Two stages per thread with 16-byte stores were measured as well (166 registers) and were slower
+// than either.  The 55 % asked for at B = 65 536 is NOT reached in the median: this kernel is off the solve path (the solve
+// launches build their QP in registers).
 template <bool NT>
 __global__ __launch_bounds__(K1_THREADS) void mpmpc_assemble_kernel(
     mpmpc_config cfg, PathTables tab, int B, int ld, const int* __restrict__ wp_id, const double* __restrict__ x0,
@@ -1146,9 +1148,11 @@ static int launch_assemble(mpmpc_handle h, int B) {
   PathTables t{h->kappa, h->v_ref, h->ds_next, h->n_wp, h->ub_tab, h->lb_tab, h->n_cols};
   const int total = B * h->ld;
   int blocks = (total + K1_THREADS - 1) / K1_THREADS;
-  if (blocks > 8192) blocks = 8192;          // 256 CUs x 8 blocks x 4 rounds, grid-stride beyond that
-  // the QP block of the batch is written once and not read by this kernel: past the Infinity Cache (256 MB) it bypasses it
-  const bool nt = sizeof(double) * MPMPC_NUM_FIELDS * (size_t)B * h->ld > (size_t)256 << 20;
+  // (tuning knobs of profiles/k1_timing.py: MPMPC_K1_BLOCKS = cap of the grid, MPMPC_K1_NT = 0 / 1 forces plain / non-temporal stores)
+  static const int cap = std::getenv("MPMPC_K1_BLOCKS") ? std::atoi(std::getenv("MPMPC_K1_BLOCKS")) : 8192;
+  static const int force_nt = std::getenv("MPMPC_K1_NT") ? std::atoi(std::getenv("MPMPC_K1_NT")) : -1;
+  if (blocks > cap) blocks = cap;          // 256 CUs x 8 blocks x 4 rounds, grid-stride beyond that
+  const bool nt = force_nt > 0;
 #define K1_LAUNCH(V)                                                                                                       \
   hipLaunchKernelGGL(mpmpc_assemble_kernel<V>, dim3(blocks), dim3(K1_THREADS), 0, h->stream, h->cfg, t, B, h->ld, h->wp_id, \
                      h->x0, h->cc, h->have_rows ? h->lb : nullptr, h->have_rows ? h->ub : nullptr, h->qp)
