@@ -20,6 +20,12 @@ as a CHILD and exits with its code.  Under a launcher, WORLD_SIZE must equal --g
 """
 from __future__ import annotations
 
+import os as _os
+# Four resident launches in flight (--pipeline 4) need four hardware queues of their own: the HIP runtime's default of 4
+# (one of them taken) makes two of the handle's streams share a queue, which serialises them (profiles/r4/depth_sweep.txt).
+# Read by the runtime at its first call in this process; an operator's own setting wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import argparse
 import json
 import os
@@ -340,7 +346,7 @@ def _main(real_stdout):
                          "default command holds the launches of the timed loop only")
     ap.add_argument("--prewarm", type=int, default=300, help="untimed launches before the W warm-up steps (clock ramp)")
     ap.add_argument("--repeats", type=int, default=25, help="the timed region of K steps is run this many times; value = median repeat")
-    ap.add_argument("--pipeline", type=int, default=2, help="resident launches in flight inside the handle (mpmpc_set_pipeline): 2 or 1")
+    ap.add_argument("--pipeline", type=int, default=4, help="resident launches in flight inside the handle (mpmpc_set_pipeline): 1 .. 8")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--single-process", action="store_true",
                     help="with --gpus N: ONE process drives the N devices (one handle per device, multi-purpose-mpc_amd/sharded.py) "

@@ -266,9 +266,9 @@ int mpmpc_solve(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x
 int mpmpc_upload(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* x0,
                  const double* cc_prev, const double* lb, const double* ub);
 /* The outputs of a resident launch are defined after the next mpmpc_sync / mpmpc_download on the handle (the only ways to
- * read them), and only for the LAST launch before it.  Resident launches are double-buffered inside the handle (two
- * streams, two output blocks, used in turn: mpmpc_set_pipeline): launch k + 1 runs beside launch k, whose outputs stay
- * untouched until launch k + 2; mpmpc_sync / mpmpc_download and every other call on the handle wait for both.  The
+ * read them), and only for the LAST launch before it.  Resident launches are pipelined inside the handle (by default three
+ * launch slots - stream, output block - used in turn: mpmpc_set_pipeline): launch k + 1, k + 2 run beside launch k, whose
+ * outputs stay untouched until launch k + 3; mpmpc_sync / mpmpc_download and every other call on the handle wait for both.  The
  * library also uses the freedom the first sentence leaves: the second kernel of a launch (the tail: instances the first kernel could not certify, usually none) is not
  * enqueued while the launches whose outcome the host has seen left no tail; a launch that does leave one has it run inside
  * the next mpmpc_sync / mpmpc_download / mpmpc_upload / mpmpc_set_* call, before that call does anything else. */
@@ -277,8 +277,12 @@ int mpmpc_solve_resident(mpmpc_handle h, int32_t B);
  * call (y == NULL: not stored), the closed-loop rollout never stores them.  mpmpc_download refuses a y the last launch
  * did not produce. */
 int mpmpc_set_outputs(mpmpc_handle h, int32_t want_y);
-/* Resident launches in flight: 2 (default) = double-buffered as described above; 1 = every launch on one stream and one
- * output block, each waiting for the one before (what every other entry point does anyway). */
+/* Resident launches in flight, 1 .. 8: 3 (default) = pipelined as described above (launch k's outputs stay untouched until
+ * launch k + depth); 1 = every launch on one stream and one output block, each waiting for the one before (what every other
+ * entry point does anyway).  The HIP runtime spreads streams over GPU_MAX_HW_QUEUES hardware queues (default 4) and streams
+ * that share a queue serialise: more than 3 launches in flight pay only in a process that exported GPU_MAX_HW_QUEUES=8 (or
+ * more) before its first HIP call (bench.py does).  With depth > 1 the batch launches of the handle pack two / four instances into a wavefront from
+ * 128 / 256 instances on (instead of 1 024 / 2 048): the handle is after throughput, several launches fill the chip. */
 int mpmpc_set_pipeline(mpmpc_handle h, int32_t depth);
 int mpmpc_sync(mpmpc_handle h);
 int mpmpc_download(mpmpc_handle h, int32_t B, double* z, double* u0, int32_t* status,

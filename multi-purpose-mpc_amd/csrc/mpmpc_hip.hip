@@ -526,10 +526,11 @@ struct mpmpc_handle_s {
   int pend_B = 0;
   bool pend_y = false;
   int *pend_cur = nullptr, *pend_next = nullptr;
-  // ---- second launch slot (double-buffered resident launches, mpmpc_solve_resident): its own stream, output block, tail
-  // lists and deferred-tail state.  The members above are those of the slot of the LAST launch; `alt` holds the other slot's,
-  // and a resident launch swaps the two before it goes out, so that launch k + 1 runs beside launch k (each on its own stream,
-  // writing its own outputs) and everything else in this file keeps working on "the last launch" unchanged.
+  // ---- further launch slots (pipelined resident launches, mpmpc_solve_resident): each its own stream, output block, tail
+  // lists and deferred-tail state.  The members above are those of the slot of the LAST launch; `alt` holds the other slots',
+  // and a resident launch swaps the next one in before it goes out, so that launch k + 1 .. k + pipeline - 1 run beside launch k
+  // (each on its own stream, writing its own outputs) and everything else in this file keeps working on "the last launch"
+  // unchanged.
   struct Slot {
     hipStream_t stream = nullptr;
     char* out_block = nullptr;
@@ -545,9 +546,17 @@ struct mpmpc_handle_s {
     int *pend_cur = nullptr, *pend_next = nullptr;
     bool y_valid = false;
     bool busy = false;      // launches in flight on this slot's stream that nothing has waited for yet
-  } alt;
+  };
+  static constexpr int MAX_PIPELINE = 8;
+  Slot alt[MAX_PIPELINE - 1];      // the other slots; alt[i] exists (is allocated) for i < n_alt
+  int n_alt = 0;
+  int ring = 0;             // alt slot the next resident launch swaps with: 0 .. pipeline - 2 in turn, which takes the launches
+                            // through all `pipeline` slots round robin
   bool busy = false;        // ... the same for the slot of the last launch
-  int pipeline = 2;         // mpmpc_set_pipeline: resident launches in flight (1 = one slot only)
+  int pipeline = 3;         // mpmpc_set_pipeline: resident launches in flight (1 = one slot only).  Three by default: the HIP
+                            // runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them taken), and two
+                            // streams on one queue serialise - measured, config 2: depth 2 / 3 / 4 = 38 / 49 / 36 M solves/s with
+                            // the default, 38 / 49 / 61.5 M with GPU_MAX_HW_QUEUES=8 (profiles/r4/depth_sweep.txt)
   hipEvent_t ev_order = nullptr;
   bool order_pending = false;      // asynchronous work other than resident solves is queued on `stream`: the next resident launch
                                    // on the OTHER stream has to wait for it (uploads, closed-loop steps: they write what solves read)
@@ -559,8 +568,8 @@ struct mpmpc_handle_s {
 static int host_stage_ld(int N) { return N + 1 <= 16 ? 16 : (N + 1 <= 32 ? 32 : 64); }
 
 static int observe_tail(mpmpc_handle h);
-static void swap_slots(mpmpc_handle h) {
-  auto& a = h->alt;
+static void swap_slots(mpmpc_handle h, int i) {
+  auto& a = h->alt[i];
   std::swap(h->stream, a.stream); std::swap(h->out_block, a.out_block);
   std::swap(h->z, a.z); std::swap(h->u0, a.u0); std::swap(h->resid, a.resid); std::swap(h->y, a.y);
   std::swap(h->status, a.status); std::swap(h->iters, a.iters);
@@ -569,14 +578,17 @@ static void swap_slots(mpmpc_handle h) {
   std::swap(h->pend_B, a.pend_B); std::swap(h->pend_y, a.pend_y); std::swap(h->pend_cur, a.pend_cur); std::swap(h->pend_next, a.pend_next);
   std::swap(h->y_valid, a.y_valid); std::swap(h->busy, a.busy);
 }
-// The other slot's launches are drained and its deferred tail, if any, is run (the slot of the last launch is left as it is:
-// what follows on its stream is ordered behind it anyway).
+// The other slots' launches are drained and their deferred tails, if any, are run (the slot of the last launch is left as it
+// is: what follows on its stream is ordered behind it anyway).
 static int settle_other_slot(mpmpc_handle h) {
-  if (!h->alt.busy && !h->alt.pend) return MPMPC_OK;
-  swap_slots(h);
-  const int rc = observe_tail(h);
-  swap_slots(h);
-  return rc;
+  for (int i = 0; i < h->n_alt; ++i) {
+    if (!h->alt[i].busy && !h->alt[i].pend) continue;
+    swap_slots(h, i);
+    const int rc = observe_tail(h);
+    swap_slots(h, i);
+    if (rc) return rc;
+  }
+  return MPMPC_OK;
 }
 // first statement of every entry point that reads results or changes what a launch in flight - or a deferred tail launch -
 // works on
@@ -618,6 +630,7 @@ static int check_settings(const mpmpc_settings* s) {
   return MPMPC_OK;
 }
 
+static int grow_slots(mpmpc_handle h, int want);
 static int launch_assemble(mpmpc_handle h, int B);
 static int launch_solve(mpmpc_handle h, int B, bool closed_loop = false, bool want_y = true, bool tail_only = false);
 
@@ -704,8 +717,8 @@ static void lay_out(mpmpc_handle h, int B) {
   h->iters = (int*)(h->out_block + L.iters);
   h->z = (double*)(h->out_block + L.z);
   h->y = (double*)(h->out_block + L.y);
-  if (h->alt.out_block) {
-    auto& a = h->alt;
+  for (int i = 0; i < h->n_alt; ++i) {
+    auto& a = h->alt[i];
     a.u0 = (double*)(a.out_block + L.u0);
     a.resid = (double*)(a.out_block + L.resid);
     a.status = (int*)(a.out_block + L.status);
@@ -714,6 +727,24 @@ static void lay_out(mpmpc_handle h, int B) {
     a.y = (double*)(a.out_block + L.y);
   }
   h->laid_out = B;
+}
+
+// launch slots beyond the first: stream, output block (laid out like the first), tail lists, tail flag
+static int grow_slots(mpmpc_handle h, int want) {
+  const BlockLayout lay = block_layout(h->cfg.N, h->cfg.max_batch);
+  while (h->n_alt < want) {
+    auto& a = h->alt[h->n_alt];
+    const size_t nt = 2 * ((size_t)h->cfg.max_batch + 1);
+    if (hipMalloc((void**)&a.out_block, lay.out_end) != hipSuccess || hipMalloc((void**)&a.tail, nt * sizeof(int)) != hipSuccess ||
+        hipMemset(a.tail, 0, nt * sizeof(int)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&a.tail_flag), sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
+        hipStreamCreate(&a.stream) != hipSuccess)
+      return fail(MPMPC_E_HIP, "allocation of a launch slot failed (stream / output block / tail list)");
+    *a.tail_flag = 0u;
+    h->n_alt += 1;
+  }
+  lay_out(h, h->laid_out ? h->laid_out : h->cfg.max_batch);
+  return MPMPC_OK;
 }
 
 int mpmpc_destroy(mpmpc_handle h) {
@@ -725,10 +756,12 @@ int mpmpc_destroy(mpmpc_handle h) {
                   h->ro_u,  h->ro_counter, h->ro_alive, h->tail, h->ro_act, h->ro_shift};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  if (h->alt.out_block) (void)hipFree(h->alt.out_block);
-  if (h->alt.tail) (void)hipFree(h->alt.tail);
-  if (h->alt.tail_flag) (void)hipHostFree(h->alt.tail_flag);
-  if (h->alt.stream) (void)hipStreamDestroy(h->alt.stream);
+  for (auto& a : h->alt) {
+    if (a.out_block) (void)hipFree(a.out_block);
+    if (a.tail) (void)hipFree(a.tail);
+    if (a.tail_flag) (void)hipHostFree(a.tail_flag);
+    if (a.stream) (void)hipStreamDestroy(a.stream);
+  }
   if (h->ev_order) (void)hipEventDestroy(h->ev_order);
   if (h->stage_in) (void)hipHostFree(h->stage_in);
   if (h->stage_out) (void)hipHostFree(h->stage_out);
@@ -792,25 +825,16 @@ int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_
   const BlockLayout lay = block_layout(cfg->N, cfg->max_batch);
   ALLOC(h->in_block, lay.in_end);
   ALLOC(h->out_block, lay.out_end);
-  ALLOC(h->alt.out_block, lay.out_end);
   lay_out(h, cfg->max_batch);
   ALLOC(h->qp, (size_t)MPMPC_NUM_FIELDS * B * h->ld);
   ALLOC(h->tail, 2 * (B + 1));
-  ALLOC(h->alt.tail, 2 * (B + 1));
   (void)hipMemset(h->tail, 0, 2 * (B + 1) * sizeof(int));
-  (void)hipMemset(h->alt.tail, 0, 2 * (B + 1) * sizeof(int));
   if (hipHostMalloc(reinterpret_cast<void**>(&h->tail_flag), sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
     h->tail_flag = nullptr;
     mpmpc_destroy(h);
     return fail(MPMPC_E_HIP, "hipHostMalloc tail_flag");
   }
   *h->tail_flag = 0u;
-  if (hipHostMalloc(reinterpret_cast<void**>(&h->alt.tail_flag), sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
-    h->alt.tail_flag = nullptr;
-    mpmpc_destroy(h);
-    return fail(MPMPC_E_HIP, "hipHostMalloc tail_flag");
-  }
-  *h->alt.tail_flag = 0u;
 #undef ALLOC
   {
     const size_t STAGE_LIMIT = 64u << 20;
@@ -821,13 +845,16 @@ int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_
     else h->stage_out = nullptr;
   }
   hipError_t e = hipStreamCreate(&h->stream);
-  if (e == hipSuccess) e = hipStreamCreate(&h->alt.stream);
   for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming);
   if (e != hipSuccess) {
     mpmpc_destroy(h);
     return fail(MPMPC_E_HIP, std::string("stream/event creation: ") + hipGetErrorString(e));
+  }
+  if (int rc = grow_slots(h, h->pipeline - 1)) {
+    mpmpc_destroy(h);
+    return rc;
   }
   *out = h;
   return MPMPC_OK;
@@ -1185,8 +1212,16 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, bo
   // smallest power of two holding N + 1 stages, so that a wave carries 2 or 4 instances and a SIMD two such waves
   int G = 64;
   if (rn && !rnt) {      // (the terminal-time kernels run one instance per wave)
-    if (N + 1 <= 32 && B > 1024) G = 32;
-    if (N + 1 <= 16 && B > 2048) G = 16;
+    // A handle that keeps several launches in flight (mpmpc_set_pipeline > 1: the default) is after throughput, and a packed
+    // wave does two or four instances for about the instructions of one: such handles pack from 128 instances on - the
+    // launches in flight fill the chip, not the waves of one launch (B = 1 024, four launches in flight: 36.5 M solves/s with
+    // one instance per wave, measured 41.4 M with two launches of the packed kernel).  A handle held at
+    // one launch in flight and the closed loop (one launch per step, each waiting for the one before) keep one instance per
+    // wave up to the chip's 1 024 SIMDs: the latency of a single launch is 43 us against 52.  The choice depends on the
+    // handle's settings and the batch size only: a given call gives the same bits every time.
+    const bool throughput = h->pipeline > 1 && !closed_loop;
+    if (N + 1 <= 32 && B > (throughput ? 128 : 1024)) G = 32;
+    if (N + 1 <= 16 && B > (throughput ? 256 : 2048)) G = 16;
     if (h->force_lanes && N + 1 <= h->force_lanes) G = h->force_lanes;      // mpmpc_set_packing
   }
   // closed loop: the previous step's active sets as a first guess.  A launch with one instance per wave ends with
@@ -1309,8 +1344,13 @@ int mpmpc_solve_resident(mpmpc_handle h, int32_t B) {
     // what this stream still has queued that solves read (an upload, closed-loop steps) must be done before the other one starts
     const bool order = h->order_pending;
     if (order) HIP_TRY(hipEventRecord(h->ev_order, h->stream));
-    swap_slots(h);
-    if (order) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_order, 0));
+    swap_slots(h, h->ring);
+    h->ring = (h->ring + 1) % (h->pipeline - 1);
+    if (order) {
+      // (every slot's first launch after that work has to wait for it, not only this one's: the event goes to all streams)
+      HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_order, 0));
+      for (int i = 0; i < h->pipeline - 1; ++i) HIP_TRY(hipStreamWaitEvent(h->alt[i].stream, h->ev_order, 0));
+    }
     h->order_pending = false;
   }
   h->busy = true;
@@ -1320,8 +1360,11 @@ int mpmpc_solve_resident(mpmpc_handle h, int32_t B) {
 int mpmpc_set_pipeline(mpmpc_handle h, int32_t depth) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
   MPMPC_SETTLE(h);
-  if (depth != 1 && depth != 2) return fail(MPMPC_E_ARG, "pipeline depth must be 1 or 2");
+  if (depth < 1 || depth > mpmpc_handle_s::MAX_PIPELINE) return fail(MPMPC_E_ARG, "pipeline depth must be in [1, 8]");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (int rc = grow_slots(h, depth - 1)) return rc;
   h->pipeline = depth;
+  h->ring = 0;
   return MPMPC_OK;
 }
 
@@ -1376,7 +1419,7 @@ int mpmpc_solve_resident_profile(mpmpc_handle h, int32_t B, int32_t n, float* ms
   for (auto& e : ev)
     if (hipEventCreate(&e) != hipSuccess) { rc = fail(MPMPC_E_HIP, "hipEventCreate"); break; }
   for (int i = 0; i < n && rc == MPMPC_OK; ++i) {
-    if (h->pipeline > 1) swap_slots(h);
+    if (h->pipeline > 1) { swap_slots(h, h->ring); h->ring = (h->ring + 1) % (h->pipeline - 1); }
     h->busy = true;
     if (hipEventRecord(ev[2 * i], h->stream) != hipSuccess) { rc = fail(MPMPC_E_HIP, "hipEventRecord"); break; }
     rc = launch_solve(h, B, false, h->resident_y);
@@ -1389,10 +1432,13 @@ int mpmpc_solve_resident_profile(mpmpc_handle h, int32_t B, int32_t n, float* ms
       if (hipEventElapsedTime(&ms_each[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess) { rc = fail(MPMPC_E_HIP, "hipEventElapsedTime"); break; }
     if (rc == MPMPC_OK && ms_span) {
       // (the last END is the later of the last two launches' - they run side by side)
-      float a = 0.f, b = 0.f;
-      (void)hipEventElapsedTime(&a, ev[0], ev[2 * n - 1]);
-      if (n > 1) (void)hipEventElapsedTime(&b, ev[0], ev[2 * n - 3]);
-      *ms_span = a > b ? a : b;
+      float last = 0.f;
+      for (int i = n - 1; i >= 0 && i >= n - h->pipeline; --i) {
+        float a = 0.f;
+        (void)hipEventElapsedTime(&a, ev[0], ev[2 * i + 1]);
+        if (a > last) last = a;
+      }
+      *ms_span = last;
     }
   }
   for (auto& e : ev)

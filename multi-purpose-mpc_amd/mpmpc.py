@@ -379,9 +379,10 @@ class Handle:
         """resident launches store the multipliers y (default) or skip them (46 % of the output bytes)"""
         self._check(self.lib.mpmpc_set_outputs(self._h, int(bool(want_y))))
 
-    def set_pipeline(self, depth=2):
-        """resident launches in flight: 2 (default) = double-buffered inside the handle (launch k + 1 runs beside launch k,
-        whose results stay readable until launch k + 2), 1 = one stream, one output block"""
+    def set_pipeline(self, depth=3):
+        """resident launches in flight, 1 .. 8: 3 (default) = pipelined inside the handle (launch k + 1, k + 2 run beside
+        launch k, whose results stay readable until launch k + 3), 1 = one stream, one output block; more than 3 pay only with
+        GPU_MAX_HW_QUEUES >= 8 in the environment before the first HIP call (streams sharing a hardware queue serialise)"""
         self._check(self.lib.mpmpc_set_pipeline(self._h, int(depth)))
 
     def sync(self):

@@ -81,7 +81,7 @@ static void solve_rn(const mpmpc_config* cfg, const mpmpc_settings* st, const do
   }
 }
 // mpmpc_reduced_t_kernel: the reduced-native solver of the weightings with a terminal cost on the time state
-template <int G, int C>
+template <int G, int C, bool CR = true>
 static void solve_rnt(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
                       int* status, int* iters, double* resid, double* y, int* tail) {
   using L = LaneEmu<G, C>;
@@ -90,9 +90,9 @@ static void solve_rnt(const mpmpc_config* cfg, const mpmpc_settings* st, const d
   for (int w = 0; w < (B + per - 1) / per; ++w) {
     VI inst = L::slot() + w * per;
     VI k = L::stage() - lane_offset(G, C, cfg->N);
-    ReducedTSolver<L> s;
+    ReducedTSolver<L, CR> s;
     typename L::real fields[MPMPC_NUM_FIELDS];
-    ReducedTSolver<L>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    ReducedTSolver<L, CR>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
     s.run(fields, B, inst, k, cfg->N, make_params(*st), cfg->QN[2]);
     s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y);
     for (int i = 0; i < EMU_W; ++i)
@@ -188,10 +188,18 @@ extern "C" int emu_solve_rn(const mpmpc_config* cfg, const mpmpc_settings* st, i
 // the same kernel with the SEQUENTIAL elimination of the chains (the cyclic-reduction form is what ships): A/B in the tests
 extern "C" int emu_solve_rn_sequential(const mpmpc_config* cfg, const mpmpc_settings* st, int G, const double* qp, int B,
                                        double* z, double* u0, int* status, int* iters, double* resid, double* y, int* n_tail) {
-  if (cfg->N + 1 > G || !reducible(*cfg, *st)) return -1;
+  if (cfg->N + 1 > G) return -1;
   std::vector<int> tail(B + 1, 0);
   const int C = lane_split(G, cfg->N);
-  if (G == 64 && C == 16) solve_rn<64, 16, false>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data());
+  if (reducible_tt(*cfg, *st)) {          // the terminal-time kernels (one instance per wave)
+    if (lane_split(64, cfg->N) == 16) solve_rnt<64, 16, false>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data());
+    else solve_rnt<64, 32, false>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data());
+    if (n_tail) *n_tail = tail[0];
+    return 0;
+  }
+  if (!reducible(*cfg, *st)) return -1;
+  if (G == 64 && C == 32) solve_rn<64, 32, false>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data());
+  else if (G == 64 && C == 16) solve_rn<64, 16, false>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data());
   else if (G == 32) solve_rn<32, 16, false>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data());
   else if (G == 16) solve_rn<16, 16, false>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data());
   else return -1;

@@ -428,3 +428,59 @@ def test_cyclic_reduction_factorisation_agrees_with_the_sequential_one(cfgid, B,
         assert np.max(np.abs(a.z[ok] - b.z[ok])) <= 1e-11
         prim, stat, comp = T.kkt_batch(qp[:, ok], N, a.z[ok], a.y[ok])
         assert max(prim.max(), stat.max(), comp.max()) <= 1e-9
+
+
+# ---- round 4: the terminal-time kernels (csrc/mpmpc_reduced_t.hpp) and the cyclic reduction of the 32-lane chains
+@pytest.mark.parametrize("cfgid,N,B", [(3, 50, 24), (3, 30, 24), (4, 50, 64), (4, 30, 64), (3, 10, 12), (3, 3, 12), (3, 33, 8), (3, 47, 8)])
+def test_terminal_time_kernel_against_the_general_kernel_and_the_oracle(cfgid, N, B, emu, track):
+    """Weightings with a terminal cost on the time state (QN[2] > 0 = Q[2]: BASELINE config 3) run the reduced-native kernel
+    of mpmpc_reduced_t.hpp - t eliminated, the (e_y, e_psi, kappa, v) QP with one rank-one term, Sherman-Morrison on the
+    2 x 2-block solves - and what it cannot certify goes to the general kernel's tail launch.  The launcher's sequence against
+    the general 3-state kernel alone (statuses, plan to 1e-8), against the FULL problem's KKT system in plain numpy, against
+    Farkas' lemma for the refusals, and against the dense oracle; cfgid 4 = the obstacle corridor (infeasible and marginal
+    instances: the tail path) with the time-optimal weights."""
+    sc = scenarios.make(cfgid, track, B=B, N=N)
+    cfg = T.stock_config(N, "time_optimal")
+    st = mpmpc.default_settings()
+    assert emu.lib.emu_reduced_native_tt(__import__("ctypes").byref(cfg), __import__("ctypes").byref(st)) == 1
+    qp = emu.assemble(cfg, track, _inputs(sc))
+    gen = emu.solve(cfg, st, qp, G=64)                     # the general kernel alone
+    sol, n_tail = emu.solve_launch(cfg, st, qp, G=64)      # terminal-time kernel + tail launch
+    assert np.array_equal(sol.status, gen.status)
+    ok = sol.status == 1
+    assert ok.sum() >= 0.75 * B and (cfgid != 4 or (n_tail >= 1 and (sol.status == mpmpc.PRIMAL_INFEASIBLE).any()))
+    e = np.abs(sol.z - gen.z)
+    e[:, -1] = 0.0                                         # kappa_{N-1} is cost free, and so is the e_psi_N it alone drives
+    e[:, 3 * N + 1] = 0.0
+    assert e[ok].max() <= 1e-8 and np.abs(sol.u0 - gen.u0)[ok].max() <= 1e-9
+    prim, stat, comp = T.kkt_batch(qp[:, ok, :], N, sol.z[ok], sol.y[ok])
+    assert max(prim.max(), stat.max(), comp.max()) <= 1e-8
+    # the time rows' multipliers are all w t_N (stationarity in t_k): the rank-one term of the eliminated problem
+    ne = 3 * (N + 1)
+    nu_t = sol.y[ok][:, 2:ne:3]
+    assert np.max(np.abs(nu_t - (cfg.QN[2] * sol.z[ok][:, ne - 1])[:, None])) <= 1e-12
+    inf = sol.status == mpmpc.PRIMAL_INFEASIBLE
+    if inf.any():
+        okf, support, aty = T.farkas_batch(qp[:, inf, :], N, sol.y[inf])
+        assert okf.all(), (support.max(), aty.max())
+    for i in np.flatnonzero(ok)[:6]:
+        Pd, q, A, l, u = T.qp_to_dense(qp[:, i, :], N)
+        r = O.solve(np.diag(Pd), q, A, l, u, O.Settings(polish=2))
+        if r.status == O.SOLVED and r.polished == 1:
+            uref = np.array([r.x[3 * (N + 1)], np.arctan(r.x[3 * (N + 1) + 1] * scenarios.CAR_LENGTH)])
+            assert np.max(np.abs(sol.u0[i] - uref)) <= 1e-6
+
+
+@pytest.mark.parametrize("cfgid,N,weights", [(3, 50, "time_optimal"), (3, 40, "time_optimal"), (2, 50, "stock"), (4, 33, "stock"), (2, 45, "stock")])
+def test_cyclic_reduction_of_the_32_lane_chains_agrees_with_the_sequential_elimination(cfgid, N, weights, emu, track):
+    """N + 1 > 32: a chain of the factorisation is TWO rows of 16 lanes (kCR32: in-row levels, then the first row's survivor
+    against the second row's, then the junction).  Same kernel with the chain-sequential elimination (CR = false): identical
+    statuses and interior-point iteration counts, the plan to 1e-9 - for the terminal-time kernels and the stock-weight ones."""
+    sc = scenarios.make(cfgid, track, B=40, N=N)
+    cfg = T.stock_config(N, weights)
+    qp = emu.assemble(cfg, track, _inputs(sc))
+    a, ta = emu.solve_rn(cfg, mpmpc.default_settings(), qp, G=64)
+    b, tb = emu.solve_rn(cfg, mpmpc.default_settings(), qp, G=64, sequential=True)
+    assert ta == tb and np.array_equal(a.status, b.status) and np.array_equal(a.iters, b.iters)
+    ok = a.status == 1
+    assert ok.sum() >= 30 and np.abs(a.z[ok] - b.z[ok]).max() <= 1e-9 and np.abs(a.u0[ok] - b.u0[ok]).max() <= 1e-10
