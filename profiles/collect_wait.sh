@@ -8,7 +8,7 @@
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash profiles/collect_wait.sh r3a'
 # profiles/summarize_wait.py condenses gpurun_out/<tag>/ into profiles/r3/pmc_wait_<tag>.json
 set -u
-TAG=${1:-r3a}
+TAG=${1:-r4w}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
@@ -22,10 +22,10 @@ G_MIX="SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INST
 G_MEM="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"
 for wl in cfg2 cfg3 cfg4 big; do
   case $wl in
-    cfg2) A="--steps 5 --warmup 1" ;;
-    cfg3) A="--config 3 --steps 5 --warmup 1" ;;
-    cfg4) A="--config 4 --steps 5 --warmup 1" ;;
-    big)  A="--batch 65536 --steps 3 --warmup 1" ;;
+    cfg2) A="--steps 5 --warmup 1 --repeats 2 --prewarm 30" ;;
+    cfg3) A="--config 3 --steps 5 --warmup 1 --repeats 2 --prewarm 30" ;;
+    cfg4) A="--config 4 --steps 5 --warmup 1 --repeats 2 --prewarm 30" ;;
+    big)  A="--batch 65536 --steps 3 --warmup 1 --repeats 2 --prewarm 30" ;;
   esac
   BENCH_ARGS="$A" prof ${wl}_wait --pmc $G_WAIT
   BENCH_ARGS="$A" prof ${wl}_fetch --pmc $G_FETCH

@@ -1,4 +1,4 @@
-"""After `gpurun -- 'bash profiles/collect_all.sh'`: condense gpurun_out/ into profiles/r3/ (run here, in the authoring container)."""
+"""After `gpurun -- 'bash profiles/collect_all.sh'`: condense gpurun_out/ into profiles/r4/ (run here, in the authoring container)."""
 import glob
 import json
 import os
@@ -9,23 +9,23 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
-for cmd in (["profiles/summarize.py", "r3"], ["profiles/summarize_wait.py", "r3w", "r3"], ["profiles/kernel_resources.py", "r3"]):
+for cmd in (["profiles/summarize.py", "r4"], ["profiles/summarize_wait.py", "r4w", "r4"], ["profiles/kernel_resources.py", "r4"]):
     subprocess.run([sys.executable] + cmd, check=True, stdout=subprocess.DEVNULL)
-for f in glob.glob("gpurun_out/r3/phases_*.txt") + ["gpurun_out/rollout_warm.txt", "gpurun_out/torchrun_1rank.json"]:
-    shutil.copy(f, "profiles/r3/")
-src = json.load(open("profiles/r3/pmc_summary.json"))["library_source_hash"]
+for f in glob.glob("gpurun_out/r4/phases_*.txt") + ["gpurun_out/rollout_warm.txt", "gpurun_out/torchrun_1rank.json"]:
+    shutil.copy(f, "profiles/r4/")
+src = json.load(open("profiles/r4/pmc_summary.json"))["library_source_hash"]
 rows = [l for l in open("gpurun_out/rnab.txt").read().split("\n") if re.match(r"^(b\d+|big|cfg\d)_", l)]
 head = ["# profiles/rn_ab.sh on one MI355X box, library src %s" % src,
         "# gen = general kernels (--set native=0; one instance per wave whatever --lanes says); rn2 = reduced-native kernels, two waves per SIMD (default);",
         "# rn1 = the SAME code object held at one wave per SIMD by 20 KB of unused dynamic LDS per block (MPMPC_RN_OCC=1)",
         "# (the table of the first reduced-native build, library src 1be653071df62190, is in the history of this file: config 4 22.2 -> 31.5 M, B = 65 536 33.6 -> 54.6 M)"]
-open("profiles/r3/occupancy.txt", "w").write("\n".join(head + [re.sub(r"\s+k2 [0-9.]+ ms", "", l) for l in rows]) + "\n")
+open("profiles/r4/occupancy.txt", "w").write("\n".join(head + [re.sub(r"\s+k2 [0-9.]+ ms", "", l) for l in rows]) + "\n")
 print("library", src, "tree", open("multi-purpose-mpc_amd/csrc/libmpmpc.srchash").read().strip())
-for f in sorted(glob.glob("profiles/r3/bench_*.json")):
+for f in sorted(glob.glob("profiles/r4/bench_*.json")):
     d = json.load(open(f))
     print("%-28s %6.2f M  %.4f ms  kernel %.4f ms  %s  ipm %.2f" % (os.path.basename(f), d["value"] / 1e6, d["ms_per_step"], d["roofline"]["avg_ms"],
                                                                  d.get("status_counts"), d["iters"]["ipm_mean"]))
-w = json.load(open("profiles/r3/pmc_wait_r3w.json"))
+w = json.load(open("profiles/r4/pmc_wait_r4w.json"))
 for wl in ("cfg2", "cfg4", "big"):
     for k, v in w[wl].items():
         if "reduced" in k:
