@@ -565,8 +565,8 @@ def _main(real_stdout):
                                             "(mpmpc_solve_resident_profile)" % n_prof,
                            "note": "achieved = algorithmic bytes per launch x launches / (first start .. last end), HIP events; "
                                    "avg_ms = mean duration of one launch in that pattern: %d launch(es) in flight inside the handle "
-                                   "(two streams, two output blocks), so avg_ms is about launches_in_flight x ms_per_step and a launch "
-                                   "takes longer than alone (avg_ms_launch_alone).  "
+                                   "(one launch slot each: stream, output block), so avg_ms is about launches_in_flight x ms_per_step and a "
+                                   "launch takes longer than alone (avg_ms_launch_alone).  "
                                    "SURVEY 8(d) bytes: 8(7N+3) in + 8(5N+5)+8 out per solve; the launch writes no multipliers here "
                                    "(mpmpc_set_outputs(0)).  K2 is FP64-VALU / dependency-chain bound, not HBM bound (DESIGN.md "
                                    "section 5): see roofline_fp64" % args.pipeline}

@@ -14,12 +14,8 @@ for cmd in (["profiles/summarize.py", "r4"], ["profiles/summarize_wait.py", "r4w
 for f in glob.glob("gpurun_out/r4/phases_*.txt") + ["gpurun_out/rollout_warm.txt", "gpurun_out/torchrun_1rank.json"]:
     shutil.copy(f, "profiles/r4/")
 src = json.load(open("profiles/r4/pmc_summary.json"))["library_source_hash"]
-rows = [l for l in open("gpurun_out/rnab.txt").read().split("\n") if re.match(r"^(b\d+|big|cfg\d)_", l)]
-head = ["# profiles/rn_ab.sh on one MI355X box, library src %s" % src,
-        "# gen = general kernels (--set native=0; one instance per wave whatever --lanes says); rn2 = reduced-native kernels, two waves per SIMD (default);",
-        "# rn1 = the SAME code object held at one wave per SIMD by 20 KB of unused dynamic LDS per block (MPMPC_RN_OCC=1)",
-        "# (the table of the first reduced-native build, library src 1be653071df62190, is in the history of this file: config 4 22.2 -> 31.5 M, B = 65 536 33.6 -> 54.6 M)"]
-open("profiles/r4/occupancy.txt", "w").write("\n".join(head + [re.sub(r"\s+k2 [0-9.]+ ms", "", l) for l in rows]) + "\n")
+if os.path.exists("gpurun_out/single_process_2handles.json"):
+    shutil.copy("gpurun_out/single_process_2handles.json", "profiles/r4/")
 print("library", src, "tree", open("multi-purpose-mpc_amd/csrc/libmpmpc.srchash").read().strip())
 for f in sorted(glob.glob("profiles/r4/bench_*.json")):
     d = json.load(open(f))

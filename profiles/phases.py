@@ -42,6 +42,11 @@ def main():
         over[k] = float(v) if any(c in v for c in ".eE") else int(v)
     h = mpmpc.Handle(cfg, mpmpc.default_settings(**over))
     h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+    # one launch in flight and the packing of such a handle, unless MPMPC_PHASES_PIPELINE says otherwise: the per-wave
+    # accumulators of the profiling build are indexed by block, so launches must not overlap; PIPELINE > 1 selects the
+    # throughput packing (two instances per wave from 128 instances on) and the launches are separated by syncs below
+    depth = int(os.environ.get("MPMPC_PHASES_PIPELINE", "1"))
+    h.set_pipeline(depth)
     h.upload(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
     for _ in range(3):
         h.solve_resident(sc.B)
@@ -51,7 +56,7 @@ def main():
     reps = 5
     for _ in range(reps):
         h.solve_resident(sc.B)
-    h.sync()
+        h.sync()
     lib.mpmpc_debug_phase(buf.ctypes.data, 0)
     waves = int((buf[:, 8] != 0).sum())
     t = buf[:waves].astype(np.float64) / reps

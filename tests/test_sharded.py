@@ -88,3 +88,33 @@ def test_sharded_batch_mpc_is_batch_mpc():
     ok = status == 1
     assert np.array_equal(status, status2) and np.max(np.abs(u[ok] - u2[ok])) <= 1e-9 and np.max(np.abs(plan[ok] - plan2[ok])) <= 1e-9
     sm.close()
+
+
+@pytest.mark.gpu
+def test_non_diagonal_stage_weights_are_refused_loudly_on_the_device_path():
+    """`Q` and `R` must be diagonal (the reference puts the whole matrices into P, src/MPC.py:150, its
+    cost vector only their diagonals).  With a device present the product classes refuse such weights with ValueError before
+    anything is launched - MPC, BatchMPC and ShardedBatchMPC alike - while a full symmetric QN is accepted; the C side has no
+    field an off-diagonal stage weight could arrive in (include/mpmpc.h: Q[3], R[2] are diagonals) and rejects a QN that is not
+    positive semi-definite with MPMPC_E_ARG."""
+    import test_host_mpc as H
+    from MPC import MPC, BatchMPC
+    from scipy import sparse
+    m, rp, car = H.build_world()
+    ic = {'umin': np.array([0.0, -np.tan(0.66) / car.length]), 'umax': np.array([1.0, np.tan(0.66) / car.length])}
+    scn = {'xmin': np.array([-np.inf] * 3), 'xmax': np.array([np.inf] * 3)}
+    Q, R, QN = sparse.diags([1.0, 0.0, 0.0]), sparse.diags([0.5, 0.0]), sparse.diags([1.0, 0.0, 0.0])
+    Qbad = np.array([[1.0, 0.1, 0.0], [0.1, 0.5, 0.0], [0.0, 0.0, 0.0]])
+    Rbad = np.array([[0.5, 0.05], [0.05, 0.1]])
+    for make in (lambda q, r: MPC(car, 10, q, r, QN, scn, ic, 4.0),
+                 lambda q, r: BatchMPC(car, 10, q, r, QN, scn, ic, 4.0, max_batch=4),
+                 lambda q, r: sharded.ShardedBatchMPC(car, 10, q, r, QN, scn, ic, 4.0, max_batch=4, devices=[0, 0])):
+        for q, r in ((Qbad, R), (Q, Rbad)):
+            with pytest.raises(ValueError):
+                make(q, r)
+    QNfull = np.array([[1.0, 0.1, 0.0], [0.1, 0.5, 0.0], [0.0, 0.0, 0.2]])
+    BatchMPC(car, 10, Q, R, QNfull, scn, ic, 4.0, max_batch=4).handle.close()          # accepted
+    cfg = T.stock_config(10, max_batch=4)
+    cfg.QN_offdiag[0] = 5.0                                                              # indefinite: 1 x 0 - 25 < 0
+    with pytest.raises(mpmpc.MpmpcError):
+        mpmpc.Handle(cfg, mpmpc.default_settings())
