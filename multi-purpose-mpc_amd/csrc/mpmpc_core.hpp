@@ -432,6 +432,14 @@ struct Solver {
   // scale(a) followed by scale(b) is scale(a + b) bit for bit; instances outside `on` keep their scaling
   // (their factors are forced to exactly 1).
   MPMPC_HD void scale(int passes, const Mk& on) {
+    ruiz(passes, on);
+    MPMPC_UNROLL
+    for (int i = 0; i < 3; ++i) leq[i] = Eeq[i] * beq_raw(i);
+    MPMPC_UNROLL
+    for (int j = 0; j < 5; ++j) { lb[j] = Eb[j] * lo_raw(j); ub[j] = Eb[j] * hi_raw(j); }
+  }
+  // the Ruiz sweeps alone: cost, rows and their scalings (the bounds are scaled by the caller)
+  MPMPC_HD void ruiz(int passes, const Mk& on) {
     const R n_total(double(5 * N + 3));
     for (int it = 0; it < passes; ++it) {
       R cn[5], rn[3], r_own[3];
@@ -498,10 +506,6 @@ struct Solver {
       if constexpr (FQ) { pod[0] = pod[0] * ct; pod[1] = pod[1] * ct; pod[2] = pod[2] * ct; }
       c = c * ct;
     }
-    MPMPC_UNROLL
-    for (int i = 0; i < 3; ++i) leq[i] = Eeq[i] * beq_raw(i);
-    MPMPC_UNROLL
-    for (int j = 0; j < 5; ++j) { lb[j] = Eb[j] * lo_raw(j); ub[j] = Eb[j] * hi_raw(j); }
   }
 
   // OSQP set_rho_vec(): per-row step size by constraint type

@@ -36,6 +36,7 @@ __device__ long long g_phase[4096 * 32];
 #include "mpmpc_core.hpp"
 #include "mpmpc_reduced.hpp"
 #include "mpmpc_reduced_t.hpp"
+#include "mpmpc_reduced_tail.hpp"
 #include "corridor_core.hpp"
 #include "rollout_core.hpp"
 #include "speed_core.hpp"
@@ -159,11 +160,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                            double* __restrict__ resid, double* __restrict__ y,
                                                            int* __restrict__ tail, int* __restrict__ act,
                                                            const int* __restrict__ shift, int* __restrict__ tail_reset,
-                                                           unsigned* __restrict__ tail_flag, unsigned seq) {
+                                                           unsigned* __restrict__ tail_flag, unsigned seq, int* __restrict__ tail2_reset) {
   using L = LaneGpu<G, C, RN_SLOTS>;
   // (the list of the NEXT launch is emptied here as well: the tail launch, which does it too, may be deferred - see
-  //  launch_solve)
-  if (blockIdx.x == 0 && threadIdx.x == 0) *tail_reset = 0;
+  //  launch_solve; and so is the list the reduced-native tail kernel of THIS launch appends to)
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *tail_reset = 0; *tail2_reset = 0; }
   const int inst = blockIdx.x * L::per_wave + L::slot();
   const int k = L::stage() - lane_offset(G, C, cfg.N);
   int guess = 0;
@@ -219,6 +220,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   if (k_o == 0 && inst_o < B && s.status == MPMPC_UNSOLVED) {
     tail[1 + atomicAdd(tail, 1)] = inst_o;
     __hip_atomic_store(tail_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// K2p: the reduced-native TAIL kernel (mpmpc_reduced_tail.hpp): phase 1 and one more attempt of the certified polish on
+// the instances the reduced-native launch listed in `tail`, one per wave, within the same 256 registers and 40 LDS slots -
+// a tail wave shares its SIMD.  What it leaves UNSOLVED is appended to tail2 for the general kernel (mode 2).
+template <int G, int C>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void mpmpc_reduced_tail_kernel(mpmpc_config cfg, SolverParams st, int B, AssembleIn ain,
+                                                           double* __restrict__ z, double* __restrict__ u0,
+                                                           int* __restrict__ status, int* __restrict__ iters,
+                                                           double* __restrict__ resid, double* __restrict__ y,
+                                                           const int* __restrict__ tail, int* __restrict__ tail_reset,
+                                                           int* __restrict__ tail2, unsigned* __restrict__ tail2_flag, unsigned seq) {
+  using L = LaneGpu<G, C, RN_SLOTS>;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *tail_reset = 0;
+  if ((int)blockIdx.x >= tail[0]) return;
+  const int inst = tail[1 + blockIdx.x];
+  const int k = L::stage() - lane_offset(G, C, cfg.N);
+  MPMPC_TICK_BEGIN(8);
+  double fields[MPMPC_NUM_FIELDS];
+  assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
+  ReducedTailSolver<L> s;
+  s.run(fields, B, inst, k, cfg.N, st, iters ? iters[inst * 2 + 1] : 0);
+  MPMPC_TICK_BEGIN(7);
+  const int inst_o = tail[1 + blockIdx.x];
+  const int k_o = L::stage_again() - lane_offset(G, C, cfg.N);
+  s.store(inst_o, k_o, cfg.wheelbase, z, u0, status, iters, resid, y);
+  MPMPC_TICK_END(7);
+  MPMPC_TICK_END(8);
+  if (k_o == 0 && s.status == MPMPC_UNSOLVED) {
+    tail2[1 + atomicAdd(tail2, 1)] = inst_o;
+    __hip_atomic_store(tail2_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -522,6 +555,10 @@ struct mpmpc_handle_s {
   bool tail_expect_empty = false;     // the last observed launch left no tail
   bool pend = false;                  // the last launch's tail launch was not enqueued
   bool tail_ran_late = false;         // the last observe_tail had to run a deferred tail
+  // Second level (reduced_native_tail configurations): the tail goes to the reduced-native tail kernel first, which appends
+  // what IT leaves to a third list (tail + 2 (max_batch + 1)) and stamps tail_flag[1]; the general kernel on that list is
+  // deferred by the same rule.
+  bool tail2_expect_empty = false, pend2 = false;
   size_t staged_bytes = 0;            // mpmpc_staged_begin without its mpmpc_staged_end: bytes of the output block on their way back
   int pend_B = 0;
   bool pend_y = false;
@@ -540,7 +577,7 @@ struct mpmpc_handle_s {
     int tail_flip = 0;
     unsigned* tail_flag = nullptr;
     unsigned seq = 0;
-    bool tail_expect_empty = false, pend = false, tail_ran_late = false;
+    bool tail_expect_empty = false, pend = false, tail_ran_late = false, tail2_expect_empty = false, pend2 = false;
     int pend_B = 0;
     bool pend_y = false;
     int *pend_cur = nullptr, *pend_next = nullptr;
@@ -575,6 +612,7 @@ static void swap_slots(mpmpc_handle h, int i) {
   std::swap(h->status, a.status); std::swap(h->iters, a.iters);
   std::swap(h->tail, a.tail); std::swap(h->tail_flip, a.tail_flip); std::swap(h->tail_flag, a.tail_flag); std::swap(h->seq, a.seq);
   std::swap(h->tail_expect_empty, a.tail_expect_empty); std::swap(h->pend, a.pend); std::swap(h->tail_ran_late, a.tail_ran_late);
+  std::swap(h->tail2_expect_empty, a.tail2_expect_empty); std::swap(h->pend2, a.pend2);
   std::swap(h->pend_B, a.pend_B); std::swap(h->pend_y, a.pend_y); std::swap(h->pend_cur, a.pend_cur); std::swap(h->pend_next, a.pend_next);
   std::swap(h->y_valid, a.y_valid); std::swap(h->busy, a.busy);
 }
@@ -582,7 +620,7 @@ static void swap_slots(mpmpc_handle h, int i) {
 // is: what follows on its stream is ordered behind it anyway).
 static int settle_other_slot(mpmpc_handle h) {
   for (int i = 0; i < h->n_alt; ++i) {
-    if (!h->alt[i].busy && !h->alt[i].pend) continue;
+    if (!h->alt[i].busy && !h->alt[i].pend && !h->alt[i].pend2) continue;
     swap_slots(h, i);
     const int rc = observe_tail(h);
     swap_slots(h, i);
@@ -598,7 +636,7 @@ static int settle_other_slot(mpmpc_handle h) {
       if (int rc_ = mpmpc_staged_end(h)) return rc_;         \
     }                                                        \
     if (int rc_ = settle_other_slot(h)) return rc_;          \
-    if ((h)->pend) {                                         \
+    if ((h)->pend || (h)->pend2) {                           \
       if (int rc_ = observe_tail(h)) return rc_;             \
     }                                                        \
     (h)->order_pending = true;                               \
@@ -632,7 +670,7 @@ static int check_settings(const mpmpc_settings* s) {
 
 static int grow_slots(mpmpc_handle h, int want);
 static int launch_assemble(mpmpc_handle h, int B);
-static int launch_solve(mpmpc_handle h, int B, bool closed_loop = false, bool want_y = true, bool tail_only = false);
+static int launch_solve(mpmpc_handle h, int B, bool closed_loop = false, bool want_y = true, int tail_only = 0);
 
 extern "C" {
 
@@ -734,13 +772,13 @@ static int grow_slots(mpmpc_handle h, int want) {
   const BlockLayout lay = block_layout(h->cfg.N, h->cfg.max_batch);
   while (h->n_alt < want) {
     auto& a = h->alt[h->n_alt];
-    const size_t nt = 2 * ((size_t)h->cfg.max_batch + 1);
+    const size_t nt = 3 * ((size_t)h->cfg.max_batch + 1);
     if (hipMalloc((void**)&a.out_block, lay.out_end) != hipSuccess || hipMalloc((void**)&a.tail, nt * sizeof(int)) != hipSuccess ||
         hipMemset(a.tail, 0, nt * sizeof(int)) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&a.tail_flag), sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&a.tail_flag), 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
         hipStreamCreate(&a.stream) != hipSuccess)
       return fail(MPMPC_E_HIP, "allocation of a launch slot failed (stream / output block / tail list)");
-    *a.tail_flag = 0u;
+    a.tail_flag[0] = a.tail_flag[1] = 0u;
     h->n_alt += 1;
   }
   lay_out(h, h->laid_out ? h->laid_out : h->cfg.max_batch);
@@ -827,14 +865,14 @@ int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_
   ALLOC(h->out_block, lay.out_end);
   lay_out(h, cfg->max_batch);
   ALLOC(h->qp, (size_t)MPMPC_NUM_FIELDS * B * h->ld);
-  ALLOC(h->tail, 2 * (B + 1));
-  (void)hipMemset(h->tail, 0, 2 * (B + 1) * sizeof(int));
-  if (hipHostMalloc(reinterpret_cast<void**>(&h->tail_flag), sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
+  ALLOC(h->tail, 3 * (B + 1));
+  (void)hipMemset(h->tail, 0, 3 * (B + 1) * sizeof(int));
+  if (hipHostMalloc(reinterpret_cast<void**>(&h->tail_flag), 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
     h->tail_flag = nullptr;
     mpmpc_destroy(h);
     return fail(MPMPC_E_HIP, "hipHostMalloc tail_flag");
   }
-  *h->tail_flag = 0u;
+  h->tail_flag[0] = h->tail_flag[1] = 0u;
 #undef ALLOC
   {
     const size_t STAGE_LIMIT = 64u << 20;
@@ -1190,8 +1228,9 @@ static int launch_assemble(mpmpc_handle h, int B) {
   return MPMPC_OK;
 }
 
-// tail_only: the deferred tail launch of the last reduced-native launch (observe_tail), nothing else
-static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, bool tail_only) {
+// tail_only: 1 = the deferred tail launches of the last reduced-native launch (observe_tail), nothing else; 2 = of those,
+// only the general kernel on what the reduced-native tail kernel left
+static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, int tail_only) {
   const int N = h->cfg.N;
   double* y_out = want_y ? h->y : nullptr;        // nobody wants the multipliers: the kernel skips their stores
   h->y_valid = want_y;
@@ -1239,8 +1278,14 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, bo
   // list of the next one, so that no memset has to sit between the launches of consecutive steps
   int* tail_cur = h->tail + (size_t)h->tail_flip * (h->cfg.max_batch + 1);
   int* tail_next = h->tail + (size_t)(1 - h->tail_flip) * (h->cfg.max_batch + 1);
+  int* tail2 = h->tail + 2 * ((size_t)h->cfg.max_batch + 1);      // what the reduced-native tail kernel leaves to the general one
   if (tail_only) { tail_cur = h->pend_cur; tail_next = h->pend_next; }
   else if (rn) { h->tail_flip = 1 - h->tail_flip; h->seq += 1; }
+  // The tail of a batch launch goes to the reduced-native tail kernel first (K2p: two waves per SIMD instead of one).  The
+  // closed loop keeps the general kernel for the whole tail: its step would pay for a third launch every time.
+  // (MPMPC_LEAN_TAIL=0: the general kernel takes the whole tail, for A/B timings)
+  static const bool lean_off = std::getenv("MPMPC_LEAN_TAIL") && std::atoi(std::getenv("MPMPC_LEAN_TAIL")) == 0;
+  const bool lean = rn && !rnt && !closed_loop && !lean_off && reduced_native_tail(h->cfg, h->st);
 #define LAUNCH_W(CC, WW, FF, MODE, BLOCKS)                                                                                \
   hipLaunchKernelGGL((mpmpc_solve_kernel<64, CC, WW, FF>), dim3(BLOCKS), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, \
                      ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, MODE, tail_cur, WW ? warm_act : nullptr,   \
@@ -1265,7 +1310,7 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, bo
 #define LAUNCH_RN_W(GG, CC, WW)                                                                                             \
   hipLaunchKernelGGL((mpmpc_reduced_kernel<GG, CC, WW>), dim3(blocks), dim3(64), rn_pad, h->stream, h->cfg, prm, B, h->ld, \
                      ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, tail_cur, warm_act, warm_shift, tail_next,      \
-                     h->tail_flag, h->seq)
+                     h->tail_flag, h->seq, tail2)
 #define LAUNCH_RN(GG, CC)                       \
   do {                                          \
     if (warm) LAUNCH_RN_W(GG, CC, true);        \
@@ -1292,8 +1337,21 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, bo
     // Deferred (see the handle): no tail launch is enqueued while the launches the host has seen leave none; the closed
     // loop consumes its results on the device and always launches it.
     h->pend = !tail_only && !closed_loop && h->tail_expect_empty;
+    h->pend2 = false;
     if (h->pend) {
       h->pend_B = B; h->pend_y = want_y; h->pend_cur = tail_cur; h->pend_next = tail_next;
+    } else if (lean) {
+      if (tail_only != 2)
+        hipLaunchKernelGGL((mpmpc_reduced_tail_kernel<64, 16>), dim3(B), dim3(64), rn_pad, h->stream, h->cfg, prm, B, ain, h->z, h->u0,
+                           h->status, h->iters, h->resid, y_out, tail_cur, tail_next, tail2, h->tail_flag + 1, h->seq);
+      // ... and the general kernel on what that left: deferred like the tail itself while the launches seen leave nothing
+      h->pend2 = tail_only != 2 && h->tail2_expect_empty;
+      if (h->pend2) {
+        h->pend_B = B; h->pend_y = want_y; h->pend_cur = tail_cur; h->pend_next = tail_next;
+      } else {
+        tail_cur = tail2;
+        LAUNCH(16, false, 2, B);
+      }
     } else if (lane_split(64, N) == 16) LAUNCH(16, false, 2, B);
     else LAUNCH(32, false, 2, B);
   } else if (C == 16) LAUNCH(16, warm, 0, blocks);
@@ -1321,11 +1379,22 @@ static int observe_tail(mpmpc_handle h) {
     h->pend = false;
     if (left) {
       h->tail_ran_late = true;
-      if (int rc = launch_solve(h, h->pend_B, false, h->pend_y, true)) return rc;
+      if (int rc = launch_solve(h, h->pend_B, false, h->pend_y, 1)) return rc;
       HIP_TRY(hipStreamSynchronize(h->stream));
     }
   }
   h->tail_expect_empty = !left;
+  // (second level: read after a tail that ran late has run)
+  const bool left2 = static_cast<volatile unsigned*>(h->tail_flag)[1] == h->seq;
+  if (h->pend2) {
+    h->pend2 = false;
+    if (left2) {
+      h->tail_ran_late = true;
+      if (int rc = launch_solve(h, h->pend_B, false, h->pend_y, 2)) return rc;
+      HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+  }
+  h->tail2_expect_empty = !left2;
   return MPMPC_OK;
 }
 

@@ -79,6 +79,11 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
 
   // ================================================================================ setup: load + Ruiz + cold
   MPMPC_HD void setup(const R* fields, int B, const I& inst, const I& k, int N_, const SolverParams& st) {
+    context(B, inst, k, N_);
+    setup_problem(fields, st);
+  }
+  // lane context: which stage this lane holds, where the elimination chains of its instance run
+  MPMPC_HD void context(int B, const I& inst, const I& k, int N_) {
     N = N_;
     n_inst = B;
     live = inst < B;
@@ -101,6 +106,8 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
       }
     }
     val[0] = vx; val[1] = vx; val[2] = vu;
+  }
+  MPMPC_HD void setup_problem(const R* fields, const SolverParams& st) {
     auto fld = [&](int f, double dflt) { return sel(vx, fields[f], R(dflt)); };
     const R zero(0.0), onec(1.0);
     // ---- the separated parts, in the UNSCALED problem
@@ -513,6 +520,136 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
     return v;
   }
 
+  // box rows in the scaled variable space:  g x in [lb, ub]  <=>  x in [lo, hi] = [lo_raw, hi_raw] / D  (slots K_LO0 .. K_HI2)
+  MPMPC_HD void make_box3(Box3& b3) const {
+    const R one(1.0);
+    const R lo_s[3] = {L::cold_get(K_LO0), R(-INFTY), L::cold_get(K_LO2)}, hi_s[3] = {L::cold_get(K_HI0), R(INFTY), L::cold_get(K_HI2)};
+    MPMPC_UNROLL
+    for (int e = 0; e < 3; ++e) {
+      const Mk fl = lo_s[e] > R(-BOX_INF), fu = hi_s[e] < R(BOX_INF);
+      const Mk pn = fl & fu & ((hi_s[e] - lo_s[e]) <= R(1e-12) * max_(one, abs_(lo_s[e])));
+      b3.lo[e] = lo_s[e];
+      b3.hi[e] = hi_s[e];
+      b3.pin[e] = pn & val[e];
+      b3.Lm[e] = fl & !pn & val[e];
+      b3.Um[e] = fu & !pn & val[e];
+    }
+  }
+
+  // The centred start of the interior point at x3 and the attempts from it (interior point, active-set rounds, certificate;
+  // see RN_ATTEMPTS).  cap: interior-point iterations an attempt may take; rd0_more: a dual residual of the start the three
+  // entries do not show (the tail solver's speed entry), or nullptr.  What is certified is committed; returns what is not.
+  template <bool WARM = false>
+  MPMPC_HD Mk attempts(Box3& b3, const SolverParams& st, int cap, Mk todo, bool committed, const R* rd0_more = nullptr) {
+    const R zero(0.0), one(1.0);
+    // ---- centred start of the interior point (Solver::polish, early attempt): slacks max(distance to the bound,
+    // ipm_start_slack in row space), multipliers mu0 / slack, no equality multipliers
+    R sl[3], su[3], zl[3], zu[3], pi[3];
+    {
+      const R ths(st.ipm_start_slack);
+      R mu0(st.ipm_start_mu);
+      if (st.ipm_start_dual > 0.0) {
+        R rd0(0.0);
+        MPMPC_UNROLL
+        for (int e = 0; e < 3; ++e) rd0 = max_(rd0, sel(val[e], abs_(fma_(P3[e], x3[e], Q3[e])), zero));
+        R rd0g = L::gmax(rd0);
+        if (rd0_more) rd0g = max_(rd0g, *rd0_more);
+        mu0 = max_(mu0, (R(st.ipm_start_dual) * ths) * rd0g);
+      }
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) {
+        const R fl = ths / L::cold_get(C_G + e);
+        sl[e] = sel(b3.Lm[e], max_(x3[e] - b3.lo[e], fl), one);
+        su[e] = sel(b3.Um[e], max_(b3.hi[e] - x3[e], fl), one);
+        zl[e] = sel(b3.Lm[e], mu0 / sl[e], zero);
+        zu[e] = sel(b3.Um[e], mu0 / su[e], zero);
+        pi[e] = L::cold_get(C_PI + e);
+      }
+    }
+    // ---- the interior point's own layout
+    BoxI bi;
+    IpmI si;
+    R pp[EI], qq[EI];
+    Mk vm[EI];
+    if constexpr (kSplit) {
+      bU[0] = sel(sU, L::from_lower(b[0]), zero);
+      bU[1] = zero;
+      vm[0] = val3[0]; vm[1] = val3[2];
+    } else {
+      vm[0] = val[0]; vm[1] = val[1]; vm[2] = val[2];
+    }
+    to_ip(b3.lo, bi.lo); to_ip(b3.hi, bi.hi); to_ip(P3, pp, 1.0); to_ip(Q3, qq);
+    mask_to_ip(b3.Lm, bi.Lm); mask_to_ip(b3.Um, bi.Um); mask_to_ip(b3.pin, bi.pin);
+    to_ip(x3, si.x); to_ip(sl, si.sl, 1.0); to_ip(su, si.su, 1.0); to_ip(zl, si.zl); to_ip(zu, si.zu); to_ip(pi, si.pi);
+    si.nu[0] = si.nu[1] = zero;
+    MPMPC_UNROLL
+    for (int e = 0; e < EI; ++e) {
+      si.tL[e] = bi.Lm[e] & (si.zl[e] > si.sl[e]);
+      si.tU[e] = bi.Um[e] & (si.zu[e] > si.su[e]);
+    }
+    if constexpr (!kSplit) {
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) { L::cold_put(K_PP + e, P3[e]); L::cold_put(K_QQ + e, Q3[e]); }
+      L::cold_put(K_LEQ, leq[0]); L::cold_put(K_LEQ + 1, leq[1]);
+      L::fence();
+    }
+    // A launch ends with its slowest wave, and a packed wave with its slower instance: feasible instances of this problem
+    // family converge in 5 - 11 iterations, so the attempt gives up after RN_IPM_CAP - what is still running by then
+    // (marginally infeasible instances: they would use all ipm_max_iter iterations) belongs to the tail launch anyway.
+    SolverParams sc = st;
+    sc.ipm_max_iter = st.ipm_max_iter < cap ? st.ipm_max_iter : cap;
+    double tol = st.native_ipm_tol;
+    for (int attempt = 0; attempt < RN_ATTEMPTS; ++attempt) {
+      MPMPC_TICK_BEGIN(4);
+      Mk conv;
+      if constexpr (kSplit) {
+        conv = this->template ipm<LAY_IP>(bi, si, pp, qq, vm, sc, tol, todo);
+      } else {
+        conv = ipm3(bi, si, sc, tol, todo);
+        // the packed interior point read its invariants from LDS; what follows takes them from there as well, so that
+        // no copy of them had to stay in registers across the loop
+        L::fence();
+        MPMPC_UNROLL
+        for (int e = 0; e < 3; ++e) { P3[e] = L::cold_get(K_PP + e); Q3[e] = L::cold_get(K_QQ + e); }
+        leq[0] = L::cold_get(K_LEQ); leq[1] = L::cold_get(K_LEQ + 1);
+        b3.lo[0] = bi.lo[0] = L::cold_get(K_LO0); b3.hi[0] = bi.hi[0] = L::cold_get(K_HI0);
+        b3.lo[2] = bi.lo[2] = L::cold_get(K_LO2); b3.hi[2] = bi.hi[2] = L::cold_get(K_HI2);
+      }
+      MPMPC_TICK_END(4);
+      // active-set guess: the indicators of the interior point's last step
+      Mk gL[EI], gU[EI], aL[3], aU[3];
+      MPMPC_UNROLL
+      for (int e = 0; e < EI; ++e) { gL[e] = bi.Lm[e] & si.tL[e]; gU[e] = bi.Um[e] & si.tU[e]; }
+      mask_from_ip(gL, aL); mask_from_ip(gU, aU);
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) { aL[e] = b3.Lm[e] & aL[e]; aU[e] = b3.Um[e] & aU[e] & !aL[e]; }
+      // (the rounds overwrite the point on every lane they run on and nothing reads it elsewhere: no copy of the interior
+      //  point's iterate has to live through them)
+      R xa[3] = {zero, zero, zero}, la[3] = {zero, zero, zero}, na[2] = {zero, zero};
+      park_ip(si);
+      MPMPC_TICK_BEGIN(5);
+      const double frac = attempt == 0 ? st.as_add_fraction : (st.as_add_fraction > 0.5 ? st.as_add_fraction : 0.5);
+      const Mk okm = this->template active_set<LAY_RED>(b3, P3, Q3, val, aL, aU, xa, na, la, st, todo & conv, frac);
+      MPMPC_TICK_END(5);
+      R prim, stat;
+      MPMPC_TICK_BEGIN(6);
+      const Mk cert = certificate3(P3, Q3, xa, na, la, st.cert_tol, prim, stat);
+      MPMPC_TICK_END(6);
+      const Mk good = todo & conv & okm & cert;
+      commit(good, committed, xa, na, la, prim, stat);
+      committed = true;
+      if constexpr (WARM) this->act_bits = seli(good, pack_active3(aL, aU), this->act_bits);
+      todo = todo & conv & !good;          // a diverged interior-point run is not retried
+      if (!L::wany(todo)) break;
+      unpark_ip(si);
+      if constexpr (kSplit) {          // (re-formed rather than carried through the rounds)
+        to_ip(b3.lo, bi.lo); to_ip(b3.hi, bi.hi); to_ip(P3, pp, 1.0); to_ip(Q3, qq);
+      }
+      tol *= RN_RETRY;
+    }
+    return todo;
+  }
+
   // WARM (closed loop): `guess` = active set of the previous step's certified plan, already shifted to this step's stages
   // (bit 30 set where there is one).  One or two active-set rounds from it usually reproduce the optimum
   // (Solver::warm_polish); what they cannot certify takes the normal path.
@@ -530,22 +667,9 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
     this->act_bits = I(0);
     Mk todo = solvable;
     if (L::wany(todo)) {
-      // ---- box rows in the scaled variable space:  g x in [lb, ub]  <=>  x in [lo, hi] = [lo_raw, hi_raw] / D
       bool committed = false;
       Box3 b3;
-      {
-        const R lo_s[3] = {L::cold_get(K_LO0), R(-INFTY), L::cold_get(K_LO2)}, hi_s[3] = {L::cold_get(K_HI0), R(INFTY), L::cold_get(K_HI2)};
-        MPMPC_UNROLL
-        for (int e = 0; e < 3; ++e) {
-          const Mk fl = lo_s[e] > R(-BOX_INF), fu = hi_s[e] < R(BOX_INF);
-          const Mk pn = fl & fu & ((hi_s[e] - lo_s[e]) <= R(1e-12) * max_(one, abs_(lo_s[e])));
-          b3.lo[e] = lo_s[e];
-          b3.hi[e] = hi_s[e];
-          b3.pin[e] = pn & val[e];
-          b3.Lm[e] = fl & !pn & val[e];
-          b3.Um[e] = fu & !pn & val[e];
-        }
-      }
+      make_box3(b3);
       if constexpr (WARM) {
         const Mk warm = L::gany(todo & bit_(guess, 30));
         if (L::wany(warm)) {
@@ -571,111 +695,7 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
           todo = todo & !good;
         }
       }
-      if (L::wany(todo)) {
-      // ---- centred start of the interior point (Solver::polish, early attempt): slacks max(distance to the bound,
-      // ipm_start_slack in row space), multipliers mu0 / slack, no equality multipliers
-      R sl[3], su[3], zl[3], zu[3], pi[3];
-      {
-        const R ths(st.ipm_start_slack);
-        R mu0(st.ipm_start_mu);
-        if (st.ipm_start_dual > 0.0) {
-          R rd0(0.0);
-          MPMPC_UNROLL
-          for (int e = 0; e < 3; ++e) rd0 = max_(rd0, sel(val[e], abs_(fma_(P3[e], x3[e], Q3[e])), zero));
-          mu0 = max_(mu0, (R(st.ipm_start_dual) * ths) * L::gmax(rd0));
-        }
-        MPMPC_UNROLL
-        for (int e = 0; e < 3; ++e) {
-          const R fl = ths / L::cold_get(C_G + e);
-          sl[e] = sel(b3.Lm[e], max_(x3[e] - b3.lo[e], fl), one);
-          su[e] = sel(b3.Um[e], max_(b3.hi[e] - x3[e], fl), one);
-          zl[e] = sel(b3.Lm[e], mu0 / sl[e], zero);
-          zu[e] = sel(b3.Um[e], mu0 / su[e], zero);
-          pi[e] = L::cold_get(C_PI + e);
-        }
-      }
-      // ---- the interior point's own layout
-      BoxI bi;
-      IpmI si;
-      R pp[EI], qq[EI];
-      Mk vm[EI];
-      if constexpr (kSplit) {
-        bU[0] = sel(sU, L::from_lower(b[0]), zero);
-        bU[1] = zero;
-        vm[0] = val3[0]; vm[1] = val3[2];
-      } else {
-        vm[0] = val[0]; vm[1] = val[1]; vm[2] = val[2];
-      }
-      to_ip(b3.lo, bi.lo); to_ip(b3.hi, bi.hi); to_ip(P3, pp, 1.0); to_ip(Q3, qq);
-      mask_to_ip(b3.Lm, bi.Lm); mask_to_ip(b3.Um, bi.Um); mask_to_ip(b3.pin, bi.pin);
-      to_ip(x3, si.x); to_ip(sl, si.sl, 1.0); to_ip(su, si.su, 1.0); to_ip(zl, si.zl); to_ip(zu, si.zu); to_ip(pi, si.pi);
-      si.nu[0] = si.nu[1] = zero;
-      MPMPC_UNROLL
-      for (int e = 0; e < EI; ++e) {
-        si.tL[e] = bi.Lm[e] & (si.zl[e] > si.sl[e]);
-        si.tU[e] = bi.Um[e] & (si.zu[e] > si.su[e]);
-      }
-      if constexpr (!kSplit) {
-        MPMPC_UNROLL
-        for (int e = 0; e < 3; ++e) { L::cold_put(K_PP + e, P3[e]); L::cold_put(K_QQ + e, Q3[e]); }
-        L::cold_put(K_LEQ, leq[0]); L::cold_put(K_LEQ + 1, leq[1]);
-        L::fence();
-      }
-      // A launch ends with its slowest wave, and a packed wave with its slower instance: feasible instances of this problem
-      // family converge in 5 - 11 iterations, so the attempt gives up after RN_IPM_CAP - what is still running by then
-      // (marginally infeasible instances: they would use all ipm_max_iter iterations) belongs to the tail launch anyway.
-      SolverParams sc = st;
-      sc.ipm_max_iter = st.ipm_max_iter < RN_IPM_CAP ? st.ipm_max_iter : RN_IPM_CAP;
-      double tol = st.native_ipm_tol;
-      for (int attempt = 0; attempt < RN_ATTEMPTS; ++attempt) {
-        MPMPC_TICK_BEGIN(4);
-        Mk conv;
-        if constexpr (kSplit) {
-          conv = this->template ipm<LAY_IP>(bi, si, pp, qq, vm, sc, tol, todo);
-        } else {
-          conv = ipm3(bi, si, sc, tol, todo);
-          // the packed interior point read its invariants from LDS; what follows takes them from there as well, so that
-          // no copy of them had to stay in registers across the loop
-          L::fence();
-          MPMPC_UNROLL
-          for (int e = 0; e < 3; ++e) { P3[e] = L::cold_get(K_PP + e); Q3[e] = L::cold_get(K_QQ + e); }
-          leq[0] = L::cold_get(K_LEQ); leq[1] = L::cold_get(K_LEQ + 1);
-          b3.lo[0] = bi.lo[0] = L::cold_get(K_LO0); b3.hi[0] = bi.hi[0] = L::cold_get(K_HI0);
-          b3.lo[2] = bi.lo[2] = L::cold_get(K_LO2); b3.hi[2] = bi.hi[2] = L::cold_get(K_HI2);
-        }
-        MPMPC_TICK_END(4);
-        // active-set guess: the indicators of the interior point's last step
-        Mk gL[EI], gU[EI], aL[3], aU[3];
-        MPMPC_UNROLL
-        for (int e = 0; e < EI; ++e) { gL[e] = bi.Lm[e] & si.tL[e]; gU[e] = bi.Um[e] & si.tU[e]; }
-        mask_from_ip(gL, aL); mask_from_ip(gU, aU);
-        MPMPC_UNROLL
-        for (int e = 0; e < 3; ++e) { aL[e] = b3.Lm[e] & aL[e]; aU[e] = b3.Um[e] & aU[e] & !aL[e]; }
-        // (the rounds overwrite the point on every lane they run on and nothing reads it elsewhere: no copy of the interior
-        //  point's iterate has to live through them)
-        R xa[3] = {zero, zero, zero}, la[3] = {zero, zero, zero}, na[2] = {zero, zero};
-        park_ip(si);
-        MPMPC_TICK_BEGIN(5);
-        const double frac = attempt == 0 ? st.as_add_fraction : (st.as_add_fraction > 0.5 ? st.as_add_fraction : 0.5);
-        const Mk okm = this->template active_set<LAY_RED>(b3, P3, Q3, val, aL, aU, xa, na, la, st, todo & conv, frac);
-        MPMPC_TICK_END(5);
-        R prim, stat;
-        MPMPC_TICK_BEGIN(6);
-        const Mk cert = certificate3(P3, Q3, xa, na, la, st.cert_tol, prim, stat);
-        MPMPC_TICK_END(6);
-        const Mk good = todo & conv & okm & cert;
-        commit(good, committed, xa, na, la, prim, stat);
-        committed = true;
-        if constexpr (WARM) this->act_bits = seli(good, pack_active3(aL, aU), this->act_bits);
-        todo = todo & conv & !good;          // a diverged interior-point run is not retried
-        if (!L::wany(todo)) break;
-        unpark_ip(si);
-        if constexpr (kSplit) {          // (re-formed rather than carried through the rounds)
-          to_ip(b3.lo, bi.lo); to_ip(b3.hi, bi.hi); to_ip(P3, pp, 1.0); to_ip(Q3, qq);
-        }
-        tol *= RN_RETRY;
-      }
-      }
+      if (L::wany(todo)) attempts<WARM>(b3, st, RN_IPM_CAP, todo, committed);
     }
     {
       const Mk warm_hit = bit_(this->act_bits, 29);
@@ -691,11 +711,13 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
   // z in the reference's ordering, u0 = (v_0, delta_0), multipliers in the reference's row order; the separated parts
   // (v, its multiplier, the roll-forward of t) are put together here, in the unscaled problem
   MPMPC_HD void store(const I& inst, const I& k, double wheelbase, double* z, double* u0, int* st_out, int* it_out,
-                      double* resid, double* y, int* act = nullptr, int ld = 0) const {
+                      double* resid, double* y, int* act = nullptr, int ld = 0, const Mk* point = nullptr, const Mk* no_lamv = nullptr) const {
     if (act) L::storei(act, inst * ld + k, vx, this->act_bits);
     const int n = 5 * N + 3, m = 8 * N + 6;
     const R zero(0.0);
-    const Mk ok = live & (status == MPMPC_SOLVED);
+    // (point / no_lamv: the tail solver's verdicts - a least-violation point with its ray, a plan over relaxed boxes - also
+    //  have a point in the slots; the ray carries no speed entry)
+    const Mk ok = point ? *point : live & (status == MPMPC_SOLVED);
     const R cinv = R(1.0) / L::cold_get(C_C);
     R D3[3];
     MPMPC_UNROLL
@@ -706,7 +728,7 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
     for (int e = 0; e < 3; ++e) { xs[e] = sel(ok, L::cold_get(C_XS + e), zero); lam3[e] = sel(ok, L::cold_get(C_LAM + e), zero); }
     nu2[0] = sel(ok, L::cold_get(C_NUS), zero); nu2[1] = sel(ok, L::cold_get(C_NUS + 1), zero);
     const R e_y = D3[0] * xs[0], e_psi = D3[1] * xs[1], kap = D3[2] * xs[2];
-    const R v = sel(ok, L::cold_get(C_V), zero), lam_v = sel(ok, L::cold_get(C_LAMV), zero);
+    const R v = sel(ok, L::cold_get(C_V), zero), lam_v = sel(no_lamv ? ok & !*no_lamv : ok, L::cold_get(C_LAMV), zero);
     // t: row 2 of equality block k is  -t_k + a20 e_y_{k-1} + t_{k-1} + b20 v_{k-1} = beq2_k  (block 0: -t_0 = -x0[2]),
     // a running sum along the stages
     const R drive = fma_(L::cold_get(C_A20), e_y, L::cold_get(C_BV)), beq2 = L::cold_get(C_BEQ2);

@@ -14,6 +14,7 @@ static long long g_emu_count[32];
 #include "mpmpc_core.hpp"
 #include "mpmpc_reduced.hpp"
 #include "mpmpc_reduced_t.hpp"
+#include "mpmpc_reduced_tail.hpp"
 #include "corridor_core.hpp"
 #include "rollout_core.hpp"
 #include <limits>
@@ -99,6 +100,33 @@ static void solve_rnt(const mpmpc_config* cfg, const mpmpc_settings* st, const d
       if (k.v[i] == 0 && inst.v[i] < B && s.status.v[i] == MPMPC_UNSOLVED) tail[1 + tail[0]++] = inst.v[i];
   }
 }
+// mpmpc_reduced_tail_kernel: the reduced-native tail solver on the instances listed in tail; what it leaves UNSOLVED is
+// appended to tail2[1..]
+static int g_emu_lean_tail = 1;          // emu_set_lean_tail: 0 = the general kernel takes the whole tail (as before round 4)
+template <int G, int C>
+static void solve_rn_tail(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
+                          int* status, int* iters, double* resid, double* y, const int* tail, int* tail2) {
+  using L = LaneEmu<G, C>;
+  const int ld = stage_ld(cfg->N);
+  for (int w = 0; w < tail[0]; ++w) {
+    VI inst = VI(tail[1 + w]);
+    VI k = L::stage() - lane_offset(G, C, cfg->N);
+    VI base(0);
+    for (int i = 0; i < EMU_W; ++i) base.v[i] = iters[inst.v[i] * 2 + 1];
+    ReducedTailSolver<L> s;
+    typename L::real fields[MPMPC_NUM_FIELDS];
+    ReducedTailSolver<L>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    s.run(fields, B, inst, k, cfg->N, make_params(*st), base);
+    s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y);
+    for (int i = 0; i < EMU_W; ++i)
+      if (k.v[i] == 0 && inst.v[i] < B && s.status.v[i] == MPMPC_UNSOLVED) tail2[1 + tail2[0]++] = inst.v[i];
+  }
+}
+extern "C" void emu_set_lean_tail(int on) { g_emu_lean_tail = on; }
+extern "C" int emu_reduced_native_tail(const mpmpc_config* cfg, const mpmpc_settings* st) { return reduced_native_tail(*cfg, *st) ? 1 : 0; }
+static int g_emu_tail2 = 0;              // instances the last emu_solve_launch's reduced-native tail solver left to the general kernel
+extern "C" int emu_last_tail2() { return g_emu_tail2; }
+
 static int solve_rnt_g(int G, const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
                        int* status, int* iters, double* resid, double* y, int* tail) {
   const int C = lane_split(64, cfg->N);
@@ -156,6 +184,14 @@ extern "C" int emu_solve_launch(const mpmpc_config* cfg, const mpmpc_settings* s
     if (reduced_native_tt(*cfg, *st) ? solve_rnt_g(G, cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data())
                                      : solve_rn_g(G, cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data())) return -1;
     if (n_tail) *n_tail = tail[0];
+    g_emu_tail2 = tail[0];
+    if (g_emu_lean_tail && !reduced_native_tt(*cfg, *st) && reduced_native_tail(*cfg, *st)) {
+      // the reduced-native tail solver first; the general kernel on what that leaves
+      std::vector<int> tail2(B + 1, 0);
+      solve_rn_tail<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data(), tail2.data());
+      tail.swap(tail2);
+      g_emu_tail2 = tail[0];
+    }
     if (lane_split(64, cfg->N) == 16) SOLVE_G(64, 16, cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 2, tail.data());
     else SOLVE_G(64, 32, cfg, st, qp, B, z, u0, status, iters, resid, y, nullptr, nullptr, 2, tail.data());
     return 0;
