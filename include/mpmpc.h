@@ -177,6 +177,12 @@ int mpmpc_set_settings(mpmpc_handle h, const mpmpc_settings* settings);
  * size (one instance per wave up to 1024 instances, then the smallest of 64 / 32 / 16 that holds the N + 1 stages);
  * 64 / 32 / 16 force that packing (parity tests and tuning; every packing returns the same answers). */
 int mpmpc_set_packing(mpmpc_handle h, int32_t lanes_per_instance);
+/* Which kernel takes the TAIL of a batch launch - the instances the reduced-native kernel could not certify: infeasible,
+ * marginally infeasible and very hard ones.  1 (default) = the reduced-native tail kernel first (phase 1 and one more
+ * attempt of the certified polish on the (e_y, e_psi, kappa) problem, two wavefronts per SIMD; horizons up to 31), the
+ * general kernel only on what that leaves; 0 = the general kernel on the whole tail (one wavefront per SIMD).  Same
+ * statuses; points equal to rounding (parity tests, A/B timings). */
+int mpmpc_set_tail_kernel(mpmpc_handle h, int32_t reduced_native);
 
 /* replaces the per-stage ReferencePath.get_waypoint() / Waypoint.__sub__ reads of
  * src/MPC.py:93-97 (src/reference_path.py:50-57,356-371): per-waypoint kappa, v_ref and the

@@ -598,6 +598,8 @@ struct mpmpc_handle_s {
   bool order_pending = false;      // asynchronous work other than resident solves is queued on `stream`: the next resident launch
                                    // on the OTHER stream has to wait for it (uploads, closed-loop steps: they write what solves read)
   int force_lanes = 0;      // mpmpc_set_packing: 0 = chosen from the batch size
+  // mpmpc_set_tail_kernel (MPMPC_LEAN_TAIL=0 in the environment: off from the start, for A/B timings of whole programs)
+  bool lean_tail = !(std::getenv("MPMPC_LEAN_TAIL") && std::atoi(std::getenv("MPMPC_LEAN_TAIL")) == 0);
   bool resident_y = true;   // mpmpc_set_outputs: do resident launches store the multipliers y (46 % of the output bytes)?
   bool y_valid = false;     // the last solve launch stored y
 };
@@ -905,6 +907,14 @@ int mpmpc_set_packing(mpmpc_handle h, int32_t lanes_per_instance) {
   if (g != 0 && g != 16 && g != 32 && g != 64) return fail(MPMPC_E_ARG, "lanes_per_instance must be 0 (auto), 16, 32 or 64");
   if (g != 0 && h->cfg.N + 1 > g) return fail(MPMPC_E_ARG, "lanes_per_instance must hold the N + 1 stages of an instance");
   h->force_lanes = g;
+  return MPMPC_OK;
+}
+
+int mpmpc_set_tail_kernel(mpmpc_handle h, int32_t reduced_native) {
+  if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  MPMPC_SETTLE(h);
+  if (reduced_native != 0 && reduced_native != 1) return fail(MPMPC_E_ARG, "reduced_native must be 0 or 1");
+  h->lean_tail = reduced_native != 0;
   return MPMPC_OK;
 }
 
@@ -1283,9 +1293,7 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
   else if (rn) { h->tail_flip = 1 - h->tail_flip; h->seq += 1; }
   // The tail of a batch launch goes to the reduced-native tail kernel first (K2p: two waves per SIMD instead of one).  The
   // closed loop keeps the general kernel for the whole tail: its step would pay for a third launch every time.
-  // (MPMPC_LEAN_TAIL=0: the general kernel takes the whole tail, for A/B timings)
-  static const bool lean_off = std::getenv("MPMPC_LEAN_TAIL") && std::atoi(std::getenv("MPMPC_LEAN_TAIL")) == 0;
-  const bool lean = rn && !rnt && !closed_loop && !lean_off && reduced_native_tail(h->cfg, h->st);
+  const bool lean = rn && !rnt && !closed_loop && h->lean_tail && reduced_native_tail(h->cfg, h->st);
 #define LAUNCH_W(CC, WW, FF, MODE, BLOCKS)                                                                                \
   hipLaunchKernelGGL((mpmpc_solve_kernel<64, CC, WW, FF>), dim3(BLOCKS), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, \
                      ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, MODE, tail_cur, WW ? warm_act : nullptr,   \

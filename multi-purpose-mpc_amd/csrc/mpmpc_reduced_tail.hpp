@@ -52,8 +52,9 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
   //   T_LV0 .. 2     least-violation point of a marginal instance while the attempt runs (three slots nothing else uses)
   enum { T_RAW = 32, T_NAX = 36, T_RD0 = 37, T_LV0 = RS::C_GAP, T_LV1 = RS::K_PP + 2, T_LV2 = RS::K_QQ + 2 };
 
-  Mk ray;          // verdict "infeasible": the slots hold the least-violation point and the ray
-  Mk bare;         // a marginal instance whose attempt failed: the slots hold the least-violation point, no multipliers
+  // (No mask of this solver lives through the attempt: "marginal" is read back from T_LV0, and the store tells a ray -
+  //  status PRIMAL_INFEASIBLE of a non-empty box - and a bare least-violation point - SOLVED_INACCURATE that no attempt
+  //  certified - from the status and the `polished` flag.)
 
   // ================================================================================ setup: the FULL problem's scaling
   MPMPC_HD void setup_full(const R* fields, int B, const I& inst, const I& k, int N_, const SolverParams& st) {
@@ -79,7 +80,8 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
       gap = L::gmax(gap);
       empty = live & (gap > zero);
       solvable = live & !empty;
-      pri_res = gap;          // (kept in a register here: the slot C_GAP serves as T_LV0)
+      pri_res = gap;          // (kept in a register here: the slot C_GAP serves as T_LV0 ...
+      L::cold_put(T_LV0, zero);      //  ... whose lanes without a stage say "marginal" by holding a violation, see run())
     }
     L::cold_put(T_RAW + 0, lo_e); L::cold_put(T_RAW + 1, hi_e); L::cold_put(T_RAW + 2, lo_k); L::cold_put(T_RAW + 3, hi_k);
     {
@@ -151,14 +153,14 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
     setup_full(fields, B, inst, k, N_, st);
     MPMPC_TICK_END(0);
     const R zero(0.0), one(1.0);
-    const R gap = pri_res;
-    status = I(MPMPC_UNSOLVED);
-    iters = I(st.early_polish);
+    // (an empty box - never in a tail list, the first launch reports it - is infeasible with a zero ray and the width of the
+    //  gap as its violation; nothing below touches such an instance)
+    status = seli(empty, I(MPMPC_PRIMAL_INFEASIBLE), I(MPMPC_UNSOLVED));
     ipm_iters = base_ipm;
     polished = I(0);
-    pri_res = dua_res = zero;
+    pri_res = sel(empty, pri_res, zero);
+    dua_res = zero;
     this->act_bits = I(0);
-    ray = bare = L::mfalse();
     const Mk todo = solvable;
     if (L::wany(todo)) {
       Box3 b3;
@@ -271,8 +273,9 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
             L::cold_put(e == 0 ? K_LO0 : K_LO2, (Ebe * lo1) / ge);
             L::cold_put(e == 0 ? K_HI0 : K_HI2, (Ebe * hi1) / ge);
           }
-          MPMPC_UNROLL
-          for (int e = 0; e < 3; ++e) L::cold_put(e == 0 ? T_LV0 : (e == 1 ? T_LV1 : T_LV2), xs[e]);
+          // (... and the violation rides on the lanes of T_LV0 that hold no stage - the wave has 64 lanes for at most 32
+          //  stages - instead of in a register through the attempt)
+          L::cold_put(T_LV0, sel(vx, xs[0], prim)); L::cold_put(T_LV1, xs[1]); L::cold_put(T_LV2, xs[2]);
           L::fence();
           RS::make_box3(b3);
         }
@@ -286,7 +289,6 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
         pri_res = sel(cert, prim, pri_res);
         dua_res = sel(cert, zero, dua_res);
         status = seli(cert, I(MPMPC_PRIMAL_INFEASIBLE), status);
-        ray = cert;
       }
       // ---- feasible to tolerance (phase 1 converged, its point violates nothing) or marginal: one more attempt of the
       //      certified polish, from phase 1's point - inside every box it can be inside of, well centred
@@ -295,32 +297,36 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
         MPMPC_UNROLL
         for (int e = 0; e < 3; ++e) x3[e] = xs[e];
         const R rd0v = L::cold_get(T_RD0);
-        (void)RS::template attempts<false>(b3, st, st.ipm_max_iter, retry, false, &rd0v);
+        // (one instance per wave: inside this branch "retry" is the instance itself)
+        (void)RS::template attempts<false>(b3, st, st.ipm_max_iter, solvable, false, &rd0v);
         // a marginal instance ends here: the optimum over the relaxed boxes, or - if the attempt could not certify that -
         // phase 1's least-violation point itself; either way a usable, inaccurate plan
-        const Mk mg = marginal & ((status == MPMPC_SOLVED) | (status == MPMPC_UNSOLVED));
-        bare = marginal & (status == MPMPC_UNSOLVED);
-        if (L::wany(bare)) {
-          L::fence();
+        L::fence();
+        const R viol = L::gmax(sel(vx, zero, L::cold_get(T_LV0)));        // > 0: the instance was marginal
+        const Mk mg = (viol > zero) & ((status == MPMPC_SOLVED) | (status == MPMPC_UNSOLVED));
+        if (L::wany(mg)) {
+          const Mk bare = mg & (status == MPMPC_UNSOLVED);
           const R lv[3] = {L::cold_get(T_LV0), L::cold_get(T_LV1), L::cold_get(T_LV2)};
           L::fence();
-          MPMPC_UNROLL
-          for (int e = 0; e < 3; ++e) { L::cold_put(C_XS + e, lv[e]); L::cold_put(C_LAM + e, zero); }
-          L::cold_put(C_NUS, zero); L::cold_put(C_NUS + 1, zero);
-          L::fence();
+          if (L::wany(bare)) {
+            MPMPC_UNROLL
+            for (int e = 0; e < 3; ++e) { L::cold_put(C_XS + e, sel(val[e], lv[e], zero)); L::cold_put(C_LAM + e, zero); }
+            L::cold_put(C_NUS, zero); L::cold_put(C_NUS + 1, zero);
+            L::fence();
+          }
+          status = seli(mg, I(MPMPC_SOLVED_INACCURATE), status);
+          pri_res = sel(mg, viol, pri_res);
         }
-        status = seli(mg, I(MPMPC_SOLVED_INACCURATE), status);
-        pri_res = sel(mg, prim, pri_res);
       }
     }
-    status = seli(empty, I(MPMPC_PRIMAL_INFEASIBLE), status);
-    pri_res = sel(empty, gap, pri_res);
+    iters = I(st.early_polish);      // (the ADMM iteration of the first launch's early attempt: Solver::run, mode 2)
   }
 
   MPMPC_HD void store(const I& inst, const I& k, double wheelbase, double* z, double* u0, int* st_out, int* it_out,
                       double* resid, double* y) const {
+    const Mk ray = (status == MPMPC_PRIMAL_INFEASIBLE) & !empty;
     const Mk point = live & ((status == MPMPC_SOLVED) | (status == MPMPC_SOLVED_INACCURATE) | ray);
-    const Mk no_lamv = ray | bare;
+    const Mk no_lamv = ray | ((status == MPMPC_SOLVED_INACCURATE) & (polished != 1));
     RS::store(inst, k, wheelbase, z, u0, st_out, it_out, resid, y, nullptr, 0, &point, &no_lamv);
   }
 };

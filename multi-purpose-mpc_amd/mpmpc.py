@@ -130,6 +130,7 @@ def load_library(path: str | None = None):
     lib.mpmpc_destroy.argtypes = [h]
     lib.mpmpc_set_settings.argtypes = [h, C.POINTER(Settings)]
     lib.mpmpc_set_packing.argtypes = [h, C.c_int32]
+    lib.mpmpc_set_tail_kernel.argtypes = [h, C.c_int32]
     lib.mpmpc_set_pipeline.argtypes = [h, C.c_int32]
     lib.mpmpc_set_path.argtypes = [h, C.c_int32, _dp, _dp, _dp]
     lib.mpmpc_set_corridor.argtypes = [h, C.c_int32, C.c_int32, _dp, _dp]
@@ -164,7 +165,7 @@ def load_library(path: str | None = None):
 
 
 EXPORTS = ["mpmpc_version", "mpmpc_last_error", "mpmpc_device_count", "mpmpc_default_settings",
-           "mpmpc_create", "mpmpc_destroy", "mpmpc_set_settings", "mpmpc_set_packing", "mpmpc_set_path", "mpmpc_set_corridor",
+           "mpmpc_create", "mpmpc_destroy", "mpmpc_set_settings", "mpmpc_set_packing", "mpmpc_set_tail_kernel", "mpmpc_set_path", "mpmpc_set_corridor",
            "mpmpc_set_map", "mpmpc_set_path_geometry", "mpmpc_build_corridor", "mpmpc_rollout_init",
            "mpmpc_rollout_step", "mpmpc_rollout_set_counters", "mpmpc_rollout_warm_start", "mpmpc_rollout_state", "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident", "mpmpc_set_outputs", "mpmpc_set_pipeline",
            "mpmpc_sync", "mpmpc_download", "mpmpc_solve_resident_timed", "mpmpc_solve_resident_profile", "mpmpc_speed_profile", "mpmpc_staging",
@@ -227,6 +228,11 @@ class Handle:
     def set_packing(self, lanes_per_instance: int = 0):
         """0 = automatic; 64 / 32 / 16 force that many lanes of a wavefront per instance (tests, tuning)."""
         self._check(self.lib.mpmpc_set_packing(self._h, int(lanes_per_instance)))
+
+    def set_tail_kernel(self, reduced_native: bool = True):
+        """True (default): the reduced-native tail kernel takes the tail of a batch launch first; False: the general kernel
+        takes all of it (parity tests, A/B timings)."""
+        self._check(self.lib.mpmpc_set_tail_kernel(self._h, 1 if reduced_native else 0))
 
     def set_path(self, kappa, v_ref, ds_next):
         k, v, d = (np.ascontiguousarray(a, dtype=np.float64) for a in (kappa, v_ref, ds_next))

@@ -95,6 +95,9 @@ def test_reduced_native_kernels_fit_two_waves_per_simd(lib):
     # ... and so must its twin for weightings with a terminal cost on the time state (BASELINE config 3)
     tt = [r for r in _kernel_rows(lib) if r["name"].startswith("mpmpc_reduced_t_kernel")]
     assert sorted(r["name"] for r in tt) == ["mpmpc_reduced_t_kernel<64, 16>", "mpmpc_reduced_t_kernel<64, 32>"], tt
+    tail = [r for r in _kernel_rows(lib) if r["name"].startswith("mpmpc_reduced_tail_kernel")]
+    assert [r["name"] for r in tail] == ["mpmpc_reduced_tail_kernel<64, 16>"], tail
+    assert tail[0]["vgpr"] <= 256 and tail[0]["agpr"] == 0 and tail[0]["lds"] <= 20 * 1024 and tail[0]["scratch"] <= 8, tail
     for r in rows + tt:
         assert r["scratch"] == 0, r
         assert r["vgpr"] <= 256 and r["agpr"] == 0, r
@@ -110,8 +113,13 @@ def test_no_batch_path_solve_kernel_has_scratch(lib):
     KNOWN_SCRATCH = {
         "mpmpc_solve_kernel<64, 32, false, 0>": 124, "mpmpc_solve_kernel<64, 32, true, 0>": 232,
         "mpmpc_solve_kernel<64, 32, false, 1>": 184, "mpmpc_solve_kernel<64, 32, true, 1>": 288,
+        # the reduced-native tail kernel: ONE dword (a lane mask the compiler keeps as 0 / 1 in a VGPR), stored once before
+        # and read once inside each attempt of a tail instance - 10 % of a config-4 batch; its two-waves-per-SIMD budget
+        # (256 registers, 20 KB of LDS) is asserted in test_reduced_native_kernels_fit_two_waves_per_simd
+        "mpmpc_reduced_tail_kernel<64, 16>": 8,
     }       # (the shipped values, profiles/r4/kernel_resources.txt: a regression of a single dword fails)
-    rows = [r for r in _kernel_rows(lib) if "solve_kernel" in r["name"] or "reduced_kernel" in r["name"] or "reduced_t_kernel" in r["name"]]
+    rows = [r for r in _kernel_rows(lib) if "solve_kernel" in r["name"] or "reduced_kernel" in r["name"] or "reduced_t_kernel" in r["name"]
+            or "reduced_tail_kernel" in r["name"]]
     assert rows
     bad = {r["name"]: r["scratch"] for r in rows if r["scratch"] > KNOWN_SCRATCH.get(r["name"], 0)}
     assert not bad, bad

@@ -484,3 +484,84 @@ def test_cyclic_reduction_of_the_32_lane_chains_agrees_with_the_sequential_elimi
     assert ta == tb and np.array_equal(a.status, b.status) and np.array_equal(a.iters, b.iters)
     ok = a.status == 1
     assert ok.sum() >= 30 and np.abs(a.z[ok] - b.z[ok]).max() <= 1e-9 and np.abs(a.u0[ok] - b.u0[ok]).max() <= 1e-10
+
+
+@pytest.mark.parametrize("cfgid,B,N,accept", [(4, 768, 30, 1), (4, 384, 30, 0), (5, 512, 30, 1), (4, 192, 10, 1), (4, 96, 3, 1)])
+def test_reduced_native_tail_solver_gives_the_general_kernels_answers(cfgid, B, N, accept, emu, track):
+    """The tail of a reduced-native launch goes to ReducedTailSolver (mpmpc_reduced_tail.hpp: phase 1 and one more attempt of
+    the certified polish, three entries per lane) before the general kernel sees it.  Same launch with the general kernel on
+    the whole tail (emu_set_lean_tail(0), the sequence of rounds 2 - 3): statuses identical; points, multipliers and residuals
+    equal to rounding - the two run the same interior point on the same scaling; and the tail solver leaves the general
+    kernel nothing on these batches (infeasible, marginally infeasible and capped instances are all it gets)."""
+    import ctypes as C
+    sc = scenarios.make(cfgid, track, B=B, N=N)
+    cfg = T.stock_config(sc.N, sc.weights)
+    qp = emu.assemble(cfg, track, _inputs(sc))
+    st = mpmpc.default_settings(phase1_accept=accept)
+    assert emu.lib.emu_reduced_native_tail(C.byref(cfg), C.byref(st)) == 1
+    try:
+        emu.lib.emu_set_lean_tail(0)
+        gen, n_tail = emu.solve_launch(cfg, st, qp, G=32 if N + 1 <= 32 else 64)
+        assert emu.lib.emu_last_tail2() == n_tail            # (knob off: the general kernel gets the whole tail)
+    finally:
+        emu.lib.emu_set_lean_tail(1)
+    lean, n_tail2 = emu.solve_launch(cfg, st, qp, G=32 if N + 1 <= 32 else 64)
+    assert n_tail2 == n_tail and n_tail >= 3
+    assert emu.lib.emu_last_tail2() == 0
+    assert np.array_equal(lean.status, gen.status)
+    assert np.count_nonzero(lean.status == mpmpc.PRIMAL_INFEASIBLE) >= 2
+    if accept and N == 30:
+        assert np.count_nonzero(lean.status == mpmpc.SOLVED_INACCURATE) >= 2
+    np.testing.assert_allclose(lean.z, gen.z, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(lean.u0, gen.u0, rtol=0, atol=1e-12)
+    scale = np.maximum(1.0, np.abs(gen.y).max(axis=1, keepdims=True))
+    assert np.max(np.abs(lean.y - gen.y) / scale) <= 1e-12
+    np.testing.assert_allclose(lean.resid, gen.resid, rtol=1e-9, atol=1e-15)
+    assert np.array_equal(lean.iters[:, 0], gen.iters[:, 0])
+    # (interior-point iterations: the attempt after phase 1 runs ReducedSolver's tolerance ladder, not Solver::polish's)
+    assert np.max(np.abs(lean.iters[:, 1] - gen.iters[:, 1])) <= 4
+
+
+def test_reduced_native_tail_solver_applies_to_the_split_layout_only(emu):
+    """Horizons above 31 (one lane per stage, no free half-wave) keep the general kernel for their tail."""
+    import ctypes as C
+    st = mpmpc.default_settings()
+    for N, want in ((3, 1), (30, 1), (31, 1), (32, 0), (50, 0)):
+        cfg = T.stock_config(N, "stock")
+        assert emu.lib.emu_reduced_native_tail(C.byref(cfg), C.byref(st)) == want, N
+    cfg = T.stock_config(30, "time_optimal")           # the terminal-time weights have their own kernel, and the general tail
+    assert emu.lib.emu_reduced_native_tail(C.byref(cfg), C.byref(st)) == 0
+    off = mpmpc.default_settings(phase1=0)
+    assert emu.lib.emu_reduced_native_tail(C.byref(T.stock_config(30, "stock")), C.byref(off)) == 0
+
+
+def test_reduced_native_tail_solver_fallbacks(emu, track):
+    """The two ways out of ReducedTailSolver that the BASELINE batches do not take, forced with as_rounds = 0 (no active-set
+    round: no attempt can certify anything).  A marginally infeasible instance then ends with phase 1's least-violation point
+    itself - status SOLVED_INACCURATE, zero multipliers, the violation in resid[0]; a feasible instance stays UNSOLVED in the
+    tail solver and goes on to the general kernel (full OSQP run).  Both exactly as with the general kernel on the whole tail."""
+    sc = scenarios.make(4, track, B=512)
+    cfg = T.stock_config(sc.N, sc.weights)
+    qp = emu.assemble(cfg, track, _inputs(sc))
+    base, _ = emu.solve_launch(cfg, mpmpc.default_settings(), qp, G=32)
+    pick = np.concatenate([np.flatnonzero(base.status == 2)[:3], np.flatnonzero(base.status == mpmpc.PRIMAL_INFEASIBLE)[:2],
+                           np.flatnonzero(base.status == 1)[:3]])
+    assert pick.size == 8
+    qps = np.ascontiguousarray(qp[:, pick, :])
+    st = mpmpc.default_settings(as_rounds=0)
+    try:
+        emu.lib.emu_set_lean_tail(0)
+        gen, n_tail = emu.solve_launch(cfg, st, qps, G=32)
+    finally:
+        emu.lib.emu_set_lean_tail(1)
+    lean, n_tail2 = emu.solve_launch(cfg, st, qps, G=32)
+    assert n_tail == n_tail2 == 8
+    assert emu.lib.emu_last_tail2() == 3                   # the three feasible instances
+    assert list(lean.status) == [2, 2, 2, mpmpc.PRIMAL_INFEASIBLE, mpmpc.PRIMAL_INFEASIBLE, 2, 2, 2] == list(gen.status)
+    assert np.all(lean.iters[5:, 0] > 25) and np.all(lean.iters[:5, 0] == 1)
+    assert np.array_equal(lean.iters, gen.iters)
+    np.testing.assert_allclose(lean.z, gen.z, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(lean.y, gen.y, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(lean.resid, gen.resid, rtol=1e-12, atol=0)
+    assert np.all(lean.y[:3] == 0.0)                       # a bare least-violation point carries no multipliers
+    assert np.all((lean.resid[:3, 0] > 1e-4) & (lean.resid[:3, 0] < 8e-3))

@@ -1039,3 +1039,84 @@ def test_empty_speed_box_is_reported_at_once_on_device(native, track):
     assert np.all(sol.status[4:] == 1)
     alone = h.solve(sc.wp_id[4:], sc.x0[4:], cc[4:], sc.lb[4:], sc.ub[4:])
     assert np.array_equal(alone.status, sol.status[4:]) and np.max(np.abs(alone.u0 - sol.u0[4:])) <= 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfgid,B,accept", [(4, 4096, 1), (5, 2048, 1), (4, 1024, 0)])
+def test_reduced_native_tail_kernel_gives_the_general_kernels_answers(cfgid, B, accept, track):
+    """K2p (mpmpc_reduced_tail_kernel) takes the tail of a batch launch before the general kernel does.  The same launch
+    with mpmpc_set_tail_kernel(h, 0) - the general kernel on the whole tail, the sequence of rounds 2 - 3: statuses identical,
+    points / multipliers / residuals equal to rounding (same interior point, same scaling), for one launch at a time and for
+    pipelined resident launches."""
+    sc = scenarios.make(cfgid, track, B=B)
+    st = mpmpc.default_settings(phase1_accept=accept)
+    res = {}
+    for lean in (True, False):
+        h = _handle(track, sc.N, sc.weights, B, settings=st)
+        h.set_tail_kernel(lean)
+        h.set_outputs(True)
+        one = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+        h.upload(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+        for _ in range(7):
+            h.solve_resident(B)
+        many = h.download(B, want_y=True)
+        assert np.array_equal(one.status, many.status)
+        np.testing.assert_allclose(many.z, one.z, rtol=0, atol=1e-9)      # (a packed wave's partner differs between the two paths)
+        res[lean] = one
+    a, b = res[True], res[False]
+    assert np.array_equal(a.status, b.status)
+    assert (a.status == mpmpc.PRIMAL_INFEASIBLE).sum() >= 20
+    if accept:
+        assert (a.status == mpmpc.SOLVED_INACCURATE).sum() >= 5
+    np.testing.assert_allclose(a.z, b.z, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(a.u0, b.u0, rtol=0, atol=1e-12)
+    scale = np.maximum(1.0, np.abs(b.y).max(axis=1, keepdims=True))
+    assert np.max(np.abs(a.y - b.y) / scale) <= 1e-12
+    np.testing.assert_allclose(a.resid, b.resid, rtol=1e-9, atol=1e-15)
+    assert np.array_equal(a.iters[:, 0], b.iters[:, 0])
+
+
+@pytest.mark.gpu
+def test_what_the_tail_kernel_leaves_reaches_the_general_kernel_also_when_deferred(track):
+    """Second level of the deferred tail: the general kernel's launch on what K2p leaves is not enqueued while the launches
+    the host has seen leave nothing there.  With as_rounds = 0 nothing can be certified by an attempt, so every feasible
+    instance falls through K2p to the general kernel's full OSQP run: a handle that has learned "K2p leaves nothing" on the
+    default settings must still deliver those results (late, at the download), exactly as a fresh handle does."""
+    B = 192
+    sc = scenarios.make(4, track, B=B)
+    hard = mpmpc.default_settings(as_rounds=0)
+    fresh = _handle(track, sc.N, sc.weights, B, settings=hard)
+    ref = fresh.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+    assert (ref.iters[:, 0] > 25).sum() >= 100 and (ref.status == mpmpc.PRIMAL_INFEASIBLE).sum() >= 3
+    old = _handle(track, sc.N, sc.weights, B, settings=hard)
+    old.set_tail_kernel(False)
+    gen = old.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+    assert np.array_equal(gen.status, ref.status) and np.array_equal(gen.iters[:, 0], ref.iters[:, 0])
+    np.testing.assert_allclose(ref.z, gen.z, rtol=0, atol=1e-12)
+
+    def same(a, b):
+        assert np.array_equal(a.status, b.status) and np.array_equal(a.iters, b.iters)
+        assert np.array_equal(a.z, b.z) and np.array_equal(a.u0, b.u0) and np.array_equal(a.resid, b.resid) and np.array_equal(a.y, b.y)
+
+    h = _handle(track, sc.N, sc.weights, B)
+    h.set_outputs(True)
+    dflt = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+    assert (dflt.iters[:, 0] == 1).all()
+    h.upload(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    for _ in range(3):                                   # the tail is there every time, K2p leaves nothing: learned
+        h.solve_resident(B)
+        h.sync()
+    same(h.download(B, want_y=True), dflt)
+    h.set_settings(hard)
+    h.solve_resident(B)                                  # K2p's leftovers: their launch is deferred ...
+    same(h.download(B, want_y=True), ref)                # ... and runs here
+    for _ in range(3):                                   # eager again, pipelined
+        h.solve_resident(B)
+    h.sync()
+    same(h.download(B, want_y=True), ref)
+    h.set_settings(mpmpc.default_settings())
+    for _ in range(2):
+        h.solve_resident(B)
+        h.sync()
+    same(h.download(B, want_y=True), dflt)
+    same(h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True), dflt)
