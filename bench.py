@@ -113,9 +113,11 @@ def algorithm_text(cfg, settings):
     if native_path(cfg, settings):
         return ("reduced-native kernel per instance: speed in closed form, one Ruiz pass, interior point from x = 0 (no OSQP iterate "
                 "is computed: iters[:, 0] = 1 marks the attempt), active-set round(s), KKT certificate on the (e_y, e_psi, kappa) QP, roll-forward of t; "
-                "uncertified instances go to a tail launch: phase 1 (Farkas ray) and, only if that cannot decide, the OSQP ADMM iteration "
-                "(the tail launch is enqueued with the step while the launches seen so far leave a tail, otherwise only when a launch "
-                "turns out to need it - checked at every sync, inside the timed region)")
+                "uncertified instances go to a tail launch of the reduced-native tail kernel (horizons up to 31; two waves per SIMD like "
+                "the first kernel): phase 1 (Farkas ray / least-violation point) and one more attempt; only what that cannot decide goes "
+                "on to the general kernel and the OSQP ADMM iteration (each tail launch is enqueued with the step while the launches "
+                "seen so far leave something for it, otherwise only when a launch turns out to need it - checked at every sync, inside "
+                "the timed region)")
     red = "reduced 2x2-block" if reduced_polish(cfg, settings) else "full 3x3-block"
     return ("general kernel per instance: %d Ruiz pass(es), %s, %s interior point + active-set round(s) + KKT "
             "certificate; phase 1 (Farkas ray) and then the full OSQP ADMM run for what that cannot certify" %
@@ -225,7 +227,7 @@ def stock_osqp_leg(tr, sc, ref, seconds=3.0):
         return {"available": True, "note": "stock-osqp leg failed: %r" % (e,)}
 
 
-def pmc_traffic_bytes(kernel_prefix, B, lib_version):
+def pmc_traffic_bytes(kernel_prefix, B, lib_version, config=2):
     """HBM bytes per launch of one kernel from the committed rocprofv3 PMC summary of THIS command
     (profiles/r4/pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  The summary records the source hash of the library it was measured
@@ -233,6 +235,8 @@ def pmc_traffic_bytes(kernel_prefix, B, lib_version):
     (with the reason) - a counter reading of another kernel is not this run's traffic."""
     path = os.path.join(ROOT, "profiles", "r4", "pmc_summary.json")
     key_f, key_w = ("pmc_fetch", "pmc_write") if B == 1024 else ("pmc_fetch_b%d" % B, "pmc_write_b%d" % B)
+    if config != 2:
+        key_f, key_w = "pmc_fetch_cfg%d" % config, "pmc_write_cfg%d" % config
     try:
         d = json.load(open(path))
     except Exception:
@@ -243,7 +247,17 @@ def pmc_traffic_bytes(kernel_prefix, B, lib_version):
     try:
         f = next(v for k, v in d[key_f].items() if k.startswith(kernel_prefix))["FETCH_SIZE"]["mean"]
         w = next(v for k, v in d[key_w].items() if k.startswith(kernel_prefix))["WRITE_SIZE"]["mean"]
-        return (2.0 * f + w) * 1024.0, "profiles/r4/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same library sources %s)" % src
+        note = ""
+        # a launch that leaves a tail also runs its tail kernel(s): their bytes belong to the launch (one tail launch per launch)
+        for tk in ("mpmpc_reduced_tail_kernel", "mpmpc_solve_kernel"):
+            if tk == kernel_prefix or config == 2:
+                continue
+            tf = [v["FETCH_SIZE"]["mean"] for k, v in d[key_f].items() if k.startswith(tk)]
+            tw = [v["WRITE_SIZE"]["mean"] for k, v in d[key_w].items() if k.startswith(tk)]
+            if tf and tw:
+                f, w, note = f + tf[0], w + tw[0], note + " + " + tk
+        return (2.0 * f + w) * 1024.0, "profiles/r4/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of %s%s, same library sources %s)" % (
+            kernel_prefix, note, src)
     except Exception:
         return None, "profiles/r4/pmc_summary.json has no counters for this kernel at B = %d" % B
 
@@ -547,14 +561,14 @@ def _main(real_stdout):
         nat = native_path(cfg, settings)
         k2_name = "mpmpc_reduced_t_kernel" if nat_tt else ("mpmpc_reduced_kernel" if nat else "mpmpc_solve_kernel")
         nat = nat or nat_tt
-        traffic, traffic_src = pmc_traffic_bytes(k2_name, B, lib_version) if args.config == 2 else (None, "PMC passes are collected for config 2 only")
+        traffic, traffic_src = pmc_traffic_bytes(k2_name, B, lib_version, args.config)
         # ms_k2: average duration of a launch of the timed pattern (HIP events around each launch on its own stream; with two
         # launches in flight each takes longer than alone and two run side by side); span: first start to last end of the
         # n_prof launches.  `achieved` is the chip's rate over that region - algorithmic bytes of all its launches / span -
         # which with one launch in flight is bytes / avg_ms.
         prof_ms, prof_src = rocprof_kernel_average(args.config, B, lib_version)
         chip_rate = bytes_k2 * n_prof / (span * 1e-3)
-        out["roofline"] = {"bound": "hbm", "kernel": k2_name + (" (+ tail launch of mpmpc_solve_kernel where a launch leaves a tail)" if nat else ""),
+        out["roofline"] = {"bound": "hbm", "kernel": k2_name + (" (+ tail launches where a launch leaves a tail: mpmpc_reduced_tail_kernel, then mpmpc_solve_kernel on what that leaves)" if nat else ""),
                            "achieved": chip_rate / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": chip_rate / HBM_PEAK,
                            "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes": bytes_k2, "bytes_per_solve": algorithmic_bytes_per_solve(N),

@@ -33,5 +33,10 @@ BENCH_ARGS="--config 5 --steps 20 --warmup 2" prof trace_cfg5 --kernel-trace --s
 BENCH_ARGS="--batch 65536 --steps 5 --warmup 1" prof trace_b65536 --kernel-trace --stats
 BENCH_ARGS="--batch 65536 --steps 3 --warmup 1 $PMC" prof pmc_fetch_b65536 --pmc FETCH_SIZE
 BENCH_ARGS="--batch 65536 --steps 3 --warmup 1 $PMC" prof pmc_write_b65536 --pmc WRITE_SIZE
+# HBM traffic of the other BASELINE configurations (one launch of config 3 / 4 / 5 = the reduced-native kernel + its tail kernel)
+for c in 3 4 5; do
+  BENCH_ARGS="--config $c --steps 5 --warmup 1 $PMC" prof pmc_fetch_cfg$c --pmc FETCH_SIZE
+  BENCH_ARGS="--config $c --steps 5 --warmup 1 $PMC" prof pmc_write_cfg$c --pmc WRITE_SIZE
+done
 lscpu | grep -E "Model name|^CPU\(s\)" > "$O/host.txt"
 ls "$O"

@@ -17,6 +17,8 @@ import scenarios        # noqa: E402
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 tr = scenarios.sim_track()
 em = T.Emul()
+if os.environ.get("MPMPC_LEAN_TAIL") == "0":      # the general kernel on the whole tail, on both sides
+    em.lib.emu_set_lean_tail(0)
 worst, n_inst, bad, notes = 0.0, 0, 0, 0
 for trial in range(40):
     N = int(rng.choice([3, 4, 7, 10, 15, 16, 17, 24, 30, 31, 32, 33, 40, 45, 50]))
@@ -42,7 +44,10 @@ for trial in range(40):
         emu, _ = em.solve_launch(cfg, st, qp, G=G)
         # (phase 1 of an infeasible instance may stop one iteration apart: the device's reciprocals are 1-ulp seeds + Newton,
         #  the emulation divides; the verdict and its certificate are what must agree)
-        it_ok = (dev.iters == emu.iters).all(axis=1) | ((dev.status == -3) & (np.abs(dev.iters - emu.iters).max(axis=1) <= 1))
+        #  ... and since round 4 the step length is sized with the reciprocal's SEED on the device (rcp_fast_), so a certified
+        #  solve may take an interior-point iteration or two more or fewer than in the emulation: same status, same point)
+        it_ok = (dev.iters == emu.iters).all(axis=1) | ((dev.status == -3) & (np.abs(dev.iters - emu.iters).max(axis=1) <= 1)) | \
+                ((dev.status == emu.status) & (dev.iters[:, 0] == emu.iters[:, 0]) & (np.abs(dev.iters[:, 1] - emu.iters[:, 1]) <= 2))
         same = np.array_equal(dev.status, emu.status) and bool(it_ok.all())
         notes += int((~(dev.iters == emu.iters).all(axis=1)).sum())
         ok = dev.status == 1
@@ -66,5 +71,5 @@ for trial in range(40):
                 print("   instance %d: device status %d iters %s | emulation status %d iters %s" % (i, dev.status[i], dev.iters[i], emu.status[i], emu.iters[i]))
     n_inst += B
     h.close()
-print("trials 40, instances %d, mismatches %d, worst |device - emulation| %.2e, phase-1 iteration counts one apart: %d" % (n_inst, bad, worst, notes))
+print("trials 40, instances %d, mismatches %d, worst |device - emulation| %.2e, interior-point iteration counts apart (same status, same point): %d" % (n_inst, bad, worst, notes))
 sys.exit(1 if bad else 0)

@@ -32,7 +32,8 @@ try:
 except Exception as e:
     print("no library version in the profiled bench line:", e)
 for name in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_fetch_b65536", "pmc_write_b65536", "pmc_sq1_cfg4", "pmc_sq2_cfg4",
-             "pmc_sq1_b65536", "pmc_sq2_b65536"):
+             "pmc_sq1_b65536", "pmc_sq2_b65536", "pmc_fetch_cfg3", "pmc_write_cfg3", "pmc_fetch_cfg4", "pmc_write_cfg4", "pmc_fetch_cfg5",
+             "pmc_write_cfg5"):
     fs = glob.glob(os.path.join(O, name, "*", "*counter_collection.csv"))
     if not fs:
         continue
@@ -62,7 +63,8 @@ for src, wl in (("trace", "bench_cfg2"), ("trace_b65536", "bench_cfg2_b65536"), 
     rows = [r for r in csv.DictReader(open(max(fs, key=os.path.getmtime)))
             if "mpmpc_reduced" in r["Kernel_Name"] or "mpmpc_solve_kernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    first = [r for r in rows if "mpmpc_reduced" in r["Kernel_Name"]] or rows         # one per step: the step's first kernel
+    # one per step: the step's first kernel (not the tail kernels, which carry "reduced" in their name as well)
+    first = [r for r in rows if "mpmpc_reduced_kernel" in r["Kernel_Name"] or "mpmpc_reduced_t_kernel" in r["Kernel_Name"]] or rows
     skip, n = int(line.get("prewarm", 300)) + int(line["warmup"]), int(line["steps"]) * int(line.get("repeats", 1))
     win = first[skip:skip + n]
     if len(win) < n:
