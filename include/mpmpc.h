@@ -317,6 +317,10 @@ int mpmpc_solve_resident_timed(mpmpc_handle h, int32_t B, float* ms_assemble, fl
  * HIP events on its own stream: ms_each[n] = duration of every launch with the other slot's launch beside it on the chip,
  * *ms_span (may be NULL) = first start to last end.  What rocprofv3 --kernel-trace reports for the same loop. */
 int mpmpc_solve_resident_profile(mpmpc_handle h, int32_t B, int32_t n, float* ms_each, float* ms_span);
+/* n launches of the stand-alone assembly kernel K1 (what mpmpc_assemble runs, without its download) back to back on the
+ * handle's stream, each between two HIP events: ms_each[n].  mpmpc_solve_resident_timed times K1 right after a solve launch,
+ * whose dirty output lines K1's writes then push out of the cache; this is K1 on its own. */
+int mpmpc_assemble_resident_timed(mpmpc_handle h, int32_t B, int32_t n, float* ms_each);
 
 /* ---- speed profile (K4): replaces ReferencePath.compute_speed_profile, src/reference_path.py:289-354,
  * the reference's second OSQP call site, for B paths of n + 1 waypoints at once (no handle needed):

@@ -201,6 +201,7 @@ struct LaneEmu {
   static void cold_put(int slot, const VD& a) { cold()[slot] = a; }
   static VD cold_get(int slot) { return cold()[slot]; }
   static void fence() {}
+  static void sched_barrier() {}
 
   // output rows: the device stages them in LDS and writes them coalesced; same memory image here
   template <class F>
@@ -214,6 +215,10 @@ struct LaneEmu {
   static VI loadi(const int* p, const VI& idx, const VB& ok, int dflt) {
     VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = ok.v[i] ? p[idx.v[i]] : dflt; return r;
   }
+  template <class F>
+  static void when(const VB& /*ok*/, F f) { f(); }          // (every store inside carries its own mask)
+  static VD gather(const double* p, const VI& idx, const VB& ok, double dflt) { return load(p, idx, ok, dflt); }
+  static VI gatheri(const int* p, const VI& idx, const VB& ok, int dflt) { return loadi(p, idx, ok, dflt); }
   static void store(double* p, const VI& idx, const VB& ok, const VD& a) {
     for (int i = 0; i < EMU_W; ++i) if (ok.v[i]) p[idx.v[i]] = a.v[i];
   }

@@ -239,6 +239,8 @@ struct LaneGpu {
   static __device__ __forceinline__ double cold_get(int slot) { return cold()[slot * 64 + lane_id()]; }
   // compiler-level fence: values parked before it are re-read after it, not kept in registers
   static __device__ __forceinline__ void fence() { asm volatile("" ::: "memory"); }
+  // scheduling barrier: the instruction scheduler moves nothing across it (K1: every field is stored when it is formed)
+  static __device__ __forceinline__ void sched_barrier() { __builtin_amdgcn_sched_barrier(0); }
 
   // Output rows (rowlen doubles per instance, instance-major in dst): the lanes drop their entries
   // into the wave's LDS buffer at their place in the row, then the wave writes the 64/G rows it owns
@@ -264,6 +266,19 @@ struct LaneGpu {
   }
   static __device__ __forceinline__ int loadi(const int* p, int idx, bool ok, int dflt) {
     return ok ? p[idx] : dflt;
+  }
+  // run f on the lanes where ok holds, as ONE divergent region (the masked stores inside it need no branch of their own)
+  template <class F>
+  static __device__ __forceinline__ void when(bool ok, F f) { if (ok) f(); }
+  // the same reads without a branch around each: a lane that has nothing to read reads element 0 and drops it, so that
+  // the loads of a gather go out back to back and are waited for once (K1 is made of such gathers; p[0] must exist)
+  static __device__ __forceinline__ double gather(const double* p, int idx, bool ok, double dflt) {
+    const double v = p[ok ? idx : 0];
+    return ok ? v : dflt;
+  }
+  static __device__ __forceinline__ int gatheri(const int* p, int idx, bool ok, int dflt) {
+    const int v = p[ok ? idx : 0];
+    return ok ? v : dflt;
   }
   static __device__ __forceinline__ void store(double* p, int idx, bool ok, double a) {
     if (ok) p[idx] = a;

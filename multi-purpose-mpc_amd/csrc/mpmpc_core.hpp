@@ -62,40 +62,50 @@ struct StageIn {
   Mk first, has_u, terminal;   // k == 0, k < N, k == N
 };
 
+// put(f, value) receives the fields one by one, in the order they are formed: K2 collects them in registers (assemble_stage),
+// K1 stores each at once (assemble_lane) - 27 values never wait for each other in registers there.
+// the curvature-dependent speed cap of src/MPC.py:84,111-113 from the previous plan's entries
 template <class L>
-MPMPC_HD void assemble_stage(const mpmpc_config& c, const StageIn<L>& in, typename L::real out[MPMPC_NUM_FIELDS]) {
+MPMPC_HD typename L::real speed_cap(const mpmpc_config& c, const typename L::real& cc_a, const typename L::real& cc_last) {
+  using R = typename L::real;
+  R kp = tan_(cc_a + cc_last) / R(c.wheelbase);
+  R vmax = sqrt_(R(c.ay_max) / (abs_(kp) + R(1e-12)));
+  R umax0(c.umax[0]);
+  return sel(vmax < umax0, vmax, umax0);
+}
+// hi_v_pre: the speed cap if the caller has formed it already (K1 does, before it gathers anything else: the tangent is the
+// register peak of the stage), else nullptr
+template <class L, class Put>
+MPMPC_HD void assemble_stage_to(const mpmpc_config& c, const StageIn<L>& in, Put&& put, const typename L::real* hi_v_pre = nullptr) {
   using R = typename L::real;
   const R zero(0.0), one(1.0);
   // linearize(v_ref, kappa_ref, delta_s), same operation order as the reference
   R a10 = (-(in.kap * in.kap)) * in.ds;
   R a20 = ((-in.kap) / in.v) * in.ds;
   R b20 = ((-one) / (in.v * in.v)) * in.ds;
-  out[F_DS] = sel(in.has_u, in.ds, zero);
-  out[F_A10] = sel(in.has_u, a10, zero);
-  out[F_A20] = sel(in.has_u, a20, zero);
-  out[F_B20] = sel(in.has_u, b20, zero);
+  put(F_DS, sel(in.has_u, in.ds, zero));
+  put(F_A10, sel(in.has_u, a10, zero));
+  put(F_A20, sel(in.has_u, a20, zero));
+  put(F_B20, sel(in.has_u, b20, zero));
   // rhs of equality block k: -x0, or uq_{k-1} = B [v, kappa] - f   (src/MPC.py:107-108)
   R b20p = ((-one) / (in.v_p * in.v_p)) * in.ds_p;
   R f2p = (one / in.v_p) * in.ds_p;
-  out[F_BEQ + 0] = sel(in.first, -in.x0[0], zero);
-  out[F_BEQ + 1] = sel(in.first, -in.x0[1], in.ds_p * in.kap_p);
-  out[F_BEQ + 2] = sel(in.first, -in.x0[2], b20p * in.v_p - f2p);
+  put(F_BEQ + 0, sel(in.first, -in.x0[0], zero));
+  put(F_BEQ + 1, sel(in.first, -in.x0[1], in.ds_p * in.kap_p));
+  put(F_BEQ + 2, sel(in.first, -in.x0[2], b20p * in.v_p - f2p));
   // state boxes (src/MPC.py:81-82,119-122)
-  out[F_LO + 0] = sel(in.first, in.x0[0], in.lbk);
-  out[F_HI + 0] = sel(in.first, in.x0[0], in.ubk);
-  out[F_LO + 1] = R(c.xmin[1]);
-  out[F_HI + 1] = R(c.xmax[1]);
-  out[F_LO + 2] = R(c.xmin[2]);
-  out[F_HI + 2] = R(c.xmax[2]);
+  put(F_LO + 0, sel(in.first, in.x0[0], in.lbk));
+  put(F_HI + 0, sel(in.first, in.x0[0], in.ubk));
+  put(F_LO + 1, R(c.xmin[1]));
+  put(F_HI + 1, R(c.xmax[1]));
+  put(F_LO + 2, R(c.xmin[2]));
+  put(F_HI + 2, R(c.xmax[2]));
   // input boxes with the curvature-dependent speed cap (src/MPC.py:84,111-113)
-  R kp = tan_(in.cc_a + in.cc_last) / R(c.wheelbase);
-  R vmax = sqrt_(R(c.ay_max) / (abs_(kp) + R(1e-12)));
-  R umax0(c.umax[0]);
-  R hi_v = sel(vmax < umax0, vmax, umax0);
-  out[F_LO + 3] = sel(in.has_u, R(c.umin[0]), R(-INFTY));
-  out[F_HI + 3] = sel(in.has_u, hi_v, R(INFTY));
-  out[F_LO + 4] = sel(in.has_u, R(c.umin[1]), R(-INFTY));
-  out[F_HI + 4] = sel(in.has_u, R(c.umax[1]), R(INFTY));
+  R hi_v = hi_v_pre ? *hi_v_pre : speed_cap<L>(c, in.cc_a, in.cc_last);
+  put(F_LO + 3, sel(in.has_u, R(c.umin[0]), R(-INFTY)));
+  put(F_HI + 3, sel(in.has_u, hi_v, R(INFTY)));
+  put(F_LO + 4, sel(in.has_u, R(c.umin[1]), R(-INFTY)));
+  put(F_HI + 4, sel(in.has_u, R(c.umax[1]), R(INFTY)));
   // cost (src/MPC.py:125,150-155): references are the corridor centre for e_y, (v_ref, kappa_ref) for u
   R xr0 = sel(in.first, zero, (in.lbk + in.ubk) / R(2.0));
   MPMPC_UNROLL
@@ -103,13 +113,17 @@ MPMPC_HD void assemble_stage(const mpmpc_config& c, const StageIn<L>& in, typena
     R xr = (i == 0) ? xr0 : zero;
     // terminal stage: -QN . xr with xr = (xr0, 0, 0), i.e. minus the first column of QN times xr0 (src/MPC.py:154)
     const double qn_i0 = i == 0 ? c.QN[0] : c.QN_offdiag[i - 1];
-    out[F_Q + i] = sel(in.terminal, -(R(qn_i0) * xr0), R(-c.Q[i]) * xr);
-    out[F_P + i] = sel(in.terminal, R(c.QN[i]), R(c.Q[i]));
+    put(F_Q + i, sel(in.terminal, -(R(qn_i0) * xr0), R(-c.Q[i]) * xr));
+    put(F_P + i, sel(in.terminal, R(c.QN[i]), R(c.Q[i])));
   }
-  out[F_Q + 3] = sel(in.has_u, R(-c.R[0]) * in.v, zero);
-  out[F_Q + 4] = sel(in.has_u, R(-c.R[1]) * in.kap, zero);
-  out[F_P + 3] = sel(in.has_u, R(c.R[0]), one);
-  out[F_P + 4] = sel(in.has_u, R(c.R[1]), one);
+  put(F_Q + 3, sel(in.has_u, R(-c.R[0]) * in.v, zero));
+  put(F_Q + 4, sel(in.has_u, R(-c.R[1]) * in.kap, zero));
+  put(F_P + 3, sel(in.has_u, R(c.R[0]), one));
+  put(F_P + 4, sel(in.has_u, R(c.R[1]), one));
+}
+template <class L>
+MPMPC_HD void assemble_stage(const mpmpc_config& c, const StageIn<L>& in, typename L::real out[MPMPC_NUM_FIELDS]) {
+  assemble_stage_to<L>(c, in, [&](int f, const typename L::real& v) { out[f] = v; });
 }
 
 // Per-path tables uploaded once per handle (device pointers in the library, host pointers in
@@ -128,40 +142,48 @@ struct PathTables {
 // stage-blocked as qp[(field * B + inst) * ld + k] (consecutive lanes -> consecutive addresses).
 // (assemble_fields: the 27 fields in registers - what the solve kernel goes on with; assemble_lane: K1, stores them)
 template <class L>
-MPMPC_HD void assemble_fields(const mpmpc_config& c, const PathTables& t, int B, const typename L::ival& inst,
-                              const typename L::ival& k, const int* wp_id, const double* x0, const double* cc,
-                              const double* lb, const double* ub, typename L::real* out) {
+MPMPC_HD void gather_stage(const mpmpc_config& c, const PathTables& t, int B, const typename L::ival& inst,
+                           const typename L::ival& k, const int* wp_id, const double* x0, const double* cc,
+                           const double* lb, const double* ub, StageIn<L>& in, bool with_cc = true) {
   using R = typename L::real;
   using Mk = typename L::mask;
   using I = typename L::ival;
   const int N = c.N;
   Mk ok = (inst < B) & (k >= 0) & (k <= N);        // (K2 keeps lanes before stage 0: lane_offset)
-  StageIn<L> in;
   in.first = (k == 0);
   in.has_u = ok & (k < N);
   in.terminal = (k == N);
-  I wp = L::loadi(wp_id, inst, ok, 0);
+  I wp = L::gatheri(wp_id, inst, ok, 0);
   I ik = wp + k, ip = maxi(wp + k - 1, 0);
   if (c.circular) { ik = modi(ik, t.n_wp); ip = modi(ip, t.n_wp); }
   else { ik = mini(ik, t.n_wp - 1); ip = mini(ip, t.n_wp - 1); }
-  in.kap = L::load(t.kappa, ik, ok, 0.0);
-  in.v = L::load(t.v_ref, ik, ok, 1.0);
-  in.ds = L::load(t.ds_next, ik, ok, 0.0);
-  in.kap_p = L::load(t.kappa, ip, ok, 0.0);
-  in.v_p = L::load(t.v_ref, ip, ok, 1.0);
-  in.ds_p = L::load(t.ds_next, ip, ok, 0.0);
+  in.kap = L::gather(t.kappa, ik, ok, 0.0);
+  in.v = L::gather(t.v_ref, ik, ok, 1.0);
+  in.ds = L::gather(t.ds_next, ik, ok, 0.0);
+  in.kap_p = L::gather(t.kappa, ip, ok, 0.0);
+  in.v_p = L::gather(t.v_ref, ip, ok, 1.0);
+  in.ds_p = L::gather(t.ds_next, ip, ok, 0.0);
   MPMPC_UNROLL
-  for (int i = 0; i < 3; ++i) in.x0[i] = L::load(x0, inst * 3 + i, ok, 0.0);
-  in.cc_a = L::load(cc, inst * (2 * N) + k + 3, in.has_u, 0.0);
-  in.cc_last = L::load(cc, inst * (2 * N) + (2 * N - 1), ok, 0.0);
+  for (int i = 0; i < 3; ++i) in.x0[i] = L::gather(x0, inst * 3 + i, ok, 0.0);
+  if (with_cc) {
+    in.cc_a = L::gather(cc, inst * (2 * N) + k + 3, in.has_u, 0.0);
+    in.cc_last = L::gather(cc, inst * (2 * N) + (2 * N - 1), ok, 0.0);
+  }
   Mk inner = ok & (k >= 1);
   if (lb != nullptr) {
-    in.lbk = L::load(lb, inst * N + k - 1, inner, 0.0);
-    in.ubk = L::load(ub, inst * N + k - 1, inner, 0.0);
+    in.lbk = L::gather(lb, inst * N + k - 1, inner, 0.0);
+    in.ubk = L::gather(ub, inst * N + k - 1, inner, 0.0);
   } else {
-    in.lbk = L::load(t.lb_tab, wp * t.n_cols + k - 1, inner, 0.0);
-    in.ubk = L::load(t.ub_tab, wp * t.n_cols + k - 1, inner, 0.0);
+    in.lbk = L::gather(t.lb_tab, wp * t.n_cols + k - 1, inner, 0.0);
+    in.ubk = L::gather(t.ub_tab, wp * t.n_cols + k - 1, inner, 0.0);
   }
+}
+template <class L>
+MPMPC_HD void assemble_fields(const mpmpc_config& c, const PathTables& t, int B, const typename L::ival& inst,
+                              const typename L::ival& k, const int* wp_id, const double* x0, const double* cc,
+                              const double* lb, const double* ub, typename L::real* out) {
+  StageIn<L> in;
+  gather_stage<L>(c, t, B, inst, k, wp_id, x0, cc, lb, ub, in);
   assemble_stage<L>(c, in, out);
 }
 template <class L>
@@ -170,12 +192,24 @@ MPMPC_HD void assemble_lane(const mpmpc_config& c, const PathTables& t, int B, i
                             const double* lb, const double* ub, double* qp) {
   using R = typename L::real;
   using I = typename L::ival;
-  R out[MPMPC_NUM_FIELDS];
-  assemble_fields<L>(c, t, B, inst, k, wp_id, x0, cc, lb, ub, out);
-  typename L::mask ok = (inst < B) & (k >= 0) & (k <= c.N);
-  I base = inst * ld + k;
-  MPMPC_UNROLL
-  for (int f = 0; f < MPMPC_NUM_FIELDS; ++f) L::store(qp, base + f * (B * ld), ok, out[f]);
+  const typename L::mask ok = (inst < B) & (k >= 0) & (k <= c.N);
+  StageIn<L> in;
+  // the speed cap first, on its own: its tangent is the register peak of the stage, and nothing else is held while it runs
+  in.cc_a = L::gather(cc, inst * (2 * c.N) + k + 3, ok & (k < c.N), 0.0);
+  in.cc_last = L::gather(cc, inst * (2 * c.N) + (2 * c.N - 1), ok, 0.0);
+  const R hi_v = speed_cap<L>(c, in.cc_a, in.cc_last);
+  L::sched_barrier();
+  gather_stage<L>(c, t, B, inst, k, wp_id, x0, cc, lb, ub, in, false);
+  const I base = inst * ld + k;
+  // The row of an instance is written up to the end of the last 128-byte line it touches (zeros behind stage N): N = 30 uses
+  // 31 of a row's 32 doubles, and a line that misses its last 8 bytes is a partial write - a read-modify-write in the memory
+  // system - for every second line of the output.
+  const int kfill = ((c.N + 1 + 15) / 16) * 16 < ld ? ((c.N + 1 + 15) / 16) * 16 : ld;
+  const typename L::mask okw = (inst < B) & (k >= 0) & (k < kfill);
+  // (one divergent region around all 27 stores: a branch around each would put a wait for the store before it at every join)
+  L::when(okw, [&] {
+    assemble_stage_to<L>(c, in, [&](int f, const R& v) { L::store(qp, base + f * (B * ld), okw, sel(ok, v, R(0.0))); L::sched_barrier(); }, &hi_v);
+  });
 }
 
 // ------------------------------------------------------------------------------------------

@@ -54,12 +54,20 @@ constexpr int K1_LDS_WP = 1024;   // path tables of up to this many waypoints ar
 // non-temporal ones 33 - 38 %.  Two stages per thread with 16-byte stores were measured as well (166 registers) and were slower
 // than either.  The 55 % asked for at B = 65 536 is NOT reached in the median: this kernel is off the solve path (the solve
 // launches build their QP in registers).
+// (-DMPMPC_K1_WAVES=w: occupancy experiments, profiles/k1_occupancy.py)
+#ifdef MPMPC_K1_WAVES
+#define MPMPC_K1_OCC __attribute__((amdgpu_waves_per_eu(MPMPC_K1_WAVES, MPMPC_K1_WAVES)))
+#else
+#define MPMPC_K1_OCC
+#endif
 template <bool NT>
-__global__ __launch_bounds__(K1_THREADS) void mpmpc_assemble_kernel(
+__global__ __launch_bounds__(K1_THREADS) MPMPC_K1_OCC void mpmpc_assemble_kernel(
     mpmpc_config cfg, PathTables tab, int B, int ld, const int* __restrict__ wp_id, const double* __restrict__ x0,
     const double* __restrict__ cc, const double* __restrict__ lb, const double* __restrict__ ub,
     double* __restrict__ qp) {
-  __shared__ double s_kappa[K1_LDS_WP], s_vref[K1_LDS_WP], s_ds[K1_LDS_WP];
+  // (dynamic LDS: 3 x n_wp doubles when the tables are staged - a 200-waypoint lap takes 4.8 KB of a block, not 24)
+  extern __shared__ double s_tab[];
+  double *s_kappa = s_tab, *s_vref = s_tab + tab.n_wp, *s_ds = s_tab + 2 * tab.n_wp;
   PathTables t = tab;
   if (tab.n_wp <= K1_LDS_WP) {   // block-uniform
     for (int i = threadIdx.x; i < tab.n_wp; i += K1_THREADS) {
@@ -72,11 +80,15 @@ __global__ __launch_bounds__(K1_THREADS) void mpmpc_assemble_kernel(
     t.v_ref = s_vref;
     t.ds_next = s_ds;
   }
-  // grid-stride over (instance, stage) pairs, stage fastest: a wavefront writes 64 consecutive
-  // doubles of one field
+  // one thread per (instance, stage) pair, stage fastest: a wavefront writes 64 consecutive doubles of one field.
+  // NO grid-stride loop: around a loop the compiler keeps every constant of the stage (the tangent's polynomial, the
+  // configuration's doubles) in registers - 109 of them, four waves per SIMD; without it 48 and eight waves per SIMD,
+  // and what bounds this kernel is how many waves have their stores in flight (profiles/micro/k1_pattern.hip: the store
+  // pattern alone reaches 77 % of the HBM peak)
   using L = LaneGpu<64>;
   const int total = B * ld;
-  for (int g = blockIdx.x * K1_THREADS + threadIdx.x; g < total; g += gridDim.x * K1_THREADS) {
+  const int g = blockIdx.x * K1_THREADS + threadIdx.x;
+  if (g < total) {
     const int inst = g / ld, k = g - inst * ld;
     if constexpr (!NT) {
       assemble_lane<L>(cfg, t, B, ld, inst, k, wp_id, x0, cc, lb, ub, qp);
@@ -1222,14 +1234,13 @@ int mpmpc_upload(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* 
 static int launch_assemble(mpmpc_handle h, int B) {
   PathTables t{h->kappa, h->v_ref, h->ds_next, h->n_wp, h->ub_tab, h->lb_tab, h->n_cols};
   const int total = B * h->ld;
-  int blocks = (total + K1_THREADS - 1) / K1_THREADS;
-  // (tuning knobs of profiles/k1_timing.py: MPMPC_K1_BLOCKS = cap of the grid, MPMPC_K1_NT = 0 / 1 forces plain / non-temporal stores)
-  static const int cap = std::getenv("MPMPC_K1_BLOCKS") ? std::atoi(std::getenv("MPMPC_K1_BLOCKS")) : 8192;
+  const int blocks = (total + K1_THREADS - 1) / K1_THREADS;
+  // (tuning knob of profiles/k1_timing.py: MPMPC_K1_NT = 1 forces non-temporal stores)
   static const int force_nt = std::getenv("MPMPC_K1_NT") ? std::atoi(std::getenv("MPMPC_K1_NT")) : -1;
-  if (blocks > cap) blocks = cap;          // 256 CUs x 8 blocks x 4 rounds, grid-stride beyond that
   const bool nt = force_nt > 0;
+  const size_t k1_lds = h->n_wp <= K1_LDS_WP ? 3 * sizeof(double) * (size_t)h->n_wp : 0;
 #define K1_LAUNCH(V)                                                                                                       \
-  hipLaunchKernelGGL(mpmpc_assemble_kernel<V>, dim3(blocks), dim3(K1_THREADS), 0, h->stream, h->cfg, t, B, h->ld, h->wp_id, \
+  hipLaunchKernelGGL(mpmpc_assemble_kernel<V>, dim3(blocks), dim3(K1_THREADS), k1_lds, h->stream, h->cfg, t, B, h->ld, h->wp_id, \
                      h->x0, h->cc, h->have_rows ? h->lb : nullptr, h->have_rows ? h->ub : nullptr, h->qp)
   if (nt) K1_LAUNCH(true);
   else K1_LAUNCH(false);
@@ -1518,6 +1529,29 @@ int mpmpc_solve_resident_profile(mpmpc_handle h, int32_t B, int32_t n, float* ms
       *ms_span = last;
     }
   }
+  for (auto& e : ev)
+    if (e) (void)hipEventDestroy(e);
+  return rc;
+}
+
+int mpmpc_assemble_resident_timed(mpmpc_handle h, int32_t B, int32_t n, float* ms_each) {
+  if (!h || !ms_each) return fail(MPMPC_E_ARG, "NULL argument");
+  if (n < 1 || n > 4096) return fail(MPMPC_E_ARG, "n must be in [1, 4096]");
+  MPMPC_SETTLE(h);
+  if (B < 1 || B > h->uploaded) return fail(MPMPC_E_STATE, "B exceeds the uploaded batch");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  std::vector<hipEvent_t> ev((size_t)n + 1, nullptr);
+  int rc = MPMPC_OK;
+  for (auto& e : ev)
+    if (hipEventCreate(&e) != hipSuccess) { rc = fail(MPMPC_E_HIP, "hipEventCreate"); break; }
+  if (rc == MPMPC_OK && hipEventRecord(ev[0], h->stream) != hipSuccess) rc = fail(MPMPC_E_HIP, "hipEventRecord");
+  for (int i = 0; i < n && rc == MPMPC_OK; ++i) {
+    rc = launch_assemble(h, B);
+    if (rc == MPMPC_OK && hipEventRecord(ev[i + 1], h->stream) != hipSuccess) rc = fail(MPMPC_E_HIP, "hipEventRecord");
+  }
+  if (rc == MPMPC_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(MPMPC_E_HIP, "hipStreamSynchronize");
+  for (int i = 0; i < n && rc == MPMPC_OK; ++i)
+    if (hipEventElapsedTime(&ms_each[i], ev[i], ev[i + 1]) != hipSuccess) rc = fail(MPMPC_E_HIP, "hipEventElapsedTime");
   for (auto& e : ev)
     if (e) (void)hipEventDestroy(e);
   return rc;

@@ -153,6 +153,7 @@ def load_library(path: str | None = None):
     lib.mpmpc_download.argtypes = [h, C.c_int32, _dp, _dp, _ip, _ip, _dp, _dp]
     lib.mpmpc_solve_resident_timed.argtypes = [h, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.mpmpc_solve_resident_profile.argtypes = [h, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.mpmpc_assemble_resident_timed.argtypes = [h, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
     lib.mpmpc_speed_profile.argtypes = [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_double, _dp, _ip, _ip]
     _ipp, _dpp = C.POINTER(_ip), C.POINTER(_dp)
     lib.mpmpc_staging.argtypes = [h, C.c_int32, _ipp, _dpp, _dpp, _dpp, _dpp, _dpp, _dpp, _ipp, _ipp, _dpp, _dpp]
@@ -168,7 +169,7 @@ EXPORTS = ["mpmpc_version", "mpmpc_last_error", "mpmpc_device_count", "mpmpc_def
            "mpmpc_create", "mpmpc_destroy", "mpmpc_set_settings", "mpmpc_set_packing", "mpmpc_set_tail_kernel", "mpmpc_set_path", "mpmpc_set_corridor",
            "mpmpc_set_map", "mpmpc_set_path_geometry", "mpmpc_build_corridor", "mpmpc_rollout_init",
            "mpmpc_rollout_step", "mpmpc_rollout_set_counters", "mpmpc_rollout_warm_start", "mpmpc_rollout_state", "mpmpc_assemble", "mpmpc_stage_ld", "mpmpc_solve", "mpmpc_upload", "mpmpc_solve_resident", "mpmpc_set_outputs", "mpmpc_set_pipeline",
-           "mpmpc_sync", "mpmpc_download", "mpmpc_solve_resident_timed", "mpmpc_solve_resident_profile", "mpmpc_speed_profile", "mpmpc_staging",
+           "mpmpc_sync", "mpmpc_download", "mpmpc_solve_resident_timed", "mpmpc_solve_resident_profile", "mpmpc_assemble_resident_timed", "mpmpc_speed_profile", "mpmpc_staging",
            "mpmpc_solve_staged", "mpmpc_staged_begin", "mpmpc_staged_end"]
 
 
@@ -411,6 +412,12 @@ class Handle:
         span = C.c_float()
         self._check(self.lib.mpmpc_solve_resident_profile(self._h, B, n, each.ctypes.data_as(C.POINTER(C.c_float)), C.byref(span)))
         return each.astype(float), span.value
+
+    def assemble_timed(self, B, n):
+        """n launches of the stand-alone assembly kernel K1 back to back, HIP events around each -> durations [n] in ms"""
+        each = np.zeros(n, np.float32)
+        self._check(self.lib.mpmpc_assemble_resident_timed(self._h, B, n, each.ctypes.data_as(C.POINTER(C.c_float))))
+        return each.astype(float)
 
 
 def device_count() -> int:

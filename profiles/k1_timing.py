@@ -26,9 +26,10 @@ for B in (8192, 65536):
     print("blocks %%s nt %%s B %%6d: K1 min %%.4f med %%.4f ms -> %%.3f / %%.3f of 8 TB/s" %% (os.environ.get("MPMPC_K1_BLOCKS"), os.environ.get("MPMPC_K1_NT"), B, min(ks), np.median(ks), byts / min(ks) / 1e-3 / 8e12, byts / np.median(ks) / 1e-3 / 8e12))
     h.close()
 ''' % (ROOT, ROOT)
+# (the grid-size knob MPMPC_K1_BLOCKS of the first version of this script is gone with the kernel's grid-stride loop: see
+#  profiles/k1_occupancy.py and profiles/r4/k1_occupancy.txt for what replaced that experiment)
 for rep in range(2):
-    for blocks in ("2048", "8192", "32768"):
-        for nt in ("0", "1"):
-            env = dict(os.environ, MPMPC_K1_BLOCKS=blocks, MPMPC_K1_NT=nt)
-            sys.stdout.write(subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True).stdout)
-            sys.stdout.flush()
+    for nt in ("0", "1"):
+        env = dict(os.environ, MPMPC_K1_NT=nt)
+        sys.stdout.write(subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True).stdout)
+        sys.stdout.flush()

@@ -111,8 +111,8 @@ def test_no_batch_path_solve_kernel_has_scratch(lib):
     configurations (N >= 32 with bounded e_psi / t or a full terminal weight) - with the bytes measured when they were
     listed: the test fails if one of them grows or a new one appears."""
     KNOWN_SCRATCH = {
-        "mpmpc_solve_kernel<64, 32, false, 0>": 124, "mpmpc_solve_kernel<64, 32, true, 0>": 232,
-        "mpmpc_solve_kernel<64, 32, false, 1>": 184, "mpmpc_solve_kernel<64, 32, true, 1>": 288,
+        "mpmpc_solve_kernel<64, 32, false, 0>": 116, "mpmpc_solve_kernel<64, 32, true, 0>": 236,
+        "mpmpc_solve_kernel<64, 32, false, 1>": 192, "mpmpc_solve_kernel<64, 32, true, 1>": 288,
         # the reduced-native tail kernel: ONE dword (a lane mask the compiler keeps as 0 / 1 in a VGPR), stored once before
         # and read once inside each attempt of a tail instance - 10 % of a config-4 batch; its two-waves-per-SIMD budget
         # (256 registers, 20 KB of LDS) is asserted in test_reduced_native_kernels_fit_two_waves_per_simd
