@@ -4,11 +4,16 @@
 //                               LDS-staged path tables, builds the stage's dynamics blocks,
 //                               offsets, bounds and cost terms, stores them stage-blocked
 //                               ([field][instance][stage], unit-stride across lanes).  HBM bound.
-//   K2  mpmpc_solve_kernel<G>   one 64-lane wavefront per 64/G instances, lane = horizon stage;
-//                               Ruiz scaling, OSQP ADMM, certified polish, all state in VGPRs,
+//   K2  mpmpc_solve_kernel      the general solve kernel, one 64-lane wavefront per instance, lane = horizon stage;
+//                               Ruiz scaling, OSQP ADMM, certified polish, phase 1, all state in VGPRs,
 //                               stage coupling by DPP shifts, norms by wavefront reductions.
-//                               FP64-VALU bound (time = instructions x 2.9 ns); builds its QP per lane with
+//                               FP64-VALU issue bound; builds its QP per lane with
 //                               K1's code and keeps it in registers: HBM sees the batch inputs and the solution.
+//   K2r mpmpc_reduced_kernel    the batch path of the reference's own weights: the (e_y, e_psi, kappa) problem only, 1 / 2 / 4
+//                               instances per wavefront, <= 256 registers and 20 KB of LDS: two wavefronts per SIMD
+//   K2t mpmpc_reduced_t_kernel  its twin for a terminal cost on the time state (rank-one term, Sherman-Morrison)
+//   K2p mpmpc_reduced_tail_kernel  the tail of a K2r launch (infeasible / marginal / capped instances) on the same footing:
+//                               phase 1 and one more attempt; K2 takes what it leaves
 //   K0 / K3 / K4                corridor tables from the map, closed-loop rollout, speed profile (see below).
 //
 // No CPU path exists in this library: every compute entry point needs a HIP device.
@@ -47,13 +52,12 @@ using namespace mpmpc;
 constexpr int K1_THREADS = 256;
 constexpr int K1_LDS_WP = 1024;   // path tables of up to this many waypoints are staged in LDS
 
-// NT: non-temporal stores (tuning knob MPMPC_K1_NT=1; off by default).  Same-box A/B (profiles/k1_timing.py,
-// profiles/r4/k1_timing.txt; medians of 30 launches): while the stage-blocked QP of the batch fits the 256 MB Infinity Cache
-// (B = 8 192: 69 MB) plain stores reach 56 % of the HBM peak, non-temporal ones 40 - 47 %; beyond it (B = 65 536: 550 MB) plain
-// stores with a grid of 8 192 blocks 39 % (best launch 54 %; the 2 048-block grid of round 3: 37 - 38 %, best 47 %),
-// non-temporal ones 33 - 38 %.  Two stages per thread with 16-byte stores were measured as well (166 registers) and were slower
-// than either.  The 55 % asked for at B = 65 536 is NOT reached in the median: this kernel is off the solve path (the solve
-// launches build their QP in registers).
+// NT: non-temporal stores (tuning knob MPMPC_K1_NT=1; off by default: same-box A/B, profiles/k1_timing.py - they are slower at
+// every size, and so were 16-byte stores with two stages per thread).  Where the kernel stands (profiles/r4/k1_occupancy.txt):
+// 60 % of the HBM peak at B = 8 192 and 59 % in the median at B = 65 536 (550 MB per launch), since its rows are written to the
+// end of their last 128-byte line (assemble_lane: N = 30 fills 31 of 32 doubles, and partial lines cost it a third of its rate:
+// 39 % before).  The store pattern alone reaches 77 % (profiles/micro/k1_pattern.hip).  Off the solve path: the solve launches
+// build their QP in registers with the same code.
 // (-DMPMPC_K1_WAVES=w: occupancy experiments, profiles/k1_occupancy.py)
 #ifdef MPMPC_K1_WAVES
 #define MPMPC_K1_OCC __attribute__((amdgpu_waves_per_eu(MPMPC_K1_WAVES, MPMPC_K1_WAVES)))

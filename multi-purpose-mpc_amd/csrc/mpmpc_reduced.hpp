@@ -15,7 +15,8 @@
 // multiplier is -(R0 v + q_v) with the sign its clip gives it, the time rows hold to rounding with zero multipliers, and
 // tests/ check every answer against the FULL problem's KKT system with numpy (mpmpc_testlib.kkt_batch).
 // What it cannot certify - infeasible and very hard instances - keeps status UNSOLVED: the launcher appends it to the
-// tail list, and the general one-instance-per-wave kernel (mode 2: phase 1, full OSQP run) decides it.
+// tail list, and the reduced-native tail solver (mpmpc_reduced_tail.hpp: phase 1 and one more attempt, same footing) decides
+// it; what even that leaves goes to the general one-instance-per-wave kernel (mode 2: phase 1, full OSQP run).
 //
 // Replaces, per instance: MPC._init_problem + osqp setup/solve (src/MPC.py:61-159,183) for the default settings.
 #pragma once
