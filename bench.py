@@ -642,6 +642,31 @@ def _main(real_stdout):
                                                   "call here) and reads u0 / status / z there; controls_only: z is not copied back"}
         except mpmpc.MpmpcError as e:          # batches above the staging limit have no staging blocks
             out["host_buffers_staged"] = {"value": None, "note": str(e)}
+        # ... and a STREAM of such calls, three in flight on this device (multi-purpose-mpc_amd/streamed.py: three handles take
+        # the batches in turn through mpmpc_staged_begin / mpmpc_staged_end): upload, launch and download of consecutive
+        # batches overlap
+        try:
+            import streamed
+            sb = streamed.StreamedBatches(cfg, settings, depth=3, copy=False)      # results read in place, like the staged call above
+            sb.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+            rates, agree = {}, True
+            for key, want_z in (("value", True), ("value_controls_only", False)):
+                for s_ in sb.map([(wp, x0, cc, lb, ub)] * 4, want_z=want_z):        # lay the staging blocks out, warm up
+                    pass
+                t1 = time.perf_counter()
+                n_s = 0
+                for s_ in sb.map([(wp, x0, cc, lb, ub)] * 24, want_z=want_z):
+                    n_s += 1
+                    agree = agree and bool(np.array_equal(s_.status, sol.status) and np.array_equal(s_.u0, sol.u0))
+                rates[key] = n_s * B / (time.perf_counter() - t1)
+            sb.close()
+            out["host_buffers_streamed"] = {"value": rates["value"], "value_controls_only": rates["value_controls_only"], "unit": "solves/s",
+                                            "calls_in_flight": 3, "same_answers_as_resident_path": agree,
+                                            "note": "PCIe-inclusive: 24 host-buffer batches through StreamedBatches (3 handles on this device "
+                                                    "in turn, each call = fill the pinned block, mpmpc_staged_begin, ..., mpmpc_staged_end; the "
+                                                    "results are read in the pinned block)"}
+        except mpmpc.MpmpcError as e:
+            out["host_buffers_streamed"] = {"value": None, "note": str(e)}
         if not args.no_cpu and world == 1:        # (the CPU baseline and the parity legs run on rank 0 at N = 1 only)
             sc_rank = scenarios.Scenario(sc_all.name, N, sc_all.weights, sc_all.obstacles, wp, x0, cc, lb, ub)
             base, ref = cpu_baseline(tr, sc_rank)

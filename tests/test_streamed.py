@@ -1,0 +1,107 @@
+"""StreamedBatches (multi-purpose-mpc_amd/streamed.py): several host-buffer calls in flight on one device, results in submission
+order.  CPU: the ordering logic with emulation-backed stand-ins for the handles; GPU: real handles against mpmpc_solve."""
+import numpy as np
+import pytest
+
+import mpmpc
+import mpmpc_testlib as T
+import scenarios
+import streamed
+
+
+class _EmuStagedHandle:
+    """the staging / staged_begin / staged_end surface of mpmpc.Handle on the CPU emulation: begin remembers, end solves"""
+
+    def __init__(self, emu, cfg, settings, track):
+        self.emu, self.cfg, self.st, self.track = emu, cfg, settings, track
+        self.v, self.pending, self.calls = None, None, 0
+
+    def set_path(self, *a):
+        pass
+
+    def staging(self, B):
+        N = self.cfg.N
+        n, m = 5 * N + 3, 8 * N + 6
+        self.v = dict(wp_id=np.zeros(B, np.int32), x0=np.zeros((B, 3)), cc_prev=np.zeros((B, 2 * N)), lb=np.zeros((B, N)), ub=np.zeros((B, N)),
+                      z=np.zeros((B, n)), u0=np.zeros((B, 2)), status=np.zeros(B, np.int32), iters=np.zeros((B, 2), np.int32),
+                      resid=np.zeros((B, 2)), y=np.zeros((B, m)))
+        return self.v
+
+    def staged_begin(self, B, with_rows=True, want_z=True, want_y=False):
+        assert self.pending is None, "one call in flight per handle"
+        self.pending = (B, want_z, want_y)
+        self.calls += 1
+
+    def staged_end(self):
+        B, want_z, want_y = self.pending
+        self.pending = None
+        v = self.v
+        qp = self.emu.assemble(self.cfg, self.track, (v["wp_id"], v["x0"], v["cc_prev"], v["lb"], v["ub"]))
+        sol, _ = self.emu.solve_launch(self.cfg, self.st, qp, G=64)
+        v["z"][:] = sol.z; v["u0"][:] = sol.u0; v["status"][:] = sol.status; v["iters"][:] = sol.iters; v["resid"][:] = sol.resid; v["y"][:] = sol.y
+
+
+def _batches(track, n, B):
+    out = []
+    for i in range(n):
+        sc = scenarios.make(4 if i % 2 else 2, track, B=B)
+        r = np.random.default_rng(100 + i).permutation(B)
+        out.append((sc.wp_id[r], sc.x0[r], sc.cc_prev[r], sc.lb[r], sc.ub[r]))
+    return out, sc
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_streamed_batches_come_back_in_order(depth, emu, track):
+    B = 6
+    batches, sc = _batches(track, 7, B)
+    cfg = T.stock_config(sc.N, sc.weights, max_batch=B)
+    st = mpmpc.default_settings()
+    hs = [_EmuStagedHandle(emu, cfg, st, track) for _ in range(depth)]
+    sb = streamed.StreamedBatches(handles=hs)
+    got = list(sb.map(batches, want_y=True))
+    assert len(got) == len(batches) and sum(h.calls for h in hs) == len(batches)
+    assert max(h.calls for h in hs) - min(h.calls for h in hs) <= 1          # round robin
+    for b, s in zip(batches, got):
+        qp = emu.assemble(cfg, track, b)
+        ref, _ = emu.solve_launch(cfg, st, qp, G=64)
+        assert np.array_equal(s.status, ref.status) and np.array_equal(s.z, ref.z) and np.array_equal(s.u0, ref.u0)
+        assert np.array_equal(s.y, ref.y) and np.array_equal(s.iters, ref.iters)
+    # submit / drain by hand: nothing comes back before the ring is full, everything after a drain
+    sb = streamed.StreamedBatches(handles=[_EmuStagedHandle(emu, cfg, st, track) for _ in range(depth)])
+    early = [sb.submit(*b, want_z=False) for b in batches[:depth]]
+    assert all(e is None for e in early)
+    first = sb.submit(*batches[depth])
+    assert first is not None and first.z is None            # (the first batch was submitted with want_z = False)
+    rest = sb.drain()
+    assert len(rest) == depth and sb.drain() == []
+    with pytest.raises(ValueError):
+        streamed.StreamedBatches(handles=[])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth", [1, 3])
+def test_streamed_batches_on_device_match_the_single_call(depth, track):
+    B = 512
+    batches, sc = _batches(track, 8, B)
+    cfg = T.stock_config(sc.N, sc.weights, max_batch=B)
+    sb = streamed.StreamedBatches(cfg, mpmpc.default_settings(), depth=depth)
+    sb.set_path(track.kappa, track.v_ref, track.ds_next)
+    # (views instead of copies: a result stays valid until `depth` more batches have been submitted)
+    sv = streamed.StreamedBatches(cfg, mpmpc.default_settings(), depth=depth, copy=False)
+    sv.set_path(track.kappa, track.v_ref, track.ds_next)
+    n_seen = 0
+    for b, s in zip(batches, sv.map(batches)):
+        assert s.z.base is not None and np.all(np.isfinite(s.u0))
+        n_seen += 1
+    assert n_seen == len(batches)
+    sv.close()
+    ref_h = mpmpc.Handle(cfg, mpmpc.default_settings())
+    ref_h.set_path(track.kappa, track.v_ref, track.ds_next)
+    got = list(sb.map(batches, want_y=True))
+    assert len(got) == len(batches)
+    for b, s in zip(batches, got):
+        ref = ref_h.solve(*b, want_y=True)
+        assert np.array_equal(s.status, ref.status) and np.array_equal(s.iters, ref.iters)
+        assert np.array_equal(s.z, ref.z) and np.array_equal(s.u0, ref.u0) and np.array_equal(s.y, ref.y) and np.array_equal(s.resid, ref.resid)
+    assert any((s.status == mpmpc.PRIMAL_INFEASIBLE).any() for s in got)      # the obstacle batches bring their tails along
+    sb.close()
