@@ -200,10 +200,13 @@ class BatchMPC:
         self.handle.set_path(kappa, v_ref, ds)
         self._path = model.reference_path
         self.corridor_cols = None
+        self._corridor_tables = None      # host copies of a static corridor table (for the further handles of get_control_stream)
+        self._stream = None
         if isinstance(corridor, str) and corridor == "device":
             self.update_corridor_from_map()
         elif corridor is not None:        # (ub, lb) tables [n_wp x >=N] of a static map
             self.handle.set_corridor(*corridor)
+            self._corridor_tables = corridor
 
     def update_corridor_from_map(self, n_cols=None):
         """(Re)build the corridor table on the device from the path's map as it is NOW (obstacles
@@ -257,6 +260,29 @@ class BatchMPC:
         self.handle.solve_staged(B, with_rows=with_rows, want_z=want_plan, want_y=False)
         st = self.handle.staging(B)
         return st["u0"], st["status"]
+
+    def get_control_stream(self, batches, depth=3, want_plan=True):
+        """A stream of get_control_batch calls from host buffers with `depth` of them in flight on this device
+        (streamed.StreamedBatches: upload, launch and download of consecutive batches overlap).  batches: iterable of
+        (wp_id, x0, cc_prev[, lb, ub]); yields (u [B,2] = (v, delta), plan [B,2N] with delta entries or None, status [B]) per
+        batch, in order.  The corridor comes with each batch (lb / ub) or from the table this controller was given."""
+        import streamed
+        if getattr(self, "_stream", None) is None or self._stream.depth != depth:
+            # (the first handle of the ring is this controller's own; the others are built like it)
+            hs = [self.handle]
+            for _ in range(depth - 1):
+                h = mpmpc.Handle(self._cfg, self.settings)
+                h.set_path(*self._path.tables())
+                if self._corridor_tables is not None:
+                    h.set_corridor(*self._corridor_tables)
+                hs.append(h)
+            self._stream = streamed.StreamedBatches(handles=hs)
+        for sol in self._stream.map(batches, want_z=want_plan):
+            plan = None
+            if want_plan:
+                plan = sol.z[:, -2 * self.N:].copy()
+                plan[:, 1::2] = np.arctan(plan[:, 1::2] * self.model.length)
+            yield sol.u0, plan, sol.status
 
     def get_control_batch(self, wp_id, x0, cc_prev, lb=None, ub=None):
         """-> (u [B,2] = (v, delta), plan [B,2N] with delta entries, status [B], Solution)."""

@@ -105,3 +105,31 @@ def test_streamed_batches_on_device_match_the_single_call(depth, track):
         assert np.array_equal(s.z, ref.z) and np.array_equal(s.u0, ref.u0) and np.array_equal(s.y, ref.y) and np.array_equal(s.resid, ref.resid)
     assert any((s.status == mpmpc.PRIMAL_INFEASIBLE).any() for s in got)      # the obstacle batches bring their tails along
     sb.close()
+
+
+@pytest.mark.gpu
+def test_batch_mpc_stream_is_batch_mpc_call_by_call():
+    """BatchMPC.get_control_stream: the class with the reference's constructor arguments, three calls in flight, against
+    get_control_batch on the same batches (corridor from the controller's table, and corridor rows coming with the batch)."""
+    import test_host_mpc as H
+    from MPC import BatchMPC
+    from scipy import sparse
+    m, rp, car = H.build_world()
+    Q, R, QN = sparse.diags([1.0, 0.0, 0.0]), sparse.diags([0.5, 0.0]), sparse.diags([1.0, 0.0, 0.0])
+    ic = {'umin': np.array([0.0, -np.tan(0.66) / car.length]), 'umax': np.array([1.0, np.tan(0.66) / car.length])}
+    scn = {'xmin': np.array([-np.inf] * 3), 'xmax': np.array([np.inf] * 3)}
+    tr = scenarios.sim_track()
+    B = 300
+    bm = BatchMPC(car, 30, Q, R, QN, scn, ic, 4.0, max_batch=B, corridor=(tr.ub_obstacles, tr.lb_obstacles))
+    batches = []
+    for i in range(5):
+        sc = scenarios.make(4, tr, B=B)
+        r = np.random.default_rng(7 + i).permutation(B)
+        batches.append((sc.wp_id[r], sc.x0[r], sc.cc_prev[r]) if i % 2 else (sc.wp_id[r], sc.x0[r], sc.cc_prev[r], sc.lb[r], sc.ub[r]))
+    want = [bm.get_control_batch(*b) for b in batches]
+    got = list(bm.get_control_stream(batches, depth=3))
+    assert len(got) == len(want)
+    for (u, plan, status, _), (u2, plan2, status2) in zip(want, got):
+        assert np.array_equal(status, status2) and np.array_equal(u, u2) and np.array_equal(plan, plan2)
+    u3 = [g[0] for g in bm.get_control_stream(batches, depth=3, want_plan=False)]
+    assert all(np.array_equal(a[0], b) for a, b in zip(want, u3))
