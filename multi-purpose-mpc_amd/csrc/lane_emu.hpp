@@ -209,6 +209,9 @@ struct LaneEmu {
     fill([&](const VI& idx, const VB& ok, const VD& v) { store(dst, inst * rowlen + idx, ok, v); });
   }
 
+  template <class F>
+  static void rows_any(double* dst, int rowlen, const VI& inst, int n_inst, F fill) { rows(dst, rowlen, inst, n_inst, fill); }
+
   static VD load(const double* p, const VI& idx, const VB& ok, double dflt) {
     VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = ok.v[i] ? p[idx.v[i]] : dflt; return r;
   }

@@ -261,6 +261,24 @@ struct LaneGpu {
     for (int i = lane; i < cnt; i += 64) out[i] = buf[i];
   }
 
+  // The same for a wave whose instances are NOT consecutive (the packed tail kernel takes them from a list): each of the
+  // 64 / G rows goes to its own instance's place.
+  template <class F>
+  static __device__ __forceinline__ void rows_any(double* dst, int rowlen, int inst, int n_inst, F fill) {
+    double* buf = cold();
+    __syncthreads();
+    const int lane = lane_again(), sl = lane / G;
+    const int mine = sl * rowlen;
+    fill([&](int idx, bool ok, double v) { if (ok) buf[mine + idx] = v; });
+    __syncthreads();
+    for (int s = 0; s < per_wave; ++s) {
+      const int inst_s = __shfl(inst, s * G);     // the instance of the wave's s-th group of lanes (wave-uniform)
+      if (inst_s >= n_inst) continue;
+      double* out = dst + (long)inst_s * rowlen;
+      for (int i = lane; i < rowlen; i += 64) out[i] = buf[s * rowlen + i];
+    }
+  }
+
   static __device__ __forceinline__ double load(const double* p, int idx, bool ok, double dflt) {
     return ok ? p[idx] : dflt;
   }

@@ -251,21 +251,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                            int* __restrict__ tail2, unsigned* __restrict__ tail2_flag, unsigned seq) {
   using L = LaneGpu<G, C, RN_SLOTS>;
   if (blockIdx.x == 0 && threadIdx.x == 0) *tail_reset = 0;
-  if ((int)blockIdx.x >= tail[0]) return;
-  const int inst = tail[1 + blockIdx.x];
+  if ((int)blockIdx.x * L::per_wave >= tail[0]) return;
+  // (the instances of a wave: consecutive entries of the list; the last wave of a packed launch may carry B = "none")
+  const int e_ = blockIdx.x * L::per_wave + L::slot();
+  const int inst = e_ < tail[0] ? tail[1 + e_] : B;
   const int k = L::stage() - lane_offset(G, C, cfg.N);
   MPMPC_TICK_BEGIN(8);
   double fields[MPMPC_NUM_FIELDS];
   assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
   ReducedTailSolver<L> s;
-  s.run(fields, B, inst, k, cfg.N, st, iters ? iters[inst * 2 + 1] : 0);
+  s.run(fields, B, inst, k, cfg.N, st, (iters && inst < B) ? iters[inst * 2 + 1] : 0);
   MPMPC_TICK_BEGIN(7);
-  const int inst_o = tail[1 + blockIdx.x];
+  const int e_o = blockIdx.x * L::per_wave + L::slot_again();
+  const int inst_o = e_o < tail[0] ? tail[1 + e_o] : B;
   const int k_o = L::stage_again() - lane_offset(G, C, cfg.N);
   s.store(inst_o, k_o, cfg.wheelbase, z, u0, status, iters, resid, y);
   MPMPC_TICK_END(7);
   MPMPC_TICK_END(8);
-  if (k_o == 0 && s.status == MPMPC_UNSOLVED) {
+  if (k_o == 0 && inst_o < B && s.status == MPMPC_UNSOLVED) {
     tail2[1 + atomicAdd(tail2, 1)] = inst_o;
     __hip_atomic_store(tail2_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -616,6 +619,7 @@ struct mpmpc_handle_s {
   int force_lanes = 0;      // mpmpc_set_packing: 0 = chosen from the batch size
   // mpmpc_set_tail_kernel (MPMPC_LEAN_TAIL=0 in the environment: off from the start, for A/B timings of whole programs)
   bool lean_tail = !(std::getenv("MPMPC_LEAN_TAIL") && std::atoi(std::getenv("MPMPC_LEAN_TAIL")) == 0);
+  bool lean_tail_packed = std::getenv("MPMPC_LEAN_TAIL") && std::atoi(std::getenv("MPMPC_LEAN_TAIL")) == 2;      // two tail instances per wave
   bool resident_y = true;   // mpmpc_set_outputs: do resident launches store the multipliers y (46 % of the output bytes)?
   bool y_valid = false;     // the last solve launch stored y
 };
@@ -929,8 +933,9 @@ int mpmpc_set_packing(mpmpc_handle h, int32_t lanes_per_instance) {
 int mpmpc_set_tail_kernel(mpmpc_handle h, int32_t reduced_native) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
   MPMPC_SETTLE(h);
-  if (reduced_native != 0 && reduced_native != 1) return fail(MPMPC_E_ARG, "reduced_native must be 0 or 1");
+  if (reduced_native < 0 || reduced_native > 2) return fail(MPMPC_E_ARG, "reduced_native must be 0, 1 or 2");
   h->lean_tail = reduced_native != 0;
+  h->lean_tail_packed = reduced_native == 2;
   return MPMPC_OK;
 }
 
@@ -1364,9 +1369,14 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
     if (h->pend) {
       h->pend_B = B; h->pend_y = want_y; h->pend_cur = tail_cur; h->pend_next = tail_next;
     } else if (lean) {
-      if (tail_only != 2)
-        hipLaunchKernelGGL((mpmpc_reduced_tail_kernel<64, 16>), dim3(B), dim3(64), rn_pad, h->stream, h->cfg, prm, B, ain, h->z, h->u0,
-                           h->status, h->iters, h->resid, y_out, tail_cur, tail_next, tail2, h->tail_flag + 1, h->seq);
+      if (tail_only != 2) {
+        if (h->lean_tail_packed)
+          hipLaunchKernelGGL((mpmpc_reduced_tail_kernel<32, 16>), dim3((B + 1) / 2), dim3(64), rn_pad, h->stream, h->cfg, prm, B, ain, h->z,
+                             h->u0, h->status, h->iters, h->resid, y_out, tail_cur, tail_next, tail2, h->tail_flag + 1, h->seq);
+        else
+          hipLaunchKernelGGL((mpmpc_reduced_tail_kernel<64, 16>), dim3(B), dim3(64), rn_pad, h->stream, h->cfg, prm, B, ain, h->z, h->u0,
+                             h->status, h->iters, h->resid, y_out, tail_cur, tail_next, tail2, h->tail_flag + 1, h->seq);
+      }
       // ... and the general kernel on what that left: deferred like the tail itself while the launches seen leave nothing
       h->pend2 = tail_only != 2 && h->tail2_expect_empty;
       if (h->pend2) {

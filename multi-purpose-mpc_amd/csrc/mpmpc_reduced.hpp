@@ -539,9 +539,12 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
 
   // The centred start of the interior point at x3 and the attempts from it (interior point, active-set rounds, certificate;
   // see RN_ATTEMPTS).  cap: interior-point iterations an attempt may take; rd0_more: a dual residual of the start the three
-  // entries do not show (the tail solver's speed entry), or nullptr.  What is certified is committed; returns what is not.
+  // entries do not show (the tail solver's speed entry), or nullptr; g3: the box-row scalings if the caller holds them in
+  // registers (the tail solver: its slots C_G / C_PI already carry a point by then; no pin multipliers in that case), or
+  // nullptr.  What is certified is committed; returns what is not.
   template <bool WARM = false>
-  MPMPC_HD Mk attempts(Box3& b3, const SolverParams& st, int cap, Mk todo, bool committed, const R* rd0_more = nullptr) {
+  MPMPC_HD Mk attempts(Box3& b3, const SolverParams& st, int cap, Mk todo, bool committed, const R* rd0_more = nullptr,
+                      const R* g3 = nullptr) {
     const R zero(0.0), one(1.0);
     // ---- centred start of the interior point (Solver::polish, early attempt): slacks max(distance to the bound,
     // ipm_start_slack in row space), multipliers mu0 / slack, no equality multipliers
@@ -559,12 +562,12 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
       }
       MPMPC_UNROLL
       for (int e = 0; e < 3; ++e) {
-        const R fl = ths / L::cold_get(C_G + e);
+        const R fl = ths / (g3 ? g3[e] : L::cold_get(C_G + e));
         sl[e] = sel(b3.Lm[e], max_(x3[e] - b3.lo[e], fl), one);
         su[e] = sel(b3.Um[e], max_(b3.hi[e] - x3[e], fl), one);
         zl[e] = sel(b3.Lm[e], mu0 / sl[e], zero);
         zu[e] = sel(b3.Um[e], mu0 / su[e], zero);
-        pi[e] = L::cold_get(C_PI + e);
+        pi[e] = g3 ? zero : L::cold_get(C_PI + e);
       }
     }
     // ---- the interior point's own layout
@@ -711,6 +714,8 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
   // ================================================================================ output
   // z in the reference's ordering, u0 = (v_0, delta_0), multipliers in the reference's row order; the separated parts
   // (v, its multiplier, the roll-forward of t) are put together here, in the unscaled problem
+  // ANY: the instances of the wave are not consecutive (the packed tail kernel): rows go out one instance at a time
+  template <bool ANY = false>
   MPMPC_HD void store(const I& inst, const I& k, double wheelbase, double* z, double* u0, int* st_out, int* it_out,
                       double* resid, double* y, int* act = nullptr, int ld = 0, const Mk* point = nullptr, const Mk* no_lamv = nullptr) const {
     if (act) L::storei(act, inst * ld + k, vx, this->act_bits);
@@ -740,16 +745,17 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
     const R E2[2] = {L::cold_get(C_E), L::cold_get(C_E + 1)};
     L::fence();
     if (z) {
-      L::rows(z, n, inst, n_inst, [&](auto put) {
+      auto fill = [&](auto put) {
         put(k * 3, vx, e_y);
         put(k * 3 + 1, vx, e_psi);
         put(k * 3 + 2, vx, t);
         put(k * 2 + (3 * (N + 1)), vu, v);
         put(k * 2 + (3 * (N + 1) + 1), vu, kap);
-      });
+      };
+      if constexpr (ANY) L::rows_any(z, n, inst, n_inst, fill); else L::rows(z, n, inst, n_inst, fill);
     }
     if (y) {
-      L::rows(y, m, inst, n_inst, [&](auto put) {
+      auto fill = [&](auto put) {
         put(k * 3, vx, (E2[0] * nu2[0]) * cinv);
         put(k * 3 + 1, vx, (E2[1] * nu2[1]) * cinv);
         put(k * 3 + 2, vx, zero);
@@ -758,7 +764,8 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
         put(k * 3 + (3 * (N + 1) + 2), vx, zero);
         put(k * 2 + (6 * (N + 1)), vu, lam_v);
         put(k * 2 + (6 * (N + 1) + 1), vu, (lam3[2] / D3[2]) * cinv);
-      });
+      };
+      if constexpr (ANY) L::rows_any(y, m, inst, n_inst, fill); else L::rows(y, m, inst, n_inst, fill);
     }
     const Mk lead = live & first;
     if (u0) {

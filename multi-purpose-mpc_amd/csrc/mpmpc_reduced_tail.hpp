@@ -43,14 +43,18 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
   using BoxI = typename RS::BoxI;
   using IpmI = typename RS::IpmI;
   static constexpr int EI = RS::EI;
-  static_assert(L::per_wave == 1 && RS::kSplit, "the tail solver runs one instance per wave, in the split layout");
-  // ---- cold slots of its own (the split layout leaves ReducedSolver's K_PP .. K_RP slots to the parked iterate, which
-  //      exists from the first attempt on: everything here is consumed before that, except the least-violation point)
+  // ---- cold slots of its own: ReducedSolver's K_PARK .. slots belong to the parked iterate / the packed interior point's
+  //      residuals from the first attempt on - everything here is consumed before that
   //   T_RAW .. +3    unscaled box of e_y and kappa (the verdict and the relaxation work in the unscaled problem)
   //   T_NAX          largest finite bound / speed of the instance (OSQP's max(|Ax|, |z|), see Solver::phase1)
   //   T_RD0          dual residual of the speed entry at the start of the attempt (scaled problem)
-  //   T_LV0 .. 2     least-violation point of a marginal instance while the attempt runs (three slots nothing else uses)
-  enum { T_RAW = 32, T_NAX = 36, T_RD0 = 37, T_LV0 = RS::C_GAP, T_LV1 = RS::K_PP + 2, T_LV2 = RS::K_QQ + 2 };
+  //   T_MARK         C_GAP's slot (the gap of an empty box is kept in a register here): on the lanes of an instance that hold
+  //                  no stage, the violation of a MARGINAL instance - read back after the attempt, so that no mask and no
+  //                  scalar of the verdict lives through it; zero otherwise
+  // The least-violation point of a verdict (infeasible: with its ray; marginal: with zero multipliers, in case the attempt
+  // fails) goes to the slots of the certified point BEFORE the attempt, which then commits in merge mode: what it certifies
+  // replaces it, what it does not leaves it there.
+  enum { T_RAW = 32, T_NAX = 36, T_RD0 = 37, T_MARK = RS::C_GAP };
 
   // (No mask of this solver lives through the attempt: "marginal" is read back from T_LV0, and the store tells a ray -
   //  status PRIMAL_INFEASIBLE of a non-empty box - and a bare least-violation point - SOLVED_INACCURATE that no attempt
@@ -80,8 +84,8 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
       gap = L::gmax(gap);
       empty = live & (gap > zero);
       solvable = live & !empty;
-      pri_res = gap;          // (kept in a register here: the slot C_GAP serves as T_LV0 ...
-      L::cold_put(T_LV0, zero);      //  ... whose lanes without a stage say "marginal" by holding a violation, see run())
+      pri_res = gap;          // (kept in a register here: the slot C_GAP serves as T_MARK)
+      L::cold_put(T_MARK, zero);
     }
     L::cold_put(T_RAW + 0, lo_e); L::cold_put(T_RAW + 1, hi_e); L::cold_put(T_RAW + 2, lo_k); L::cold_put(T_RAW + 3, hi_k);
     {
@@ -183,9 +187,13 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
         BoxI bi;
         IpmI si;
         Mk vm[EI];
-        bU[0] = sel(sU, L::from_lower(b[0]), zero);
-        bU[1] = zero;
-        vm[0] = val3[0]; vm[1] = val3[2];
+        if constexpr (RS::kSplit) {
+          bU[0] = sel(sU, L::from_lower(b[0]), zero);
+          bU[1] = zero;
+          vm[0] = val3[0]; vm[1] = val3[2];
+        } else {
+          vm[0] = val[0]; vm[1] = val[1]; vm[2] = val[2];
+        }
         RS::to_ip(b3.lo, bi.lo); RS::to_ip(b3.hi, bi.hi);
         RS::mask_to_ip(b3.Lm, bi.Lm); RS::mask_to_ip(b3.Um, bi.Um); RS::mask_to_ip(b3.pin, bi.pin);
         const R z3[3] = {zero, zero, zero};
@@ -270,53 +278,52 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
             const R lo1 = fma_(R(-1.5), wl, lo0), hi1 = fma_(R(1.5), wh, hi0);
             // (Eb = g / D: the general kernel keeps Eb itself; the quotient differs from it in the last bit at most)
             const R Ebe = ge / De;
-            L::cold_put(e == 0 ? K_LO0 : K_LO2, (Ebe * lo1) / ge);
-            L::cold_put(e == 0 ? K_HI0 : K_HI2, (Ebe * hi1) / ge);
+            // (merged: a partner instance of the wave keeps its boxes to the bit)
+            L::cold_put(e == 0 ? K_LO0 : K_LO2, sel(marginal, (Ebe * lo1) / ge, L::cold_get(e == 0 ? K_LO0 : K_LO2)));
+            L::cold_put(e == 0 ? K_HI0 : K_HI2, sel(marginal, (Ebe * hi1) / ge, L::cold_get(e == 0 ? K_HI0 : K_HI2)));
           }
-          // (... and the violation rides on the lanes of T_LV0 that hold no stage - the wave has 64 lanes for at most 32
-          //  stages - instead of in a register through the attempt)
-          L::cold_put(T_LV0, sel(vx, xs[0], prim)); L::cold_put(T_LV1, xs[1]); L::cold_put(T_LV2, xs[2]);
+          L::cold_put(T_MARK, sel(marginal & !vx, prim, zero));
           L::fence();
           RS::make_box3(b3);
         }
       }
-      // ---- verdict "infeasible": least-violation point, ray, violation
-      if (L::wany(cert)) {
+      // ---- feasible to tolerance (phase 1 converged, its point violates nothing) or marginal: one more attempt of the
+      //      certified polish, from phase 1's point - inside every box it can be inside of, well centred
+      const Mk retry = todo & !cert & ((S::p1_converged & !(prim > R(st.cert_tol))) | marginal);
+      // the box-row scalings of the attempt's start: the slots they live in take the verdict's point now
+      R g3[3];
+      MPMPC_UNROLL
+      for (int e = 0; e < 3; ++e) g3[e] = L::cold_get(C_G + e);
+      L::fence();
+      // ---- the point of a verdict: least-violation point, for "infeasible" with the ray; for a marginal instance with zero
+      //      multipliers - what it ends with if the attempt cannot certify the optimum over the relaxed boxes
+      {
+        const Mk pre = cert | marginal;
         MPMPC_UNROLL
-        for (int e = 0; e < 3; ++e) { L::cold_put(C_XS + e, xs[e]); L::cold_put(C_LAM + e, lam[e]); }
-        L::cold_put(C_NUS, nus[0]); L::cold_put(C_NUS + 1, nus[1]);
+        for (int e = 0; e < 3; ++e) {
+          L::cold_put(C_XS + e, sel(pre, xs[e], L::cold_get(C_XS + e)));
+          L::cold_put(C_LAM + e, sel(pre, sel(cert, lam[e], zero), L::cold_get(C_LAM + e)));
+        }
+        L::cold_put(C_NUS, sel(pre, sel(cert, nus[0], zero), L::cold_get(C_NUS)));
+        L::cold_put(C_NUS + 1, sel(pre, sel(cert, nus[1], zero), L::cold_get(C_NUS + 1)));
         L::fence();
         pri_res = sel(cert, prim, pri_res);
         dua_res = sel(cert, zero, dua_res);
         status = seli(cert, I(MPMPC_PRIMAL_INFEASIBLE), status);
       }
-      // ---- feasible to tolerance (phase 1 converged, its point violates nothing) or marginal: one more attempt of the
-      //      certified polish, from phase 1's point - inside every box it can be inside of, well centred
-      const Mk retry = todo & !cert & ((S::p1_converged & !(prim > R(st.cert_tol))) | marginal);
       if (L::wany(retry)) {
         MPMPC_UNROLL
-        for (int e = 0; e < 3; ++e) x3[e] = xs[e];
+        for (int e = 0; e < 3; ++e) x3[e] = sel(retry, xs[e], zero);
         const R rd0v = L::cold_get(T_RD0);
-        // (one instance per wave: inside this branch "retry" is the instance itself)
-        (void)RS::template attempts<false>(b3, st, st.ipm_max_iter, solvable, false, &rd0v);
+        // (merge mode: what the attempt certifies replaces the point in the slots, what it does not leaves it there)
+        (void)RS::template attempts<false>(b3, st, st.ipm_max_iter, retry, true, &rd0v, g3);
         // a marginal instance ends here: the optimum over the relaxed boxes, or - if the attempt could not certify that -
         // phase 1's least-violation point itself; either way a usable, inaccurate plan
         L::fence();
-        const R viol = L::gmax(sel(vx, zero, L::cold_get(T_LV0)));        // > 0: the instance was marginal
+        const R viol = L::gmax(sel(vx, zero, L::cold_get(T_MARK)));        // > 0: the instance was marginal
         const Mk mg = (viol > zero) & ((status == MPMPC_SOLVED) | (status == MPMPC_UNSOLVED));
-        if (L::wany(mg)) {
-          const Mk bare = mg & (status == MPMPC_UNSOLVED);
-          const R lv[3] = {L::cold_get(T_LV0), L::cold_get(T_LV1), L::cold_get(T_LV2)};
-          L::fence();
-          if (L::wany(bare)) {
-            MPMPC_UNROLL
-            for (int e = 0; e < 3; ++e) { L::cold_put(C_XS + e, sel(val[e], lv[e], zero)); L::cold_put(C_LAM + e, zero); }
-            L::cold_put(C_NUS, zero); L::cold_put(C_NUS + 1, zero);
-            L::fence();
-          }
-          status = seli(mg, I(MPMPC_SOLVED_INACCURATE), status);
-          pri_res = sel(mg, viol, pri_res);
-        }
+        status = seli(mg, I(MPMPC_SOLVED_INACCURATE), status);
+        pri_res = sel(mg, viol, pri_res);
       }
     }
     iters = I(st.early_polish);      // (the ADMM iteration of the first launch's early attempt: Solver::run, mode 2)
@@ -327,7 +334,7 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
     const Mk ray = (status == MPMPC_PRIMAL_INFEASIBLE) & !empty;
     const Mk point = live & ((status == MPMPC_SOLVED) | (status == MPMPC_SOLVED_INACCURATE) | ray);
     const Mk no_lamv = ray | ((status == MPMPC_SOLVED_INACCURATE) & (polished != 1));
-    RS::store(inst, k, wheelbase, z, u0, st_out, it_out, resid, y, nullptr, 0, &point, &no_lamv);
+    RS::template store<(L::per_wave > 1)>(inst, k, wheelbase, z, u0, st_out, it_out, resid, y, nullptr, 0, &point, &no_lamv);
   }
 };
 

@@ -231,9 +231,9 @@ class Handle:
         self._check(self.lib.mpmpc_set_packing(self._h, int(lanes_per_instance)))
 
     def set_tail_kernel(self, reduced_native: bool = True):
-        """True (default): the reduced-native tail kernel takes the tail of a batch launch first; False: the general kernel
-        takes all of it (parity tests, A/B timings)."""
-        self._check(self.lib.mpmpc_set_tail_kernel(self._h, 1 if reduced_native else 0))
+        """True / 1 (default): the reduced-native tail kernel takes the tail of a batch launch first; False / 0: the general kernel
+        takes all of it (parity tests, A/B timings); 2: experimental - the tail kernel with two instances per wavefront."""
+        self._check(self.lib.mpmpc_set_tail_kernel(self._h, int(reduced_native)))
 
     def set_path(self, kappa, v_ref, ds_next):
         k, v, d = (np.ascontiguousarray(a, dtype=np.float64) for a in (kappa, v_ref, ds_next))

@@ -102,17 +102,23 @@ static void solve_rnt(const mpmpc_config* cfg, const mpmpc_settings* st, const d
 }
 // mpmpc_reduced_tail_kernel: the reduced-native tail solver on the instances listed in tail; what it leaves UNSOLVED is
 // appended to tail2[1..]
-static int g_emu_lean_tail = 1;          // emu_set_lean_tail: 0 = the general kernel takes the whole tail (as before round 4)
+static int g_emu_lean_tail = 1;          // emu_set_lean_tail: 0 = the general kernel takes the whole tail (as before round 4);
+                                         // 2 = the tail solver with TWO instances per wave (32 lanes each, three entries per lane)
 template <int G, int C>
 static void solve_rn_tail(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
                           int* status, int* iters, double* resid, double* y, const int* tail, int* tail2) {
   using L = LaneEmu<G, C>;
   const int ld = stage_ld(cfg->N);
-  for (int w = 0; w < tail[0]; ++w) {
-    VI inst = VI(tail[1 + w]);
+  const int per = L::per_wave;
+  for (int w = 0; w < (tail[0] + per - 1) / per; ++w) {
+    // (the instances of a wave: consecutive entries of the list; a wave of the last, partly filled group carries B = "none")
+    VI slot = L::slot(), inst, base(0);
+    for (int i = 0; i < EMU_W; ++i) {
+      const int e = w * per + slot.v[i];
+      inst.v[i] = e < tail[0] ? tail[1 + e] : B;
+      base.v[i] = inst.v[i] < B ? iters[inst.v[i] * 2 + 1] : 0;
+    }
     VI k = L::stage() - lane_offset(G, C, cfg->N);
-    VI base(0);
-    for (int i = 0; i < EMU_W; ++i) base.v[i] = iters[inst.v[i] * 2 + 1];
     ReducedTailSolver<L> s;
     typename L::real fields[MPMPC_NUM_FIELDS];
     ReducedTailSolver<L>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
@@ -188,7 +194,8 @@ extern "C" int emu_solve_launch(const mpmpc_config* cfg, const mpmpc_settings* s
     if (g_emu_lean_tail && !reduced_native_tt(*cfg, *st) && reduced_native_tail(*cfg, *st)) {
       // the reduced-native tail solver first; the general kernel on what that leaves
       std::vector<int> tail2(B + 1, 0);
-      solve_rn_tail<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data(), tail2.data());
+      if (g_emu_lean_tail == 2) solve_rn_tail<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data(), tail2.data());
+      else solve_rn_tail<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data(), tail2.data());
       tail.swap(tail2);
       g_emu_tail2 = tail[0];
     }

@@ -565,3 +565,32 @@ def test_reduced_native_tail_solver_fallbacks(emu, track):
     np.testing.assert_allclose(lean.resid, gen.resid, rtol=1e-12, atol=0)
     assert np.all(lean.y[:3] == 0.0)                       # a bare least-violation point carries no multipliers
     assert np.all((lean.resid[:3, 0] > 1e-4) & (lean.resid[:3, 0] < 8e-3))
+
+
+def test_two_tail_instances_per_wave_give_the_same_verdicts(emu, track):
+    """The experimental packing of the tail solver (mpmpc_set_tail_kernel(h, 2) / emu_set_lean_tail(2): 32 lanes per instance,
+    three entries per lane, the general soft interior point for phase 1) against the shipped one-instance-per-wave form: the
+    same statuses and iteration counts; the least-violation points, rays and relaxed plans agree to ~1e-7 (phase 1 converges
+    to 1e-11 in the scaled problem along a different arithmetic path), certified optima to 1e-9."""
+    for cfgid, B, accept in ((4, 513, 1), (5, 300, 1), (4, 257, 0)):
+        sc = scenarios.make(cfgid, track, B=B)
+        cfg = T.stock_config(sc.N, sc.weights)
+        qp = emu.assemble(cfg, track, _inputs(sc))
+        st = mpmpc.default_settings(phase1_accept=accept)
+        one, n_tail = emu.solve_launch(cfg, st, qp, G=32)
+        try:
+            emu.lib.emu_set_lean_tail(2)
+            two, n_tail2 = emu.solve_launch(cfg, st, qp, G=32)
+            assert emu.lib.emu_last_tail2() == 0
+        finally:
+            emu.lib.emu_set_lean_tail(1)
+        assert n_tail == n_tail2 and n_tail >= 15
+        assert np.array_equal(one.status, two.status) and np.array_equal(one.iters[:, 0], two.iters[:, 0])
+        assert np.max(np.abs(one.iters[:, 1] - two.iters[:, 1])) <= 1
+        ok = one.status == 1
+        np.testing.assert_allclose(two.z[ok], one.z[ok], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(two.z, one.z, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(two.resid[:, 0], one.resid[:, 0], rtol=1e-6, atol=1e-9)
+        inf = np.flatnonzero(two.status == mpmpc.PRIMAL_INFEASIBLE)
+        for i in inf[:12]:
+            assert _farkas_ok(qp[:, i, :], sc.N, two.y[i])

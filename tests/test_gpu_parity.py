@@ -1077,6 +1077,24 @@ def test_reduced_native_tail_kernel_gives_the_general_kernels_answers(cfgid, B, 
 
 
 @pytest.mark.gpu
+def test_two_tail_instances_per_wave_on_device(track, emu):
+    """mpmpc_set_tail_kernel(h, 2), the experimental packing of the tail kernel: statuses of the shipped form, points within
+    1e-6 (certified optima 1e-9), and bit for bit what the emulation of the same kernel gives on statuses."""
+    sc = scenarios.make(4, track, B=2049)
+    res = {}
+    for mode in (1, 2):
+        h = _handle(track, sc.N, sc.weights, sc.B)
+        h.set_tail_kernel(mode)
+        res[mode] = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+    a, b = res[1], res[2]
+    assert np.array_equal(a.status, b.status) and (a.status == mpmpc.PRIMAL_INFEASIBLE).sum() >= 100 and (a.status == 2).sum() >= 5
+    ok = a.status == 1
+    np.testing.assert_allclose(b.z[ok], a.z[ok], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(b.z, a.z, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(b.resid[:, 0], a.resid[:, 0], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
 def test_what_the_tail_kernel_leaves_reaches_the_general_kernel_also_when_deferred(track):
     """Second level of the deferred tail: the general kernel's launch on what K2p leaves is not enqueued while the launches
     the host has seen leave nothing there.  With as_rounds = 0 nothing can be certified by an attempt, so every feasible
