@@ -2064,6 +2064,10 @@ struct Solver {
       for (int j = 0; j < E; ++j) xn[j] = ln[j] = zero;
       MPMPC_UNROLL
       for (int i = 0; i < NQ; ++i) nn[i] = zero;
+      // Packed waves: every instance takes exactly the refinement steps it would take alone - `refine` = the instances whose
+      // refinement still runs; a step is committed where it was needed - so that an answer does not depend on which
+      // instance shares the wave (the tail kernel's partners come from a list whose order differs from run to run).
+      [[maybe_unused]] Mk refine = todo;
       for (int rf = 0; rf <= st.as_refine; ++rf) {
         R At[E], Ax[NQ], rhs[E], r2[NQ], r3[E], dx[E], dnu[NQ];
         AeqT_mul_t<LAY>(nn, At);
@@ -2085,7 +2089,13 @@ struct Solver {
         MPMPC_UNROLL
         for (int i = 0; i < NQ; ++i) { r2[i] = leq[i] - Ax[i]; rs = max_(rs, sel(vx, abs_(r2[i]), zero)); }
         // the point already satisfies the system to rounding level (1e-15) for every instance in the wave: no further solve
-        if (rf >= 1 && !L::wany(todo & (L::gmax(rs) > R(1e-15)))) break;
+        [[maybe_unused]] Mk need = todo;
+        if constexpr (L::per_wave == 1) {
+          if (rf >= 1 && !L::wany(todo & (L::gmax(rs) > R(1e-15)))) break;
+        } else {
+          if (rf >= 1) need = refine & (L::gmax(rs) > R(1e-15));
+          if (!L::wany(need)) break;
+        }
         MPMPC_TICK_COUNT(18);
         MPMPC_TICK_BEGIN(14);
         kkt_solve_t<LAY>(rhs, r2, dx, dnu);
@@ -2093,14 +2103,19 @@ struct Solver {
         R big(0.0);
         MPMPC_UNROLL
         for (int j = 0; j < E; ++j) {
-          ln[j] = ln[j] + sel(act[j], (dx[j] - r3[j]) * idelta, zero);
-          xn[j] = xn[j] + dx[j];
+          ln[j] = updw(need, ln[j] + sel(act[j], (dx[j] - r3[j]) * idelta, zero), ln[j]);
+          xn[j] = updw(need, xn[j] + dx[j], xn[j]);
           big = max_(big, sel(vm[j], abs_(dx[j]) - R(1e-14) * abs_(xn[j]), zero));
         }
         MPMPC_UNROLL
-        for (int i = 0; i < NQ; ++i) nn[i] = nn[i] + dnu[i];
+        for (int i = 0; i < NQ; ++i) nn[i] = updw(need, nn[i] + dnu[i], nn[i]);
         // refinement has converged for every instance in the wave: stop early
-        if (rf >= 1 && !L::wany(todo & (L::gmax(big) > R(1e-15)))) break;
+        if constexpr (L::per_wave == 1) {
+          if (rf >= 1 && !L::wany(todo & (L::gmax(big) > R(1e-15)))) break;
+        } else {
+          refine = rf < 1 ? need : need & (L::gmax(big) > R(1e-15));
+          if (!L::wany(refine)) break;
+        }
         // ... or every instance still in the wave has a violation far beyond what refinement can still move
         // (1e-6): this active set is wrong, the next round does not need its exact solution
         // (one instance per wave only: a packed wave would need all its instances to agree, and rarely does)

@@ -240,8 +240,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 
 // K2p: the reduced-native TAIL kernel (mpmpc_reduced_tail.hpp): phase 1 and one more attempt of the certified polish on
-// the instances the reduced-native launch listed in `tail`, one per wave, within the same 256 registers and 40 LDS slots -
-// a tail wave shares its SIMD.  What it leaves UNSOLVED is appended to tail2 for the general kernel (mode 2).
+// the instances the reduced-native launch listed in `tail` - two per wave (<32,16>, the default: 241 registers, no scratch)
+// or one per wave (<64,16>, the split layout) - within the same 256 registers and 40 LDS slots: a tail wave shares its
+// SIMD.  What it leaves UNSOLVED is appended to tail2 for the general kernel (mode 2).
 template <int G, int C>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void mpmpc_reduced_tail_kernel(mpmpc_config cfg, SolverParams st, int B, AssembleIn ain,
                                                            double* __restrict__ z, double* __restrict__ u0,
@@ -619,7 +620,7 @@ struct mpmpc_handle_s {
   int force_lanes = 0;      // mpmpc_set_packing: 0 = chosen from the batch size
   // mpmpc_set_tail_kernel (MPMPC_LEAN_TAIL=0 in the environment: off from the start, for A/B timings of whole programs)
   bool lean_tail = !(std::getenv("MPMPC_LEAN_TAIL") && std::atoi(std::getenv("MPMPC_LEAN_TAIL")) == 0);
-  bool lean_tail_packed = std::getenv("MPMPC_LEAN_TAIL") && std::atoi(std::getenv("MPMPC_LEAN_TAIL")) == 2;      // two tail instances per wave
+  bool lean_tail_single = std::getenv("MPMPC_LEAN_TAIL") && std::atoi(std::getenv("MPMPC_LEAN_TAIL")) == 2;      // ONE tail instance per wave
   bool resident_y = true;   // mpmpc_set_outputs: do resident launches store the multipliers y (46 % of the output bytes)?
   bool y_valid = false;     // the last solve launch stored y
 };
@@ -935,7 +936,7 @@ int mpmpc_set_tail_kernel(mpmpc_handle h, int32_t reduced_native) {
   MPMPC_SETTLE(h);
   if (reduced_native < 0 || reduced_native > 2) return fail(MPMPC_E_ARG, "reduced_native must be 0, 1 or 2");
   h->lean_tail = reduced_native != 0;
-  h->lean_tail_packed = reduced_native == 2;
+  h->lean_tail_single = reduced_native == 2;
   return MPMPC_OK;
 }
 
@@ -1370,10 +1371,12 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
       h->pend_B = B; h->pend_y = want_y; h->pend_cur = tail_cur; h->pend_next = tail_next;
     } else if (lean) {
       if (tail_only != 2) {
-        if (h->lean_tail_packed)
+        // (the list's order differs from run to run - atomic appends - and with it the two instances that share a wave of the
+        //  packed form: the solver's arithmetic does not depend on the partner, Solver::active_set)
+        if (!h->lean_tail_single) {
           hipLaunchKernelGGL((mpmpc_reduced_tail_kernel<32, 16>), dim3((B + 1) / 2), dim3(64), rn_pad, h->stream, h->cfg, prm, B, ain, h->z,
                              h->u0, h->status, h->iters, h->resid, y_out, tail_cur, tail_next, tail2, h->tail_flag + 1, h->seq);
-        else
+        } else
           hipLaunchKernelGGL((mpmpc_reduced_tail_kernel<64, 16>), dim3(B), dim3(64), rn_pad, h->stream, h->cfg, prm, B, ain, h->z, h->u0,
                              h->status, h->iters, h->resid, y_out, tail_cur, tail_next, tail2, h->tail_flag + 1, h->seq);
       }

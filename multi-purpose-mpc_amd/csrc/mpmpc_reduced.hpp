@@ -254,6 +254,10 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
   // wait in LDS and are re-read where they are used (~40 LDS reads and 5 writes per iteration, 2 % of its instructions);
   // across a factorisation or a KKT solve a lane holds the iterate, the slack reciprocals and the complementarity
   // targets - nothing else.  Entry 1 (e_psi) is never boxed (reducible()).
+  // SOFT = true: phase 1 (Solver::ipm<LAY, true>: every boxed entry reads lo <= x + w <= hi with the cost 1/2 w^2 and nothing
+  // else in the cost; w = zl - zu is never stored; the loop also ends at the first iterate whose multipliers pass the Farkas
+  // test).  Same operations in the same order as the general routine; K_PP / K_QQ are not read then.
+  template <bool SOFT = false>
   MPMPC_HD Mk ipm3(const Box3& bx, typename S::template IpmT<LAY_RED>& s, const SolverParams& st, double tol, const Mk& run) {
     const R reg(st.ipm_reg), ireg(st.inv_ipm_reg), one(1.0), zero(0.0);
     constexpr int JB[2] = {0, 2};                       // the boxed entries: e_y, kappa
@@ -273,8 +277,9 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
     // that eliminate the slack steps - a zero in place of its slack reciprocal (isl / isu below): its multiplier step is then
     // exactly zero whatever its slack residual is, and that residual (finite: the clipped infinities are 1e30) needs no mask
     // except where it would enter a norm.  The iterates are bit for bit those of the fully masked form (Solver::ipm<LAY_RED>).
-    auto rl_of = [&](int b) { const int j = JB[b]; return s.x[j] - lo_of(b) - s.sl[j]; };
-    auto ru_of = [&](int b) { const int j = JB[b]; return hi_of(b) - s.x[j] - s.su[j]; };
+    auto w_of = [&](int j) { return SOFT ? s.zl[j] - s.zu[j] : zero; };
+    auto rl_of = [&](int b) { const int j = JB[b]; return SOFT ? s.x[j] + w_of(j) - lo_of(b) - s.sl[j] : s.x[j] - lo_of(b) - s.sl[j]; };
+    auto ru_of = [&](int b) { const int j = JB[b]; return SOFT ? hi_of(b) - s.x[j] - w_of(j) - s.su[j] : hi_of(b) - s.x[j] - s.su[j]; };
     auto rpin_of = [&](int b) { const int j = JB[b]; return sel(bx.pin[j], s.x[j] - lo_of(b), zero); };
     for (int it = 0; it <= st.ipm_max_iter; ++it) {
       R mu;
@@ -288,7 +293,10 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
         MPMPC_UNROLL
         for (int i = 0; i < 2; ++i) { rp[i] = rp[i] - L::cold_get(K_LEQ + i); res = max_(res, sel(vx, abs_(rp[i]), zero)); }
         MPMPC_UNROLL
-        for (int j = 0; j < 3; ++j) rd[j] = fma_(L::cold_get(K_PP + j), s.x[j], L::cold_get(K_QQ + j)) + At[j] - s.zl[j] + s.zu[j] + s.pi[j];
+        for (int j = 0; j < 3; ++j) {
+          if constexpr (SOFT) rd[j] = At[j] - s.zl[j] + s.zu[j] + s.pi[j];
+          else rd[j] = fma_(L::cold_get(K_PP + j), s.x[j], L::cold_get(K_QQ + j)) + At[j] - s.zl[j] + s.zu[j] + s.pi[j];
+        }
         res = max_(res, sel(val[1], abs_(rd[1]), zero));
         MPMPC_UNROLL
         for (int b = 0; b < 2; ++b) {
@@ -301,27 +309,57 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
         L::cold_put(K_RP, rp[0]); L::cold_put(K_RP + 1, rp[1]);
         res = L::gmax(res);
         mu = L::gsum(msum) * inb;
-        const Mk ok = (res < R(tol > 1e-11 ? tol : 1e-11)) & (mu < R(tol));
+        Mk ok = (res < R(tol > 1e-11 ? tol : 1e-11)) & (mu < R(tol));
+        if constexpr (SOFT) {
+          S::p1_converged = selb(active, ok, S::p1_converged);
+          // Farkas test on the multipliers y = (nu, zu - zl + pi) in the scaled problem: A'y is the dual residual rd itself
+          R ny(0.0), na(0.0), sup(0.0);
+          MPMPC_UNROLL
+          for (int i = 0; i < 2; ++i) { ny = max_(ny, sel(vx, abs_(s.nu[i]), zero)); sup = sup + sel(vx, L::cold_get(K_LEQ + i) * s.nu[i], zero); }
+          na = max_(na, sel(val[0], abs_(rd[0]), zero));
+          na = max_(na, sel(val[1], abs_(rd[1]), zero));
+          na = max_(na, sel(val[2], abs_(rd[2]), zero));
+          MPMPC_UNROLL
+          for (int b = 0; b < 2; ++b) {
+            const int j = JB[b];
+            const R lam = s.zu[j] - s.zl[j] + s.pi[j];
+            ny = max_(ny, sel(val[j], abs_(lam), zero));
+            sup = sup + sel(val[j] & (lam > zero) & (bx.Um[j] | bx.pin[j]), sel(bx.pin[j], lo_of(b), hi_of(b)) * lam, zero) +
+                  sel(val[j] & (lam < zero) & (bx.Lm[j] | bx.pin[j]), lo_of(b) * lam, zero);
+          }
+          ny = L::gmax(ny); na = L::gmax(na); sup = L::gsum(sup);
+          const R thr = R(st.phase1_eps) * ny;
+          ok = ok | ((ny > R(st.phase1_eps)) & (na < thr) & (sup < -thr));
+        }
         conv = conv | (active & ok);
         active = active & !ok;
         if (it == st.ipm_max_iter || !L::wany(active)) break;
-        active = active & !(mu > R(st.ipm_diverged) * mu_min) & !((mu < R(tol * 1e-3)) & (res > R(1e-5)));
-        mu_min = min_(mu_min, mu);
-        if (!L::wany(active)) break;
+        if constexpr (!SOFT) {
+          active = active & !(mu > R(st.ipm_diverged) * mu_min) & !((mu < R(tol * 1e-3)) & (res > R(1e-5)));
+          mu_min = min_(mu_min, mu);
+          if (!L::wany(active)) break;
+        }
       }
       ipm_iters = seli(active, ipm_iters + I(1), ipm_iters);
       // ---- factor
       R isl[2], isu[2], rcl[2], rcu[2];
+      [[maybe_unused]] R kap[2];
       {
         L::fence();
         R h[3];
-        h[1] = rcp_(L::cold_get(K_PP + 1) + reg);
+        h[1] = SOFT ? rcp_(reg) : rcp_(L::cold_get(K_PP + 1) + reg);
         MPMPC_UNROLL
         for (int b = 0; b < 2; ++b) {
           const int j = JB[b];
           const R il = rcp_(s.sl[j]), iu = rcp_(s.su[j]);
-          h[j] = rcp_(L::cold_get(K_PP + j) + reg + sel(bx.Lm[j], s.zl[j] * il, zero) + sel(bx.Um[j], s.zu[j] * iu, zero) +
-                      sel(bx.pin[j], ireg, zero));
+          if constexpr (SOFT) {
+            // k = 1 / (1 + th), th = zl / sl + zu / su; the diagonal carries k th = 1 - k
+            const R kp = rcp_(one + sel(bx.Lm[j], s.zl[j] * il, zero) + sel(bx.Um[j], s.zu[j] * iu, zero));
+            h[j] = rcp_((reg + one) - kp + sel(bx.pin[j], ireg, zero));
+          } else {
+            h[j] = rcp_(L::cold_get(K_PP + j) + reg + sel(bx.Lm[j], s.zl[j] * il, zero) + sel(bx.Um[j], s.zu[j] * iu, zero) +
+                        sel(bx.pin[j], ireg, zero));
+          }
         }
         this->template factor_t<LAY_RED>(h, reg);
         // (the slack reciprocals and complementarity products are formed AFTER the factorisation: four reciprocals twice are
@@ -332,11 +370,14 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
           const int j = JB[b];
           isl[b] = sel(bx.Lm[j], rcp_(s.sl[j]), zero); isu[b] = sel(bx.Um[j], rcp_(s.su[j]), zero);
           rcl[b] = s.sl[j] * s.zl[j]; rcu[b] = s.su[j] * s.zu[j];
+          // (k again, like the reciprocals: two registers less across the factorisation)
+          if constexpr (SOFT) kap[b] = rcp_(one + s.zl[j] * isl[b] + s.zu[j] * isu[b]);
         }
       }
       R alpha_aff(1.0);
       for (int pass = 0; pass < 2; ++pass) {
         R dx[3], dnu[2];
+        [[maybe_unused]] R cul[2];          // phase 1: cu - cl of the boxed entries
         {
           L::fence();
           R rhs[3], nreq[2];
@@ -344,11 +385,42 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
           MPMPC_UNROLL
           for (int b = 0; b < 2; ++b) {
             const int j = JB[b];
-            rhs[j] = -L::cold_get(K_RD + j) - fma_(s.zl[j], rl_of(b), rcl[b]) * isl[b] + fma_(s.zu[j], ru_of(b), rcu[b]) * isu[b] -
-                     sel(bx.pin[j], rpin_of(b) * ireg, zero);
+            if constexpr (SOFT) {
+              cul[b] = fma_(s.zu[j], ru_of(b), rcu[b]) * isu[b] - fma_(s.zl[j], rl_of(b), rcl[b]) * isl[b];
+              rhs[j] = fma_(kap[b], cul[b], -L::cold_get(K_RD + j)) - sel(bx.pin[j], rpin_of(b) * ireg, zero);
+            } else {
+              rhs[j] = -L::cold_get(K_RD + j) - fma_(s.zl[j], rl_of(b), rcl[b]) * isl[b] + fma_(s.zu[j], ru_of(b), rcu[b]) * isu[b] -
+                       sel(bx.pin[j], rpin_of(b) * ireg, zero);
+            }
           }
           nreq[0] = -L::cold_get(K_RP); nreq[1] = -L::cold_get(K_RP + 1);
           this->template kkt_solve_t<LAY_RED>(rhs, nreq, dx, dnu);
+          if (SOFT && pass == 1) {
+            // one refinement step against the UN-regularised Newton matrix (Solver::ipm: a clean ray is what phase 1 is asked
+            // for).  The step waits in the residuals' slots - free until the next iteration - while the second solve runs.
+            R Ad[2], Atd[3], r1[3], r2[2];
+            this->template Aeq_mul_t<LAY_RED>(dx, Ad);
+            this->template AeqT_mul_t<LAY_RED>(dnu, Atd);
+            r1[1] = rhs[1] - Atd[1];                                  // (H - reg of the free entry is zero)
+            MPMPC_UNROLL
+            for (int b = 0; b < 2; ++b) {
+              const int j = JB[b];
+              r1[j] = rhs[j] - fma_((one - kap[b]) + sel(bx.pin[j], ireg, zero), dx[j], Atd[j]);
+            }
+            r2[0] = nreq[0] - Ad[0]; r2[1] = nreq[1] - Ad[1];
+            L::fence();
+            MPMPC_UNROLL
+            for (int j = 0; j < 3; ++j) L::cold_put(K_RD + j, dx[j]);
+            L::cold_put(K_RP, dnu[0]); L::cold_put(K_RP + 1, dnu[1]);
+            L::fence();
+            R ddx[3], ddn[2];
+            this->template kkt_solve_t<LAY_RED>(r1, r2, ddx, ddn);
+            L::fence();
+            MPMPC_UNROLL
+            for (int j = 0; j < 3; ++j) dx[j] = L::cold_get(K_RD + j) + sel(val[j], ddx[j], zero);
+            dnu[0] = L::cold_get(K_RP) + sel(vx, ddn[0], zero);
+            dnu[1] = L::cold_get(K_RP + 1) + sel(vx, ddn[1], zero);
+          }
         }
         L::fence();
         // largest step that keeps slacks and multipliers positive: 1 / max(-ds/s, -dz/z)
@@ -357,8 +429,9 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
         MPMPC_UNROLL
         for (int b = 0; b < 2; ++b) {
           const int j = JB[b];
-          dsl[b] = dx[j] + rl_of(b);
-          dsu[b] = -dx[j] + ru_of(b);
+          const R ex = SOFT ? kap[b] * (dx[j] + cul[b]) : dx[j];          // step of x + w:  k (dx + cu - cl)
+          dsl[b] = ex + rl_of(b);
+          dsu[b] = -ex + ru_of(b);
           dzl[b] = -fma_(s.zl[j], dsl[b], rcl[b]) * isl[b];
           dzu[b] = -fma_(s.zu[j], dsu[b], rcu[b]) * isu[b];
           dpi[b] = sel(bx.pin[j], (rpin_of(b) + dx[j]) * ireg, zero);
@@ -395,8 +468,10 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
           for (int b = 0; b < 2; ++b) {
             const int j = JB[b];
             s.x[j] = sel(active, fma_(al, dx[j], s.x[j]), s.x[j]);
-            s.tL[j] = selb(active, bx.Lm[j] & (dsl[b] * s.zl[j] < dzl[b] * s.sl[j]), s.tL[j]);
-            s.tU[j] = selb(active, bx.Um[j] & (dsu[b] * s.zu[j] < dzu[b] * s.su[j]), s.tU[j]);
+            if constexpr (!SOFT) {
+              s.tL[j] = selb(active, bx.Lm[j] & (dsl[b] * s.zl[j] < dzl[b] * s.sl[j]), s.tL[j]);
+              s.tU[j] = selb(active, bx.Um[j] & (dsu[b] * s.zu[j] < dzu[b] * s.su[j]), s.tU[j]);
+            }
             s.sl[j] = sel(active, fma_(al, dsl[b], s.sl[j]), s.sl[j]);
             s.su[j] = sel(active, fma_(al, dsu[b], s.su[j]), s.su[j]);
             s.zl[j] = sel(active, fma_(al, dzl[b], s.zl[j]), s.zl[j]);

@@ -43,18 +43,21 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
   using BoxI = typename RS::BoxI;
   using IpmI = typename RS::IpmI;
   static constexpr int EI = RS::EI;
-  // ---- cold slots of its own: ReducedSolver's K_PARK .. slots belong to the parked iterate / the packed interior point's
-  //      residuals from the first attempt on - everything here is consumed before that
-  //   T_RAW .. +3    unscaled box of e_y and kappa (the verdict and the relaxation work in the unscaled problem)
+  // ---- cold slots of its own, in places nothing else uses until the verdict is out: the last three slots of the parking
+  //      area (the packed interior point's residuals end below them) and the slots of the start's pin multipliers (there are
+  //      none here: attempts() is given the box-row scalings in registers and then reads neither)
+  //   T_RAW0 .. 3    unscaled box of e_y and kappa (the verdict and the relaxation work in the unscaled problem)
   //   T_NAX          largest finite bound / speed of the instance (OSQP's max(|Ax|, |z|), see Solver::phase1)
   //   T_RD0          dual residual of the speed entry at the start of the attempt (scaled problem)
-  //   T_MARK         C_GAP's slot (the gap of an empty box is kept in a register here): on the lanes of an instance that hold
-  //                  no stage, the violation of a MARGINAL instance - read back after the attempt, so that no mask and no
-  //                  scalar of the verdict lives through it; zero otherwise
+  //   T_MARK         C_GAP's slot (the gap of an empty box is kept in a register here): the violation of a MARGINAL instance on
+  //                  its lanes, zero otherwise - read back after the attempt, so that no mask and no scalar of the verdict
+  //                  lives through it
   // The least-violation point of a verdict (infeasible: with its ray; marginal: with zero multipliers, in case the attempt
   // fails) goes to the slots of the certified point BEFORE the attempt, which then commits in merge mode: what it certifies
   // replaces it, what it does not leaves it there.
-  enum { T_RAW = 32, T_NAX = 36, T_RD0 = 37, T_MARK = RS::C_GAP };
+  enum { T_RAW0 = 37, T_RAW1 = 38, T_RAW2 = 39, T_RAW3 = RS::C_PI, T_NAX = RS::C_PI + 1, T_RD0 = RS::C_PI + 2, T_MARK = RS::C_GAP };
+  static_assert(RS::K_RP + 2 <= 37, "the packed interior point's residual slots must end below T_RAW0");
+  MPMPC_HD static constexpr int t_raw(int i) { return i == 0 ? T_RAW0 : (i == 1 ? T_RAW1 : (i == 2 ? T_RAW2 : T_RAW3)); }
 
   // (No mask of this solver lives through the attempt: "marginal" is read back from T_LV0, and the store tells a ray -
   //  status PRIMAL_INFEASIBLE of a non-empty box - and a bare least-violation point - SOLVED_INACCURATE that no attempt
@@ -87,7 +90,6 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
       pri_res = gap;          // (kept in a register here: the slot C_GAP serves as T_MARK)
       L::cold_put(T_MARK, zero);
     }
-    L::cold_put(T_RAW + 0, lo_e); L::cold_put(T_RAW + 1, hi_e); L::cold_put(T_RAW + 2, lo_k); L::cold_put(T_RAW + 3, hi_k);
     {
       auto fin = [&](const R& bnd) { return sel(abs_(bnd) < R(INF_BOUND), abs_(bnd), zero); };
       R m = sel(vx, max_(fin(lo_e), fin(hi_e)), zero);
@@ -118,9 +120,9 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
       P3[e] = S::p[J5[e]]; Q3[e] = S::q[J5[e]];
       L::cold_put(C_D + e, S::D[J5[e]]);
       L::cold_put(C_G + e, S::g[J5[e]]);
-      L::cold_put(C_PI + e, zero);
       x3[e] = zero;
     }
+    L::cold_put(T_RAW0, lo_e); L::cold_put(T_RAW1, hi_e); L::cold_put(T_RAW2, lo_k); L::cold_put(T_RAW3, hi_k);
     leq[0] = S::Eeq[0] * fld(F_BEQ + 0, 0.0);
     leq[1] = S::Eeq[1] * fld(F_BEQ + 1, 0.0);
     L::cold_put(C_E, S::Eeq[0]); L::cold_put(C_E + 1, S::Eeq[1]);
@@ -145,7 +147,7 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
     for (int b2 = 0; b2 < 2; ++b2) {
       const int e = b2 == 0 ? 0 : 2;
       const R xu = L::cold_get(C_D + e) * xs[e];
-      pv = max_(pv, sel(val[e], max_(max_(L::cold_get(T_RAW + 2 * b2) - xu, xu - L::cold_get(T_RAW + 2 * b2 + 1)), zero), zero));
+      pv = max_(pv, sel(val[e], max_(max_(L::cold_get(t_raw(2 * b2)) - xu, xu - L::cold_get(t_raw(2 * b2 + 1))), zero), zero));
     }
     return L::gmax(pv);
   }
@@ -204,7 +206,23 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
         S::p1_converged = L::mfalse();
         MPMPC_TICK_BEGIN(9);
         // (two digits further than the polish: Solver::phase1)
-        this->template ipm<RS::LAY_IP, true>(bi, si, nullptr, nullptr, vm, st, st.ipm_tol * 1e-2 < 1e-11 ? st.ipm_tol * 1e-2 : 1e-11, todo);
+        const double tol1 = st.ipm_tol * 1e-2 < 1e-11 ? st.ipm_tol * 1e-2 : 1e-11;
+        if constexpr (RS::kSplit) {
+          this->template ipm<RS::LAY_IP, true>(bi, si, nullptr, nullptr, vm, st, tol1, todo);
+        } else {
+          // the packed interior point reads the equality offsets from LDS; the cost - not read in phase 1 - waits in its own
+          // slots there meanwhile instead of in twelve registers
+          MPMPC_UNROLL
+          for (int e = 0; e < 3; ++e) { L::cold_put(RS::K_PP + e, P3[e]); L::cold_put(RS::K_QQ + e, Q3[e]); }
+          L::cold_put(RS::K_LEQ, leq[0]); L::cold_put(RS::K_LEQ + 1, leq[1]);
+          L::fence();
+          RS::template ipm3<true>(bi, si, st, tol1, todo);
+          L::fence();
+          MPMPC_UNROLL
+          for (int e = 0; e < 3; ++e) { P3[e] = L::cold_get(RS::K_PP + e); Q3[e] = L::cold_get(RS::K_QQ + e); }
+          leq[0] = L::cold_get(RS::K_LEQ); leq[1] = L::cold_get(RS::K_LEQ + 1);
+          b3.lo[0] = L::cold_get(K_LO0); b3.hi[0] = L::cold_get(K_HI0); b3.lo[2] = L::cold_get(K_LO2); b3.hi[2] = L::cold_get(K_HI2);
+        }
         MPMPC_TICK_END(9);
         L::fence();
         // point and ray (lam = zu - zl + pi in variable space)
@@ -272,7 +290,7 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
           for (int b2 = 0; b2 < 2; ++b2) {
             const int e = b2 == 0 ? 0 : 2;
             const R De = L::cold_get(C_D + e), ge = L::cold_get(C_G + e);
-            const R xu = De * xs[e], lo0 = L::cold_get(T_RAW + 2 * b2), hi0 = L::cold_get(T_RAW + 2 * b2 + 1);
+            const R xu = De * xs[e], lo0 = L::cold_get(t_raw(2 * b2)), hi0 = L::cold_get(t_raw(2 * b2 + 1));
             const R wl = sel(val[e] & (lo0 > R(-INF_BOUND)), max_(lo0 - xu, zero), zero);
             const R wh = sel(val[e] & (hi0 < R(INF_BOUND)), max_(xu - hi0, zero), zero);
             const R lo1 = fma_(R(-1.5), wl, lo0), hi1 = fma_(R(1.5), wh, hi0);
@@ -282,7 +300,7 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
             L::cold_put(e == 0 ? K_LO0 : K_LO2, sel(marginal, (Ebe * lo1) / ge, L::cold_get(e == 0 ? K_LO0 : K_LO2)));
             L::cold_put(e == 0 ? K_HI0 : K_HI2, sel(marginal, (Ebe * hi1) / ge, L::cold_get(e == 0 ? K_HI0 : K_HI2)));
           }
-          L::cold_put(T_MARK, sel(marginal & !vx, prim, zero));
+          L::cold_put(T_MARK, sel(marginal, prim, zero));
           L::fence();
           RS::make_box3(b3);
         }
@@ -294,6 +312,7 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
       R g3[3];
       MPMPC_UNROLL
       for (int e = 0; e < 3; ++e) g3[e] = L::cold_get(C_G + e);
+      const R rd0v = L::cold_get(T_RD0);          // (its slot is one of the point's as well)
       L::fence();
       // ---- the point of a verdict: least-violation point, for "infeasible" with the ray; for a marginal instance with zero
       //      multipliers - what it ends with if the attempt cannot certify the optimum over the relaxed boxes
@@ -314,13 +333,12 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
       if (L::wany(retry)) {
         MPMPC_UNROLL
         for (int e = 0; e < 3; ++e) x3[e] = sel(retry, xs[e], zero);
-        const R rd0v = L::cold_get(T_RD0);
         // (merge mode: what the attempt certifies replaces the point in the slots, what it does not leaves it there)
         (void)RS::template attempts<false>(b3, st, st.ipm_max_iter, retry, true, &rd0v, g3);
         // a marginal instance ends here: the optimum over the relaxed boxes, or - if the attempt could not certify that -
         // phase 1's least-violation point itself; either way a usable, inaccurate plan
         L::fence();
-        const R viol = L::gmax(sel(vx, zero, L::cold_get(T_MARK)));        // > 0: the instance was marginal
+        const R viol = L::gmax(L::cold_get(T_MARK));        // > 0: the instance was marginal
         const Mk mg = (viol > zero) & ((status == MPMPC_SOLVED) | (status == MPMPC_UNSOLVED));
         status = seli(mg, I(MPMPC_SOLVED_INACCURATE), status);
         pri_res = sel(mg, viol, pri_res);

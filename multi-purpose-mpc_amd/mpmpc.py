@@ -231,8 +231,8 @@ class Handle:
         self._check(self.lib.mpmpc_set_packing(self._h, int(lanes_per_instance)))
 
     def set_tail_kernel(self, reduced_native: bool = True):
-        """True / 1 (default): the reduced-native tail kernel takes the tail of a batch launch first; False / 0: the general kernel
-        takes all of it (parity tests, A/B timings); 2: experimental - the tail kernel with two instances per wavefront."""
+        """True / 1 (default): the reduced-native tail kernel takes the tail of a batch launch first, two instances per wavefront;
+        2: the same, one instance per wavefront; False / 0: the general kernel takes all of it (parity tests, A/B timings)."""
         self._check(self.lib.mpmpc_set_tail_kernel(self._h, int(reduced_native)))
 
     def set_path(self, kappa, v_ref, ds_next):

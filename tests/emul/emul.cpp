@@ -102,8 +102,9 @@ static void solve_rnt(const mpmpc_config* cfg, const mpmpc_settings* st, const d
 }
 // mpmpc_reduced_tail_kernel: the reduced-native tail solver on the instances listed in tail; what it leaves UNSOLVED is
 // appended to tail2[1..]
-static int g_emu_lean_tail = 1;          // emu_set_lean_tail: 0 = the general kernel takes the whole tail (as before round 4);
-                                         // 2 = the tail solver with TWO instances per wave (32 lanes each, three entries per lane)
+static int g_emu_lean_tail = 1;          // emu_set_lean_tail, like mpmpc_set_tail_kernel: 0 = the general kernel takes the whole
+                                         // tail (as before round 4); 1 = the tail solver, TWO instances per wave (32 lanes each,
+                                         // three entries per lane: the device's default); 2 = the tail solver, one instance per wave
 template <int G, int C>
 static void solve_rn_tail(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
                           int* status, int* iters, double* resid, double* y, const int* tail, int* tail2) {
@@ -194,7 +195,7 @@ extern "C" int emu_solve_launch(const mpmpc_config* cfg, const mpmpc_settings* s
     if (g_emu_lean_tail && !reduced_native_tt(*cfg, *st) && reduced_native_tail(*cfg, *st)) {
       // the reduced-native tail solver first; the general kernel on what that leaves
       std::vector<int> tail2(B + 1, 0);
-      if (g_emu_lean_tail == 2) solve_rn_tail<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data(), tail2.data());
+      if (g_emu_lean_tail != 2) solve_rn_tail<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data(), tail2.data());
       else solve_rn_tail<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data(), tail2.data());
       tail.swap(tail2);
       g_emu_tail2 = tail[0];

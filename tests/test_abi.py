@@ -99,7 +99,7 @@ def test_reduced_native_kernels_fit_two_waves_per_simd(lib):
     assert sorted(r["name"] for r in tail) == ["mpmpc_reduced_tail_kernel<32, 16>", "mpmpc_reduced_tail_kernel<64, 16>"], tail
     for r in tail:
         assert r["vgpr"] <= 256 and r["agpr"] == 0 and r["lds"] <= 20 * 1024, r
-        assert r["scratch"] <= (8 if "<64, 16>" in r["name"] else 152), r
+        assert r["scratch"] <= (8 if "<64, 16>" in r["name"] else 0), r
     for r in rows + tt:
         assert r["scratch"] == 0, r
         assert r["vgpr"] <= 256 and r["agpr"] == 0, r
@@ -115,13 +115,11 @@ def test_no_batch_path_solve_kernel_has_scratch(lib):
     KNOWN_SCRATCH = {
         "mpmpc_solve_kernel<64, 32, false, 0>": 116, "mpmpc_solve_kernel<64, 32, true, 0>": 236,
         "mpmpc_solve_kernel<64, 32, false, 1>": 192, "mpmpc_solve_kernel<64, 32, true, 1>": 288,
-        # the reduced-native tail kernel: ONE dword (a lane mask the compiler keeps as 0 / 1 in a VGPR), stored once before
+        # the one-instance-per-wave form of the reduced-native tail kernel (mpmpc_set_tail_kernel(h, 2); the default form,
+        # <32, 16>, has none): ONE dword (a lane mask the compiler keeps as 0 / 1 in a VGPR), stored once before
         # and read once inside each attempt of a tail instance - 10 % of a config-4 batch; its two-waves-per-SIMD budget
         # (256 registers, 20 KB of LDS) is asserted in test_reduced_native_kernels_fit_two_waves_per_simd
         "mpmpc_reduced_tail_kernel<64, 16>": 8,
-        # experimental, NOT the default (mpmpc_set_tail_kernel(h, 2)): two tail instances per wave through the general soft
-        # interior point in the three-entries-per-lane layout; what it would take to ship it is in DESIGN.md section 9
-        "mpmpc_reduced_tail_kernel<32, 16>": 152,
     }       # (the shipped values, profiles/r4/kernel_resources.txt: a regression of a single dword fails)
     rows = [r for r in _kernel_rows(lib) if "solve_kernel" in r["name"] or "reduced_kernel" in r["name"] or "reduced_t_kernel" in r["name"]
             or "reduced_tail_kernel" in r["name"]]

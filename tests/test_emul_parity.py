@@ -185,8 +185,10 @@ def test_warm_start_reproduces_the_cold_solution(cfgid, G, emu, track):
     st = mpmpc.default_settings()
     cold, act = emu.solve_warm(cfg, st, qp, np.zeros((sc.B, mpmpc.stage_ld(sc.N)), np.int32), G=G)
     ref, _ = emu.solve_launch(cfg, st, qp, G=G)          # the launcher's cold sequence of kernels
-    assert np.array_equal(cold.status, ref.status) and np.array_equal(cold.u0, ref.u0)      # no guess: the plain path
     ok = cold.status == 1
+    # no guess: the plain path (the closed loop hands its tail to the general kernel, the batch launch to the tail solver:
+    # an infeasible instance's least-violation point agrees to ~1e-8 between the two)
+    assert np.array_equal(cold.status, ref.status) and np.array_equal(cold.u0[ok], ref.u0[ok]) and np.max(np.abs(cold.u0 - ref.u0)) <= 1e-6
     assert np.all((act[ok, 0] >> 30) & 1) and not np.any(act[~ok])
     warm, act2 = emu.solve_warm(cfg, st, qp, act, G=G)
     assert np.array_equal(warm.status, cold.status)
@@ -489,10 +491,12 @@ def test_cyclic_reduction_of_the_32_lane_chains_agrees_with_the_sequential_elimi
 @pytest.mark.parametrize("cfgid,B,N,accept", [(4, 768, 30, 1), (4, 384, 30, 0), (5, 512, 30, 1), (4, 192, 10, 1), (4, 96, 3, 1)])
 def test_reduced_native_tail_solver_gives_the_general_kernels_answers(cfgid, B, N, accept, emu, track):
     """The tail of a reduced-native launch goes to ReducedTailSolver (mpmpc_reduced_tail.hpp: phase 1 and one more attempt of
-    the certified polish, three entries per lane) before the general kernel sees it.  Same launch with the general kernel on
-    the whole tail (emu_set_lean_tail(0), the sequence of rounds 2 - 3): statuses identical; points, multipliers and residuals
-    equal to rounding - the two run the same interior point on the same scaling; and the tail solver leaves the general
-    kernel nothing on these batches (infeasible, marginally infeasible and capped instances are all it gets)."""
+    the certified polish, three entries per lane) before the general kernel sees it.  Its one-instance-per-wave form
+    (emu_set_lean_tail(2): the split layout, the general kernel's own phase-1 routine) against the same launch with the general
+    kernel on the whole tail (emu_set_lean_tail(0), the sequence of rounds 2 - 3): statuses identical; points, multipliers and
+    residuals equal to rounding - the two run the same interior point on the same scaling; and the tail solver leaves the general
+    kernel nothing on these batches (infeasible, marginally infeasible and capped instances are all it gets).  (The default,
+    two instances per wave, is compared with this form in test_two_tail_instances_per_wave_give_the_same_verdicts.)"""
     import ctypes as C
     sc = scenarios.make(cfgid, track, B=B, N=N)
     cfg = T.stock_config(sc.N, sc.weights)
@@ -503,11 +507,13 @@ def test_reduced_native_tail_solver_gives_the_general_kernels_answers(cfgid, B, 
         emu.lib.emu_set_lean_tail(0)
         gen, n_tail = emu.solve_launch(cfg, st, qp, G=32 if N + 1 <= 32 else 64)
         assert emu.lib.emu_last_tail2() == n_tail            # (knob off: the general kernel gets the whole tail)
+        emu.lib.emu_set_lean_tail(2)
+        lean, n_tail2 = emu.solve_launch(cfg, st, qp, G=32 if N + 1 <= 32 else 64)
+        left = emu.lib.emu_last_tail2()
     finally:
         emu.lib.emu_set_lean_tail(1)
-    lean, n_tail2 = emu.solve_launch(cfg, st, qp, G=32 if N + 1 <= 32 else 64)
     assert n_tail2 == n_tail and n_tail >= 3
-    assert emu.lib.emu_last_tail2() == 0
+    assert left == 0
     assert np.array_equal(lean.status, gen.status)
     assert np.count_nonzero(lean.status == mpmpc.PRIMAL_INFEASIBLE) >= 2
     if accept and N == 30:
@@ -552,11 +558,18 @@ def test_reduced_native_tail_solver_fallbacks(emu, track):
     try:
         emu.lib.emu_set_lean_tail(0)
         gen, n_tail = emu.solve_launch(cfg, st, qps, G=32)
+        emu.lib.emu_set_lean_tail(2)
+        lean, n_tail2 = emu.solve_launch(cfg, st, qps, G=32)
+        left = emu.lib.emu_last_tail2()
     finally:
         emu.lib.emu_set_lean_tail(1)
-    lean, n_tail2 = emu.solve_launch(cfg, st, qps, G=32)
     assert n_tail == n_tail2 == 8
-    assert emu.lib.emu_last_tail2() == 3                   # the three feasible instances
+    assert left == 3                                       # the three feasible instances
+    # (the default form, two instances per wave: the same verdicts, the same three left over)
+    packed, _ = emu.solve_launch(cfg, st, qps, G=32)
+    assert emu.lib.emu_last_tail2() == 3 and np.array_equal(packed.status, gen.status) and np.array_equal(packed.iters, gen.iters)
+    np.testing.assert_allclose(packed.z, gen.z, rtol=0, atol=1e-6)
+    assert np.all(packed.y[:3] == 0.0)
     assert list(lean.status) == [2, 2, 2, mpmpc.PRIMAL_INFEASIBLE, mpmpc.PRIMAL_INFEASIBLE, 2, 2, 2] == list(gen.status)
     assert np.all(lean.iters[5:, 0] > 25) and np.all(lean.iters[:5, 0] == 1)
     assert np.array_equal(lean.iters, gen.iters)
@@ -568,19 +581,20 @@ def test_reduced_native_tail_solver_fallbacks(emu, track):
 
 
 def test_two_tail_instances_per_wave_give_the_same_verdicts(emu, track):
-    """The experimental packing of the tail solver (mpmpc_set_tail_kernel(h, 2) / emu_set_lean_tail(2): 32 lanes per instance,
-    three entries per lane, the general soft interior point for phase 1) against the shipped one-instance-per-wave form: the
-    same statuses and iteration counts; the least-violation points, rays and relaxed plans agree to ~1e-7 (phase 1 converges
-    to 1e-11 in the scaled problem along a different arithmetic path), certified optima to 1e-9."""
+    """The default form of the tail solver - two instances per wave, 32 lanes each, three entries per lane, phase 1 through
+    ipm3<SOFT> - against its one-instance-per-wave form (mpmpc_set_tail_kernel(h, 2) / emu_set_lean_tail(2): the split layout,
+    the general routine): the same statuses and iteration counts; the least-violation points, rays and relaxed plans agree to
+    ~1e-7 (phase 1 converges to 1e-11 in the scaled problem along a different arithmetic path), certified optima to 1e-9."""
     for cfgid, B, accept in ((4, 513, 1), (5, 300, 1), (4, 257, 0)):
         sc = scenarios.make(cfgid, track, B=B)
         cfg = T.stock_config(sc.N, sc.weights)
         qp = emu.assemble(cfg, track, _inputs(sc))
         st = mpmpc.default_settings(phase1_accept=accept)
-        one, n_tail = emu.solve_launch(cfg, st, qp, G=32)
+        two, n_tail2 = emu.solve_launch(cfg, st, qp, G=32)
+        assert emu.lib.emu_last_tail2() == 0
         try:
             emu.lib.emu_set_lean_tail(2)
-            two, n_tail2 = emu.solve_launch(cfg, st, qp, G=32)
+            one, n_tail = emu.solve_launch(cfg, st, qp, G=32)
             assert emu.lib.emu_last_tail2() == 0
         finally:
             emu.lib.emu_set_lean_tail(1)

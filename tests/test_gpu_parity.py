@@ -1044,14 +1044,15 @@ def test_empty_speed_box_is_reported_at_once_on_device(native, track):
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfgid,B,accept", [(4, 4096, 1), (5, 2048, 1), (4, 1024, 0)])
 def test_reduced_native_tail_kernel_gives_the_general_kernels_answers(cfgid, B, accept, track):
-    """K2p (mpmpc_reduced_tail_kernel) takes the tail of a batch launch before the general kernel does.  The same launch
-    with mpmpc_set_tail_kernel(h, 0) - the general kernel on the whole tail, the sequence of rounds 2 - 3: statuses identical,
-    points / multipliers / residuals equal to rounding (same interior point, same scaling), for one launch at a time and for
-    pipelined resident launches."""
+    """K2p (mpmpc_reduced_tail_kernel) takes the tail of a batch launch before the general kernel does.  Its
+    one-instance-per-wave form (mpmpc_set_tail_kernel(h, 2)) against the same launch with mpmpc_set_tail_kernel(h, 0) - the
+    general kernel on the whole tail, the sequence of rounds 2 - 3: statuses identical, points / multipliers / residuals equal
+    to rounding (same interior point, same scaling), for one launch at a time and for pipelined resident launches.  The default
+    form (two instances per wave) against both: same statuses, certified optima to 1e-9, least-violation points to 1e-6."""
     sc = scenarios.make(cfgid, track, B=B)
     st = mpmpc.default_settings(phase1_accept=accept)
     res = {}
-    for lean in (True, False):
+    for lean in (2, 0, 1):
         h = _handle(track, sc.N, sc.weights, B, settings=st)
         h.set_tail_kernel(lean)
         h.set_outputs(True)
@@ -1063,7 +1064,12 @@ def test_reduced_native_tail_kernel_gives_the_general_kernels_answers(cfgid, B, 
         assert np.array_equal(one.status, many.status)
         np.testing.assert_allclose(many.z, one.z, rtol=0, atol=1e-9)      # (a packed wave's partner differs between the two paths)
         res[lean] = one
-    a, b = res[True], res[False]
+    a, b, dflt = res[2], res[0], res[1]
+    assert np.array_equal(dflt.status, b.status) and np.array_equal(dflt.iters[:, 0], b.iters[:, 0])
+    okd = dflt.status == 1
+    np.testing.assert_allclose(dflt.z[okd], b.z[okd], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(dflt.z, b.z, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(dflt.resid[:, 0], b.resid[:, 0], rtol=1e-6, atol=1e-9)
     assert np.array_equal(a.status, b.status)
     assert (a.status == mpmpc.PRIMAL_INFEASIBLE).sum() >= 20
     if accept:
@@ -1078,17 +1084,24 @@ def test_reduced_native_tail_kernel_gives_the_general_kernels_answers(cfgid, B, 
 
 @pytest.mark.gpu
 def test_two_tail_instances_per_wave_on_device(track, emu):
-    """mpmpc_set_tail_kernel(h, 2), the experimental packing of the tail kernel: statuses of the shipped form, points within
-    1e-6 (certified optima 1e-9), and bit for bit what the emulation of the same kernel gives on statuses."""
+    """The default form of the tail kernel (two instances per wave, an odd tail included) against mpmpc_set_tail_kernel(h, 2),
+    one instance per wave: the same statuses, points within 1e-6 (certified optima 1e-9), and what the emulation of the same
+    kernel gives."""
     sc = scenarios.make(4, track, B=2049)
     res = {}
-    for mode in (1, 2):
+    for mode in (2, 1):
         h = _handle(track, sc.N, sc.weights, sc.B)
         h.set_tail_kernel(mode)
         res[mode] = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
-    a, b = res[1], res[2]
-    assert np.array_equal(a.status, b.status) and (a.status == mpmpc.PRIMAL_INFEASIBLE).sum() >= 100 and (a.status == 2).sum() >= 5
+    a, b = res[2], res[1]
     ok = a.status == 1
+    cfg = T.stock_config(sc.N, sc.weights)
+    qp = emu.assemble(cfg, track, (sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub))
+    e, _ = emu.solve_launch(cfg, mpmpc.default_settings(), qp, G=32)
+    # (least-violation points of infeasible instances sit in flat directions of phase 1's problem: the device's reciprocal
+    #  seeds and the emulation's divisions end micrometres apart there; certified optima agree to 1e-9)
+    assert np.array_equal(e.status, b.status) and np.max(np.abs(e.z[ok] - b.z[ok])) <= 1e-9 and np.max(np.abs(e.z - b.z)) <= 1e-4
+    assert np.array_equal(a.status, b.status) and (a.status == mpmpc.PRIMAL_INFEASIBLE).sum() >= 100 and (a.status == 2).sum() >= 5
     np.testing.assert_allclose(b.z[ok], a.z[ok], rtol=0, atol=1e-9)
     np.testing.assert_allclose(b.z, a.z, rtol=0, atol=1e-6)
     np.testing.assert_allclose(b.resid[:, 0], a.resid[:, 0], rtol=1e-6, atol=1e-9)
@@ -1110,7 +1123,7 @@ def test_what_the_tail_kernel_leaves_reaches_the_general_kernel_also_when_deferr
     old.set_tail_kernel(False)
     gen = old.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
     assert np.array_equal(gen.status, ref.status) and np.array_equal(gen.iters[:, 0], ref.iters[:, 0])
-    np.testing.assert_allclose(ref.z, gen.z, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(ref.z, gen.z, rtol=0, atol=1e-6)          # (least-violation points: the default form's phase 1)
 
     def same(a, b):
         assert np.array_equal(a.status, b.status) and np.array_equal(a.iters, b.iters)
