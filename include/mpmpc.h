@@ -179,8 +179,8 @@ int mpmpc_set_settings(mpmpc_handle h, const mpmpc_settings* settings);
 int mpmpc_set_packing(mpmpc_handle h, int32_t lanes_per_instance);
 /* Which kernel takes the TAIL of a batch launch - the instances the reduced-native kernel could not certify: infeasible,
  * marginally infeasible and very hard ones.  1 (default) = the reduced-native tail kernel first (phase 1 and one more
- * attempt of the certified polish on the (e_y, e_psi, kappa) problem, two wavefronts per SIMD, two instances per wavefront;
- * horizons up to 31), the general kernel only on what that leaves; 2 = the same with ONE instance per wavefront (the split
+ * attempt of the certified polish on the (e_y, e_psi, kappa) problem, two wavefronts per SIMD, two instances per wavefront
+ * for horizons up to 31, one for horizons 32 .. 63), the general kernel only on what that leaves; 2 = the same with ONE instance per wavefront (the split
  * layout of the general kernel's phase 1: its answers to rounding, 4e-16); 0 = the general kernel on the whole tail (one
  * wavefront per SIMD).  Same statuses in all three; least-violation points and relaxed plans of 1 agree with those of 2 / 0
  * to ~1e-8 (phase 1 converges along another arithmetic path).  Parity tests, A/B timings. */

@@ -240,9 +240,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 
 // K2p: the reduced-native TAIL kernel (mpmpc_reduced_tail.hpp): phase 1 and one more attempt of the certified polish on
-// the instances the reduced-native launch listed in `tail` - two per wave (<32,16>, the default: 241 registers, no scratch)
-// or one per wave (<64,16>, the split layout) - within the same 256 registers and 40 LDS slots: a tail wave shares its
-// SIMD.  What it leaves UNSOLVED is appended to tail2 for the general kernel (mode 2).
+// the instances the reduced-native launch listed in `tail` - two per wave (<32,16>, the default: 243 registers, no scratch),
+// one per wave in the split layout (<64,16>) or, for horizons 32 .. 63, one per wave with a lane per stage (<64,32>: 235
+// registers, no scratch) - within the same 256 registers and 40 LDS slots: a tail wave shares its SIMD.  What it leaves UNSOLVED is appended to tail2 for the general kernel (mode 2).
 template <int G, int C>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void mpmpc_reduced_tail_kernel(mpmpc_config cfg, SolverParams st, int B, AssembleIn ain,
                                                            double* __restrict__ z, double* __restrict__ u0,
@@ -1373,7 +1373,10 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
       if (tail_only != 2) {
         // (the list's order differs from run to run - atomic appends - and with it the two instances that share a wave of the
         //  packed form: the solver's arithmetic does not depend on the partner, Solver::active_set)
-        if (!h->lean_tail_single) {
+        if (lane_split(64, N) == 32)          // horizons 32 .. 63: one lane per stage, one instance per wave
+          hipLaunchKernelGGL((mpmpc_reduced_tail_kernel<64, 32>), dim3(B), dim3(64), rn_pad, h->stream, h->cfg, prm, B, ain, h->z, h->u0,
+                             h->status, h->iters, h->resid, y_out, tail_cur, tail_next, tail2, h->tail_flag + 1, h->seq);
+        else if (!h->lean_tail_single) {
           hipLaunchKernelGGL((mpmpc_reduced_tail_kernel<32, 16>), dim3((B + 1) / 2), dim3(64), rn_pad, h->stream, h->cfg, prm, B, ain, h->z,
                              h->u0, h->status, h->iters, h->resid, y_out, tail_cur, tail_next, tail2, h->tail_flag + 1, h->seq);
         } else
@@ -1386,7 +1389,8 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
         h->pend_B = B; h->pend_y = want_y; h->pend_cur = tail_cur; h->pend_next = tail_next;
       } else {
         tail_cur = tail2;
-        LAUNCH(16, false, 2, B);
+        if (lane_split(64, N) == 16) LAUNCH(16, false, 2, B);
+        else LAUNCH(32, false, 2, B);
       }
     } else if (lane_split(64, N) == 16) LAUNCH(16, false, 2, B);
     else LAUNCH(32, false, 2, B);

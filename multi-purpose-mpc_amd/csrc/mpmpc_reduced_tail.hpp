@@ -20,9 +20,9 @@
 
 namespace mpmpc {
 
-// May the tail of a reduced-native launch run this solver first?  (horizons up to 31: the split layout of the interior point)
+// May the tail of a reduced-native launch run this solver first?  (every configuration the first kernel runs, with phase 1 on)
 inline bool reduced_native_tail(const mpmpc_config& c, const mpmpc_settings& st) {
-  return reduced_native(c, st) && st.phase1 != 0 && lane_split(64, c.N) == 16;
+  return reduced_native(c, st) && st.phase1 != 0;
 }
 
 template <class L, bool CR = true>

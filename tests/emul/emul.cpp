@@ -195,7 +195,8 @@ extern "C" int emu_solve_launch(const mpmpc_config* cfg, const mpmpc_settings* s
     if (g_emu_lean_tail && !reduced_native_tt(*cfg, *st) && reduced_native_tail(*cfg, *st)) {
       // the reduced-native tail solver first; the general kernel on what that leaves
       std::vector<int> tail2(B + 1, 0);
-      if (g_emu_lean_tail != 2) solve_rn_tail<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data(), tail2.data());
+      if (lane_split(64, cfg->N) == 32) solve_rn_tail<64, 32>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data(), tail2.data());
+      else if (g_emu_lean_tail != 2) solve_rn_tail<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data(), tail2.data());
       else solve_rn_tail<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data(), tail2.data());
       tail.swap(tail2);
       g_emu_tail2 = tail[0];

@@ -528,11 +528,11 @@ def test_reduced_native_tail_solver_gives_the_general_kernels_answers(cfgid, B, 
     assert np.max(np.abs(lean.iters[:, 1] - gen.iters[:, 1])) <= 4
 
 
-def test_reduced_native_tail_solver_applies_to_the_split_layout_only(emu):
-    """Horizons above 31 (one lane per stage, no free half-wave) keep the general kernel for their tail."""
+def test_where_the_reduced_native_tail_solver_applies(emu):
+    """Every configuration the reduced-native first kernel runs (stock-type weights, any horizon up to 63) with phase 1 on."""
     import ctypes as C
     st = mpmpc.default_settings()
-    for N, want in ((3, 1), (30, 1), (31, 1), (32, 0), (50, 0)):
+    for N, want in ((3, 1), (30, 1), (31, 1), (32, 1), (50, 1)):
         cfg = T.stock_config(N, "stock")
         assert emu.lib.emu_reduced_native_tail(C.byref(cfg), C.byref(st)) == want, N
     cfg = T.stock_config(30, "time_optimal")           # the terminal-time weights have their own kernel, and the general tail
@@ -608,3 +608,28 @@ def test_two_tail_instances_per_wave_give_the_same_verdicts(emu, track):
         inf = np.flatnonzero(two.status == mpmpc.PRIMAL_INFEASIBLE)
         for i in inf[:12]:
             assert _farkas_ok(qp[:, i, :], sc.N, two.y[i])
+
+
+@pytest.mark.parametrize("N,B", [(40, 160), (50, 96), (32, 120)])
+def test_reduced_native_tail_solver_at_horizons_above_31(N, B, emu, track):
+    """Horizons 32 .. 63: one lane per stage, one instance per wave (<64, 32>), phase 1 through ipm3<SOFT>.  Against the general
+    kernel on the whole tail: the same statuses and ADMM counters, certified optima to 1e-9, least-violation points and relaxed
+    plans to 1e-6; nothing left to the general kernel."""
+    sc = scenarios.make(4, track, B=B, N=N)
+    cfg = T.stock_config(sc.N, sc.weights)
+    qp = emu.assemble(cfg, track, _inputs(sc))
+    st = mpmpc.default_settings()
+    try:
+        emu.lib.emu_set_lean_tail(0)
+        gen, n_tail = emu.solve_launch(cfg, st, qp, G=64)
+    finally:
+        emu.lib.emu_set_lean_tail(1)
+    lean, n_tail2 = emu.solve_launch(cfg, st, qp, G=64)
+    assert n_tail == n_tail2 and n_tail >= 3 and emu.lib.emu_last_tail2() == 0
+    assert np.array_equal(lean.status, gen.status) and np.array_equal(lean.iters[:, 0], gen.iters[:, 0])
+    assert (lean.status == mpmpc.PRIMAL_INFEASIBLE).sum() >= 2
+    ok = lean.status == 1
+    np.testing.assert_allclose(lean.z[ok], gen.z[ok], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(lean.z, gen.z, rtol=0, atol=1e-6)
+    for i in np.flatnonzero(lean.status == mpmpc.PRIMAL_INFEASIBLE)[:8]:
+        assert _farkas_ok(qp[:, i, :], sc.N, lean.y[i])

@@ -1151,3 +1151,28 @@ def test_what_the_tail_kernel_leaves_reaches_the_general_kernel_also_when_deferr
         h.sync()
     same(h.download(B, want_y=True), dflt)
     same(h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True), dflt)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,B", [(40, 600), (50, 300), (32, 257)])
+def test_reduced_native_tail_kernel_at_horizons_above_31(N, B, track, emu):
+    """mpmpc_reduced_tail_kernel<64,32>: the tail of the stock-type weights at horizons 32 .. 63 (one lane per stage).  Against
+    the general kernel on the whole tail and against the emulation of the same kernel."""
+    sc = scenarios.make(4, track, B=B, N=N)
+    res = {}
+    for mode in (1, 0):
+        h = _handle(track, sc.N, sc.weights, B)
+        h.set_tail_kernel(mode)
+        res[mode] = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+    a, b = res[1], res[0]
+    assert np.array_equal(a.status, b.status) and np.array_equal(a.iters[:, 0], b.iters[:, 0])
+    assert (a.status == mpmpc.PRIMAL_INFEASIBLE).sum() >= 3 and (a.iters[:, 0] == 1).all()
+    ok = a.status == 1
+    np.testing.assert_allclose(a.z[ok], b.z[ok], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(a.z, b.z, rtol=0, atol=1e-5)
+    cfg = T.stock_config(sc.N, sc.weights)
+    qp = emu.assemble(cfg, track, (sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub))
+    e, _ = emu.solve_launch(cfg, mpmpc.default_settings(), qp, G=64)
+    assert np.array_equal(e.status, a.status) and np.max(np.abs(e.z[ok] - a.z[ok])) <= 1e-9
+    inf = a.status == mpmpc.PRIMAL_INFEASIBLE
+    assert T.farkas_batch(qp[:, inf, :], sc.N, a.y[inf])[0].all()
