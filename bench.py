@@ -113,8 +113,8 @@ def algorithm_text(cfg, settings):
     if native_path(cfg, settings):
         return ("reduced-native kernel per instance: speed in closed form, one Ruiz pass, interior point from x = 0 (no OSQP iterate "
                 "is computed: iters[:, 0] = 1 marks the attempt), active-set round(s), KKT certificate on the (e_y, e_psi, kappa) QP, roll-forward of t; "
-                "uncertified instances go to a tail launch of the reduced-native tail kernel (horizons up to 31; two waves per SIMD like "
-                "the first kernel): phase 1 (Farkas ray / least-violation point) and one more attempt; only what that cannot decide goes "
+                "uncertified instances go to a tail launch of the reduced-native tail kernel (two instances per wave for horizons up to 31, "
+                "two waves per SIMD like the first kernel): phase 1 (Farkas ray / least-violation point) and one more attempt; only what that cannot decide goes "
                 "on to the general kernel and the OSQP ADMM iteration (each tail launch is enqueued with the step while the launches "
                 "seen so far leave something for it, otherwise only when a launch turns out to need it - checked at every sync, inside "
                 "the timed region)")
