@@ -145,7 +145,6 @@ template <class L>
 MPMPC_HD void gather_stage(const mpmpc_config& c, const PathTables& t, int B, const typename L::ival& inst,
                            const typename L::ival& k, const int* wp_id, const double* x0, const double* cc,
                            const double* lb, const double* ub, StageIn<L>& in, bool with_cc = true) {
-  using R = typename L::real;
   using Mk = typename L::mask;
   using I = typename L::ival;
   const int N = c.N;

@@ -874,7 +874,7 @@ int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_
   h->ld = host_stage_ld(cfg->N);
   h->n = 5 * cfg->N + 3;
   h->m = 8 * cfg->N + 6;
-  const size_t B = (size_t)cfg->max_batch, N = (size_t)cfg->N;
+  const size_t B = (size_t)cfg->max_batch;
 #define ALLOC(ptr, count)                                                                \
   do {                                                                                   \
     hipError_t e_ = hipMalloc((void**)&(ptr), (count) * sizeof(*(ptr)));                 \

@@ -737,7 +737,7 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
     MPMPC_TICK_BEGIN(0);
     setup(fields, B, inst, k, N_, st);
     MPMPC_TICK_END(0);
-    const R zero(0.0), one(1.0);
+    const R zero(0.0);
     status = I(MPMPC_UNSOLVED);
     iters = I(1);
     ipm_iters = I(0);
