@@ -52,11 +52,11 @@ using namespace mpmpc;
 constexpr int K1_THREADS = 256;
 constexpr int K1_LDS_WP = 1024;   // path tables of up to this many waypoints are staged in LDS
 
-// NT: non-temporal stores (tuning knob MPMPC_K1_NT=1; off by default: same-box A/B, profiles/k1_timing.py - they are slower at
-// every size, and so were 16-byte stores with two stages per thread).  Where the kernel stands (profiles/r4/k1_occupancy.txt):
-// 60 % of the HBM peak at B = 8 192 and 59 % in the median at B = 65 536 (550 MB per launch), since its rows are written to the
-// end of their last 128-byte line (assemble_lane: N = 30 fills 31 of 32 doubles, and partial lines cost it a third of its rate:
-// 39 % before).  The store pattern alone reaches 77 % (profiles/micro/k1_pattern.hip).  Off the solve path: the solve launches
+// NT: non-temporal stores - the default (MPMPC_K1_NT=0: plain stores).  Where the kernel stands (profiles/r4/k1_occupancy.txt,
+// same-box medians): 71 - 76 % of the HBM peak at B = 65 536 (550 MB per launch), 59 - 62 % at B = 8 192.  Two things it took:
+// rows written to the end of their last 128-byte line (N = 30 fills 31 of a row's 32 doubles; with partial lines the kernel
+// reached 39 %, and non-temporal stores were SLOWER than plain ones), and then non-temporal stores (plain ones: 56 - 58 %).
+// That is the rate of the store pattern alone (profiles/micro/k1_pattern.hip: 77 %).  Off the solve path: the solve launches
 // build their QP in registers with the same code.
 // (-DMPMPC_K1_WAVES=w: occupancy experiments, profiles/k1_occupancy.py)
 #ifdef MPMPC_K1_WAVES
@@ -99,10 +99,12 @@ __global__ __launch_bounds__(K1_THREADS) MPMPC_K1_OCC void mpmpc_assemble_kernel
     } else {
       double f0[MPMPC_NUM_FIELDS];
       assemble_fields<L>(cfg, t, B, inst, k, wp_id, x0, cc, lb, ub, f0);
-      if (inst < B && k <= cfg.N) {
+      // (rows written to the end of their last 128-byte line, like assemble_lane)
+      const int kfill = ((cfg.N + 1 + 15) / 16) * 16 < ld ? ((cfg.N + 1 + 15) / 16) * 16 : ld;
+      if (inst < B && k < kfill) {
         double* base = qp + (size_t)inst * ld + k;
         MPMPC_UNROLL
-        for (int f = 0; f < MPMPC_NUM_FIELDS; ++f) __builtin_nontemporal_store(f0[f], base + f * ((size_t)B * ld));
+        for (int f = 0; f < MPMPC_NUM_FIELDS; ++f) __builtin_nontemporal_store(k <= cfg.N ? f0[f] : 0.0, base + f * ((size_t)B * ld));
       }
     }
   }
@@ -1245,9 +1247,9 @@ static int launch_assemble(mpmpc_handle h, int B) {
   PathTables t{h->kappa, h->v_ref, h->ds_next, h->n_wp, h->ub_tab, h->lb_tab, h->n_cols};
   const int total = B * h->ld;
   const int blocks = (total + K1_THREADS - 1) / K1_THREADS;
-  // (tuning knob of profiles/k1_timing.py: MPMPC_K1_NT = 1 forces non-temporal stores)
+  // (tuning knob of profiles/k1_timing.py: MPMPC_K1_NT = 0 forces plain stores)
   static const int force_nt = std::getenv("MPMPC_K1_NT") ? std::atoi(std::getenv("MPMPC_K1_NT")) : -1;
-  const bool nt = force_nt > 0;
+  const bool nt = force_nt != 0;
   const size_t k1_lds = h->n_wp <= K1_LDS_WP ? 3 * sizeof(double) * (size_t)h->n_wp : 0;
 #define K1_LAUNCH(V)                                                                                                       \
   hipLaunchKernelGGL(mpmpc_assemble_kernel<V>, dim3(blocks), dim3(K1_THREADS), k1_lds, h->stream, h->cfg, t, B, h->ld, h->wp_id, \
