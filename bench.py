@@ -236,7 +236,7 @@ def pmc_traffic_bytes(kernel_prefix, B, lib_version, config=2):
     path = os.path.join(ROOT, "profiles", "r4", "pmc_summary.json")
     key_f, key_w = ("pmc_fetch", "pmc_write") if B == 1024 else ("pmc_fetch_b%d" % B, "pmc_write_b%d" % B)
     if config != 2:
-        key_f, key_w = "pmc_fetch_cfg%d" % config, "pmc_write_cfg%d" % config
+        key_f, key_w = "pmc_fetch_cfg%d" % abs(config), "pmc_write_cfg%d" % abs(config)
     try:
         d = json.load(open(path))
     except Exception:
@@ -250,7 +250,7 @@ def pmc_traffic_bytes(kernel_prefix, B, lib_version, config=2):
         note = ""
         # a launch that leaves a tail also runs its tail kernel(s): their bytes belong to the launch (one tail launch per launch)
         for tk in ("mpmpc_reduced_tail_kernel", "mpmpc_solve_kernel"):
-            if tk == kernel_prefix or config == 2:
+            if tk == kernel_prefix or config == 2 or config < 0:          # (config < 0: one kernel alone, K1)
                 continue
             tf = [v["FETCH_SIZE"]["mean"] for k, v in d[key_f].items() if k.startswith(tk)]
             tw = [v["WRITE_SIZE"]["mean"] for k, v in d[key_w].items() if k.startswith(tk)]
@@ -601,10 +601,12 @@ def _main(real_stdout):
                                         "instructions x stage-holding lanes; both fitted on the census of the emulated lane "
                                         "code (profiles/census.py, bench.py:_FLOPS)"}
         bytes_k1 = k1_bytes_per_solve(N) * B
+        # (PMC traffic of K1 from the same committed summary; the config-2 passes at B = 1 024 / 65 536 and the per-config passes)
+        k1_traffic, k1_traffic_src = pmc_traffic_bytes("mpmpc_assemble_kernel", B, lib_version, 2 if args.config == 2 else -args.config)
         out["roofline_assembly"] = {"bound": "hbm", "kernel": "mpmpc_assemble_kernel", "on_solve_path": False,
                                     "achieved": bytes_k1 / (ms_k1 * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
                                     "unit": "GB/s", "frac": bytes_k1 / (ms_k1 * 1e-3) / HBM_PEAK, "avg_ms": ms_k1,
-                                    "algorithmic_bytes": bytes_k1,
+                                    "algorithmic_bytes": bytes_k1, "traffic": k1_traffic, "traffic_source": k1_traffic_src,
                                     "note": "the stand-alone K1 (mpmpc_assemble, parity / debug export) timed beside the solve "
                                             "launch; the solve launch assembles its own QP in registers"}
         st, cnt = np.unique(sol.status, return_counts=True)
