@@ -7,10 +7,12 @@
 // step for 10.7 % of its instances).
 //
 // This solver does the same two steps on ReducedSolver's footing: three entries per lane, 40 LDS slots, at most 256
-// registers - a tail wave shares its SIMD with another wave.  Phase 1 is Solver::phase1 restated for three entries, on the
-// SAME scaling as the general kernel's (the Ruiz sweeps of the FULL problem, Solver::ruiz: the least-violation point of
-// phase 1 is a minimum in the scaled metric, so the scaling is part of the answer) and through the same interior point
-// (Solver::ipm<LAY_REDSPLIT, true>); the verdict is OSQP's primal-infeasibility test on the ray, in unscaled terms, as there.
+// registers - a tail wave shares its SIMD with another wave, and carries two instances where the horizon fits 32 lanes.
+// Phase 1 is Solver::phase1 restated for three entries, on the SAME scaling as the general kernel's (the Ruiz sweeps of the
+// FULL problem, Solver::ruiz: the least-violation point of phase 1 is a minimum in the scaled metric, so the scaling is part
+// of the answer) and through the same interior point - ReducedSolver::ipm3<SOFT> in the packed layouts (<32,16>, <64,32>),
+// Solver::ipm<LAY_REDSPLIT, true> itself in the split layout (<64,16>: the general kernel's answers to the last bits); the
+// verdict is OSQP's primal-infeasibility test on the ray, in unscaled terms, as there.  Every verdict is a per-instance mask.
 // What it leaves UNSOLVED (nothing, on the BASELINE configurations) goes on to the general kernel.
 //
 // Replaces, per instance: what osqp.solve() (src/MPC.py:183) answers on an infeasible or marginally infeasible QP - status
@@ -59,7 +61,7 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
   static_assert(RS::K_RP + 2 <= 37, "the packed interior point's residual slots must end below T_RAW0");
   MPMPC_HD static constexpr int t_raw(int i) { return i == 0 ? T_RAW0 : (i == 1 ? T_RAW1 : (i == 2 ? T_RAW2 : T_RAW3)); }
 
-  // (No mask of this solver lives through the attempt: "marginal" is read back from T_LV0, and the store tells a ray -
+  // (No mask of this solver lives through the attempt: "marginal" is read back from T_MARK, and the store tells a ray -
   //  status PRIMAL_INFEASIBLE of a non-empty box - and a bare least-violation point - SOLVED_INACCURATE that no attempt
   //  certified - from the status and the `polished` flag.)
 
