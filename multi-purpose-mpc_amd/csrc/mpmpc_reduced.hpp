@@ -144,7 +144,7 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
     // OSQP scale_data() on the reduced problem: Ruiz passes over the columns (e_y, e_psi, kappa) and the rows (2 dynamics
     // rows, 3 box rows), each with the cost normalisation
     const int passes = st.early_scaling > 0 && st.early_scaling < st.scaling ? st.early_scaling : st.scaling;
-    const R n_total(double(3 * N + 2));
+    const R inv_n_total(1.0 / double(3 * N + 2));
     for (int it = 0; it < passes; ++it) {
       R cn[3], rn[2], r_own[2];
       cn[0] = max_(max_(max_(abs_(P3[0]), abs_(mI[0])), max_(abs_(a[0]), abs_(a[2]))), abs_(G3[0]));
@@ -156,13 +156,13 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
       MPMPC_UNROLL
       for (int i = 0; i < 2; ++i) {
         rn[i] = max_(abs_(mI[i]), L::up(r_own[i]));
-        Et[i] = R(1.0) / sqrt_(S::limit(rn[i]));
+        Et[i] = rsqrt_(S::limit(rn[i]));          // (reciprocal square roots and reciprocals, ~1 ulp: 12 - 27 instructions each less than 1 / sqrt, a / b)
         Etd[i] = L::down(Et[i]);
       }
       MPMPC_UNROLL
       for (int e = 0; e < 3; ++e) {
-        Dt[e] = R(1.0) / sqrt_(S::limit(cn[e]));
-        Etb[e] = R(1.0) / sqrt_(S::limit(abs_(G3[e])));
+        Dt[e] = rsqrt_(S::limit(cn[e]));
+        Etb[e] = rsqrt_(S::limit(abs_(G3[e])));
         P3[e] = (Dt[e] * P3[e]) * Dt[e];
         G3[e] = (Etb[e] * G3[e]) * Dt[e];
         Q3[e] = Dt[e] * Q3[e];
@@ -180,9 +180,9 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
         s = s + sel(val[e], abs_(P3[e]), zero);
         mq = max_(mq, sel(val[e], abs_(Q3[e]), zero));
       }
-      R ct = L::gsum(s) / n_total;
+      R ct = L::gsum(s) * inv_n_total;
       const R nq = S::limit(L::gmax(mq));
-      ct = R(1.0) / S::limit(max_(ct, nq));
+      ct = rcp_(S::limit(max_(ct, nq)));
       MPMPC_UNROLL
       for (int e = 0; e < 3; ++e) { P3[e] = P3[e] * ct; Q3[e] = Q3[e] * ct; }
       c3 = c3 * ct;
@@ -194,7 +194,10 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
     L::cold_put(C_E, E2[0]); L::cold_put(C_E + 1, E2[1]);
     L::cold_put(C_C, c3);
     // box in the scaled variable space:  g x in [lb, ub]  <=>  x in [lo_raw, hi_raw] / D
-    L::cold_put(K_LO0, lo_e / D3[0]); L::cold_put(K_HI0, hi_e / D3[0]); L::cold_put(K_LO2, lo_k / D3[2]); L::cold_put(K_HI2, hi_k / D3[2]);
+    {
+      const R i0 = rcp_(D3[0]), i2 = rcp_(D3[2]);
+      L::cold_put(K_LO0, lo_e * i0); L::cold_put(K_HI0, hi_e * i0); L::cold_put(K_LO2, lo_k * i2); L::cold_put(K_HI2, hi_k * i2);
+    }
     // ---- start of the interior point: x = 0, no pin multipliers.  (The first reduced-native build started from OSQP's first
     // iterate of the reduced system - one factorisation + one KKT solve, like Solver::reduced_start: 0.25 interior-point
     // iterations fewer on config 2, none fewer on config 4, for the price of 0.4 iterations; measured without it: config 2
@@ -493,14 +496,14 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
     R Ax[2], At[3];
     this->template Aeq_mul_t<LAY_RED>(xs, Ax);
     this->template AeqT_mul_t<LAY_RED>(nus, At);
-    const R cinv = R(1.0) / L::cold_get(C_C);
+    const R cinv = rcp_(L::cold_get(C_C));
     R pv(0.0), sv(0.0), cv(0.0);
     MPMPC_UNROLL
-    for (int i = 0; i < 2; ++i) pv = max_(pv, sel(vx, abs_((Ax[i] - leq[i]) / L::cold_get(C_E + i)), zero));
+    for (int i = 0; i < 2; ++i) pv = max_(pv, sel(vx, abs_((Ax[i] - leq[i]) * rcp_(L::cold_get(C_E + i))), zero));
     Mk bad = L::mfalse();
     MPMPC_UNROLL
     for (int e = 0; e < 3; ++e) {
-      const R De = L::cold_get(C_D + e);
+      const R De = L::cold_get(C_D + e), iDe = rcp_(De);
       // (the box in scaled units; distances go back to the unscaled problem through D)
       const R lo0 = e == 0 ? L::cold_get(K_LO0) : (e == 2 ? L::cold_get(K_LO2) : R(-INFTY));
       const R hi0 = e == 0 ? L::cold_get(K_HI0) : (e == 2 ? L::cold_get(K_HI2) : R(INFTY));
@@ -508,8 +511,8 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
       const R dlo = sel(fl, De * (xs[e] - lo0), R(INFTY)), dhi = sel(fu, De * (hi0 - xs[e]), R(INFTY));   // unscaled distances to the bounds
       pv = max_(pv, sel(val[e], max_(max_(-dlo, -dhi), zero), zero));
       const R rd = fma_(pp[e], xs[e], qq[e]) + At[e] + lam[e];
-      sv = max_(sv, sel(val[e], abs_(rd / De) * cinv, zero));
-      const R yu = (lam[e] / De) * cinv;                  // multiplier of the unscaled box row
+      sv = max_(sv, sel(val[e], abs_(rd * iDe) * cinv, zero));
+      const R yu = (lam[e] * iDe) * cinv;                 // multiplier of the unscaled box row
       const R cu = sel(fu, max_(yu, zero) * abs_(dhi), sel(yu > zero, R(1e300), zero));
       const R cl = sel(fl, max_(-yu, zero) * abs_(dlo), sel(yu < zero, R(1e300), zero));
       cv = max_(cv, sel(val[e], max_(cu, cl), zero));
@@ -637,11 +640,11 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
       }
       MPMPC_UNROLL
       for (int e = 0; e < 3; ++e) {
-        const R fl = ths / (g3 ? g3[e] : L::cold_get(C_G + e));
+        const R fl = ths * rcp_(g3 ? g3[e] : L::cold_get(C_G + e));
         sl[e] = sel(b3.Lm[e], max_(x3[e] - b3.lo[e], fl), one);
         su[e] = sel(b3.Um[e], max_(b3.hi[e] - x3[e], fl), one);
-        zl[e] = sel(b3.Lm[e], mu0 / sl[e], zero);
-        zu[e] = sel(b3.Um[e], mu0 / su[e], zero);
+        zl[e] = sel(b3.Lm[e], mu0 * rcp_(sl[e]), zero);
+        zu[e] = sel(b3.Um[e], mu0 * rcp_(su[e]), zero);
         pi[e] = g3 ? zero : L::cold_get(C_PI + e);
       }
     }
@@ -799,7 +802,7 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
     // (point / no_lamv: the tail solver's verdicts - a least-violation point with its ray, a plan over relaxed boxes - also
     //  have a point in the slots; the ray carries no speed entry)
     const Mk ok = point ? *point : live & (status == MPMPC_SOLVED);
-    const R cinv = R(1.0) / L::cold_get(C_C);
+    const R cinv = rcp_(L::cold_get(C_C));
     R D3[3];
     MPMPC_UNROLL
     for (int e = 0; e < 3; ++e) D3[e] = L::cold_get(C_D + e);
@@ -834,11 +837,11 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
         put(k * 3, vx, (E2[0] * nu2[0]) * cinv);
         put(k * 3 + 1, vx, (E2[1] * nu2[1]) * cinv);
         put(k * 3 + 2, vx, zero);
-        put(k * 3 + (3 * (N + 1)), vx, (lam3[0] / D3[0]) * cinv);
-        put(k * 3 + (3 * (N + 1) + 1), vx, (lam3[1] / D3[1]) * cinv);
+        put(k * 3 + (3 * (N + 1)), vx, (lam3[0] * rcp_(D3[0])) * cinv);
+        put(k * 3 + (3 * (N + 1) + 1), vx, (lam3[1] * rcp_(D3[1])) * cinv);
         put(k * 3 + (3 * (N + 1) + 2), vx, zero);
         put(k * 2 + (6 * (N + 1)), vu, lam_v);
-        put(k * 2 + (6 * (N + 1) + 1), vu, (lam3[2] / D3[2]) * cinv);
+        put(k * 2 + (6 * (N + 1) + 1), vu, (lam3[2] * rcp_(D3[2])) * cinv);
       };
       if constexpr (ANY) L::rows_any(y, m, inst, n_inst, fill); else L::rows(y, m, inst, n_inst, fill);
     }
