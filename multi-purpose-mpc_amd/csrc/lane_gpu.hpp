@@ -169,6 +169,20 @@ struct LaneGpu {
     int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(a), 0x142, 0xA, 0xf, false);
     return __hiloint2double(hi, lo);
   }
+  // bcast31(a): lanes 32 .. 63 get a of lane 31 (DPP row_bcast:31), all others 0
+  static __device__ __forceinline__ double bcast31(double a) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(a), 0x143, 0xC, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(a), 0x143, 0xC, 0xf, false);
+    return __hiloint2double(hi, lo);
+  }
+  // Inclusive prefix sum along the lanes of an instance (lane order): four shifted adds inside the rows of 16, then the
+  // total of the row below (G >= 32) and of the half below (G = 64) - 5 / 6 steps instead of G - 1 dependent ones.
+  static __device__ __forceinline__ double gscan(double a) {
+    a += rshr<1>(a); a += rshr<2>(a); a += rshr<4>(a); a += rshr<8>(a);
+    if constexpr (G >= 32) a += bcast15(a);
+    if constexpr (G == 64) a += bcast31(a);
+    return a;
+  }
   // lane roles of that scheme: the first row's survivor of each chain (position 15 of rows 0 and 2), and the lanes of the
   // second rows whose lower neighbour, at the level that eliminates them, is that survivor (positions 0, 1, 3, 7 of rows 1, 3)
   static __device__ __forceinline__ bool cr_low15() { return (threadIdx.x & 31) == 15; }

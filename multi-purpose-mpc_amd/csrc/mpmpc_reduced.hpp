@@ -818,7 +818,9 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
     const R drive = fma_(L::cold_get(C_A20), e_y, L::cold_get(C_BV)), beq2 = L::cold_get(C_BEQ2);
     const R t0 = -beq2;
     R t = t0;
-    for (int it = 0; it < N; ++it) t = sel(first, t0, L::up(t + drive) - beq2);
+    // (t_k = t_{k-1} + drive_{k-1} - beq2_k: an inclusive prefix sum along the stages, L::gscan - 5 / 6 shifted adds instead of N
+    //  dependent steps)
+    t = L::gscan(sel(first, t0, sel(vx, L::up(drive) - beq2, R(0.0))));
     t = sel(ok & vx, t, zero);
     const R E2[2] = {L::cold_get(C_E), L::cold_get(C_E + 1)};
     L::fence();

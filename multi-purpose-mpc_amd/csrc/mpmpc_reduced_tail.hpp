@@ -280,7 +280,7 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
         const R drive = fma_(L::cold_get(C_A20), e_y, L::cold_get(C_BV)), beq2 = L::cold_get(C_BEQ2);
         const R t0 = -beq2;
         R t = t0;
-        for (int it = 0; it < N; ++it) t = sel(first, t0, L::up(t + drive) - beq2);
+        t = L::gscan(sel(first, t0, sel(vx, L::up(drive) - beq2, zero)));
         R m = sel(vx, max_(max_(abs_(e_y), abs_(e_psi)), abs_(t)), zero);
         m = max_(m, sel(vu, abs_(kap), zero));
         const R nAx = max_(L::gmax(m), L::cold_get(T_NAX));
