@@ -154,8 +154,16 @@ MPMPC_HD void gather_stage(const mpmpc_config& c, const PathTables& t, int B, co
   in.terminal = (k == N);
   I wp = L::gatheri(wp_id, inst, ok, 0);
   I ik = wp + k, ip = maxi(wp + k - 1, 0);
-  if (c.circular) { ik = modi(ik, t.n_wp); ip = modi(ip, t.n_wp); }
-  else { ik = mini(ik, t.n_wp - 1); ip = mini(ip, t.n_wp - 1); }
+  if (c.circular) {
+    if (t.n_wp > N) {        // 0 <= wp < n_wp (checked at upload) and k <= N < n_wp: one wrap at most - no integer division
+      ik = seli(ik >= t.n_wp, ik - t.n_wp, ik);
+      ip = seli(ip >= t.n_wp, ip - t.n_wp, ip);
+    } else {
+      ik = modi(ik, t.n_wp); ip = modi(ip, t.n_wp);
+    }
+  } else {
+    ik = mini(ik, t.n_wp - 1); ip = mini(ip, t.n_wp - 1);
+  }
   in.kap = L::gather(t.kappa, ik, ok, 0.0);
   in.v = L::gather(t.v_ref, ik, ok, 1.0);
   in.ds = L::gather(t.ds_next, ik, ok, 0.0);
