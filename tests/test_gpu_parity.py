@@ -243,6 +243,11 @@ def test_errors_are_loud(track):
         h.solve(np.zeros(8, np.int32), np.zeros((8, 3)), np.zeros((8, 60)), np.zeros((8, 30)), np.zeros((8, 30)))
     with pytest.raises(mpmpc.MpmpcError):          # waypoint out of range
         h.solve(np.array([999], np.int32), np.zeros((1, 3)), np.zeros((1, 60)), np.zeros((1, 30)), np.zeros((1, 30)))
+    for bad in (3, -1):                             # tail-kernel modes are 0, 1, 2
+        with pytest.raises(mpmpc.MpmpcError):
+            h.set_tail_kernel(bad)
+    with pytest.raises(mpmpc.MpmpcError):          # K1 timing entry: the batch must have been uploaded
+        h.assemble_timed(4, 2)
     h.close()
     with pytest.raises(ValueError):
         T.stock_config(2)
