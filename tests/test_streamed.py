@@ -133,3 +133,26 @@ def test_batch_mpc_stream_is_batch_mpc_call_by_call():
         assert np.array_equal(status, status2) and np.array_equal(u, u2) and np.array_equal(plan, plan2)
     u3 = [g[0] for g in bm.get_control_stream(batches, depth=3, want_plan=False)]
     assert all(np.array_equal(a[0], b) for a, b in zip(want, u3))
+
+
+@pytest.mark.gpu
+def test_streamed_batches_of_changing_size(track):
+    """The staging blocks of a handle are laid out for the batch size of the call: a stream whose batches change size re-lays
+    them out between calls (never under a call in flight) and still returns every batch's results, in order."""
+    sizes = [256, 100, 256, 17, 300, 1, 256]
+    full = scenarios.make(4, track, B=300)
+    cfg = T.stock_config(full.N, full.weights, max_batch=300)
+    batches = []
+    for i, B in enumerate(sizes):
+        r = np.random.default_rng(50 + i).permutation(300)[:B]
+        batches.append((full.wp_id[r], full.x0[r], full.cc_prev[r], full.lb[r], full.ub[r]))
+    sb = streamed.StreamedBatches(cfg, mpmpc.default_settings(), depth=3)
+    sb.set_path(track.kappa, track.v_ref, track.ds_next)
+    ref_h = mpmpc.Handle(cfg, mpmpc.default_settings())
+    ref_h.set_path(track.kappa, track.v_ref, track.ds_next)
+    got = list(sb.map(batches))
+    assert [g.status.size for g in got] == sizes
+    for b, s in zip(batches, got):
+        ref = ref_h.solve(*b)
+        assert np.array_equal(s.status, ref.status) and np.array_equal(s.z, ref.z) and np.array_equal(s.u0, ref.u0)
+    sb.close()
