@@ -19,6 +19,8 @@ cd /tmp; export TMPDIR=/tmp
 PMC="--repeats 2 --prewarm 30"
 prof() { out=$1; shift; rocprofv3 "$@" --output-format csv -d "$O/$out" -- python3 "$R/bench.py" ${BENCH_ARGS:-} --no-cpu > "$O/$out.json" 2>/dev/null; }
 BENCH_ARGS="" prof trace --kernel-trace --stats
+# ... and of the driver's own command (20-step regions)
+BENCH_ARGS="--gpus 1 --steps 20 --warmup 5" prof trace_driver --kernel-trace --stats
 BENCH_ARGS="--steps 5 --warmup 1 $PMC" prof pmc_fetch --pmc FETCH_SIZE
 BENCH_ARGS="--steps 5 --warmup 1 $PMC" prof pmc_write --pmc WRITE_SIZE
 BENCH_ARGS="--config 4 --steps 5 --warmup 1 $PMC" prof pmc_sq1_cfg4 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR

@@ -18,7 +18,8 @@ for name in ("bench_cfg2.json", "bench_cfg3.json", "bench_cfg4.json", "bench_cfg
         shutil.copy(os.path.join(O, name), os.path.join(P, name))
 if os.path.exists(os.path.join(O, "trace_b65536.json")) and not os.path.exists(os.path.join(O, "bench_cfg2_b65536.json")):
     shutil.copy(os.path.join(O, "trace_b65536.json"), os.path.join(P, "bench_cfg2_b65536.json"))
-for src, dst in (("trace", "bench_cfg2_kernel_stats.csv"), ("trace_b65536", "bench_cfg2_b65536_kernel_stats.csv"),
+for src, dst in (("trace", "bench_cfg2_kernel_stats.csv"), ("trace_driver", "bench_cfg2_driver_command_kernel_stats.csv"),
+                 ("trace_b65536", "bench_cfg2_b65536_kernel_stats.csv"),
                  ("trace_cfg3", "bench_cfg3_kernel_stats.csv"), ("trace_cfg4", "bench_cfg4_kernel_stats.csv"), ("trace_cfg5", "bench_cfg5_kernel_stats.csv")):
     fs = glob.glob(os.path.join(O, src, "*", "*kernel_stats.csv"))
     if fs:                                   # gpurun merges runs into the same directory: newest wins
@@ -44,14 +45,15 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_fetch_b65536",
             agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in sorted(agg.items()):
         out.setdefault(name, {}).setdefault(k, {})[c] = {"launches": len(v), "mean": sum(v) / len(v)}
-for src, dst in (("trace_cfg4", "bench_cfg4_profiled.json"), ("trace_cfg5", "bench_cfg5_profiled.json")):
+for src, dst in (("trace_cfg4", "bench_cfg4_profiled.json"), ("trace_cfg5", "bench_cfg5_profiled.json"),
+                 ("trace_driver", "bench_cfg2_driver_command_profiled.json")):
     if os.path.exists(os.path.join(O, src + ".json")):
         shutil.copy(os.path.join(O, src + ".json"), os.path.join(P, dst))
 # ---- the TIMED launches of every traced bench run: rows of the kernel trace in start order, without the
 # prewarm + warm-up launches at the head and the profile / isolated launches bench.py issues after its timed loop; per kernel the
 # average duration and, over the window, the average number of solve kernels on the chip (launches are double-buffered)
 timed = {}
-for src, wl in (("trace", "bench_cfg2"), ("trace_b65536", "bench_cfg2_b65536"), ("trace_cfg3", "bench_cfg3"), ("trace_cfg4", "bench_cfg4"),
+for src, wl in (("trace", "bench_cfg2"), ("trace_driver", "bench_cfg2_driver_command"), ("trace_b65536", "bench_cfg2_b65536"), ("trace_cfg3", "bench_cfg3"), ("trace_cfg4", "bench_cfg4"),
                 ("trace_cfg5", "bench_cfg5")):
     fs = glob.glob(os.path.join(O, src, "*", "*kernel_trace.csv"))
     try:
