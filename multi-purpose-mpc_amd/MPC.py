@@ -202,26 +202,72 @@ class BatchMPC:
         self.corridor_cols = None
         self._corridor_tables = None      # host copies of a static corridor table (for the further handles of get_control_stream)
         self._stream = None
+        self._ring = []                   # the further handles of get_control_stream (built like self.handle, kept in step with it)
+        self._packing, self._tail_kernel = None, None
         if isinstance(corridor, str) and corridor == "device":
             self.update_corridor_from_map()
         elif corridor is not None:        # (ub, lb) tables [n_wp x >=N] of a static map
             self.handle.set_corridor(*corridor)
             self._corridor_tables = corridor
 
+    def _handles(self):
+        return [self.handle] + list(self._ring)
+
+    def _corridor_from_map(self, h, n_cols):
+        rp, m = self._path, self._path.map
+        wps = rp.waypoints
+        h.set_map(m.data, m.origin, m.resolution)
+        h.set_path_geometry([w.x for w in wps], [w.y for w in wps], [w.psi for w in wps],
+                            [w.static_border_cells[0] for w in wps], [w.static_border_cells[1] for w in wps])
+        sm = self.model.safety_margin
+        return h.build_corridor(n_cols, 2 * sm, sm, want_tables=False)[2]
+
+    # Everything that changes what a handle solves goes through these, so that the ring of get_control_stream never works on a
+    # stale corridor or stale settings (a call on `self.handle` alone reaches only the first handle of the ring).
+    def set_settings(self, settings):
+        self.settings = settings
+        for h in self._handles():
+            h.set_settings(settings)
+
+    def set_packing(self, lanes_per_instance=0):
+        self._packing = lanes_per_instance
+        for h in self._handles():
+            h.set_packing(lanes_per_instance)
+
+    def set_tail_kernel(self, reduced_native=True):
+        self._tail_kernel = reduced_native
+        for h in self._handles():
+            h.set_tail_kernel(reduced_native)
+
+    def set_corridor(self, ub, lb):
+        """a static corridor table [n_wp x >= N] for every handle of this controller"""
+        for h in self._handles():
+            h.set_corridor(ub, lb)
+        self._corridor_tables, self.corridor_cols = (ub, lb), None
+
+    def _close_ring(self):
+        if self._stream is not None:
+            self._stream.discard()
+        for h in self._ring:
+            h.close()
+        self._ring, self._stream = [], None
+
+    def close(self):
+        self._close_ring()
+        self.handle.close()
+
     def update_corridor_from_map(self, n_cols=None):
         """(Re)build the corridor table on the device from the path's map as it is NOW (obstacles
         added since the last call included): update_path_constraints(w + 1, n_cols, 2*sm, sm) for every
         start waypoint w (src/MPC.py:116-118, src/reference_path.py:522-648), without leaving the GPU.
-        Returns the number of start waypoints whose first horizon waypoint is fully blocked."""
-        rp, m = self._path, self._path.map
+        Returns the number of start waypoints whose first horizon waypoint is fully blocked.  Every handle of this
+        controller - the ring of get_control_stream included - gets the new table."""
         n_cols = int(n_cols or self.N)
-        wps = rp.waypoints
-        self.handle.set_map(m.data, m.origin, m.resolution)
-        self.handle.set_path_geometry([w.x for w in wps], [w.y for w in wps], [w.psi for w in wps],
-                                      [w.static_border_cells[0] for w in wps], [w.static_border_cells[1] for w in wps])
-        sm = self.model.safety_margin
-        _, _, bad = self.handle.build_corridor(n_cols, 2 * sm, sm, want_tables=False)
+        if self._stream is not None:
+            self._stream.discard()        # nothing of a stream may still be in flight on a handle whose table changes
+        bad = [self._corridor_from_map(h, n_cols) for h in self._handles()][0]
         self.corridor_cols = n_cols
+        self._corridor_tables = None
         return bad
 
     def spatial_states(self, s, poses):
@@ -265,18 +311,30 @@ class BatchMPC:
         """A stream of get_control_batch calls from host buffers with `depth` of them in flight on this device
         (streamed.StreamedBatches: upload, launch and download of consecutive batches overlap).  batches: iterable of
         (wp_id, x0, cc_prev[, lb, ub]); yields (u [B,2] = (v, delta), plan [B,2N] with delta entries or None, status [B]) per
-        batch, in order.  The corridor comes with each batch (lb / ub) or from the table this controller was given."""
+        batch, in order.  The corridor comes with each batch (lb / ub) or from the table this controller was given or built
+        (corridor=(ub, lb), corridor="device" / update_corridor_from_map: every handle of the ring holds it).  Settings,
+        packing and tail kernel follow this controller's set_settings / set_packing / set_tail_kernel."""
         import streamed
-        if getattr(self, "_stream", None) is None or self._stream.depth != depth:
-            # (the first handle of the ring is this controller's own; the others are built like it)
-            hs = [self.handle]
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        if self._stream is None or self._stream.depth != depth:
+            # (the first handle of the ring is this controller's own; the others are built like it and carry its corridor,
+            #  settings, packing and tail kernel; a ring of another depth is closed first: each handle holds output blocks and
+            #  pinned staging)
+            self._close_ring()
             for _ in range(depth - 1):
                 h = mpmpc.Handle(self._cfg, self.settings)
                 h.set_path(*self._path.tables())
                 if self._corridor_tables is not None:
                     h.set_corridor(*self._corridor_tables)
-                hs.append(h)
-            self._stream = streamed.StreamedBatches(handles=hs)
+                elif self.corridor_cols is not None:
+                    self._corridor_from_map(h, self.corridor_cols)
+                if self._packing is not None:
+                    h.set_packing(self._packing)
+                if self._tail_kernel is not None:
+                    h.set_tail_kernel(self._tail_kernel)
+                self._ring.append(h)
+            self._stream = streamed.StreamedBatches(handles=self._handles())
         for sol in self._stream.map(batches, want_z=want_plan):
             plan = None
             if want_plan:

@@ -623,6 +623,7 @@ struct mpmpc_handle_s {
   // mpmpc_set_tail_kernel (MPMPC_LEAN_TAIL=0 in the environment: off from the start, for A/B timings of whole programs)
   bool lean_tail = !(std::getenv("MPMPC_LEAN_TAIL") && std::atoi(std::getenv("MPMPC_LEAN_TAIL")) == 0);
   bool lean_tail_single = std::getenv("MPMPC_LEAN_TAIL") && std::atoi(std::getenv("MPMPC_LEAN_TAIL")) == 2;      // ONE tail instance per wave
+  bool staged_async = true; // mpmpc_staged_begin was called as such (not as the first half of mpmpc_solve_staged)
   bool resident_y = true;   // mpmpc_set_outputs: do resident launches store the multipliers y (46 % of the output bytes)?
   bool y_valid = false;     // the last solve launch stored y
 };
@@ -695,7 +696,9 @@ static int check_settings(const mpmpc_settings* s) {
 
 static int grow_slots(mpmpc_handle h, int want);
 static int launch_assemble(mpmpc_handle h, int B);
-static int launch_solve(mpmpc_handle h, int B, bool closed_loop = false, bool want_y = true, int tail_only = 0);
+// how a solve launch was asked for (decides the packing of the reduced-native kernels, see launch_solve)
+enum LaunchKind { LAUNCH_SINGLE = 0, LAUNCH_PIPELINED = 1 };
+static int launch_solve(mpmpc_handle h, int B, bool closed_loop = false, bool want_y = true, int tail_only = 0, LaunchKind kind = LAUNCH_SINGLE);
 
 extern "C" {
 
@@ -915,10 +918,7 @@ int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_
     mpmpc_destroy(h);
     return fail(MPMPC_E_HIP, std::string("stream/event creation: ") + hipGetErrorString(e));
   }
-  if (int rc = grow_slots(h, h->pipeline - 1)) {
-    mpmpc_destroy(h);
-    return rc;
-  }
+  // (the further launch slots of pipelined resident launches are allocated by the first such launch: next_slot)
   *out = h;
   return MPMPC_OK;
 }
@@ -1263,7 +1263,7 @@ static int launch_assemble(mpmpc_handle h, int B) {
 
 // tail_only: 1 = the deferred tail launches of the last reduced-native launch (observe_tail), nothing else; 2 = of those,
 // only the general kernel on what the reduced-native tail kernel left
-static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, int tail_only) {
+static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, int tail_only, LaunchKind kind) {
   const int N = h->cfg.N;
   double* y_out = want_y ? h->y : nullptr;        // nobody wants the multipliers: the kernel skips their stores
   h->y_valid = want_y;
@@ -1284,14 +1284,18 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
   // smallest power of two holding N + 1 stages, so that a wave carries 2 or 4 instances and a SIMD two such waves
   int G = 64;
   if (rn && !rnt) {      // (the terminal-time kernels run one instance per wave)
-    // A handle that keeps several launches in flight (mpmpc_set_pipeline > 1: the default) is after throughput, and a packed
-    // wave does two or four instances for about the instructions of one: such handles pack from 128 instances on - the
-    // launches in flight fill the chip, not the waves of one launch (B = 1 024, four launches in flight: 36.5 M solves/s with
-    // one instance per wave, measured 41.4 M with two launches of the packed kernel).  A handle held at
-    // one launch in flight and the closed loop (one launch per step, each waiting for the one before) keep one instance per
-    // wave up to the chip's 1 024 SIMDs: the latency of a single launch is 43 us against 52.  The choice depends on the
-    // handle's settings and the batch size only: a given call gives the same bits every time.
-    const bool throughput = h->pipeline > 1 && !closed_loop;
+    // A launch that is one of several in flight - a pipelined resident launch (mpmpc_solve_resident with mpmpc_set_pipeline > 1:
+    // the default) or the begun half of a split host-buffer call (mpmpc_staged_begin: the caller keeps several handles busy) -
+    // is after throughput, and a packed wave does two or four instances for about the instructions of one: such launches pack
+    // from 128 instances on - the launches in flight fill the chip, not the waves of one launch (B = 1 024, four launches in
+    // flight: 36.5 M solves/s with one instance per wave, measured 41.4 M with two launches of the packed kernel, DESIGN.md
+    // section 4).  A launch that is waited for on its own - mpmpc_solve, mpmpc_solve_staged, the timed launch, a handle held at
+    // one launch in flight - and the closed loop (one launch per step, each waiting for the one before) keep one instance per
+    // wave up to the chip's 1 024 SIMDs: the latency of a single launch is 43 us against 52 (the decision used to
+    // follow the handle's pipeline depth alone, so single calls paid the packed kernel's latency).  The choice depends on the
+    // entry point, the handle's settings and the batch size only: a given call gives the same bits every time - and every
+    // packing returns the same bits anyway (tests).
+    const bool throughput = kind == LAUNCH_PIPELINED && h->pipeline > 1 && !closed_loop;
     if (N + 1 <= 32 && B > (throughput ? 128 : 1024)) G = 32;
     if (N + 1 <= 16 && B > (throughput ? 256 : 2048)) G = 16;
     if (h->force_lanes && N + 1 <= h->force_lanes) G = h->force_lanes;      // mpmpc_set_packing
@@ -1444,6 +1448,30 @@ static int observe_tail(mpmpc_handle h) {
 // beside launch k - a batch launch fills one of the two wave slots of a SIMD (B <= 1 024) or leaves SIMDs idle while its last
 // waves and its tail launch run, and the next batch takes what is idle.  The results of launch k stay where they are until
 // launch k + 2; mpmpc_download / mpmpc_sync and every other call on the handle refer to the LAST launch and wait for both.
+// The next launch slot of a pipelined handle becomes "the slot of the last launch".  What the current stream still has queued
+// that solves read (an upload, closed-loop steps) must be done before ANY slot's next launch starts: an event goes to all
+// streams.  Shared by mpmpc_solve_resident and mpmpc_solve_resident_profile (the profile loop used to swap slots
+// without it, so an upload followed by it could be overtaken).  The further slots are allocated on first use: a handle that
+// never launches resident batches (single calls, host-buffer streams, the closed loop) holds one output block, not three.
+static int next_slot(mpmpc_handle h) {
+  if (h->pipeline > 1) {
+    if (h->n_alt < h->pipeline - 1) {
+      if (int rc = grow_slots(h, h->pipeline - 1)) return rc;
+    }
+    const bool order = h->order_pending;
+    if (order) HIP_TRY(hipEventRecord(h->ev_order, h->stream));
+    swap_slots(h, h->ring);
+    h->ring = (h->ring + 1) % (h->pipeline - 1);
+    if (order) {
+      HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_order, 0));
+      for (int i = 0; i < h->pipeline - 1; ++i) HIP_TRY(hipStreamWaitEvent(h->alt[i].stream, h->ev_order, 0));
+    }
+    h->order_pending = false;
+  }
+  h->busy = true;
+  return MPMPC_OK;
+}
+
 int mpmpc_solve_resident(mpmpc_handle h, int32_t B) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
   if (h->staged_bytes) {
@@ -1451,29 +1479,14 @@ int mpmpc_solve_resident(mpmpc_handle h, int32_t B) {
   }
   if (B < 1 || B > h->uploaded) return fail(MPMPC_E_STATE, "B exceeds the uploaded batch");
   HIP_TRY(hipSetDevice(h->cfg.device));
-  if (h->pipeline > 1) {
-    // what this stream still has queued that solves read (an upload, closed-loop steps) must be done before the other one starts
-    const bool order = h->order_pending;
-    if (order) HIP_TRY(hipEventRecord(h->ev_order, h->stream));
-    swap_slots(h, h->ring);
-    h->ring = (h->ring + 1) % (h->pipeline - 1);
-    if (order) {
-      // (every slot's first launch after that work has to wait for it, not only this one's: the event goes to all streams)
-      HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_order, 0));
-      for (int i = 0; i < h->pipeline - 1; ++i) HIP_TRY(hipStreamWaitEvent(h->alt[i].stream, h->ev_order, 0));
-    }
-    h->order_pending = false;
-  }
-  h->busy = true;
-  return launch_solve(h, B, false, h->resident_y);      // one launch: the assembly runs inside K2
+  if (int rc = next_slot(h)) return rc;
+  return launch_solve(h, B, false, h->resident_y, 0, LAUNCH_PIPELINED);      // one launch: the assembly runs inside K2
 }
 
 int mpmpc_set_pipeline(mpmpc_handle h, int32_t depth) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
   MPMPC_SETTLE(h);
   if (depth < 1 || depth > mpmpc_handle_s::MAX_PIPELINE) return fail(MPMPC_E_ARG, "pipeline depth must be in [1, 8]");
-  HIP_TRY(hipSetDevice(h->cfg.device));
-  if (int rc = grow_slots(h, depth - 1)) return rc;
   h->pipeline = depth;
   h->ring = 0;
   return MPMPC_OK;
@@ -1530,10 +1543,9 @@ int mpmpc_solve_resident_profile(mpmpc_handle h, int32_t B, int32_t n, float* ms
   for (auto& e : ev)
     if (hipEventCreate(&e) != hipSuccess) { rc = fail(MPMPC_E_HIP, "hipEventCreate"); break; }
   for (int i = 0; i < n && rc == MPMPC_OK; ++i) {
-    if (h->pipeline > 1) { swap_slots(h, h->ring); h->ring = (h->ring + 1) % (h->pipeline - 1); }
-    h->busy = true;
+    if ((rc = next_slot(h)) != MPMPC_OK) break;
     if (hipEventRecord(ev[2 * i], h->stream) != hipSuccess) { rc = fail(MPMPC_E_HIP, "hipEventRecord"); break; }
-    rc = launch_solve(h, B, false, h->resident_y);
+    rc = launch_solve(h, B, false, h->resident_y, 0, LAUNCH_PIPELINED);
     if (rc == MPMPC_OK && hipEventRecord(ev[2 * i + 1], h->stream) != hipSuccess) rc = fail(MPMPC_E_HIP, "hipEventRecord");
   }
   if (rc == MPMPC_OK) rc = settle_other_slot(h);
@@ -1741,7 +1753,11 @@ int mpmpc_staged_end(mpmpc_handle h) {
 }
 
 int mpmpc_solve_staged(mpmpc_handle h, int32_t B, int32_t with_rows, int32_t want_z, int32_t want_y) {
-  if (int rc = mpmpc_staged_begin(h, B, with_rows, want_z, want_y)) return rc;
+  if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
+  h->staged_async = false;          // one call, waited for at once: the packing of a single launch
+  const int rc = mpmpc_staged_begin(h, B, with_rows, want_z, want_y);
+  h->staged_async = true;
+  if (rc) return rc;
   return mpmpc_staged_end(h);
 }
 
@@ -1767,7 +1783,7 @@ int mpmpc_staged_begin(mpmpc_handle h, int32_t B, int32_t with_rows, int32_t wan
   HIP_TRY(hipMemcpyAsync(h->in_block, h->stage_in, with_rows ? L.in_end : L.in_end_cc, hipMemcpyHostToDevice, h->stream));
   h->have_rows = with_rows != 0;
   h->uploaded = B;
-  if (int rc = launch_solve(h, B, false, want_y != 0)) return rc;
+  if (int rc = launch_solve(h, B, false, want_y != 0, 0, h->staged_async ? LAUNCH_PIPELINED : LAUNCH_SINGLE)) return rc;
   const size_t out_bytes = want_y ? L.out_end : (want_z ? L.out_end_z : L.z);
   HIP_TRY(hipMemcpyAsync(h->stage_out, h->out_block, out_bytes, hipMemcpyDeviceToHost, h->stream));
   h->staged_bytes = out_bytes;

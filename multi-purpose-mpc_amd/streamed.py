@@ -76,27 +76,34 @@ class StreamedBatches:
 
     def submit(self, wp_id, x0, cc_prev, lb=None, ub=None, want_z=True, want_y=False):
         """Start one batch.  -> the Solution of the OLDEST batch in flight if its handle was needed for this one, else None
-        (results always come back in submission order: from submit, then from drain)."""
+        (results always come back in submission order: from submit, then from drain).
+        If the new batch cannot be started (bad arguments, a device error) the exception carries the Solution that had to be
+        collected to make room for it as `exc.done` (or None), and the ring stays where it was: the failed batch took no slot."""
         i = self._next
-        self._next = (i + 1) % len(self.handles)
         done = None
         if self._busy[i] is not None:
             assert self._order and self._order[0] == i
             self._order.popleft()
             done = self._collect(i)
-        wp_id = np.asarray(wp_id)
-        B = int(wp_id.size)
-        if self._views[i] is None or self._views[i][0] != B:
-            self._views[i] = (B, self.handles[i].staging(B))
-        v = self._views[i][1]
-        v["wp_id"][:] = wp_id
-        v["x0"][:] = x0
-        v["cc_prev"][:] = cc_prev
-        rows = lb is not None
-        if rows:
-            v["lb"][:] = lb
-            v["ub"][:] = ub
-        self.handles[i].staged_begin(B, with_rows=rows, want_z=want_z, want_y=want_y)
+        try:
+            wp_id = np.asarray(wp_id)
+            B = int(wp_id.size)
+            if self._views[i] is None or self._views[i][0] != B:
+                self._views[i] = (B, self.handles[i].staging(B))
+            v = self._views[i][1]
+            v["wp_id"][:] = wp_id
+            v["x0"][:] = x0
+            v["cc_prev"][:] = cc_prev
+            rows = lb is not None
+            if rows:
+                v["lb"][:] = lb
+                v["ub"][:] = ub
+            self.handles[i].staged_begin(B, with_rows=rows, want_z=want_z, want_y=want_y)
+        except Exception as exc:
+            exc.done = done          # already collected: hand it to the caller instead of dropping it
+            raise
+        # only now does the batch own the slot
+        self._next = (i + 1) % len(self.handles)
         self._busy[i] = (B, want_z, want_y)
         self._order.append(i)
         return done
@@ -108,11 +115,33 @@ class StreamedBatches:
             out.append(self._collect(self._order.popleft()))
         return out
 
+    def discard(self):
+        """wait for every batch still in flight and drop its results (a consumer that left a stream early)"""
+        while self._order:
+            i = self._order.popleft()
+            try:
+                self.handles[i].staged_end()
+            finally:
+                self._busy[i] = None
+
     def map(self, batches, want_z=True, want_y=False):
-        """generator: Solutions of `batches` (tuples wp_id, x0, cc_prev[, lb, ub]) in order, `depth` of them in flight"""
-        for b in batches:
-            done = self.submit(*b, want_z=want_z, want_y=want_y)
-            if done is not None:
-                yield done
-        for s in self.drain():
-            yield s
+        """generator: Solutions of `batches` (tuples wp_id, x0, cc_prev[, lb, ub]) in order, `depth` of them in flight.
+        Whatever a previous, abandoned stream left in flight is discarded first, and a consumer that stops early (break,
+        exception, garbage-collected generator) leaves nothing in flight either: the next stream never sees stale results."""
+        self.discard()
+        try:
+            for b in batches:
+                try:
+                    done = self.submit(*b, want_z=want_z, want_y=want_y)
+                except Exception as exc:
+                    held = getattr(exc, "done", None)
+                    if held is not None:
+                        exc.done = None
+                        yield held      # the batch before the one that failed is still delivered, in order
+                    raise
+                if done is not None:
+                    yield done
+            for s in self.drain():
+                yield s
+        finally:
+            self.discard()

@@ -1,11 +1,11 @@
 #!/bin/bash
-# A/B two builds of libmpmpc.so (multi-purpose-mpc_amd/csrc/_ab/{A,B}.so) on the same box:
+# A/B two builds of libmpmpc.so (profiles/_ab/{A,B}.so) on the same box:
 #   /usr/local/graft/bin/gpurun -- 'bash profiles/ab.sh "2 3 4"'
 CS=${1:-"2 4"}
 D=multi-purpose-mpc_amd/csrc
 cp $D/libmpmpc.so /tmp/keep.so
 for v in A B A B; do
-  cp $D/_ab/$v.so $D/libmpmpc.so
+  cp profiles/_ab/$v.so $D/libmpmpc.so
   for c in $CS; do
     python bench.py --config $c --steps 10 --warmup 2 --no-cpu > /tmp/ab.json 2>/dev/null
     python - "$v" "$c" <<'PY'

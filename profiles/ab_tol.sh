@@ -1,9 +1,9 @@
 #!/bin/bash
-# A = shipped library, B = a variant in multi-purpose-mpc_amd/csrc/_ab/B.so: the tolerance sweep on both, same box
+# A = shipped library, B = a variant in profiles/_ab/B.so: the tolerance sweep on both, same box
 D=multi-purpose-mpc_amd/csrc
 cp $D/libmpmpc.so /tmp/keep.so
 for v in A B; do
-  cp $D/_ab/$v.so $D/libmpmpc.so
+  cp profiles/_ab/$v.so $D/libmpmpc.so
   echo "=== library $v"
   bash profiles/sweep_tol.sh ${KEY:-ipm_tol} "$@"
 done

@@ -1,4 +1,4 @@
-"""K1 at 4 / 5 / 6 / 8 waves per SIMD (builds -DMPMPC_K1_WAVES=w in csrc/_ab/K1w<w>.so), same box, K1 launched alone back to back
+"""K1 at 4 / 5 / 6 / 8 waves per SIMD (builds -DMPMPC_K1_WAVES=w in profiles/_ab/K1w<w>.so), same box, K1 launched alone back to back
 (mpmpc_solve_resident_timed interleaves it with K2, whose dirty output lines K1's writes then have to push out of the cache) and
 interleaved:   /usr/local/graft/bin/gpurun --timeout 600 -- 'python profiles/k1_occupancy.py'"""
 import os
@@ -11,7 +11,7 @@ import sys, os
 sys.path[:0] = [os.path.join(%r, "multi-purpose-mpc_amd"), os.path.join(%r, "tests"), %r]
 import numpy as np, mpmpc, scenarios
 w = sys.argv[1]
-mpmpc._lib = mpmpc.load_library(os.path.join(%r, "multi-purpose-mpc_amd", "csrc", "_ab", "K1w%%s.so" %% w))
+mpmpc._lib = mpmpc.load_library(os.path.join(%r, "profiles", "_ab", "K1w%%s.so" %% w))
 tr = scenarios.sim_track()
 for B in (8192, 65536):
     sc = scenarios.make(2, tr, B=B)

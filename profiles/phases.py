@@ -3,9 +3,9 @@ mpmpc_hip.hip / mpmpc_core.hpp MPMPC_TICK_*).  Usage on the GPU box:
 
     python profiles/phases.py [config] [batch]
 
-with multi-purpose-mpc_amd/csrc/_ab/P.so built by
+with profiles/_ab/P.so built by
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -DMPMPC_PHASE_CLOCK \
-          -Iinclude -o multi-purpose-mpc_amd/csrc/_ab/P.so multi-purpose-mpc_amd/csrc/mpmpc_hip.hip
+          -Iinclude -o profiles/_ab/P.so multi-purpose-mpc_amd/csrc/mpmpc_hip.hip
 Prints mean / max over the waves of each phase in microseconds (wall_clock64, 10 ns ticks)."""
 import ctypes as C
 import os
@@ -27,7 +27,7 @@ COUNTS = {16: "ipm iterations", 17: "as rounds", 18: "as solves"}
 
 def main():
     cfg_id = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-    lib = mpmpc.load_library(os.path.join(ROOT, "multi-purpose-mpc_amd", "csrc", "_ab", "P.so"))
+    lib = mpmpc.load_library(os.path.join(ROOT, "profiles", "_ab", "P.so"))
     lib.mpmpc_debug_phase.argtypes = [C.c_void_p, C.c_int]
     mpmpc._lib = lib            # the handles below run in the profiling build
     tr = scenarios.sim_track()

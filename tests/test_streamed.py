@@ -78,6 +78,52 @@ def test_streamed_batches_come_back_in_order(depth, emu, track):
         streamed.StreamedBatches(handles=[])
 
 
+def test_abandoned_stream_leaves_nothing_in_flight(emu, track):
+    """a consumer that breaks out of map() early, or a submit that fails, must not leave batches in flight - the next
+    stream would hand their stale Solutions out as the results of its own first batches."""
+    B, depth = 4, 3
+    batches, sc = _batches(track, 8, B)
+    cfg = T.stock_config(sc.N, sc.weights, max_batch=B)
+    st = mpmpc.default_settings()
+    hs = [_EmuStagedHandle(emu, cfg, st, track) for _ in range(depth)]
+    sb = streamed.StreamedBatches(handles=hs)
+    ref = [emu.solve_launch(cfg, st, emu.assemble(cfg, track, b), G=64)[0] for b in batches]
+    for k, s in enumerate(sb.map(batches)):          # (1) early break: batches 1 .. depth are in flight at this point
+        assert np.array_equal(s.z, ref[k].z)
+        if k == 1:
+            break
+    assert not sb._order and all(b is None for b in sb._busy) and all(h.pending is None for h in hs)
+    got = list(sb.map(batches[4:]))                  # the next stream: its own results, from its first batch on
+    assert len(got) == 4 and all(np.array_equal(g.z, r.z) and np.array_equal(g.status, r.status) for g, r in zip(got, ref[4:]))
+    # (2) a generator dropped without being exhausted or closed explicitly
+    g = sb.map(batches)
+    next(g)
+    del g
+    import gc
+    gc.collect()
+    assert not sb._order and all(h.pending is None for h in hs)
+    # (3) a batch that cannot be started: the batches before it are still delivered in order, the error surfaces, and the
+    # ring is clean afterwards
+    bad = list(batches[:5])
+    bad[4] = (bad[4][0], np.zeros((B + 1, 3)), bad[4][2], bad[4][3], bad[4][4])       # x0 of the wrong shape
+    seen = []
+    with pytest.raises(ValueError):
+        for s in sb.map(bad):
+            seen.append(s)
+    assert len(seen) == 2 and all(np.array_equal(s.z, r.z) for s, r in zip(seen, ref))     # batches 0 and 1 came back, in order
+    assert not sb._order and all(b is None for b in sb._busy) and all(h.pending is None for h in hs)
+    # ... submit() by hand: the Solution collected to make room rides on the exception
+    for b in batches[:depth]:
+        assert sb.submit(*b) is None
+    with pytest.raises(ValueError) as ei:
+        sb.submit(*bad[4])
+    assert ei.value.done is not None and np.array_equal(ei.value.done.z, ref[0].z)
+    rest = sb.drain()
+    assert len(rest) == depth - 1 and np.array_equal(rest[0].z, ref[1].z)
+    assert sb.submit(*batches[3]) is None            # the failed batch took no slot: the ring goes on where it was
+    assert np.array_equal(sb.drain()[0].z, ref[3].z)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("depth", [1, 3])
 def test_streamed_batches_on_device_match_the_single_call(depth, track):
@@ -156,3 +202,51 @@ def test_streamed_batches_of_changing_size(track):
         ref = ref_h.solve(*b)
         assert np.array_equal(s.status, ref.status) and np.array_equal(s.z, ref.z) and np.array_equal(s.u0, ref.u0)
     sb.close()
+
+
+@pytest.mark.gpu
+def test_batch_mpc_stream_ring_follows_corridor_and_settings():
+    """the further handles of get_control_stream must carry what the controller's own handle carries - a corridor
+    table built on the DEVICE (corridor="device"), a table rebuilt after the map changed, changed settings - and a ring of
+    another depth closes the handles of the old one."""
+    import test_host_mpc as H
+    from MPC import BatchMPC
+    from map import Obstacle
+    from scipy import sparse
+    m, rp, car = H.build_world(obstacles=False)
+    Q, R, QN = sparse.diags([1.0, 0.0, 0.0]), sparse.diags([0.5, 0.0]), sparse.diags([1.0, 0.0, 0.0])
+    ic = {'umin': np.array([0.0, -np.tan(0.66) / car.length]), 'umax': np.array([1.0, np.tan(0.66) / car.length])}
+    scn = {'xmin': np.array([-np.inf] * 3), 'xmax': np.array([np.inf] * 3)}
+    tr = scenarios.sim_track()
+    B = 200
+    bm = BatchMPC(car, 30, Q, R, QN, scn, ic, 4.0, max_batch=B, corridor="device")
+    batches = []
+    for i in range(6):
+        sc = scenarios.make(4, tr, B=B)
+        r = np.random.default_rng(70 + i).permutation(B)
+        batches.append((sc.wp_id[r], sc.x0[r], sc.cc_prev[r]))            # no corridor rows: every handle needs the table
+
+    def same(want, got):
+        assert len(got) == len(want)
+        for (u, plan, status, _), (u2, plan2, status2) in zip(want, got):
+            assert np.array_equal(status, status2) and np.array_equal(u, u2) and np.array_equal(plan, plan2)
+
+    want_free = [bm.get_control_batch(*b) for b in batches]
+    same(want_free, list(bm.get_control_stream(batches, depth=3)))          # (the 2nd / 3rd handle used to raise MPMPC_E_STATE here)
+    # the map changes: the rebuilt table must reach the whole ring
+    m.add_obstacles([Obstacle(cx=c[0], cy=c[1], radius=c[2]) for c in
+                     ((0.0, 0.0, 0.05), (-0.8, -0.5, 0.08), (-0.3, -1.0, 0.08), (0.73, -0.9, 0.07), (1.2, 0.0, 0.08))])
+    bm.update_corridor_from_map()
+    want_obs = [bm.get_control_batch(*b) for b in batches]
+    assert any(not np.array_equal(a[2], b[2]) or not np.array_equal(a[0], b[0]) for a, b in zip(want_free, want_obs))
+    same(want_obs, list(bm.get_control_stream(batches, depth=3)))
+    # settings through the controller reach every handle
+    bm.set_settings(mpmpc.default_settings(phase1_accept=0))
+    want_strict = [bm.get_control_batch(*b) for b in batches]
+    assert not any((w[2] == mpmpc.SOLVED_INACCURATE).any() for w in want_strict)
+    same(want_strict, list(bm.get_control_stream(batches, depth=3)))
+    # another depth: the old ring's handles are closed, the new ring is complete
+    old = list(bm._ring)
+    same(want_strict, list(bm.get_control_stream(batches, depth=2)))
+    assert len(old) == 2 and all(not h._h for h in old) and len(bm._ring) == 1
+    bm.close()
