@@ -50,12 +50,15 @@ typedef struct mpmpc_handle_s* mpmpc_handle;
 
 /* Controller constants: what MPC.__init__ stores (src/MPC.py:15-59) plus the model's wheelbase
  * (src/spatial_bicycle_models.py:130) and the path's `circular` flag (src/reference_path.py:96).
- * Q, R are the DIAGONALS of the reference's weight matrices.  RESTRICTION: the reference puts the whole Q and R into the
- * Hessian (src/MPC.py:150) although its cost vector only ever uses diag(Q), diag(R) (src/MPC.py:153-155); this library
- * supports diagonal stage weights only (what src/simulation.py:101-103 builds) - the host class raises ValueError for
- * anything else.  QN is used as a whole (src/MPC.py:150,154): its diagonal goes into QN, its off-diagonal entries
- * (symmetric) into QN_offdiag; such a configuration, like one with bounds on e_psi / t or a cost on t, runs the general
- * kernels, one instance per wavefront.  HORIZON: 3 <= N <= 63 (one wavefront lane per stage; the reference has no upper limit). */
+ * Q, R, QN hold the DIAGONALS of the reference's weight matrices, Q_offdiag / R_offdiag / QN_offdiag their off-diagonal
+ * entries (symmetric; all zero for what src/simulation.py:101-103 builds).  The reference puts the WHOLE Q, R, QN into the
+ * Hessian (src/MPC.py:150) while its cost vector uses only diag(Q), diag(R) but the whole QN (src/MPC.py:153-155) - a quirk
+ * that is reproduced: with non-diagonal Q or R the minimiser is not the tracking reference even without constraints.
+ * A configuration with any off-diagonal weight, like one with bounds on e_psi / t or a cost on t, runs the general kernels,
+ * one instance per wavefront (dense 3 x 3 / 2 x 2 stage Hessian blocks); diagonal weights run the reduced-native kernels
+ * unchanged.  Q, R, QN must be positive semidefinite.
+ * HORIZON: 3 <= N <= MPMPC_MAX_HORIZON (one lane per stage: a wavefront up to N = 63, a workgroup of 2 / 4 wavefronts whose
+ * stages talk through LDS beyond that; the reference has no upper limit). */
 typedef struct {
   int32_t N;          /* horizon, 3 <= N <= MPMPC_MAX_HORIZON (the kappa_pred quirk of MPC.py:86 needs N >= 3) */
   int32_t max_batch;  /* largest B of any later call */
@@ -67,6 +70,8 @@ typedef struct {
   double ay_max;           /* MPC.ay_max */
   double wheelbase;        /* model.length */
   double QN_offdiag[3];    /* QN[0][1], QN[0][2], QN[1][2] (= their transposes); all zero for the reference's weights */
+  double Q_offdiag[3];     /* Q[0][1], Q[0][2], Q[1][2]: enter the Hessian only (src/MPC.py:150), not the cost vector (153) */
+  double R_offdiag[1];     /* R[0][1]: likewise (src/MPC.py:150,155) */
 } mpmpc_config;
 
 /* Solver settings: OSQP 0.6.x names and defaults for the ADMM stage (what

@@ -17,9 +17,10 @@ polish).  There is no CPU solver behind this class: without the library / a devi
 `BatchMPC` is the one API extension: B independent controller instances per call (scenario
 sweeps, Monte-Carlo initial poses) on one device.
 
-Restrictions (checked, not silently ignored): Q and R must be diagonal (the reference's cost
-vector only ever uses diag(Q), diag(R), src/MPC.py:153-155); QN may be any symmetric positive
-semidefinite 3x3 matrix (the reference uses it as a whole, src/MPC.py:150,154); 3 <= N <= 63.
+Weights: Q, R, QN may be any symmetric positive semidefinite matrices (scipy sparse or dense).  Like
+the reference, the Hessian takes the whole matrices (src/MPC.py:150) while the cost vector uses
+diag(Q), diag(R) and the whole QN (src/MPC.py:153-155).  Diagonal weights (src/simulation.py:101-103)
+run the reduced-native kernels; anything else the general kernels.  3 <= N <= mpmpc.MAX_HORIZON.
 """
 from __future__ import annotations
 
@@ -31,30 +32,22 @@ from spatial_bicycle_models import current_waypoint_batch, t2s_batch
 PREDICTION = '#BA4A00'
 
 
-def _diagonal(M, n, name):
-    """diag of a scipy.sparse / dense weight matrix; refuses off-diagonal weights."""
-    D = M.toarray() if hasattr(M, "toarray") else np.asarray(M, float)
-    D = np.atleast_2d(D)
-    if D.shape != (n, n):
-        raise ValueError("%s must be %dx%d" % (name, n, n))
-    if np.any(D - np.diag(np.diag(D)) != 0):
-        raise ValueError("%s must be diagonal on the GPU path" % name)
-    return np.diag(D).astype(float)
-
-
 def _symmetric(M, n, name):
+    """a weight matrix (scipy sparse or dense) as a dense symmetric positive semidefinite array - anything else is refused"""
     D = M.toarray() if hasattr(M, "toarray") else np.asarray(M, float)
     D = np.atleast_2d(D).astype(float)
     if D.shape != (n, n):
         raise ValueError("%s must be %dx%d" % (name, n, n))
     if not np.array_equal(D, D.T):
         raise ValueError("%s must be symmetric" % name)
+    if not np.all(np.isfinite(D)) or np.linalg.eigvalsh(D).min() < -1e-12 * (1.0 + np.abs(D).max()):
+        raise ValueError("%s must be finite and positive semidefinite" % name)
     return D
 
 
 def _make_config(model, N, Q, R, QN, StateConstraints, InputConstraints, ay_max, max_batch, device):
     rp = model.reference_path
-    return mpmpc.make_config(N, _diagonal(Q, 3, "Q"), _diagonal(R, 2, "R"), _symmetric(QN, 3, "QN"),
+    return mpmpc.make_config(N, _symmetric(Q, 3, "Q"), _symmetric(R, 2, "R"), _symmetric(QN, 3, "QN"),
                              StateConstraints['xmin'], StateConstraints['xmax'],
                              InputConstraints['umin'], InputConstraints['umax'], ay_max, model.length,
                              circular=rp.circular, max_batch=max_batch, device=device)

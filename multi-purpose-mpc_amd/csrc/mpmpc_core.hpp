@@ -242,8 +242,20 @@ inline SolverParams make_params(const mpmpc_settings& st) {
 
 // May the certified polish solve the reduced (e_y, e_psi, kappa) problem?  (mpmpc_settings::reduce, layouts table
 // in the Solver: the time state must carry neither cost nor bound, the speed must have its own strictly convex cost.)
+// Does any weight matrix have an off-diagonal entry?  (src/MPC.py:150 puts the whole Q, R, QN into the Hessian.)  Such a
+// configuration runs the general kernels with dense stage blocks (template flag FQ of the Solver), which take the seven
+// numbers as one array: QN (01, 02, 12), Q (01, 02, 12), R (01) - weight_offdiag().
+inline bool full_weights(const mpmpc_config& c) {
+  for (int i = 0; i < 3; ++i)
+    if (c.QN_offdiag[i] != 0.0 || c.Q_offdiag[i] != 0.0) return true;
+  return c.R_offdiag[0] != 0.0;
+}
+MPMPC_HOST_DEVICE inline void weight_offdiag(const mpmpc_config& c, double w[7]) {
+  for (int i = 0; i < 3; ++i) { w[i] = c.QN_offdiag[i]; w[3 + i] = c.Q_offdiag[i]; }
+  w[6] = c.R_offdiag[0];
+}
 inline bool reducible(const mpmpc_config& c, const mpmpc_settings& st) {
-  return st.reduce != 0 && st.polish != 0 && c.Q[2] == 0.0 && c.QN[2] == 0.0 && c.QN_offdiag[0] == 0.0 &&
+  return st.reduce != 0 && st.polish != 0 && !full_weights(c) && c.Q[2] == 0.0 && c.QN[2] == 0.0 && c.QN_offdiag[0] == 0.0 &&
          c.QN_offdiag[1] == 0.0 && c.QN_offdiag[2] == 0.0 && c.R[0] > 0.0 && !(c.xmin[2] > -INFTY) && !(c.xmax[2] < INFTY) &&
          !(c.xmin[1] > -INFTY) && !(c.xmax[1] < INFTY);      // (and e_psi unbounded: the reduced layouts carry no slack for it)
 }
@@ -263,12 +275,14 @@ MPMPC_HOST_DEVICE inline int lane_offset(int G, int C, int N) {
   return (C >= G || o < 0) ? 0 : o;
 }
 
-// FQ: the terminal weight QN is a full symmetric 3 x 3 matrix (src/MPC.py:150,154 use the whole matrix).  Its three
-// off-diagonal entries exist on the lane of stage N only (pod), and so do the off-diagonals of the inverse of that
-// stage's 3 x 3 Hessian block (hod): the terminal state enters the equality rows through -I alone, so the Schur
-// complement keeps its block-tridiagonal structure and only the diagonal block of stage N, the products with P and
-// the products with inv(H) gain terms.  With FQ = false (the reference's own weights are diagonal) none of this
-// code exists in the kernel.
+// FQ: FULL WEIGHTS - Q, R, QN are symmetric matrices with off-diagonal entries (src/MPC.py:150 puts the whole matrices into
+// the Hessian).  The Hessian stays block diagonal - a 3 x 3 state block (Q on stages 0 .. N - 1, QN on stage N) and a 2 x 2
+// input block (R) per stage - so a lane keeps the three off-diagonals of its state block (pod), the one of its input block
+// (rod), and the off-diagonals of the INVERSES of the blocks of the current H = P + diagonal terms (hod, hud: dense 3 x 3 /
+// 2 x 2 inverses per lane); the Schur complement keeps its block-tridiagonal structure, its blocks A inv(H) A' + B inv(H_u) B'
+// and A inv(H) (-I)' are formed with the dense inverses (factor_core), and the products with P and with inv(H) gain terms.
+// A block without off-diagonal entries is inverted entry by entry exactly as without the flag.  With FQ = false (the
+// reference's own weights are diagonal) none of this code exists in the kernel.
 // FREEX: the states e_psi and t are never boxed (xmin[1..2] = -inf, xmax[1..2] = +inf: the reference's own constraints,
 // src/simulation.py:110-111) - the interior point of the FULL problem then carries no slack arithmetic for them
 // (left out at compile time, like e_psi in the reduced layouts).
@@ -309,7 +323,10 @@ struct Solver {
   Mk p1_converged;       // phase 1 ended at its converged optimum (not at an earlier iterate that already passed the ray test)
   Mk p1_marginal;        // infeasible by less than OSQP's own primal tolerance: solved on the boxes relaxed by that much (phase1_accept)
   R p1_viol;             // ... and the violation (unscaled) the plan is allowed
-  R pod[3], hod[3];      // FQ: off-diagonals (01, 02, 12) of the terminal cost block and of the terminal inv(H) block
+  R pod[3], hod[3];      // FQ: off-diagonals (01, 02, 12) of the lane's state cost block and of its inv(H) state block
+  R rod, hud;            // FQ: off-diagonal (v, kappa) of the lane's input cost block and of its inv(H) input block
+  R podS[3];             // FQ, split layout of the interior point: pod on the state lanes, (rod of the stage, 0, 0) on the
+                         // input lanes - there entries 0, 1 are (v, kappa), and hod[0] then holds hud
   Mk term;               // this lane holds stage N
   R leq[3], lb[5], ub[5];
   // ---- linear algebra
@@ -383,20 +400,48 @@ struct Solver {
     v[1] = fma_(od[2], w[2], fma_(od[0], w[0], v[1]));
     v[2] = fma_(od[2], w[1], fma_(od[1], w[0], v[2]));
   }
-  // Hd: diagonal of the Hessian block whose inverse h the caller has just formed entry by entry.  On the terminal lane
-  // the block is dense (Hd on the diagonal, pod off it): replace h[0..2] by the diagonal of its inverse, keep the rest in hod.
-  template <bool USE = true>
-  MPMPC_HD void dense_terminal(const R* Hd, R* h) {
+  // Hd: diagonal of the Hessian blocks whose inverses h the caller has just formed entry by entry (layout LAY: LAY_FULL = 0,
+  // LAY_SPLIT = 1).  Where a block has off-diagonal cost entries it is dense (Hd on the diagonal, pod / rod off it): replace
+  // its entries of h by the diagonal of its inverse and keep the inverse's off-diagonals in hod / hud.
+  template <int LAY = 0, bool USE = true>
+  MPMPC_HD void dense_blocks(const R* Hd, R* h) {
     if constexpr (FQ && USE) {
-      const R c00 = fma_(Hd[1], Hd[2], -(pod[2] * pod[2])), c01 = fma_(pod[1], pod[2], -(pod[0] * Hd[2])),
-              c02 = fma_(pod[0], pod[2], -(pod[1] * Hd[1])), c11 = fma_(Hd[0], Hd[2], -(pod[1] * pod[1])),
-              c12 = fma_(pod[0], pod[1], -(Hd[0] * pod[2])), c22 = fma_(Hd[0], Hd[1], -(pod[0] * pod[0]));
-      const R idet = R(1.0) / fma_(pod[1], c02, fma_(pod[0], c01, Hd[0] * c00));
-      h[0] = sel(term, c00 * idet, h[0]); h[1] = sel(term, c11 * idet, h[1]); h[2] = sel(term, c22 * idet, h[2]);
-      hod[0] = sel(term, c01 * idet, R(0.0)); hod[1] = sel(term, c02 * idet, R(0.0)); hod[2] = sel(term, c12 * idet, R(0.0));
+      const R* po = LAY == 1 ? podS : pod;
+      const R zero(0.0);
+      const Mk dn = (abs_(po[0]) > zero) | (abs_(po[1]) > zero) | (abs_(po[2]) > zero);
+      const R c00 = fma_(Hd[1], Hd[2], -(po[2] * po[2])), c01 = fma_(po[1], po[2], -(po[0] * Hd[2])),
+              c02 = fma_(po[0], po[2], -(po[1] * Hd[1])), c11 = fma_(Hd[0], Hd[2], -(po[1] * po[1])),
+              c12 = fma_(po[0], po[1], -(Hd[0] * po[2])), c22 = fma_(Hd[0], Hd[1], -(po[0] * po[0]));
+      const R idet = R(1.0) / fma_(po[1], c02, fma_(po[0], c01, Hd[0] * c00));
+      h[0] = sel(dn, c00 * idet, h[0]); h[1] = sel(dn, c11 * idet, h[1]); h[2] = sel(dn, c22 * idet, h[2]);
+      hod[0] = sel(dn, c01 * idet, zero); hod[1] = sel(dn, c02 * idet, zero); hod[2] = sel(dn, c12 * idet, zero);
+      if constexpr (LAY == 0) {
+        const Mk d2 = abs_(rod) > zero;
+        const R idet2 = R(1.0) / fma_(Hd[3], Hd[4], -(rod * rod));
+        const R h3 = Hd[4] * idet2, h4 = Hd[3] * idet2;
+        h[3] = sel(d2, h3, h[3]); h[4] = sel(d2, h4, h[4]);
+        hud = sel(d2, -(rod * idet2), zero);
+      }
     } else if constexpr (FQ) {
       hod[0] = hod[1] = hod[2] = R(0.0);
+      hud = R(0.0);
     }
+  }
+  // out += offdiag(P) x  and  t += offdiag(inv H) r  in the layout LAY (FQ only; LAY_FULL: 5 entries, LAY_SPLIT: 3)
+  template <int LAY>
+  MPMPC_HD void Poff_add(const R* x, R* out) const {
+    if constexpr (LAY == 0) {
+      od_mul_add(pod, x, out);
+      out[3] = fma_(rod, x[4], out[3]); out[4] = fma_(rod, x[3], out[4]);
+    } else {
+      static_assert(LAY == 1, "full weights run the full problem: LAY_FULL or LAY_SPLIT");
+      od_mul_add(podS, x, out);
+    }
+  }
+  template <int LAY>
+  MPMPC_HD void Hoff_add(const R* r, R* t) const {
+    od_mul_add(hod, r, t);
+    if constexpr (LAY == 0) { t[3] = fma_(hud, r[4], t[3]); t[4] = fma_(hud, r[3], t[4]); }
   }
 
   // ======================================================================== setup
@@ -416,7 +461,7 @@ struct Solver {
   }
 
   // fields: the 27 stage fields of this lane's (instance, stage) - assemble_fields, or fetch_fields
-  // qn_off: off-diagonals (01, 02, 12) of QN (FQ only; mpmpc_config::QN_offdiag)
+  // qn_off: the seven off-diagonal weights (FQ only): QN (01, 02, 12), Q (01, 02, 12), R (01) - mpmpc_config::QN_offdiag ..
   MPMPC_HD void load(const R* fields, int B, const I& inst, const I& k, int N_, const double* qn_off = nullptr) {
     N = N_;
     n_inst = B;
@@ -444,7 +489,12 @@ struct Solver {
     term = live & (k == N);
     if constexpr (FQ) {
       MPMPC_UNROLL
-      for (int i = 0; i < 3; ++i) { pod[i] = sel(term, R(qn_off ? qn_off[i] : 0.0), R(0.0)); hod[i] = R(0.0); }
+      for (int i = 0; i < 3; ++i) {
+        pod[i] = sel(term, R(qn_off ? qn_off[i] : 0.0), sel(vu, R(qn_off ? qn_off[3 + i] : 0.0), R(0.0)));
+        hod[i] = R(0.0); podS[i] = R(0.0);
+      }
+      rod = sel(vu, R(qn_off ? qn_off[6] : 0.0), R(0.0));
+      hud = R(0.0);
     }
     auto fld = [&](int f, double dflt) { return sel(vx, fields[f], R(dflt)); };
     MPMPC_UNROLL
@@ -494,6 +544,7 @@ struct Solver {
       }
       cn[3] = max_(max_(abs_(p[3]), abs_(b[1])), abs_(g[3]));
       cn[4] = max_(max_(abs_(p[4]), abs_(b[0])), abs_(g[4]));
+      if constexpr (FQ) { cn[3] = max_(cn[3], abs_(rod)); cn[4] = max_(cn[4], abs_(rod)); }
       r_own[0] = max_(abs_(a[0]), abs_(a[1]));
       r_own[1] = max_(max_(abs_(a[2]), abs_(a[3])), abs_(b[0]));
       r_own[2] = max_(max_(abs_(a[4]), abs_(a[5])), abs_(b[1]));
@@ -519,6 +570,7 @@ struct Solver {
       }
       if constexpr (FQ) {
         pod[0] = (Dt[0] * pod[0]) * Dt[1]; pod[1] = (Dt[0] * pod[1]) * Dt[2]; pod[2] = (Dt[1] * pod[2]) * Dt[2];
+        rod = (Dt[3] * rod) * Dt[4];
       }
       MPMPC_UNROLL
       for (int i = 0; i < 3; ++i) { mI[i] = (Et[i] * mI[i]) * Dt[i]; Eeq[i] = Eeq[i] * Et[i]; }
@@ -535,6 +587,7 @@ struct Solver {
           if (j == 0) colmax = max_(colmax, max_(abs_(pod[0]), abs_(pod[1])));
           if (j == 1) colmax = max_(colmax, max_(abs_(pod[0]), abs_(pod[2])));
           if (j == 2) colmax = max_(colmax, max_(abs_(pod[1]), abs_(pod[2])));
+          if (j >= 3) colmax = max_(colmax, abs_(rod));
         }
         s = s + sel(valid[j], colmax, R(0.0));
         mq = max_(mq, sel(valid[j], abs_(q[j]), R(0.0)));
@@ -544,7 +597,7 @@ struct Solver {
       ct = keep(on, R(1.0) / limit(max_(ct, nq)), R(1.0));
       MPMPC_UNROLL
       for (int j = 0; j < 5; ++j) { p[j] = p[j] * ct; q[j] = q[j] * ct; }
-      if constexpr (FQ) { pod[0] = pod[0] * ct; pod[1] = pod[1] * ct; pod[2] = pod[2] * ct; }
+      if constexpr (FQ) { pod[0] = pod[0] * ct; pod[1] = pod[1] * ct; pod[2] = pod[2] * ct; rod = rod * ct; }
       c = c * ct;
     }
   }
@@ -582,13 +635,31 @@ struct Solver {
   MPMPC_HD void factor(const R h[5], const R& r) {
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) hinv[j] = h[j];
-    factor_core(h, (b[0] * b[0]) * h[4], (b[1] * b[1]) * h[3], r);
+    if constexpr (FQ) factor_core(h, (b[0] * b[0]) * h[4], (b[1] * b[1]) * h[3], r, (b[0] * b[1]) * hud);
+    else factor_core(h, (b[0] * b[0]) * h[4], (b[1] * b[1]) * h[3], r);
   }
-  // hx = 1/H of the three states; w2b, w5b = b0^2 h_kappa, b1^2 h_v (what the inputs add to A H A' + B H B')
-  MPMPC_HD void factor_core(const R hx[3], const R& w2b, const R& w5b, const R& r) {
+  // hx = 1/H of the three states; w2b, w5b = b0^2 h_kappa, b1^2 h_v (what the inputs add to A H A' + B H B'); FQ: w4b = b0 b1
+  // times the off-diagonal of the inputs' inverse block (rows e_psi, t of B inv(H_u) B')
+  MPMPC_HD void factor_core(const R hx[3], const R& w2b, const R& w5b, const R& r, const R& w4b = R(0.0)) {
     const R* h = hx;
     R W[6], T[6], Dg[6], To[9];
-    {
+    [[maybe_unused]] R T9[9];
+    if constexpr (FQ) {
+      // dense inverse of the state block: h on the diagonal, hod (01, 02, 12) off it.  AH = A inv(H), row-major 3 x 3
+      (void)T;
+      const R ah00 = fma_(a[1], hod[0], a[0] * h[0]), ah01 = fma_(a[1], h[1], a[0] * hod[0]), ah02 = fma_(a[1], hod[2], a[0] * hod[1]);
+      const R ah10 = fma_(a[3], hod[0], a[2] * h[0]), ah11 = fma_(a[3], h[1], a[2] * hod[0]), ah12 = fma_(a[3], hod[2], a[2] * hod[1]);
+      const R ah20 = fma_(a[5], hod[1], a[4] * h[0]), ah21 = fma_(a[5], hod[2], a[4] * hod[0]), ah22 = fma_(a[5], h[2], a[4] * hod[1]);
+      W[0] = fma_(ah01, a[1], ah00 * a[0]);
+      W[1] = fma_(ah11, a[1], ah10 * a[0]);
+      W[2] = fma_(ah11, a[3], ah10 * a[2]) + w2b;
+      W[3] = fma_(ah21, a[1], ah20 * a[0]);
+      W[4] = fma_(ah21, a[3], ah20 * a[2]) + w4b;
+      W[5] = fma_(ah22, a[5], ah20 * a[4]) + w5b;
+      T9[0] = ah00 * mI[0]; T9[1] = ah01 * mI[1]; T9[2] = ah02 * mI[2];      // S_{k+1,k} = A inv(H) (-I)': dense
+      T9[3] = ah10 * mI[0]; T9[4] = ah11 * mI[1]; T9[5] = ah12 * mI[2];
+      T9[6] = ah20 * mI[0]; T9[7] = ah21 * mI[1]; T9[8] = ah22 * mI[2];
+    } else {
       R a0h = a[0] * h[0], a2h = a[2] * h[0], a4h = a[4] * h[0], a1h = a[1] * h[1], a3h = a[3] * h[1];
       W[0] = fma_(a[1], a1h, a[0] * a0h);
       W[1] = fma_(a[3], a1h, a[2] * a0h);
@@ -612,7 +683,17 @@ struct Solver {
       Dg[4] = fma_(mI[1] * mI[2], hod[2], Dg[4]);
     }
     // coupling handed on: S_{k+1,k} = T going up, S_{k-1,k} = T_{k-1}' going down, nothing from mid
-    {
+    if constexpr (FQ) {
+      R Tu[9];
+      MPMPC_UNROLL
+      for (int i = 0; i < 9; ++i) Tu[i] = L::up(T9[i]);
+      const R zero(0.0);
+      MPMPC_UNROLL
+      for (int i = 0; i < 3; ++i) {
+        MPMPC_UNROLL
+        for (int j = 0; j < 3; ++j) To[3 * i + j] = sel(is_mid, zero, sel(down_chain, Tu[3 * j + i], T9[3 * i + j]));
+      }
+    } else {
       R Tu[6];
       MPMPC_UNROLL
       for (int i = 0; i < 6; ++i) Tu[i] = L::up(T[i]);
@@ -626,7 +707,7 @@ struct Solver {
     MPMPC_UNROLL
     for (int i = 0; i < 6; ++i) Dg[i] = L::mirror(Dg[i]);
     MPMPC_UNROLL
-    for (int i = 0; i < 9; ++i) if (i != 5 && i != 7) To[i] = L::mirror(To[i]);
+    for (int i = 0; i < 9; ++i) if (FQ || (i != 5 && i != 7)) To[i] = L::mirror(To[i]);
     R M[9], Ls[9];
     MPMPC_UNROLL
     for (int i = 0; i < 9; ++i) M[i] = R(0.0);
@@ -670,6 +751,11 @@ struct Solver {
       M[0] = To[0] * i00; M[1] = fma_(To[1], i11, To[0] * i10); M[2] = fma_(To[2], i22, fma_(To[1], i21, To[0] * i20));
       M[3] = To[3] * i00; M[4] = fma_(To[4], i11, To[3] * i10); M[5] = fma_(To[4], i21, To[3] * i20);
       M[6] = To[6] * i00; M[7] = To[6] * i10;                   M[8] = fma_(To[8], i22, To[6] * i20);
+      if constexpr (FQ) {       // (dense coupling: the two entries the diagonal-weight blocks do not have)
+        M[5] = fma_(To[5], i22, M[5]);
+        M[7] = fma_(To[7], i11, M[7]);
+        M[8] = fma_(To[7], i21, M[8]);
+      }
     };
     {
       MPMPC_SERIAL_BEGIN();
@@ -781,7 +867,7 @@ struct Solver {
     R t[5], bv[3], s[5];
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) t[j] = hinv[j] * rx[j];
-    if constexpr (FQ) od_mul_add(hod, rx, t);
+    if constexpr (FQ) Hoff_add<0>(rx, t);
     Aeq_mul(t, bv);
     MPMPC_UNROLL
     for (int i = 0; i < 3; ++i) bv[i] = bv[i] - req[i];
@@ -789,7 +875,7 @@ struct Solver {
     AeqT_mul(nu, s);
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) { s[j] = rx[j] - s[j]; xt[j] = hinv[j] * s[j]; }
-    if constexpr (FQ) od_mul_add(hod, s, xt);
+    if constexpr (FQ) Hoff_add<0>(s, xt);
   }
 
   // ---- the same operators on the split layout (S = true: 3 entries per lane, see kSplit) or the plain one
@@ -952,7 +1038,11 @@ struct Solver {
       for (int e = 0; e < 3; ++e) hinv[e] = h[e];
       R w2b = L::from_upper((bU[0] * bU[0]) * h[1]), w5b = L::from_upper((bU[1] * bU[1]) * h[0]);
       w2b = sel(sU, R(0.0), w2b); w5b = sel(sU, R(0.0), w5b);
-      factor_core(h, w2b, w5b, r);
+      if constexpr (FQ) {       // (on the input lanes hod[0] is the off-diagonal of the inputs' inverse block: dense_blocks<LAY_SPLIT>)
+        const R w4b = sel(sU, R(0.0), L::from_upper((bU[0] * bU[1]) * hod[0]));
+        // ... which belongs to the input lanes only: the state lanes' own hod is what factor_core reads
+        factor_core(h, w2b, w5b, r, w4b);
+      } else factor_core(h, w2b, w5b, r);
     } else if constexpr (LAY == LAY_RED) {
       MPMPC_UNROLL
       for (int e = 0; e < 3; ++e) hinv[e] = h[e];
@@ -997,7 +1087,7 @@ struct Solver {
     R t[E], bv[NQ], s[E];
     MPMPC_UNROLL
     for (int j = 0; j < E; ++j) t[j] = hinv[j] * rx[j];
-    if constexpr (FQ) od_mul_add(hod, rx, t);
+    if constexpr (FQ) Hoff_add<LAY>(rx, t);
     Aeq_mul_t<LAY>(t, bv);
     MPMPC_UNROLL
     for (int i = 0; i < NQ; ++i) bv[i] = bv[i] - req[i];
@@ -1005,7 +1095,7 @@ struct Solver {
     AeqT_mul_t<LAY>(nu, s);
     MPMPC_UNROLL
     for (int j = 0; j < E; ++j) { s[j] = rx[j] - s[j]; xt[j] = hinv[j] * s[j]; }
-    if constexpr (FQ) od_mul_add(hod, s, xt);
+    if constexpr (FQ) Hoff_add<LAY>(s, xt);
   }
 
   // ---- the reduced problem's block-tridiagonal Cholesky: factor_core / s_solve with 2 x 2 blocks (rows e_y, e_psi).
@@ -1417,7 +1507,7 @@ struct Solver {
     R h[5], Hd[5];
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) { Hd[j] = p[j] + R(sigma) + (g[j] * g[j]) * rb[j]; h[j] = R(1.0) / Hd[j]; }
-    dense_terminal(Hd, h);
+    dense_blocks(Hd, h);
     factor(h, rinv_eq);
   }
 
@@ -1443,8 +1533,8 @@ struct Solver {
       sAx = max_(sAx, sel(vx, abs_(Axe[i]), R(0.0)));
     }
     R dua(0.0), nq(0.0), nAty(0.0), nPx(0.0), srd(0.0), sq(0.0), sAty(0.0), sPx(0.0);
-    R Pod[3] = {R(0.0), R(0.0), R(0.0)};          // off-diagonal part of P x (FQ)
-    if constexpr (FQ) od_mul_add(pod, x, Pod);
+    R Pod[5] = {R(0.0), R(0.0), R(0.0), R(0.0), R(0.0)};          // off-diagonal part of P x (FQ)
+    if constexpr (FQ) Poff_add<0>(x, Pod);
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) {
       R ei = R(1.0) / Eb[j], di = R(1.0) / D[j];
@@ -1458,7 +1548,7 @@ struct Solver {
       sAx = max_(sAx, sel(valid[j], abs_(Axb), R(0.0)));
       R aty = fma_(g[j], yb[j], Aty[j]);
       R Px = p[j] * x[j];
-      if constexpr (FQ) { if (j < 3) Px = Px + Pod[j]; }
+      if constexpr (FQ) Px = Px + Pod[j];
       R rd = Px + q[j] + aty;
       dua = max_(dua, sel(valid[j], abs_(di * rd), R(0.0)));
       nq = max_(nq, sel(valid[j], abs_(di * q[j]), R(0.0)));
@@ -1532,7 +1622,7 @@ struct Solver {
     R Pdx[5];
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) Pdx[j] = p[j] * dx[j];
-    if constexpr (FQ) od_mul_add(pod, dx, Pdx);
+    if constexpr (FQ) Poff_add<0>(dx, Pdx);
     MPMPC_UNROLL
     for (int j = 0; j < 5; ++j) {
       nrm = max_(nrm, sel(valid[j], abs_(D[j] * dx[j]), R(0.0)));
@@ -1843,8 +1933,12 @@ struct Solver {
       AeqT_mul_t<LAY>(s.nu, At);
       Aeq_mul_t<LAY>(s.x, rp);
       R res(0.0), msum(0.0);
-      [[maybe_unused]] R Pod[3] = {zero, zero, zero};          // off-diagonal part of P x (FQ, not in phase 1)
-      if constexpr (FQ && !SOFT) od_mul_add(pod, s.x, Pod);
+      [[maybe_unused]] R Pod[E];                               // off-diagonal part of P x (FQ, not in phase 1)
+      if constexpr (FQ && !SOFT) {
+        MPMPC_UNROLL
+        for (int j = 0; j < E; ++j) Pod[j] = zero;
+        Poff_add<LAY>(s.x, Pod);
+      }
       [[maybe_unused]] R rk_dot(0.0);                          // rank-one part of P x: rk_c (rk_c' x)   (LAY_RED4)
       if constexpr (LAY == LAY_RED4 && !SOFT) rk_dot = rank_one_dot(s.x);
       MPMPC_UNROLL
@@ -1854,7 +1948,7 @@ struct Solver {
         if constexpr (SOFT) rd[j] = At[j] - s.zl[j] + s.zu[j] + s.pi[j];
         else {
           rd[j] = fma_(pp[j], s.x[j], qq[j]) + At[j] - s.zl[j] + s.zu[j] + s.pi[j];
-          if constexpr (FQ) { if (j < 3) rd[j] = rd[j] + Pod[j]; }
+          if constexpr (FQ) rd[j] = rd[j] + Pod[j];
           if constexpr (LAY == LAY_RED4) { if (j == 0 || j == 3) rd[j] = fma_(rk_c[j == 0 ? 0 : 1], rk_dot, rd[j]); }
         }
         if (!boxed(j)) { res = max_(res, sel(vm[j], abs_(rd[j]), zero)); continue; }
@@ -1924,7 +2018,7 @@ struct Solver {
       [[maybe_unused]] R Hd[E];
       MPMPC_UNROLL
       for (int j = 0; j < E; ++j) { const R Hj = H_of(j); if constexpr (FQ) Hd[j] = Hj; h[j] = rcp_(Hj); }
-      dense_terminal<!SOFT>(Hd, h);
+      dense_blocks<LAY, !SOFT>(Hd, h);
       factor_t<LAY>(h, reg);
       MPMPC_TICK_END(11);
       // ---- predictor and corrector share the factorisation.  (No iterative refinement of the directions: over
@@ -2057,7 +2151,7 @@ struct Solver {
           Hd[j] = pp[j] + delta + sel(act[j], idelta, zero);
           h[j] = one / Hd[j];
         }
-        dense_terminal(Hd, h);
+        dense_blocks<LAY>(Hd, h);
         MPMPC_TICK_COUNT(17);
         MPMPC_TICK_BEGIN(13);
         factor_t<LAY>(h, delta);
@@ -2080,14 +2174,18 @@ struct Solver {
         AeqT_mul_t<LAY>(nn, At);
         Aeq_mul_t<LAY>(xn, Ax);
         R rs(0.0);                       // KKT residual of the unregularised system at (xn, nn, ln)
-        [[maybe_unused]] R Pod[3] = {zero, zero, zero};
-        if constexpr (FQ) od_mul_add(pod, xn, Pod);
+        [[maybe_unused]] R Pod[E];
+        if constexpr (FQ) {
+          MPMPC_UNROLL
+          for (int j = 0; j < E; ++j) Pod[j] = zero;
+          Poff_add<LAY>(xn, Pod);
+        }
         [[maybe_unused]] R rk_dot(0.0);
         if constexpr (LAY == LAY_RED4) rk_dot = rank_one_dot(xn);
         MPMPC_UNROLL
         for (int j = 0; j < E; ++j) {
           R r1 = -qq[j] - pp[j] * xn[j] - At[j] - ln[j];
-          if constexpr (FQ) { if (j < 3) r1 = r1 - Pod[j]; }
+          if constexpr (FQ) r1 = r1 - Pod[j];
           if constexpr (LAY == LAY_RED4) { if (j == 0 || j == 3) r1 = fma_(-rk_c[j == 0 ? 0 : 1], rk_dot, r1); }
           r3[j] = sel(act[j], bound[j] - xn[j], zero);
           rhs[j] = fma_(r3[j], idelta, r1);
@@ -2210,8 +2308,8 @@ struct Solver {
     AeqT_mul(nus, At);
     R pv(0.0), sv(0.0), cv(0.0);
     R cinv = R(1.0) / c;
-    R Pod[3] = {R(0.0), R(0.0), R(0.0)};
-    if constexpr (FQ) od_mul_add(pod, xs, Pod);
+    R Pod[5] = {R(0.0), R(0.0), R(0.0), R(0.0), R(0.0)};
+    if constexpr (FQ) Poff_add<0>(xs, Pod);
     MPMPC_UNROLL
     for (int i = 0; i < 3; ++i) pv = max_(pv, sel(vx, abs_((Ax[i] - leq[i]) / Eeq[i]), R(0.0)));
     MPMPC_UNROLL
@@ -2221,7 +2319,7 @@ struct Solver {
       R viol = max_(max_(lo0 - xu, xu - hi0), R(0.0));
       pv = max_(pv, sel(valid[j], viol, R(0.0)));
       R rd = fma_(p[j], xs[j], q[j]) + At[j] + lam[j];
-      if constexpr (FQ) { if (j < 3) rd = rd + Pod[j]; }
+      if constexpr (FQ) rd = rd + Pod[j];
       sv = max_(sv, sel(valid[j], abs_(rd / D[j]) * cinv, R(0.0)));
       R yu = (lam[j] / D[j]) * cinv;                      // multiplier of the unscaled box row
       Mk fu = hi0 < R(INF_BOUND), fl = lo0 > R(-INF_BOUND);
@@ -2285,6 +2383,9 @@ struct Solver {
     if constexpr (SPL<LAY>) {
       MPMPC_UNROLL
       for (int i = 0; i < 2; ++i) bU[i] = sel(sU, L::from_lower(b[i]), zero);
+      if constexpr (FQ) {       // the cost's off-diagonals in the split layout: the input lanes' entries 0, 1 are (v, kappa)
+        podS[0] = sel(sU, L::from_lower(rod), pod[0]); podS[1] = sel(sU, zero, pod[1]); podS[2] = sel(sU, zero, pod[2]);
+      }
     }
     to_lay<LAY>(bx.lo, bi.lo); to_lay<LAY>(bx.hi, bi.hi); to_lay<LAY>(p, pp); to_lay<LAY>(q, qq);
     mask_to_lay<LAY>(bx.Lm, bi.Lm); mask_to_lay<LAY>(bx.Um, bi.Um); mask_to_lay<LAY>(bx.pin, bi.pin);
@@ -2408,12 +2509,12 @@ struct Solver {
         // ... and multipliers commensurate with the dual residual they will have to balance: mu0 at least
         // ipm_start_dual x slack floor x |P x + q|_inf of the start point
         R rd0(0.0);
-        [[maybe_unused]] R Pod[3] = {zero, zero, zero};
-        if constexpr (FQ) od_mul_add(pod, x, Pod);
+        [[maybe_unused]] R Pod[5] = {zero, zero, zero, zero, zero};
+        if constexpr (FQ) Poff_add<0>(x, Pod);
         MPMPC_UNROLL
         for (int j = 0; j < 5; ++j) {
           R v = fma_(p[j], x[j], q[j]);
-          if constexpr (FQ) { if (j < 3) v = v + Pod[j]; }
+          if constexpr (FQ) v = v + Pod[j];
           rd0 = max_(rd0, sel(valid[j], abs_(v), zero));
         }
         mu0 = max_(mu0, (R(st.ipm_start_dual) * ths) * L::gmax(rd0));

@@ -124,7 +124,7 @@ struct AssembleIn {
   const int* wp_id;
   const double *x0, *cc, *lb, *ub;
 };
-// VAR: 0 = the full problem with a diagonal terminal weight, 1 = full terminal weight (FQ), 2 = reduced polish (RED),
+// VAR: 0 = the full problem with diagonal weights, 1 = full weights (FQ: Q, R, QN with off-diagonal entries), 2 = reduced polish (RED),
 //      3 = the full problem whose states e_psi and t have no bounds (FREEX; one-instance-per-wave kernels only)
 template <int G, int C, bool WARM, int VAR = 0>
 __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, SolverParams st, int B, int ld,
@@ -156,7 +156,9 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
   // (second launch of a packed batch: the interior-point iterations the first launch spent on this instance)
   const int base_ipm = (mode == 2 && iters) ? iters[inst * 2 + 1] : 0;
   static_assert(G == 64, "the general kernels run one instance per wave (only the reduced-native kernels pack)");
-  s.template run<WARM, true>(fields, B, inst, k, cfg.N, st, mode, guess, base_ipm, cfg.QN_offdiag);
+  double woff[7];
+  weight_offdiag(cfg, woff);
+  s.template run<WARM, true>(fields, B, inst, k, cfg.N, st, mode, guess, base_ipm, VAR == 1 ? woff : nullptr);
   MPMPC_TICK_BEGIN(7);
   s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y, WARM ? act : nullptr, ld);
   MPMPC_TICK_END(7);
@@ -850,14 +852,20 @@ int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_
   for (int i = 0; i < 3; ++i)
     if (!(cfg->Q[i] >= 0) || !(cfg->QN[i] >= 0)) return fail(MPMPC_E_ARG, "Q, QN diagonals must be >= 0");
   {
-    // QN positive semidefinite: leading principal minors of the symmetric 3 x 3 (with a rounding allowance)
-    const double a = cfg->QN[0], b = cfg->QN[1], c = cfg->QN[2], d = cfg->QN_offdiag[0], e = cfg->QN_offdiag[1], f = cfg->QN_offdiag[2];
-    if (!std::isfinite(d) || !std::isfinite(e) || !std::isfinite(f)) return fail(MPMPC_E_ARG, "QN must be finite");
-    const double tol = 1e-12 * (1.0 + a * a + b * b + c * c);
-    const double m2a = a * b - d * d, m2b = a * c - e * e, m2c = b * c - f * f;
-    const double det = a * (b * c - f * f) - d * (d * c - f * e) + e * (d * f - b * e);
-    if (m2a < -tol || m2b < -tol || m2c < -tol || det < -tol * (1.0 + a + b + c))
-      return fail(MPMPC_E_ARG, "QN must be positive semidefinite");
+    // Q, QN positive semidefinite: principal minors of the symmetric 3 x 3 (with a rounding allowance)
+    auto psd3 = [](const double* dg, const double* od) {
+      const double a = dg[0], b = dg[1], c = dg[2], d = od[0], e = od[1], f = od[2];
+      if (!std::isfinite(d) || !std::isfinite(e) || !std::isfinite(f)) return false;
+      const double tol = 1e-12 * (1.0 + a * a + b * b + c * c);
+      const double m2a = a * b - d * d, m2b = a * c - e * e, m2c = b * c - f * f;
+      const double det = a * (b * c - f * f) - d * (d * c - f * e) + e * (d * f - b * e);
+      return !(m2a < -tol || m2b < -tol || m2c < -tol || det < -tol * (1.0 + a + b + c));
+    };
+    if (!psd3(cfg->QN, cfg->QN_offdiag)) return fail(MPMPC_E_ARG, "QN must be finite and positive semidefinite");
+    if (!psd3(cfg->Q, cfg->Q_offdiag)) return fail(MPMPC_E_ARG, "Q must be finite and positive semidefinite");
+    const double r = cfg->R_offdiag[0];
+    if (!std::isfinite(r) || cfg->R[0] * cfg->R[1] - r * r < -1e-12 * (1.0 + cfg->R[0] * cfg->R[0] + cfg->R[1] * cfg->R[1]))
+      return fail(MPMPC_E_ARG, "R must be finite and positive semidefinite");
   }
   for (int i = 0; i < 2; ++i) {
     if (!(cfg->R[i] >= 0)) return fail(MPMPC_E_ARG, "R diagonal must be >= 0");
@@ -1271,9 +1279,9 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
   ain.tab = PathTables{h->kappa, h->v_ref, h->ds_next, h->n_wp, h->ub_tab, h->lb_tab, h->n_cols};
   ain.wp_id = h->wp_id; ain.x0 = h->x0; ain.cc = h->cc;
   ain.lb = h->have_rows ? h->lb : nullptr; ain.ub = h->have_rows ? h->ub : nullptr;
-  // A full terminal weight (QN with off-diagonal entries), bounds on e_psi / t or a cost on t rule the reduction out:
+  // Full weights (Q, R or QN with off-diagonal entries), bounds on e_psi / t or a cost on t rule the reduction out:
   // such configurations run the general kernels, one instance per wave.
-  const bool fullqn = h->cfg.QN_offdiag[0] != 0.0 || h->cfg.QN_offdiag[1] != 0.0 || h->cfg.QN_offdiag[2] != 0.0;
+  const bool fullqn = full_weights(h->cfg);
   const bool red = reducible(h->cfg, h->st);      // the polish may work on the (e_y, e_psi, kappa) problem
   const bool freex = !fullqn && !red && free_states(h->cfg);
   // The reduced-native kernels (mpmpc_reduced.hpp) take the batch path of every configuration they apply to - cold and

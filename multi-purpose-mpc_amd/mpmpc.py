@@ -27,7 +27,8 @@ class Config(C.Structure):
                 ("Q", C.c_double * 3), ("R", C.c_double * 2), ("QN", C.c_double * 3),
                 ("xmin", C.c_double * 3), ("xmax", C.c_double * 3),
                 ("umin", C.c_double * 2), ("umax", C.c_double * 2),
-                ("ay_max", C.c_double), ("wheelbase", C.c_double), ("QN_offdiag", C.c_double * 3)]
+                ("ay_max", C.c_double), ("wheelbase", C.c_double), ("QN_offdiag", C.c_double * 3),
+                ("Q_offdiag", C.c_double * 3), ("R_offdiag", C.c_double * 1)]
 
 
 class Settings(C.Structure):
@@ -76,12 +77,24 @@ def make_config(N, Q, R, QN, xmin, xmax, umin, umax, ay_max, wheelbase, circular
         raise ValueError("horizon N must satisfy 3 <= N <= %d" % MAX_HORIZON)
     c = Config(N=int(N), max_batch=int(max_batch), device=int(device), circular=int(bool(circular)),
                ay_max=float(ay_max), wheelbase=float(wheelbase))
-    QN = np.asarray(QN.toarray() if hasattr(QN, "toarray") else QN, float)
-    if QN.shape == (3, 3):          # the reference uses QN as a whole (src/MPC.py:150,154): diagonal + off-diagonals
-        if not np.array_equal(QN, QN.T):
-            raise ValueError("QN must be symmetric")
-        c.QN_offdiag = (C.c_double * 3)(QN[0, 1], QN[0, 2], QN[1, 2])
-        QN = np.diag(QN)
+    # The reference puts the WHOLE weight matrices into the Hessian (src/MPC.py:150): a matrix argument is split into its
+    # diagonal and its off-diagonal entries; a vector argument is a diagonal.
+    def split(M, n, name):
+        M = np.asarray(M.toarray() if hasattr(M, "toarray") else M, float)
+        if M.shape != (n, n):
+            return M, None
+        if not np.array_equal(M, M.T):
+            raise ValueError("%s must be symmetric" % name)
+        return np.diag(M).copy(), [M[i, j] for i in range(n) for j in range(i + 1, n)]
+    QN, off = split(QN, 3, "QN")
+    if off is not None:
+        c.QN_offdiag = (C.c_double * 3)(*off)
+    Q, off = split(Q, 3, "Q")
+    if off is not None:
+        c.Q_offdiag = (C.c_double * 3)(*off)
+    R, off = split(R, 2, "R")
+    if off is not None:
+        c.R_offdiag = (C.c_double * 1)(*off)
     for name, val, n in (("Q", Q, 3), ("R", R, 2), ("QN", QN, 3), ("xmin", xmin, 3), ("xmax", xmax, 3),
                          ("umin", umin, 2), ("umax", umax, 2)):
         a = np.asarray(val, float).ravel()

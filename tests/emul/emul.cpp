@@ -43,12 +43,15 @@ static void solve_g(const mpmpc_config* cfg, const mpmpc_settings* st, const dou
       if (mode == 2) base.v[i] = iters[in * 2 + 1];
     }
     Solver<L, FQ, RED, FREEX, RED> s;
+    double woff7[7];
+    weight_offdiag(*cfg, woff7);
+    const double* woff = FQ ? woff7 : nullptr;
     typename L::real fields[MPMPC_NUM_FIELDS];
     Solver<L, FQ, RED, FREEX, RED>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
     // (like the device: the packed kernels carry no phase-1 code when they run as the first of two launches)
-    if (guess) s.template run<true>(fields, B, inst, k, cfg->N, make_params(*st), mode, gs, base, cfg->QN_offdiag);
-    else if (mode == 1) s.template run<false, (G == 64)>(fields, B, inst, k, cfg->N, make_params(*st), mode, VI(0), base, cfg->QN_offdiag);
-    else s.template run<false, true>(fields, B, inst, k, cfg->N, make_params(*st), mode, VI(0), base, cfg->QN_offdiag);
+    if (guess) s.template run<true>(fields, B, inst, k, cfg->N, make_params(*st), mode, gs, base, woff);
+    else if (mode == 1) s.template run<false, (G == 64)>(fields, B, inst, k, cfg->N, make_params(*st), mode, VI(0), base, woff);
+    else s.template run<false, true>(fields, B, inst, k, cfg->N, make_params(*st), mode, VI(0), base, woff);
     s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y, act, ld);
     if (mode == 1)
       for (int i = 0; i < EMU_W; ++i)
@@ -166,7 +169,7 @@ extern "C" int emu_solve(const mpmpc_config* cfg, const mpmpc_settings* st, int 
                          double* z, double* u0, int* status, int* iters, double* resid, double* y) {
   if (cfg->N + 1 > G) return -1;
   const int C = lane_split(G, cfg->N);       // same variant as the launcher picks
-  const bool fullqn = cfg->QN_offdiag[0] != 0.0 || cfg->QN_offdiag[1] != 0.0 || cfg->QN_offdiag[2] != 0.0;
+  const bool fullqn = full_weights(*cfg);          // Q, R or QN with off-diagonal entries
   if (fullqn && G != 64) return -1;          // the launcher gives such instances a wave each
   if (fullqn && C == 16) solve_g<64, 16, true>(cfg, st, qp, B, z, u0, status, iters, resid, y);
   else if (fullqn) solve_g<64, 32, true>(cfg, st, qp, B, z, u0, status, iters, resid, y);

@@ -17,6 +17,7 @@ Stages
   speed     G2  speed-profile QP capture (reference_path.py:289-354) + certified v_ref
   corridor  G3  update_path_constraints tables [200 x 50], with and without obstacles
   assembly  G4  exact (P,q,A,l,u) the reference hands to osqp.setup for seeded cases
+  assembly_full  G4f  the same with non-diagonal Q, R, QN (g4f_assembly_N*.npz: P as triplets)
   loop      G6  closed-loop lap, N=10, teacher-forced per-step record
 """
 import os
@@ -41,6 +42,9 @@ OBSTACLES = [(0.0, 0.0, 0.05), (-0.8, -0.5, 0.08), (-0.7, -1.5, 0.05), (-0.3, -1
              (0.27, -1.0, 0.05), (0.78, -1.47, 0.05), (0.73, -0.9, 0.07), (1.2, 0.0, 0.08),
              (0.67, -0.05, 0.06)]
 NMAX = 50
+# one non-diagonal weight set (round 5): symmetric positive definite Q, R, QN with every off-diagonal entry set
+FULL_WEIGHTS = dict(Q=[[1.0, 0.2, 0.05], [0.2, 0.3, -0.1], [0.05, -0.1, 0.2]], R=[[0.5, 0.1], [0.1, 0.2]],
+                    QN=[[1.0, 0.3, -0.1], [0.3, 0.5, 0.2], [-0.1, 0.2, 0.4]])
 SPEED = {'a_min': -0.1, 'a_max': 0.5, 'v_min': 0.0, 'v_max': 1.0, 'ay_max': 4.0}
 CAR = dict(length=0.12, width=0.06, Ts=0.05)
 
@@ -134,6 +138,8 @@ def make_controller(rp, N, weights):
     car = BicycleModel(reference_path=rp, **CAR)
     if weights == "stock":            # simulation.py:101-103
         Q, R, QN = sparse.diags([1.0, 0.0, 0.0]), sparse.diags([0.5, 0.0]), sparse.diags([1.0, 0.0, 0.0])
+    elif weights == "full":           # NON-diagonal Q, R, QN (round 5): the reference accepts any sparse matrices (src/MPC.py:150)
+        Q, R, QN = (sparse.csc_matrix(np.array(FULL_WEIGHTS[k])) for k in ("Q", "R", "QN"))
     else:                             # config 3 "time optimal" (build-defined)
         Q, R, QN = sparse.diags([0.3, 0.0, 0.0]), sparse.diags([0.5, 0.0]), sparse.diags([0.3, 0.0, 1.0])
     ic = {'umin': np.array([0.0, -np.tan(0.66) / car.length]),
@@ -142,7 +148,7 @@ def make_controller(rp, N, weights):
     return car, MPC(car, N, Q, R, QN, sc, ic, 4.0)
 
 
-def stage_assembly():
+def stage_assembly(cases=((3, "stock", 32), (10, "stock", 64), (30, "stock", 96), (50, "time_optimal", 64)), tag=""):
     """G4: what the reference passes to osqp.setup for seeded (s, pose, previous plan) cases."""
     osqp.SOLVE = False
     worlds = {}
@@ -158,10 +164,10 @@ def stage_assembly():
         for w, v in zip(rp.waypoints, v_ref):
             w.v_ref = v
     # 256 captures in all; the first 16 / 24 / 32 / 24 of each horizon are the cases of round 1
-    for N, weights, ncase in ((3, "stock", 32), (10, "stock", 64), (30, "stock", 96), (50, "time_optimal", 64)):
+    for N, weights, ncase in cases:
         rng = np.random.default_rng(1000 + N)
         rec = {k: [] for k in ("s", "pose", "cc_prev", "obst", "wp_id", "x0", "lb", "ub", "q", "l", "u",
-                               "P_diag", "P_nnz", "A_indptr", "A_indices", "A_data")}
+                               "P_diag", "P_nnz", "A_indptr", "A_indices", "A_data", "P_row", "P_col", "P_val")}
         for c in range(ncase):
             obst = bool(c % 2)
             rp = worlds[obst]
@@ -206,6 +212,8 @@ def stage_assembly():
             rec["u"].append(cap["u"])
             rec["P_diag"].append(P.diagonal())
             rec["P_nnz"].append(P.nnz)
+            Pc = P.tocoo()            # the WHOLE matrix the reference handed over (the same pattern for every case of a file)
+            rec["P_row"].append(Pc.row); rec["P_col"].append(Pc.col); rec["P_val"].append(Pc.data)
             rec["A_indptr"].append(A.indptr)
             rec["A_indices"].append(A.indices)
             rec["A_data"].append(A.data)
@@ -214,10 +222,19 @@ def stage_assembly():
         out.update(A_indptr=np.array(rec["A_indptr"]), A_indices=np.concatenate(rec["A_indices"]),
                    A_data=np.concatenate(rec["A_data"]), A_case_ptr=a_ptr, N=np.array([N]),
                    weights=np.array([weights]))
-        np.savez_compressed(os.path.join(HERE, "g4_assembly_N%d.npz" % N), **out)
-        print("G4 N=%d: %d cases, nnz(A) %s, wp_ids %s" % (N, len(rec["s"]), sorted(set(np.diff(a_ptr))),
-                                                          rec["wp_id"][:8]))
+        if not tag:                   # (the files of rounds 1 - 4 keep their content: diagonal P, P_diag says it all)
+            for k in ("P_row", "P_col", "P_val"):
+                out.pop(k)
+        np.savez_compressed(os.path.join(HERE, "g4%s_assembly_N%d.npz" % (tag, N)), **out)
+        print("G4%s N=%d: %d cases, nnz(A) %s, nnz(P) %s, wp_ids %s" % (tag, N, len(rec["s"]), sorted(set(np.diff(a_ptr))),
+                                                                   sorted(set(rec["P_nnz"])), rec["wp_id"][:8]))
     osqp.SOLVE = True
+
+
+def stage_assembly_full():
+    """G4f: the same captures with NON-diagonal Q, R, QN (FULL_WEIGHTS): the reference puts the whole matrices into P
+    (src/MPC.py:150) and only diag(Q), diag(R) - but the whole QN - into q (src/MPC.py:153-155)."""
+    stage_assembly(cases=((3, "full", 16), (10, "full", 32), (30, "full", 48), (50, "full", 24)), tag="f")
 
 
 def stage_loop():
@@ -336,7 +353,7 @@ def stage_raster():
 
 
 STAGES = dict(raster=stage_raster, path=stage_path, speed=stage_speed, corridor=stage_corridor, assembly=stage_assembly,
-              loop=stage_loop, loop_stock=stage_loop_stock)
+              loop=stage_loop, loop_stock=stage_loop_stock, assembly_full=stage_assembly_full)
 
 if __name__ == "__main__":
     assert os.getcwd().rstrip("/") == "/root/reference/src", "run with cwd=/root/reference/src"

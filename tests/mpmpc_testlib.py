@@ -70,6 +70,21 @@ def qp_to_dense(qp_i, N):
     return Pd, q, A, l, u
 
 
+def qp_to_dense_full(qp_i, N, cfg):
+    """(P, q, A, l, u) of one instance with the WHOLE weight matrices in P, as the reference builds it (src/MPC.py:150):
+    K1's 27 stage fields carry the diagonals of the blocks, the configuration their off-diagonal entries."""
+    Pd, q, A, l, u = qp_to_dense(qp_i, N)
+    P = np.diag(Pd)
+    ne = 3 * (N + 1)
+    for k in range(N + 1):
+        od = cfg.QN_offdiag if k == N else cfg.Q_offdiag
+        for (i, j), v in zip(((0, 1), (0, 2), (1, 2)), od):
+            P[3 * k + i, 3 * k + j] = P[3 * k + j, 3 * k + i] = v
+        if k < N:
+            P[ne + 2 * k, ne + 2 * k + 1] = P[ne + 2 * k + 1, ne + 2 * k] = cfg.R_offdiag[0]
+    return P, q, A, l, u
+
+
 def kkt_batch(qp, N, z, y):
     """Vectorised KKT residuals of a whole batch from the stage-blocked fields qp [27, B, LD]:
     (prim, stat, comp) [B] each, in the reference's unscaled problem (rows [dynamics; state boxes; input

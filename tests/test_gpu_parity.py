@@ -738,6 +738,117 @@ def test_full_terminal_weight_on_device(cfgid, N, B, track, emu):
     assert set(np.unique(sol.status)) <= {1, 2, -3}
 
 
+@pytest.mark.parametrize("N", [3, 10, 30, 50])
+def test_full_stage_weights_on_device_reference_captures(N, track, emu):
+    """non-diagonal Q and R through the drop-in.  Golden G4f = what the REFERENCE handed to osqp.setup with
+    non-diagonal Q, R, QN.  Through libmpmpc.so: K1's fields + the configuration's off-diagonals rebuild the reference's
+    (P, q, A, l) bit for bit (u to the ulps of the device's tan), the general kernel (dense 3 x 3 / 2 x 2 stage blocks) agrees
+    with its lock-step emulation, reaches the C oracle's optimum of the CAPTURED QP (statuses, z to 1e-6, first control to
+    1e-8) and every solved instance carries the plain-numpy KKT certificate and the uniqueness certificate on the captured data."""
+    from scipy import sparse
+    import oracle_c as OC
+    import independent as I
+    from test_emul_parity import full_weight_config
+    g = np.load(M.GOLDEN + "/g4f_assembly_N%d.npz" % N)
+    B, n, m = g["s"].size, 5 * N + 3, 8 * N + 6
+    cfg = full_weight_config(N, "full", max_batch=B)
+    h = mpmpc.Handle(cfg)
+    h.set_path(track.kappa, track.v_ref, track.ds_next)
+    args = (g["wp_id"].astype(np.int32), g["x0"], g["cc_prev"], g["lb"], g["ub"])
+    qp = h.assemble(*args)
+    sol = h.solve(*args, want_y=True)
+    h.close()
+    ref = emu.solve(cfg, mpmpc.default_settings(), qp, G=64)
+    assert np.array_equal(sol.status, ref.status) and np.array_equal(sol.iters[:, 0], ref.iters[:, 0])
+    ok = ref.status == 1
+    assert np.max(np.abs(sol.z[ok] - ref.z[ok])) <= 1e-9
+    keep, _ = I.compared_coordinates(N)
+    n_ok = 0
+    for c in range(B):
+        P, q, A, l, u = T.qp_to_dense_full(qp[:, c, :], N, cfg)
+        Pref = sparse.coo_matrix((g["P_val"][c], (g["P_row"][c], g["P_col"][c])), shape=(n, n)).toarray()
+        lo, hi = g["A_case_ptr"][c], g["A_case_ptr"][c + 1]
+        Aref = sparse.csc_matrix((g["A_data"][lo:hi], g["A_indices"][lo:hi], g["A_indptr"][c]), shape=(m, n)).toarray()
+        assert np.array_equal(P, Pref) and np.array_equal(q, g["q"][c]) and np.array_equal(A, Aref)
+        assert np.array_equal(l, np.where(g["l"][c] <= -1e30, -np.inf, g["l"][c]))
+        fin = np.isfinite(g["u"][c])
+        assert np.max(np.abs(u[fin] - g["u"][c][fin])) <= 8 * np.finfo(float).eps
+        x, y, info = OC.solve(Pref, g["q"][c], Aref, g["l"][c], g["u"][c])
+        assert sol.status[c] == info.status or (sol.status[c] == 2 and info.status == -3), (c, sol.status[c], info.status)
+        if info.status == 1 and info.polished == 1:
+            n_ok += 1
+            e = np.abs(sol.z[c] - x)
+            e[-1] = 0.0
+            assert e.max() <= 1e-6 and np.max(e[3 * (N + 1):3 * (N + 1) + 2]) <= 1e-8
+            assert O.kkt_certificate(Pref, g["q"][c], Aref, g["l"][c], g["u"][c], sol.z[c], sol.y[c])["ok_tol"](1e-8)
+            assert I.uniqueness_certificate(Pref, Aref, g["l"][c], g["u"][c], sol.z[c], sol.y[c], keep)["unique"], c
+    assert n_ok >= B // 2
+
+
+@pytest.mark.parametrize("name,cfgid,N,B", [("full", 4, 30, 1500), ("rank1", 2, 30, 200), ("q_only", 4, 10, 300), ("r_only", 3, 50, 100)])
+def test_full_stage_weights_on_device_batches(name, cfgid, N, B, track, emu):
+    """Non-diagonal stage weights on BASELINE-type batches (beyond 1 024 instances too: one instance per wave, the packed
+    kernels carry no dense-block code): device = emulation of the same lane code, KKT certificate with plain numpy on the dense
+    data for every solved instance checked, Farkas rays for the refused ones; singular (rank-one) weight blocks included."""
+    from test_emul_parity import full_weight_config, FULL_WEIGHT_SETS
+    sc = scenarios.make(cfgid, track, B=B, N=N)
+    cfg = full_weight_config(N, name, max_batch=B)
+    h = mpmpc.Handle(cfg, mpmpc.default_settings(**STRICT))
+    h.set_path(track.kappa, track.v_ref, track.ds_next)
+    qp = h.assemble(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    sol = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+    h.close()
+    nn = min(B, 64)
+    ref = emu.solve(cfg, mpmpc.default_settings(**STRICT), np.ascontiguousarray(qp[:, :nn, :]), G=64)
+    assert np.array_equal(sol.status[:nn], ref.status) and np.array_equal(sol.iters[:nn], ref.iters)
+    ok = ref.status == 1
+    f = lambda P, q, x: 0.5 * x @ P @ x + q @ x
+    if name != "rank1":
+        assert np.max(np.abs(sol.z[:nn][ok] - ref.z[ok])) <= 1e-9
+    assert set(np.unique(sol.status)) <= {1, -3} and (sol.status == 1).mean() > 0.8
+    rng = np.random.default_rng(0)
+    for i in rng.permutation(B)[:40]:
+        P, q, A, l, u = T.qp_to_dense_full(qp[:, i, :], N, cfg)
+        if sol.status[i] == 1:
+            assert O.kkt_certificate(P, q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8), i
+        else:
+            assert O.farkas_certificate(A, l, u, sol.y[i], 1e-6)["ok"], i
+    for i in np.flatnonzero(ok)[:8]:             # objective against the emulation (flat directions of singular blocks excused)
+        P, q, A, l, u = T.qp_to_dense_full(qp[:, i, :], N, cfg)
+        assert abs(f(P, q, sol.z[i]) - f(P, q, ref.z[i])) <= 1e-10 * max(1.0, abs(f(P, q, ref.z[i])))
+
+
+def test_diagonal_weights_given_as_matrices_keep_the_reduced_native_kernels(track):
+    """Diagonal Q, R, QN handed over as full MATRICES (dense or scipy sparse, as src/simulation.py:101-103 does) give the very
+    configuration the vectors give - byte for byte - and therefore the same dispatch (reduced-native kernels) and the same
+    bits; one non-zero off-diagonal entry moves the configuration to the general kernels (same statuses, another optimum)."""
+    from scipy import sparse
+    sc = scenarios.make(4, track, B=600)
+    Q, R, QN = scenarios.WEIGHTS["stock"]
+    mk = lambda q, r, qn: mpmpc.make_config(sc.N, q, r, qn, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX,
+                                            scenarios.AY_MAX, scenarios.CAR_LENGTH, max_batch=sc.B)
+    c_vec, c_mat, c_sp = mk(Q, R, QN), mk(np.diag(Q), np.diag(R), np.diag(QN)), mk(sparse.diags(Q), sparse.diags(R), sparse.diags(QN))
+    assert bytes(c_vec) == bytes(c_mat) == bytes(c_sp)
+    sols = []
+    for c in (c_vec, c_mat):
+        h = mpmpc.Handle(c)
+        h.set_path(track.kappa, track.v_ref, track.ds_next)
+        sols.append(h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub))
+        h.close()
+    assert np.array_equal(sols[0].z, sols[1].z) and np.array_equal(sols[0].status, sols[1].status)
+    Rf = np.diag(R).copy()
+    Rf[0, 1] = Rf[1, 0] = 1e-3
+    Qf = np.diag(Q).copy()
+    Qf[1, 1] = 1e-4                      # (R must stay PSD: its kappa weight is zero, so the coupling needs a positive one)
+    Rf[1, 1] = 1e-4
+    h = mpmpc.Handle(mk(Qf, Rf, QN))
+    h.set_path(track.kappa, track.v_ref, track.ds_next)
+    s2 = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    h.close()
+    both = (sols[0].status == 1) & (s2.status == 1)
+    assert both.mean() > 0.8 and np.max(np.abs(s2.u0[both] - sols[0].u0[both])) > 1e-7
+
+
 def test_paths_longer_than_the_lds_staging_of_k1(emu):
     """K1 stages the three path tables in LDS when the path has at most 1 024 waypoints and reads them from memory
     otherwise (the limit's far side was untested): a 1 500-waypoint synthetic path, assembly bit for bit and

@@ -132,9 +132,16 @@ def test_rejects_unsupported_weights_and_missing_profile():
     from scipy import sparse
     ic = {'umin': np.array([0.0, -1.0]), 'umax': np.array([1.0, 1.0])}
     sc = {'xmin': np.array([-np.inf] * 3), 'xmax': np.array([np.inf] * 3)}
-    Qbad = np.array([[1.0, 0.1, 0], [0.1, 0, 0], [0, 0, 0]])
+    Qbad = np.array([[1.0, 0.1, 0], [0.1, 0, 0], [0, 0, 0]])          # indefinite: 1 x 0 - 0.01 < 0
     with pytest.raises(ValueError):
         MPC(car, 10, Qbad, sparse.diags([0.5, 0.0]), sparse.diags([1.0, 0, 0]), sc, ic, 4.0, backend=object())
+    with pytest.raises(ValueError):                                    # not symmetric
+        MPC(car, 10, np.array([[1.0, 0.1, 0], [0.2, 1, 0], [0, 0, 0]]), sparse.diags([0.5, 0.0]), sparse.diags([1.0, 0, 0]), sc, ic, 4.0,
+            backend=object())
+    # a symmetric positive semidefinite Q / R with off-diagonal entries is taken, like in the reference (src/MPC.py:150)
+    mpc = MPC(car, 10, np.array([[1.0, 0.1, 0], [0.1, 0.5, 0], [0, 0, 0]]), np.array([[0.5, 0.05], [0.05, 0.1]]), sparse.diags([1.0, 0, 0]),
+              sc, ic, 4.0, backend=object())
+    assert list(mpc._cfg.Q_offdiag) == [0.1, 0.0, 0.0] and list(mpc._cfg.R_offdiag) == [0.05] and list(mpc._cfg.Q) == [1.0, 0.5, 0.0]
     with pytest.raises(ValueError):
         MPC(car, 2, sparse.diags([1.0, 0, 0]), sparse.diags([0.5, 0.0]), sparse.diags([1.0, 0, 0]), sc, ic, 4.0,
             backend=object())

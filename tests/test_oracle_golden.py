@@ -41,6 +41,40 @@ def test_assembly_matches_reference_capture(N, otrack):
         assert all((i >= 6 * (N + 1)) and ((i - 6 * (N + 1)) % 2 == 0) for i in cap)
 
 
+@pytest.mark.parametrize("N", [3, 10, 30, 50])
+def test_assembly_with_full_weights_matches_reference_capture(N, otrack):
+    """G4f: NON-diagonal Q, R, QN through the reference itself (tests/golden/make_golden.py assembly_full).  The reference
+    puts the whole matrices into P (src/MPC.py:150) and only diag(Q), diag(R) - but the whole QN - into q (src/MPC.py:153-155):
+    the numpy restatement reproduces its (P, q, A, l, u) bit for bit, P's sparsity pattern included."""
+    g = np.load(M.GOLDEN + "/g4f_assembly_N%d.npz" % N)
+    assert str(g["weights"][0]) == "full" and g["s"].size >= 12
+    w = full_weights()
+    lim = M.Limits.stock()
+    n = 5 * N + 3
+    assert int(g["P_nnz"][0]) == 9 * (N + 1) + 4 * N                      # dense 3 x 3 and 2 x 2 blocks
+    for c in range(g["s"].size):
+        wp = int(g["wp_id"][c])
+        P, q, A, l, u = M.assemble(otrack, wp, g["x0"][c], g["cc_prev"][c], g["lb"][c], g["ub"][c], N, w, lim)
+        Pref = sparse.coo_matrix((g["P_val"][c], (g["P_row"][c], g["P_col"][c])), shape=(n, n)).toarray()
+        assert np.array_equal(P, Pref) and np.count_nonzero(P) == int(g["P_nnz"][c])
+        lo, hi = g["A_case_ptr"][c], g["A_case_ptr"][c + 1]
+        Aref = sparse.csc_matrix((g["A_data"][lo:hi], g["A_indices"][lo:hi], g["A_indptr"][c]), shape=A.shape)
+        assert np.array_equal(A, Aref.toarray())
+        assert np.array_equal(q, g["q"][c]) and np.array_equal(np.signbit(q), np.signbit(g["q"][c]))
+        assert np.array_equal(l, g["l"][c]) and _ulp_close(u, g["u"][c], 4)
+        # the quirk: q is NOT -P xr - the off-diagonal entries of Q never reach it
+        ey_ref = np.zeros(n)
+        ey_ref[3:3 * (N + 1):3] = (g["lb"][c] + g["ub"][c]) / 2
+        if np.any(ey_ref[:3 * N] != 0):
+            assert not np.allclose(q[:3 * N], -(Pref @ ey_ref)[:3 * N])
+
+
+def full_weights():
+    """the weight set of golden G4f (tests/golden/make_golden.py: FULL_WEIGHTS)"""
+    return M.Weights(np.array([[1.0, 0.2, 0.05], [0.2, 0.3, -0.1], [0.05, -0.1, 0.2]]), np.array([[0.5, 0.1], [0.1, 0.2]]),
+                     np.array([[1.0, 0.3, -0.1], [0.3, 0.5, 0.2], [-0.1, 0.2, 0.4]]))
+
+
 def test_edge_cases_present():
     g = np.load(M.GOLDEN + "/g4_assembly_N30.npz")
     assert 0 in g["wp_id"] and 199 in g["wp_id"]          # int kappa at wp 0, the 199 -> 0 wrap

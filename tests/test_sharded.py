@@ -91,12 +91,12 @@ def test_sharded_batch_mpc_is_batch_mpc():
 
 
 @pytest.mark.gpu
-def test_non_diagonal_stage_weights_are_refused_loudly_on_the_device_path():
-    """`Q` and `R` must be diagonal (the reference puts the whole matrices into P, src/MPC.py:150, its
-    cost vector only their diagonals).  With a device present the product classes refuse such weights with ValueError before
-    anything is launched - MPC, BatchMPC and ShardedBatchMPC alike - while a full symmetric QN is accepted; the C side has no
-    field an off-diagonal stage weight could arrive in (include/mpmpc.h: Q[3], R[2] are diagonals) and rejects a QN that is not
-    positive semi-definite with MPMPC_E_ARG."""
+def test_non_diagonal_stage_weights_are_accepted_by_every_product_class():
+    """Round 5: `Q` and `R` may be any symmetric positive semidefinite matrices, like in the reference
+    (src/MPC.py:150 puts the whole matrices into P; its cost vector uses only their diagonals, src/MPC.py:153-155 - reproduced).
+    MPC, BatchMPC and ShardedBatchMPC take them and agree with each other; what is still refused - loudly, before anything is
+    launched - is a matrix that is not symmetric or not positive semidefinite (ValueError from the host classes, MPMPC_E_ARG
+    from the C side for a caller that fills mpmpc_config itself)."""
     import test_host_mpc as H
     from MPC import MPC, BatchMPC
     from scipy import sparse
@@ -104,16 +104,32 @@ def test_non_diagonal_stage_weights_are_refused_loudly_on_the_device_path():
     ic = {'umin': np.array([0.0, -np.tan(0.66) / car.length]), 'umax': np.array([1.0, np.tan(0.66) / car.length])}
     scn = {'xmin': np.array([-np.inf] * 3), 'xmax': np.array([np.inf] * 3)}
     Q, R, QN = sparse.diags([1.0, 0.0, 0.0]), sparse.diags([0.5, 0.0]), sparse.diags([1.0, 0.0, 0.0])
-    Qbad = np.array([[1.0, 0.1, 0.0], [0.1, 0.5, 0.0], [0.0, 0.0, 0.0]])
-    Rbad = np.array([[0.5, 0.05], [0.05, 0.1]])
-    for make in (lambda q, r: MPC(car, 10, q, r, QN, scn, ic, 4.0),
-                 lambda q, r: BatchMPC(car, 10, q, r, QN, scn, ic, 4.0, max_batch=4),
-                 lambda q, r: sharded.ShardedBatchMPC(car, 10, q, r, QN, scn, ic, 4.0, max_batch=4, devices=[0, 0])):
-        for q, r in ((Qbad, R), (Q, Rbad)):
-            with pytest.raises(ValueError):
-                make(q, r)
-    QNfull = np.array([[1.0, 0.1, 0.0], [0.1, 0.5, 0.0], [0.0, 0.0, 0.2]])
-    BatchMPC(car, 10, Q, R, QNfull, scn, ic, 4.0, max_batch=4).handle.close()          # accepted
+    Qf = np.array([[1.0, 0.1, 0.0], [0.1, 0.5, 0.0], [0.0, 0.0, 0.0]])
+    Rf = np.array([[0.5, 0.05], [0.05, 0.1]])
+    QNf = np.array([[1.0, 0.1, 0.0], [0.1, 0.5, 0.0], [0.0, 0.0, 0.2]])
+    tr = scenarios.sim_track()
+    sc = scenarios.make(4, tr, B=64, N=10)
+    outs = []
+    for q, r in ((Qf, R), (Q, Rf), (sparse.csc_matrix(Qf), sparse.csc_matrix(Rf))):
+        bm = BatchMPC(car, 10, q, r, QNf, scn, ic, 4.0, max_batch=sc.B)
+        u, plan, status, _ = bm.get_control_batch(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+        sm = sharded.ShardedBatchMPC(car, 10, q, r, QNf, scn, ic, 4.0, max_batch=sc.B, devices=[0, 0])
+        u2, plan2, status2, _ = sm.get_control_batch(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+        assert np.array_equal(status, status2) and np.array_equal(u, u2) and (status == 1).mean() > 0.5
+        outs.append(u[status == 1])
+        bm.close()
+        sm.close()
+    assert np.max(np.abs(outs[0] - outs[1])) > 1e-6            # different weights, different optima
+    # the single-car class: one step of the reference's loop
+    mpc = MPC(car, 10, Qf, Rf, QNf, scn, ic, 4.0)
+    car.s = 0.3
+    u = mpc.get_control()
+    assert u.shape == (2,) and np.all(np.isfinite(u)) and mpc.last_status in (1, 2, -3)
+    with pytest.raises(ValueError):
+        BatchMPC(car, 10, np.array([[1.0, 0.1, 0.0], [0.2, 0.5, 0.0], [0.0, 0.0, 0.0]]), R, QN, scn, ic, 4.0, max_batch=4)      # not symmetric
+    for bad_q, bad_r in ((np.array([[1.0, 2.0, 0.0], [2.0, 0.5, 0.0], [0.0, 0.0, 0.0]]), R), (Q, np.array([[0.5, 1.0], [1.0, 0.1]]))):
+        with pytest.raises(ValueError):                                                                                         # indefinite
+            BatchMPC(car, 10, bad_q, bad_r, QN, scn, ic, 4.0, max_batch=4)
     cfg = T.stock_config(10, max_batch=4)
     cfg.QN_offdiag[0] = 5.0                                                              # indefinite: 1 x 0 - 25 < 0
     with pytest.raises(mpmpc.MpmpcError):
