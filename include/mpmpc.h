@@ -27,7 +27,7 @@ extern "C" {
 
 #define MPMPC_NX 3
 #define MPMPC_NU 2
-#define MPMPC_MAX_HORIZON 63
+#define MPMPC_MAX_HORIZON 255
 #define MPMPC_NUM_FIELDS 27 /* doubles per (instance, stage) of the stage-blocked QP, see below */
 
 /* per-instance status, OSQP's numbering (drives the fallback branch of src/MPC.py:208-216) */
@@ -60,7 +60,9 @@ typedef struct mpmpc_handle_s* mpmpc_handle;
  * HORIZON: 3 <= N <= MPMPC_MAX_HORIZON (one lane per stage: a wavefront up to N = 63, a workgroup of 2 / 4 wavefronts whose
  * stages talk through LDS beyond that; the reference has no upper limit). */
 typedef struct {
-  int32_t N;          /* horizon, 3 <= N <= MPMPC_MAX_HORIZON (the kappa_pred quirk of MPC.py:86 needs N >= 3) */
+  int32_t N;          /* horizon, 3 <= N <= MPMPC_MAX_HORIZON (the kappa_pred quirk of MPC.py:86 needs N >= 3); N <= 63: one wavefront
+                         (or a part of one) per instance; 64 .. 127 / 128 .. 255: a workgroup of 2 / 4 wavefronts per instance,
+                         general kernel (csrc/lane_gpu.hpp: LaneBlock) */
   int32_t max_batch;  /* largest B of any later call */
   int32_t device;     /* HIP device ordinal */
   int32_t circular;   /* ReferencePath.circular */

@@ -9,7 +9,12 @@
 
 namespace mpmpc {
 
-constexpr int EMU_W = 64;
+// width of the emulated execution group: one wavefront (64), or - horizons above 63, tests/emul/emul_wide.cpp - a workgroup of
+// 2 / 4 wavefronts whose lanes exchange through LDS on the device (lane_gpu.hpp: LaneBlock); -DMPMPC_EMU_W=128 / 256
+#ifndef MPMPC_EMU_W
+#define MPMPC_EMU_W 64
+#endif
+constexpr int EMU_W = MPMPC_EMU_W;
 
 // Optional instruction census (tests/emul built with -DMPMPC_COUNT_OPS): wave-level FP64
 // instructions by class, used to state the algorithmic flop count of a solve in DESIGN.md.
@@ -106,7 +111,7 @@ inline VB within_(const VI& v, int lo, int hi) { VB r; for (int i = 0; i < EMU_W
 inline VB bit_(const VI& v, int b) { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = ((v.v[i] >> b) & 1) != 0; return r; }
 inline VB selb(const VB& m, const VB& a, const VB& b) { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
 
-// G = lanes per instance (16, 32 or 64); one emulated wave carries 64/G instances.
+// G = lanes per instance (16, 32 or 64; 128 / 256 in the wide builds); one emulated wave carries EMU_W / G instances.
 // C = split of the twisted factorisation (mpmpc_core.hpp, factor): lanes [C, 2C) of an instance are
 // reversed in chain layout; C == G means no second chain.
 template <int G, int C = G / 2>

@@ -320,4 +320,126 @@ struct LaneGpu {
   }
 };
 
+// ----------------------------------------------------------------------------------------------------------------
+// Horizons above 63: one instance = one WORKGROUP of G = 128 / 256 threads (2 / 4 wavefronts), still one lane per stage.
+// The same lane code (mpmpc_core.hpp: Solver) runs on it; what changes is how lanes talk: a neighbour may sit in another
+// wavefront, so every lane exchange goes through an LDS buffer between two workgroup barriers, and an instance-wide
+// reduction is the in-wave DPP butterfly followed by a combination of the 2 / 4 wave results that every lane forms in the
+// same order (the result is bit-identical on all lanes - it decides block-uniform branches - and associates like the xor
+// butterfly of the emulation, lane_emu.hpp: pairs of waves first).  Chains of the twisted factorisation: lanes [0, G/2) climb,
+// lanes [G/2, G) descend (C = G / 2), exactly as for <64, 32>.  No cyclic reduction, no split layout (those are arrangements
+// of the 64-lane kernels); this is the general kernel's code at one wavefront per SIMD, paying two barriers per exchange -
+// the price of a horizon the reference allows (src/MPC.py:73-74 has no limit) and a 64-lane wavefront does not hold.
+// LDS per workgroup: SLOTS cold slots of G doubles (also the staging of the output rows) + one exchange row + the
+// reduction scratch: 67 KB at G = 128, 134 KB at G = 256, passed as DYNAMIC shared memory (above the 64 KB static limit).
+template <int G, int SLOTS = 66>
+struct LaneBlock {
+  static_assert(G == 128 || G == 256, "a workgroup of 2 or 4 wavefronts");
+  static constexpr int split = G / 2;
+  static constexpr int C = G / 2;
+  using real = double;
+  using mask = bool;
+  using ival = int;
+  static constexpr int group = G;
+  static constexpr int per_wave = 1;          // ONE instance per execution group: instance-wide conditions are group-wide
+  static constexpr int waves = G / 64;
+  static constexpr int cold_slots = SLOTS;
+  static constexpr size_t lds_bytes = sizeof(double) * ((size_t)(SLOTS + 1) * G + 8);
+
+  static __device__ __forceinline__ int lane_id() { return threadIdx.x; }
+  static __device__ __forceinline__ int stage() { return threadIdx.x; }
+  static __device__ __forceinline__ int slot() { return 0; }
+  static __device__ __forceinline__ int lane_again() { return threadIdx.x; }
+  static __device__ __forceinline__ int stage_again() { return threadIdx.x; }
+  static __device__ __forceinline__ int slot_again() { return 0; }
+  static __device__ __forceinline__ bool mtrue() { return true; }
+  static __device__ __forceinline__ bool mfalse() { return false; }
+
+  static __device__ __forceinline__ double* lds() {
+    extern __shared__ double mpmpc_block_lds[];
+    return mpmpc_block_lds;
+  }
+  static __device__ __forceinline__ double* cold() { return lds(); }
+  static __device__ __forceinline__ double* xrow() { return lds() + (size_t)SLOTS * G; }
+  static __device__ __forceinline__ double* rrow() { return lds() + (size_t)(SLOTS + 1) * G; }
+
+  // the value lane `src` holds (src outside [0, G): 0) - every lane of the workgroup must call it
+  static __device__ __forceinline__ double take(double a, int src) {
+    double* x = xrow();
+    x[threadIdx.x] = a;
+    __syncthreads();
+    const double r = (unsigned)src < (unsigned)G ? x[src] : 0.0;
+    __syncthreads();          // (the row is free again before anyone writes the next exchange into it)
+    return r;
+  }
+  static __device__ __forceinline__ double up(double a) { return take(a, (int)threadIdx.x - 1); }
+  static __device__ __forceinline__ double down(double a) { return take(a, (int)threadIdx.x + 1); }
+  // chain layout: lanes [C, 2C) reversed; one-lane shifts along the chains with zero inflow at the chain heads
+  static __device__ __forceinline__ double mirror(double a) {
+    const int t = threadIdx.x;
+    return take(a, t < C ? t : 3 * C - 1 - t);
+  }
+  static __device__ __forceinline__ double cup(double a) {
+    const int t = threadIdx.x;
+    return take(a, (t == 0 || t == C) ? -1 : t - 1);
+  }
+  static __device__ __forceinline__ double cdown(double a) {
+    const int t = threadIdx.x;
+    return take(a, (t == C - 1 || t == 2 * C - 1) ? -1 : t + 1);
+  }
+
+  template <class F>
+  static __device__ __forceinline__ double reduce(double a, F f) {
+    a = LaneGpu<64, 32, 1>::bfly(a, f);          // wave-uniform
+    double* r = rrow();
+    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = a;
+    __syncthreads();
+    double t = f(r[0], r[1]);
+    if constexpr (waves == 4) t = f(t, f(r[2], r[3]));
+    __syncthreads();
+    return t;
+  }
+  static __device__ __forceinline__ double gmax(double a) { return reduce(a, [](double x, double y) { return __builtin_fmax(x, y); }); }
+  static __device__ __forceinline__ double gmin(double a) { return reduce(a, [](double x, double y) { return __builtin_fmin(x, y); }); }
+  static __device__ __forceinline__ double gsum(double a) { return reduce(a, [](double x, double y) { return x + y; }); }
+  static __device__ __forceinline__ bool gany(bool m) { return __syncthreads_or(m ? 1 : 0) != 0; }
+  static __device__ __forceinline__ bool wany(bool m) { return __syncthreads_or(m ? 1 : 0) != 0; }
+  static __device__ __forceinline__ double gcount(bool m) { return double(__syncthreads_count(m ? 1 : 0)); }
+
+  static __device__ __forceinline__ void cold_put(int slot, double a) { cold()[slot * G + threadIdx.x] = a; }
+  static __device__ __forceinline__ double cold_get(int slot) { return cold()[slot * G + threadIdx.x]; }
+  static __device__ __forceinline__ void fence() { asm volatile("" ::: "memory"); }
+  static __device__ __forceinline__ void sched_barrier() { __builtin_amdgcn_sched_barrier(0); }
+
+  // output row of the workgroup's instance: staged in LDS (the cold slots: the solve is over), written as one run
+  template <class F>
+  static __device__ __forceinline__ void rows(double* dst, int rowlen, int inst, int n_inst, F fill) {
+    double* buf = cold();
+    __syncthreads();
+    fill([&](int idx, bool ok, double v) { if (ok) buf[idx] = v; });
+    __syncthreads();
+    if (inst < n_inst) {
+      double* out = dst + (long)inst * rowlen;
+      for (int i = threadIdx.x; i < rowlen; i += G) out[i] = buf[i];
+    }
+  }
+  template <class F>
+  static __device__ __forceinline__ void rows_any(double* dst, int rowlen, int inst, int n_inst, F fill) { rows(dst, rowlen, inst, n_inst, fill); }
+
+  static __device__ __forceinline__ double load(const double* p, int idx, bool ok, double dflt) { return ok ? p[idx] : dflt; }
+  static __device__ __forceinline__ int loadi(const int* p, int idx, bool ok, int dflt) { return ok ? p[idx] : dflt; }
+  template <class F>
+  static __device__ __forceinline__ void when(bool ok, F f) { if (ok) f(); }
+  static __device__ __forceinline__ double gather(const double* p, int idx, bool ok, double dflt) {
+    const double v = p[ok ? idx : 0];
+    return ok ? v : dflt;
+  }
+  static __device__ __forceinline__ int gatheri(const int* p, int idx, bool ok, int dflt) {
+    const int v = p[ok ? idx : 0];
+    return ok ? v : dflt;
+  }
+  static __device__ __forceinline__ void store(double* p, int idx, bool ok, double a) { if (ok) p[idx] = a; }
+  static __device__ __forceinline__ void storei(int* p, int idx, bool ok, int a) { if (ok) p[idx] = a; }
+};
+
 }  // namespace mpmpc

@@ -45,7 +45,9 @@ constexpr double INFTY = 1e30, MIN_SCALING = 1e-4, MAX_SCALING = 1e4;
 constexpr double RHO_MIN = 1e-6, RHO_MAX = 1e6, RHO_TOL = 1e-4, RHO_EQ_FACTOR = 1e3;
 constexpr double INF_BOUND = INFTY * MIN_SCALING;   // a scaled bound beyond this is "infinite"
 
-MPMPC_HD int stage_ld(int N) { return N + 1 <= 16 ? 16 : (N + 1 <= 32 ? 32 : 64); }
+// lanes that hold the N + 1 stages of an instance: a power of two, 16 .. 64 inside a wavefront, 128 / 256 = a workgroup of
+// 2 / 4 wavefronts (horizons above 63: lane_gpu.hpp, LaneBlock)
+MPMPC_HD int stage_ld(int N) { return N + 1 <= 16 ? 16 : (N + 1 <= 32 ? 32 : (N + 1 <= 64 ? 64 : (N + 1 <= 128 ? 128 : 256))); }
 
 // ------------------------------------------------------------------------------------------
 // K1 math: the 27 fields of stage k of one instance.
@@ -267,7 +269,7 @@ inline bool free_states(const mpmpc_config& c) {
 
 // Lane split of the twisted factorisation for G lanes per instance and horizon N (shared by the
 // launcher and the emulation): the chains meet at lane C - 1.
-inline int lane_split(int G, int N) { return G == 16 ? 16 : (G == 32 ? 16 : (N + 1 <= 32 ? 16 : 32)); }
+inline int lane_split(int G, int N) { return G > 64 ? G / 2 : (G == 16 ? 16 : (G == 32 ? 16 : (N + 1 <= 32 ? 16 : 32))); }
 // Stage 0 sits on lane lane_offset of its instance, so that the two chains are equally long for any horizon:
 // lanes off .. C-1 climb through stages 0 .. C-1-off, lanes C .. descend through N .. C-off (no second chain: 0).
 MPMPC_HOST_DEVICE inline int lane_offset(int G, int C, int N) {

@@ -166,6 +166,26 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
   if (mode == 1 && k == 0 && inst < B && s.status == MPMPC_UNSOLVED) tail[1 + atomicAdd(tail, 1)] = inst;
 }
 
+// K2b: the general solve kernel for horizons above 63 - one instance per WORKGROUP of G = 128 / 256 threads (2 / 4
+// wavefronts), one lane per stage as before; the lanes of different wavefronts talk through LDS (lane_gpu.hpp: LaneBlock).
+// Same Solver code, the whole solve in one launch (mode 0), cold starts.  FQ: full weight matrices.
+template <int G, bool FQ>
+__global__ __launch_bounds__(G) void mpmpc_solve_block_kernel(mpmpc_config cfg, SolverParams st, int B, AssembleIn ain,
+                                                              double* __restrict__ z, double* __restrict__ u0,
+                                                              int* __restrict__ status, int* __restrict__ iters,
+                                                              double* __restrict__ resid, double* __restrict__ y) {
+  using L = LaneBlock<G>;
+  const int inst = blockIdx.x;
+  const int k = L::stage() - lane_offset(G, G / 2, cfg.N);
+  double fields[MPMPC_NUM_FIELDS];
+  assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
+  Solver<L, FQ> s;
+  double woff[7];
+  weight_offdiag(cfg, woff);
+  s.template run<false, true>(fields, B, inst, k, cfg.N, st, 0, 0, 0, FQ ? woff : nullptr);
+  s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y, nullptr, 0);
+}
+
 // K2r: the reduced-native solve kernel (mpmpc_reduced.hpp) - the batch path of every configuration whose time state
 // separates (the reference's own weights).  One launch assembles (K1's code, in registers), solves and stores; the ids of
 // the instances it cannot certify are appended to tail[1..] (tail[0] counts) for the general kernel in mode 2.
@@ -630,7 +650,7 @@ struct mpmpc_handle_s {
   bool y_valid = false;     // the last solve launch stored y
 };
 
-static int host_stage_ld(int N) { return N + 1 <= 16 ? 16 : (N + 1 <= 32 ? 32 : 64); }
+static int host_stage_ld(int N) { return N + 1 <= 16 ? 16 : (N + 1 <= 32 ? 32 : (N + 1 <= 64 ? 64 : (N + 1 <= 128 ? 128 : 256))); }
 
 static int observe_tail(mpmpc_handle h);
 static void swap_slots(mpmpc_handle h, int i) {
@@ -846,7 +866,7 @@ int mpmpc_create(const mpmpc_config* cfg, const mpmpc_settings* settings, mpmpc_
   if (!cfg || !out) return fail(MPMPC_E_ARG, "cfg/out is NULL");
   *out = nullptr;
   if (cfg->N < 3 || cfg->N > MPMPC_MAX_HORIZON)
-    return fail(MPMPC_E_ARG, "horizon N must satisfy 3 <= N <= 63");
+    return fail(MPMPC_E_ARG, "horizon N must satisfy 3 <= N <= " + std::to_string(MPMPC_MAX_HORIZON));
   if (cfg->max_batch < 1) return fail(MPMPC_E_ARG, "max_batch must be >= 1");
   if (!(cfg->wheelbase > 0)) return fail(MPMPC_E_ARG, "wheelbase must be > 0");
   for (int i = 0; i < 3; ++i)
@@ -936,7 +956,7 @@ int mpmpc_set_packing(mpmpc_handle h, int32_t lanes_per_instance) {
   MPMPC_SETTLE(h);
   const int g = lanes_per_instance;
   if (g != 0 && g != 16 && g != 32 && g != 64) return fail(MPMPC_E_ARG, "lanes_per_instance must be 0 (auto), 16, 32 or 64");
-  if (g != 0 && h->cfg.N + 1 > g) return fail(MPMPC_E_ARG, "lanes_per_instance must hold the N + 1 stages of an instance");
+  if (g != 0 && h->cfg.N + 1 > g) return fail(MPMPC_E_ARG, "lanes_per_instance must hold the N + 1 stages of an instance (horizons above 63 take a workgroup: only 0)");
   h->force_lanes = g;
   return MPMPC_OK;
 }
@@ -1282,6 +1302,29 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
   // Full weights (Q, R or QN with off-diagonal entries), bounds on e_psi / t or a cost on t rule the reduction out:
   // such configurations run the general kernels, one instance per wave.
   const bool fullqn = full_weights(h->cfg);
+  if (N + 1 > 64) {
+    // Horizons above 63: one instance per workgroup of 2 / 4 wavefronts, the general solver, the whole solve in one launch
+    // (no packing, no tail lists, cold starts in the closed loop too); 67 / 134 KB of dynamic LDS per workgroup.
+    if (tail_only) return MPMPC_OK;
+    h->pend = h->pend2 = false;
+    const SolverParams prm = make_params(h->st);
+#define LAUNCH_BLOCK(GG, FF)                                                                                                          \
+  do {                                                                                                                                \
+    static bool attr_set = false;                                                                                                     \
+    if (!attr_set) {                                                                                                                  \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpmpc_solve_block_kernel<GG, FF>),                                  \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LaneBlock<GG>::lds_bytes));                        \
+      attr_set = true;                                                                                                                \
+    }                                                                                                                                 \
+    hipLaunchKernelGGL((mpmpc_solve_block_kernel<GG, FF>), dim3(B), dim3(GG), LaneBlock<GG>::lds_bytes, h->stream, h->cfg, prm, B, \
+                       ain, h->z, h->u0, h->status, h->iters, h->resid, y_out);                                                       \
+  } while (0)
+    if (N + 1 <= 128) { if (fullqn) LAUNCH_BLOCK(128, true); else LAUNCH_BLOCK(128, false); }
+    else { if (fullqn) LAUNCH_BLOCK(256, true); else LAUNCH_BLOCK(256, false); }
+#undef LAUNCH_BLOCK
+    HIP_TRY(hipGetLastError());
+    return MPMPC_OK;
+  }
   const bool red = reducible(h->cfg, h->st);      // the polish may work on the (e_y, e_psi, kappa) problem
   const bool freex = !fullqn && !red && free_states(h->cfg);
   // The reduced-native kernels (mpmpc_reduced.hpp) take the batch path of every configuration they apply to - cold and

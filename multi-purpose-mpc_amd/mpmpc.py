@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libmpmpc.so")
 
 NX, NU = 3, 2
 NUM_FIELDS = 27
-MAX_HORIZON = 63
+MAX_HORIZON = 255
 
 SOLVED, SOLVED_INACCURATE = 1, 2
 MAX_ITER_REACHED, PRIMAL_INFEASIBLE, DUAL_INFEASIBLE, UNSOLVED = -2, -3, -4, -10
@@ -105,7 +105,10 @@ def make_config(N, Q, R, QN, xmin, xmax, umin, umax, ay_max, wheelbase, circular
 
 
 def stage_ld(N: int) -> int:
-    return 16 if N + 1 <= 16 else (32 if N + 1 <= 32 else 64)
+    for ld in (16, 32, 64, 128):
+        if N + 1 <= ld:
+            return ld
+    return 256
 
 
 _dp = C.POINTER(C.c_double)

@@ -1,0 +1,44 @@
+// CPU lock-step emulation of the general solve kernel for horizons above 63 (TEST INFRASTRUCTURE ONLY).
+// On the device such an instance takes a WORKGROUP of 2 / 4 wavefronts - one lane per stage, neighbours across the wavefront
+// boundaries through LDS (lane_gpu.hpp: LaneBlock<128> / LaneBlock<256>, mpmpc_solve_block_kernel); here the same lane code
+// (mpmpc_core.hpp: Solver) runs on an emulated execution group of MPMPC_EMU_W = 128 / 256 lanes.  Built twice
+// (tests/emul/Makefile: libmpmpc_emul_w128.so, libmpmpc_emul_w256.so).  Never loaded by the product.
+#include <cstring>
+#define MPMPC_TICK_BEGIN(i) ((void)0)
+#define MPMPC_TICK_END(i) ((void)0)
+#define MPMPC_TICK_COUNT(i) ((void)0)
+#include "lane_emu.hpp"
+#include "mpmpc_core.hpp"
+
+using namespace mpmpc;
+static_assert(EMU_W == 128 || EMU_W == 256, "build with -DMPMPC_EMU_W=128 or 256");
+
+template <bool FQ>
+static void solve_wide(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
+                       int* status, int* iters, double* resid, double* y) {
+  constexpr int G = EMU_W, C = EMU_W / 2;
+  using L = LaneEmu<G, C>;
+  const int ld = stage_ld(cfg->N);
+  for (int w = 0; w < B; ++w) {
+    VI inst = L::slot() + w;
+    VI k = L::stage() - lane_offset(G, C, cfg->N);
+    Solver<L, FQ> s;
+    double woff7[7];
+    weight_offdiag(*cfg, woff7);
+    typename L::real fields[MPMPC_NUM_FIELDS];
+    Solver<L, FQ>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    s.template run<false, true>(fields, B, inst, k, cfg->N, make_params(*st), 0, VI(0), VI(0), FQ ? woff7 : nullptr);
+    s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y, nullptr, ld);
+  }
+}
+
+// the kernel the launcher picks for a horizon above 63: the general solver, one instance per workgroup; full weights (FQ)
+// where a weight matrix has off-diagonal entries.  -1: the horizon does not belong to this width.
+extern "C" int emuw_width() { return EMU_W; }
+extern "C" int emuw_solve(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
+                          int* status, int* iters, double* resid, double* y) {
+  if (stage_ld(cfg->N) != EMU_W) return -1;
+  if (full_weights(*cfg)) solve_wide<true>(cfg, st, qp, B, z, u0, status, iters, resid, y);
+  else solve_wide<false>(cfg, st, qp, B, z, u0, status, iters, resid, y);
+  return 0;
+}

@@ -209,8 +209,16 @@ class Emul:
 
     def __init__(self):
         so = os.path.join(ROOT, "tests", "_build", "libmpmpc_emul.so")
-        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emul")], check=True)
+        subprocess.run(["make", "-s", "-j4", "-C", os.path.join(ROOT, "tests", "emul")], check=True)
         self.lib = C.CDLL(so)
+        self._wide = {}
+
+    def wide(self, width):
+        """the general solver on an emulated WORKGROUP of 128 / 256 lanes (horizons 64 .. 255: tests/emul/emul_wide.cpp)"""
+        if width not in self._wide:
+            self._wide[width] = C.CDLL(os.path.join(ROOT, "tests", "_build", "libmpmpc_emul_w%d.so" % width))
+            assert self._wide[width].emuw_width() == width
+        return self._wide[width]
 
     def assemble(self, cfg, track, inputs, use_table=False, obstacles=False):
         wp, x0, cc, lb, ub = inputs
@@ -239,6 +247,12 @@ class Emul:
         st, it, rs = np.zeros(B, np.int32), np.zeros((B, 2), np.int32), np.zeros((B, 2))
         y = np.zeros((B, m)) if want_y else None
         qp = np.ascontiguousarray(qp)
+        if N + 1 > 64:        # one instance per workgroup of 2 / 4 wavefronts on the device: the wide emulation
+            yy = y if want_y else np.zeros((B, m))
+            rc = self.wide(mpmpc.stage_ld(N)).emuw_solve(C.byref(cfg), C.byref(settings), _d(qp), C.c_int(B), _d(z), _d(u0), _i(st), _i(it),
+                                                         _d(rs), _d(yy))
+            assert rc == 0
+            return mpmpc.Solution(z, u0, st, it, rs, y)
         rc = self.lib.emu_solve(C.byref(cfg), C.byref(settings), C.c_int(G), _d(qp), C.c_int(B), _d(z), _d(u0),
                                 _i(st), _i(it), _d(rs), _d(y))
         assert rc == 0
@@ -286,6 +300,37 @@ class Emul:
                                      _i(guess), _d(z), _d(u0), _i(st), _i(it), _d(rs), _d(y), _i(act))
         assert rc == 0
         return mpmpc.Solution(z, u0, st, it, rs, y), act
+
+
+_WIDE_TRACKS = {}
+
+
+def wide_track(track, emu, n_cols):
+    """The golden track with corridor tables of n_cols > 50 columns (horizons above 50: golden G3 holds 50), built by the CPU
+    emulation of the device's corridor kernels from golden G1's grids - bit-identical to G3 on the first 50 columns (checked
+    here; tests/test_corridor.py pins the emulation to G3 for every start waypoint)."""
+    import dataclasses
+    key = (id(track), n_cols)
+    if key in _WIDE_TRACKS:
+        return _WIDE_TRACKS[key]
+    g1 = np.load(os.path.join(ROOT, "tests", "golden", "g1_path_sim_track.npz"))
+    g3 = np.load(os.path.join(ROOT, "tests", "golden", "g3_corridor.npz"))
+    h, w = g1["grid_shape"]
+    sm = float(g3["safety_margin"][0])
+    n = g1["x"].size
+    arrs = [np.ascontiguousarray(g1[k], float) for k in ("x", "y", "psi", "ds_next")]
+    bu, bl = np.ascontiguousarray(g1["border_ub"], float), np.ascontiguousarray(g1["border_lb"], float)
+    out = {}
+    for name in ("free", "obstacles"):
+        grid = np.ascontiguousarray(np.unpackbits(g1["grid_" + name])[:h * w].reshape(h, w).astype(np.int8))
+        ub, lb = np.zeros((n, n_cols)), np.zeros((n, n_cols))
+        bad = emu.lib.emu_corridor(C.c_int(grid.shape[0]), C.c_int(grid.shape[1]), grid.ctypes.data_as(C.POINTER(C.c_int8)),
+                                   C.c_double(-1.0), C.c_double(-2.0), C.c_double(0.005), C.c_int(n), *[_d(a) for a in arrs], C.c_int(1),
+                                   _d(bu), _d(bl), C.c_int(n_cols), C.c_double(2 * sm), C.c_double(sm), _d(ub), _d(lb), None)
+        assert bad == 0 and np.array_equal(ub[:, :50], g3["ub_" + name]) and np.array_equal(lb[:, :50], g3["lb_" + name])
+        out["ub_" + name], out["lb_" + name] = ub, lb
+    _WIDE_TRACKS[key] = dataclasses.replace(track, **out)
+    return _WIDE_TRACKS[key]
 
 
 def emu_speed_profile(li, kappa, limits, eps=1e-12, device=0):

@@ -1,0 +1,185 @@
+"""Horizons above 63 (the reference has no limit, src/MPC.py:73-74).  Up to N = 63 an instance is a part
+of / one 64-lane wavefront; beyond that it takes a WORKGROUP of 2 / 4 wavefronts - still one lane per stage, the lanes of
+different wavefronts talk through LDS (csrc/lane_gpu.hpp: LaneBlock, mpmpc_solve_block_kernel).  Same lane code: the CPU suite
+runs it on an emulated group of 128 / 256 lanes (tests/emul/emul_wide.cpp) against the C oracle and the plain-numpy KKT test;
+the GPU suite runs libmpmpc.so against that emulation, the C oracle and the certificates."""
+import numpy as np
+import pytest
+
+import mpmpc
+import mpmpc_testlib as T
+import oracle_c as OC
+import osqp_np as O
+import scenarios
+
+LONG = [(64, 2), (64, 4), (100, 4), (127, 2), (128, 4), (200, 2), (255, 4)]
+
+
+def _oracle(track, sc, weights, xmin=scenarios.XMIN, xmax=scenarios.XMAX, **st):
+    ocfg = OC.mpc_cfg(sc.N, weights, scenarios.UMIN, scenarios.UMAX, xmin, xmax, 4.0, 0.12)
+    return OC.mpc_batch(ocfg, OC.settings(**st), track.kappa, track.v_ref, track.ds_next, sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+
+
+@pytest.mark.parametrize("N,cfgid", LONG)
+def test_long_horizons_in_the_emulation_against_the_c_oracle(N, cfgid, emu, track):
+    """K1 + the general solver on an emulated workgroup: statuses and ADMM counts of the C oracle, controls to 1e-6 (measured
+    1e-13), every solved instance through the vectorised plain-numpy KKT test on K1's own output, Farkas rays for the rest."""
+    B = 10
+    tw = T.wide_track(track, emu, N)
+    sc = scenarios.make(cfgid, tw, B=B, N=N)
+    cfg = T.stock_config(N, sc.weights)
+    assert mpmpc.stage_ld(N) == (128 if N + 1 <= 128 else 256) if N + 1 > 64 else True
+    qp = emu.assemble(cfg, tw, (sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub))
+    st = mpmpc.default_settings(phase1_accept=0)
+    sol = emu.solve(cfg, st, qp)
+    ref = _oracle(track, sc, scenarios.WEIGHTS[sc.weights])
+    assert np.array_equal(sol.status, ref["status"]) and np.array_equal(sol.iters[:, 0], ref["iters"][:, 0])
+    ok = sol.status == 1
+    assert ok.sum() >= B // 2 and np.max(np.abs(sol.u0[ok] - ref["u0"][ok])) <= 1e-6
+    e = np.abs(sol.z[ok] - ref["z"][ok])
+    e[:, -1] = 0.0                                   # the cost-free kappa_{N-1}
+    e[:, 3 * N + 1] = 0.0                            # ... and e_psi,N it drives
+    assert e.max() <= 1e-6
+    prim, stat, comp = T.kkt_batch(qp[:, ok, :], N, sol.z[ok], sol.y[ok])
+    assert max(prim.max(), stat.max(), comp.max()) <= 1e-8
+    if (~ok).any():
+        good, _, _ = T.farkas_batch(qp[:, ~ok, :], N, sol.y[~ok])
+        assert good.all()
+
+
+@pytest.mark.parametrize("N", [64, 130])
+def test_long_horizons_other_problem_classes_in_the_emulation(N, emu, track):
+    """What else the general kernel serves, at a horizon that needs a workgroup: full weight matrices (dense stage blocks),
+    the time-optimal weights, bounded e_psi / t, and the restated OSQP alone (stock settings) - against the dense / C oracle."""
+    from test_emul_parity import full_weight_config
+    tw = T.wide_track(track, emu, N)
+    sc = scenarios.make(4, tw, B=4, N=N)
+    inp = (sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    # full weights
+    cfg = full_weight_config(N, "full")
+    qp = emu.assemble(cfg, tw, inp)
+    sol = emu.solve(cfg, mpmpc.default_settings(), qp)
+    for i in range(sc.B):
+        P, q, A, l, u = T.qp_to_dense_full(qp[:, i, :], N, cfg)
+        x, y, info = OC.solve(P, q, A, l, u)
+        assert sol.status[i] == info.status or (sol.status[i] == 2 and info.status == -3)
+        if info.status == 1 and info.polished == 1:
+            e = np.abs(sol.z[i] - x)
+            e[-1] = 0.0
+            assert e.max() <= 1e-6 and O.kkt_certificate(P, q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8)
+    # time-optimal weights, and a box on e_psi and t
+    xmin, xmax = np.array([-np.inf, -0.6, -np.inf]), np.array([np.inf, 0.6, 0.2 * N])
+    for weights, lo, hi in (("time_optimal", scenarios.XMIN, scenarios.XMAX), ("stock", xmin, xmax)):
+        Q, R, QN = scenarios.WEIGHTS[weights]
+        cfg = mpmpc.make_config(N, Q, R, QN, lo, hi, scenarios.UMIN, scenarios.UMAX, 4.0, 0.12)
+        sol = emu.solve(cfg, mpmpc.default_settings(phase1_accept=0), emu.assemble(cfg, tw, inp))
+        ref = _oracle(track, sc, (Q, R, QN), lo, hi)
+        assert np.array_equal(sol.status, ref["status"])
+        ok = sol.status == 1
+        assert ok.any() and np.max(np.abs(sol.u0[ok] - ref["u0"][ok])) <= 1e-6
+    # the restated OSQP alone: its verdicts and iteration counts
+    cfg = T.stock_config(N)
+    sol = emu.solve(cfg, mpmpc.stock_settings(), emu.assemble(cfg, tw, inp))
+    ref = _oracle(track, sc, scenarios.WEIGHTS["stock"], polish=0, early_polish=0, phase1=0)
+    assert np.array_equal(sol.status, ref["status"]) and np.array_equal(sol.iters[:, 0], ref["iters"][:, 0])
+    ok = sol.status == 1
+    assert np.max(np.abs(sol.z[ok] - ref["z"][ok])) <= 1e-6 if ok.any() else True
+
+
+def test_horizon_limits_are_checked():
+    with pytest.raises(ValueError):
+        T.stock_config(256)
+    with pytest.raises(ValueError):
+        T.stock_config(2)
+    assert mpmpc.MAX_HORIZON == 255 and [mpmpc.stage_ld(n) for n in (15, 16, 31, 63, 64, 127, 128, 255)] == [16, 32, 32, 64, 128, 128, 256, 256]
+
+
+# ------------------------------------------------------------------------------------------------------------------ device
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,cfgid", LONG)
+def test_long_horizons_on_device(N, cfgid, track, emu):
+    """libmpmpc.so at horizons 64 .. 255: K1 bit for bit with the emulation, the workgroup kernel with its emulation (statuses,
+    iteration counts, z to 1e-9), the whole batch against the C oracle (statuses, controls to 1e-6) and through the KKT /
+    Farkas tests with plain numpy."""
+    B = 96
+    tw = T.wide_track(track, emu, N)
+    sc = scenarios.make(cfgid, tw, B=B, N=N)
+    cfg = T.stock_config(N, sc.weights, max_batch=B)
+    st = mpmpc.default_settings(phase1_accept=0)
+    h = mpmpc.Handle(cfg, st)
+    h.set_path(track.kappa, track.v_ref, track.ds_next)
+    inp = (sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    qp = h.assemble(*inp)
+    sol = h.solve(*inp, want_y=True)
+    # ... the resident path and the corridor table instead of rows give the same bits
+    h.set_corridor(tw.ub_obstacles if sc.obstacles else tw.ub_free, tw.lb_obstacles if sc.obstacles else tw.lb_free)
+    h.upload(sc.wp_id, sc.x0, sc.cc_prev)
+    h.solve_resident(B)
+    sol2 = h.download(B, want_y=True)
+    h.close()
+    assert np.array_equal(sol.z, sol2.z) and np.array_equal(sol.status, sol2.status) and np.array_equal(sol.y, sol2.y)
+    qp_e = emu.assemble(cfg, tw, inp)
+    cap = 15                                   # the speed cap goes through tan(): device libm vs the host's, a few ulp
+    other = np.delete(np.arange(mpmpc.NUM_FIELDS), cap)
+    assert np.array_equal(qp[other][:, :, :N + 1], qp_e[other][:, :, :N + 1])
+    assert np.max(np.abs(qp[cap, :, :N + 1] - qp_e[cap, :, :N + 1])) <= 8 * np.finfo(float).eps
+    nn = 12
+    ref = emu.solve(cfg, st, np.ascontiguousarray(qp[:, :nn, :]))
+    assert np.array_equal(sol.status[:nn], ref.status) and np.array_equal(sol.iters[:nn], ref.iters)
+    okr = ref.status == 1
+    assert np.max(np.abs(sol.z[:nn][okr] - ref.z[okr])) <= 1e-9
+    orc = _oracle(track, sc, scenarios.WEIGHTS[sc.weights])
+    assert np.array_equal(sol.status, orc["status"])
+    ok = sol.status == 1
+    assert ok.mean() > 0.5 and np.max(np.abs(sol.u0[ok] - orc["u0"][ok])) <= 1e-6
+    prim, stat, comp = T.kkt_batch(qp[:, ok, :], N, sol.z[ok], sol.y[ok])
+    assert max(prim.max(), stat.max(), comp.max()) <= 1e-8
+    if (~ok).any():
+        good, _, _ = T.farkas_batch(qp[:, ~ok, :], N, sol.y[~ok])
+        assert good.all()
+
+
+@pytest.mark.gpu
+def test_long_horizon_full_weights_and_host_class_on_device(track, emu):
+    """Full weight matrices at N = 100 through the workgroup kernel (device = emulation, KKT on the dense data), and the
+    reference's own loop (MPC.get_control) at N = 80 against the emulation-backed controller, step by step."""
+    from test_emul_parity import full_weight_config
+    import test_host_mpc as H
+    from spatial_bicycle_models import TemporalState
+    N, B = 100, 48
+    tw = T.wide_track(track, emu, N)
+    sc = scenarios.make(4, tw, B=B, N=N)
+    cfg = full_weight_config(N, "full", max_batch=B)
+    h = mpmpc.Handle(cfg)
+    h.set_path(track.kappa, track.v_ref, track.ds_next)
+    inp = (sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    qp = h.assemble(*inp)
+    sol = h.solve(*inp, want_y=True)
+    h.close()
+    ref = emu.solve(cfg, mpmpc.default_settings(), np.ascontiguousarray(qp[:, :8, :]))
+    assert np.array_equal(sol.status[:8], ref.status) and np.max(np.abs(sol.z[:8][ref.status == 1] - ref.z[ref.status == 1])) <= 1e-9
+    for i in np.flatnonzero(sol.status == 1)[:10]:
+        P, q, A, l, u = T.qp_to_dense_full(qp[:, i, :], N, cfg)
+        assert O.kkt_certificate(P, q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8)
+    # the host class: ten steps of the reference's loop at N = 80, the device against the emulation-backed controller
+    g = np.load(H.G + "/g6_closed_loop_N30.npz")
+    us = []
+    for backend in (None, "emu"):
+        m, rp, car = H.build_world()
+        from scipy import sparse
+        Q, R, QN = sparse.diags([1.0, 0.0, 0.0]), sparse.diags([0.5, 0.0]), sparse.diags([1.0, 0.0, 0.0])
+        ic = {'umin': np.array([0.0, -np.tan(0.66) / car.length]), 'umax': np.array([1.0, np.tan(0.66) / car.length])}
+        scn = {'xmin': np.array([-np.inf] * 3), 'xmax': np.array([np.inf] * 3)}
+        from MPC import MPC
+        be = T.EmuBackend(T.stock_config(80), mpmpc.default_settings()) if backend == "emu" else None
+        mpc = MPC(car, 80, Q, R, QN, scn, ic, 4.0, backend=be)
+        out = []
+        for t in range(0, 40, 4):
+            car.s = float(g["s"][t])
+            car.temporal_state = TemporalState(*g["pose"][t])
+            mpc.current_control = np.zeros(160)
+            mpc.infeasibility_counter = 0
+            out.append((mpc.get_control(), mpc.last_status))
+        us.append(out)
+    for (u_d, s_d), (u_e, s_e) in zip(*us):
+        assert s_d == s_e and np.max(np.abs(u_d - u_e)) <= 1e-9
