@@ -141,11 +141,14 @@ typedef struct {
                             least violation, the polish solves that problem, and the plan comes back as MPMPC_SOLVED_INACCURATE
                             with the violation in resid[0] (a usable status: no fallback step).  0: every proven infeasibility
                             is reported as MPMPC_PRIMAL_INFEASIBLE however small the margin (batch sweeps that want the verdict).
-                            The threshold is a PROXY of OSQP's test, not the test: max(|Ax|, |z|) is taken as the largest
-                            finite box bound (or entry of the least-violation point) of the instance, which stands for the
-                            iterate stock OSQP would stop at; a borderline instance can therefore take the other branch than
-                            stock OSQP would.  Validated on the reference's own laps (golden G6s); mpmpc.stock_settings() runs
-                            the restated OSQP itself. */
+                            The test is a MODEL of OSQP's, not a run of it: the least-violation point is the limit of OSQP's
+                            ADMM iteration (the minimiser of the sum of the squared scaled violations, dynamics rows weighted a
+                            thousand times the box rows: Solver::phase1), max(|Ax|, |z|) is taken at that point; what it
+                            cannot know is an instance OSQP abandons at max_iter before either of its tests passes (it then
+                            returns its iterate: "solved inaccurate"), or one within 0.1 % of the threshold, where OSQP stops
+                            an iterate short of its limit.  Validated on the reference's own laps (golden G6s) and
+                            on BASELINE's obstacle batches (tests, bench line); mpmpc.stock_settings() runs the restated OSQP
+                            itself. */
   int32_t native;        /* 1 (default): where `reduce` applies and the settings are the defaults of the early attempt
                             (early_polish = 1, ipm_start_mu > 0) the batch launches run the REDUCED-NATIVE kernels: a lane
                             never holds the 3-state problem - v in closed form at load time, own Ruiz pass / start / interior
@@ -169,6 +172,11 @@ typedef struct {
                             11.08 instead of 11.43 interior-point iterations from x = 0 and saves the iterate's 11 us per
                             wave.  The reduced-native kernels always start from x = 0.  iters[.][0] = 1 marks the early
                             attempt either way. */
+  double phase1_band;    /* phase1_accept: phase 1 leaves at the first iterate whose multipliers are a valid Farkas ray only while
+                            that iterate violates a bound by more than phase1_band times OSQP's primal tolerance (eps_abs +
+                            eps_rel x the largest finite bound); inside the band it runs to its converged optimum, because the
+                            violation of THAT point decides whether the reference's OSQP call would have returned a plan, and
+                            it is up to 2.4 times smaller than the early iterate's (measured on configs 4 / 5).  Default 4. */
 } mpmpc_settings;
 
 const char* mpmpc_version(void);

@@ -44,6 +44,12 @@ enum Field { F_DS = 0, F_A10 = 1, F_A20 = 2, F_B20 = 3, F_BEQ = 4, F_LO = 7, F_H
 constexpr double INFTY = 1e30, MIN_SCALING = 1e-4, MAX_SCALING = 1e4;
 constexpr double RHO_MIN = 1e-6, RHO_MAX = 1e6, RHO_TOL = 1e-4, RHO_EQ_FACTOR = 1e3;
 constexpr double INF_BOUND = INFTY * MIN_SCALING;   // a scaled bound beyond this is "infinite"
+// The dynamics rows of phase 1 are as soft as OSQP's: its ADMM iteration weights the violation of an equality row
+// RHO_EQ_FACTOR = 1000 times that of an inequality row, so its limit point on an infeasible QP trades a little dynamics
+// violation (~1e-5) for 0.5 % less box violation - enough to decide instances within that of OSQP's threshold.  Phase 1
+// minimises  sum_boxes (scaled violation)^2 + RHO_EQ_FACTOR sum_dynamics (scaled residual)^2:  the equality block of its KKT
+// systems carries -1 / RHO_EQ_FACTOR, and its least-violation point leaves the dynamics rows by nu / RHO_EQ_FACTOR.
+constexpr double P1_EQ_SOFT = 1.0 / RHO_EQ_FACTOR;
 
 // lanes that hold the N + 1 stages of an instance: a power of two, 16 .. 64 inside a wavefront, 128 / 256 = a workgroup of
 // 2 / 4 wavefronts (horizons above 63: lane_gpu.hpp, LaneBlock)
@@ -325,6 +331,9 @@ struct Solver {
   Mk p1_converged;       // phase 1 ended at its converged optimum (not at an earlier iterate that already passed the ray test)
   Mk p1_marginal;        // infeasible by less than OSQP's own primal tolerance: solved on the boxes relaxed by that much (phase1_accept)
   R p1_viol;             // ... and the violation (unscaled) the plan is allowed
+  R p1_band;             // phase 1 may stop at the first iterate whose ray passes the Farkas test only while that iterate's
+                         // violation exceeds this (unscaled); below it the iteration runs to its converged optimum, whose
+                         // violation decides "marginal" (phase1_accept).  0: stop at the first ray.
   R pod[3], hod[3];      // FQ: off-diagonals (01, 02, 12) of the lane's state cost block and of its inv(H) state block
   R rod, hud;            // FQ: off-diagonal (v, kappa) of the lane's input cost block and of its inv(H) input block
   R podS[3];             // FQ, split layout of the interior point: pod on the state lanes, (rod of the stage, 0, 0) on the
@@ -1896,10 +1905,12 @@ struct Solver {
   // pp, qq, vm: cost diagonal, cost vector and validity masks of the lane's entries in the layout S
   //
   // SOFT = true is PHASE 1 (see phase1()): every box entry j with a finite side reads  lo <= x_j + w_j <= hi  with
-  // the cost 1/2 w_j^2 and nothing else in the cost (pp, qq are not read).  Stationarity in w gives w = zl - zu, so w
-  // is never stored: it shifts the slack residuals, and eliminating its Newton step  dw = k ((cu - cl) - th dx),
-  // k = 1 / (1 + th),  th = zl / sl + zu / su,  leaves the hard problem's reduced system with  k th = 1 - k  in place
-  // of th on the diagonal and  k (cu - cl)  in place of  cu - cl  on the right-hand side.  Pinned entries stay hard.
+  // the cost 1/2 om_j w_j^2 and nothing else in the cost (qq is not read; pp carries the WEIGHTS om_j > 0 - phase1() passes
+  // the squares of the box rows' scaled entries, which makes the cost OSQP's own metric of a violation, see there).
+  // Stationarity in w gives om w = zl - zu, so w is never stored: it shifts the slack residuals, and eliminating its
+  // Newton step  dw = ((cu - cl) - th dx) / (om + th),  th = zl / sl + zu / su,  leaves the hard problem's reduced system
+  // with  k th = om (1 - k),  k = om / (om + th),  in place of th on the diagonal and  k (cu - cl)  in place of  cu - cl
+  // on the right-hand side.  Pinned entries stay hard.
   // The loop also ends for an instance as soon as its multipliers pass the Farkas test in the scaled problem
   // (|A'y| <= eps |y|, support <= -eps |y|): what is asked of phase 1 is a ray, not a converged point.
   template <int LAY, bool SOFT = false>
@@ -1923,10 +1934,15 @@ struct Solver {
     const R inb = rcp_(max_(L::gsum(cnt), one));      // (its reciprocal once: the complementarity measures below are products)
     I stall(0);
     R mu_min(1e300);
+    [[maybe_unused]] R iom[E];        // phase 1: reciprocals of the weights
+    if constexpr (SOFT) {
+      MPMPC_UNROLL
+      for (int j = 0; j < E; ++j) iom[j] = boxed(j) ? rcp_(pp[j]) : one;
+    }
     for (int it = 0; it <= st.ipm_max_iter; ++it) {
       // ---- residuals (the slack residuals rl, ru, rpin are cheap functions of the iterate: they are
       //      re-evaluated where needed instead of being carried across the sweeps)
-      auto w_of = [&](int j) { return SOFT ? s.zl[j] - s.zu[j] : zero; };
+      auto w_of = [&](int j) { return SOFT ? (s.zl[j] - s.zu[j]) * iom[j] : zero; };
       auto rl_of = [&](int j) { return sel(bx.Lm[j], s.x[j] + w_of(j) - bx.lo[j] - s.sl[j], zero); };
       auto ru_of = [&](int j) { return sel(bx.Um[j], bx.hi[j] - s.x[j] - w_of(j) - s.su[j], zero); };
       auto rpin_of = [&](int j) { return sel(bx.pin[j], s.x[j] - bx.lo[j], zero); };
@@ -1944,7 +1960,11 @@ struct Solver {
       [[maybe_unused]] R rk_dot(0.0);                          // rank-one part of P x: rk_c (rk_c' x)   (LAY_RED4)
       if constexpr (LAY == LAY_RED4 && !SOFT) rk_dot = rank_one_dot(s.x);
       MPMPC_UNROLL
-      for (int i = 0; i < NQ; ++i) { rp[i] = rp[i] - leq[i]; res = max_(res, sel(vx, abs_(rp[i]), zero)); }
+      for (int i = 0; i < NQ; ++i) {
+        rp[i] = rp[i] - leq[i];
+        if constexpr (SOFT) rp[i] = fma_(R(-P1_EQ_SOFT), s.nu[i], rp[i]);          // (soft dynamics rows: see P1_EQ_SOFT)
+        res = max_(res, sel(vx, abs_(rp[i]), zero));
+      }
       MPMPC_UNROLL
       for (int j = 0; j < E; ++j) {
         if constexpr (SOFT) rd[j] = At[j] - s.zl[j] + s.zu[j] + s.pi[j];
@@ -1980,7 +2000,19 @@ struct Solver {
         }
         ny = L::gmax(ny); na = L::gmax(na); sup = L::gsum(sup);
         const R thr = R(st.phase1_eps) * ny;
-        ok = ok | ((ny > R(st.phase1_eps)) & (na < thr) & (sup < -thr));
+        Mk ray = (ny > R(st.phase1_eps)) & (na < thr) & (sup < -thr);
+        if (st.phase1_accept) {
+          // A ray settles "infeasible" - but whether the instance is MARGINALLY so is decided by the violation of the
+          // converged least-violation point, which can be less than half of an early iterate's: the loop leaves at a ray only
+          // while the iterate's violation (|w| in unscaled units; qq carries D / om in phase 1) is beyond the band in which
+          // that question is open
+          R wv(0.0);
+          MPMPC_UNROLL
+          for (int j = 0; j < E; ++j)
+            if (boxed(j)) wv = max_(wv, sel(vm[j], abs_(s.zl[j] - s.zu[j]) * qq[j], zero));
+          ray = ray & (L::gmax(wv) > p1_band);
+        }
+        ok = ok | ray;
       }
       conv = conv | (active & ok);
       active = active & !ok;
@@ -2010,8 +2042,8 @@ struct Solver {
       auto H_of = [&](int j) {
         if (!boxed(j)) return SOFT ? reg : pp[j] + reg;
         if constexpr (SOFT) {
-          kap[j] = rcp_(one + sel(bx.Lm[j], s.zl[j] * isl[j], zero) + sel(bx.Um[j], s.zu[j] * isu[j], zero));
-          return (reg + one) - kap[j] + sel(bx.pin[j], ireg, zero);          // k th = 1 - k
+          kap[j] = rcp_(fma_(sel(bx.Lm[j], s.zl[j] * isl[j], zero) + sel(bx.Um[j], s.zu[j] * isu[j], zero), iom[j], one));
+          return fma_(-pp[j], kap[j], reg + pp[j]) + sel(bx.pin[j], ireg, zero);          // k th = om (1 - k)
         } else {
           return pp[j] + reg + sel(bx.Lm[j], s.zl[j] * isl[j], zero) + sel(bx.Um[j], s.zu[j] * isu[j], zero) +
                  sel(bx.pin[j], ireg, zero);
@@ -2021,7 +2053,7 @@ struct Solver {
       MPMPC_UNROLL
       for (int j = 0; j < E; ++j) { const R Hj = H_of(j); if constexpr (FQ) Hd[j] = Hj; h[j] = rcp_(Hj); }
       dense_blocks<LAY, !SOFT>(Hd, h);
-      factor_t<LAY>(h, reg);
+      factor_t<LAY>(h, SOFT ? reg + R(P1_EQ_SOFT) : reg);
       MPMPC_TICK_END(11);
       // ---- predictor and corrector share the factorisation.  (No iterative refinement of the directions: over
       //      thousands of instances of every configuration it changed neither an iteration count nor a status -
@@ -2061,7 +2093,7 @@ struct Solver {
           MPMPC_UNROLL
           for (int j = 0; j < E; ++j) r1[j] = rhs[j] - fma_(rcp_(h[j]) - reg, dx[j], Atd[j]);
           MPMPC_UNROLL
-          for (int i = 0; i < NQ; ++i) r2[i] = nreq[i] - Ad[i];
+          for (int i = 0; i < NQ; ++i) r2[i] = fma_(R(P1_EQ_SOFT), dnu[i], nreq[i] - Ad[i]);
           kkt_solve_t<LAY>(r1, r2, ddx, ddn);
           MPMPC_UNROLL
           for (int j = 0; j < E; ++j) dx[j] = dx[j] + sel(vm[j], ddx[j], zero);
@@ -2074,8 +2106,8 @@ struct Solver {
         MPMPC_UNROLL
         for (int j = 0; j < E; ++j) {
           if (!boxed(j)) continue;
-          R ex = dx[j];                     // step of x + w:  dx + k ((cu - cl) - th dx) = k (dx + cu - cl)
-          if constexpr (SOFT) ex = kap[j] * (dx[j] + cul[j]);
+          R ex = dx[j];                     // step of x + w:  dx + ((cu - cl) - th dx) / (om + th) = k (dx + (cu - cl) / om)
+          if constexpr (SOFT) ex = kap[j] * fma_(cul[j], iom[j], dx[j]);
           dsl[j] = sel(bx.Lm[j], ex + rl_of(j), zero);
           dsu[j] = sel(bx.Um[j], -ex + ru_of(j), zero);
           dzl[j] = sel(bx.Lm[j], -fma_(s.zl[j], dsl[j], rcl[j]) * isl[j], zero);
@@ -2641,6 +2673,37 @@ struct Solver {
     Mk vm[E];
     problem_in_layout<LAY>(bx, bi, pp, qq, vm);
     iterate_to_layout<LAY>(s, si);
+    {
+      // THE METRIC of the least violation (round 5).  What decides whether the reference's OSQP call returns a plan for an
+      // infeasible QP is the point its ADMM iteration converges to: the minimiser of  sum_r rho_r (scaled violation of row r)^2
+      // (rho on the box rows, a thousand times that on the dynamics rows: practically hard), which OSQP then puts to its
+      // primal test  |Ax - z|_inf < eps_abs + eps_rel max(|Ax|, |z|).  Phase 1 minimises that same sum over the box rows: the
+      // scaled violation of the box row of entry j is  g_j w_j  (g = the row's scaled entry, w the violation of the scaled
+      // variable), hence the weights  om_j = g_j^2.  (Rounds 2 - 4 used om = 1 - unit weight on the violation of the scaled
+      // VARIABLE and left at the first iterate with a valid ray; on config 4 that took the other branch than restated stock
+      // OSQP on 28 of 8 192 instances, this on 5 - the five OSQP abandons at max_iter: profiles/r5/branch_agreement.txt.
+      // More Ruiz passes before phase 1 - OSQP's row scalings after ten passes instead of the early attempt's one - were tried
+      // and changed no verdict on configs 4 and 5.)
+      R om5[5], omL[E];
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) om5[j] = g[j] * g[j];
+      to_lay<LAY>(om5, omL);
+      MPMPC_UNROLL
+      for (int e = 0; e < E; ++e) pp[e] = sel(omL[e] > zero, omL[e], one);
+      // ... and what turns the iterate's w = (zl - zu) / om into an unscaled violation: D / om (read in place of the cost vector)
+      R dL[E];
+      to_lay<LAY>(D, dL);
+      MPMPC_UNROLL
+      for (int e = 0; e < E; ++e) qq[e] = dL[e] / pp[e];
+      // the band below which "marginal" is an open question: phase1_band times OSQP's primal tolerance at the largest finite bound
+      R nb(0.0);
+      MPMPC_UNROLL
+      for (int j = 0; j < 5; ++j) {
+        const R lo0 = lo_raw(j), hi0 = hi_raw(j);
+        nb = max_(nb, sel(valid[j], max_(sel(lo0 > R(-INF_BOUND), abs_(lo0), zero), sel(hi0 < R(INF_BOUND), abs_(hi0), zero)), zero));
+      }
+      p1_band = st.phase1_accept ? R(st.phase1_band) * fma_(R(st.eps_rel), L::gmax(nb), R(st.eps_abs)) : zero;
+    }
     p1_converged = L::mfalse();
     stash();
     // phase 1 has no use for the cost: it waits in cold storage as well (slots COLD_COST ..)

@@ -708,6 +708,7 @@ static int check_settings(const mpmpc_settings* s) {
   if (!(s->native_ipm_tol > 0)) return fail(MPMPC_E_ARG, "need native_ipm_tol > 0");
   if (s->early_start != 0 && s->early_start != 1) return fail(MPMPC_E_ARG, "early_start must be 0 or 1");
   if (s->phase1_accept != 0 && s->phase1_accept != 1) return fail(MPMPC_E_ARG, "phase1_accept must be 0 or 1");
+  if (!(s->phase1_band >= 0)) return fail(MPMPC_E_ARG, "phase1_band must be >= 0");
   if (!(s->ipm_start_dual >= 0)) return fail(MPMPC_E_ARG, "need ipm_start_dual >= 0");
   if (!(s->ipm_start_mu >= 0) || !(s->ipm_start_slack > 0)) return fail(MPMPC_E_ARG, "need ipm_start_mu >= 0, ipm_start_slack > 0");
   if (!(s->as_add_fraction >= 0) || !(s->as_add_fraction <= 1)) return fail(MPMPC_E_ARG, "need 0 <= as_add_fraction <= 1");
@@ -765,6 +766,7 @@ void mpmpc_default_settings(mpmpc_settings* s) {
   s->native = 1;
   s->native_ipm_tol = 1e-7;
   s->early_start = 0;
+  s->phase1_band = 4.0;
 }
 
 int32_t mpmpc_stage_ld(int32_t N) { return host_stage_ld(N); }

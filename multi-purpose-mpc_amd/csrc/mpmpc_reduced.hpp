@@ -257,11 +257,14 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
   // wait in LDS and are re-read where they are used (~40 LDS reads and 5 writes per iteration, 2 % of its instructions);
   // across a factorisation or a KKT solve a lane holds the iterate, the slack reciprocals and the complementarity
   // targets - nothing else.  Entry 1 (e_psi) is never boxed (reducible()).
-  // SOFT = true: phase 1 (Solver::ipm<LAY, true>: every boxed entry reads lo <= x + w <= hi with the cost 1/2 w^2 and nothing
-  // else in the cost; w = zl - zu is never stored; the loop also ends at the first iterate whose multipliers pass the Farkas
-  // test).  Same operations in the same order as the general routine; K_PP / K_QQ are not read then.
+  // SOFT = true: phase 1 (Solver::ipm<LAY, true>: every boxed entry reads lo <= x + w <= hi with the cost 1/2 om w^2 and nothing
+  // else in the cost; om w = zl - zu is never stored; the loop also ends at the first iterate whose multipliers pass the Farkas
+  // test).  The weights om = g^2 - OSQP's metric of a violation, Solver::phase1 - are formed from the box-row scalings in the
+  // slots C_G where they are used.  Same operations in the same order as the general routine; K_PP / K_QQ are not read then.
+  // band_slot (SOFT, phase1_accept): cold slot of the violation beyond which the loop may leave at the first valid ray
+  // (Solver::p1_band), -1: leave at any
   template <bool SOFT = false>
-  MPMPC_HD Mk ipm3(const Box3& bx, typename S::template IpmT<LAY_RED>& s, const SolverParams& st, double tol, const Mk& run) {
+  MPMPC_HD Mk ipm3(const Box3& bx, typename S::template IpmT<LAY_RED>& s, const SolverParams& st, double tol, const Mk& run, int band_slot = -1) {
     const R reg(st.ipm_reg), ireg(st.inv_ipm_reg), one(1.0), zero(0.0);
     constexpr int JB[2] = {0, 2};                       // the boxed entries: e_y, kappa
     Mk active = run, conv = L::mfalse();
@@ -280,7 +283,8 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
     // that eliminate the slack steps - a zero in place of its slack reciprocal (isl / isu below): its multiplier step is then
     // exactly zero whatever its slack residual is, and that residual (finite: the clipped infinities are 1e30) needs no mask
     // except where it would enter a norm.  The iterates are bit for bit those of the fully masked form (Solver::ipm<LAY_RED>).
-    auto w_of = [&](int j) { return SOFT ? s.zl[j] - s.zu[j] : zero; };
+    auto iom_of = [&](int j) { const R gj = L::cold_get(C_G + j); return rcp_(gj * gj); };      // (phase 1 only)
+    auto w_of = [&](int j) { return SOFT ? (s.zl[j] - s.zu[j]) * iom_of(j) : zero; };
     auto rl_of = [&](int b) { const int j = JB[b]; return SOFT ? s.x[j] + w_of(j) - lo_of(b) - s.sl[j] : s.x[j] - lo_of(b) - s.sl[j]; };
     auto ru_of = [&](int b) { const int j = JB[b]; return SOFT ? hi_of(b) - s.x[j] - w_of(j) - s.su[j] : hi_of(b) - s.x[j] - s.su[j]; };
     auto rpin_of = [&](int b) { const int j = JB[b]; return sel(bx.pin[j], s.x[j] - lo_of(b), zero); };
@@ -294,7 +298,11 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
         this->template Aeq_mul_t<LAY_RED>(s.x, rp);
         R res(0.0), msum(0.0);
         MPMPC_UNROLL
-        for (int i = 0; i < 2; ++i) { rp[i] = rp[i] - L::cold_get(K_LEQ + i); res = max_(res, sel(vx, abs_(rp[i]), zero)); }
+        for (int i = 0; i < 2; ++i) {
+          rp[i] = rp[i] - L::cold_get(K_LEQ + i);
+          if constexpr (SOFT) rp[i] = fma_(R(-P1_EQ_SOFT), s.nu[i], rp[i]);          // (soft dynamics rows: mpmpc_core.hpp, P1_EQ_SOFT)
+          res = max_(res, sel(vx, abs_(rp[i]), zero));
+        }
         MPMPC_UNROLL
         for (int j = 0; j < 3; ++j) {
           if constexpr (SOFT) rd[j] = At[j] - s.zl[j] + s.zu[j] + s.pi[j];
@@ -332,7 +340,18 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
           }
           ny = L::gmax(ny); na = L::gmax(na); sup = L::gsum(sup);
           const R thr = R(st.phase1_eps) * ny;
-          ok = ok | ((ny > R(st.phase1_eps)) & (na < thr) & (sup < -thr));
+          Mk ray = (ny > R(st.phase1_eps)) & (na < thr) & (sup < -thr);
+          if (band_slot >= 0) {
+            // (Solver::ipm: inside the band the iteration runs to its converged optimum - its violation decides "marginal")
+            R wv(0.0);
+            MPMPC_UNROLL
+            for (int b = 0; b < 2; ++b) {
+              const int j = JB[b];
+              wv = max_(wv, sel(val[j], abs_(w_of(j)) * L::cold_get(C_D + j), zero));
+            }
+            ray = ray & (L::gmax(wv) > L::cold_get(band_slot));
+          }
+          ok = ok | ray;
         }
         conv = conv | (active & ok);
         active = active & !ok;
@@ -356,15 +375,16 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
           const int j = JB[b];
           const R il = rcp_(s.sl[j]), iu = rcp_(s.su[j]);
           if constexpr (SOFT) {
-            // k = 1 / (1 + th), th = zl / sl + zu / su; the diagonal carries k th = 1 - k
-            const R kp = rcp_(one + sel(bx.Lm[j], s.zl[j] * il, zero) + sel(bx.Um[j], s.zu[j] * iu, zero));
-            h[j] = rcp_((reg + one) - kp + sel(bx.pin[j], ireg, zero));
+            // k = om / (om + th), th = zl / sl + zu / su; the diagonal carries k th = om (1 - k)
+            const R gj = L::cold_get(C_G + j), om = gj * gj;
+            const R kp = rcp_(fma_(sel(bx.Lm[j], s.zl[j] * il, zero) + sel(bx.Um[j], s.zu[j] * iu, zero), rcp_(om), one));
+            h[j] = rcp_(fma_(-om, kp, reg + om) + sel(bx.pin[j], ireg, zero));
           } else {
             h[j] = rcp_(L::cold_get(K_PP + j) + reg + sel(bx.Lm[j], s.zl[j] * il, zero) + sel(bx.Um[j], s.zu[j] * iu, zero) +
                         sel(bx.pin[j], ireg, zero));
           }
         }
-        this->template factor_t<LAY_RED>(h, reg);
+        this->template factor_t<LAY_RED>(h, SOFT ? reg + R(P1_EQ_SOFT) : reg);
         // (the slack reciprocals and complementarity products are formed AFTER the factorisation: four reciprocals twice are
         //  cheaper than eight registers across the factorisation's levels)
         L::fence();
@@ -374,7 +394,7 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
           isl[b] = sel(bx.Lm[j], rcp_(s.sl[j]), zero); isu[b] = sel(bx.Um[j], rcp_(s.su[j]), zero);
           rcl[b] = s.sl[j] * s.zl[j]; rcu[b] = s.su[j] * s.zu[j];
           // (k again, like the reciprocals: two registers less across the factorisation)
-          if constexpr (SOFT) kap[b] = rcp_(one + s.zl[j] * isl[b] + s.zu[j] * isu[b]);
+          if constexpr (SOFT) kap[b] = rcp_(fma_(s.zl[j] * isl[b] + s.zu[j] * isu[b], iom_of(j), one));
         }
       }
       R alpha_aff(1.0);
@@ -408,9 +428,10 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
             MPMPC_UNROLL
             for (int b = 0; b < 2; ++b) {
               const int j = JB[b];
-              r1[j] = rhs[j] - fma_((one - kap[b]) + sel(bx.pin[j], ireg, zero), dx[j], Atd[j]);
+              const R gj = L::cold_get(C_G + j), om = gj * gj;
+              r1[j] = rhs[j] - fma_(fma_(-om, kap[b], om) + sel(bx.pin[j], ireg, zero), dx[j], Atd[j]);
             }
-            r2[0] = nreq[0] - Ad[0]; r2[1] = nreq[1] - Ad[1];
+            r2[0] = fma_(R(P1_EQ_SOFT), dnu[0], nreq[0] - Ad[0]); r2[1] = fma_(R(P1_EQ_SOFT), dnu[1], nreq[1] - Ad[1]);
             L::fence();
             MPMPC_UNROLL
             for (int j = 0; j < 3; ++j) L::cold_put(K_RD + j, dx[j]);
@@ -432,7 +453,7 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
         MPMPC_UNROLL
         for (int b = 0; b < 2; ++b) {
           const int j = JB[b];
-          const R ex = SOFT ? kap[b] * (dx[j] + cul[b]) : dx[j];          // step of x + w:  k (dx + cu - cl)
+          const R ex = SOFT ? kap[b] * fma_(cul[b], iom_of(j), dx[j]) : dx[j];          // step of x + w:  k (dx + (cu - cl) / om)
           dsl[b] = ex + rl_of(b);
           dsu[b] = -ex + ru_of(b);
           dzl[b] = -fma_(s.zl[j], dsl[b], rcl[b]) * isl[b];

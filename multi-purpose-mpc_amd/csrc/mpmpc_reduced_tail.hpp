@@ -57,7 +57,8 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
   // The least-violation point of a verdict (infeasible: with its ray; marginal: with zero multipliers, in case the attempt
   // fails) goes to the slots of the certified point BEFORE the attempt, which then commits in merge mode: what it certifies
   // replaces it, what it does not leaves it there.
-  enum { T_RAW0 = 37, T_RAW1 = 38, T_RAW2 = 39, T_RAW3 = RS::C_PI, T_NAX = RS::C_PI + 1, T_RD0 = RS::C_PI + 2, T_MARK = RS::C_GAP };
+  enum { T_RAW0 = 37, T_RAW1 = 38, T_RAW2 = 39, T_RAW3 = RS::C_PI, T_NAX = RS::C_PI + 1, T_RD0 = RS::C_PI + 2, T_MARK = RS::C_GAP,
+         T_BAND = RS::C_NUS };      // (the slots of the certified point's equality multipliers: written when a verdict is out)
   static_assert(RS::K_RP + 2 <= 37, "the packed interior point's residual slots must end below T_RAW0");
   MPMPC_HD static constexpr int t_raw(int i) { return i == 0 ? T_RAW0 : (i == 1 ? T_RAW1 : (i == 2 ? T_RAW2 : T_RAW3)); }
 
@@ -97,6 +98,11 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
       R m = sel(vx, max_(fin(lo_e), fin(hi_e)), zero);
       m = max_(m, sel(vu, max_(max_(fin(lo_v), fin(hi_v)), max_(abs_(v), max_(fin(lo_k), fin(hi_k)))), zero));
       L::cold_put(T_NAX, L::gmax(m));
+      // (Solver::p1_band: the violation beyond which phase 1 may leave at the first valid ray; from the finite BOUNDS alone,
+      //  as the general kernel forms it)
+      R mb = sel(vx, max_(fin(lo_e), fin(hi_e)), zero);
+      mb = max_(mb, sel(vu, max_(max_(fin(lo_v), fin(hi_v)), max_(fin(lo_k), fin(hi_k))), zero));
+      L::cold_put(T_BAND, st.phase1_accept ? R(st.phase1_band) * fma_(R(st.eps_rel), L::gmax(mb), R(st.eps_abs)) : zero);
     }
     // ---- the FULL problem (5 entries, 3 equality rows per stage) as Solver::load sets it up, through Solver::ruiz
     const R ds = fld(F_DS, 0.0), one = sel(vu, onec, zero);
@@ -210,7 +216,18 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
         // (two digits further than the polish: Solver::phase1)
         const double tol1 = st.ipm_tol * 1e-2 < 1e-11 ? st.ipm_tol * 1e-2 : 1e-11;
         if constexpr (RS::kSplit) {
-          this->template ipm<RS::LAY_IP, true>(bi, si, nullptr, nullptr, vm, st, tol1, todo);
+          // (the weights of phase 1's metric, Solver::phase1: squares of the box rows' scaled entries)
+          R om3[3], omI[EI];
+          MPMPC_UNROLL
+          for (int e = 0; e < 3; ++e) { const R ge = L::cold_get(C_G + e); om3[e] = ge * ge; }
+          RS::to_ip(om3, omI, 1.0);
+          // ... and D / om: the iterate's w in unscaled units (Solver::ipm reads it in place of the cost vector)
+          R d3[3], dI[EI];
+          MPMPC_UNROLL
+          for (int e = 0; e < 3; ++e) d3[e] = L::cold_get(C_D + e) / om3[e];
+          RS::to_ip(d3, dI, 1.0);
+          S::p1_band = L::cold_get(T_BAND);
+          this->template ipm<RS::LAY_IP, true>(bi, si, omI, dI, vm, st, tol1, todo);
         } else {
           // the packed interior point reads the equality offsets from LDS; the cost - not read in phase 1 - waits in its own
           // slots there meanwhile instead of in twelve registers
@@ -218,7 +235,7 @@ struct ReducedTailSolver : ReducedSolver<L, CR> {
           for (int e = 0; e < 3; ++e) { L::cold_put(RS::K_PP + e, P3[e]); L::cold_put(RS::K_QQ + e, Q3[e]); }
           L::cold_put(RS::K_LEQ, leq[0]); L::cold_put(RS::K_LEQ + 1, leq[1]);
           L::fence();
-          RS::template ipm3<true>(bi, si, st, tol1, todo);
+          RS::template ipm3<true>(bi, si, st, tol1, todo, st.phase1_accept ? (int)T_BAND : -1);
           L::fence();
           MPMPC_UNROLL
           for (int e = 0; e < 3; ++e) { P3[e] = L::cold_get(RS::K_PP + e); Q3[e] = L::cold_get(RS::K_QQ + e); }

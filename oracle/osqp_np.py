@@ -487,6 +487,9 @@ def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, 
     Ax = w.A @ x
     P, q = (w.P, w.q) if soft is None else (np.zeros_like(w.P), np.zeros_like(w.q))
     g2 = np.zeros(m) if soft is None else np.where(L | U, soft, 0.0)
+    # phase 1: the equality rows are as soft as OSQP's ADMM makes them - RHO_EQ_OVER_RHO_INEQ times the weight of an inequality
+    # row's violation (mpmpc_core.hpp: P1_EQ_SOFT)
+    eqs = 0.0 if soft is None else 1.0 / RHO_EQ_OVER_RHO_INEQ
     nu = np.where(eq, y0, 0.0)
     sl = np.where(L, np.maximum(Ax - w.l, theta), 1.0)
     su = np.where(U, np.maximum(w.u - Ax, theta), 1.0)
@@ -511,7 +514,7 @@ def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, 
         Ax = w.A @ x
         y = nu + zu - zl
         rd = P @ x + q + w.A.T @ y
-        req = np.where(eq, Ax - beq, 0.0)
+        req = np.where(eq, Ax - beq - eqs * nu, 0.0)
         rl = np.where(L, Ax - g2 * (zu - zl) - w.l - sl, 0.0)
         ru = np.where(U, w.u - Ax + g2 * (zu - zl) - su, 0.0)
         mu = (np.sum(sl * zl * L) + np.sum(su * zu * U)) / nb
@@ -531,7 +534,7 @@ def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, 
             break           # (... or mu has collapsed far below the tolerance while the residual has not moved)
         mu_min = min(mu_min, mu)
         wt = np.where(L, zl / sl, 0.0) + np.where(U, zu / su, 0.0)
-        d = np.where(eq, reg, np.where(L | U, 1.0 / np.maximum(wt, 1e-300), 1e30))
+        d = np.where(eq, reg + eqs, np.where(L | U, 1.0 / np.maximum(wt, 1e-300), 1e30))
         dk = d + g2                     # soft rows: gamma^2 on top of the barrier term
         K = np.zeros((n + m, n + m))
         K[:n, :n] = P + reg * np.eye(n)
@@ -547,7 +550,7 @@ def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, 
             sol = sla.lu_solve(lu, rhs)
             # one refinement step against the un-regularised Newton matrix
             K0x = P @ sol[:n] + w.A.T @ sol[n:]
-            K0y = w.A @ sol[:n] - np.where(eq, 0.0, dk) * sol[n:]
+            K0y = w.A @ sol[:n] - np.where(eq, eqs, dk) * sol[n:]
             sol = sol + sla.lu_solve(lu, rhs - np.concatenate([K0x, K0y]))
             dx, dyv = sol[:n], sol[n:]
             Adx = w.A @ dx - g2 * dyv
@@ -589,8 +592,10 @@ def _ipm_refine(w: Workspace, x0, y0, st: Settings, tol, theta=3e-3, soft=None, 
 # zero iff the QP is feasible; and at its optimum the multipliers y satisfy  A'y = 0  and
 # u'max(y,0) + l'min(y,0) = -|w|^2 < 0:  a Farkas ray, the certificate OSQP's own infeasibility test asks for
 # (is_primal_infeasible), reached by ~10 interior-point iterations on the structured KKT system instead of
-# hundreds or thousands of ADMM iterations.  gamma_r = max |A_r.| of the SCALED row (the box rows of the MPC problem
-# have one entry, g), i.e. unit weight on a violation measured in the scaled variable.
+# hundreds or thousands of ADMM iterations.  gamma_r = 1: unit weight on the violation of the SCALED ROW - the measure OSQP's
+# own ADMM iteration minimises on an infeasible QP (its limit point minimises sum_r rho_r (scaled violation of row r)^2, rho
+# the same on all inequality rows), so that the least-violation point is the point the reference's solver call would test
+# (round 5; rounds 2 - 4 used gamma_r = max |A_r.| of the scaled row: unit weight on the violation of the scaled variable).
 # ---------------------------------------------------------------------------
 def farkas_certificate(A, l, u, y, eps=1e-4):
     """Solver-independent check that y proves  {x : l <= Ax <= u}  empty (unscaled data), with OSQP's normalisation:
@@ -629,7 +634,7 @@ def _phase1(w: Workspace, st: Settings, x0=None):
         violation is positive, so the problem is infeasible however small the margin - taken when the ray's support is
         negative by at least a hundred times its own residual |A'y|."""
     n, m = w.n, w.m
-    soft = np.max(np.abs(w.A), axis=1) ** 2
+    soft = np.ones(m)
     stop = lambda x, y: _primal_infeasible(w, y, st.phase1_eps)
     # (two digits beyond the polish's tolerance: for an instance infeasible by a tenth of a millimetre the quantities of
     #  the verdict - the ray's support - are themselves at the 1e-9 level)

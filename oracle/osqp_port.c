@@ -531,6 +531,9 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
   double* g2 = (double*)calloc(m, sizeof(double));
   double* dk = (double*)malloc(sizeof(double) * m);
   if (soft) for (int r = 0; r < m; ++r) g2[r] = (cl->L[r] || cl->U[r]) ? soft[r] : 0.0;
+  /* phase 1: the equality rows are as soft as OSQP's ADMM makes them - RHO_EQ_OVER_RHO_INEQ times the weight of an inequality
+     row's violation (osqp_np._ipm_refine; mpmpc_core.hpp: P1_EQ_SOFT) */
+  const double eqs = soft ? 1.0 / RHO_EQ_OVER_RHO_INEQ : 0.0;
   for (it = 0; it <= st->ipm_max_iter; ++it) {
     csc_mul(&w->A, x, Ax);
     for (int r = 0; r < m; ++r) yy[r] = nu[r] + zu[r] - zl[r];
@@ -538,7 +541,7 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
     double res = 0, mu = 0;
     for (int j = 0; j < n; ++j) { rd[j] += w->q[j] + tn[j]; res = dmax(res, fabs(rd[j])); }
     for (int r = 0; r < m; ++r) {
-      req[r] = cl->eq[r] ? Ax[r] - w->l[r] : 0.0;
+      req[r] = cl->eq[r] ? Ax[r] - w->l[r] - eqs * nu[r] : 0.0;
       rl[r] = cl->L[r] ? Ax[r] - g2[r] * (zu[r] - zl[r]) - w->l[r] - sl[r] : 0.0;
       ru[r] = cl->U[r] ? w->u[r] - Ax[r] + g2[r] * (zu[r] - zl[r]) - su[r] : 0.0;
       res = dmax(res, dmax(fabs(req[r]), dmax(fabs(rl[r]), fabs(ru[r]))));
@@ -555,7 +558,7 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
     mu_min = dmin(mu_min, mu);
     for (int r = 0; r < m; ++r) {
       double wt = (cl->L[r] ? zl[r] / sl[r] : 0.0) + (cl->U[r] ? zu[r] / su[r] : 0.0);
-      d[r] = cl->eq[r] ? reg : ((cl->L[r] || cl->U[r]) ? 1.0 / dmax(wt, 1e-300) : 1e30);
+      d[r] = cl->eq[r] ? reg + eqs : ((cl->L[r] || cl->U[r]) ? 1.0 / dmax(wt, 1e-300) : 1e30);
       dk[r] = d[r] + g2[r];
     }
     if (kkt_fill_and_factor(w, K, F, reg, dk, m) != 0) break;
@@ -572,7 +575,7 @@ static int ipm_refine(work_t* w, kkt_t* K, ldl_t* F, const classes_t* cl, double
       sym_mul(&w->P, sol, tn); csc_tmul(&w->A, sol + n, res2);
       for (int j = 0; j < n; ++j) res2[j] = rhs[j] - (tn[j] + res2[j]);
       csc_mul(&w->A, sol, tm);
-      for (int r = 0; r < m; ++r) res2[n + r] = rhs[n + r] - (tm[r] - (cl->eq[r] ? 0.0 : dk[r]) * sol[n + r]);
+      for (int r = 0; r < m; ++r) res2[n + r] = rhs[n + r] - (tm[r] - (cl->eq[r] ? eqs : dk[r]) * sol[n + r]);
       ldl_solve(F, res2, cor);
       for (int k = 0; k < N; ++k) sol[k] += cor[k];
       csc_mul(&w->A, sol, tm);
@@ -766,7 +769,7 @@ static int certified_polish(work_t* w, const double* x, const double* y, double 
  *     min 1/2 |w|^2   s.t.  equality rows as they are,  l <= (Ax)_r + gamma_r w_r <= u  on every other finite row
  * Always feasible when the equality rows are; optimum 0 iff the QP is feasible; at its optimum the multipliers y satisfy
  * A'y = 0 and u'max(y,0) + l'min(y,0) = -|w|^2 < 0: a Farkas ray, put to OSQP's own primal-infeasibility test.
- * gamma_r = max |A_r.| of the scaled row.  Returns 1 when certified; x_out: least-violation point, y_out: the ray. */
+ * gamma_r = 1 (the violation of the scaled row counts).  Returns 1 when certified; x_out: least-violation point, y_out: the ray. */
 static int certified_polish(work_t* w, const double* x, const double* y, double theta, double mu0, double* x_out, double* y_out, oracle_info* info);
 /* returns 1: certified infeasible, 2: found FEASIBLE and certified optimal by a second polish attempt from phase 1's
  * point (inside every box, well centred: the warm-started interior point of the first attempt occasionally jams next to
@@ -781,9 +784,9 @@ static int phase1(work_t* w, double* x_out, double* y_out, oracle_info* info) {
     cl.L[r] = fl && !cl.eq[r]; cl.U[r] = fu && !cl.eq[r];
   }
   double* soft = (double*)calloc(m, sizeof(double));
-  for (int j = 0; j < n; ++j)
-    for (int k = w->A.p[j]; k < w->A.p[j + 1]; ++k) soft[w->A.i[k]] = dmax(soft[w->A.i[k]], fabs(w->A.x[k]));
-  for (int r = 0; r < m; ++r) soft[r] *= soft[r];
+  /* gamma_r = 1: unit weight on the violation of the SCALED ROW - OSQP's own measure, the one its ADMM iteration minimises
+     on an infeasible QP (osqp_np._phase1; rounds 2 - 4: gamma_r = max |A_r.|, the violation of the scaled variable) */
+  for (int r = 0; r < m; ++r) soft[r] = 1.0;
   int pnnz = w->P.p[n];
   double* Psave = (double*)malloc(sizeof(double) * (pnnz > 0 ? pnnz : 1)); memcpy(Psave, w->P.x, sizeof(double) * pnnz);
   double* qsave = (double*)malloc(sizeof(double) * n); memcpy(qsave, w->q, sizeof(double) * n);

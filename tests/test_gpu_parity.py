@@ -119,6 +119,12 @@ def test_certified_matches_oracle(cfgid, B, N, track):
             assert O.kkt_certificate(np.diag(Pd), q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8)
             n_skip += 1
             continue
+        # (default verdicts on the device: an instance the oracle proves infeasible may be MARGINALLY so - status 2, a plan on
+        #  relaxed boxes, mpmpc_settings::phase1_accept)
+        if sol.status[i] == mpmpc.SOLVED_INACCURATE and r.status == O.PRIMAL_INFEASIBLE:
+            assert sol.resid[i, 0] <= 1e-3 + 1e-3 * scenarios.UMAX[1] * 1.01
+            n_inf += 1
+            continue
         assert sol.status[i] == r.status
         # same ADMM iteration count, unless exactly one side certified at the early-polish attempt
         # (the dense numpy interior point is less robust than the kernel's / the C port's)
@@ -267,7 +273,9 @@ def test_mpc_get_control_replays_reference_lap_on_gpu():
     from spatial_bicycle_models import TemporalState
     g = np.load(M.GOLDEN + "/g6_closed_loop_N30.npz")
     m, rp, car = H.build_world()
-    mpc = H.make_mpc(car, 30)                       # real backend
+    # (G6 is the lap of the CERTIFIED stand-in - every proven infeasibility reported: phase1_accept = 0, as in the CPU twin
+    #  tests/test_host_mpc.py; the default verdicts are pinned by the stock lap G6s below)
+    mpc = H.make_mpc(car, 30, settings=mpmpc.default_settings(phase1_accept=0))                       # real backend
     assert isinstance(mpc.optimizer, mpmpc.Handle)
     n_inf = 0
     for t in range(0, g["s"].size, 2):
