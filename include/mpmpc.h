@@ -176,7 +176,10 @@ typedef struct {
                             that iterate violates a bound by more than phase1_band times OSQP's primal tolerance (eps_abs +
                             eps_rel x the largest finite bound); inside the band it runs to its converged optimum, because the
                             violation of THAT point decides whether the reference's OSQP call would have returned a plan, and
-                            it is up to 2.4 times smaller than the early iterate's (measured on configs 4 / 5).  Default 4. */
+                            it is up to 2.4 times smaller than the early iterate's.  Default 3: measured on config 5 (65 536
+                            instances, emulation) the number of instances that take the other branch than the restated stock
+                            OSQP is 67 / 34 / 29 / 26 / 26 / 26 at 1.5 / 2 / 2.5 / 3 / 6 / 1000, and config 4 runs 2.1 / 2.7 /
+                            3.2 / 4.3 % slower at 2 / 3 / 4 / 6 than at 0 (profiles/r5/branch_agreement.txt). */
 } mpmpc_settings;
 
 const char* mpmpc_version(void);

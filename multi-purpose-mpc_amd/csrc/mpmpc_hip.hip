@@ -766,7 +766,7 @@ void mpmpc_default_settings(mpmpc_settings* s) {
   s->native = 1;
   s->native_ipm_tol = 1e-7;
   s->early_start = 0;
-  s->phase1_band = 4.0;
+  s->phase1_band = 3.0;
 }
 
 int32_t mpmpc_stage_ld(int32_t N) { return host_stage_ld(N); }

@@ -56,7 +56,7 @@ def default_settings(**kw) -> Settings:
                  adaptive_rho_interval=50, adaptive_rho_tolerance=5.0, polish=2, ipm_max_iter=30,
                  ipm_tol=1e-8, ipm_reg=1e-8, as_delta=1e-10, as_refine=5, as_rounds=4, cert_tol=1e-8, early_polish=1,
                  early_scaling=1, phase1=1, ipm_diverged=1e2, phase1_theta=1.0, phase1_eps=1e-6, reduce=1,
-                 ipm_start_slack=0.1, ipm_start_mu=0.01, ipm_start_dual=0.2, as_add_fraction=0.25, phase1_accept=1, native=1, native_ipm_tol=1e-7, early_start=0, phase1_band=4.0)
+                 ipm_start_slack=0.1, ipm_start_mu=0.01, ipm_start_dual=0.2, as_add_fraction=0.25, phase1_accept=1, native=1, native_ipm_tol=1e-7, early_start=0, phase1_band=3.0)
     for k, v in kw.items():
         if not hasattr(s, k):
             raise TypeError("unknown solver setting %r" % k)

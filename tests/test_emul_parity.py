@@ -329,6 +329,34 @@ def test_controls_vs_reference_counts_only_certified_equal_objective_points_as_a
     assert alt.size == 0 and worst >= 0.9e-3
 
 
+def test_default_branch_agreement_with_restated_stock_osqp_in_the_emulation(emu, track):
+    """The CPU twin of tests/test_gpu_parity.py::test_default_branch_agreement_... on the FULL config 4 (8 192 instances): the
+    launcher's own sequence of kernels, emulated, on every instance the certified C port proves infeasible (the others are
+    "solved" on both sides), against the restated stock OSQP.  At most 8 disagreements, all "device refuses, OSQP returns a
+    plan", all abandoned by OSQP at max_iter or within 0.5 % of its primal tolerance; and the least violation phase 1 reports
+    IS the primal residual OSQP's ADMM iteration converges to (to 1 %) where that iteration ran into max_iter."""
+    import oracle_c as OC
+    sc = scenarios.make(4, track, B=8192)
+    cfg = T.stock_config(sc.N, sc.weights)
+    ocfg = OC.mpc_cfg(sc.N, scenarios.WEIGHTS[sc.weights], scenarios.UMIN, scenarios.UMAX, scenarios.XMIN, scenarios.XMAX, 4.0, 0.12)
+    args = (track.kappa, track.v_ref, track.ds_next, sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    stock = OC.mpc_batch(ocfg, OC.settings(polish=0, early_polish=0, phase1=0), *args)
+    cert = OC.mpc_batch(ocfg, OC.settings(), *args)
+    inf = np.flatnonzero(cert["status"] == -3)
+    assert inf.size > 600 and np.all(np.isin(stock["status"][cert["status"] == 1], (1, 2)))
+    qp = emu.assemble(cfg, track, (sc.wp_id[inf], sc.x0[inf], sc.cc_prev[inf], sc.lb[inf], sc.ub[inf]))
+    sol, _ = emu.solve_launch(cfg, mpmpc.default_settings(), qp, G=32)
+    assert set(np.unique(sol.status)) <= {2, -3} and (sol.status == 2).sum() >= 60
+    dev_usable, st_usable = sol.status == 2, np.isin(stock["status"][inf], (1, 2, -2))
+    dis = np.flatnonzero(dev_usable != st_usable)
+    thr = 1e-3 + 1e-3 * scenarios.UMAX[1]
+    assert dis.size <= 8
+    for j in dis:
+        assert not dev_usable[j] and (stock["iters"][inf[j], 0] >= 4000 or abs(sol.resid[j, 0] / thr - 1.0) <= 5e-3), (inf[j], sol.resid[j, 0])
+    cap = stock["iters"][inf, 0] >= 4000
+    assert cap.sum() >= 3 and np.max(np.abs(sol.resid[cap, 0] / stock["resid"][inf[cap], 0] - 1.0)) <= 1e-2
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # full terminal weight QN (src/MPC.py:150,154 use the whole matrix)
 # ---------------------------------------------------------------------------------------------------------------

@@ -380,6 +380,26 @@ def test_device_against_the_independent_leg_on_the_reference_captures(N, track):
     assert r["refused_by_device_only"] == 0 and r["refused_by_independent_only"] == 0, r
 
 
+@pytest.mark.parametrize("cfgid", [4, 5])
+def test_default_branch_agreement_with_restated_stock_osqp_on_the_batch_configs(cfgid):
+    """VERDICT r4 item 3.  Which branch of src/MPC.py:185-216 get_control takes with the DEFAULT settings - against the
+    restated stock OSQP on the full obstacle batch of config 4 and a shard of config 5 (8 192 instances each).  Since round 5
+    phase 1 measures infeasibility the way OSQP's ADMM iteration does (Solver::phase1); what is left is pinned here in SIZE,
+    DIRECTION and CAUSE: at most 8 instances, every one refused by the device and accepted by OSQP, and every one either
+    abandoned by OSQP at max_iter (it then returns its iterate, "solved inaccurate": nothing but its 4 000 iterations can know
+    that) or within 0.5 % of OSQP's primal tolerance (OSQP stops an iterate short of its limit point).  Round 4: 28 / 24."""
+    import sys
+    sys.path.insert(0, T.ROOT + "/profiles")
+    import branch_agreement
+    r = branch_agreement.compare(cfgid, 8192)
+    assert r["agreement"] >= 0.999 and len(r["rows"]) <= 8, r
+    for i, dev_status, dev_viol, st_status, st_iters, st_pri in r["rows"]:
+        assert dev_status == mpmpc.PRIMAL_INFEASIBLE and st_status in (1, 2), (i, dev_status, st_status)
+        assert st_iters >= 4000 or abs(dev_viol / r["threshold"] - 1.0) <= 5e-3, (i, dev_viol, st_iters, st_pri)
+        assert dev_viol > r["threshold"] * (1 - 1e-9)          # the device's own rule: refused means beyond OSQP's tolerance
+    assert r["device"].get(2, 0) >= 60 and r["device"].get(-3, 0) >= 600
+
+
 @pytest.mark.parametrize("N", [10, 30])
 def test_default_path_takes_the_branch_stock_osqp_takes_on_device(N, track):
     """ADVICE r2 (high), on the device: golden G6s is the reference's own loop run with the restated OSQP at ITS DEFAULTS
@@ -559,6 +579,14 @@ def test_the_polish_settings_change_the_route_not_the_answer(cfgid, B, track):
         assert np.array_equal(o.status, ref.status), kw
         worst, alt = T.controls_vs_reference(qp, sc.N, o, dict(status=ref.status, u0=ref.u0, z=ref.z, y=ref.y), 1e-8)
         assert worst <= 1e-8 and alt.size <= 1, (kw, worst, alt)
+        # (an instance excused as an "alternative optimum" needs a PROOF that its optimum is not a point: the uniqueness
+        #  certificate must FAIL on the compared coordinates - as in test_full_batches_against_c_oracle; VERDICT r4 "weak" 10)
+        if alt.size:
+            import independent as I
+            keep, _ = I.compared_coordinates(sc.N)
+            for i in alt:
+                Pd, q, A, l, u = T.qp_to_dense(qp[:, i, :], sc.N)
+                assert not I.uniqueness_certificate(Pd, A, l, u, o.z[i], o.y[i], keep)["unique"], (kw, i)
         prim, stat, comp = T.kkt_batch(qp[:, ok, :], sc.N, o.z[ok], o.y[ok])
         assert max(prim.max(), stat.max(), comp.max()) <= 1e-8, kw
 
@@ -605,6 +633,24 @@ def test_baseline_batch_sizes_carry_kkt_certificates(cfgid, B, track):
         hs.close()
         assert np.array_equal(strict.status == -3, mg | inf) and np.array_equal(strict.status == 1, ok)
         assert np.array_equal(strict.u0[ok], sol.u0[ok])
+    # ... and the C oracle on the WHOLE batch (VERDICT r4 "weak" 9: it does 65 536 instances in seconds): every status of the
+    # certified port (the device's strict verdicts), every control to 1e-6
+    import oracle_c as OC
+    ocfg = OC.mpc_cfg(sc.N, scenarios.WEIGHTS[sc.weights], scenarios.UMIN, scenarios.UMAX, scenarios.XMIN, scenarios.XMAX, 4.0, 0.12)
+    ref = OC.mpc_batch(ocfg, OC.settings(), track.kappa, track.v_ref, track.ds_next, sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+    assert np.array_equal(ref["status"] == 1, ok) and np.array_equal(ref["status"] == -3, sol.status != 1)
+    worst, alt = T.controls_vs_reference(qp, sc.N, sol, ref, 1e-6)
+    assert worst <= 1e-6 and alt.size <= 4, (worst, alt)
+    if alt.size:
+        import independent as I
+        keep, _ = I.compared_coordinates(sc.N)
+        for i in alt:
+            # (every optimal point pairs with the multipliers of ANY KKT point: the proof may use either side's.  A weakly
+            #  active corridor bound carries a multiplier of 1e-6 on one side and exactly zero on the other - 65 536 instances
+            #  hold a handful of those)
+            Pd, q, A, l, u = T.qp_to_dense(qp[:, i, :], sc.N)
+            assert not (I.uniqueness_certificate(Pd, A, l, u, sol.z[i], sol.y[i], keep)["unique"] and
+                        I.uniqueness_certificate(Pd, A, l, u, ref["z"][i], ref["y"][i], keep)["unique"]), i
     perm = np.random.default_rng(0).permutation(B)
     sol2 = h.solve(sc.wp_id[perm], sc.x0[perm], sc.cc_prev[perm], sc.lb[perm], sc.ub[perm])
     assert np.array_equal(sol2.status, sol.status[perm]) and np.array_equal(sol2.iters, sol.iters[perm])
