@@ -584,6 +584,14 @@ struct mpmpc_handle_s {
   // synchronous and slow; nullptr above STAGE_LIMIT bytes: large batches amortise the direct path)
   char *stage_in = nullptr, *stage_out = nullptr;
   size_t stage_in_bytes = 0, stage_out_bytes = 0;
+  // ... above that limit an upload goes through a small page-locked bounce buffer in two halves (allocated by the first such
+  // upload): the device copy of one half runs while the host fills the other, and the call returns when the caller's buffers
+  // have been read - not when the device has them.  (A copy from pageable memory is synchronous: one process feeding several
+  // devices - sharded.py - would otherwise serve them one after the other)
+  char* bounce = nullptr;
+  hipEvent_t ev_bounce[2] = {nullptr, nullptr};
+  bool bounce_busy[2] = {false, false};
+  int bounce_turn = 0;
   // instances the early pass of a packed (2 or 4 per wave) launch could not certify: [0] = count, [1..] = ids
   int* tail = nullptr;
   int tail_flip = 0;          // which of the two lists the next reduced-native launch fills
@@ -853,6 +861,9 @@ int mpmpc_destroy(mpmpc_handle h) {
     if (a.stream) (void)hipStreamDestroy(a.stream);
   }
   if (h->ev_order) (void)hipEventDestroy(h->ev_order);
+  if (h->bounce) (void)hipHostFree(h->bounce);
+  for (auto& e : h->ev_bounce)
+    if (e) (void)hipEventDestroy(e);
   if (h->stage_in) (void)hipHostFree(h->stage_in);
   if (h->stage_out) (void)hipHostFree(h->stage_out);
   if (h->tail_flag) (void)hipHostFree(h->tail_flag);
@@ -1259,17 +1270,38 @@ int mpmpc_upload(mpmpc_handle h, int32_t B, const int32_t* wp_id, const double* 
     HIP_TRY(hipEventRecord(h->ev_in, h->stream));
     h->in_flight = true;
   } else {
-    HIP_TRY(hipMemcpyAsync(h->wp_id, wp_id, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->x0, x0, sizeof(double) * 3 * B, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->cc, cc_prev, sizeof(double) * 2 * N * B, hipMemcpyHostToDevice, h->stream));
+    // (no staging block of this size: through the bounce buffer - asynchronous on the device's side, the caller's buffers are
+    //  free when the call returns)
+    if (int rc = upload_through_bounce(h, h->wp_id, wp_id, sizeof(int) * B)) return rc;
+    if (int rc = upload_through_bounce(h, h->x0, x0, sizeof(double) * 3 * B)) return rc;
+    if (int rc = upload_through_bounce(h, h->cc, cc_prev, sizeof(double) * 2 * N * B)) return rc;
     if (lb) {
-      HIP_TRY(hipMemcpyAsync(h->lb, lb, sizeof(double) * N * B, hipMemcpyHostToDevice, h->stream));
-      HIP_TRY(hipMemcpyAsync(h->ub, ub, sizeof(double) * N * B, hipMemcpyHostToDevice, h->stream));
+      if (int rc = upload_through_bounce(h, h->lb, lb, sizeof(double) * N * B)) return rc;
+      if (int rc = upload_through_bounce(h, h->ub, ub, sizeof(double) * N * B)) return rc;
     }
-    HIP_TRY(hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller
   }
   h->have_rows = lb != nullptr;
   h->uploaded = B;
+  return MPMPC_OK;
+}
+
+constexpr size_t BOUNCE_HALF = 8u << 20;
+static int upload_through_bounce(mpmpc_handle h, void* dst, const void* src, size_t bytes) {
+  if (!h->bounce) {
+    HIP_TRY(hipHostMalloc((void**)&h->bounce, 2 * BOUNCE_HALF, hipHostMallocDefault));
+    for (auto& e : h->ev_bounce) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  for (size_t off = 0; off < bytes; off += BOUNCE_HALF) {
+    const int k = h->bounce_turn;
+    if (h->bounce_busy[k]) HIP_TRY(hipEventSynchronize(h->ev_bounce[k]));      // its last copy has left this half
+    const size_t n = bytes - off < BOUNCE_HALF ? bytes - off : BOUNCE_HALF;
+    char* half = h->bounce + (size_t)k * BOUNCE_HALF;
+    std::memcpy(half, static_cast<const char*>(src) + off, n);
+    HIP_TRY(hipMemcpyAsync(static_cast<char*>(dst) + off, half, n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipEventRecord(h->ev_bounce[k], h->stream));
+    h->bounce_busy[k] = true;
+    h->bounce_turn = 1 - k;
+  }
   return MPMPC_OK;
 }
 

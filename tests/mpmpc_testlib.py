@@ -371,6 +371,49 @@ class EmuBackend:
         return self.emu.solve(self.cfg, self.settings, qp, G=64, want_y=want_y)
 
 
+class DryHandle(EmuBackend):
+    """The RESIDENT surface of mpmpc.Handle (upload / solve_resident / sync / download, set_pipeline / set_outputs / set_packing)
+    on the CPU emulation: what `bench.py --dry-run` drives when it rehearses the multi-rank plumbing on a box without GPUs.
+    A resident launch is emulated when its results are asked for (download); the launches of a timed loop cost nothing."""
+
+    class _Lib:
+        @staticmethod
+        def mpmpc_version():
+            return b"mpmpc DRY RUN (CPU emulation of the kernels, tests/emul)"
+
+    def __init__(self, cfg, settings, emu=None):
+        super().__init__(cfg, settings, emu)
+        self.lib = DryHandle._Lib()
+        self.pipeline, self.uploaded, self.launches, self._sol = 3, None, 0, None
+
+    def set_packing(self, lanes_per_instance=0):
+        pass
+
+    def set_outputs(self, want_y=True):
+        pass
+
+    def set_pipeline(self, depth=3):
+        self.pipeline = int(depth)
+
+    def upload(self, wp_id, x0, cc_prev, lb=None, ub=None):
+        self.uploaded, self._sol = (np.asarray(wp_id, np.int32), x0, cc_prev, lb, ub), None
+
+    def solve_resident(self, B):
+        assert self.uploaded is not None and B <= self.uploaded[0].size
+        self.launches += 1
+
+    def sync(self):
+        pass
+
+    def download(self, B, want_y=False):
+        if self._sol is None:
+            self._sol = self.solve(*self.uploaded, want_y=want_y)
+        return self._sol
+
+    def close(self):
+        pass
+
+
 # ---- the independent leg (oracle/independent.py, golden G8): nothing below shares code with the device algorithm
 def g8(name):
     return np.load(os.path.join(ROOT, "tests", "golden", "g8_independent_%s.npz" % name))

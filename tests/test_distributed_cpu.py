@@ -116,3 +116,24 @@ def test_bench_rejects_a_world_size_that_differs_from_gpus():
     assert r.returncode != 0
     assert "WORLD_SIZE=2" in (r.stderr + r.stdout)
     assert '"n_gpus"' not in r.stdout
+
+
+@pytest.mark.skipif(mpmpc.device_count() > 0, reason="the rehearsal is for boxes without GPUs")
+def test_bench_launcher_rehearsal_with_eight_ranks():
+    """`bench.py --gpus 8` end to end on the CPU box - the launcher (this process spawns torch.distributed.run
+    with 8 ranks as a child), GPU_MAX_HW_QUEUES=8 in every rank's environment, LOCAL_RANK -> device ordinal of the rank's handle,
+    the contiguous shards of the 8 x B batch, the barriers / MAX reductions of the timed loop and the gather check against one
+    process solving the whole batch - over gloo, the kernels emulated (--dry-run: value is null, nothing is measured)."""
+    import json
+    r = _run_bench(["--gpus", "8", "--dry-run", "--config", "5", "--batch", "3", "--steps", "2", "--warmup", "1", "--repeats", "2",
+                    "--prewarm", "1", "--no-cpu"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                     # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["value"] is None and d["n_gpus"] == 8 and d["world_size"] == 8
+    assert d["gpu_max_hw_queues"] == "8" and d["launches_in_flight"] == 4
+    assert [x["rank"] for x in d["ranks"]] == list(range(8)) and [x["device"] for x in d["ranks"]] == list(range(8))
+    assert sum(x["solved"] + x["solved_inaccurate"] + x["infeasible"] + x["other"] for x in d["ranks"]) == 24
+    assert d["gather_check"]["instances"] == 24 and d["gather_check"]["status_equal"] is True and d["gather_check"]["max_abs_u_diff"] == 0.0
+    assert len(d["ms_per_step_by_rank_emulated"]) == 8 and d["config"]["batch_per_gpu"] == 3

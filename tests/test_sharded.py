@@ -134,3 +134,40 @@ def test_non_diagonal_stage_weights_are_accepted_by_every_product_class():
     cfg.QN_offdiag[0] = 5.0                                                              # indefinite: 1 x 0 - 25 < 0
     with pytest.raises(mpmpc.MpmpcError):
         mpmpc.Handle(cfg, mpmpc.default_settings())
+
+
+@pytest.mark.gpu
+def test_eight_handles_with_ragged_shards_reproduce_one_handle_at_65536():
+    """the first 8-GPU run's data path, on one device - eight handles (device 0), ragged contiguous shards
+    of a 65 536 + 5 instance config-5 batch through ShardedHandles (upload + resident launch of every shard STARTED before any
+    is collected) against ONE handle solving the whole batch: bit for bit.  The single handle's batch is above the 64 MiB
+    staging limit, so its upload goes through the page-locked bounce buffer (item 7b): same bits again."""
+    tr = scenarios.sim_track()
+    B = 65536 + 5
+    sc = scenarios.make(5, tr, B=B)
+    world = 8
+    per = -(-B // world)
+    hs = []
+    for r in range(world):
+        h = mpmpc.Handle(T.stock_config(sc.N, sc.weights, max_batch=per))
+        h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+        hs.append(h)
+    sh = sharded.ShardedHandles(hs)
+    sizes = [hi - lo for lo, hi in sh.bounds(B)]
+    assert sum(sizes) == B and max(sizes) - min(sizes) == 1          # ragged
+    got = sh.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    sh.close()
+    one_h = mpmpc.Handle(T.stock_config(sc.N, sc.weights, max_batch=B))
+    one_h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+    with pytest.raises(mpmpc.MpmpcError):
+        one_h.staging(16)                                              # (no staging blocks at this size: the bounce path it is)
+    one = one_h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    # ... and the resident path after such an upload
+    one_h.upload(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    one_h.solve_resident(B)
+    two = one_h.download(B)
+    one_h.close()
+    for a in (got, two):
+        assert np.array_equal(a.status, one.status) and np.array_equal(a.iters, one.iters)
+        assert np.array_equal(a.u0, one.u0) and np.array_equal(a.z, one.z) and np.array_equal(a.resid, one.resid)
+    assert (one.status == 1).mean() > 0.85 and (one.status == -3).sum() > 3000
