@@ -726,6 +726,7 @@ static int check_settings(const mpmpc_settings* s) {
 }
 
 static int grow_slots(mpmpc_handle h, int want);
+static int upload_through_bounce(mpmpc_handle h, void* dst, const void* src, size_t bytes);
 static int launch_assemble(mpmpc_handle h, int B);
 // how a solve launch was asked for (decides the packing of the reduced-native kernels, see launch_solve)
 enum LaunchKind { LAUNCH_SINGLE = 0, LAUNCH_PIPELINED = 1 };

@@ -375,10 +375,10 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
           const int j = JB[b];
           const R il = rcp_(s.sl[j]), iu = rcp_(s.su[j]);
           if constexpr (SOFT) {
-            // k = om / (om + th), th = zl / sl + zu / su; the diagonal carries k th = om (1 - k)
-            const R gj = L::cold_get(C_G + j), om = gj * gj;
-            const R kp = rcp_(fma_(sel(bx.Lm[j], s.zl[j] * il, zero) + sel(bx.Um[j], s.zu[j] * iu, zero), rcp_(om), one));
-            h[j] = rcp_(fma_(-om, kp, reg + om) + sel(bx.pin[j], ireg, zero));
+            // k = om / (om + th), th = zl / sl + zu / su; the diagonal carries k th (= om (1 - k))
+            const R th = sel(bx.Lm[j], s.zl[j] * il, zero) + sel(bx.Um[j], s.zu[j] * iu, zero);
+            const R kp = rcp_(fma_(th, iom_of(j), one));
+            h[j] = rcp_(fma_(kp, th, reg) + sel(bx.pin[j], ireg, zero));
           } else {
             h[j] = rcp_(L::cold_get(K_PP + j) + reg + sel(bx.Lm[j], s.zl[j] * il, zero) + sel(bx.Um[j], s.zu[j] * iu, zero) +
                         sel(bx.pin[j], ireg, zero));
@@ -428,8 +428,8 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
             MPMPC_UNROLL
             for (int b = 0; b < 2; ++b) {
               const int j = JB[b];
-              const R gj = L::cold_get(C_G + j), om = gj * gj;
-              r1[j] = rhs[j] - fma_(fma_(-om, kap[b], om) + sel(bx.pin[j], ireg, zero), dx[j], Atd[j]);
+              // (k th again: th = zl / sl + zu / su from the masked reciprocals)
+              r1[j] = rhs[j] - fma_(kap[b] * (s.zl[j] * isl[b] + s.zu[j] * isu[b]) + sel(bx.pin[j], ireg, zero), dx[j], Atd[j]);
             }
             r2[0] = fma_(R(P1_EQ_SOFT), dnu[0], nreq[0] - Ad[0]); r2[1] = fma_(R(P1_EQ_SOFT), dnu[1], nreq[1] - Ad[1]);
             L::fence();
