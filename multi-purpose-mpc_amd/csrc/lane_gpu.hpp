@@ -77,6 +77,7 @@ struct LaneGpu {
   using ival = int;
   static constexpr int group = G;
   static constexpr int per_wave = 64 / G;
+  static constexpr bool batched = false;       // lane exchanges are register moves: nothing to batch (Solver::cup_n)
 
   static __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
   static __device__ __forceinline__ int stage() { return (threadIdx.x & 63) % G; }
@@ -330,8 +331,8 @@ struct LaneGpu {
 // lanes [G/2, G) descend (C = G / 2), exactly as for <64, 32>.  No cyclic reduction, no split layout (those are arrangements
 // of the 64-lane kernels); this is the general kernel's code at one wavefront per SIMD, paying two barriers per exchange -
 // the price of a horizon the reference allows (src/MPC.py:73-74 has no limit) and a 64-lane wavefront does not hold.
-// LDS per workgroup: SLOTS cold slots of G doubles (also the staging of the output rows) + one exchange row + the
-// reduction scratch: 67 KB at G = 128, 134 KB at G = 256, passed as DYNAMIC shared memory (above the 64 KB static limit).
+// LDS per workgroup: SLOTS cold slots of G doubles (also the staging of the output rows) + nine exchange rows + the
+// reduction scratch: 77 KB at G = 128 (two workgroups per CU), 154 KB at G = 256, passed as DYNAMIC shared memory (above the 64 KB static limit).
 template <int G, int SLOTS = 66>
 struct LaneBlock {
   static_assert(G == 128 || G == 256, "a workgroup of 2 or 4 wavefronts");
@@ -344,7 +345,9 @@ struct LaneBlock {
   static constexpr int per_wave = 1;          // ONE instance per execution group: instance-wide conditions are group-wide
   static constexpr int waves = G / 64;
   static constexpr int cold_slots = SLOTS;
-  static constexpr size_t lds_bytes = sizeof(double) * ((size_t)(SLOTS + 1) * G + 8);
+  static constexpr bool batched = true;       // several values of a step share one pass through LDS (Solver::cup_n)
+  static constexpr int xrows = 9;             // exchange rows: the widest batch is the 3 x 3 block of a factorisation step
+  static constexpr size_t lds_bytes = sizeof(double) * ((size_t)(SLOTS + xrows) * G + 8);
 
   static __device__ __forceinline__ int lane_id() { return threadIdx.x; }
   static __device__ __forceinline__ int stage() { return threadIdx.x; }
@@ -361,7 +364,7 @@ struct LaneBlock {
   }
   static __device__ __forceinline__ double* cold() { return lds(); }
   static __device__ __forceinline__ double* xrow() { return lds() + (size_t)SLOTS * G; }
-  static __device__ __forceinline__ double* rrow() { return lds() + (size_t)(SLOTS + 1) * G; }
+  static __device__ __forceinline__ double* rrow() { return lds() + (size_t)(SLOTS + xrows) * G; }
 
   // the value lane `src` holds (src outside [0, G): 0) - every lane of the workgroup must call it
   static __device__ __forceinline__ double take(double a, int src) {
@@ -371,6 +374,29 @@ struct LaneBlock {
     const double r = (unsigned)src < (unsigned)G ? x[src] : 0.0;
     __syncthreads();          // (the row is free again before anyone writes the next exchange into it)
     return r;
+  }
+  // ... NV values at once: one barrier pair for all of them
+  template <int NV>
+  static __device__ __forceinline__ void takev(const double* v, double* o, int src) {
+    static_assert(NV <= xrows, "widen the exchange rows");
+    double* x = xrow();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) x[i * G + threadIdx.x] = v[i];
+    __syncthreads();
+    const bool ok = (unsigned)src < (unsigned)G;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) o[i] = ok ? x[i * G + src] : 0.0;
+    __syncthreads();
+  }
+  template <int NV> static __device__ __forceinline__ void upv(const double* v, double* o) { takev<NV>(v, o, (int)threadIdx.x - 1); }
+  template <int NV> static __device__ __forceinline__ void downv(const double* v, double* o) { takev<NV>(v, o, (int)threadIdx.x + 1); }
+  template <int NV> static __device__ __forceinline__ void cupv(const double* v, double* o) {
+    const int t = threadIdx.x;
+    takev<NV>(v, o, (t == 0 || t == C) ? -1 : t - 1);
+  }
+  template <int NV> static __device__ __forceinline__ void cdownv(const double* v, double* o) {
+    const int t = threadIdx.x;
+    takev<NV>(v, o, (t == C - 1 || t == 2 * C - 1) ? -1 : t + 1);
   }
   static __device__ __forceinline__ double up(double a) { return take(a, (int)threadIdx.x - 1); }
   static __device__ __forceinline__ double down(double a) { return take(a, (int)threadIdx.x + 1); }

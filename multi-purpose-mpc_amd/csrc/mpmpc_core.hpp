@@ -184,6 +184,25 @@ struct Solver {
     R r = sel(v < R(MIN_SCALING), R(1.0), v);
     return sel(r > R(MAX_SCALING), R(MAX_SCALING), r);
   }
+  // NV lane exchanges at once.  Where the lanes of an instance sit in different wavefronts (LaneBlock: horizons above 63) every
+  // exchange is a pass through LDS between two workgroup barriers, and the NV values of a step share one pass; on a
+  // wavefront these are the plain per-value DPP moves - the same instructions as before.
+  template <int NV> MPMPC_HD static void cup_n(const R* v, R* o) {
+    if constexpr (L::batched) L::template cupv<NV>(v, o);
+    else { MPMPC_UNROLL for (int i = 0; i < NV; ++i) o[i] = L::cup(v[i]); }
+  }
+  template <int NV> MPMPC_HD static void cdown_n(const R* v, R* o) {
+    if constexpr (L::batched) L::template cdownv<NV>(v, o);
+    else { MPMPC_UNROLL for (int i = 0; i < NV; ++i) o[i] = L::cdown(v[i]); }
+  }
+  template <int NV> MPMPC_HD static void up_n(const R* v, R* o) {
+    if constexpr (L::batched) L::template upv<NV>(v, o);
+    else { MPMPC_UNROLL for (int i = 0; i < NV; ++i) o[i] = L::up(v[i]); }
+  }
+  template <int NV> MPMPC_HD static void down_n(const R* v, R* o) {
+    if constexpr (L::batched) L::template downv<NV>(v, o);
+    else { MPMPC_UNROLL for (int i = 0; i < NV; ++i) o[i] = L::down(v[i]); }
+  }
   // w = A_k x_k + B_k u_k  (contribution of this stage to equality block k+1)
   MPMPC_HD void couple(const R v[5], R w[3]) const {
     w[0] = fma_(a[1], v[1], a[0] * v[0]);
@@ -191,15 +210,15 @@ struct Solver {
     w[2] = fma_(b[1], v[3], fma_(a[5], v[2], a[4] * v[0]));
   }
   MPMPC_HD void Aeq_mul(const R v[5], R r[3]) const {
-    R w[3];
+    R w[3], wu[3];
     couple(v, w);
+    up_n<3>(w, wu);
     MPMPC_UNROLL
-    for (int i = 0; i < 3; ++i) r[i] = fma_(mI[i], v[i], L::up(w[i]));
+    for (int i = 0; i < 3; ++i) r[i] = fma_(mI[i], v[i], wu[i]);
   }
   MPMPC_HD void AeqT_mul(const R nu[3], R t[5]) const {
     R nd[3];
-    MPMPC_UNROLL
-    for (int i = 0; i < 3; ++i) nd[i] = L::down(nu[i]);
+    down_n<3>(nu, nd);
     t[0] = fma_(a[4], nd[2], fma_(a[2], nd[1], fma_(a[0], nd[0], mI[0] * nu[0])));
     t[1] = fma_(a[3], nd[1], fma_(a[1], nd[0], mI[1] * nu[1]));
     t[2] = fma_(a[5], nd[2], mI[2] * nu[2]);

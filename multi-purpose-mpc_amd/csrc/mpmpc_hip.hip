@@ -1339,7 +1339,7 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
   const bool fullqn = full_weights(h->cfg);
   if (N + 1 > 64) {
     // Horizons above 63: one instance per workgroup of 2 / 4 wavefronts, the general solver, the whole solve in one launch
-    // (no packing, no tail lists, cold starts in the closed loop too); 67 / 134 KB of dynamic LDS per workgroup.
+    // (no packing, no tail lists, cold starts in the closed loop too); 77 / 154 KB of dynamic LDS per workgroup.
     if (tail_only) return MPMPC_OK;
     h->pend = h->pend2 = false;
     const SolverParams prm = make_params(h->st);

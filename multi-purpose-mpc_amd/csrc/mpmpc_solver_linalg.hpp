@@ -102,8 +102,7 @@
     const int last = chain_steps();
     auto fstep = [&](bool junction) {
       R Mr[9];
-      MPMPC_UNROLL
-      for (int i = 0; i < 9; ++i) Mr[i] = L::cup(M[i]);
+      cup_n<9>(M, Mr);
       // S = Dg - Mr Mr' (lower part), products subtracted inside the FMAs
       R S00 = fma_(-Mr[2], Mr[2], fma_(-Mr[1], Mr[1], fma_(-Mr[0], Mr[0], Dg[0])));
       R S10 = fma_(-Mr[5], Mr[2], fma_(-Mr[4], Mr[1], fma_(-Mr[3], Mr[0], Dg[1])));
@@ -184,7 +183,10 @@
     // A loop-back branch costs about as much as six of the step's fifteen instructions, and the compiler
     // may not partially unroll a loop of convergent (DPP) operations: four steps per trip by hand.
     auto in_step = [&]() {
-      R p0 = L::cup(y0), p1 = L::cup(y1), p2 = L::cup(y2);
+      const R yv[3] = {y0, y1, y2};
+      R pv[3];
+      cup_n<3>(yv, pv);
+      const R p0 = pv[0], p1 = pv[1], p2 = pv[2];
       y0 = fma_(Gin[2], p2, fma_(Gin[1], p1, fma_(Gin[0], p0, c0)));
       y1 = fma_(Gin[5], p2, fma_(Gin[4], p1, fma_(Gin[3], p0, c1)));
       y2 = fma_(Gin[8], p2, fma_(Gin[7], p1, fma_(Gin[6], p0, c2)));
@@ -235,7 +237,10 @@
     }
     R n0(0.0), n1(0.0), n2(0.0);
     auto out_step = [&]() {
-      R p0 = L::cdown(n0), p1 = L::cdown(n1), p2 = L::cdown(n2);
+      const R nv[3] = {n0, n1, n2};
+      R pv[3];
+      cdown_n<3>(nv, pv);
+      const R p0 = pv[0], p1 = pv[1], p2 = pv[2];
       n0 = fma_(Gout[2], p2, fma_(Gout[1], p1, fma_(Gout[0], p0, d0)));
       n1 = fma_(Gout[5], p2, fma_(Gout[4], p1, fma_(Gout[3], p0, d1)));
       n2 = fma_(Gout[8], p2, fma_(Gout[7], p1, fma_(Gout[6], p0, d2)));

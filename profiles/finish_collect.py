@@ -1,4 +1,5 @@
-"""After `gpurun -- 'bash profiles/collect_all.sh'`: condense gpurun_out/ into profiles/r4/ (run here, in the authoring container)."""
+"""After `gpurun -- 'bash profiles/collect_all.sh'`: condense gpurun_out/ into profiles/<round>/ (run here, in the authoring container):
+    python profiles/finish_collect.py [r5]"""
 import glob
 import json
 import os
@@ -8,20 +9,21 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RND = sys.argv[1] if len(sys.argv) > 1 else "r5"
 os.chdir(ROOT)
-for cmd in (["profiles/summarize.py", "r4"], ["profiles/summarize_wait.py", "r4w", "r4"], ["profiles/kernel_resources.py", "r4"]):
+for cmd in (["profiles/summarize.py", RND], ["profiles/summarize_wait.py", RND + "w", RND], ["profiles/kernel_resources.py", RND]):
     subprocess.run([sys.executable] + cmd, check=True, stdout=subprocess.DEVNULL)
-for f in glob.glob("gpurun_out/r4/phases_*.txt") + ["gpurun_out/rollout_warm.txt", "gpurun_out/torchrun_1rank.json"]:
-    shutil.copy(f, "profiles/r4/")
-src = json.load(open("profiles/r4/pmc_summary.json"))["library_source_hash"]
+for f in glob.glob("gpurun_out/%s/phases_*.txt" % RND) + ["gpurun_out/rollout_warm.txt", "gpurun_out/torchrun_1rank.json", "gpurun_out/branch_agreement.txt", "gpurun_out/long_horizon.txt"]:
+    shutil.copy(f, "profiles/%s/" % RND)
+src = json.load(open("profiles/%s/pmc_summary.json" % RND))["library_source_hash"]
 if os.path.exists("gpurun_out/single_process_2handles.json"):
-    shutil.copy("gpurun_out/single_process_2handles.json", "profiles/r4/")
+    shutil.copy("gpurun_out/single_process_2handles.json", "profiles/%s/" % RND)
 print("library", src, "tree", open("multi-purpose-mpc_amd/csrc/libmpmpc.srchash").read().strip())
-for f in sorted(glob.glob("profiles/r4/bench_*.json")):
+for f in sorted(glob.glob("profiles/%s/bench_*.json" % RND)):
     d = json.load(open(f))
     print("%-28s %6.2f M  %.4f ms  kernel %.4f ms  %s  ipm %.2f" % (os.path.basename(f), d["value"] / 1e6, d["ms_per_step"], d["roofline"]["avg_ms"],
                                                                  d.get("status_counts"), d["iters"]["ipm_mean"]))
-w = json.load(open("profiles/r4/pmc_wait_r4w.json"))
+w = json.load(open("profiles/%s/pmc_wait_%sw.json" % (RND, RND)))
 for wl in ("cfg2", "cfg4", "big"):
     for k, v in w[wl].items():
         if "reduced" in k:
