@@ -28,6 +28,19 @@ __device__ __forceinline__ double rcp_fast_(double a) { return __builtin_amdgcn_
 __device__ __forceinline__ double abs_(double a) { return __builtin_fabs(a); }
 __device__ __forceinline__ double max_(double a, double b) { return __builtin_fmax(a, b); }   // v_max_f64
 __device__ __forceinline__ double min_(double a, double b) { return __builtin_fmin(a, b); }   // v_min_f64
+// v_max_f64 / v_min_f64 as ONE instruction, for the steps of a wave reduction: through __builtin_fmax the compiler (IEEE mode)
+// puts a canonicalising v_max x, x, x in front of every operand it cannot prove quiet - and a value that has come through a
+// DPP move is one.  The instruction itself quiets what it returns and returns the other operand for a NaN.
+__device__ __forceinline__ double max_raw_(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double min_raw_(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ double tan_(double a) { return ::tan(a); }
 __device__ __forceinline__ double atan_(double a) { return ::atan(a); }
 __device__ __forceinline__ double sel(bool m, double a, double b) { return m ? a : b; }
@@ -225,8 +238,8 @@ struct LaneGpu {
     if constexpr (G == 64) a = f(from_lower(a), from_upper(a));
     return a;
   }
-  static __device__ __forceinline__ double gmax(double a) { return bfly(a, [](double x, double y) { return __builtin_fmax(x, y); }); }
-  static __device__ __forceinline__ double gmin(double a) { return bfly(a, [](double x, double y) { return __builtin_fmin(x, y); }); }
+  static __device__ __forceinline__ double gmax(double a) { return bfly(a, [](double x, double y) { return max_raw_(x, y); }); }
+  static __device__ __forceinline__ double gmin(double a) { return bfly(a, [](double x, double y) { return min_raw_(x, y); }); }
   static __device__ __forceinline__ double gsum(double a) { return bfly(a, [](double x, double y) { return x + y; }); }
   static __device__ __forceinline__ bool gany(bool m) {
     unsigned long long b = __ballot(m);
@@ -390,26 +403,48 @@ struct LaneBlock {
   }
   template <int NV> static __device__ __forceinline__ void upv(const double* v, double* o) { takev<NV>(v, o, (int)threadIdx.x - 1); }
   template <int NV> static __device__ __forceinline__ void downv(const double* v, double* o) { takev<NV>(v, o, (int)threadIdx.x + 1); }
+  // G = 128: a chain of the twisted factorisation IS a wavefront (lanes [0, 64) climb, lanes [64, 128) descend), so the
+  // one-lane shifts along the chains - what the sequential sweeps of a factorisation or a solve are made of, some hundred per
+  // interior-point iteration - are wavefront shifts in registers (DPP, zero inflow at lane 0 / lane 63 = the chain heads) and
+  // need no barrier at all.  G = 256: a chain spans two wavefronts, the shift goes through LDS.
   template <int NV> static __device__ __forceinline__ void cupv(const double* v, double* o) {
-    const int t = threadIdx.x;
-    takev<NV>(v, o, (t == 0 || t == C) ? -1 : t - 1);
+    if constexpr (G == 128) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) o[i] = dpp_shift<DPP_WAVE_SHR1>(v[i]);
+    } else {
+      const int t = threadIdx.x;
+      takev<NV>(v, o, (t == 0 || t == C) ? -1 : t - 1);
+    }
   }
   template <int NV> static __device__ __forceinline__ void cdownv(const double* v, double* o) {
-    const int t = threadIdx.x;
-    takev<NV>(v, o, (t == C - 1 || t == 2 * C - 1) ? -1 : t + 1);
+    if constexpr (G == 128) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) o[i] = dpp_shift<DPP_WAVE_SHL1>(v[i]);
+    } else {
+      const int t = threadIdx.x;
+      takev<NV>(v, o, (t == C - 1 || t == 2 * C - 1) ? -1 : t + 1);
+    }
   }
   static __device__ __forceinline__ double up(double a) { return take(a, (int)threadIdx.x - 1); }
   static __device__ __forceinline__ double down(double a) { return take(a, (int)threadIdx.x + 1); }
   // chain layout: lanes [C, 2C) reversed; one-lane shifts along the chains with zero inflow at the chain heads
   static __device__ __forceinline__ double mirror(double a) {
     const int t = threadIdx.x;
-    return take(a, t < C ? t : 3 * C - 1 - t);
+    if constexpr (G == 128) {
+      // (the second wavefront reverses itself: a lane permutation inside the wave, ds_bpermute, no barrier)
+      if (t >= 64) a = __shfl(a, 127 - t, 64);
+      return a;
+    } else {
+      return take(a, t < C ? t : 3 * C - 1 - t);
+    }
   }
   static __device__ __forceinline__ double cup(double a) {
+    if constexpr (G == 128) return dpp_shift<DPP_WAVE_SHR1>(a);
     const int t = threadIdx.x;
     return take(a, (t == 0 || t == C) ? -1 : t - 1);
   }
   static __device__ __forceinline__ double cdown(double a) {
+    if constexpr (G == 128) return dpp_shift<DPP_WAVE_SHL1>(a);
     const int t = threadIdx.x;
     return take(a, (t == C - 1 || t == 2 * C - 1) ? -1 : t + 1);
   }
@@ -425,8 +460,8 @@ struct LaneBlock {
     __syncthreads();
     return t;
   }
-  static __device__ __forceinline__ double gmax(double a) { return reduce(a, [](double x, double y) { return __builtin_fmax(x, y); }); }
-  static __device__ __forceinline__ double gmin(double a) { return reduce(a, [](double x, double y) { return __builtin_fmin(x, y); }); }
+  static __device__ __forceinline__ double gmax(double a) { return reduce(a, [](double x, double y) { return max_(x, y); }); }
+  static __device__ __forceinline__ double gmin(double a) { return reduce(a, [](double x, double y) { return min_(x, y); }); }
   static __device__ __forceinline__ double gsum(double a) { return reduce(a, [](double x, double y) { return x + y; }); }
   static __device__ __forceinline__ bool gany(bool m) { return __syncthreads_or(m ? 1 : 0) != 0; }
   static __device__ __forceinline__ bool wany(bool m) { return __syncthreads_or(m ? 1 : 0) != 0; }

@@ -758,10 +758,16 @@
     const Mk E = L::template cr_elim<D>();
     // nu_e = inv(L_e)' (y_e - Ua nu_a - Ub nu_b),  nu_a from lane e - D, nu_b from lane e + D
     const R a0 = L::template rshr<D>(n0), a1 = L::template rshr<D>(n1), c0 = L::template rshl<D>(n0), c1 = L::template rshl<D>(n1);
-    const R r0 = y0 - fma_(Gin[1], a1, Gin[0] * a0) - fma_(Gout[1], c1, Gout[0] * c0);
-    const R r1 = y1 - fma_(Gin[3], a1, Gin[2] * a0) - fma_(Gout[3], c1, Gout[2] * c0);
-    n0 = sel(E, fma_(Li[1], r1, Li[0] * r0), n0);
-    n1 = sel(E, Li[2] * r1, n1);
+    // (the level's lanes as ONE region: on the device only the lanes of E execute it, the selects inside fold away and nu is
+    //  written in place under the execution mask; the lock-step emulation runs the body on every lane and the selects do the
+    //  masking - the same values either way.  Not for the rank-one kernels (RKS): there it costs five registers too many.)
+    auto level = [&] {
+      const R r0 = fma_(-Gout[1], c1, fma_(-Gout[0], c0, fma_(-Gin[1], a1, fma_(-Gin[0], a0, y0))));
+      const R r1 = fma_(-Gout[3], c1, fma_(-Gout[2], c0, fma_(-Gin[3], a1, fma_(-Gin[2], a0, y1))));
+      n0 = sel(E, fma_(Li[1], r1, Li[0] * r0), n0);
+      n1 = sel(E, Li[2] * r1, n1);
+    };
+    if constexpr (RKS == 0) L::when(E, level); else level();
   }
   MPMPC_HD void s_solve_cr2(const R bv[2], R nu[2]) const {
     const R zero(0.0);
