@@ -189,6 +189,17 @@ struct LaneGpu {
     int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(a), 0x143, 0xC, 0xf, false);
     return __hiloint2double(hi, lo);
   }
+  // ---- junction of the two chains (Solver::end_to_mid / mid_to_end): lane C - 1 of an instance gets a of its lane 2C - 1, and
+  // back.  What the other lanes get is not used (the caller masks).  C = 16: up the rows with row_bcast:15 (one move per
+  // dword); down them there is no single move, so row 1 is reversed and the wavefront shifted by one lane (two moves per
+  // dword - without the pre-mask, the zero inflow and the second select of the general form).  C = 32: the half swap / row_bcast:31.
+  static constexpr bool junction_moves = (C != G);
+  static __device__ __forceinline__ double end_to_mid(double a) {
+    if constexpr (C == 16) return dpp_shift<DPP_WAVE_SHL1>(mirror(a)); else return from_upper(a);
+  }
+  static __device__ __forceinline__ double mid_to_end(double a) {
+    if constexpr (C == 16) return bcast15(a); else return bcast31(a);
+  }
   // Inclusive prefix sum along the lanes of an instance (lane order): four shifted adds inside the rows of 16, then the
   // total of the row below (G >= 32) and of the half below (G = 64) - 5 / 6 steps instead of G - 1 dependent ones.
   static __device__ __forceinline__ double gscan(double a) {
@@ -359,6 +370,7 @@ struct LaneBlock {
   static constexpr int waves = G / 64;
   static constexpr int cold_slots = SLOTS;
   static constexpr bool batched = true;       // several values of a step share one pass through LDS (Solver::cup_n)
+  static constexpr bool junction_moves = false;
   static constexpr int xrows = 9;             // exchange rows: the widest batch is the 3 x 3 block of a factorisation step
   static constexpr size_t lds_bytes = sizeof(double) * ((size_t)(SLOTS + xrows) * G + 8);
 

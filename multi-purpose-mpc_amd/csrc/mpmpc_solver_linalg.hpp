@@ -15,6 +15,20 @@
   // where M_in is the coupling block received from the chain predecessor and M_own the one handed on
   // (L_{k+1,k} going up, U_{k-1,k} going down).  The end lane keeps M_own itself in Gout: its only
   // outward neighbour is mid, reached through the two junction steps of s_solve.
+  // ---- the two moves of a junction step: the value the END lane of the descending chain holds, on the meeting lane (zero
+  // elsewhere), and back.  In chain layout that is lane 2C - 1 -> lane C - 1 of the instance: the general form goes through
+  // mirror + a one-lane shift (two moves and two selects more per dword); a wavefront backend does it with ONE row / half
+  // swap (v_permlane16_swap / v_permlane32_swap: LaneGpu::end_to_mid).  Same values on every lane either way.
+  MPMPC_HD R end_to_mid(const R& q) const {
+    const R zero(0.0);
+    if constexpr (L::junction_moves) return sel(is_mid, L::end_to_mid(q), zero);
+    else return sel(is_mid, L::down(L::mirror(sel(is_end, q, zero))), zero);
+  }
+  MPMPC_HD R mid_to_end(const R& v) const {
+    const R zero(0.0);
+    if constexpr (L::junction_moves) return sel(is_end, L::mid_to_end(v), zero);
+    else return sel(is_end, L::mirror(L::up(sel(is_mid, v, zero))), zero);
+  }
   MPMPC_HD int chain_steps() const {
     const int C = L::split;
     int fwd = N + 1 < C - 1 - off_ ? N + 1 : C - 1 - off_, bwd = N - C + off_ + 1;
@@ -114,7 +128,7 @@
         // junction: both chains have settled; mid also loses the block of the end lane
         R Mx[9];
         MPMPC_UNROLL
-        for (int i = 0; i < 9; ++i) Mx[i] = sel(is_mid, L::down(L::mirror(M[i])), R(0.0));
+        for (int i = 0; i < 9; ++i) Mx[i] = end_to_mid(M[i]);
         S00 = fma_(-Mx[2], Mx[2], fma_(-Mx[1], Mx[1], fma_(-Mx[0], Mx[0], S00)));
         S10 = fma_(-Mx[5], Mx[2], fma_(-Mx[4], Mx[1], fma_(-Mx[3], Mx[0], S10)));
         S11 = fma_(-Mx[5], Mx[5], fma_(-Mx[4], Mx[4], fma_(-Mx[3], Mx[3], S11)));
@@ -205,9 +219,9 @@
       R t1 = fma_(Gout[5], y2, fma_(Gout[4], y1, Gout[3] * y0));
       R t2 = fma_(Gout[8], y2, fma_(Gout[7], y1, Gout[6] * y0));
       const R zero(0.0);
-      t0 = sel(is_mid, L::down(L::mirror(t0)), zero);
-      t1 = sel(is_mid, L::down(L::mirror(t1)), zero);
-      t2 = sel(is_mid, L::down(L::mirror(t2)), zero);
+      t0 = end_to_mid(t0);
+      t1 = end_to_mid(t1);
+      t2 = end_to_mid(t2);
       R e0 = c0 - Li[0] * t0;
       R e1 = c1 - fma_(Li[2], t1, Li[1] * t0);
       R e2 = c2 - fma_(Li[5], t2, fma_(Li[4], t1, Li[3] * t0));
@@ -224,9 +238,9 @@
       // outward junction: nu of mid is final (it has no successor); the end lane takes it through M_own'
       MPMPC_SERIAL_BEGIN();
       const R zero(0.0);
-      R m0 = sel(is_end, L::mirror(L::up(d0)), zero);
-      R m1 = sel(is_end, L::mirror(L::up(d1)), zero);
-      R m2 = sel(is_end, L::mirror(L::up(d2)), zero);
+      R m0 = mid_to_end(d0);
+      R m1 = mid_to_end(d1);
+      R m2 = mid_to_end(d2);
       R w0 = fma_(Gout[6], m2, fma_(Gout[3], m1, Gout[0] * m0));
       R w1 = fma_(Gout[7], m2, fma_(Gout[4], m1, Gout[1] * m0));
       R w2 = fma_(Gout[8], m2, fma_(Gout[5], m1, Gout[2] * m0));
@@ -540,7 +554,7 @@
       if (junction) {
         R Mx[4];
         MPMPC_UNROLL
-        for (int i = 0; i < 4; ++i) Mx[i] = sel(is_mid, L::down(L::mirror(M[i])), R(0.0));
+        for (int i = 0; i < 4; ++i) Mx[i] = end_to_mid(M[i]);
         S00 = fma_(-Mx[1], Mx[1], fma_(-Mx[0], Mx[0], S00));
         S10 = fma_(-Mx[3], Mx[1], fma_(-Mx[2], Mx[0], S10));
         S11 = fma_(-Mx[3], Mx[3], fma_(-Mx[2], Mx[2], S11));
@@ -724,7 +738,7 @@
       for (int i = 0; i < 4; ++i) Gout[i] = sel(is_end, M[i], Gout[i]);          // the end lane keeps M_own (as in the sequential scheme)
       R Mx[4];
       MPMPC_UNROLL
-      for (int i = 0; i < 4; ++i) Mx[i] = sel(is_mid, L::down(L::mirror(sel(is_end, M[i], zero))), zero);
+      for (int i = 0; i < 4; ++i) Mx[i] = end_to_mid(M[i]);
       Dg[0] = fma_(-Mx[1], Mx[1], fma_(-Mx[0], Mx[0], Dg[0]));
       Dg[1] = fma_(-Mx[3], Mx[1], fma_(-Mx[2], Mx[0], Dg[1]));
       Dg[2] = fma_(-Mx[3], Mx[3], fma_(-Mx[2], Mx[2], Dg[2]));
@@ -804,12 +818,12 @@
     MPMPC_SERIAL_BEGIN();                                                           // (census: useful on the two lanes of the junction only)
     const R ye0 = Li[0] * b0, ye1 = fma_(Li[2], b1, Li[1] * b0);                   // valid on the end lane (and, pre-update, on mid)
     const R q0 = fma_(Gout[1], ye1, Gout[0] * ye0), q1 = fma_(Gout[3], ye1, Gout[2] * ye0);      // M y_end on the end lane
-    const R qm0 = sel(is_mid, L::down(L::mirror(sel(is_end, q0, zero))), zero), qm1 = sel(is_mid, L::down(L::mirror(sel(is_end, q1, zero))), zero);
+    const R qm0 = end_to_mid(q0), qm1 = end_to_mid(q1);
     const R bm0 = b0 - qm0, bm1 = b1 - qm1;
     const R ym0 = Li[0] * bm0, ym1 = fma_(Li[2], bm1, Li[1] * bm0);
     const R nm0 = fma_(Li[1], ym1, Li[0] * ym0), nm1 = Li[2] * ym1;               // nu of the meeting stage (on mid)
     // to the end lane: M' nu_mid
-    const R me0 = sel(is_end, L::mirror(L::up(sel(is_mid, nm0, zero))), zero), me1 = sel(is_end, L::mirror(L::up(sel(is_mid, nm1, zero))), zero);
+    const R me0 = mid_to_end(nm0), me1 = mid_to_end(nm1);
     const R re0 = ye0 - fma_(Gout[2], me1, Gout[0] * me0), re1 = ye1 - fma_(Gout[3], me1, Gout[1] * me0);
     const R ne0 = fma_(Li[1], re1, Li[0] * re0), ne1 = Li[2] * re1;
     R n0 = sel(is_mid, nm0, sel(is_end, ne0, zero)), n1 = sel(is_mid, nm1, sel(is_end, ne1, zero));
@@ -863,8 +877,8 @@
       R t0 = fma_(Gout[1], y1, Gout[0] * y0);
       R t1 = fma_(Gout[3], y1, Gout[2] * y0);
       const R zero(0.0);
-      t0 = sel(is_mid, L::down(L::mirror(t0)), zero);
-      t1 = sel(is_mid, L::down(L::mirror(t1)), zero);
+      t0 = end_to_mid(t0);
+      t1 = end_to_mid(t1);
       R e0 = c0 - Li[0] * t0;
       R e1 = c1 - fma_(Li[2], t1, Li[1] * t0);
       R p0 = L::cup(y0), p1 = L::cup(y1);
@@ -878,8 +892,8 @@
       // outward junction: nu of mid is final; the end lane takes it through M_own'
       MPMPC_SERIAL_BEGIN();
       const R zero(0.0);
-      R m0 = sel(is_end, L::mirror(L::up(d0)), zero);
-      R m1 = sel(is_end, L::mirror(L::up(d1)), zero);
+      R m0 = mid_to_end(d0);
+      R m1 = mid_to_end(d1);
       R w0 = fma_(Gout[2], m1, Gout[0] * m0);
       R w1 = fma_(Gout[3], m1, Gout[1] * m0);
       d0 = d0 - fma_(Li[1], w1, Li[0] * w0);
