@@ -288,6 +288,7 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
     auto rl_of = [&](int b) { const int j = JB[b]; return SOFT ? s.x[j] + w_of(j) - lo_of(b) - s.sl[j] : s.x[j] - lo_of(b) - s.sl[j]; };
     auto ru_of = [&](int b) { const int j = JB[b]; return SOFT ? hi_of(b) - s.x[j] - w_of(j) - s.su[j] : hi_of(b) - s.x[j] - s.su[j]; };
     auto rpin_of = [&](int b) { const int j = JB[b]; return sel(bx.pin[j], s.x[j] - lo_of(b), zero); };
+    auto rpin_raw = [&](int b) { const int j = JB[b]; return s.x[j] - lo_of(b); };       // (where a select on pin follows anyway)
     for (int it = 0; it <= st.ipm_max_iter; ++it) {
       R mu;
       {
@@ -313,7 +314,8 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
         for (int b = 0; b < 2; ++b) {
           const int j = JB[b];
           res = max_(res, sel(val[j], max_(max_(abs_(rd[j]), abs_(rpin_of(b))), max_(sel(bx.Lm[j], abs_(rl_of(b)), zero), sel(bx.Um[j], abs_(ru_of(b)), zero))), zero));
-          msum = msum + sel(bx.Lm[j], s.sl[j] * s.zl[j], zero) + sel(bx.Um[j], s.su[j] * s.zu[j], zero);
+          // (a side without a bound keeps a finite slack and an exactly zero multiplier - see above: its product is an exact zero)
+          msum = msum + s.sl[j] * s.zl[j] + s.su[j] * s.zu[j];
         }
         MPMPC_UNROLL
         for (int j = 0; j < 3; ++j) L::cold_put(K_RD + j, rd[j]);
@@ -410,10 +412,10 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
             const int j = JB[b];
             if constexpr (SOFT) {
               cul[b] = fma_(s.zu[j], ru_of(b), rcu[b]) * isu[b] - fma_(s.zl[j], rl_of(b), rcl[b]) * isl[b];
-              rhs[j] = fma_(kap[b], cul[b], -L::cold_get(K_RD + j)) - sel(bx.pin[j], rpin_of(b) * ireg, zero);
+              rhs[j] = fma_(kap[b], cul[b], -L::cold_get(K_RD + j)) - sel(bx.pin[j], rpin_raw(b) * ireg, zero);
             } else {
               rhs[j] = -L::cold_get(K_RD + j) - fma_(s.zl[j], rl_of(b), rcl[b]) * isl[b] + fma_(s.zu[j], ru_of(b), rcu[b]) * isu[b] -
-                       sel(bx.pin[j], rpin_of(b) * ireg, zero);
+                       sel(bx.pin[j], rpin_raw(b) * ireg, zero);
             }
           }
           nreq[0] = -L::cold_get(K_RP); nreq[1] = -L::cold_get(K_RP + 1);
@@ -458,10 +460,11 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
           dsu[b] = -ex + ru_of(b);
           dzl[b] = -fma_(s.zl[j], dsl[b], rcl[b]) * isl[b];
           dzu[b] = -fma_(s.zu[j], dsu[b], rcu[b]) * isu[b];
-          dpi[b] = sel(bx.pin[j], (rpin_of(b) + dx[j]) * ireg, zero);
+          dpi[b] = sel(bx.pin[j], (rpin_raw(b) + dx[j]) * ireg, zero);
           blk = max_(blk, max_(-dsl[b] * isl[b], -dsu[b] * isu[b]));
           // (the ratios -dz / z only size the step, which keeps 0.5 % from the boundary anyway: the reciprocal's seed will do)
-          blk = max_(blk, max_(sel(bx.Lm[j], -dzl[b] * rcp_fast_(s.zl[j]), zero), sel(bx.Um[j], -dzu[b] * rcp_fast_(s.zu[j]), zero)));
+          // (a side without a bound: dz = 0 over z = 0 is 0 x inf = NaN, which max_ - v_max_f64, fmax - passes over)
+          blk = max_(blk, max_(-dzl[b] * rcp_fast_(s.zl[j]), -dzu[b] * rcp_fast_(s.zu[j])));
         }
         blk = L::gmax(blk);
         const R ratio = sel(blk > zero, rcp_(blk), R(1e300));
@@ -471,8 +474,8 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
           MPMPC_UNROLL
           for (int b = 0; b < 2; ++b) {
             const int j = JB[b];
-            ms = ms + sel(bx.Lm[j], fma_(alpha_aff, dsl[b], s.sl[j]) * fma_(alpha_aff, dzl[b], s.zl[j]), zero) +
-                 sel(bx.Um[j], fma_(alpha_aff, dsu[b], s.su[j]) * fma_(alpha_aff, dzu[b], s.zu[j]), zero);
+            ms = ms + fma_(alpha_aff, dsl[b], s.sl[j]) * fma_(alpha_aff, dzl[b], s.zl[j]) +
+                 fma_(alpha_aff, dsu[b], s.su[j]) * fma_(alpha_aff, dzu[b], s.zu[j]);
           }
           const R mu_aff = L::gsum(ms) * inb;
           R sg = mu_aff * rcp_(max_(mu, R(1e-300)));

@@ -251,7 +251,8 @@ struct ReducedTSolver : Solver<L, false, true, false, CR, 11> {
         for (int b = 0; b < NB; ++b) {
           const int j = JB[b];
           res = max_(res, sel(val[j], max_(abs_(rd[j]), max_(sel(bx.Lm[j], abs_(rl_of(b)), zero), sel(bx.Um[j], abs_(ru_of(b)), zero))), zero));
-          msum = msum + sel(bx.Lm[j], s.sl[j] * s.zl[j], zero) + sel(bx.Um[j], s.su[j] * s.zu[j], zero);
+          // (a side without a bound keeps a finite slack and an exactly zero multiplier: its product is an exact zero)
+          msum = msum + s.sl[j] * s.zl[j] + s.su[j] * s.zu[j];
         }
         MPMPC_UNROLL
         for (int j = 0; j < 4; ++j) L::cold_put(S_RD + j, rd[j]);
@@ -321,7 +322,8 @@ struct ReducedTSolver : Solver<L, false, true, false, CR, 11> {
           dzu[b] = -fma_(s.zu[j], dsu[b], rcu[b]) * isu[b];
           blk = max_(blk, max_(-dsl[b] * isl[b], -dsu[b] * isu[b]));
           // (the ratios -dz / z only size the step, which keeps 0.5 % from the boundary anyway: the reciprocal's seed will do)
-          blk = max_(blk, max_(sel(bx.Lm[j], -dzl[b] * rcp_fast_(s.zl[j]), zero), sel(bx.Um[j], -dzu[b] * rcp_fast_(s.zu[j]), zero)));
+          // (a side without a bound: dz = 0 over z = 0 is 0 x inf = NaN, which max_ - v_max_f64, fmax - passes over)
+          blk = max_(blk, max_(-dzl[b] * rcp_fast_(s.zl[j]), -dzu[b] * rcp_fast_(s.zu[j])));
         }
         blk = L::gmax(blk);
         const R ratio = sel(blk > zero, rcp_(blk), R(1e300));
@@ -331,8 +333,8 @@ struct ReducedTSolver : Solver<L, false, true, false, CR, 11> {
           MPMPC_UNROLL
           for (int b = 0; b < NB; ++b) {
             const int j = JB[b];
-            ms = ms + sel(bx.Lm[j], fma_(alpha_aff, dsl[b], s.sl[j]) * fma_(alpha_aff, dzl[b], s.zl[j]), zero) +
-                 sel(bx.Um[j], fma_(alpha_aff, dsu[b], s.su[j]) * fma_(alpha_aff, dzu[b], s.zu[j]), zero);
+            ms = ms + fma_(alpha_aff, dsl[b], s.sl[j]) * fma_(alpha_aff, dzl[b], s.zl[j]) +
+                 fma_(alpha_aff, dsu[b], s.su[j]) * fma_(alpha_aff, dzu[b], s.zu[j]);
           }
           const R mu_aff = L::gsum(ms) * inb;
           R sg = mu_aff * rcp_(max_(mu, R(1e-300)));
