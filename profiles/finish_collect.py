@@ -13,7 +13,7 @@ RND = sys.argv[1] if len(sys.argv) > 1 else "r5"
 os.chdir(ROOT)
 for cmd in (["profiles/summarize.py", RND], ["profiles/summarize_wait.py", RND + "w", RND], ["profiles/kernel_resources.py", RND]):
     subprocess.run([sys.executable] + cmd, check=True, stdout=subprocess.DEVNULL)
-for f in glob.glob("gpurun_out/%s/phases_*.txt" % RND) + ["gpurun_out/rollout_warm.txt", "gpurun_out/torchrun_1rank.json", "gpurun_out/branch_agreement.txt", "gpurun_out/long_horizon.txt"]:
+for f in glob.glob("gpurun_out/%s/phases_*.txt" % RND) + ["gpurun_out/rollout_warm.txt", "gpurun_out/torchrun_1rank.json", "gpurun_out/branch_agreement.txt", "gpurun_out/long_horizon.txt", "gpurun_out/depth_sweep.txt"]:
     shutil.copy(f, "profiles/%s/" % RND)
 src = json.load(open("profiles/%s/pmc_summary.json" % RND))["library_source_hash"]
 if os.path.exists("gpurun_out/single_process_2handles.json"):
