@@ -168,8 +168,10 @@ __global__ __launch_bounds__(64) void mpmpc_solve_kernel(mpmpc_config cfg, Solve
 
 // K2b: the general solve kernel for horizons above 63 - one instance per WORKGROUP of G = 128 / 256 threads (2 / 4
 // wavefronts), one lane per stage as before; the lanes of different wavefronts talk through LDS (lane_gpu.hpp: LaneBlock).
-// Same Solver code, the whole solve in one launch (mode 0), cold starts.  FQ: full weight matrices.
-template <int G, bool FQ>
+// Same Solver code, the whole solve in one launch (mode 0), cold starts.  VAR as for mpmpc_solve_kernel: 0 = the full problem,
+// 1 = full weight matrices, 2 = the polish on the (e_y, e_psi, kappa) problem where the time state separates (the reference's
+// own weights: 2 x 2 blocks in the sweeps instead of 3 x 3, three entries per lane instead of five, fewer iterations).
+template <int G, int VAR>
 __global__ __launch_bounds__(G) void mpmpc_solve_block_kernel(mpmpc_config cfg, SolverParams st, int B, AssembleIn ain,
                                                               double* __restrict__ z, double* __restrict__ u0,
                                                               int* __restrict__ status, int* __restrict__ iters,
@@ -179,10 +181,10 @@ __global__ __launch_bounds__(G) void mpmpc_solve_block_kernel(mpmpc_config cfg, 
   const int k = L::stage() - lane_offset(G, G / 2, cfg.N);
   double fields[MPMPC_NUM_FIELDS];
   assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
-  Solver<L, FQ> s;
+  Solver<L, VAR == 1, VAR == 2> s;
   double woff[7];
   weight_offdiag(cfg, woff);
-  s.template run<false, true>(fields, B, inst, k, cfg.N, st, 0, 0, 0, FQ ? woff : nullptr);
+  s.template run<false, true>(fields, B, inst, k, cfg.N, st, 0, 0, 0, VAR == 1 ? woff : nullptr);
   s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y, nullptr, 0);
 }
 
@@ -1343,19 +1345,20 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
     if (tail_only) return MPMPC_OK;
     h->pend = h->pend2 = false;
     const SolverParams prm = make_params(h->st);
-#define LAUNCH_BLOCK(GG, FF)                                                                                                          \
+#define LAUNCH_BLOCK(GG, VV)                                                                                                          \
   do {                                                                                                                                \
     static bool attr_set = false;                                                                                                     \
     if (!attr_set) {                                                                                                                  \
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpmpc_solve_block_kernel<GG, FF>),                                  \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpmpc_solve_block_kernel<GG, VV>),                                  \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LaneBlock<GG>::lds_bytes));                        \
       attr_set = true;                                                                                                                \
     }                                                                                                                                 \
-    hipLaunchKernelGGL((mpmpc_solve_block_kernel<GG, FF>), dim3(B), dim3(GG), LaneBlock<GG>::lds_bytes, h->stream, h->cfg, prm, B, \
+    hipLaunchKernelGGL((mpmpc_solve_block_kernel<GG, VV>), dim3(B), dim3(GG), LaneBlock<GG>::lds_bytes, h->stream, h->cfg, prm, B, \
                        ain, h->z, h->u0, h->status, h->iters, h->resid, y_out);                                                       \
   } while (0)
-    if (N + 1 <= 128) { if (fullqn) LAUNCH_BLOCK(128, true); else LAUNCH_BLOCK(128, false); }
-    else { if (fullqn) LAUNCH_BLOCK(256, true); else LAUNCH_BLOCK(256, false); }
+    const bool redb = !fullqn && reducible(h->cfg, h->st);
+    if (N + 1 <= 128) { if (fullqn) LAUNCH_BLOCK(128, 1); else if (redb) LAUNCH_BLOCK(128, 2); else LAUNCH_BLOCK(128, 0); }
+    else { if (fullqn) LAUNCH_BLOCK(256, 1); else if (redb) LAUNCH_BLOCK(256, 2); else LAUNCH_BLOCK(256, 0); }
 #undef LAUNCH_BLOCK
     HIP_TRY(hipGetLastError());
     return MPMPC_OK;

@@ -13,7 +13,7 @@
 using namespace mpmpc;
 static_assert(EMU_W == 128 || EMU_W == 256, "build with -DMPMPC_EMU_W=128 or 256");
 
-template <bool FQ>
+template <int VAR>
 static void solve_wide(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
                        int* status, int* iters, double* resid, double* y) {
   constexpr int G = EMU_W, C = EMU_W / 2;
@@ -22,23 +22,25 @@ static void solve_wide(const mpmpc_config* cfg, const mpmpc_settings* st, const 
   for (int w = 0; w < B; ++w) {
     VI inst = L::slot() + w;
     VI k = L::stage() - lane_offset(G, C, cfg->N);
-    Solver<L, FQ> s;
+    using S = Solver<L, VAR == 1, VAR == 2>;
+    S s;
     double woff7[7];
     weight_offdiag(*cfg, woff7);
     typename L::real fields[MPMPC_NUM_FIELDS];
-    Solver<L, FQ>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
-    s.template run<false, true>(fields, B, inst, k, cfg->N, make_params(*st), 0, VI(0), VI(0), FQ ? woff7 : nullptr);
+    S::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    s.template run<false, true>(fields, B, inst, k, cfg->N, make_params(*st), 0, VI(0), VI(0), VAR == 1 ? woff7 : nullptr);
     s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y, nullptr, ld);
   }
 }
 
-// the kernel the launcher picks for a horizon above 63: the general solver, one instance per workgroup; full weights (FQ)
-// where a weight matrix has off-diagonal entries.  -1: the horizon does not belong to this width.
+// the kernel the launcher picks for a horizon above 63: the general solver, one instance per workgroup; full weights
+// where a weight matrix has off-diagonal entries, the reduced polish where the time state separates.  -1: the horizon does not belong to this width.
 extern "C" int emuw_width() { return EMU_W; }
 extern "C" int emuw_solve(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
                           int* status, int* iters, double* resid, double* y) {
   if (stage_ld(cfg->N) != EMU_W) return -1;
-  if (full_weights(*cfg)) solve_wide<true>(cfg, st, qp, B, z, u0, status, iters, resid, y);
-  else solve_wide<false>(cfg, st, qp, B, z, u0, status, iters, resid, y);
+  if (full_weights(*cfg)) solve_wide<1>(cfg, st, qp, B, z, u0, status, iters, resid, y);
+  else if (reducible(*cfg, *st)) solve_wide<2>(cfg, st, qp, B, z, u0, status, iters, resid, y);      // (the launcher's choice: mpmpc_hip.hip, launch_solve)
+  else solve_wide<0>(cfg, st, qp, B, z, u0, status, iters, resid, y);
   return 0;
 }
