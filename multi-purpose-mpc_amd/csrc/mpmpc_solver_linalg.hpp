@@ -637,31 +637,40 @@
     Dg[1] = fma_(-gb[3], gb[2], fma_(-gb[1], gb[0], Dg[1]));
     Dg[2] = fma_(-gb[3], gb[3], fma_(-gb[1], gb[1], Dg[2]));
     // Ua = inv(L) S_ea = inv(L) Cm
-    R ga[4];
-    {
-      R Ua[4];
-      Ua[0] = i00 * Cm[0]; Ua[1] = i00 * Cm[1];
-      Ua[2] = fma_(i11, Cm[2], i10 * Cm[0]); Ua[3] = fma_(i11, Cm[3], i10 * Cm[1]);
-      MPMPC_UNROLL
-      for (int i = 0; i < 4; ++i) Gin[i] = Gin[i] + Ua[i];
-      // to the lower neighbour a (lane e - D):  D_a -= Ua'Ua
+    // (The LAST level, D = 8, eliminates position 7, whose lower neighbour would be position -1: nothing of a row receives
+    //  what it sends downwards - the row shifts have zero inflow - so D_a needs no update; and in a 16-lane chain its coupling
+    //  Cm is an exact zero (the chain head's hand-on is zero and every fill S_ba below it is a product with that zero), so
+    //  Ua, its share of Gin and of the new couplings are exact zeros too and are not formed: 16 moves and some thirty
+    //  operations per factorisation.  In a 32-lane chain position 7 of the SECOND row has the first row's survivor below it:
+    //  its Ua stays - in Gin, and in the fill S_YX it leaves with position 15.)
+    constexpr bool kLast = (D == 8), kUa = !kLast || kCR32;
+    if constexpr (kUa) {
+      R ga[4];
       {
-        R fa[4];
+        R Ua[4];
+        Ua[0] = i00 * Cm[0]; Ua[1] = i00 * Cm[1];
+        Ua[2] = fma_(i11, Cm[2], i10 * Cm[0]); Ua[3] = fma_(i11, Cm[3], i10 * Cm[1]);
         MPMPC_UNROLL
-        for (int i = 0; i < 4; ++i) fa[i] = L::template rshl<D>(Ua[i]);
-        Dg[0] = fma_(-fa[2], fa[2], fma_(-fa[0], fa[0], Dg[0]));
-        Dg[1] = fma_(-fa[3], fa[2], fma_(-fa[1], fa[0], Dg[1]));
-        Dg[2] = fma_(-fa[3], fa[3], fma_(-fa[1], fa[1], Dg[2]));
+        for (int i = 0; i < 4; ++i) Gin[i] = Gin[i] + Ua[i];
+        // to the lower neighbour a (lane e - D):  D_a -= Ua'Ua
+        if constexpr (!kLast) {
+          R fa[4];
+          MPMPC_UNROLL
+          for (int i = 0; i < 4; ++i) fa[i] = L::template rshl<D>(Ua[i]);
+          Dg[0] = fma_(-fa[2], fa[2], fma_(-fa[0], fa[0], Dg[0]));
+          Dg[1] = fma_(-fa[3], fa[2], fma_(-fa[1], fa[0], Dg[1]));
+          Dg[2] = fma_(-fa[3], fa[3], fma_(-fa[1], fa[1], Dg[2]));
+        }
+        MPMPC_UNROLL
+        for (int i = 0; i < 4; ++i) ga[i] = L::template rshr<D>(Ua[i]);
       }
-      MPMPC_UNROLL
-      for (int i = 0; i < 4; ++i) ga[i] = L::template rshr<D>(Ua[i]);
+      // ... and S_ba = -Ub'Ua: the coupling of b with its new lower neighbour a (a lane that survives this level has the
+      // eliminated lane p - D below it: its old coupling is consumed)
+      Cm[0] = sel(E, Cm[0], -fma_(gb[2], ga[2], gb[0] * ga[0]));
+      Cm[1] = sel(E, Cm[1], -fma_(gb[2], ga[3], gb[0] * ga[1]));
+      Cm[2] = sel(E, Cm[2], -fma_(gb[3], ga[2], gb[1] * ga[0]));
+      Cm[3] = sel(E, Cm[3], -fma_(gb[3], ga[3], gb[1] * ga[1]));
     }
-    // ... and S_ba = -Ub'Ua: the coupling of b with its new lower neighbour a (a lane that survives this level has the
-    // eliminated lane p - D below it: its old coupling is consumed)
-    Cm[0] = sel(E, Cm[0], -fma_(gb[2], ga[2], gb[0] * ga[0]));
-    Cm[1] = sel(E, Cm[1], -fma_(gb[2], ga[3], gb[0] * ga[1]));
-    Cm[2] = sel(E, Cm[2], -fma_(gb[3], ga[2], gb[1] * ga[0]));
-    Cm[3] = sel(E, Cm[3], -fma_(gb[3], ga[3], gb[1] * ga[1]));
   }
   // Dg: diagonal blocks, To: coupling S_{succ(p), p} with the chain successor, both in chain layout
   MPMPC_HD void factor_cr2(R Dg[3], const R To[4]) {
@@ -761,23 +770,38 @@
     const R t0 = Li[0] * b0, t1 = fma_(Li[2], b1, Li[1] * b0);            // y = inv(L) b
     const R e0 = sel(E, t0, zero), e1 = sel(E, t1, zero);
     y0 = y0 + e0; y1 = y1 + e1;                                            // (each lane is eliminated once: an exact accumulation)
-    // b_a -= Ua' y,  b_b -= Ub' y
-    const R pa0 = fma_(Gin[2], e1, Gin[0] * e0), pa1 = fma_(Gin[3], e1, Gin[1] * e0);
+    // b_a -= Ua' y,  b_b -= Ub' y  (the last level, D = 8, has nobody below position 7 inside its row: cr_level)
     const R pb0 = fma_(Gout[2], e1, Gout[0] * e0), pb1 = fma_(Gout[3], e1, Gout[1] * e0);
-    b0 = b0 - L::template rshl<D>(pa0) - L::template rshr<D>(pb0);
-    b1 = b1 - L::template rshl<D>(pa1) - L::template rshr<D>(pb1);
+    if constexpr (D == 8) {
+      b0 = b0 - L::template rshr<D>(pb0);
+      b1 = b1 - L::template rshr<D>(pb1);
+    } else {
+      const R pa0 = fma_(Gin[2], e1, Gin[0] * e0), pa1 = fma_(Gin[3], e1, Gin[1] * e0);
+      b0 = b0 - L::template rshl<D>(pa0) - L::template rshr<D>(pb0);
+      b1 = b1 - L::template rshl<D>(pa1) - L::template rshr<D>(pb1);
+    }
   }
   template <int D>
   MPMPC_HD void cr_backward(const R& y0, const R& y1, R& n0, R& n1) const {
     const Mk E = L::template cr_elim<D>();
-    // nu_e = inv(L_e)' (y_e - Ua nu_a - Ub nu_b),  nu_a from lane e - D, nu_b from lane e + D
-    const R a0 = L::template rshr<D>(n0), a1 = L::template rshr<D>(n1), c0 = L::template rshl<D>(n0), c1 = L::template rshl<D>(n1);
+    // nu_e = inv(L_e)' (y_e - Ua nu_a - Ub nu_b),  nu_a from lane e - D, nu_b from lane e + D  (the last level, D = 8: nothing
+    // flows in from below position 7 - nu_a is the shift's zero inflow there)
+    // (The exchanges stay OUTSIDE the region below: a DPP move reads nothing from a lane the execution mask has switched off.)
+    const R c0 = L::template rshl<D>(n0), c1 = L::template rshl<D>(n1);
+    [[maybe_unused]] R a0(0.0), a1(0.0);
+    if constexpr (D != 8) { a0 = L::template rshr<D>(n0); a1 = L::template rshr<D>(n1); }
     // (the level's lanes as ONE region: on the device only the lanes of E execute it, the selects inside fold away and nu is
     //  written in place under the execution mask; the lock-step emulation runs the body on every lane and the selects do the
     //  masking - the same values either way.  Not for the rank-one kernels (RKS): there it costs five registers too many.)
     auto level = [&] {
-      const R r0 = fma_(-Gout[1], c1, fma_(-Gout[0], c0, fma_(-Gin[1], a1, fma_(-Gin[0], a0, y0))));
-      const R r1 = fma_(-Gout[3], c1, fma_(-Gout[2], c0, fma_(-Gin[3], a1, fma_(-Gin[2], a0, y1))));
+      R r0, r1;
+      if constexpr (D == 8) {
+        r0 = fma_(-Gout[1], c1, fma_(-Gout[0], c0, y0));
+        r1 = fma_(-Gout[3], c1, fma_(-Gout[2], c0, y1));
+      } else {
+        r0 = fma_(-Gout[1], c1, fma_(-Gout[0], c0, fma_(-Gin[1], a1, fma_(-Gin[0], a0, y0))));
+        r1 = fma_(-Gout[3], c1, fma_(-Gout[2], c0, fma_(-Gin[3], a1, fma_(-Gin[2], a0, y1))));
+      }
       n0 = sel(E, fma_(Li[1], r1, Li[0] * r0), n0);
       n1 = sel(E, Li[2] * r1, n1);
     };
