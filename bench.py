@@ -83,13 +83,14 @@ _FLOPS = {
 # (cyclic-reduction factorisation of the 16-lane chains: every stage is eliminated at one of the four levels, so a level's
 #  work counts once per stage in "algorithmic" - like one step per stage of a serial sweep - and four times in "executed")
 # the terminal-time kernels (config 3, N = 50; profiles/census.py 3): the active-set rounds vary too much for an intercept, the
-# fit is through the origin (mean 0.493 / 1.045 MFLOP per solve at 10.3 iterations)
-_FLOPS_NATIVE_TT = {1: dict(algorithmic=(0.0, 47900.0), executed=(0.0, 101500.0), N=50)}
+# fit is through the origin (round 5: mean 0.451 / 0.944 MFLOP per solve at 9.7 iterations)
+_FLOPS_NATIVE_TT = {1: dict(algorithmic=(0.0, 46500.0), executed=(0.0, 97300.0), N=50)}
 _FLOPS_NATIVE = {
-    # (refitted on the final round-4 code, profiles/census.py 2 256 / 4 512: reciprocals in the one-time parts, prefix-sum
-    #  roll-forward; infeasible instances through the reduced-native tail solver, two per wave)
-    1: dict(algorithmic=(31255.0, 19062.0), executed=(56228.0, 29990.0), N=30),
-    -3: dict(algorithmic=(19331.0, 21474.0), executed=(17150.0, 38253.0), N=30),
+    # (refitted on the final round-5 code, profiles/census.py 2 256 / 4 512: the zero half of the last cyclic-reduction level
+    #  is no longer formed - and no longer counted; infeasible instances through the reduced-native tail solver, two per
+    #  wave, whose phase 1 now runs to its converged optimum inside the band: more iterations, hence the intercepts)
+    1: dict(algorithmic=(30484.0, 18553.0), executed=(53147.0, 27954.0), N=30),
+    -3: dict(algorithmic=(-1566.0, 24631.0), executed=(-34128.0, 42580.0), N=30),
 }
 
 
