@@ -124,6 +124,7 @@ struct LaneEmu {
   static constexpr int per_wave = EMU_W / G;
   static constexpr bool batched = false;
   static constexpr bool junction_moves = false;
+  static constexpr bool staged_sweeps = false;
 
   static VI lane_id() { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = i; return r; }
   static VI stage() { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = i % G; return r; }

@@ -91,6 +91,7 @@ struct LaneGpu {
   static constexpr int group = G;
   static constexpr int per_wave = 64 / G;
   static constexpr bool batched = false;       // lane exchanges are register moves: nothing to batch (Solver::cup_n)
+  static constexpr bool staged_sweeps = false; // a chain never spans two wavefronts here (Solver::staged_sweep)
 
   static __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
   static __device__ __forceinline__ int stage() { return (threadIdx.x & 63) % G; }
@@ -371,8 +372,10 @@ struct LaneBlock {
   static constexpr int cold_slots = SLOTS;
   static constexpr bool batched = true;       // several values of a step share one pass through LDS (Solver::cup_n)
   static constexpr bool junction_moves = false;
+  static constexpr bool staged_sweeps = (G == 256);   // a chain spans two wavefronts: Solver::staged_sweep
   static constexpr int xrows = 9;             // exchange rows: the widest batch is the 3 x 3 block of a factorisation step
-  static constexpr size_t lds_bytes = sizeof(double) * ((size_t)(SLOTS + xrows) * G + 8);
+  // ... + 8 doubles of reduction scratch + the edge values of a staged sweep (xrows per chain)
+  static constexpr size_t lds_bytes = sizeof(double) * ((size_t)(SLOTS + xrows) * G + 8 + 2 * xrows);
 
   static __device__ __forceinline__ int lane_id() { return threadIdx.x; }
   static __device__ __forceinline__ int stage() { return threadIdx.x; }
@@ -390,6 +393,35 @@ struct LaneBlock {
   static __device__ __forceinline__ double* cold() { return lds(); }
   static __device__ __forceinline__ double* xrow() { return lds() + (size_t)SLOTS * G; }
   static __device__ __forceinline__ double* rrow() { return lds() + (size_t)(SLOTS + xrows) * G; }
+  static __device__ __forceinline__ double* erow() { return rrow() + 8; }
+  static __device__ __forceinline__ void sync() { __syncthreads(); }
+  // ---- staged sweeps (G = 256; Solver::staged_sweep).  Chain layout: chain 0 = wavefronts 0 | 1, chain 1 = wavefronts 2 | 3.
+  // sweep_first(DIR): this lane's wavefront is the first of its chain in the direction of the sweep (DIR -1: values flow
+  // towards higher lanes - the even wavefronts; DIR +1: the odd ones).
+  static __device__ __forceinline__ bool sweep_first(int dir) { return ((threadIdx.x >> 6) & 1) == (dir < 0 ? 0 : 1); }
+  // chain_shift<NV, DIR, MODE>: the one-lane shift along the chains inside the wavefront (DPP, zero inflow).  MODE 1 (first
+  // wavefront): its edge lane also leaves v - what the next lane of the chain would take - in LDS.  MODE 2 (second
+  // wavefront): its edge lane takes that instead of the zero.  No barrier: the sweep places them.
+  template <int NV, int DIR, int MODE>
+  static __device__ __forceinline__ void chain_shift(const double* v, double* o) {
+    static_assert(G == 256 && NV <= xrows && (MODE == 1 || MODE == 2), "staged sweeps: chains of two wavefronts");
+    const int lane = threadIdx.x & 63, chain = threadIdx.x >> 7;
+    double* e = erow() + chain * xrows;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) o[i] = DIR < 0 ? dpp_shift<DPP_WAVE_SHR1>(v[i]) : dpp_shift<DPP_WAVE_SHL1>(v[i]);
+    const bool edge_out = DIR < 0 ? lane == 63 : lane == 0, edge_in = DIR < 0 ? lane == 0 : lane == 63;
+    if constexpr (MODE == 1) {
+      if (edge_out) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) e[i] = v[i];
+      }
+    } else {
+      if (edge_in) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) o[i] = e[i];
+      }
+    }
+  }
 
   // the value lane `src` holds (src outside [0, G): 0) - every lane of the workgroup must call it
   static __device__ __forceinline__ double take(double a, int src) {

@@ -187,13 +187,38 @@ struct Solver {
   // NV lane exchanges at once.  Where the lanes of an instance sit in different wavefronts (LaneBlock: horizons above 63) every
   // exchange is a pass through LDS between two workgroup barriers, and the NV values of a step share one pass; on a
   // wavefront these are the plain per-value DPP moves - the same instructions as before.
-  template <int NV> MPMPC_HD static void cup_n(const R* v, R* o) {
-    if constexpr (L::batched) L::template cupv<NV>(v, o);
+  // MODE (only where L::staged_sweeps - a chain of the factorisation spans TWO wavefronts, LaneBlock<256>): 0 = the plain
+  // exchange; 1 / 2 = the two stages of a staged sweep (staged_sweep below).
+  template <int M> struct SweepMode { static constexpr int value = M; };
+  template <int NV, int MODE = 0> MPMPC_HD static void cup_n(const R* v, R* o) {
+    if constexpr (MODE != 0) L::template chain_shift<NV, -1, MODE>(v, o);
+    else if constexpr (L::batched) L::template cupv<NV>(v, o);
     else { MPMPC_UNROLL for (int i = 0; i < NV; ++i) o[i] = L::cup(v[i]); }
   }
-  template <int NV> MPMPC_HD static void cdown_n(const R* v, R* o) {
-    if constexpr (L::batched) L::template cdownv<NV>(v, o);
+  template <int NV, int MODE = 0> MPMPC_HD static void cdown_n(const R* v, R* o) {
+    if constexpr (MODE != 0) L::template chain_shift<NV, +1, MODE>(v, o);
+    else if constexpr (L::batched) L::template cdownv<NV>(v, o);
     else { MPMPC_UNROLL for (int i = 0; i < NV; ++i) o[i] = L::cdown(v[i]); }
+  }
+  // A sequential sweep along chains that span two wavefronts (L::staged_sweeps).  In the lock-step form every lane executes
+  // every step and every step passes through LDS between two workgroup barriers, although lane k's value is final after k
+  // steps and only ONE value per chain crosses the wavefront edge.  Staged: the first wavefront of each chain (in the
+  // direction of the sweep) runs its 64 steps alone, shifting in registers, and its edge lane leaves what it hands on in
+  // LDS - one more step, which recomputes the final values, leaves the FINAL hand-on there; a barrier; the second wavefront
+  // runs the remaining steps with that value flowing in at its edge lane at every step.  Two barriers per sweep instead of
+  // two per step, and each wavefront executes half the steps.  Every lane ends with the value of the lock-step form: its
+  // last step sees its predecessor's final value either way.  step(SweepMode<m>) must do all its chain shifts through
+  // cup_n / cdown_n<NV, m> and nothing else that talks across lanes.
+  template <int DIR, class F> MPMPC_HD static void staged_sweep(int steps, F step) {
+    // (The chains are right-aligned - they end at the meeting lane - so the wavefront next to the junction is full and the
+    //  other one holds the rest: an inward sweep, DIR -1, runs the partial wavefront first and then the full one, 64 steps;
+    //  an outward sweep the full one first and then the steps that are left.)
+    const bool first = L::sweep_first(DIR);
+    const int second = DIR < 0 ? 64 : steps - 64;
+    if (first) { for (int s = 0; s < 65; ++s) step(SweepMode<1>{}); }
+    L::sync();
+    if (!first) { for (int s = 0; s < second; ++s) step(SweepMode<2>{}); }
+    L::sync();
   }
   template <int NV> MPMPC_HD static void up_n(const R* v, R* o) {
     if constexpr (L::batched) L::template upv<NV>(v, o);

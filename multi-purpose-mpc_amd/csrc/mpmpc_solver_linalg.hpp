@@ -114,9 +114,9 @@
     MPMPC_UNROLL
     for (int i = 0; i < 9; ++i) M[i] = R(0.0);
     const int last = chain_steps();
-    auto fstep = [&](bool junction) {
+    auto fstep = [&](auto mode, bool junction) {
       R Mr[9];
-      cup_n<9>(M, Mr);
+      cup_n<9, decltype(mode)::value>(M, Mr);
       // S = Dg - Mr Mr' (lower part), products subtracted inside the FMAs
       R S00 = fma_(-Mr[2], Mr[2], fma_(-Mr[1], Mr[1], fma_(-Mr[0], Mr[0], Dg[0])));
       R S10 = fma_(-Mr[5], Mr[2], fma_(-Mr[4], Mr[1], fma_(-Mr[3], Mr[0], Dg[1])));
@@ -160,10 +160,14 @@
     };
     {
       MPMPC_SERIAL_BEGIN();
-      int s = 0;                                   // two steps per trip (see s_solve), then the junction step
-      for (; s + 2 <= last; s += 2) { fstep(false); fstep(false); }
-      for (; s < last; ++s) fstep(false);
-      fstep(true);
+      if constexpr (L::staged_sweeps) {
+        staged_sweep<-1>(last, [&](auto mode) { fstep(mode, false); });
+      } else {
+        int s = 0;                                   // two steps per trip (see s_solve), then the junction step
+        for (; s + 2 <= last; s += 2) { fstep(SweepMode<0>{}, false); fstep(SweepMode<0>{}, false); }
+        for (; s < last; ++s) fstep(SweepMode<0>{}, false);
+      }
+      fstep(SweepMode<0>{}, true);
       MPMPC_SERIAL_END(last + 1);
     }
     // recurrence matrices of the two substitution sweeps (stored negated, so a sweep step is 9 FMAs):
@@ -196,10 +200,10 @@
     R y0(0.0), y1(0.0), y2(0.0);
     // A loop-back branch costs about as much as six of the step's fifteen instructions, and the compiler
     // may not partially unroll a loop of convergent (DPP) operations: four steps per trip by hand.
-    auto in_step = [&]() {
+    auto in_step = [&](auto mode) {
       const R yv[3] = {y0, y1, y2};
       R pv[3];
-      cup_n<3>(yv, pv);
+      cup_n<3, decltype(mode)::value>(yv, pv);
       const R p0 = pv[0], p1 = pv[1], p2 = pv[2];
       y0 = fma_(Gin[2], p2, fma_(Gin[1], p1, fma_(Gin[0], p0, c0)));
       y1 = fma_(Gin[5], p2, fma_(Gin[4], p1, fma_(Gin[3], p0, c1)));
@@ -207,9 +211,14 @@
     };
     {
       MPMPC_SERIAL_BEGIN();
-      int s = 0;
-      for (; s + 4 <= last; s += 4) { in_step(); in_step(); in_step(); in_step(); }
-      for (; s < last; ++s) in_step();
+      if constexpr (L::staged_sweeps) {
+        staged_sweep<-1>(last, in_step);
+      } else {
+        const SweepMode<0> m0{};
+        int s = 0;
+        for (; s + 4 <= last; s += 4) { in_step(m0); in_step(m0); in_step(m0); in_step(m0); }
+        for (; s < last; ++s) in_step(m0);
+      }
       MPMPC_SERIAL_END(last);
     }
     {
@@ -250,10 +259,10 @@
       MPMPC_SERIAL_END(N + 1);
     }
     R n0(0.0), n1(0.0), n2(0.0);
-    auto out_step = [&]() {
+    auto out_step = [&](auto mode) {
       const R nv[3] = {n0, n1, n2};
       R pv[3];
-      cdown_n<3>(nv, pv);
+      cdown_n<3, decltype(mode)::value>(nv, pv);
       const R p0 = pv[0], p1 = pv[1], p2 = pv[2];
       n0 = fma_(Gout[2], p2, fma_(Gout[1], p1, fma_(Gout[0], p0, d0)));
       n1 = fma_(Gout[5], p2, fma_(Gout[4], p1, fma_(Gout[3], p0, d1)));
@@ -261,9 +270,14 @@
     };
     {
       MPMPC_SERIAL_BEGIN();
-      int s = 0;
-      for (; s + 4 <= last + 1; s += 4) { out_step(); out_step(); out_step(); out_step(); }
-      for (; s <= last; ++s) out_step();
+      if constexpr (L::staged_sweeps) {
+        staged_sweep<+1>(last + 1, out_step);
+      } else {
+        const SweepMode<0> m0{};
+        int s = 0;
+        for (; s + 4 <= last + 1; s += 4) { out_step(m0); out_step(m0); out_step(m0); out_step(m0); }
+        for (; s <= last; ++s) out_step(m0);
+      }
       MPMPC_SERIAL_END(last + 1);
     }
     nu[0] = L::mirror(n0); nu[1] = L::mirror(n1); nu[2] = L::mirror(n2);
@@ -544,10 +558,9 @@
     MPMPC_UNROLL
     for (int i = 0; i < 4; ++i) M[i] = R(0.0);
     const int last = chain_steps();
-    auto fstep = [&](bool junction) {
+    auto fstep = [&](auto mode, bool junction) {
       R Mr[4];
-      MPMPC_UNROLL
-      for (int i = 0; i < 4; ++i) Mr[i] = L::cup(M[i]);
+      cup_n<4, decltype(mode)::value>(M, Mr);
       R S00 = fma_(-Mr[1], Mr[1], fma_(-Mr[0], Mr[0], Dg[0]));
       R S10 = fma_(-Mr[3], Mr[1], fma_(-Mr[2], Mr[0], Dg[1]));
       R S11 = fma_(-Mr[3], Mr[3], fma_(-Mr[2], Mr[2], Dg[2]));
@@ -572,10 +585,14 @@
     };
     {
       MPMPC_SERIAL_BEGIN();
-      int s = 0;
-      for (; s + 2 <= last; s += 2) { fstep(false); fstep(false); }
-      for (; s < last; ++s) fstep(false);
-      fstep(true);
+      if constexpr (L::staged_sweeps) {
+        staged_sweep<-1>(last, [&](auto mode) { fstep(mode, false); });
+      } else {
+        int s = 0;
+        for (; s + 2 <= last; s += 2) { fstep(SweepMode<0>{}, false); fstep(SweepMode<0>{}, false); }
+        for (; s < last; ++s) fstep(SweepMode<0>{}, false);
+      }
+      fstep(SweepMode<0>{}, true);
       MPMPC_SERIAL_END(last + 1);
     }
     //   inward    y_k  = inv(L_kk) b_k + Gin_k y_pred,        Gin_k  = -inv(L_kk) M_in
@@ -883,16 +900,24 @@
     R c1 = fma_(Li[2], b1, Li[1] * b0);
     const int last = chain_steps();
     R y0(0.0), y1(0.0);
-    auto in_step = [&]() {
-      R p0 = L::cup(y0), p1 = L::cup(y1);
+    auto in_step = [&](auto mode) {
+      const R yv[2] = {y0, y1};
+      R pv[2];
+      cup_n<2, decltype(mode)::value>(yv, pv);
+      const R p0 = pv[0], p1 = pv[1];
       y0 = fma_(Gin[1], p1, fma_(Gin[0], p0, c0));
       y1 = fma_(Gin[3], p1, fma_(Gin[2], p0, c1));
     };
     {
       MPMPC_SERIAL_BEGIN();
-      int s = 0;
-      for (; s + 4 <= last; s += 4) { in_step(); in_step(); in_step(); in_step(); }
-      for (; s < last; ++s) in_step();
+      if constexpr (L::staged_sweeps) {
+        staged_sweep<-1>(last, in_step);
+      } else {
+        const SweepMode<0> m0{};
+        int s = 0;
+        for (; s + 4 <= last; s += 4) { in_step(m0); in_step(m0); in_step(m0); in_step(m0); }
+        for (; s < last; ++s) in_step(m0);
+      }
       MPMPC_SERIAL_END(last);
     }
     {
@@ -925,16 +950,24 @@
       MPMPC_SERIAL_END(N + 1);
     }
     R n0(0.0), n1(0.0);
-    auto out_step = [&]() {
-      R p0 = L::cdown(n0), p1 = L::cdown(n1);
+    auto out_step = [&](auto mode) {
+      const R nv[2] = {n0, n1};
+      R pv[2];
+      cdown_n<2, decltype(mode)::value>(nv, pv);
+      const R p0 = pv[0], p1 = pv[1];
       n0 = fma_(Gout[1], p1, fma_(Gout[0], p0, d0));
       n1 = fma_(Gout[3], p1, fma_(Gout[2], p0, d1));
     };
     {
       MPMPC_SERIAL_BEGIN();
-      int s = 0;
-      for (; s + 4 <= last + 1; s += 4) { out_step(); out_step(); out_step(); out_step(); }
-      for (; s <= last; ++s) out_step();
+      if constexpr (L::staged_sweeps) {
+        staged_sweep<+1>(last + 1, out_step);
+      } else {
+        const SweepMode<0> m0{};
+        int s = 0;
+        for (; s + 4 <= last + 1; s += 4) { out_step(m0); out_step(m0); out_step(m0); out_step(m0); }
+        for (; s <= last; ++s) out_step(m0);
+      }
       MPMPC_SERIAL_END(last + 1);
     }
     nu[0] = L::mirror(n0); nu[1] = L::mirror(n1);

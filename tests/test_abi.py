@@ -114,13 +114,13 @@ def test_no_batch_path_solve_kernel_has_scratch(lib):
     configurations (N >= 32 with bounded e_psi / t or full weight matrices; horizons above 63) - with the bytes measured when they were
     listed: the test fails if one of them grows or a new one appears."""
     KNOWN_SCRATCH = {
-        "mpmpc_solve_kernel<64, 32, false, 0>": 220, "mpmpc_solve_kernel<64, 32, true, 0>": 352,
+        "mpmpc_solve_kernel<64, 32, false, 0>": 80, "mpmpc_solve_kernel<64, 32, true, 0>": 96,
         # (VAR 1 = full weights: since round 5 Q and R may have off-diagonal entries too - dense blocks on every lane)
-        "mpmpc_solve_kernel<64, 32, false, 1>": 324, "mpmpc_solve_kernel<64, 32, true, 1>": 464,
+        "mpmpc_solve_kernel<64, 32, false, 1>": 228, "mpmpc_solve_kernel<64, 32, true, 1>": 236,
         # horizons above 63 (round 5): the general solver on a workgroup of 2 / 4 wavefronts, 512 registers per lane
         # (VAR 2, the reduced polish of the reference's own weights, has none)
         "mpmpc_solve_block_kernel<128, 0>": 128, "mpmpc_solve_block_kernel<128, 1>": 252,
-        "mpmpc_solve_block_kernel<256, 0>": 264, "mpmpc_solve_block_kernel<256, 1>": 384,
+        "mpmpc_solve_block_kernel<256, 0>": 264, "mpmpc_solve_block_kernel<256, 1>": 388,
         # the one-instance-per-wave form of the reduced-native tail kernel (mpmpc_set_tail_kernel(h, 2); the default form,
         # <32, 16>, has none): ONE dword (a lane mask the compiler keeps as 0 / 1 in a VGPR), stored once before
         # and read once inside each attempt of a tail instance - 10 % of a config-4 batch; its two-waves-per-SIMD budget
