@@ -47,6 +47,47 @@ def test_long_horizons_in_the_emulation_against_the_c_oracle(N, cfgid, emu, trac
         assert good.all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [70, 150])
+def test_long_horizon_general_variants_on_device(N, track, emu):
+    """The workgroup kernel's OTHER variants on the device - full weight matrices (3 x 3 dense blocks), the time-optimal
+    weights and bounded e_psi / t (the full 3-state problem), and the restated OSQP alone - at 128 and at 256 lanes (where
+    the sweeps of the factorisation are staged wavefront by wavefront): statuses and iteration counts of the emulation, z to
+    1e-9, KKT on the dense data."""
+    from test_emul_parity import full_weight_config
+    B = 24
+    tw = T.wide_track(track, emu, N)
+    sc = scenarios.make(4, tw, B=B, N=N)
+    inp = (sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    xmin, xmax = np.array([-np.inf, -0.6, -np.inf]), np.array([np.inf, 0.6, 0.2 * N])
+    Qt, Rt, QNt = scenarios.WEIGHTS["time_optimal"]
+    Qs, Rs, QNs = scenarios.WEIGHTS["stock"]
+    cases = [("full weights", full_weight_config(N, "full", max_batch=B), mpmpc.default_settings()),
+             ("time-optimal", mpmpc.make_config(N, Qt, Rt, QNt, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX, 4.0, 0.12, max_batch=B),
+              mpmpc.default_settings(phase1_accept=0)),
+             ("bounded states", mpmpc.make_config(N, Qs, Rs, QNs, xmin, xmax, scenarios.UMIN, scenarios.UMAX, 4.0, 0.12, max_batch=B),
+              mpmpc.default_settings(phase1_accept=0)),
+             ("stock OSQP", T.stock_config(N, max_batch=B), mpmpc.stock_settings())]
+    for name, cfg, st in cases:
+        h = mpmpc.Handle(cfg, st)
+        h.set_path(track.kappa, track.v_ref, track.ds_next)
+        qp = h.assemble(*inp)
+        sol = h.solve(*inp, want_y=True)
+        h.close()
+        nn = 8
+        ref = emu.solve(cfg, st, np.ascontiguousarray(qp[:, :nn, :]))
+        assert np.array_equal(sol.status[:nn], ref.status), (name, sol.status[:nn], ref.status)
+        assert np.array_equal(sol.iters[:nn, 0], ref.iters[:, 0]), name
+        assert np.max(np.abs(sol.iters[:nn, 1] - ref.iters[:, 1])) <= 1, name
+        okr = ref.status == 1
+        assert okr.any() and np.max(np.abs(sol.z[:nn][okr] - ref.z[okr])) <= (1e-9 if name != "stock OSQP" else 1e-7), name
+        if name == "stock OSQP":
+            continue
+        for i in np.flatnonzero(sol.status == 1)[:6]:
+            P, q, A, l, u = T.qp_to_dense_full(qp[:, i, :], N, cfg)
+            assert O.kkt_certificate(P, q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8), (name, i)
+
+
 @pytest.mark.parametrize("N", [64, 130])
 def test_long_horizons_other_problem_classes_in_the_emulation(N, emu, track):
     """What else the general kernel serves, at a horizon that needs a workgroup: full weight matrices (dense stage blocks),
