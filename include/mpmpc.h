@@ -58,7 +58,8 @@ typedef struct mpmpc_handle_s* mpmpc_handle;
  * one instance per wavefront (dense 3 x 3 / 2 x 2 stage Hessian blocks); diagonal weights run the reduced-native kernels
  * unchanged.  Q, R, QN must be positive semidefinite.
  * HORIZON: 3 <= N <= MPMPC_MAX_HORIZON (one lane per stage: a wavefront up to N = 63, a workgroup of 2 / 4 wavefronts whose
- * stages talk through LDS beyond that; the reference has no upper limit). */
+ * stages talk through LDS beyond that - several times slower per solve; the reference has no
+ * upper limit). */
 typedef struct {
   int32_t N;          /* horizon, 3 <= N <= MPMPC_MAX_HORIZON (the kappa_pred quirk of MPC.py:86 needs N >= 3); N <= 63: one wavefront
                          (or a part of one) per instance; 64 .. 127 / 128 .. 255: a workgroup of 2 / 4 wavefronts per instance,
