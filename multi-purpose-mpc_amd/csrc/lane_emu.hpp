@@ -172,6 +172,14 @@ struct LaneEmu {
   static VB cr_low15() { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (i & 31) == 15; return r; }
   static VB cr_special() { VB r; for (int i = 0; i < EMU_W; ++i) { const int p = i & 15; r.v[i] = (i & 16) != 0 && ((p & (p + 1)) == 0) && p != 15; } return r; }
 
+  // ---- 64-lane chains (a wavefront of a 128-lane workgroup: four rows; lane_gpu.hpp: LaneBlock<128>, Solver::kCR64)
+  static VB cr64_x(int r) { VB m; for (int i = 0; i < EMU_W; ++i) m.v[i] = (i & 63) == 16 * r + 15; return m; }
+  static VB cr64_special(int r) { VB m; for (int i = 0; i < EMU_W; ++i) { const int p = i & 15; m.v[i] = ((i >> 4) & 3) == r + 1 && ((p & (p + 1)) == 0) && p != 15; } return m; }
+  static VD row_next(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = ((i & 63) + 16 < 64) ? a.v[i + 16] : 0.0; return r; }
+  static VD row_prev(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = ((i & 63) >= 16) ? a.v[i - 16] : 0.0; return r; }
+  static VD wdown(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = ((i & 63) != 63) ? a.v[i + 1] : 0.0; return r; }
+  static VD bcast15_next(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = ((i & 63) >= 16) ? a.v[((i & ~15) - 16) | 15] : 0.0; return r; }
+
   // half-wave exchange (see lane_gpu.hpp)
   static VD from_upper(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i | 32]; return r; }
   static VD from_lower(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i & 31]; return r; }

@@ -496,6 +496,27 @@ struct LaneBlock {
     return take(a, (t == C - 1 || t == 2 * C - 1) ? -1 : t + 1);
   }
 
+  // ---- cyclic reduction of 64-lane chains (G = 128: a chain is a wavefront of four rows; Solver::kCR64).  The in-row shifts
+  // and masks of the levels are the wavefront backend's; the survivors of the rows meet through moves by whole rows.
+  template <int D> static __device__ __forceinline__ double rshr(double a) { return dpp_shift<0x110 + D>(a); }
+  template <int D> static __device__ __forceinline__ double rshl(double a) { return dpp_shift<0x100 + D>(a); }
+  template <int D> static __device__ __forceinline__ bool cr_elim() { return (((threadIdx.x & 15) + D + 1) & (2 * D - 1)) == 0; }
+  static __device__ __forceinline__ bool cr64_x(int r) { return (int)(threadIdx.x & 63) == 16 * r + 15; }
+  static __device__ __forceinline__ bool cr64_special(int r) {
+    const int p = threadIdx.x & 15;
+    return (int)((threadIdx.x >> 4) & 3) == r + 1 && ((p & (p + 1)) == 0) && p != 15;
+  }
+  // the same position of the next / previous row of the wavefront (what a lane without such a row gets is not used)
+  static __device__ __forceinline__ double row_next(double a) { return __shfl(a, ((int)threadIdx.x + 16) & 63, 64); }
+  static __device__ __forceinline__ double row_prev(double a) { return __shfl(a, ((int)threadIdx.x - 16) & 63, 64); }
+  static __device__ __forceinline__ double wdown(double a) { return dpp_shift<DPP_WAVE_SHL1>(a); }     // lane i <- lane i + 1 inside the wavefront
+  // every lane of rows 1 .. 3 gets a of position 15 of the row below (row_bcast:15), row 0 gets 0
+  static __device__ __forceinline__ double bcast15_next(double a) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(a), 0x142, 0xE, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(a), 0x142, 0xE, 0xf, false);
+    return __hiloint2double(hi, lo);
+  }
+
   template <class F>
   static __device__ __forceinline__ double reduce(double a, F f) {
     a = LaneGpu<64, 32, 1>::bfly(a, f);          // wave-uniform

@@ -181,7 +181,8 @@ __global__ __launch_bounds__(G) void mpmpc_solve_block_kernel(mpmpc_config cfg, 
   const int k = L::stage() - lane_offset(G, G / 2, cfg.N);
   double fields[MPMPC_NUM_FIELDS];
   assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
-  Solver<L, VAR == 1, VAR == 2> s;
+  // (the reduced variant factors 64-lane chains - G = 128: a chain is a wavefront - by cyclic reduction: Solver::kCR64)
+  Solver<L, VAR == 1, VAR == 2, false, VAR == 2> s;
   double woff[7];
   weight_offdiag(cfg, woff);
   s.template run<false, true>(fields, B, inst, k, cfg.N, st, 0, 0, 0, VAR == 1 ? woff : nullptr);

@@ -31,7 +31,15 @@ def main():
     lib.mpmpc_debug_phase.argtypes = [C.c_void_p, C.c_int]
     mpmpc._lib = lib            # the handles below run in the profiling build
     tr = scenarios.sim_track()
-    sc = scenarios.make(cfg_id, tr, B=int(sys.argv[2]) if len(sys.argv) > 2 else None)
+    n_over = int(os.environ.get("MPMPC_PHASES_N", "0"))       # another horizon (above 50 the corridor tables come from the emulation)
+    if n_over:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import mpmpc_testlib as T
+        tw = T.wide_track(tr, T.Emul(), max(n_over, 50))
+        sc = scenarios.make(cfg_id, tw, B=int(sys.argv[2]) if len(sys.argv) > 2 else None, N=n_over)
+    else:
+        sc = scenarios.make(cfg_id, tr, B=int(sys.argv[2]) if len(sys.argv) > 2 else None)
     Q, R, QN = scenarios.WEIGHTS[scenarios.CONFIGS[cfg_id]["weights"]]
     cfg = mpmpc.make_config(sc.N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX,
                             scenarios.AY_MAX, scenarios.CAR_LENGTH, max_batch=sc.B)
@@ -58,7 +66,7 @@ def main():
         h.solve_resident(sc.B)
         h.sync()
     lib.mpmpc_debug_phase(buf.ctypes.data, 0)
-    waves = int((buf[:, 8] != 0).sum())
+    waves = int((buf[:, 8] != 0).sum()) or int((buf[:, 3] != 0).sum())       # (the workgroup kernel has no body clock)
     t = buf[:waves].astype(np.float64) / reps
     print("config %d  B=%d N=%d  waves=%d" % (cfg_id, sc.B, sc.N, waves))
     for i, name in NAMES.items():

@@ -13,6 +13,10 @@
 using namespace mpmpc;
 static_assert(EMU_W == 128 || EMU_W == 256, "build with -DMPMPC_EMU_W=128 or 256");
 
+// (a chain of the 128-lane workgroup is a wavefront: the reduced variant factors it by cyclic reduction, as on the device)
+static_assert(EMU_W != 128 || Solver<LaneEmu<EMU_W, EMU_W / 2>, false, true, false, true>::kCR64, "cyclic reduction of 64-lane chains");
+static_assert(EMU_W != 256 || !Solver<LaneEmu<EMU_W, EMU_W / 2>, false, true, false, true>::kCR, "256 lanes: sequential (staged) sweeps");
+
 template <int VAR>
 static void solve_wide(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
                        int* status, int* iters, double* resid, double* y) {
@@ -22,7 +26,7 @@ static void solve_wide(const mpmpc_config* cfg, const mpmpc_settings* st, const 
   for (int w = 0; w < B; ++w) {
     VI inst = L::slot() + w;
     VI k = L::stage() - lane_offset(G, C, cfg->N);
-    using S = Solver<L, VAR == 1, VAR == 2>;
+    using S = Solver<L, VAR == 1, VAR == 2, false, VAR == 2>;      // (as mpmpc_solve_block_kernel: cyclic reduction where a chain is a wavefront)
     S s;
     double woff7[7];
     weight_offdiag(*cfg, woff7);
