@@ -160,12 +160,22 @@ struct LaneEmu {
   // row-pair exchanges and lane roles of the 32-lane chains' cyclic reduction (see lane_gpu.hpp)
   static VD from_even_row(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i & ~16]; return r; }
   static VD from_odd_row(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i | 16]; return r; }
-  static VD bcast31(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (i & 32) ? a.v[31] : 0.0; return r; }
+  static VD bcast31(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (i & 32) ? a.v[(i & ~63) | 31] : 0.0; return r; }
   // inclusive prefix sum along the lanes of an instance, in the device's order of additions (lane_gpu.hpp: gscan)
   static VD gscan(VD a) {
     a = a + rshr<1>(a); a = a + rshr<2>(a); a = a + rshr<4>(a); a = a + rshr<8>(a);
     if constexpr (G >= 32) a = a + bcast15(a);
-    if constexpr (G == 64) a = a + bcast31(a);
+    if constexpr (G >= 64) a = a + bcast31(a);
+    if constexpr (G > 64) {       // a workgroup of 2 / 4 wavefronts: the totals of the wavefronts below, one after the other (LaneBlock::gscan)
+      VD off;
+      for (int i = 0; i < EMU_W; ++i) {
+        double o = 0.0;
+        for (int j = 0; j < (i % G) / 64; ++j) o = o + a.v[(i - i % G) + 64 * j + 63];
+        off.v[i] = o;
+      }
+      MPMPC_OP(shift);
+      a = a + off;
+    }
     return a;
   }
   static VD bcast15(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (i & 16) ? a.v[(i & ~31) | 15] : 0.0; return r; }

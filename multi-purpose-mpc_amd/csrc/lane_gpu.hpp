@@ -531,6 +531,20 @@ struct LaneBlock {
   static __device__ __forceinline__ double gmax(double a) { return reduce(a, [](double x, double y) { return max_(x, y); }); }
   static __device__ __forceinline__ double gmin(double a) { return reduce(a, [](double x, double y) { return min_(x, y); }); }
   static __device__ __forceinline__ double gsum(double a) { return reduce(a, [](double x, double y) { return x + y; }); }
+  // inclusive prefix sum along the lanes of the workgroup: the 64-lane scan of the wavefront backend, then the totals of the
+  // wavefronts below, added one after the other (lane_emu.hpp: gscan adds in the same order)
+  static __device__ __forceinline__ double gscan(double a) {
+    a = LaneGpu<64, 32, 1>::gscan(a);
+    double* r = rrow();
+    if ((threadIdx.x & 63) == 63) r[threadIdx.x >> 6] = a;
+    __syncthreads();
+    double off = 0.0;
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < waves - 1; ++j) off = (j < w) ? off + r[j] : off;
+    __syncthreads();
+    return a + off;
+  }
   static __device__ __forceinline__ bool gany(bool m) { return __syncthreads_or(m ? 1 : 0) != 0; }
   static __device__ __forceinline__ bool wany(bool m) { return __syncthreads_or(m ? 1 : 0) != 0; }
   static __device__ __forceinline__ double gcount(bool m) { return double(__syncthreads_count(m ? 1 : 0)); }

@@ -175,9 +175,13 @@ template <int G, int VAR>
 __global__ __launch_bounds__(G) void mpmpc_solve_block_kernel(mpmpc_config cfg, SolverParams st, int B, AssembleIn ain,
                                                               double* __restrict__ z, double* __restrict__ u0,
                                                               int* __restrict__ status, int* __restrict__ iters,
-                                                              double* __restrict__ resid, double* __restrict__ y) {
+                                                              double* __restrict__ resid, double* __restrict__ y,
+                                                              const int* __restrict__ tail) {
   using L = LaneBlock<G>;
-  const int inst = blockIdx.x;
+  // tail: the instances the reduced-native workgroup kernel (below) could not certify - one workgroup each, straight to
+  // phase 1 and the full iteration (mode 2, as for the wavefront kernels); null: every instance, the whole solve
+  if (tail && (int)blockIdx.x >= tail[0]) return;
+  const int inst = tail ? tail[1 + blockIdx.x] : (int)blockIdx.x;
   const int k = L::stage() - lane_offset(G, G / 2, cfg.N);
   double fields[MPMPC_NUM_FIELDS];
   assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
@@ -185,8 +189,31 @@ __global__ __launch_bounds__(G) void mpmpc_solve_block_kernel(mpmpc_config cfg, 
   Solver<L, VAR == 1, VAR == 2, false, VAR == 2> s;
   double woff[7];
   weight_offdiag(cfg, woff);
-  s.template run<false, true>(fields, B, inst, k, cfg.N, st, 0, 0, 0, VAR == 1 ? woff : nullptr);
+  const int base_ipm = (tail && iters) ? iters[inst * 2 + 1] : 0;       // (the interior-point iterations the first kernel spent on it)
+  s.template run<false, true>(fields, B, inst, k, cfg.N, st, tail ? 2 : 0, 0, base_ipm, VAR == 1 ? woff : nullptr);
   s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y, nullptr, 0);
+}
+
+// K2rb: the reduced-native solver (mpmpc_reduced.hpp: the (e_y, e_psi, kappa) problem from the start - own scaling, interior
+// point from x = 0, active-set rounds, certificate) on a workgroup, for the reference's own weights at horizons above 63.
+// What it cannot certify is listed in `tail` for mpmpc_solve_block_kernel<G, 2>.
+// (40 cold slots like K2r instead of the general solver's 66: 50 KB of LDS per workgroup at G = 128 - three workgroups per CU)
+constexpr int RNB_SLOTS = 40;
+template <int G>
+__global__ __launch_bounds__(G) void mpmpc_reduced_block_kernel(mpmpc_config cfg, SolverParams st, int B, AssembleIn ain,
+                                                                double* __restrict__ z, double* __restrict__ u0,
+                                                                int* __restrict__ status, int* __restrict__ iters,
+                                                                double* __restrict__ resid, double* __restrict__ y,
+                                                                int* __restrict__ tail) {
+  using L = LaneBlock<G, RNB_SLOTS>;
+  const int inst = blockIdx.x;
+  const int k = L::stage() - lane_offset(G, G / 2, cfg.N);
+  double fields[MPMPC_NUM_FIELDS];
+  assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
+  ReducedSolver<L> s;
+  s.template run<false>(fields, B, inst, k, cfg.N, st, 0);
+  s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y, nullptr, 0);
+  if (k == 0 && inst < B && s.status == MPMPC_UNSOLVED) tail[1 + atomicAdd(tail, 1)] = inst;
 }
 
 // K2r: the reduced-native solve kernel (mpmpc_reduced.hpp) - the batch path of every configuration whose time state
@@ -1355,11 +1382,33 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
       attr_set = true;                                                                                                                \
     }                                                                                                                                 \
     hipLaunchKernelGGL((mpmpc_solve_block_kernel<GG, VV>), dim3(B), dim3(GG), LaneBlock<GG>::lds_bytes, h->stream, h->cfg, prm, B, \
-                       ain, h->z, h->u0, h->status, h->iters, h->resid, y_out);                                                       \
+                       ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, tail_blk);                                             \
+  } while (0)
+#define LAUNCH_RBLOCK(GG)                                                                                                             \
+  do {                                                                                                                                \
+    using LB_ = LaneBlock<GG, RNB_SLOTS>;                                                                                             \
+    static bool attr_set = false;                                                                                                     \
+    if (!attr_set) {                                                                                                                  \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpmpc_reduced_block_kernel<GG>),                                    \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LB_::lds_bytes));                                 \
+      attr_set = true;                                                                                                                \
+    }                                                                                                                                 \
+    hipLaunchKernelGGL((mpmpc_reduced_block_kernel<GG>), dim3(B), dim3(GG), LB_::lds_bytes, h->stream, h->cfg, prm, B,             \
+                       ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, h->tail);                                              \
   } while (0)
     const bool redb = !fullqn && reducible(h->cfg, h->st);
+    // the reference's own weights at the default settings: the reduced-native solver first (K2rb), the general one on what
+    // it lists (the same split as below 64 stages, without packing and without the deferred tail: the list is cleared here)
+    const bool rnb = !fullqn && reduced_native(h->cfg, h->st);
+    const int* tail_blk = nullptr;
+    if (rnb) {
+      HIP_TRY(hipMemsetAsync(h->tail, 0, sizeof(int), h->stream));
+      if (N + 1 <= 128) LAUNCH_RBLOCK(128); else LAUNCH_RBLOCK(256);
+      tail_blk = h->tail;
+    }
     if (N + 1 <= 128) { if (fullqn) LAUNCH_BLOCK(128, 1); else if (redb) LAUNCH_BLOCK(128, 2); else LAUNCH_BLOCK(128, 0); }
     else { if (fullqn) LAUNCH_BLOCK(256, 1); else if (redb) LAUNCH_BLOCK(256, 2); else LAUNCH_BLOCK(256, 0); }
+#undef LAUNCH_RBLOCK
 #undef LAUNCH_BLOCK
     HIP_TRY(hipGetLastError());
     return MPMPC_OK;

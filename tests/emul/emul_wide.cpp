@@ -4,11 +4,13 @@
 // (mpmpc_core.hpp: Solver) runs on an emulated execution group of MPMPC_EMU_W = 128 / 256 lanes.  Built twice
 // (tests/emul/Makefile: libmpmpc_emul_w128.so, libmpmpc_emul_w256.so).  Never loaded by the product.
 #include <cstring>
+#include <vector>
 #define MPMPC_TICK_BEGIN(i) ((void)0)
 #define MPMPC_TICK_END(i) ((void)0)
 #define MPMPC_TICK_COUNT(i) ((void)0)
 #include "lane_emu.hpp"
 #include "mpmpc_core.hpp"
+#include "mpmpc_reduced.hpp"
 
 using namespace mpmpc;
 static_assert(EMU_W == 128 || EMU_W == 256, "build with -DMPMPC_EMU_W=128 or 256");
@@ -37,12 +39,45 @@ static void solve_wide(const mpmpc_config* cfg, const mpmpc_settings* st, const 
   }
 }
 
+// the launcher's sequence for the reference's own weights at the default settings (reduced_native): the reduced-native solver
+// on the workgroup first (mpmpc_reduced_block_kernel), then the general one - straight to phase 1 and the full iteration, mode 2 -
+// on what that could not certify
+static void solve_wide_native(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
+                              int* status, int* iters, double* resid, double* y) {
+  constexpr int G = EMU_W, C = EMU_W / 2;
+  using L = LaneEmu<G, C>;
+  const int ld = stage_ld(cfg->N);
+  std::vector<int> tail;
+  for (int w = 0; w < B; ++w) {
+    VI inst = L::slot() + w;
+    VI k = L::stage() - lane_offset(G, C, cfg->N);
+    ReducedSolver<L> s;
+    typename L::real fields[MPMPC_NUM_FIELDS];
+    ReducedSolver<L>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    s.template run<false>(fields, B, inst, k, cfg->N, make_params(*st), VI(0));
+    s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y, nullptr, ld);
+    for (int i = 0; i < EMU_W; ++i)
+      if (k.v[i] == 0 && inst.v[i] < B && s.status.v[i] == MPMPC_UNSOLVED) tail.push_back(inst.v[i]);
+  }
+  for (int id : tail) {
+    VI inst = L::slot() + id;
+    VI k = L::stage() - lane_offset(G, C, cfg->N);
+    using S = Solver<L, false, true, false, true>;
+    S s;
+    typename L::real fields[MPMPC_NUM_FIELDS];
+    S::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    s.template run<false, true>(fields, B, inst, k, cfg->N, make_params(*st), 2, VI(0), VI(iters[id * 2 + 1]), nullptr);
+    s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y, nullptr, ld);
+  }
+}
+
 // the kernel the launcher picks for a horizon above 63: the general solver, one instance per workgroup; full weights
 // where a weight matrix has off-diagonal entries, the reduced polish where the time state separates.  -1: the horizon does not belong to this width.
 extern "C" int emuw_width() { return EMU_W; }
 extern "C" int emuw_solve(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
                           int* status, int* iters, double* resid, double* y) {
   if (stage_ld(cfg->N) != EMU_W) return -1;
+  if (!full_weights(*cfg) && reduced_native(*cfg, *st)) { solve_wide_native(cfg, st, qp, B, z, u0, status, iters, resid, y); return 0; }
   if (full_weights(*cfg)) solve_wide<1>(cfg, st, qp, B, z, u0, status, iters, resid, y);
   else if (reducible(*cfg, *st)) solve_wide<2>(cfg, st, qp, B, z, u0, status, iters, resid, y);      // (the launcher's choice: mpmpc_hip.hip, launch_solve)
   else solve_wide<0>(cfg, st, qp, B, z, u0, status, iters, resid, y);
