@@ -14,6 +14,8 @@
 //   K2t mpmpc_reduced_t_kernel  its twin for a terminal cost on the time state (rank-one term, Sherman-Morrison)
 //   K2p mpmpc_reduced_tail_kernel  the tail of a K2r launch (infeasible / marginal / capped instances) on the same footing:
 //                               phase 1 and one more attempt; K2 takes what it leaves
+//   K2b / K2rb                  horizons 64 .. 255: the general and the reduced-native solver on a WORKGROUP of 2 / 4 wavefronts
+//                               per instance (lane_gpu.hpp: LaneBlock)
 //   K0 / K3 / K4                corridor tables from the map, closed-loop rollout, speed profile (see below).
 //
 // No CPU path exists in this library: every compute entry point needs a HIP device.
