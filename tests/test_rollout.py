@@ -100,6 +100,45 @@ def test_device_rollout_matches_host_loop():
 
 
 @pytest.mark.gpu
+def test_device_rollout_matches_host_loop_at_a_long_horizon(emu):
+    """The closed loop at N = 70 - one instance per WORKGROUP of two wavefronts on the device (reduced-native solver, general
+    kernel on its tail), cold starts: every car follows the reference's own loop run with our host classes."""
+    import test_host_mpc as H
+    g1 = np.load(M.GOLDEN + "/g1_path_sim_track.npz")
+    tr = __import__("scenarios").sim_track()
+    N, steps = 70, 6
+    tw = T.wide_track(tr, emu, N)                   # corridor tables with N columns (golden G3 has 50; bit-equal on those)
+    starts = np.array([5, 61, 120, 171])
+    cum = np.cumsum(g1["segment_lengths"])
+    B = starts.size
+    host = []
+    for w in starts:
+        m, rp, car = H.build_world()
+        mpc = H.make_mpc(car, N)
+        car.s = float(cum[w])
+        car.temporal_state.x, car.temporal_state.y, car.temporal_state.psi = rp.waypoints[w].x, rp.waypoints[w].y, rp.waypoints[w].psi
+        for _ in range(steps):
+            u = mpc.get_control()
+            car.drive(u)
+        host.append((car.s, car.temporal_state.x, car.temporal_state.y, car.temporal_state.psi, u[0], u[1]))
+    host = np.array(host)
+    cfg = T.stock_config(N, max_batch=B)
+    h = mpmpc.Handle(cfg)
+    h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+    h.set_corridor(tw.ub_obstacles, tw.lb_obstacles)
+    h.set_path_geometry(g1["x"], g1["y"], g1["psi"], g1["border_ub"], g1["border_lb"])
+    poses = np.stack([g1["x"][starts], g1["y"][starts], g1["psi"][starts]], axis=1)
+    h.rollout_init(0.05, cum, cum[starts], poses)
+    h.rollout_step(steps)
+    st = h.rollout_state()
+    h.close()
+    assert np.all(st["alive"] == 1)
+    assert np.max(np.abs(st["s"] - host[:, 0])) <= 1e-8
+    assert np.max(np.abs(st["pose"] - host[:, 1:4])) <= 1e-8
+    assert np.max(np.abs(st["u"] - host[:, 4:6])) <= 1e-6
+
+
+@pytest.mark.gpu
 def test_rollout_warm_start_changes_nothing_but_the_time():
     """The closed loop with the warm start (previous step's shifted active set first, default) and without it:
     same trajectories, same statuses; most steps of the warm run need no ADMM / interior-point iteration."""
