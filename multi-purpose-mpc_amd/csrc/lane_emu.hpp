@@ -182,13 +182,16 @@ struct LaneEmu {
   static VB cr_low15() { VB r; for (int i = 0; i < EMU_W; ++i) r.v[i] = (i & 31) == 15; return r; }
   static VB cr_special() { VB r; for (int i = 0; i < EMU_W; ++i) { const int p = i & 15; r.v[i] = (i & 16) != 0 && ((p & (p + 1)) == 0) && p != 15; } return r; }
 
-  // ---- 64-lane chains (a wavefront of a 128-lane workgroup: four rows; lane_gpu.hpp: LaneBlock<128>, Solver::kCR64)
-  static VB cr64_x(int r) { VB m; for (int i = 0; i < EMU_W; ++i) m.v[i] = (i & 63) == 16 * r + 15; return m; }
-  static VB cr64_special(int r) { VB m; for (int i = 0; i < EMU_W; ++i) { const int p = i & 15; m.v[i] = ((i >> 4) & 3) == r + 1 && ((p & (p + 1)) == 0) && p != 15; } return m; }
-  static VD row_next(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = ((i & 63) + 16 < 64) ? a.v[i + 16] : 0.0; return r; }
-  static VD row_prev(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = ((i & 63) >= 16) ? a.v[i - 16] : 0.0; return r; }
-  static VD wdown(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = ((i & 63) != 63) ? a.v[i + 1] : 0.0; return r; }
-  static VD bcast15_next(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = ((i & 63) >= 16) ? a.v[((i & ~15) - 16) | 15] : 0.0; return r; }
+  // ---- chains of four / eight rows (a 128- / 256-lane workgroup; lane_gpu.hpp: LaneBlock, Solver::kCR64): position of a lane in
+  // its chain = lane % C; step r works on the survivor X of row r, the survivor Y of row r + 1 and that row's lanes 0, 1, 3, 7
+  static VB cr64_x(int r) { VB m; for (int i = 0; i < EMU_W; ++i) m.v[i] = (i % C) == 16 * r + 15; return m; }
+  static VB cr64_special(int r) { VB m; for (int i = 0; i < EMU_W; ++i) { const int p = i & 15; m.v[i] = ((i % C) >> 4) == r + 1 && ((p & (p + 1)) == 0) && p != 15; } return m; }
+  // pull: every lane gets v of the same position one row up the chain; push: one row down; down: of the next lane; bcast: of
+  // position 15 of the row below (what a lane without such a source gets is not used: 0 here)
+  template <int NV> static void cr_pull(int, const VD* v, VD* o) { MPMPC_OP(shift); for (int k = 0; k < NV; ++k) for (int i = 0; i < EMU_W; ++i) o[k].v[i] = ((i % C) + 16 < C) ? v[k].v[i + 16] : 0.0; }
+  template <int NV> static void cr_push(int, const VD* v, VD* o) { MPMPC_OP(shift); for (int k = 0; k < NV; ++k) for (int i = 0; i < EMU_W; ++i) o[k].v[i] = ((i % C) >= 16) ? v[k].v[i - 16] : 0.0; }
+  template <int NV> static void cr_down(int, const VD* v, VD* o) { MPMPC_OP(shift); for (int k = 0; k < NV; ++k) for (int i = 0; i < EMU_W; ++i) o[k].v[i] = ((i % C) != C - 1) ? v[k].v[i + 1] : 0.0; }
+  template <int NV> static void cr_bcast(int, const VD* v, VD* o) { MPMPC_OP(shift); for (int k = 0; k < NV; ++k) for (int i = 0; i < EMU_W; ++i) o[k].v[i] = ((i % C) >= 16) ? v[k].v[((i & ~15) - 16) | 15] : 0.0; }
 
   // half-wave exchange (see lane_gpu.hpp)
   static VD from_upper(const VD& a) { MPMPC_OP(shift); VD r; for (int i = 0; i < EMU_W; ++i) r.v[i] = a.v[i | 32]; return r; }

@@ -496,25 +496,46 @@ struct LaneBlock {
     return take(a, (t == C - 1 || t == 2 * C - 1) ? -1 : t + 1);
   }
 
-  // ---- cyclic reduction of 64-lane chains (G = 128: a chain is a wavefront of four rows; Solver::kCR64).  The in-row shifts
-  // and masks of the levels are the wavefront backend's; the survivors of the rows meet through moves by whole rows.
+  // ---- cyclic reduction of the chains (G = 128: a chain is a wavefront of four rows; G = 256: two wavefronts, eight rows;
+  // Solver::kCR64).  The in-row shifts and masks of the levels are the wavefront backend's; the survivors of the rows meet
+  // through moves by whole rows.
   template <int D> static __device__ __forceinline__ double rshr(double a) { return dpp_shift<0x110 + D>(a); }
   template <int D> static __device__ __forceinline__ double rshl(double a) { return dpp_shift<0x100 + D>(a); }
   template <int D> static __device__ __forceinline__ bool cr_elim() { return (((threadIdx.x & 15) + D + 1) & (2 * D - 1)) == 0; }
-  static __device__ __forceinline__ bool cr64_x(int r) { return (int)(threadIdx.x & 63) == 16 * r + 15; }
+  // position of a lane in its chain = lane % C; step r works on the survivor X of row r (position 15), the survivor Y of row
+  // r + 1 and that row's lanes 0, 1, 3, 7.  At G = 256 (chains of eight rows over two wavefronts) step 3 crosses the wavefronts.
+  static __device__ __forceinline__ bool cr64_x(int r) { return (int)(threadIdx.x & (C - 1)) == 16 * r + 15; }
   static __device__ __forceinline__ bool cr64_special(int r) {
     const int p = threadIdx.x & 15;
-    return (int)((threadIdx.x >> 4) & 3) == r + 1 && ((p & (p + 1)) == 0) && p != 15;
+    return (int)((threadIdx.x & (C - 1)) >> 4) == r + 1 && ((p & (p + 1)) == 0) && p != 15;
   }
-  // the same position of the next / previous row of the wavefront (what a lane without such a row gets is not used)
-  static __device__ __forceinline__ double row_next(double a) { return __shfl(a, ((int)threadIdx.x + 16) & 63, 64); }
-  static __device__ __forceinline__ double row_prev(double a) { return __shfl(a, ((int)threadIdx.x - 16) & 63, 64); }
-  static __device__ __forceinline__ double wdown(double a) { return dpp_shift<DPP_WAVE_SHL1>(a); }     // lane i <- lane i + 1 inside the wavefront
-  // every lane of rows 1 .. 3 gets a of position 15 of the row below (row_bcast:15), row 0 gets 0
-  static __device__ __forceinline__ double bcast15_next(double a) {
-    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(a), 0x142, 0xE, 0xf, false);
-    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(a), 0x142, 0xE, 0xf, false);
-    return __hiloint2double(hi, lo);
+  static __device__ __forceinline__ bool cr_crosses(int r) { return G == 256 && r == 3; }
+  // pull: every lane gets v of the same position one row up the chain (lane + 16); push: one row down (lane - 16); down: of
+  // the next lane; bcast: of position 15 of the row below.  Inside a wavefront a lane permutation / DPP move per value; the
+  // crossing step batches its values through the exchange rows (what a lane without such a source gets is not used).
+  template <int NV> static __device__ __forceinline__ void cr_pull(int r, const double* v, double* o) {
+    if (cr_crosses(r)) { takev<NV>(v, o, (int)threadIdx.x + 16); return; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) o[i] = __shfl(v[i], ((int)threadIdx.x + 16) & 63, 64);
+  }
+  template <int NV> static __device__ __forceinline__ void cr_push(int r, const double* v, double* o) {
+    if (cr_crosses(r)) { takev<NV>(v, o, (int)threadIdx.x - 16); return; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) o[i] = __shfl(v[i], ((int)threadIdx.x - 16) & 63, 64);
+  }
+  template <int NV> static __device__ __forceinline__ void cr_down(int r, const double* v, double* o) {
+    if (cr_crosses(r)) { takev<NV>(v, o, (int)threadIdx.x + 1); return; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) o[i] = dpp_shift<DPP_WAVE_SHL1>(v[i]);
+  }
+  template <int NV> static __device__ __forceinline__ void cr_bcast(int r, const double* v, double* o) {
+    if (cr_crosses(r)) { takev<NV>(v, o, (((int)threadIdx.x & ~15) - 16) | 15); return; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {        // row_bcast:15 into rows 1 .. 3 of the wavefront
+      int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v[i]), 0x142, 0xE, 0xf, false);
+      int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v[i]), 0x142, 0xE, 0xf, false);
+      o[i] = __hiloint2double(hi, lo);
+    }
   }
 
   template <class F>

@@ -117,9 +117,12 @@ MPMPC_HOST_DEVICE inline int lane_offset(int G, int C, int N) {
 template <class L, bool FQ = false, bool RED = false, bool FREEX = false, bool CR = false, int RKS = 0>
 struct Solver {
   static_assert(!(FQ && RED), "the reduced problem needs a diagonal terminal weight");
-  static constexpr bool kCR = CR && (L::split == 16 || L::split == 32 || L::split == 64);
+  static constexpr bool kCR = CR && (L::split == 16 || L::split == 32 || L::split == 64 || L::split == 128);
   static constexpr bool kCR32 = kCR && L::split == 32;      // a chain is TWO rows of 16 lanes (see factor_cr2)
-  static constexpr bool kCR64 = kCR && L::split == 64;      // ... FOUR rows: a whole wavefront of a 128-lane workgroup (LaneBlock<128>)
+  // ... FOUR rows - a whole wavefront of a 128-lane workgroup - or EIGHT, two wavefronts of a 256-lane one (LaneBlock): the
+  // survivors of the rows are eliminated one after the other, kCRrows - 1 steps
+  static constexpr bool kCR64 = kCR && (L::split == 64 || L::split == 128);
+  static constexpr int kCRrows = L::split / 16;
   using R = typename L::real;
   using Mk = typename L::mask;
   using I = typename L::ival;

@@ -747,19 +747,26 @@
       MPMPC_SERIAL_END(N + 1);
     }
     if constexpr (kCR64) {
-      // ---- 64-lane chains (a wavefront of a 128-lane workgroup): FOUR rows.  The same step as above, three times in turn:
-      // step r = 0, 1, 2 eliminates the survivor X of row r (position 15) against the survivor Y of row r + 1 - which is the
-      // X of the next step, and after the last one the lane of the junction.  The moves are by whole rows inside the wavefront.
+      // ---- chains of FOUR rows (a wavefront of a 128-lane workgroup) or EIGHT (two wavefronts of a 256-lane one).  The same
+      // step as above, kCRrows - 1 times in turn: step r eliminates the survivor X of row r (position 15) against the survivor
+      // Y of row r + 1 - which is the X of the next step, and after the last one the lane of the junction.  The moves are by
+      // whole rows: inside the wavefront, or - the one step of an eight-row chain that crosses its two wavefronts - through LDS
+      // (L::cr_pull / cr_push / cr_down / cr_bcast).
       MPMPC_SERIAL_BEGIN();
       MPMPC_UNROLL
-      for (int r = 0; r < 3; ++r) {
+      for (int r = 0; r < kCRrows - 1; ++r) {
         const Mk spec = L::cr64_special(r), isX = L::cr64_x(r), isY = L::cr64_x(r + 1);
         R w0 = sel(spec, fma_(Gin[2], Gin[2], Gin[0] * Gin[0]), zero), w1 = sel(spec, fma_(Gin[3], Gin[2], Gin[1] * Gin[0]), zero),
           w2 = sel(spec, fma_(Gin[3], Gin[3], Gin[1] * Gin[1]), zero);
         w0 = w0 + L::template rshl<1>(w0); w1 = w1 + L::template rshl<1>(w1); w2 = w2 + L::template rshl<1>(w2);
         w0 = w0 + L::template rshl<3>(w0); w1 = w1 + L::template rshl<3>(w1); w2 = w2 + L::template rshl<3>(w2);
         w0 = w0 + L::template rshl<7>(w0); w1 = w1 + L::template rshl<7>(w1); w2 = w2 + L::template rshl<7>(w2);
-        Dg[0] = Dg[0] - sel(isX, L::wdown(w0), zero); Dg[1] = Dg[1] - sel(isX, L::wdown(w1), zero); Dg[2] = Dg[2] - sel(isX, L::wdown(w2), zero);
+        {
+          const R wv[3] = {w0, w1, w2};
+          R wd[3];
+          L::template cr_down<3>(r, wv, wd);
+          Dg[0] = Dg[0] - sel(isX, wd[0], zero); Dg[1] = Dg[1] - sel(isX, wd[1], zero); Dg[2] = Dg[2] - sel(isX, wd[2], zero);
+        }
         R i00 = rsqrt_(Dg[0]);
         const R l10 = Dg[1] * i00;
         R i11 = rsqrt_(fma_(-l10, l10, Dg[2]));
@@ -767,12 +774,12 @@
         i00 = sel(isX, i00, zero); i10 = sel(isX, i10, zero); i11 = sel(isX, i11, zero);
         Li[0] = Li[0] + i00; Li[1] = Li[1] + i10; Li[2] = Li[2] + i11;
         R Cb[4], Ub[4], gb[4];
-        MPMPC_UNROLL
-        for (int i = 0; i < 4; ++i) Cb[i] = L::row_next(Cm[i]);
+        L::template cr_pull<4>(r, Cm, Cb);
         Ub[0] = i00 * Cb[0]; Ub[1] = i00 * Cb[2];
         Ub[2] = fma_(i11, Cb[1], i10 * Cb[0]); Ub[3] = fma_(i11, Cb[3], i10 * Cb[2]);
+        L::template cr_push<4>(r, Ub, gb);
         MPMPC_UNROLL
-        for (int i = 0; i < 4; ++i) { Gout[i] = Gout[i] + Ub[i]; gb[i] = sel(isY, L::row_prev(Ub[i]), zero); }
+        for (int i = 0; i < 4; ++i) { Gout[i] = Gout[i] + Ub[i]; gb[i] = sel(isY, gb[i], zero); }
         Dg[0] = fma_(-gb[2], gb[2], fma_(-gb[0], gb[0], Dg[0]));
         Dg[1] = fma_(-gb[3], gb[2], fma_(-gb[1], gb[0], Dg[1]));
         Dg[2] = fma_(-gb[3], gb[3], fma_(-gb[1], gb[1], Dg[2]));
@@ -890,17 +897,22 @@
     if constexpr (kCR64) {
       MPMPC_SERIAL_BEGIN();
       MPMPC_UNROLL
-      for (int r = 0; r < 3; ++r) {                     // (factor_cr2: the survivors of rows 0, 1, 2 in turn)
+      for (int r = 0; r < kCRrows - 1; ++r) {           // (factor_cr2: the survivors of the rows in turn)
         const Mk spec64 = L::cr64_special(r), isX64 = L::cr64_x(r), isY64 = L::cr64_x(r + 1);
         R c0 = sel(spec64, fma_(Gin[2], y1, Gin[0] * y0), zero), c1 = sel(spec64, fma_(Gin[3], y1, Gin[1] * y0), zero);
         c0 = c0 + L::template rshl<1>(c0); c1 = c1 + L::template rshl<1>(c1);
         c0 = c0 + L::template rshl<3>(c0); c1 = c1 + L::template rshl<3>(c1);
         c0 = c0 + L::template rshl<7>(c0); c1 = c1 + L::template rshl<7>(c1);
-        const R bx0 = b0 - L::wdown(c0), bx1 = b1 - L::wdown(c1);
+        const R cv[2] = {c0, c1};
+        R cd[2];
+        L::template cr_down<2>(r, cv, cd);
+        const R bx0 = b0 - cd[0], bx1 = b1 - cd[1];
         const R yx0 = sel(isX64, Li[0] * bx0, zero), yx1 = sel(isX64, fma_(Li[2], bx1, Li[1] * bx0), zero);
         y0 = y0 + yx0; y1 = y1 + yx1;
-        const R p0 = fma_(Gout[2], yx1, Gout[0] * yx0), p1 = fma_(Gout[3], yx1, Gout[1] * yx0);
-        b0 = b0 - sel(isY64, L::row_prev(p0), zero); b1 = b1 - sel(isY64, L::row_prev(p1), zero);
+        const R pv[2] = {fma_(Gout[2], yx1, Gout[0] * yx0), fma_(Gout[3], yx1, Gout[1] * yx0)};
+        R pp_[2];
+        L::template cr_push<2>(r, pv, pp_);
+        b0 = b0 - sel(isY64, pp_[0], zero); b1 = b1 - sel(isY64, pp_[1], zero);
       }
       MPMPC_SERIAL_END(N + 1);
     }
@@ -935,13 +947,19 @@
     if constexpr (kCR64) {
       MPMPC_SERIAL_BEGIN();
       MPMPC_UNROLL
-      for (int r = 2; r >= 0; --r) {                    // (the survivors backwards: row 2's first - its Y is the junction lane)
+      for (int r = kCRrows - 2; r >= 0; --r) {          // (the survivors backwards: the last row's first - its Y is the junction lane)
         const Mk spec64 = L::cr64_special(r), isX64 = L::cr64_x(r);
-        const R c0 = L::row_next(n0), c1 = L::row_next(n1);
+        const R nv_[2] = {n0, n1};
+        R cn_[2];
+        L::template cr_pull<2>(r, nv_, cn_);
+        const R c0 = cn_[0], c1 = cn_[1];
         const R r0 = y0 - fma_(Gout[1], c1, Gout[0] * c0), r1 = y1 - fma_(Gout[3], c1, Gout[2] * c0);
         n0 = sel(isX64, fma_(Li[1], r1, Li[0] * r0), n0);
         n1 = sel(isX64, Li[2] * r1, n1);
-        const R x0 = L::bcast15_next(n0), x1 = L::bcast15_next(n1);
+        const R nx_[2] = {n0, n1};
+        R xb_[2];
+        L::template cr_bcast<2>(r, nx_, xb_);
+        const R x0 = xb_[0], x1 = xb_[1];
         y0 = y0 - sel(spec64, fma_(Gin[1], x1, Gin[0] * x0), zero);
         y1 = y1 - sel(spec64, fma_(Gin[3], x1, Gin[2] * x0), zero);
       }

@@ -17,7 +17,7 @@ static_assert(EMU_W == 128 || EMU_W == 256, "build with -DMPMPC_EMU_W=128 or 256
 
 // (a chain of the 128-lane workgroup is a wavefront: the reduced variant factors it by cyclic reduction, as on the device)
 static_assert(EMU_W != 128 || Solver<LaneEmu<EMU_W, EMU_W / 2>, false, true, false, true>::kCR64, "cyclic reduction of 64-lane chains");
-static_assert(EMU_W != 256 || !Solver<LaneEmu<EMU_W, EMU_W / 2>, false, true, false, true>::kCR, "256 lanes: sequential (staged) sweeps");
+static_assert(EMU_W != 256 || Solver<LaneEmu<EMU_W, EMU_W / 2>, false, true, false, true>::kCRrows == 8, "256 lanes: chains of eight rows");
 
 template <int VAR>
 static void solve_wide(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,

@@ -118,7 +118,9 @@ def test_no_batch_path_solve_kernel_has_scratch(lib):
         # (VAR 1 = full weights: since round 5 Q and R may have off-diagonal entries too - dense blocks on every lane)
         "mpmpc_solve_kernel<64, 32, false, 1>": 228, "mpmpc_solve_kernel<64, 32, true, 1>": 236,
         # horizons above 63 (round 5): the general solver on a workgroup of 2 / 4 wavefronts, 512 registers per lane
-        # (VAR 2, the reduced polish of the reference's own weights, has none)
+        # (VAR 2, the reduced polish of the reference's own weights - the tail of the reduced-native workgroup kernel, which has
+        #  none - has none at 128 lanes and 28 B at 256, where the eight-row cyclic reduction crosses the wavefronts)
+        "mpmpc_solve_block_kernel<256, 2>": 28,
         "mpmpc_solve_block_kernel<128, 0>": 128, "mpmpc_solve_block_kernel<128, 1>": 256,
         "mpmpc_solve_block_kernel<256, 0>": 268, "mpmpc_solve_block_kernel<256, 1>": 392,
         # the one-instance-per-wave form of the reduced-native tail kernel (mpmpc_set_tail_kernel(h, 2); the default form,
