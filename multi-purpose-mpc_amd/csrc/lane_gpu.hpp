@@ -356,9 +356,9 @@ struct LaneGpu {
 // lanes [G/2, G) descend (C = G / 2), exactly as for <64, 32>.  The one-lane shifts ALONG the chains - what the sequential
 // sweeps are made of - avoid the barriers: at G = 128 a chain is a wavefront and they are DPP shifts in registers; at G = 256 a
 // chain spans two wavefronts and the sweep is staged wavefront by wavefront (chain_shift; Solver::staged_sweep).  The reduced
-// variant at G = 128 does without the sweeps: its 64-lane chains are factored by cyclic reduction (rshl / rshr / cr64_* below;
-// Solver::kCR64).  No split layout, no packing; this is the general kernel's code at one wavefront per SIMD - the price of a
-// horizon the reference allows (src/MPC.py:73-74 has no limit) and a 64-lane wavefront does not hold.
+// solvers (2 x 2 blocks) do without the sweeps: their chains of four / eight rows are factored by cyclic reduction (rshl / rshr /
+// cr64_* / cr_pull .. below; Solver::kCR64).  No split layout, no packing; one wavefront per SIMD for the general solver - the
+// price of a horizon the reference allows (src/MPC.py:73-74 has no limit) and a 64-lane wavefront does not hold.
 // LDS per workgroup: SLOTS cold slots of G doubles (also the staging of the output rows) + nine exchange rows + the
 // reduction scratch: 77 KB at G = 128 (two workgroups per CU), 154 KB at G = 256, passed as DYNAMIC shared memory (above the 64 KB static limit).
 template <int G, int SLOTS = 66>

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(G) void mpmpc_solve_block_kernel(mpmpc_config cfg, 
   const int k = L::stage() - lane_offset(G, G / 2, cfg.N);
   double fields[MPMPC_NUM_FIELDS];
   assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
-  // (the reduced variant factors 64-lane chains - G = 128: a chain is a wavefront - by cyclic reduction: Solver::kCR64)
+  // (the reduced variant factors its chains of four / eight rows by cyclic reduction: Solver::kCR64)
   Solver<L, VAR == 1, VAR == 2, false, VAR == 2> s;
   double woff[7];
   weight_offdiag(cfg, woff);
