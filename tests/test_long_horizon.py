@@ -47,6 +47,26 @@ def test_long_horizons_in_the_emulation_against_the_c_oracle(N, cfgid, emu, trac
         assert good.all()
 
 
+@pytest.mark.parametrize("N", [65, 80, 96, 112, 126, 129, 144, 160, 192, 224, 254])
+def test_cyclic_reduction_of_partly_filled_rows(N, emu, track):
+    """The chains of a workgroup instance are right-aligned: their first rows are empty or partly filled, differently for every
+    horizon.  The reduced-native workgroup solver (cyclic reduction inside the rows, the row survivors in turn, one step across
+    the wavefronts at 256 lanes) against the C oracle at horizons on and beside the row boundaries."""
+    B = 6
+    tw = T.wide_track(track, emu, N)
+    for cfgid in (2, 4):
+        sc = scenarios.make(cfgid, tw, B=B, N=N)
+        cfg = T.stock_config(N, sc.weights)
+        qp = emu.assemble(cfg, tw, (sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub))
+        sol = emu.solve(cfg, mpmpc.default_settings(phase1_accept=0), qp)
+        ref = _oracle(track, sc, scenarios.WEIGHTS[sc.weights])
+        assert np.array_equal(sol.status, ref["status"])
+        ok = sol.status == 1
+        assert ok.any() and np.max(np.abs(sol.u0[ok] - ref["u0"][ok])) <= 1e-6
+        prim, stat, comp = T.kkt_batch(qp[:, ok, :], N, sol.z[ok], sol.y[ok])
+        assert max(prim.max(), stat.max(), comp.max()) <= 1e-8
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("N", [70, 150])
 def test_long_horizon_general_variants_on_device(N, track, emu):
