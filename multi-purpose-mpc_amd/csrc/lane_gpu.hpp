@@ -485,6 +485,15 @@ struct LaneBlock {
       return take(a, t < C ? t : 3 * C - 1 - t);
     }
   }
+  template <int NV> static __device__ __forceinline__ void mirrorv(const double* v, double* o) {
+    if constexpr (G == 128) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) o[i] = mirror(v[i]);
+    } else {
+      const int t = threadIdx.x;
+      takev<NV>(v, o, t < C ? t : 3 * C - 1 - t);
+    }
+  }
   static __device__ __forceinline__ double cup(double a) {
     if constexpr (G == 128) return dpp_shift<DPP_WAVE_SHR1>(a);
     const int t = threadIdx.x;

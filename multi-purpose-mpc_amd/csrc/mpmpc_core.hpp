@@ -224,6 +224,10 @@ struct Solver {
     if (!first) { for (int s = 0; s < second; ++s) step(SweepMode<2>{}); }
     L::sync();
   }
+  template <int NV> MPMPC_HD static void mirror_n(const R* v, R* o) {
+    if constexpr (L::batched) L::template mirrorv<NV>(v, o);
+    else { MPMPC_UNROLL for (int i = 0; i < NV; ++i) o[i] = L::mirror(v[i]); }
+  }
   template <int NV> MPMPC_HD static void up_n(const R* v, R* o) {
     if constexpr (L::batched) L::template upv<NV>(v, o);
     else { MPMPC_UNROLL for (int i = 0; i < NV; ++i) o[i] = L::up(v[i]); }

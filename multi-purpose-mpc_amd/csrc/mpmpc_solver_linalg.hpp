@@ -29,6 +29,38 @@
     if constexpr (L::junction_moves) return sel(is_end, L::mid_to_end(v), zero);
     else return sel(is_end, L::mirror(L::up(sel(is_mid, v, zero))), zero);
   }
+  // ... NV values at once: where an exchange passes workgroup barriers (L::batched) the values share one pass
+  template <int NV> MPMPC_HD void end_to_mid_n(const R* q, R* o) const {
+    if constexpr (L::batched) {
+      const R zero(0.0);
+      R e[NV], m[NV], d[NV];
+      MPMPC_UNROLL
+      for (int i = 0; i < NV; ++i) e[i] = sel(is_end, q[i], zero);
+      mirror_n<NV>(e, m);
+      down_n<NV>(m, d);
+      MPMPC_UNROLL
+      for (int i = 0; i < NV; ++i) o[i] = sel(is_mid, d[i], zero);
+    } else {
+      MPMPC_UNROLL
+      for (int i = 0; i < NV; ++i) o[i] = end_to_mid(q[i]);
+    }
+  }
+  template <int NV> MPMPC_HD void mid_to_end_n(const R* v, R* o) const {
+    if constexpr (L::batched) {
+      const R zero(0.0);
+      R m[NV], u[NV];
+      MPMPC_UNROLL
+      for (int i = 0; i < NV; ++i) m[i] = sel(is_mid, v[i], zero);
+      up_n<NV>(m, u);
+      R w[NV];
+      mirror_n<NV>(u, w);
+      MPMPC_UNROLL
+      for (int i = 0; i < NV; ++i) o[i] = sel(is_end, w[i], zero);
+    } else {
+      MPMPC_UNROLL
+      for (int i = 0; i < NV; ++i) o[i] = mid_to_end(v[i]);
+    }
+  }
   MPMPC_HD int chain_steps() const {
     const int C = L::split;
     int fwd = N + 1 < C - 1 - off_ ? N + 1 : C - 1 - off_, bwd = N - C + off_ + 1;
@@ -127,8 +159,7 @@
       if (junction) {
         // junction: both chains have settled; mid also loses the block of the end lane
         R Mx[9];
-        MPMPC_UNROLL
-        for (int i = 0; i < 9; ++i) Mx[i] = end_to_mid(M[i]);
+        end_to_mid_n<9>(M, Mx);
         S00 = fma_(-Mx[2], Mx[2], fma_(-Mx[1], Mx[1], fma_(-Mx[0], Mx[0], S00)));
         S10 = fma_(-Mx[5], Mx[2], fma_(-Mx[4], Mx[1], fma_(-Mx[3], Mx[0], S10)));
         S11 = fma_(-Mx[5], Mx[5], fma_(-Mx[4], Mx[4], fma_(-Mx[3], Mx[3], S11)));
@@ -228,9 +259,7 @@
       R t1 = fma_(Gout[5], y2, fma_(Gout[4], y1, Gout[3] * y0));
       R t2 = fma_(Gout[8], y2, fma_(Gout[7], y1, Gout[6] * y0));
       const R zero(0.0);
-      t0 = end_to_mid(t0);
-      t1 = end_to_mid(t1);
-      t2 = end_to_mid(t2);
+      { const R tv[3] = {t0, t1, t2}; R to_[3]; end_to_mid_n<3>(tv, to_); t0 = to_[0]; t1 = to_[1]; t2 = to_[2]; }
       R e0 = c0 - Li[0] * t0;
       R e1 = c1 - fma_(Li[2], t1, Li[1] * t0);
       R e2 = c2 - fma_(Li[5], t2, fma_(Li[4], t1, Li[3] * t0));
@@ -247,9 +276,8 @@
       // outward junction: nu of mid is final (it has no successor); the end lane takes it through M_own'
       MPMPC_SERIAL_BEGIN();
       const R zero(0.0);
-      R m0 = mid_to_end(d0);
-      R m1 = mid_to_end(d1);
-      R m2 = mid_to_end(d2);
+      R m0, m1, m2;
+      { const R dv[3] = {d0, d1, d2}; R mo_[3]; mid_to_end_n<3>(dv, mo_); m0 = mo_[0]; m1 = mo_[1]; m2 = mo_[2]; }
       R w0 = fma_(Gout[6], m2, fma_(Gout[3], m1, Gout[0] * m0));
       R w1 = fma_(Gout[7], m2, fma_(Gout[4], m1, Gout[1] * m0));
       R w2 = fma_(Gout[8], m2, fma_(Gout[5], m1, Gout[2] * m0));
@@ -413,10 +441,11 @@
       MPMPC_UNROLL
       for (int i = 0; i < 3; ++i) r[i] = fma_(mI[i], v[i], L::up(w[i]));
     } else if constexpr (LAY == LAY_RED || LAY == LAY_RED4) {      // (the speed, entry 3 of LAY_RED4, is in no equality row)
-      R w0 = fma_(a[1], v[1], a[0] * v[0]);
-      R w1 = fma_(b[0], v[2], fma_(a[3], v[1], a[2] * v[0]));
-      r[0] = fma_(mI[0], v[0], L::up(w0));
-      r[1] = fma_(mI[1], v[1], L::up(w1));
+      const R w[2] = {fma_(a[1], v[1], a[0] * v[0]), fma_(b[0], v[2], fma_(a[3], v[1], a[2] * v[0]))};
+      R wu[2];
+      up_n<2>(w, wu);
+      r[0] = fma_(mI[0], v[0], wu[0]);
+      r[1] = fma_(mI[1], v[1], wu[1]);
     } else {
       R c1 = L::from_upper(bU[0] * v[0]);
       R w0 = fma_(a[1], v[1], a[0] * v[0]);
@@ -438,7 +467,9 @@
       t[1] = fma_(bU[0], u1, fma_(a[3], nd[1], fma_(a[1], nd[0], mI[1] * nu[1])));
       t[2] = fma_(a[5], nd[2], mI[2] * nu[2]);
     } else if constexpr (LAY == LAY_RED || LAY == LAY_RED4) {
-      R nd0 = L::down(nu[0]), nd1 = L::down(nu[1]);
+      R nd_[2];
+      down_n<2>(nu, nd_);
+      const R nd0 = nd_[0], nd1 = nd_[1];
       t[0] = fma_(a[2], nd1, fma_(a[0], nd0, mI[0] * nu[0]));
       t[1] = fma_(a[3], nd1, fma_(a[1], nd0, mI[1] * nu[1]));
       t[2] = b[0] * nd1;
@@ -534,14 +565,12 @@
       T[0] = a0h * mI[0]; T[1] = a1h * mI[1];
       T[2] = a2h * mI[0]; T[3] = a3h * mI[1];
     }
-    MPMPC_UNROLL
-    for (int i = 0; i < 3; ++i) Dg[i] = L::up(W[i]);
+    up_n<3>(W, Dg);
     Dg[0] = Dg[0] + fma_(mI[0] * mI[0], h[0], r);
     Dg[2] = Dg[2] + fma_(mI[1] * mI[1], h[1], r);
     {
       R Tu[4];
-      MPMPC_UNROLL
-      for (int i = 0; i < 4; ++i) Tu[i] = L::up(T[i]);
+      up_n<4>(T, Tu);
       const R zero(0.0);
       // coupling handed on: S_{k+1,k} = T going up, S_{k-1,k} = T_{k-1}' going down, nothing from mid
       To[0] = sel(down_chain, Tu[0], T[0]); To[1] = sel(down_chain, Tu[2], T[1]);
@@ -549,10 +578,8 @@
       MPMPC_UNROLL
       for (int i = 0; i < 4; ++i) To[i] = sel(is_mid, zero, To[i]);
     }
-    MPMPC_UNROLL
-    for (int i = 0; i < 3; ++i) Dg[i] = L::mirror(Dg[i]);
-    MPMPC_UNROLL
-    for (int i = 0; i < 4; ++i) To[i] = L::mirror(To[i]);
+    { R t_[3]; mirror_n<3>(Dg, t_); MPMPC_UNROLL for (int i = 0; i < 3; ++i) Dg[i] = t_[i]; }
+    { R t_[4]; mirror_n<4>(To, t_); MPMPC_UNROLL for (int i = 0; i < 4; ++i) To[i] = t_[i]; }
     if constexpr (kCR) { factor_cr2(Dg, To); return; }
     R M[4], Ls[4];
     MPMPC_UNROLL
@@ -566,8 +593,7 @@
       R S11 = fma_(-Mr[3], Mr[3], fma_(-Mr[2], Mr[2], Dg[2]));
       if (junction) {
         R Mx[4];
-        MPMPC_UNROLL
-        for (int i = 0; i < 4; ++i) Mx[i] = end_to_mid(M[i]);
+        end_to_mid_n<4>(M, Mx);
         S00 = fma_(-Mx[1], Mx[1], fma_(-Mx[0], Mx[0], S00));
         S10 = fma_(-Mx[3], Mx[1], fma_(-Mx[2], Mx[0], S10));
         S11 = fma_(-Mx[3], Mx[3], fma_(-Mx[2], Mx[2], S11));
@@ -803,8 +829,7 @@
       MPMPC_UNROLL
       for (int i = 0; i < 4; ++i) Gout[i] = sel(is_end, M[i], Gout[i]);          // the end lane keeps M_own (as in the sequential scheme)
       R Mx[4];
-      MPMPC_UNROLL
-      for (int i = 0; i < 4; ++i) Mx[i] = end_to_mid(M[i]);
+      end_to_mid_n<4>(M, Mx);
       Dg[0] = fma_(-Mx[1], Mx[1], fma_(-Mx[0], Mx[0], Dg[0]));
       Dg[1] = fma_(-Mx[3], Mx[1], fma_(-Mx[2], Mx[0], Dg[1]));
       Dg[2] = fma_(-Mx[3], Mx[3], fma_(-Mx[2], Mx[2], Dg[2]));
@@ -866,7 +891,9 @@
   }
   MPMPC_HD void s_solve_cr2(const R bv[2], R nu[2]) const {
     const R zero(0.0);
-    R b0 = sel(vxc, L::mirror(bv[0]), zero), b1 = sel(vxc, L::mirror(bv[1]), zero);
+    R bm_[2];
+    mirror_n<2>(bv, bm_);
+    R b0 = sel(vxc, bm_[0], zero), b1 = sel(vxc, bm_[1], zero);
     R y0(0.0), y1(0.0);
     {
       MPMPC_SERIAL_BEGIN();
@@ -921,12 +948,14 @@
     MPMPC_SERIAL_BEGIN();                                                           // (census: useful on the two lanes of the junction only)
     const R ye0 = Li[0] * b0, ye1 = fma_(Li[2], b1, Li[1] * b0);                   // valid on the end lane (and, pre-update, on mid)
     const R q0 = fma_(Gout[1], ye1, Gout[0] * ye0), q1 = fma_(Gout[3], ye1, Gout[2] * ye0);      // M y_end on the end lane
-    const R qm0 = end_to_mid(q0), qm1 = end_to_mid(q1);
+    R qm0, qm1;
+    { const R qv[2] = {q0, q1}; R qo_[2]; end_to_mid_n<2>(qv, qo_); qm0 = qo_[0]; qm1 = qo_[1]; }
     const R bm0 = b0 - qm0, bm1 = b1 - qm1;
     const R ym0 = Li[0] * bm0, ym1 = fma_(Li[2], bm1, Li[1] * bm0);
     const R nm0 = fma_(Li[1], ym1, Li[0] * ym0), nm1 = Li[2] * ym1;               // nu of the meeting stage (on mid)
     // to the end lane: M' nu_mid
-    const R me0 = mid_to_end(nm0), me1 = mid_to_end(nm1);
+    R me0, me1;
+    { const R nv2[2] = {nm0, nm1}; R mo2_[2]; mid_to_end_n<2>(nv2, mo2_); me0 = mo2_[0]; me1 = mo2_[1]; }
     const R re0 = ye0 - fma_(Gout[2], me1, Gout[0] * me0), re1 = ye1 - fma_(Gout[3], me1, Gout[1] * me0);
     const R ne0 = fma_(Li[1], re1, Li[0] * re0), ne1 = Li[2] * re1;
     R n0 = sel(is_mid, nm0, sel(is_end, ne0, zero)), n1 = sel(is_mid, nm1, sel(is_end, ne1, zero));
@@ -973,7 +1002,7 @@
       cr_backward<1>(y0, y1, n0, n1);
       MPMPC_SERIAL_END(4);
     }
-    nu[0] = L::mirror(n0); nu[1] = L::mirror(n1);
+    { const R nn_[2] = {n0, n1}; mirror_n<2>(nn_, nu); }
   }
 
   MPMPC_HD void s_solve2(const R bv[2], R nu[2]) const {
@@ -1009,8 +1038,7 @@
       R t0 = fma_(Gout[1], y1, Gout[0] * y0);
       R t1 = fma_(Gout[3], y1, Gout[2] * y0);
       const R zero(0.0);
-      t0 = end_to_mid(t0);
-      t1 = end_to_mid(t1);
+      { const R tv[2] = {t0, t1}; R to_[2]; end_to_mid_n<2>(tv, to_); t0 = to_[0]; t1 = to_[1]; }
       R e0 = c0 - Li[0] * t0;
       R e1 = c1 - fma_(Li[2], t1, Li[1] * t0);
       R p0 = L::cup(y0), p1 = L::cup(y1);
@@ -1024,8 +1052,8 @@
       // outward junction: nu of mid is final; the end lane takes it through M_own'
       MPMPC_SERIAL_BEGIN();
       const R zero(0.0);
-      R m0 = mid_to_end(d0);
-      R m1 = mid_to_end(d1);
+      R m0, m1;
+      { const R dv[2] = {d0, d1}; R mo_[2]; mid_to_end_n<2>(dv, mo_); m0 = mo_[0]; m1 = mo_[1]; }
       R w0 = fma_(Gout[2], m1, Gout[0] * m0);
       R w1 = fma_(Gout[3], m1, Gout[1] * m0);
       d0 = d0 - fma_(Li[1], w1, Li[0] * w0);
@@ -1053,7 +1081,7 @@
       }
       MPMPC_SERIAL_END(last + 1);
     }
-    nu[0] = L::mirror(n0); nu[1] = L::mirror(n1);
+    { const R nn_[2] = {n0, n1}; mirror_n<2>(nn_, nu); }
   }
 
   MPMPC_HD void admm_factor(double sigma) {

@@ -122,7 +122,7 @@ def test_no_batch_path_solve_kernel_has_scratch(lib):
         #  none - has none at 128 lanes and 28 B at 256, where the eight-row cyclic reduction crosses the wavefronts)
         "mpmpc_solve_block_kernel<256, 2>": 28,
         "mpmpc_solve_block_kernel<128, 0>": 128, "mpmpc_solve_block_kernel<128, 1>": 256,
-        "mpmpc_solve_block_kernel<256, 0>": 268, "mpmpc_solve_block_kernel<256, 1>": 392,
+        "mpmpc_solve_block_kernel<256, 0>": 268, "mpmpc_solve_block_kernel<256, 1>": 396,
         # the one-instance-per-wave form of the reduced-native tail kernel (mpmpc_set_tail_kernel(h, 2); the default form,
         # <32, 16>, has none): ONE dword (a lane mask the compiler keeps as 0 / 1 in a VGPR), stored once before
         # and read once inside each attempt of a tail instance - 10 % of a config-4 batch; its two-waves-per-SIMD budget
