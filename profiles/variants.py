@@ -1,0 +1,81 @@
+"""One kernel VARIANT of the solve path, timed on a resident batch - the measurements VERDICT r5 (missing 4) asked for:
+non-diagonal Q / R (src/MPC.py:150-155) and the workgroup kernels of horizons above 63 (src/MPC.py:73-74 has no limit),
+incl. their time-optimal / bounded-state / full-weight variants.  One JSON line per run; the same command goes under
+`rocprofv3 --kernel-trace --stats` and under one `--pmc` pass (profiles/collect_variants.sh), profiles/summarize_variants.py
+turns the raw output into profiles/<round>/variants.{json,md}.
+
+    python profiles/variants.py --weights stock|full|time_optimal|bounded --N 30 --B 8192 [--cfgid 4] [--steps 20] [--pipeline 1|4]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("tests", "multi-purpose-mpc_amd", "oracle", ""):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import numpy as np  # noqa: E402
+
+import mpmpc  # noqa: E402
+import mpmpc_testlib as T  # noqa: E402
+import scenarios  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--weights", default="stock")
+ap.add_argument("--N", type=int, default=30)
+ap.add_argument("--B", type=int, default=8192)
+ap.add_argument("--cfgid", type=int, default=4)
+ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--repeats", type=int, default=5)
+ap.add_argument("--pipeline", type=int, default=1)
+ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE")
+a = ap.parse_args()
+
+track = scenarios.sim_track()
+N, B = a.N, a.B
+tw = T.wide_track(track, T.Emul(), max(N, 50)) if N > 50 else track
+sc = scenarios.make(a.cfgid, tw, B=B, N=N)
+kw = {}
+for kv in a.set:
+    k, v = kv.split("=")
+    kw[k] = float(v) if "." in v or "e" in v else int(v)
+st = mpmpc.default_settings(**kw)
+if a.weights == "full":
+    Q, R, QN = scenarios.FULL_WEIGHT_SETS["full"]
+    cfg = mpmpc.make_config(N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX, scenarios.AY_MAX,
+                            scenarios.CAR_LENGTH, max_batch=B)
+elif a.weights == "bounded":
+    Q, R, QN = scenarios.WEIGHTS["stock"]
+    xmin, xmax = np.array([-np.inf, -0.6, -np.inf]), np.array([np.inf, 0.6, 0.2 * N])
+    cfg = mpmpc.make_config(N, Q, R, QN, xmin, xmax, scenarios.UMIN, scenarios.UMAX, scenarios.AY_MAX, scenarios.CAR_LENGTH, max_batch=B)
+else:
+    Q, R, QN = scenarios.WEIGHTS[a.weights]
+    cfg = mpmpc.make_config(N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX, scenarios.AY_MAX,
+                            scenarios.CAR_LENGTH, max_batch=B)
+h = mpmpc.Handle(cfg, st)
+h.set_path(track.kappa, track.v_ref, track.ds_next)
+h.set_outputs(False)
+h.set_pipeline(a.pipeline)
+h.upload(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+for _ in range(5):
+    h.solve_resident(B)
+h.sync()
+ts = []
+for _ in range(a.repeats):
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        h.solve_resident(B)
+    h.sync()
+    ts.append((time.perf_counter() - t0) / a.steps)
+dt = float(np.median(ts))
+sol = h.download(B)
+lib = h.lib.mpmpc_version().decode()
+h.close()
+stat, cnt = np.unique(sol.status, return_counts=True)
+print(json.dumps({"library": lib, "weights": a.weights, "N": N, "B": B, "cfgid": a.cfgid, "lanes_per_instance": mpmpc.stage_ld(N),
+                  "launches_in_flight": a.pipeline, "steps": a.steps, "ms_per_step": dt * 1e3, "ms_per_step_min": min(ts) * 1e3,
+                  "solves_per_s": B / dt, "ipm_iters_mean": float(sol.iters[:, 1].mean()), "ipm_iters_max": int(sol.iters[:, 1].max()),
+                  "admm_iters_mean": float(sol.iters[:, 0].mean()),
+                  "status_counts": {str(int(s)): int(c) for s, c in zip(stat, cnt)}}))

@@ -31,6 +31,17 @@ WEIGHTS = {
 }
 
 
+# non-diagonal weight matrices (src/MPC.py:150 puts the whole Q, R, QN into the Hessian): one symmetric positive definite set
+# with every off-diagonal entry set, and singular (rank-one) blocks - shared by the tests and the profiling scripts
+QN_FULL = np.array([[1.0, 0.3, -0.1], [0.3, 0.5, 0.2], [-0.1, 0.2, 0.4]])
+Q_FULL = np.array([[1.0, 0.2, 0.05], [0.2, 0.3, -0.1], [0.05, -0.1, 0.2]])
+R_FULL = np.array([[0.5, 0.1], [0.1, 0.2]])
+Q_RANK1 = np.outer([1.0, 0.5, 0.0], [1.0, 0.5, 0.0])
+R_RANK1 = np.outer([0.7, 0.02], [0.7, 0.02])
+FULL_WEIGHT_SETS = {"full": (Q_FULL, R_FULL, QN_FULL), "q_only": (Q_FULL, np.diag([0.5, 0.0]), np.diag([1.0, 0.0, 0.0])),
+                    "r_only": (np.diag([1.0, 0.0, 0.0]), R_FULL, np.diag([1.0, 0.0, 0.0])), "rank1": (Q_RANK1, R_RANK1, Q_RANK1)}
+
+
 @dataclasses.dataclass
 class Track:
     x: np.ndarray

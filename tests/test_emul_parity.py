@@ -360,7 +360,7 @@ def test_default_branch_agreement_with_restated_stock_osqp_in_the_emulation(emu,
 # ---------------------------------------------------------------------------------------------------------------
 # full terminal weight QN (src/MPC.py:150,154 use the whole matrix)
 # ---------------------------------------------------------------------------------------------------------------
-QN_FULL = np.array([[1.0, 0.3, -0.1], [0.3, 0.5, 0.2], [-0.1, 0.2, 0.4]])
+QN_FULL = scenarios.QN_FULL
 
 
 def _dense_with_qn(qp_i, N, QN):
@@ -413,13 +413,10 @@ def test_full_terminal_weight_matches_oracle(cfgid, N, B, emu, track, otrack):
 # full stage weights: Q and R with off-diagonal entries (src/MPC.py:150 puts the whole matrices into P, src/MPC.py:153-155
 # only their diagonals into q)
 # ---------------------------------------------------------------------------------------------------------------
-Q_FULL = np.array([[1.0, 0.2, 0.05], [0.2, 0.3, -0.1], [0.05, -0.1, 0.2]])
-R_FULL = np.array([[0.5, 0.1], [0.1, 0.2]])
-# positive SEMI-definite, singular blocks: Q of rank one (no cost on t at all), R of rank one
-Q_RANK1 = np.outer([1.0, 0.5, 0.0], [1.0, 0.5, 0.0])
-R_RANK1 = np.outer([0.7, 0.02], [0.7, 0.02])
-FULL_WEIGHT_SETS = {"full": (Q_FULL, R_FULL, QN_FULL), "q_only": (Q_FULL, np.diag([0.5, 0.0]), np.diag([1.0, 0.0, 0.0])),
-                    "r_only": (np.diag([1.0, 0.0, 0.0]), R_FULL, np.diag([1.0, 0.0, 0.0])), "rank1": (Q_RANK1, R_RANK1, Q_RANK1)}
+# (the weight sets live beside the workload generator: scenarios.py - positive definite with every off-diagonal set, and
+#  positive SEMI-definite, singular blocks: Q of rank one (no cost on t at all), R of rank one)
+Q_FULL, R_FULL, Q_RANK1, R_RANK1 = scenarios.Q_FULL, scenarios.R_FULL, scenarios.Q_RANK1, scenarios.R_RANK1
+FULL_WEIGHT_SETS = scenarios.FULL_WEIGHT_SETS
 
 
 def full_weight_config(N, name, max_batch=1):
