@@ -194,7 +194,9 @@ int mpmpc_destroy(mpmpc_handle h);
 int mpmpc_set_settings(mpmpc_handle h, const mpmpc_settings* settings);
 /* Lanes of a 64-lane wavefront given to one QP instance by the solve launches: 0 (default) = chosen from the batch
  * size (one instance per wave up to 1024 instances, then the smallest of 64 / 32 / 16 that holds the N + 1 stages);
- * 64 / 32 / 16 force that packing (parity tests and tuning; every packing returns the same answers). */
+ * 64 / 32 / 16 force that packing (parity tests and tuning; every packing returns the same answers).  16 with 17 .. 32
+ * stages (16 <= N <= 31) selects the layout with TWO stages per lane - four instances per wavefront - for the batch launches
+ * of the reference's own weights (cold starts; every other launch keeps one stage per lane). */
 int mpmpc_set_packing(mpmpc_handle h, int32_t lanes_per_instance);
 /* Which kernel takes the TAIL of a batch launch - the instances the reduced-native kernel could not certify: infeasible,
  * marginally infeasible and very hard ones.  1 (default) = the reduced-native tail kernel first (phase 1 and one more

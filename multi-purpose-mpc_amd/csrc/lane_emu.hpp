@@ -6,6 +6,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#define MPMPC_LANE_EMU 1          // (lane_pair.hpp: a "scalar" of the lanes underneath is a vector over the emulated lanes)
 
 namespace mpmpc {
 
@@ -125,6 +126,7 @@ struct LaneEmu {
   static constexpr bool batched = false;
   static constexpr bool junction_moves = false;
   static constexpr bool staged_sweeps = false;
+  static constexpr int stages_per_lane = 1;          // (2: lane_pair.hpp)
 
   static VI lane_id() { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = i; return r; }
   static VI stage() { VI r; for (int i = 0; i < EMU_W; ++i) r.v[i] = i % G; return r; }
@@ -233,7 +235,7 @@ struct LaneEmu {
 
   // "cold" per-lane storage (LDS on the GPU) for values that are only needed at termination checks
   // and in the certificate, so that they do not occupy registers inside the iteration loops
-  static constexpr int cold_slots = 66;
+  static constexpr int cold_slots = 80;          // (66: the general solver; 2 x 40: the reduced-native one with two stages per lane)
   static VD* cold() { static VD buf[cold_slots]; return buf; }
   static void cold_put(int slot, const VD& a) { cold()[slot] = a; }
   static VD cold_get(int slot) { return cold()[slot]; }

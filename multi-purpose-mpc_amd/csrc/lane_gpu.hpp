@@ -91,6 +91,7 @@ struct LaneGpu {
   static constexpr int group = G;
   static constexpr int per_wave = 64 / G;
   static constexpr bool batched = false;       // lane exchanges are register moves: nothing to batch (Solver::cup_n)
+  static constexpr int stages_per_lane = 1;    // (2: lane_pair.hpp on top of LaneGpu<16, 16>)
   static constexpr bool staged_sweeps = false; // a chain never spans two wavefronts here (Solver::staged_sweep)
 
   static __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -374,6 +375,7 @@ struct LaneBlock {
   static constexpr int waves = G / 64;
   static constexpr int cold_slots = SLOTS;
   static constexpr bool batched = true;       // several values of a step share one pass through LDS (Solver::cup_n)
+  static constexpr int stages_per_lane = 1;
   static constexpr bool junction_moves = false;
   static constexpr bool staged_sweeps = (G == 256);   // a chain spans two wavefronts: Solver::staged_sweep
   static constexpr int xrows = 9;             // exchange rows: the widest batch is the 3 x 3 block of a factorisation step

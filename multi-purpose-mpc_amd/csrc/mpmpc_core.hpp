@@ -117,7 +117,9 @@ MPMPC_HOST_DEVICE inline int lane_offset(int G, int C, int N) {
 template <class L, bool FQ = false, bool RED = false, bool FREEX = false, bool CR = false, int RKS = 0>
 struct Solver {
   static_assert(!(FQ && RED), "the reduced problem needs a diagonal terminal weight");
-  static constexpr bool kCR = CR && (L::split == 16 || L::split == 32 || L::split == 64 || L::split == 128);
+  // kS2: TWO stages per lane (lane_pair.hpp) - the reduced problem's factorisation is factor_core2_s2 / s_solve_s2 (mpmpc_solver_s2.hpp)
+  static constexpr bool kS2 = (L::stages_per_lane == 2);
+  static constexpr bool kCR = CR && !kS2 && (L::split == 16 || L::split == 32 || L::split == 64 || L::split == 128);
   static constexpr bool kCR32 = kCR && L::split == 32;      // a chain is TWO rows of 16 lanes (see factor_cr2)
   // ... FOUR rows - a whole wavefront of a 128-lane workgroup - or EIGHT, two wavefronts of a 256-lane one (LaneBlock): the
   // survivors of the rows are eliminated one after the other, kCRrows - 1 steps
@@ -496,6 +498,8 @@ struct Solver {
 
 #define MPMPC_SOLVER_BODY 1
 #include "mpmpc_solver_linalg.hpp"
+
+#include "mpmpc_solver_s2.hpp"
 
 #include "mpmpc_solver_admm.hpp"
 

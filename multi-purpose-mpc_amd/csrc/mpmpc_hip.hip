@@ -40,6 +40,7 @@ __device__ long long g_phase[4096 * 32];
 #define MPMPC_TICK_COUNT(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) g_phase[blockIdx.x * 32 + (i)] += 1; } while (0)
 #endif
 #include "lane_gpu.hpp"
+#include "lane_pair.hpp"
 #include "mpmpc_core.hpp"
 #include "mpmpc_reduced.hpp"
 #include "mpmpc_reduced_t.hpp"
@@ -260,6 +261,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     tail[1 + atomicAdd(tail, 1)] = inst_o;
     // "this launch left a tail": the launch's sequence number, in host memory the device writes through (read by the host
     // after the stream has drained: observe_tail)
+    __hip_atomic_store(tail_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// K2r2: K2r with TWO STAGES PER LANE (lane_pair.hpp): an instance of 17 .. 32 stages takes 16 lanes, a
+// wavefront carries FOUR.  The same ReducedSolver on the pair backend: every elementwise operation is issued for both stages of
+// the lane (the work per stage is what it was), a stage-order shift moves one of the two components across lanes, a wave
+// reduction serves four instances, and the cyclic reduction eliminates the even stages inside the lanes before its four
+// cross-lane levels run on the survivors (mpmpc_solver_s2.hpp).  Twice the state per lane: up to 512 registers and 80 LDS slots
+// (40 KB), ONE wavefront per SIMD - the two independent stages of a lane stand in for the second wave.  Cold starts only (the
+// closed loop keeps K2r); same launch contract as K2r, same tail lists.
+constexpr int RN2_SLOTS = 80;
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void mpmpc_reduced_pair_kernel(mpmpc_config cfg, SolverParams st, int B, int ld, AssembleIn ain,
+                                                           double* __restrict__ z, double* __restrict__ u0,
+                                                           int* __restrict__ status, int* __restrict__ iters,
+                                                           double* __restrict__ resid, double* __restrict__ y,
+                                                           int* __restrict__ tail, int* __restrict__ tail_reset,
+                                                           unsigned* __restrict__ tail_flag, unsigned seq, int* __restrict__ tail2_reset) {
+  using L = LanePair<LaneGpu<16, 16, RN2_SLOTS>>;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *tail_reset = 0; *tail2_reset = 0; }
+  const I2 inst = L::slot() + (int)(blockIdx.x * L::per_wave);
+  const I2 k = L::stage();          // (one chain, stage 0 on lane 0: no lane offset)
+  MPMPC_TICK_BEGIN(8);
+  D2 fields[MPMPC_NUM_FIELDS];
+  assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
+  ReducedSolver<L> s;
+  s.template run<false>(fields, B, inst, k, cfg.N, st);
+  MPMPC_TICK_BEGIN(7);
+  const I2 inst_o = L::slot_again() + (int)(blockIdx.x * L::per_wave);
+  const I2 k_o = L::stage_again();
+  s.store(inst_o, k_o, cfg.wheelbase, z, u0, status, iters, resid, y, nullptr, ld);
+  MPMPC_TICK_END(7);
+  MPMPC_TICK_END(8);
+  if (k_o.v[0] == 0 && inst_o.v[0] < B && s.status.v[0] == MPMPC_UNSOLVED) {
+    tail[1 + atomicAdd(tail, 1)] = inst_o.v[0];
     __hip_atomic_store(tail_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
@@ -1002,7 +1038,9 @@ int mpmpc_set_packing(mpmpc_handle h, int32_t lanes_per_instance) {
   MPMPC_SETTLE(h);
   const int g = lanes_per_instance;
   if (g != 0 && g != 16 && g != 32 && g != 64) return fail(MPMPC_E_ARG, "lanes_per_instance must be 0 (auto), 16, 32 or 64");
-  if (g != 0 && h->cfg.N + 1 > g) return fail(MPMPC_E_ARG, "lanes_per_instance must hold the N + 1 stages of an instance (horizons above 63 take a workgroup: only 0)");
+  // (16 lanes for 17 .. 32 stages: TWO stages per lane, four instances per wavefront - the reduced-native batch kernel only)
+  const bool two = g == 16 && h->cfg.N + 1 > 16 && h->cfg.N + 1 <= 32;
+  if (g != 0 && h->cfg.N + 1 > g && !two) return fail(MPMPC_E_ARG, "lanes_per_instance must hold the N + 1 stages of an instance, or half of them at 16 (horizons above 63 take a workgroup: only 0)");
   h->force_lanes = g;
   return MPMPC_OK;
 }
@@ -1424,6 +1462,7 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
   // lanes per instance: one instance per wave while there are no more instances than SIMDs (1024); beyond that the
   // smallest power of two holding N + 1 stages, so that a wave carries 2 or 4 instances and a SIMD two such waves
   int G = 64;
+  bool two = false;
   if (rn && !rnt) {      // (the terminal-time kernels run one instance per wave)
     // A launch that is one of several in flight - a pipelined resident launch (mpmpc_solve_resident with mpmpc_set_pipeline > 1:
     // the default) or the begun half of a split host-buffer call (mpmpc_staged_begin: the caller keeps several handles busy) -
@@ -1440,6 +1479,8 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
     if (N + 1 <= 32 && B > (throughput ? 128 : 1024)) G = 32;
     if (N + 1 <= 16 && B > (throughput ? 256 : 2048)) G = 16;
     if (h->force_lanes && N + 1 <= h->force_lanes) G = h->force_lanes;      // mpmpc_set_packing
+    // TWO stages per lane (K2r2): 17 .. 32 stages in 16 lanes, four instances per wavefront; cold starts only
+    if (h->force_lanes == 16 && N + 1 > 16 && N + 1 <= 32 && !closed_loop) { G = 32; two = true; }
   }
   // closed loop: the previous step's active sets as a first guess.  A launch with one instance per wave ends with
   // its slowest car, and with more than a handful of cars one of them always misses its guess (hit rate 91-93 %
@@ -1448,7 +1489,7 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
   const bool warm = closed_loop && !rnt && (h->ro_warm == 1 || (h->ro_warm == 2 && (G < 64 || B <= 16)));
   int* warm_act = warm ? h->ro_act : nullptr;
   const int* warm_shift = warm ? h->ro_shift : nullptr;
-  const int per = 64 / G;
+  const int per = two ? 4 : 64 / G;
   const int blocks = (B + per - 1) / per;
   const SolverParams prm = make_params(h->st);
   const int C = lane_split(G, N);        // where the two elimination chains of the factorisation meet
@@ -1499,6 +1540,9 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
     if (!tail_only && rnt) {
       if (C == 16) LAUNCH_RNT(64, 16);
       else LAUNCH_RNT(64, 32);
+    } else if (!tail_only && two) {
+      hipLaunchKernelGGL(mpmpc_reduced_pair_kernel, dim3(blocks), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, ain, h->z, h->u0, h->status,
+                         h->iters, h->resid, y_out, tail_cur, tail_next, h->tail_flag, h->seq, tail2);
     } else if (!tail_only) {
       if (G == 64 && C == 16) LAUNCH_RN(64, 16);
       else if (G == 64) LAUNCH_RN(64, 32);

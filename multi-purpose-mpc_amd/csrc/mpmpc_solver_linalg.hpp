@@ -555,6 +555,7 @@
   // first entries of the member arrays.
   //   A_k = [[a0, a1], [a2, a3]],  B_k = [0; b0]:   W = A H A' + B h_kappa B',   T = S_{k+1,k} = A H (-I)'
   MPMPC_HD void factor_core2(const R hx[2], const R& wb, const R& r) {
+    if constexpr (kS2) { factor_core2_s2(hx, wb, r); return; }          // two stages per lane: mpmpc_solver_s2.hpp
     const R* h = hx;
     R W[3], T[4], Dg[3], To[4];
     {
@@ -1006,6 +1007,7 @@
   }
 
   MPMPC_HD void s_solve2(const R bv[2], R nu[2]) const {
+    if constexpr (kS2) { s_solve_s2(bv, nu); return; }
     if constexpr (kCR) { s_solve_cr2(bv, nu); return; }
     R b0 = sel(vxc, L::mirror(bv[0]), R(0.0)), b1 = sel(vxc, L::mirror(bv[1]), R(0.0));
     R c0 = Li[0] * b0;

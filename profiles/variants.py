@@ -30,6 +30,7 @@ ap.add_argument("--cfgid", type=int, default=4)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--repeats", type=int, default=5)
 ap.add_argument("--pipeline", type=int, default=1)
+ap.add_argument("--lanes", type=int, default=0, help="mpmpc_set_packing: 0 = automatic; 16 at 17 .. 32 stages = two stages per lane")
 ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE")
 a = ap.parse_args()
 
@@ -57,6 +58,8 @@ else:
 h = mpmpc.Handle(cfg, st)
 h.set_path(track.kappa, track.v_ref, track.ds_next)
 h.set_outputs(False)
+if a.lanes:
+    h.set_packing(a.lanes)
 h.set_pipeline(a.pipeline)
 h.upload(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
 for _ in range(5):
@@ -74,7 +77,7 @@ sol = h.download(B)
 lib = h.lib.mpmpc_version().decode()
 h.close()
 stat, cnt = np.unique(sol.status, return_counts=True)
-print(json.dumps({"library": lib, "weights": a.weights, "N": N, "B": B, "cfgid": a.cfgid, "lanes_per_instance": mpmpc.stage_ld(N),
+print(json.dumps({"library": lib, "weights": a.weights, "N": N, "B": B, "cfgid": a.cfgid, "lanes_per_instance": a.lanes or mpmpc.stage_ld(N),
                   "launches_in_flight": a.pipeline, "steps": a.steps, "ms_per_step": dt * 1e3, "ms_per_step_min": min(ts) * 1e3,
                   "solves_per_s": B / dt, "ipm_iters_mean": float(sol.iters[:, 1].mean()), "ipm_iters_max": int(sol.iters[:, 1].max()),
                   "admm_iters_mean": float(sol.iters[:, 0].mean()),

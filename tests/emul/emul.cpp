@@ -11,6 +11,7 @@ static long long g_emu_count[32];
 #define MPMPC_TICK_END(i) ((void)0)
 #define MPMPC_TICK_COUNT(i) (++g_emu_count[i])
 #include "lane_emu.hpp"
+#include "lane_pair.hpp"
 #include "mpmpc_core.hpp"
 #include "mpmpc_reduced.hpp"
 #include "mpmpc_reduced_t.hpp"
@@ -84,6 +85,25 @@ static void solve_rn(const mpmpc_config* cfg, const mpmpc_settings* st, const do
       if (k.v[i] == 0 && inst.v[i] < B && s.status.v[i] == MPMPC_UNSOLVED) tail[1 + tail[0]++] = inst.v[i];
   }
 }
+// mpmpc_reduced_pair_kernel: the same solver with TWO stages per lane (lane_pair.hpp) - 16 lanes per instance for N + 1 <= 32,
+// four instances per emulated wave
+static void solve_rn2(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
+                      int* status, int* iters, double* resid, double* y, int* tail) {
+  using L = LanePair<LaneEmu<16, 16>>;
+  const int ld = stage_ld(cfg->N);
+  const int per = L::per_wave;
+  for (int w = 0; w < (B + per - 1) / per; ++w) {
+    const I2 inst = L::slot() + w * per;
+    const I2 k = L::stage();
+    ReducedSolver<L> s;
+    typename L::real fields[MPMPC_NUM_FIELDS];
+    ReducedSolver<L>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    s.template run<false>(fields, B, inst, k, cfg->N, make_params(*st));
+    s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y, nullptr, ld);
+    for (int i = 0; i < EMU_W; ++i)
+      if (k.v[0].v[i] == 0 && inst.v[0].v[i] < B && s.status.v[0].v[i] == MPMPC_UNSOLVED) tail[1 + tail[0]++] = inst.v[0].v[i];
+  }
+}
 // mpmpc_reduced_t_kernel: the reduced-native solver of the weightings with a terminal cost on the time state
 template <int G, int C, bool CR = true>
 static void solve_rnt(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
@@ -149,6 +169,8 @@ static int solve_rnt_g(int G, const mpmpc_config* cfg, const mpmpc_settings* st,
 static int solve_rn_g(int G, const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
                       int* status, int* iters, double* resid, double* y, int* tail, const int* guess = nullptr, int* act = nullptr) {
   const int C = lane_split(G, cfg->N);
+  // (16 lanes for more than 16 stages: two stages per lane - cold starts only, like the launcher)
+  if (G == 16 && cfg->N + 1 > 16) { if (guess || cfg->N + 1 > 32) return -1; solve_rn2(cfg, st, qp, B, z, u0, status, iters, resid, y, tail); return 0; }
   if (G == 64 && C == 16) solve_rn<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail, guess, act);
   else if (G == 64) solve_rn<64, 32>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail, guess, act);
   else if (G == 32) solve_rn<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail, guess, act);
@@ -185,7 +207,7 @@ extern "C" int emu_solve(const mpmpc_config* cfg, const mpmpc_settings* st, int 
 // the <64, C> kernel in mode 2 on the instances it left unsolved (phase 1, full ADMM run); otherwise one launch.
 extern "C" int emu_solve_launch(const mpmpc_config* cfg, const mpmpc_settings* st, int G, const double* qp, int B,
                                 double* z, double* u0, int* status, int* iters, double* resid, double* y, int* n_tail) {
-  if (cfg->N + 1 > G) return -1;
+  if (cfg->N + 1 > G && !(G == 16 && cfg->N + 1 <= 32 && reduced_native(*cfg, *st))) return -1;      // (two stages per lane: solve_rn2)
   const bool early = st->polish && st->early_polish > 0 && st->early_polish < st->max_iter;
   if (n_tail) *n_tail = 0;
   std::vector<int> tail(B + 1, 0);
@@ -221,7 +243,7 @@ extern "C" int emu_solve_launch(const mpmpc_config* cfg, const mpmpc_settings* s
 // the reduced-native kernel alone: what it cannot certify stays UNSOLVED and is counted in *n_tail
 extern "C" int emu_solve_rn(const mpmpc_config* cfg, const mpmpc_settings* st, int G, const double* qp, int B,
                             double* z, double* u0, int* status, int* iters, double* resid, double* y, int* n_tail) {
-  if (cfg->N + 1 > G) return -1;
+  if (cfg->N + 1 > G && !(G == 16 && cfg->N + 1 <= 32 && reducible(*cfg, *st))) return -1;
   std::vector<int> tail(B + 1, 0);
   if (reducible_tt(*cfg, *st)) {
     if (solve_rnt_g(G, cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data())) return -1;

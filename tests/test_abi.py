@@ -107,6 +107,16 @@ def test_reduced_native_kernels_fit_two_waves_per_simd(lib):
         assert r["lds"] <= 20 * 1024, r
 
 
+def test_pair_layout_kernel_fits_one_wave_per_simd(lib):
+    """mpmpc_reduced_pair_kernel (two stages per lane, csrc/lane_pair.hpp): twice the per-lane state of the one-stage kernels -
+    one wavefront per SIMD, four per CU: at most 512 registers, 40 KB of LDS (80 slots), and the three dwords of scratch it
+    was measured with (a regression fails)."""
+    rows = [r for r in _kernel_rows(lib) if r["name"].startswith("mpmpc_reduced_pair_kernel")]
+    assert len(rows) == 1, rows
+    r = rows[0]
+    assert r["vgpr"] <= 512 and r["lds"] <= 40 * 1024 and r["scratch"] <= 12, r
+
+
 def test_no_batch_path_solve_kernel_has_scratch(lib):
     """private_segment_fixed_size must be 0 for every solve kernel a batch launch can pick: the reduced-native kernels, and
     the one-instance-per-wave general kernels that take their tail / the configurations the reduction does not apply to.

@@ -1,0 +1,124 @@
+"""The layout with TWO horizon stages per lane (csrc/lane_pair.hpp, mpmpc_solver_s2.hpp): an instance of
+17 .. 32 stages takes 16 lanes - four instances per wavefront - and the cyclic reduction of the factorisation eliminates the
+even stages inside the lanes before its cross-lane levels run on the survivors.  Same lane-generic solver code as the shipped
+one-stage layout, so the bar is the same: statuses and iteration counts of the C oracle (oracle/osqp_port.c, which restates
+src/MPC.py:61-159 + the certified solve), controls to 1e-6, the plain-numpy KKT test on the layout's own output.  CPU: the
+lock-step emulation (tests/emul/emul.cpp: solve_rn2); GPU: libmpmpc.so through mpmpc_set_packing(16)."""
+import numpy as np
+import pytest
+
+import mpmpc
+import mpmpc_testlib as T
+import oracle_c as OC
+import scenarios
+
+
+def _inputs(sc):
+    return sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub
+
+
+def _oracle(track, sc, **st):
+    ocfg = OC.mpc_cfg(sc.N, scenarios.WEIGHTS[sc.weights], scenarios.UMIN, scenarios.UMAX, scenarios.XMIN, scenarios.XMAX, 4.0, 0.12)
+    return OC.mpc_batch(ocfg, OC.settings(**st), track.kappa, track.v_ref, track.ds_next, sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+
+
+@pytest.mark.parametrize("cfgid,B,N", [(2, 96, 30), (4, 128, 30), (4, 40, 16), (2, 24, 17), (4, 40, 23), (4, 40, 31), (5, 64, 30), (4, 7, 30)])
+def test_two_stages_per_lane_in_the_emulation(cfgid, B, N, emu, track):
+    """The pair layout against the one-stage layout (<32,16>: the shipped packed kernel) - statuses, hand-overs to the tail and
+    iteration counts instance by instance, controls to rounding - and against the C oracle; ragged batches (B not a multiple
+    of 4), every horizon class of the layout (16 = its shortest, 31 = full rows)."""
+    sc = scenarios.make(cfgid, track, B=B, N=N)
+    cfg = T.stock_config(N, sc.weights)
+    st = mpmpc.default_settings()
+    qp = emu.assemble(cfg, track, _inputs(sc), obstacles=sc.obstacles)
+    one, t1 = emu.solve_rn(cfg, st, qp, G=32)
+    two, t2 = emu.solve_rn(cfg, st, qp, G=16)
+    assert t1 == t2 and np.array_equal(one.status, two.status) and np.array_equal(one.iters, two.iters)
+    ok = two.status == 1
+    assert ok.sum() >= B // 2
+    assert np.max(np.abs(one.u0[ok] - two.u0[ok])) <= 1e-13 and np.max(np.abs(one.z[ok] - two.z[ok])) <= 1e-10
+    prim, stat, comp = T.kkt_batch(qp[:, ok], N, two.z[ok], two.y[ok])
+    assert max(prim.max(), stat.max(), comp.max()) <= 1e-9
+    # the launcher's whole sequence (pair kernel, reduced-native tail kernel, general kernel) against the C oracle
+    sol, _ = emu.solve_launch(cfg, mpmpc.default_settings(phase1_accept=0), qp, G=16)
+    ref = _oracle(track, sc)
+    assert np.array_equal(sol.status, ref["status"])
+    ok = sol.status == 1
+    assert np.max(np.abs(sol.u0[ok] - ref["u0"][ok])) <= 1e-6
+    if (~ok).any():
+        good, _, _ = T.farkas_batch(qp[:, ~ok, :], N, sol.y[~ok])
+        assert good.all()
+
+
+def test_two_stages_per_lane_reach_the_g5_optima_of_the_reference_qps(emu, track):
+    """The reference's own captured inputs at N = 30 (G4) through K1 + the pair kernel: statuses of G5, its certified optima
+    to 1e-6 (measured ~1e-8)."""
+    import mpc_np as M
+    N = 30
+    g4 = np.load(M.GOLDEN + "/g4_assembly_N%d.npz" % N)
+    g5 = np.load(M.GOLDEN + "/g5_solutions_N%d.npz" % N)
+    cfg = T.stock_config(N, str(g4["weights"][0]))
+    qp = emu.assemble(cfg, track, (g4["wp_id"].astype(np.int32), g4["x0"], g4["cc_prev"], g4["lb"], g4["ub"]))
+    sol, _ = emu.solve_launch(cfg, mpmpc.default_settings(phase1_accept=0), qp, G=16)
+    assert np.array_equal(sol.status, g5["status"])
+    ok = g5["status"] == 1
+    assert np.max(np.abs(sol.z[ok] - g5["x"][ok])) < 1e-6
+    assert np.max(np.abs(sol.z[ok][:, -2 * N:-2 * N + 2] - g5["x"][ok][:, -2 * N:-2 * N + 2])) < 1e-8
+
+
+def test_the_pair_layout_is_refused_where_it_does_not_apply(emu, track):
+    """16 lanes hold at most 32 stages, and only the reduced-native batch kernel has the layout (time-optimal weights: no)."""
+    sc = scenarios.make(3, track, B=4, N=30)
+    cfg = T.stock_config(30, "time_optimal")
+    qp = emu.assemble(cfg, track, _inputs(sc))
+    nt = __import__("ctypes").c_int(0)
+    z = np.zeros((4, 153)); u0 = np.zeros((4, 2)); y = np.zeros((4, 246)); s = np.zeros(4, np.int32); it = np.zeros((4, 2), np.int32); rs = np.zeros((4, 2))
+    import ctypes as C
+    rc = emu.lib.emu_solve_launch(C.byref(cfg), C.byref(mpmpc.default_settings()), C.c_int(16), T._d(qp), C.c_int(4), T._d(z), T._d(u0), T._i(s), T._i(it),
+                                  T._d(rs), T._d(y), C.byref(nt))
+    assert rc == -1
+
+
+# ------------------------------------------------------------------------------------------------------------------ device
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfgid,B,N", [(2, 1024, 30), (4, 8192, 30), (4, 1021, 31), (4, 515, 16), (2, 130, 23)])
+def test_two_stages_per_lane_on_device_against_the_c_oracle(cfgid, B, N, track, emu):
+    """mpmpc_reduced_pair_kernel (set_packing(16)) on the FULL BASELINE batches 2 and 4 and on ragged batches at the layout's
+    other horizons: statuses and iteration counts of the C oracle and of the one-stage kernels, controls to 1e-6 (measured
+    1e-15 against the one-stage kernel), KKT / Farkas with plain numpy on K1's output; the resident and the host-buffer path
+    give the same bits."""
+    sc = scenarios.make(cfgid, track, B=B, N=N)
+    cfg = T.stock_config(N, sc.weights, max_batch=B)
+    st = mpmpc.default_settings(phase1_accept=0)
+    inp = _inputs(sc)
+    sols = {}
+    for lanes in (32, 16):
+        h = mpmpc.Handle(cfg, st)
+        h.set_path(track.kappa, track.v_ref, track.ds_next)
+        h.set_packing(lanes)
+        qp = h.assemble(*inp)
+        sols[lanes] = h.solve(*inp, want_y=True)
+        if lanes == 16:
+            h.upload(*inp)
+            h.solve_resident(B)
+            again = h.download(B, want_y=True)
+            assert np.array_equal(again.z, sols[16].z) and np.array_equal(again.status, sols[16].status) and np.array_equal(again.y, sols[16].y)
+        h.close()
+    one, two = sols[32], sols[16]
+    assert np.array_equal(one.status, two.status) and np.array_equal(one.iters, two.iters)
+    ok = two.status == 1
+    assert ok.mean() > 0.5 and np.max(np.abs(one.u0[ok] - two.u0[ok])) <= 1e-12
+    ref = _oracle(track, sc)
+    assert np.array_equal(two.status, ref["status"])
+    assert np.max(np.abs(two.u0[ok] - ref["u0"][ok])) <= 1e-6
+    prim, stat, comp = T.kkt_batch(qp[:, ok, :], N, two.z[ok], two.y[ok])
+    assert max(prim.max(), stat.max(), comp.max()) <= 1e-8
+    if (~ok).any():
+        good, _, _ = T.farkas_batch(qp[:, ~ok, :], N, two.y[~ok])
+        assert good.all()
+    # the emulation of the same lane code gives the device's answers (statuses, iteration counts, z to 1e-9)
+    nn = 24
+    e, _ = emu.solve_rn(cfg, st, np.ascontiguousarray(qp[:, :nn, :]), G=16)
+    solved = e.status == 1
+    assert np.array_equal(two.status[:nn][solved], e.status[solved]) and np.array_equal(two.iters[:nn][solved], e.iters[solved])
+    assert np.max(np.abs(two.z[:nn][solved] - e.z[solved])) <= 1e-9
