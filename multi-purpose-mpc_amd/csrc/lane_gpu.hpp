@@ -83,7 +83,8 @@ __device__ __forceinline__ double dpp_merge(double keep, double a) {
 // waves per CU, one per SIMD), 40 for the reduced-native one (20 KB: eight waves per CU, two per SIMD, exactly the 160 KB).
 template <int G, int C = G / 2, int SLOTS = 66>
 struct LaneGpu {
-  static_assert((G == 64 && (C == 16 || C == 32)) || (G == 32 && C == 16) || (G == 16 && C == 16), "unsupported lane split");
+  // (<64, 64>: ONE chain of four rows - the lanes underneath the two-stages-per-lane layout of horizons 64 .. 127, lane_pair.hpp)
+  static_assert((G == 64 && (C == 16 || C == 32 || C == 64)) || (G == 32 && C == 16) || (G == 16 && C == 16), "unsupported lane split");
   static constexpr int split = C;
   using real = double;
   using mask = bool;
@@ -216,6 +217,35 @@ struct LaneGpu {
   static __device__ __forceinline__ bool cr_special() {
     const int p = threadIdx.x & 15;
     return (threadIdx.x & 16) != 0 && ((p & (p + 1)) == 0) && p != 15;      // p = 2^m - 1: 0, 1, 3, 7
+  }
+
+  // ---- a chain of FOUR rows inside the wavefront (<64, 64>; Solver::s2_rows_*): step r works on the survivor X of row r
+  // (position 15), the survivor Y of row r + 1 and that row's lanes 0, 1, 3, 7 - the moves of LaneBlock's chains, none of which
+  // leaves the wavefront here
+  static __device__ __forceinline__ bool cr64_x(int r) { return (int)(threadIdx.x & 63) == 16 * r + 15; }
+  static __device__ __forceinline__ bool cr64_special(int r) {
+    const int p = threadIdx.x & 15;
+    return (int)((threadIdx.x & 63) >> 4) == r + 1 && ((p & (p + 1)) == 0) && p != 15;
+  }
+  template <int NV> static __device__ __forceinline__ void cr_pull(int, const double* v, double* o) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) o[i] = __shfl(v[i], ((int)threadIdx.x + 16) & 63, 64);
+  }
+  template <int NV> static __device__ __forceinline__ void cr_push(int, const double* v, double* o) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) o[i] = __shfl(v[i], ((int)threadIdx.x - 16) & 63, 64);
+  }
+  template <int NV> static __device__ __forceinline__ void cr_down(int, const double* v, double* o) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) o[i] = dpp_shift<DPP_WAVE_SHL1>(v[i]);
+  }
+  template <int NV> static __device__ __forceinline__ void cr_bcast(int, const double* v, double* o) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {        // row_bcast:15 into rows 1 .. 3
+      int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v[i]), 0x142, 0xE, 0xf, false);
+      int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v[i]), 0x142, 0xE, 0xf, false);
+      o[i] = __hiloint2double(hi, lo);
+    }
   }
 
   // ---- half-wave exchange (G = 64, N + 1 <= 32: lanes 32..63 carry the inputs of the stage on lane - 32)

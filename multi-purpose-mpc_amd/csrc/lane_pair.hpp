@@ -87,10 +87,12 @@ MPMPC_HD B2 selb(const B2& m, const B2& a, const B2& b) { return B2(selb(m.v[0],
 MPMPC_HD B2 within_(const I2& v, int lo, int hi) { return B2(within_(v.v[0], lo, hi), within_(v.v[1], lo, hi)); }
 MPMPC_HD B2 bit_(const I2& v, int b) { return B2(bit_(v.v[0], b), bit_(v.v[1], b)); }
 
-// Base: a one-stage-per-lane backend whose instance is ONE chain of G lanes that is also a DPP row (G = C = 16)
+// Base: a one-stage-per-lane backend whose instance is ONE chain of G lanes (no twist): a DPP row (G = C = 16: horizons
+// 16 .. 31, four instances per wavefront) or a whole wavefront of four rows (G = C = 64: horizons 64 .. 127 in ONE wavefront -
+// no LDS exchange, no workgroup barrier - where the one-stage layout needs a workgroup of two)
 template <class Base>
 struct LanePair {
-  static_assert(Base::group == 16 && Base::split == 16, "two stages per lane: 16 lanes = one chain = one row per instance");
+  static_assert(Base::split == Base::group && (Base::group == 16 || Base::group == 64), "two stages per lane: one chain of 16 or 64 lanes per instance");
   using L1 = Base;                    // the lanes underneath: what the cross-lane levels of the cyclic reduction run on
   using real = D2;
   using mask = B2;
@@ -116,8 +118,11 @@ struct LanePair {
 
   // the previous / next STAGE's value: stage 2p takes stage 2p - 1 from the lane below (a row shift: zero inflow at stage 0),
   // stage 2p + 1 takes stage 2p from its own lane - and the other way round
-  static MPMPC_HD D2 up(const D2& a) { return D2(Base::template rshr<1>(a.v[1]), a.v[0]); }
-  static MPMPC_HD D2 down(const D2& a) { return D2(a.v[1], Base::template rshl<1>(a.v[0])); }
+  // (the lanes' own one-lane shift with zero inflow at the ends of the instance: the row shift where an instance is a row)
+  static MPMPC_HD R1 up1(const R1& a) { if constexpr (Base::group == 16) return Base::template rshr<1>(a); else return Base::up(a); }
+  static MPMPC_HD R1 down1(const R1& a) { if constexpr (Base::group == 16) return Base::template rshl<1>(a); else return Base::down(a); }
+  static MPMPC_HD D2 up(const D2& a) { return D2(up1(a.v[1]), a.v[0]); }
+  static MPMPC_HD D2 down(const D2& a) { return D2(a.v[1], down1(a.v[0])); }
   // (one chain in stage order: the chain layout is the stage layout)
   static MPMPC_HD D2 mirror(const D2& a) { return a; }
   static MPMPC_HD D2 cup(const D2& a) { return up(a); }
@@ -133,7 +138,7 @@ struct LanePair {
   // inclusive prefix sum along the stages: the lane totals are scanned across the lanes, the lanes below add to both stages
   static MPMPC_HD D2 gscan(const D2& a) {
     const R1 t = a.v[0] + a.v[1];
-    const R1 below = Base::template rshr<1>(Base::gscan(t));
+    const R1 below = up1(Base::gscan(t));
     return D2(below + a.v[0], below + t);
   }
 

@@ -272,14 +272,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // cross-lane levels run on the survivors (mpmpc_solver_s2.hpp).  Twice the state per lane: up to 512 registers and 80 LDS slots
 // (40 KB), ONE wavefront per SIMD - the two independent stages of a lane stand in for the second wave.  Cold starts only (the
 // closed loop keeps K2r); same launch contract as K2r, same tail lists.
+// GB = 64: an instance of 65 .. 128 stages (horizons 64 .. 127) in ONE wavefront - a chain of four rows, no LDS exchange and
+// no workgroup barrier, where the one-stage layout takes a workgroup of two wavefronts (K2rb); what it cannot certify goes to
+// mpmpc_solve_block_kernel<128, 2> through the same list.
 constexpr int RN2_SLOTS = 80;
+template <int GB>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void mpmpc_reduced_pair_kernel(mpmpc_config cfg, SolverParams st, int B, int ld, AssembleIn ain,
                                                            double* __restrict__ z, double* __restrict__ u0,
                                                            int* __restrict__ status, int* __restrict__ iters,
                                                            double* __restrict__ resid, double* __restrict__ y,
                                                            int* __restrict__ tail, int* __restrict__ tail_reset,
                                                            unsigned* __restrict__ tail_flag, unsigned seq, int* __restrict__ tail2_reset) {
-  using L = LanePair<LaneGpu<16, 16, RN2_SLOTS>>;
+  using L = LanePair<LaneGpu<GB, GB, RN2_SLOTS>>;
   if (blockIdx.x == 0 && threadIdx.x == 0) { *tail_reset = 0; *tail2_reset = 0; }
   const I2 inst = L::slot() + (int)(blockIdx.x * L::per_wave);
   const I2 k = L::stage();          // (one chain, stage 0 on lane 0: no lane offset)
@@ -1037,9 +1041,11 @@ int mpmpc_set_packing(mpmpc_handle h, int32_t lanes_per_instance) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
   MPMPC_SETTLE(h);
   const int g = lanes_per_instance;
-  if (g != 0 && g != 16 && g != 32 && g != 64) return fail(MPMPC_E_ARG, "lanes_per_instance must be 0 (auto), 16, 32 or 64");
+  if (g != 0 && g != 16 && g != 32 && g != 64 && !(g == 128 && h->cfg.N + 1 > 64 && h->cfg.N + 1 <= 128))
+    return fail(MPMPC_E_ARG, "lanes_per_instance must be 0 (auto), 16, 32 or 64 (128: the workgroup kernel of horizons 64 .. 127)");
   // (16 lanes for 17 .. 32 stages: TWO stages per lane, four instances per wavefront - the reduced-native batch kernel only)
-  const bool two = g == 16 && h->cfg.N + 1 > 16 && h->cfg.N + 1 <= 32;
+  // (64 / 128 at 65 .. 128 stages: two stages per lane in one wavefront - the default there - or the workgroup kernel)
+  const bool two = (g == 16 && h->cfg.N + 1 > 16 && h->cfg.N + 1 <= 32) || ((g == 64 || g == 128) && h->cfg.N + 1 > 64 && h->cfg.N + 1 <= 128);
   if (g != 0 && h->cfg.N + 1 > g && !two) return fail(MPMPC_E_ARG, "lanes_per_instance must hold the N + 1 stages of an instance, or half of them at 16 (horizons above 63 take a workgroup: only 0)");
   h->force_lanes = g;
   return MPMPC_OK;
@@ -1443,7 +1449,15 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
     const int* tail_blk = nullptr;
     if (rnb) {
       HIP_TRY(hipMemsetAsync(h->tail, 0, sizeof(int), h->stream));
-      if (N + 1 <= 128) LAUNCH_RBLOCK(128); else LAUNCH_RBLOCK(256);
+      // 65 .. 128 stages: TWO stages per lane, the whole instance in ONE wavefront (K2r2<64>; mpmpc_set_packing(h, 128) keeps the
+      // workgroup kernel K2rb).  Its "lists of the next launch" are two words behind the list it fills; the tail kernel below
+      // always runs, so the host-side flag it stamps is not consulted.
+      if (N + 1 <= 128 && h->force_lanes != 128) {
+        int* spare = h->tail + ((size_t)h->cfg.max_batch + 1);
+        hipLaunchKernelGGL(mpmpc_reduced_pair_kernel<64>, dim3(B), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, ain, h->z, h->u0, h->status,
+                           h->iters, h->resid, y_out, h->tail, spare, h->tail_flag, h->seq, spare + ((size_t)h->cfg.max_batch + 1));
+      } else if (N + 1 <= 128) LAUNCH_RBLOCK(128);
+      else LAUNCH_RBLOCK(256);
       tail_blk = h->tail;
     }
     if (N + 1 <= 128) { if (fullqn) LAUNCH_BLOCK(128, 1); else if (redb) LAUNCH_BLOCK(128, 2); else LAUNCH_BLOCK(128, 0); }
@@ -1541,7 +1555,7 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
       if (C == 16) LAUNCH_RNT(64, 16);
       else LAUNCH_RNT(64, 32);
     } else if (!tail_only && two) {
-      hipLaunchKernelGGL(mpmpc_reduced_pair_kernel, dim3(blocks), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, ain, h->z, h->u0, h->status,
+      hipLaunchKernelGGL(mpmpc_reduced_pair_kernel<16>, dim3(blocks), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, ain, h->z, h->u0, h->status,
                          h->iters, h->resid, y_out, tail_cur, tail_next, h->tail_flag, h->seq, tail2);
     } else if (!tail_only) {
       if (G == 64 && C == 16) LAUNCH_RN(64, 16);

@@ -1,6 +1,6 @@
 // PART OF struct mpmpc::Solver (mpmpc_core.hpp) - the reduced problem's block-tridiagonal Cholesky for the layout with TWO
-// STAGES PER LANE (lane_pair.hpp: a lane holds the stages 2p, 2p + 1 of its instance, an instance of up to 32 stages is one
-// chain of 16 lanes = one DPP row, four instances per wavefront).
+// STAGES PER LANE (lane_pair.hpp: a lane holds the stages 2p, 2p + 1 of its instance; an instance of up to 32 stages is one
+// chain of 16 lanes = one DPP row, four instances per wavefront; one of 65 .. 128 stages a chain of 64 lanes, one wavefront).
 // This file is included INSIDE the class body; it is not a header of its own.
 #ifndef MPMPC_SOLVER_BODY
 #error "include mpmpc_core.hpp"
@@ -13,7 +13,10 @@
   //             odd stages are a block-tridiagonal system of their own, one stage per lane;
   //   levels D = 1, 2, 4, 8 on those survivors, on SCALAR values of the lanes underneath (L::L1) - what a wavefront of the
   //             one-stage layout does for two instances it does here for four;
-  //   position 15 (stage 31, or the identity-like block behind a shorter horizon) is factored last.
+  //   chains of FOUR rows (64 lanes per instance: horizons 64 .. 127 in one wavefront): the survivors of the rows are eliminated one
+  //             after the other exactly as in factor_cr2's kCR64 part (step r: the survivor X of row r against the survivor Y of
+  //             row r + 1 and that row's lanes 0, 1, 3, 7, whose lower neighbour X was when they were eliminated);
+  //   the last position (the last stage, or the identity-like block behind a shorter horizon) is factored last.
   // Per lane: component 0 of Li / Gin / Gout = inv(L_e), Ua, Ub of the even stage, component 1 = the survivor's blocks of the
   // level that eliminated it.  Horizons below 31 leave identity-like blocks with zero couplings at the end of the chain; they
   // factor harmlessly (as in the one-stage layout).
@@ -41,7 +44,9 @@
     Dg[0] = fma_(-gb[2], gb[2], fma_(-gb[0], gb[0], Dg[0]));
     Dg[1] = fma_(-gb[3], gb[2], fma_(-gb[1], gb[0], Dg[1]));
     Dg[2] = fma_(-gb[3], gb[3], fma_(-gb[1], gb[1], Dg[2]));
-    if constexpr (D != 8) {
+    // (the last level, D = 8, eliminates position 7: nobody of its row is below it - in a one-row chain its coupling is an exact
+    //  zero, in a chain of several rows the survivor of the row below is, and takes its update in s2_rows_factor)
+    if constexpr (D != 8 || LL::group > 16) {
       T ga[4];
       {
         T Ua[4];
@@ -50,8 +55,10 @@
         MPMPC_UNROLL
         for (int i = 0; i < 4; ++i) Gin1[i] = Gin1[i] + Ua[i];
         // to the lower neighbour: D_a -= Ua'Ua (the three sums are formed where Ua is and travel, not the four entries)
-        const T w0 = fma_(Ua[2], Ua[2], Ua[0] * Ua[0]), w1 = fma_(Ua[3], Ua[2], Ua[1] * Ua[0]), w2 = fma_(Ua[3], Ua[3], Ua[1] * Ua[1]);
-        Dg[0] = Dg[0] - LL::template rshl<D>(w0); Dg[1] = Dg[1] - LL::template rshl<D>(w1); Dg[2] = Dg[2] - LL::template rshl<D>(w2);
+        if constexpr (D != 8) {
+          const T w0 = fma_(Ua[2], Ua[2], Ua[0] * Ua[0]), w1 = fma_(Ua[3], Ua[2], Ua[1] * Ua[0]), w2 = fma_(Ua[3], Ua[3], Ua[1] * Ua[1]);
+          Dg[0] = Dg[0] - LL::template rshl<D>(w0); Dg[1] = Dg[1] - LL::template rshl<D>(w1); Dg[2] = Dg[2] - LL::template rshl<D>(w2);
+        }
         MPMPC_UNROLL
         for (int i = 0; i < 4; ++i) ga[i] = LL::template rshr<D>(Ua[i]);
       }
@@ -59,6 +66,87 @@
       Cm[1] = sel(E, Cm[1], -fma_(gb[2], ga[3], gb[0] * ga[1]));
       Cm[2] = sel(E, Cm[2], -fma_(gb[3], ga[2], gb[1] * ga[0]));
       Cm[3] = sel(E, Cm[3], -fma_(gb[3], ga[3], gb[1] * ga[1]));
+    }
+  }
+  // ---- chains of several rows: the survivors in turn (factor_cr2, kCR64 - on scalars of the lanes underneath)
+  template <class LL, class T>
+  MPMPC_HD static void s2_rows_factor(T Dg[3], const T Cm[4], T Li1[3], const T Gin1[4], T Gout1[4]) {
+    constexpr int ROWS = LL::group / 16;
+    const T zero(0.0);
+    MPMPC_UNROLL
+    for (int r = 0; r < ROWS - 1; ++r) {
+      const auto spec = LL::cr64_special(r), isX = LL::cr64_x(r), isY = LL::cr64_x(r + 1);
+      T w0 = sel(spec, fma_(Gin1[2], Gin1[2], Gin1[0] * Gin1[0]), zero), w1 = sel(spec, fma_(Gin1[3], Gin1[2], Gin1[1] * Gin1[0]), zero),
+        w2 = sel(spec, fma_(Gin1[3], Gin1[3], Gin1[1] * Gin1[1]), zero);
+      w0 = w0 + LL::template rshl<1>(w0); w1 = w1 + LL::template rshl<1>(w1); w2 = w2 + LL::template rshl<1>(w2);
+      w0 = w0 + LL::template rshl<3>(w0); w1 = w1 + LL::template rshl<3>(w1); w2 = w2 + LL::template rshl<3>(w2);
+      w0 = w0 + LL::template rshl<7>(w0); w1 = w1 + LL::template rshl<7>(w1); w2 = w2 + LL::template rshl<7>(w2);
+      {
+        const T wv[3] = {w0, w1, w2};
+        T wd[3];
+        LL::template cr_down<3>(r, wv, wd);
+        Dg[0] = Dg[0] - sel(isX, wd[0], zero); Dg[1] = Dg[1] - sel(isX, wd[1], zero); Dg[2] = Dg[2] - sel(isX, wd[2], zero);
+      }
+      T i00 = rsqrt_(Dg[0]);
+      const T l10 = Dg[1] * i00;
+      T i11 = rsqrt_(fma_(-l10, l10, Dg[2]));
+      T i10 = -(l10 * i00) * i11;
+      i00 = sel(isX, i00, zero); i10 = sel(isX, i10, zero); i11 = sel(isX, i11, zero);
+      Li1[0] = Li1[0] + i00; Li1[1] = Li1[1] + i10; Li1[2] = Li1[2] + i11;
+      T Cb[4], Ub[4], gb[4];
+      LL::template cr_pull<4>(r, Cm, Cb);
+      Ub[0] = i00 * Cb[0]; Ub[1] = i00 * Cb[2];
+      Ub[2] = fma_(i11, Cb[1], i10 * Cb[0]); Ub[3] = fma_(i11, Cb[3], i10 * Cb[2]);
+      LL::template cr_push<4>(r, Ub, gb);
+      MPMPC_UNROLL
+      for (int i = 0; i < 4; ++i) { Gout1[i] = Gout1[i] + Ub[i]; gb[i] = sel(isY, gb[i], zero); }
+      Dg[0] = fma_(-gb[2], gb[2], fma_(-gb[0], gb[0], Dg[0]));
+      Dg[1] = fma_(-gb[3], gb[2], fma_(-gb[1], gb[0], Dg[1]));
+      Dg[2] = fma_(-gb[3], gb[3], fma_(-gb[1], gb[1], Dg[2]));
+    }
+  }
+  template <class LL, class T>
+  MPMPC_HD static void s2_rows_forward(T& b0, T& b1, T& y0, T& y1, const T Li1[3], const T Gin1[4], const T Gout1[4]) {
+    constexpr int ROWS = LL::group / 16;
+    const T zero(0.0);
+    MPMPC_UNROLL
+    for (int r = 0; r < ROWS - 1; ++r) {
+      const auto spec = LL::cr64_special(r), isX = LL::cr64_x(r), isY = LL::cr64_x(r + 1);
+      T c0 = sel(spec, fma_(Gin1[2], y1, Gin1[0] * y0), zero), c1 = sel(spec, fma_(Gin1[3], y1, Gin1[1] * y0), zero);
+      c0 = c0 + LL::template rshl<1>(c0); c1 = c1 + LL::template rshl<1>(c1);
+      c0 = c0 + LL::template rshl<3>(c0); c1 = c1 + LL::template rshl<3>(c1);
+      c0 = c0 + LL::template rshl<7>(c0); c1 = c1 + LL::template rshl<7>(c1);
+      const T cv[2] = {c0, c1};
+      T cd[2];
+      LL::template cr_down<2>(r, cv, cd);
+      const T bx0 = b0 - cd[0], bx1 = b1 - cd[1];
+      const T yx0 = sel(isX, Li1[0] * bx0, zero), yx1 = sel(isX, fma_(Li1[2], bx1, Li1[1] * bx0), zero);
+      y0 = y0 + yx0; y1 = y1 + yx1;
+      const T pv[2] = {fma_(Gout1[2], yx1, Gout1[0] * yx0), fma_(Gout1[3], yx1, Gout1[1] * yx0)};
+      T pp_[2];
+      LL::template cr_push<2>(r, pv, pp_);
+      b0 = b0 - sel(isY, pp_[0], zero); b1 = b1 - sel(isY, pp_[1], zero);
+    }
+  }
+  template <class LL, class T>
+  MPMPC_HD static void s2_rows_backward(T& y0, T& y1, T& n0, T& n1, const T Li1[3], const T Gin1[4], const T Gout1[4]) {
+    constexpr int ROWS = LL::group / 16;
+    const T zero(0.0);
+    MPMPC_UNROLL
+    for (int r = ROWS - 2; r >= 0; --r) {
+      const auto spec = LL::cr64_special(r), isX = LL::cr64_x(r);
+      const T nv_[2] = {n0, n1};
+      T cn_[2];
+      LL::template cr_pull<2>(r, nv_, cn_);
+      const T c0 = cn_[0], c1 = cn_[1];
+      const T r0 = y0 - fma_(Gout1[1], c1, Gout1[0] * c0), r1 = y1 - fma_(Gout1[3], c1, Gout1[2] * c0);
+      n0 = sel(isX, fma_(Li1[1], r1, Li1[0] * r0), n0);
+      n1 = sel(isX, Li1[2] * r1, n1);
+      const T nx_[2] = {n0, n1};
+      T xb_[2];
+      LL::template cr_bcast<2>(r, nx_, xb_);
+      y0 = y0 - sel(spec, fma_(Gin1[1], xb_[1], Gin1[0] * xb_[0]), zero);
+      y1 = y1 - sel(spec, fma_(Gin1[3], xb_[1], Gin1[2] * xb_[0]), zero);
     }
   }
   MPMPC_HD void factor_core2_s2(const R hx[2], const R& wb, const R& r) {
@@ -87,7 +175,7 @@
       const T i10 = -(l10 * i00) * i11;
       T Cm[4], Ua[4], Ub[4];
       MPMPC_UNROLL
-      for (int i = 0; i < 4; ++i) Cm[i] = LL::template rshr<1>(Tc[i].v[1]);       // S_{e, a}: what the odd stage below hands up
+      for (int i = 0; i < 4; ++i) Cm[i] = L::up1(Tc[i].v[1]);       // S_{e, a}: what the odd stage below hands up
       Ub[0] = i00 * Tc[0].v[0]; Ub[1] = i00 * Tc[2].v[0];                         // inv(L_e) S_be'
       Ub[2] = fma_(i11, Tc[1].v[0], i10 * Tc[0].v[0]); Ub[3] = fma_(i11, Tc[3].v[0], i10 * Tc[2].v[0]);
       Ua[0] = i00 * Cm[0]; Ua[1] = i00 * Cm[1];
@@ -96,7 +184,7 @@
       D1[1] = fma_(-Ub[3], Ub[2], fma_(-Ub[1], Ub[0], Dg[1].v[1]));
       D1[2] = fma_(-Ub[3], Ub[3], fma_(-Ub[1], Ub[1], Dg[2].v[1]));
       const T w0 = fma_(Ua[2], Ua[2], Ua[0] * Ua[0]), w1 = fma_(Ua[3], Ua[2], Ua[1] * Ua[0]), w2 = fma_(Ua[3], Ua[3], Ua[1] * Ua[1]);
-      D1[0] = D1[0] - LL::template rshl<1>(w0); D1[1] = D1[1] - LL::template rshl<1>(w1); D1[2] = D1[2] - LL::template rshl<1>(w2);
+      D1[0] = D1[0] - L::down1(w0); D1[1] = D1[1] - L::down1(w1); D1[2] = D1[2] - L::down1(w2);
       C1[0] = -fma_(Ub[2], Ua[2], Ub[0] * Ua[0]);
       C1[1] = -fma_(Ub[2], Ua[3], Ub[0] * Ua[1]);
       C1[2] = -fma_(Ub[3], Ua[2], Ub[1] * Ua[0]);
@@ -119,6 +207,11 @@
       s2_level<LL, 4>(D1, C1, Li1, Gin1, Gout1);
       s2_level<LL, 8>(D1, C1, Li1, Gin1, Gout1);
       MPMPC_SERIAL_END(4);
+    }
+    if constexpr (LL::group > 16) {
+      MPMPC_SERIAL_BEGIN();
+      s2_rows_factor<LL>(D1, C1, Li1, Gin1, Gout1);
+      MPMPC_SERIAL_END(N + 1);
     }
     {
       MPMPC_SERIAL_BEGIN();          // (census: useful on one lane)
@@ -188,8 +281,8 @@
       t0 = Li[0].v[0] * b0.v[0]; t1 = fma_(Li[2].v[0], b1.v[0], Li[1].v[0] * b0.v[0]);
       const T pb0 = fma_(Gout[2].v[0], t1, Gout[0].v[0] * t0), pb1 = fma_(Gout[3].v[0], t1, Gout[1].v[0] * t0);
       const T pa0 = fma_(Gin[2].v[0], t1, Gin[0].v[0] * t0), pa1 = fma_(Gin[3].v[0], t1, Gin[1].v[0] * t0);
-      c0 = b0.v[1] - pb0 - LL::template rshl<1>(pa0);
-      c1 = b1.v[1] - pb1 - LL::template rshl<1>(pa1);
+      c0 = b0.v[1] - pb0 - L::down1(pa0);
+      c1 = b1.v[1] - pb1 - L::down1(pa1);
       MPMPC_SERIAL_END(1);
     }
     T y0(0.0), y1(0.0);
@@ -201,6 +294,11 @@
       s2_forward<LL, 8>(c0, c1, y0, y1, Li1, Gin1, Gout1);
       MPMPC_SERIAL_END(4);
     }
+    if constexpr (LL::group > 16) {
+      MPMPC_SERIAL_BEGIN();
+      s2_rows_forward<LL>(c0, c1, y0, y1, Li1, Gin1, Gout1);
+      MPMPC_SERIAL_END(N + 1);
+    }
     T n0, n1;
     {
       // position 15: y = inv(L) b, nu = inv(L)'y
@@ -209,6 +307,11 @@
       const T ye0 = Li1[0] * c0, ye1 = fma_(Li1[2], c1, Li1[1] * c0);
       n0 = sel(last, fma_(Li1[1], ye1, Li1[0] * ye0), zero);
       n1 = sel(last, Li1[2] * ye1, zero);
+      MPMPC_SERIAL_END(N + 1);
+    }
+    if constexpr (LL::group > 16) {
+      MPMPC_SERIAL_BEGIN();
+      s2_rows_backward<LL>(y0, y1, n0, n1, Li1, Gin1, Gout1);
       MPMPC_SERIAL_END(N + 1);
     }
     {
@@ -222,7 +325,7 @@
     {
       // ---- level H backward: nu_e = inv(L_e)' (y_e - Ua nu_a - Ub nu_b),  nu_a from the lane below, nu_b in the lane
       MPMPC_SERIAL_BEGIN();
-      const T a0 = LL::template rshr<1>(n0), a1 = LL::template rshr<1>(n1);
+      const T a0 = L::up1(n0), a1 = L::up1(n1);
       const T r0 = fma_(-Gout[1].v[0], n1, fma_(-Gout[0].v[0], n0, fma_(-Gin[1].v[0], a1, fma_(-Gin[0].v[0], a0, t0))));
       const T r1 = fma_(-Gout[3].v[0], n1, fma_(-Gout[2].v[0], n0, fma_(-Gin[3].v[0], a1, fma_(-Gin[2].v[0], a0, t1))));
       nu[0] = R(fma_(Li[1].v[0], r1, Li[0].v[0] * r0), n0);

@@ -17,7 +17,8 @@ emu = T.Emul()
 track = scenarios.sim_track()
 print("# %s" % mpmpc.load_library().mpmpc_version().decode())
 print("# N, kernel, B: ms per launch (resident, one launch in flight), solves/s; interior-point iterations mean")
-for N, native in ((50, 1), (63, 1), (63, 0), (64, 1), (100, 1), (127, 1), (128, 1), (200, 1), (255, 1)):
+# (lanes: 0 = the launcher's choice; at horizons 64 .. 127 that is TWO stages per lane in one wavefront, 128 = the workgroup kernels)
+for N, native, lanes in ((50, 1, 0), (63, 1, 0), (63, 0, 0), (64, 1, 0), (64, 1, 128), (100, 1, 0), (100, 1, 128), (127, 1, 0), (127, 1, 128), (128, 1, 0), (200, 1, 0), (255, 1, 0)):
     tw = T.wide_track(track, emu, max(N, 50))
     for B in (64, 1024, 8192):
         sc = scenarios.make(2, tw, B=B, N=N)
@@ -25,6 +26,8 @@ for N, native in ((50, 1), (63, 1), (63, 0), (64, 1), (100, 1), (127, 1), (128, 
         h = mpmpc.Handle(cfg, mpmpc.default_settings(native=native))
         h.set_path(track.kappa, track.v_ref, track.ds_next)
         h.set_outputs(False)
+        if lanes:
+            h.set_packing(lanes)
         h.set_pipeline(1)
         h.upload(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
         for _ in range(3):
@@ -38,5 +41,5 @@ for N, native in ((50, 1), (63, 1), (63, 0), (64, 1), (100, 1), (127, 1), (128, 
         dt = (time.perf_counter() - t0) / n
         sol = h.download(B)
         h.close()
-        kern = "workgroup of %d lanes" % mpmpc.stage_ld(N) if N > 63 else ("reduced-native wavefront kernel" if native else "general wavefront kernel")
+        kern = ("two stages per lane, one wavefront" if 63 < N < 128 and not lanes else "workgroup of %d lanes" % mpmpc.stage_ld(N)) if N > 63 else ("reduced-native wavefront kernel" if native else "general wavefront kernel")
         print("N %3d  %-32s B %5d: %8.3f ms  %10.0f solves/s  ipm %.2f  solved %d" % (N, kern, B, dt * 1e3, B / dt, sol.iters[:, 1].mean(), int((sol.status == 1).sum())))

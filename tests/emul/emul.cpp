@@ -87,9 +87,11 @@ static void solve_rn(const mpmpc_config* cfg, const mpmpc_settings* st, const do
 }
 // mpmpc_reduced_pair_kernel: the same solver with TWO stages per lane (lane_pair.hpp) - 16 lanes per instance for N + 1 <= 32,
 // four instances per emulated wave
+// (GB = 64: horizons 64 .. 127 in ONE emulated wavefront - on the one-stage layout they take a workgroup of two, emul_wide.cpp)
+template <int GB>
 static void solve_rn2(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
                       int* status, int* iters, double* resid, double* y, int* tail) {
-  using L = LanePair<LaneEmu<16, 16>>;
+  using L = LanePair<LaneEmu<GB, GB>>;
   const int ld = stage_ld(cfg->N);
   const int per = L::per_wave;
   for (int w = 0; w < (B + per - 1) / per; ++w) {
@@ -170,7 +172,8 @@ static int solve_rn_g(int G, const mpmpc_config* cfg, const mpmpc_settings* st, 
                       int* status, int* iters, double* resid, double* y, int* tail, const int* guess = nullptr, int* act = nullptr) {
   const int C = lane_split(G, cfg->N);
   // (16 lanes for more than 16 stages: two stages per lane - cold starts only, like the launcher)
-  if (G == 16 && cfg->N + 1 > 16) { if (guess || cfg->N + 1 > 32) return -1; solve_rn2(cfg, st, qp, B, z, u0, status, iters, resid, y, tail); return 0; }
+  if (G == 16 && cfg->N + 1 > 16) { if (guess || cfg->N + 1 > 32) return -1; solve_rn2<16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail); return 0; }
+  if (G == 64 && cfg->N + 1 > 64) { if (guess || cfg->N + 1 > 128) return -1; solve_rn2<64>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail); return 0; }
   if (G == 64 && C == 16) solve_rn<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail, guess, act);
   else if (G == 64) solve_rn<64, 32>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail, guess, act);
   else if (G == 32) solve_rn<32, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail, guess, act);
@@ -243,7 +246,7 @@ extern "C" int emu_solve_launch(const mpmpc_config* cfg, const mpmpc_settings* s
 // the reduced-native kernel alone: what it cannot certify stays UNSOLVED and is counted in *n_tail
 extern "C" int emu_solve_rn(const mpmpc_config* cfg, const mpmpc_settings* st, int G, const double* qp, int B,
                             double* z, double* u0, int* status, int* iters, double* resid, double* y, int* n_tail) {
-  if (cfg->N + 1 > G && !(G == 16 && cfg->N + 1 <= 32 && reducible(*cfg, *st))) return -1;
+  if (cfg->N + 1 > G && !((G == 16 || G == 64) && cfg->N + 1 <= 2 * G && reducible(*cfg, *st))) return -1;
   std::vector<int> tail(B + 1, 0);
   if (reducible_tt(*cfg, *st)) {
     if (solve_rnt_g(G, cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data())) return -1;

@@ -71,6 +71,28 @@ static void solve_wide_native(const mpmpc_config* cfg, const mpmpc_settings* st,
   }
 }
 
+// the tail alone: mpmpc_solve_block_kernel<G, 2> on the listed instances (mode 2: phase 1 and the full iteration) - what follows
+// the reduced-native kernel with two stages per lane (horizons 64 .. 127 in one wavefront: emul.cpp, solve_rn2<64>)
+extern "C" int emuw_solve_tail(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
+                               int* status, int* iters, double* resid, double* y, const int* ids, int n_ids) {
+  if (stage_ld(cfg->N) != EMU_W || !reducible(*cfg, *st)) return -1;
+  constexpr int G = EMU_W, C = EMU_W / 2;
+  using L = LaneEmu<G, C>;
+  const int ld = stage_ld(cfg->N);
+  for (int j = 0; j < n_ids; ++j) {
+    const int id = ids[j];
+    VI inst = L::slot() + id;
+    VI k = L::stage() - lane_offset(G, C, cfg->N);
+    using S = Solver<L, false, true, false, true>;
+    S s;
+    typename L::real fields[MPMPC_NUM_FIELDS];
+    S::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    s.template run<false, true>(fields, B, inst, k, cfg->N, make_params(*st), 2, VI(0), VI(iters[id * 2 + 1]), nullptr);
+    s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y, nullptr, ld);
+  }
+  return 0;
+}
+
 // the kernel the launcher picks for a horizon above 63: the general solver, one instance per workgroup; full weights
 // where a weight matrix has off-diagonal entries, the reduced polish where the time state separates.  -1: the horizon does not belong to this width.
 extern "C" int emuw_width() { return EMU_W; }

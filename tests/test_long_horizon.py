@@ -147,6 +147,28 @@ def test_long_horizons_other_problem_classes_in_the_emulation(N, emu, track):
     assert np.max(np.abs(sol.z[ok] - ref["z"][ok])) <= 1e-6 if ok.any() else True
 
 
+@pytest.mark.parametrize("N,cfgid,B", [(64, 2, 10), (64, 4, 12), (65, 4, 6), (80, 4, 16), (96, 2, 6), (100, 4, 10), (112, 2, 6), (126, 4, 6), (127, 2, 10)])
+def test_two_stages_per_lane_in_one_wavefront_against_the_workgroup_emulation(N, cfgid, B, emu, track):
+    """Horizons 64 .. 127 (round 6): the reduced-native solver with TWO stages per lane - the whole instance in one wavefront, a
+    chain of four rows (csrc/lane_pair.hpp, mpmpc_solver_s2.hpp: level H inside the lanes, four in-row levels, the row survivors
+    in turn) - against the workgroup emulation of the same solver (one stage per lane, 128 lanes) and the C oracle: statuses,
+    iteration counts, controls; KKT with plain numpy.  Row boundaries (N = 64, 65, 96, 112, 126, 127) included."""
+    tw = T.wide_track(track, emu, N)
+    sc = scenarios.make(cfgid, tw, B=B, N=N)
+    cfg = T.stock_config(N, sc.weights)
+    st = mpmpc.default_settings(phase1_accept=0)
+    qp = emu.assemble(cfg, tw, (sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub))
+    pair = emu.solve(cfg, st, qp)                  # the launcher's sequence: pair kernel, then the workgroup kernel on its list
+    wg = emu.solve(cfg, st, qp, G=128)             # ... and with mpmpc_set_packing(h, 128): the workgroup kernels alone
+    assert np.array_equal(pair.status, wg.status) and np.array_equal(pair.iters, wg.iters)
+    ok = pair.status == 1
+    assert ok.sum() >= B // 2 and np.max(np.abs(pair.u0[ok] - wg.u0[ok])) <= 1e-13 and np.max(np.abs(pair.z[ok] - wg.z[ok])) <= 1e-10
+    ref = _oracle(track, sc, scenarios.WEIGHTS[sc.weights])
+    assert np.array_equal(pair.status, ref["status"]) and np.max(np.abs(pair.u0[ok] - ref["u0"][ok])) <= 1e-6
+    prim, stat, comp = T.kkt_batch(qp[:, ok, :], N, pair.z[ok], pair.y[ok])
+    assert max(prim.max(), stat.max(), comp.max()) <= 1e-8
+
+
 def test_horizon_limits_are_checked():
     with pytest.raises(ValueError):
         T.stock_config(256)
@@ -198,6 +220,29 @@ def test_long_horizons_on_device(N, cfgid, track, emu):
     if (~ok).any():
         good, _, _ = T.farkas_batch(qp[:, ~ok, :], N, sol.y[~ok])
         assert good.all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,cfgid", [(64, 4), (100, 2), (127, 4)])
+def test_pair_kernel_and_workgroup_kernel_agree_on_device(N, cfgid, track, emu):
+    """Horizons 64 .. 127: the default (two stages per lane, one wavefront per instance) against mpmpc_set_packing(h, 128) (the
+    workgroup kernels of round 5) on 512 instances: statuses, iteration counts of the certified instances, controls to 1e-12."""
+    B = 512
+    tw = T.wide_track(track, emu, N)
+    sc = scenarios.make(cfgid, tw, B=B, N=N)
+    cfg = T.stock_config(N, sc.weights, max_batch=B)
+    sols = {}
+    for lanes in (0, 128):
+        h = mpmpc.Handle(cfg, mpmpc.default_settings())
+        h.set_path(track.kappa, track.v_ref, track.ds_next)
+        h.set_packing(lanes)
+        sols[lanes] = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
+        h.close()
+    a, b = sols[0], sols[128]
+    assert np.array_equal(a.status, b.status)
+    ok = a.status == 1
+    assert ok.mean() > 0.5 and np.max(np.abs(a.iters[ok, 1] - b.iters[ok, 1])) <= 1 and (a.iters[ok, 1] != b.iters[ok, 1]).sum() <= 2
+    assert np.max(np.abs(a.u0[ok] - b.u0[ok])) <= 1e-12
 
 
 @pytest.mark.gpu
