@@ -72,23 +72,25 @@ def test_cyclic_reduction_of_partly_filled_rows(N, emu, track):
 def test_long_horizon_general_variants_on_device(N, track, emu):
     """The workgroup kernel's OTHER variants on the device - full weight matrices (3 x 3 dense blocks), the time-optimal
     weights and bounded e_psi / t (the full 3-state problem), and the restated OSQP alone - at 128 and at 256 lanes (where
-    the sweeps of the factorisation are staged wavefront by wavefront): statuses and iteration counts of the emulation, z to
-    1e-9, KKT on the dense data."""
+    the sweeps of the factorisation are staged wavefront by wavefront).  EVERY instance of a batch of 96 against the C ORACLE
+    (statuses, controls to 1e-6, the plan to 1e-6) and through the plain-numpy KKT / Farkas tests; eight of
+    them against the emulation of the same lane code (statuses, iteration counts, z to 1e-9)."""
     from test_emul_parity import full_weight_config
-    B = 24
+    B = 96
     tw = T.wide_track(track, emu, N)
     sc = scenarios.make(4, tw, B=B, N=N)
     inp = (sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
     xmin, xmax = np.array([-np.inf, -0.6, -np.inf]), np.array([np.inf, 0.6, 0.2 * N])
     Qt, Rt, QNt = scenarios.WEIGHTS["time_optimal"]
     Qs, Rs, QNs = scenarios.WEIGHTS["stock"]
-    cases = [("full weights", full_weight_config(N, "full", max_batch=B), mpmpc.default_settings()),
+    strict = mpmpc.default_settings(phase1_accept=0)          # (every proven infeasibility reported: the oracle's semantics)
+    cases = [("full weights", full_weight_config(N, "full", max_batch=B), strict, None),
              ("time-optimal", mpmpc.make_config(N, Qt, Rt, QNt, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX, 4.0, 0.12, max_batch=B),
-              mpmpc.default_settings(phase1_accept=0)),
+              strict, ((Qt, Rt, QNt), scenarios.XMIN, scenarios.XMAX)),
              ("bounded states", mpmpc.make_config(N, Qs, Rs, QNs, xmin, xmax, scenarios.UMIN, scenarios.UMAX, 4.0, 0.12, max_batch=B),
-              mpmpc.default_settings(phase1_accept=0)),
-             ("stock OSQP", T.stock_config(N, max_batch=B), mpmpc.stock_settings())]
-    for name, cfg, st in cases:
+              strict, ((Qs, Rs, QNs), xmin, xmax)),
+             ("stock OSQP", T.stock_config(N, max_batch=B), mpmpc.stock_settings(), None)]
+    for name, cfg, st, orc in cases:
         h = mpmpc.Handle(cfg, st)
         h.set_path(track.kappa, track.v_ref, track.ds_next)
         qp = h.assemble(*inp)
@@ -102,10 +104,41 @@ def test_long_horizon_general_variants_on_device(N, track, emu):
         okr = ref.status == 1
         assert okr.any() and np.max(np.abs(sol.z[:nn][okr] - ref.z[okr])) <= (1e-9 if name != "stock OSQP" else 1e-7), name
         if name == "stock OSQP":
+            r = _oracle(track, sc, scenarios.WEIGHTS["stock"], polish=0, early_polish=0, phase1=0)
+            assert np.array_equal(sol.status, r["status"]) and np.array_equal(sol.iters[:, 0], r["iters"][:, 0]), name
+            ok = sol.status == 1
+            assert np.max(np.abs(sol.z[ok] - r["z"][ok])) <= 1e-6
             continue
-        for i in np.flatnonzero(sol.status == 1)[:6]:
-            P, q, A, l, u = T.qp_to_dense_full(qp[:, i, :], N, cfg)
-            assert O.kkt_certificate(P, q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8), (name, i)
+        ok = sol.status == 1
+        assert ok.sum() >= B // 2, name
+        if orc is not None:
+            # diagonal weights: the C oracle's MPC path on the same inputs, all 96 instances
+            r = _oracle(track, sc, *orc)
+            assert np.array_equal(sol.status, r["status"]), (name, np.flatnonzero(sol.status != r["status"]))
+            assert np.max(np.abs(sol.u0[ok] - r["u0"][ok])) <= 1e-6, name
+            e = np.abs(sol.z[ok] - r["z"][ok])
+            e[:, -1] = 0.0
+            e[:, 3 * N + 1] = 0.0                        # (kappa_{N-1} and the e_psi,N it drives carry no cost)
+            assert e.max() <= 1e-6, name
+            prim, stat, comp = T.kkt_batch(qp[:, ok, :], N, sol.z[ok], sol.y[ok])
+            assert max(prim.max(), stat.max(), comp.max()) <= 1e-8, name
+            if (~ok).any():
+                good, _, _ = T.farkas_batch(qp[:, ~ok, :], N, sol.y[~ok])
+                assert good.all(), name
+        else:
+            # full weights: the C oracle's generic QP path on the dense (P, q, A, l, u) rebuilt from K1's fields, instance by instance
+            for i in range(B):
+                P, q, A, l, u = T.qp_to_dense_full(qp[:, i, :], N, cfg)
+                x, y, info = OC.solve(P, q, A, l, u)
+                assert sol.status[i] == info.status, (name, i, sol.status[i], info.status)
+                if sol.status[i] == 1:
+                    assert O.kkt_certificate(P, q, A, l, u, sol.z[i], sol.y[i])["ok_tol"](1e-8), (name, i)
+                    if info.polished == 1:
+                        e = np.abs(sol.z[i] - x)
+                        e[-1] = 0.0
+                        assert e.max() <= 1e-6 and np.max(np.abs(sol.u0[i] - [x[3 * (N + 1)], np.arctan(x[3 * (N + 1) + 1] * scenarios.CAR_LENGTH)])) <= 1e-6, (name, i)
+                else:
+                    assert O.farkas_certificate(A, l, u, sol.y[i], 1e-6)["ok"], (name, i)
 
 
 @pytest.mark.parametrize("N", [64, 130])
