@@ -44,7 +44,7 @@ import bench_dist  # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
 HBM_ACHIEVABLE = 6.29e12   # B/s, the guide's measured-achievable rate (79 % of the peak): a streaming kernel cannot beat it from HBM
-PROFILE_ROUNDS = ("r5", "r4")      # committed rocprofv3 summaries are looked up newest round first (each names its library sources)
+PROFILE_ROUNDS = ("r6", "r5", "r4")      # committed rocprofv3 summaries are looked up newest round first (each names its library sources)
 FP64_VALU_PEAK = 78.6e12   # FLOP/s vector FP64 (spec)
 
 
@@ -269,34 +269,59 @@ def pmc_traffic_bytes(kernel_prefix, B, lib_version, config=2):
         w = next(v for k, v in d[key_w].items() if k.startswith(kernel_prefix))["WRITE_SIZE"]["mean"]
         note = ""
         # a launch that leaves a tail also runs its tail kernel(s): their bytes belong to the launch (one tail launch per launch)
-        for tk in ("mpmpc_reduced_tail_kernel", "mpmpc_solve_kernel"):
-            if tk == kernel_prefix or config == 2 or config < 0:          # (config < 0: one kernel alone, K1)
+        # (the EXACT instantiations the launcher uses for a tail - not any kernel of the family: a pass that also ran the restated
+        #  OSQP at stock settings holds mpmpc_solve_kernel<.., 3> launches of another kind beside the tail's <.., 2>; ADVICE r5.
+        #  The profiling scripts now pass --no-extra-legs, so such launches are not in new summaries at all.)
+        tails = ("mpmpc_reduced_tail_kernel<", "mpmpc_solve_kernel<64, 16, false, 2>", "mpmpc_solve_kernel<64, 32, false, 2>") if config != 3 \
+            else ("mpmpc_solve_kernel<64, 32, false, 3>",)
+        for tk in tails:
+            if tk.startswith(kernel_prefix) or config == 2 or config < 0:          # (config < 0: one kernel alone, K1)
                 continue
             tf = [v["FETCH_SIZE"]["mean"] for k, v in d[key_f].items() if k.startswith(tk)]
             tw = [v["WRITE_SIZE"]["mean"] for k, v in d[key_w].items() if k.startswith(tk)]
-            if tf and tw:
-                f, w, note = f + tf[0], w + tw[0], note + " + " + tk
+            if len(tf) == 1 and len(tw) == 1:
+                f, w, note = f + tf[0], w + tw[0], note + " + " + tk.rstrip("<")
         return (2.0 * f + w) * 1024.0, "profiles/%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of %s%s, same library sources %s)" % (
             rnd, kernel_prefix, note, src)
     except Exception:
         return None, "profiles/%s/pmc_summary.json has no counters for this kernel at B = %d" % (rnd, B)
 
 
+def check_ranks(args, dist, rank, world, ranks):
+    """Every rank holds the same per-rank reports (bench_dist.rank_reports all-gathers them): all of them leave, non-zero and
+    before rank 0 prints, unless the process group has --gpus ranks and every rank drives a device of its own."""
+    if world <= 1:
+        return
+    devs = [r_["device"] for r_ in ranks] if ranks else []
+    if dist is None or int(dist.get_world_size()) != args.gpus or len(set(devs)) != args.gpus:
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d, but the process group has %s ranks on devices %s: no line printed\n"
+                             % (args.gpus, dist.get_world_size() if dist is not None else None, devs))
+        sys.exit(3)
+
+
 def single_process_bench(args, real_stdout):
     """--gpus N --single-process: the N shards of a world x B batch on N handles of THIS process (device r for shard r; no
-    torch, no process group, no collective).  A step = one resident launch on every handle; the clock stops when every
-    device is idle.  The line carries the contract's fields; parity legs and rooflines are those of the default run."""
+    torch, no process group, no collective) - a second way to run config 5 should the box's torch / RCCL pairing misbehave.
+    A step = one resident launch on every handle; the clock stops when every device is idle.  Same schema as the torchrun
+    line where it applies: `ranks` (device and status counts per handle), `roofline`, `value_one_launch_in_flight`,
+    `gather_check`.  With --dry-run the handles are the CPU emulation's stand-ins (a rehearsal: value null)."""
     import sharded
     tr = scenarios.sim_track()
     spec = scenarios.CONFIGS[args.config]
     B = args.batch or spec.get("B_per_gpu", spec["B"])
     world = args.gpus
-    n_dev = mpmpc.device_count()
-    if n_dev < 1:
-        sys.exit("bench.py: no HIP device visible")
-    if world > n_dev and not os.environ.get("MPMPC_BENCH_SHARE_DEVICE"):
-        sys.exit("bench.py: --gpus %d --single-process but %d device(s) visible (MPMPC_BENCH_SHARE_DEVICE=1 puts the handles on "
-                 "device 0 for a functional check)" % (world, n_dev))
+    if args.dry_run:
+        sys.path.insert(0, os.path.join(ROOT, "bench_support"))
+        import emulation
+        n_dev = world
+    else:
+        n_dev = mpmpc.device_count()
+        if n_dev < 1:
+            sys.exit("bench.py: no HIP device visible")
+        if world > n_dev and not os.environ.get("MPMPC_BENCH_SHARE_DEVICE"):
+            sys.exit("bench.py: --gpus %d --single-process but %d device(s) visible (MPMPC_BENCH_SHARE_DEVICE=1 puts the handles on "
+                     "device 0 for a functional check)" % (world, n_dev))
     sc_all = scenarios.make(args.config, tr, B=B * world)
     N = sc_all.N
     Q, R, QN = scenarios.WEIGHTS[sc_all.weights]
@@ -305,7 +330,7 @@ def single_process_bench(args, real_stdout):
     for r in range(world):
         cfg = mpmpc.make_config(N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX, scenarios.AY_MAX,
                                 scenarios.CAR_LENGTH, circular=True, max_batch=B, device=r if world <= n_dev else 0)
-        h = mpmpc.Handle(cfg, settings)
+        h = emulation.DryHandle(cfg, settings) if args.dry_run else mpmpc.Handle(cfg, settings)
         h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
         h.set_outputs(want_y=False)
         h.set_pipeline(args.pipeline)
@@ -319,37 +344,85 @@ def single_process_bench(args, real_stdout):
     def sync():
         for h in hs:
             h.sync()
-    for _ in range(args.prewarm + args.warmup):
+
+    def timed(repeats):
+        dts = []
+        for _ in range(max(1, repeats)):
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            sync()
+            dts.append(time.perf_counter() - t0)
+        return dts
+    for _ in range((0 if args.dry_run else args.prewarm) + args.warmup):
         step()
-    dts = []
-    for _ in range(max(1, args.repeats)):
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync()
-        dts.append(time.perf_counter() - t0)
+    dts = timed(args.repeats)
     dt = float(np.median(dts))
+    # per-device status counts of the timed launches' results (the torchrun line's `ranks`)
+    ranks = []
+    for r, h in enumerate(hs):
+        st = h.download(B, want_y=False).status
+        ranks.append({"rank": r, "device": int(h.cfg.device), "solved": int(np.sum(st == 1)), "solved_inaccurate": int(np.sum(st == 2)),
+                      "infeasible": int(np.sum(st == -3)), "other": int(np.sum((st != 1) & (st != 2) & (st != -3)))})
+    # the other operating point: one launch in flight per handle
+    for h in hs:
+        h.set_pipeline(1)
+    for _ in range(max(args.warmup, 5)):
+        step()
+    dt1 = float(np.median(timed(args.repeats)))
+    for h in hs:
+        h.set_pipeline(args.pipeline)
+    # launch durations on device 0's streams (HIP events around each launch of the pipelined pattern)
+    roof = None
+    if not args.dry_run:
+        n_prof = max(8, min(args.steps, 64))
+        each, span = hs[0].solve_resident_profile(B, n_prof)
+        bytes_k2 = algorithmic_bytes_per_solve(N) * B
+        agg = bytes_k2 * world * args.steps / dt
+        roof = {"bound": "hbm", "achieved": agg / 1e9, "peak": world * HBM_PEAK / 1e9, "unit": "GB/s", "frac": agg / (world * HBM_PEAK),
+                "frac_per_kernel": bytes_k2 / (float(np.mean(each)) * 1e-3) / HBM_PEAK, "avg_ms": float(np.mean(each)), "span_ms": float(span),
+                "launches_measured": int(n_prof), "algorithmic_bytes": bytes_k2, "bytes_per_solve": algorithmic_bytes_per_solve(N), "traffic": None,
+                "note": "achieved = algorithmic bytes of all devices' timed launches / the timed region, peak = n_gpus x 8 TB/s; avg_ms / "
+                        "frac_per_kernel: HIP events around each launch on device 0's own streams (mpmpc_solve_resident_profile).  The solve "
+                        "kernels are FP64-VALU bound, not HBM bound: see the default run's roofline_fp64"}
     # the shards through the product class against one handle solving the whole batch (outside the timed region)
     sh = sharded.ShardedHandles(hs)
     got = sh.solve(sc_all.wp_id, sc_all.x0, sc_all.cc_prev, sc_all.lb, sc_all.ub)
     cfg1 = mpmpc.make_config(N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX, scenarios.AY_MAX,
                              scenarios.CAR_LENGTH, circular=True, max_batch=B * world, device=0)
-    h1 = mpmpc.Handle(cfg1, settings)
+    h1 = emulation.DryHandle(cfg1, settings) if args.dry_run else mpmpc.Handle(cfg1, settings)
     h1.set_path(tr.kappa, tr.v_ref, tr.ds_next)
     one = h1.solve(sc_all.wp_id, sc_all.x0, sc_all.cc_prev, sc_all.lb, sc_all.ub)
     h1.close()
-    out = {"metric": "MPC QP solves/sec (batch, horizon N=%d)" % N, "value": world * B * args.steps / dt, "unit": "solves/s",
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "repeats": len(dts), "ms_per_step_min": 1e3 * min(dts) / args.steps, "ms_per_step_max": 1e3 * max(dts) / args.steps,
+    out = {"metric": "MPC QP solves/sec (batch, horizon N=%d)" % N, "value": None if args.dry_run else world * B * args.steps / dt, "unit": "solves/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None if args.dry_run else 1e3 * dt / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "repeats": len(dts), "ms_per_step_min": None if args.dry_run else 1e3 * min(dts) / args.steps,
+           "ms_per_step_max": None if args.dry_run else 1e3 * max(dts) / args.steps,
+           "value_one_launch_in_flight": None if args.dry_run else world * B * args.steps / dt1,
+           "one_launch_in_flight": {"value": None if args.dry_run else world * B * args.steps / dt1, "unit": "solves/s",
+                                    "ms_per_step": None if args.dry_run else 1e3 * dt1 / args.steps,
+                                    "note": "mpmpc_set_pipeline(h, 1) on every handle: same K, same repeats as `value`"},
            "config": {"workload": "config%d: batch=%d independent poses per GPU, %s weights, N=%d; ONE process, one handle per device "
-                                  "(sharded.ShardedHandles), no process group" % (args.config, B, sc_all.weights, N),
+                                  "(sharded.ShardedHandles), no process group%s" % (args.config, B, sc_all.weights, N, "; REHEARSAL on the CPU emulation" if args.dry_run else ""),
                       "batch_per_gpu": B, "horizon": N, "parallelism": "single-process batch-shard x%d" % world},
-           "devices": [int(h.cfg.device) for h in hs], "launches_in_flight": int(args.pipeline),
+           "devices": [int(h.cfg.device) for h in hs], "ranks": ranks, "rccl_world_size": 0, "launches_in_flight": int(args.pipeline),
            "gather_check": {"same_status": bool(np.array_equal(got.status, one.status)), "same_u0": bool(np.array_equal(got.u0, one.u0)),
                             "instances": int(B * world)},
            "library": hs[0].lib.mpmpc_version().decode()}
+    if roof:
+        out["roofline"] = roof
+    if args.dry_run:
+        out["dry_run"] = True
+        out["note"] = "handles, shards, status counts and the gather check rehearsed on the kernels' CPU emulation; not a measurement"
+    # what --gpus promised: that many handles, a device each (MPMPC_BENCH_SHARE_DEVICE=1: a functional run on one device, said so)
+    shared = bool(os.environ.get("MPMPC_BENCH_SHARE_DEVICE")) and not args.dry_run
+    if len(set(out["devices"])) != world and not shared:
+        sys.stderr.write("bench.py: --gpus %d --single-process, but the handles sit on devices %s: no line printed\n" % (world, out["devices"]))
+        sys.exit(3)
+    if shared:
+        out["devices_shared"] = True
     real_stdout.write(json.dumps(out) + "\n")
     real_stdout.flush()
     sh.close()
@@ -382,6 +455,10 @@ def _main(real_stdout):
     ap.add_argument("--repeats", type=int, default=25, help="the timed region of K steps is run this many times; value = median repeat")
     ap.add_argument("--pipeline", type=int, default=4, help="resident launches in flight inside the handle (mpmpc_set_pipeline): 1 .. 8")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the legs beside the timed loop that launch OTHER kernels or packings (one launch in flight, the restated "
+                         "OSQP at stock settings): what the profiling scripts pass, so that a kernel trace / PMC pass of the command "
+                         "holds the kernels of the timed loop only (ADVICE r5)")
     ap.add_argument("--single-process", action="store_true",
                     help="with --gpus N: ONE process drives the N devices (one handle per device, multi-purpose-mpc_amd/sharded.py) "
                          "instead of one rank per GPU under torch.distributed; a second way to run config 5")
@@ -448,9 +525,9 @@ def _main(real_stdout):
         overrides[k] = float(v) if any(c in v for c in ".eE") else int(v)
     settings = mpmpc.default_settings(**overrides)
     if args.dry_run:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import mpmpc_testlib
-        h = mpmpc_testlib.DryHandle(cfg, settings)          # the handle's resident surface on the CPU emulation (test infrastructure)
+        sys.path.insert(0, os.path.join(ROOT, "bench_support"))
+        import emulation
+        h = emulation.DryHandle(cfg, settings)          # the handle's resident surface on the CPU emulation (rehearsal infrastructure)
     else:
         h = mpmpc.Handle(cfg, settings)
     h.set_path(tr.kappa, tr.v_ref, tr.ds_next)
@@ -524,6 +601,20 @@ def _main(real_stdout):
     med = int(np.argsort(dts)[len(dts) // 2])
     dt = float(dts[med])                                                       # median repeat
     dt_ranks = bench_dist.all_ranks(dist, mine[med], device=dev)
+    # The same loop in regions of 200 steps: a region of K = 20 steps pays the ramp and the drain of the
+    # launches in flight - the chip holds fewer kernels at its two ends - which a long-running caller does not.  Reported
+    # beside `value` (value_200_step_regions, ramp_drain_share), never as it.
+    dt200 = None
+    if not args.dry_run and args.steps < 200:
+        d2 = []
+        for _ in range(5):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                h.solve_resident(B)
+            h.sync()
+            d2.append(bench_dist.max_over_ranks(dist, time.perf_counter() - t0, device=dev))
+        dt200 = float(np.median(d2))
 
     if args.dry_run:
         # the rehearsal ends here: what the ranks exchange - the gathered result buffer against one process solving the whole
@@ -533,11 +624,12 @@ def _main(real_stdout):
         def solve_whole_dry():
             cfg1 = mpmpc.make_config(N, Q, R, QN, scenarios.XMIN, scenarios.XMAX, scenarios.UMIN, scenarios.UMAX, scenarios.AY_MAX,
                                      scenarios.CAR_LENGTH, circular=True, max_batch=B * world, device=local_rank)
-            h1 = mpmpc_testlib.DryHandle(cfg1, settings)
+            h1 = emulation.DryHandle(cfg1, settings)
             h1.set_path(tr.kappa, tr.v_ref, tr.ds_next)
             return h1.solve(sc_all.wp_id, sc_all.x0, sc_all.cc_prev, sc_all.lb, sc_all.ub)
         gather_check = bench_dist.gather_check(dist, rank, sol.u0, sol.status, B * world, solve_whole_dry, device=dev)
         ranks = bench_dist.rank_reports(dist, cfg.device, sol.status, device=dev)
+        check_ranks(args, dist, rank, world, ranks)
         if rank == 0:
             out = {"metric": "MPC QP solves/sec (batch, horizon N=%d)" % N, "value": None, "unit": "solves/s", "dry_run": True,
                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
@@ -573,50 +665,54 @@ def _main(real_stdout):
 
     # The OTHER operating point (VERDICT r4 "weak" 4): ONE launch in flight - a caller whose step k + 1 needs the result of
     # step k (the reference's own loop, src/simulation.py:134-140) cannot pipeline.  Same K, same repeats, same clock.
-    h.set_pipeline(1)
-    for _ in range(max(args.warmup, 5)):
-        h.solve_resident(B)
-    dts1 = []
-    for _ in range(repeats):
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
+    dt1, dts1, same1 = None, [], None
+    if not args.no_extra_legs:
+        h.set_pipeline(1)
+        for _ in range(max(args.warmup, 5)):
             h.solve_resident(B)
-        h.sync()
-        dts1.append(bench_dist.max_over_ranks(dist, time.perf_counter() - t0, device=dev))
-    dt1 = float(np.median(dts1))
-    sol1 = h.download(B, want_y=False)
-    same1 = bool(np.array_equal(sol1.status, sol.status) and np.array_equal(sol1.u0, sol.u0))
-    h.set_pipeline(args.pipeline)
+        dts1 = []
+        for _ in range(repeats):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                h.solve_resident(B)
+            h.sync()
+            dts1.append(bench_dist.max_over_ranks(dist, time.perf_counter() - t0, device=dev))
+        dt1 = float(np.median(dts1))
+        sol1 = h.download(B, want_y=False)
+        same1 = bool(np.array_equal(sol1.status, sol.status) and np.array_equal(sol1.u0, sol.u0))
+        h.set_pipeline(args.pipeline)
 
     # ... and the algorithm north_star names, run as such: the restated OSQP ADMM iteration at OSQP's own defaults (no polish,
     # no phase 1: mpmpc.stock_settings(), the general kernel) on the same resident batch - its own throughput figure
-    hs_ = mpmpc.Handle(cfg, mpmpc.stock_settings())
-    hs_.set_path(tr.kappa, tr.v_ref, tr.ds_next)
-    hs_.set_outputs(want_y=False)
-    hs_.upload(wp, x0, cc, lb, ub)
-    k_st = max(2, min(args.steps, 8))
-    for _ in range(2):
-        hs_.solve_resident(B)
-    dts_s = []
-    for _ in range(3):
-        hs_.sync()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(k_st):
+    admm_stock = None
+    if not args.no_extra_legs:
+        hs_ = mpmpc.Handle(cfg, mpmpc.stock_settings())
+        hs_.set_path(tr.kappa, tr.v_ref, tr.ds_next)
+        hs_.set_outputs(want_y=False)
+        hs_.upload(wp, x0, cc, lb, ub)
+        k_st = max(2, min(args.steps, 8))
+        for _ in range(2):
             hs_.solve_resident(B)
-        hs_.sync()
-        dts_s.append(bench_dist.max_over_ranks(dist, time.perf_counter() - t0, device=dev))
-    sol_s = hs_.download(B, want_y=False)
-    hs_.close()
-    admm_stock = {"value": world * B * k_st / float(np.median(dts_s)), "unit": "solves/s", "steps": int(k_st), "repeats": 3,
-                  "ms_per_step": 1e3 * float(np.median(dts_s)) / k_st,
-                  "admm_iters_mean": float(sol_s.iters[:, 0].mean()), "admm_iters_max": int(sol_s.iters[:, 0].max()),
-                  "status_counts": {int(a): int(b) for a, b in zip(*np.unique(sol_s.status, return_counts=True))},
-                  "kernel": "mpmpc_solve_kernel (general kernel, one instance per wave, Solver::admm)",
-                  "note": "the restated OSQP ADMM iteration at OSQP's defaults (eps 1e-3, rho adaptation, no polish, no phase 1: "
-                          "mpmpc.stock_settings()) on the same resident batch, launches pipelined like `value`; a launch ends with its "
-                          "slowest instance (max-iter instances: 4 000 iterations)"}
+        dts_s = []
+        for _ in range(3):
+            hs_.sync()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(k_st):
+                hs_.solve_resident(B)
+            hs_.sync()
+            dts_s.append(bench_dist.max_over_ranks(dist, time.perf_counter() - t0, device=dev))
+        sol_s = hs_.download(B, want_y=False)
+        hs_.close()
+        admm_stock = {"value": world * B * k_st / float(np.median(dts_s)), "unit": "solves/s", "steps": int(k_st), "repeats": 3,
+                      "ms_per_step": 1e3 * float(np.median(dts_s)) / k_st,
+                      "admm_iters_mean": float(sol_s.iters[:, 0].mean()), "admm_iters_max": int(sol_s.iters[:, 0].max()),
+                      "status_counts": {int(a): int(b) for a, b in zip(*np.unique(sol_s.status, return_counts=True))},
+                      "kernel": "mpmpc_solve_kernel (general kernel, one instance per wave, Solver::admm)",
+                      "note": "the restated OSQP ADMM iteration at OSQP's defaults (eps 1e-3, rho adaptation, no polish, no phase 1: "
+                              "mpmpc.stock_settings()) on the same resident batch, launches pipelined like `value`; a launch ends with its "
+                              "slowest instance (max-iter instances: 4 000 iterations)"}
 
     # Two batches in flight (reported beside `value`, never as it): a second handle - its own stream, its own copy of the batch -
     # and the K steps go to the two handles in turn, as a serving loop that double-buffers its batches would issue them.  The
@@ -664,6 +760,9 @@ def _main(real_stdout):
 
     gather_check = bench_dist.gather_check(dist, rank, sol.u0, sol.status, B * world, solve_whole, device=dev)
     ranks = bench_dist.rank_reports(dist, cfg.device, sol.status, device=dev)
+    # a multi-rank line is only printed for what --gpus promised: a process group of that many ranks, every
+    # rank on a device of its own - otherwise the run ends non-zero WITHOUT a line (a one-GPU figure must not pass for N GPUs)
+    check_ranks(args, dist, rank, world, ranks)
 
     if rank == 0:
         value = world * B * args.steps / dt
@@ -678,13 +777,15 @@ def _main(real_stdout):
             "value_from": "median of %d repeats of the timed region of exactly %d steps (max over ranks of every repeat)" % (repeats, args.steps),
             "barrier_ms": 1e3 * float(np.median(barrier_s)),
             "launches_in_flight": int(args.pipeline), "prewarm": int(n_prewarm), "prewarm_fixed": int(args.prewarm),
-            "value_one_launch_in_flight": world * B * args.steps / dt1,
-            "one_launch_in_flight": {"value": world * B * args.steps / dt1, "unit": "solves/s", "ms_per_step": 1e3 * dt1 / args.steps,
-                                     "repeats": repeats, "ms_per_step_min": 1e3 * float(min(dts1)) / args.steps,
-                                     "ms_per_step_max": 1e3 * float(max(dts1)) / args.steps, "same_answers": same1,
+            "value_200_step_regions": (world * B * 200 / dt200) if dt200 else world * B * args.steps / dt,
+            "ramp_drain_share": (1.0 - (world * B * args.steps / dt) / (world * B * 200 / dt200)) if dt200 else 0.0,
+            "value_one_launch_in_flight": (world * B * args.steps / dt1) if dt1 else None,
+            "one_launch_in_flight": {"value": (world * B * args.steps / dt1) if dt1 else None, "unit": "solves/s", "ms_per_step": (1e3 * dt1 / args.steps) if dt1 else None,
+                                     "repeats": repeats, "ms_per_step_min": (1e3 * float(min(dts1)) / args.steps) if dts1 else None,
+                                     "ms_per_step_max": (1e3 * float(max(dts1)) / args.steps) if dts1 else None, "same_answers": same1,
                                      "note": "mpmpc_set_pipeline(h, 1): every launch waits for the one before, as in a loop whose step "
                                              "k + 1 needs step k's control (src/simulation.py:134-140); same K, same repeats as `value`"},
-            "admm_stock_mode": admm_stock,
+            "admm_stock_mode": admm_stock if admm_stock is not None else {"value": None, "note": "skipped: --no-extra-legs"},
             "config": {"workload": "config%d: batch=%d independent poses per GPU, %s weights, N=%d, %s corridor; %s" %
                                    (args.config, B, sc_all.weights, N, "obstacle" if sc_all.obstacles else "free",
                                     algorithm_text(cfg, settings)),
@@ -861,6 +962,9 @@ def _main(real_stdout):
             out["status_agreement_pairings"] = {
                 "strict_device_vs_certified_port": float(np.mean(strict.status == ref["status"])),
                 "default_device_usable_vs_stock_osqp_port_usable": float(np.mean(((sol.status[:n2] == 1) | (sol.status[:n2] == 2)) == (ref_stock["status"][:n2] > 0))),
+                # ... and as a COUNT: the instances on the other branch, of how many
+                "default_device_vs_stock_osqp_port_disagreeing_instances": int(np.sum(((sol.status[:n2] == 1) | (sol.status[:n2] == 2)) != (ref_stock["status"][:n2] > 0))),
+                "default_device_vs_stock_osqp_port_disagreeing_of": int(n2),
                 "marginal_instances_status_2": int(np.sum(sol.status[:ns] == 2)), "sample": int(ns), "sample_stock": int(n2)}
             # whole plan (z without the cost-free kappa_{N-1} and e_psi_N) against the certified optimum
             keep = np.ones(5 * N + 3, bool)

@@ -217,23 +217,34 @@ class BatchMPC:
 
     # Everything that changes what a handle solves goes through these, so that the ring of get_control_stream never works on a
     # stale corridor or stale settings (a call on `self.handle` alone reaches only the first handle of the ring).
+    def _quiesce_stream(self):
+        """nothing of a stream may still be in flight on a handle whose settings, packing, tail kernel or corridor change: the
+        C side would settle the staged call (MPMPC_SETTLE) and a live get_control_stream generator would then yield fewer or
+        stale batches - what is in flight is waited for and dropped, the generator ends at its next step"""
+        if self._stream is not None:
+            self._stream.discard()
+
     def set_settings(self, settings):
+        self._quiesce_stream()
         self.settings = settings
         for h in self._handles():
             h.set_settings(settings)
 
     def set_packing(self, lanes_per_instance=0):
+        self._quiesce_stream()
         self._packing = lanes_per_instance
         for h in self._handles():
             h.set_packing(lanes_per_instance)
 
     def set_tail_kernel(self, reduced_native=True):
+        self._quiesce_stream()
         self._tail_kernel = reduced_native
         for h in self._handles():
             h.set_tail_kernel(reduced_native)
 
     def set_corridor(self, ub, lb):
         """a static corridor table [n_wp x >= N] for every handle of this controller"""
+        self._quiesce_stream()
         for h in self._handles():
             h.set_corridor(ub, lb)
         self._corridor_tables, self.corridor_cols = (ub, lb), None

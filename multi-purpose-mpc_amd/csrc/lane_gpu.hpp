@@ -437,11 +437,14 @@ struct LaneBlock {
   // chain_shift<NV, DIR, MODE>: the one-lane shift along the chains inside the wavefront (DPP, zero inflow).  MODE 1 (first
   // wavefront): its edge lane also leaves v - what the next lane of the chain would take - in LDS.  MODE 2 (second
   // wavefront): its edge lane takes that instead of the zero.  No barrier: the sweep places them.
-  template <int NV, int DIR, int MODE>
+  // OFF: first of the NV edge slots this shift uses.  A step of a staged sweep that shifts TWICE must give its shifts disjoint slot
+  // ranges - with the same range the second would overwrite what the first handed on before the other wavefront has read it
+  // (the sweeps of the solver shift once per step: OFF = 0).
+  template <int NV, int DIR, int MODE, int OFF = 0>
   static __device__ __forceinline__ void chain_shift(const double* v, double* o) {
-    static_assert(G == 256 && NV <= xrows && (MODE == 1 || MODE == 2), "staged sweeps: chains of two wavefronts");
+    static_assert(G == 256 && OFF >= 0 && OFF + NV <= xrows && (MODE == 1 || MODE == 2), "staged sweeps: chains of two wavefronts, edge slots within a chain's row");
     const int lane = threadIdx.x & 63, chain = threadIdx.x >> 7;
-    double* e = erow() + chain * xrows;
+    double* e = erow() + chain * xrows + OFF;
 #pragma unroll
     for (int i = 0; i < NV; ++i) o[i] = DIR < 0 ? dpp_shift<DPP_WAVE_SHR1>(v[i]) : dpp_shift<DPP_WAVE_SHL1>(v[i]);
     const bool edge_out = DIR < 0 ? lane == 63 : lane == 0, edge_in = DIR < 0 ? lane == 0 : lane == 63;

@@ -21,6 +21,7 @@
 // No CPU path exists in this library: every compute entry point needs a HIP device.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1419,13 +1420,17 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
     if (tail_only) return MPMPC_OK;
     h->pend = h->pend2 = false;
     const SolverParams prm = make_params(h->st);
+    constexpr int MAX_DEVICES = 64;
+    const int dev_slot = h->cfg.device >= 0 && h->cfg.device < MAX_DEVICES ? h->cfg.device : 0;
 #define LAUNCH_BLOCK(GG, VV)                                                                                                          \
   do {                                                                                                                                \
-    static bool attr_set = false;                                                                                                     \
-    if (!attr_set) {                                                                                                                  \
+    /* (per DEVICE: one process may drive several - sharded.py, bench.py --single-process - and the attribute belongs to the   \
+       function on the device that is current; two threads may both set it once - the call is idempotent) */                                                                          \
+    static std::atomic<bool> attr_set[MAX_DEVICES];                                                                                           \
+    if (!attr_set[dev_slot]) {                                                                                                        \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpmpc_solve_block_kernel<GG, VV>),                                  \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LaneBlock<GG>::lds_bytes));                        \
-      attr_set = true;                                                                                                                \
+      attr_set[dev_slot] = true;                                                                                                      \
     }                                                                                                                                 \
     hipLaunchKernelGGL((mpmpc_solve_block_kernel<GG, VV>), dim3(B), dim3(GG), LaneBlock<GG>::lds_bytes, h->stream, h->cfg, prm, B, \
                        ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, tail_blk);                                             \
@@ -1433,11 +1438,11 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
 #define LAUNCH_RBLOCK(GG)                                                                                                             \
   do {                                                                                                                                \
     using LB_ = LaneBlock<GG, RNB_SLOTS>;                                                                                             \
-    static bool attr_set = false;                                                                                                     \
-    if (!attr_set) {                                                                                                                  \
+    static std::atomic<bool> attr_set[MAX_DEVICES];                                                                                           \
+    if (!attr_set[dev_slot]) {                                                                                                        \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpmpc_reduced_block_kernel<GG>),                                    \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LB_::lds_bytes));                                 \
-      attr_set = true;                                                                                                                \
+      attr_set[dev_slot] = true;                                                                                                      \
     }                                                                                                                                 \
     hipLaunchKernelGGL((mpmpc_reduced_block_kernel<GG>), dim3(B), dim3(GG), LB_::lds_bytes, h->stream, h->cfg, prm, B,             \
                        ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, h->tail);                                              \

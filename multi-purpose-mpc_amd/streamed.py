@@ -116,13 +116,21 @@ class StreamedBatches:
         return out
 
     def discard(self):
-        """wait for every batch still in flight and drop its results (a consumer that left a stream early)"""
+        """wait for every batch still in flight and drop its results (a consumer that left a stream early).  EVERY slot is
+        drained even if one of them fails - the first error is raised once the ring is empty and back at its first handle, so
+        that the next submit never meets a slot that is still marked busy."""
+        first_error = None
         while self._order:
             i = self._order.popleft()
             try:
                 self.handles[i].staged_end()
+            except Exception as exc:          # noqa: BLE001 - kept, raised below
+                first_error = first_error or exc
             finally:
                 self._busy[i] = None
+        self._next = 0
+        if first_error is not None:
+            raise first_error
 
     def map(self, batches, want_z=True, want_y=False):
         """generator: Solutions of `batches` (tuples wp_id, x0, cc_prev[, lb, ub]) in order, `depth` of them in flight.

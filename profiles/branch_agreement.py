@@ -15,30 +15,10 @@ import numpy as np  # noqa: E402
 
 import mpmpc  # noqa: E402
 import mpmpc_testlib as T  # noqa: E402
-import oracle_c as OC  # noqa: E402
 import scenarios  # noqa: E402
 
 
-def compare(cfgid, B, settings=None):
-    """-> dict(agreement, rows): rows = (instance, device status, device violation, stock status, stock iterations, stock pri_res)"""
-    track = scenarios.sim_track()
-    sc = scenarios.make(cfgid, track, B=B)
-    cfg = T.stock_config(sc.N, sc.weights, max_batch=B)
-    st = settings or mpmpc.default_settings()
-    h = mpmpc.Handle(cfg, st)
-    h.set_path(track.kappa, track.v_ref, track.ds_next)
-    sol = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
-    h.close()
-    ocfg = OC.mpc_cfg(sc.N, scenarios.WEIGHTS[sc.weights], scenarios.UMIN, scenarios.UMAX, scenarios.XMIN, scenarios.XMAX, 4.0, 0.12)
-    stock = OC.mpc_batch(ocfg, OC.settings(polish=0, early_polish=0, phase1=0), track.kappa, track.v_ref, track.ds_next, sc.wp_id,
-                         sc.x0, sc.cc_prev, sc.lb, sc.ub)
-    usable = lambda s: np.isin(s, (1, 2, -2))
-    dis = np.flatnonzero(usable(sol.status) != usable(stock["status"]))
-    rows = [(int(i), int(sol.status[i]), float(sol.resid[i, 0]), int(stock["status"][i]), int(stock["iters"][i, 0]), float(stock["resid"][i, 0]))
-            for i in dis]
-    return dict(agreement=1.0 - dis.size / B, rows=rows, device=dict(zip(*map(lambda a: a.tolist(), np.unique(sol.status, return_counts=True)))),
-                stock=dict(zip(*map(lambda a: a.tolist(), np.unique(stock["status"], return_counts=True)))), B=B,
-                threshold=1e-3 + 1e-3 * float(scenarios.UMAX[1]))
+compare = T.branch_compare          # (tests/mpmpc_testlib.py: the GPU test pins what this script prints)
 
 
 if __name__ == "__main__":

@@ -17,7 +17,7 @@ python bench.py --batch 65536 --steps 5 --warmup 1 --no-cpu > "$O/bench_cfg2_b65
 cd /tmp; export TMPDIR=/tmp
 # (counter passes serialise the kernels and are slow per launch: few repeats, short clock ramp)
 PMC="--repeats 2 --prewarm 30"
-prof() { out=$1; shift; rocprofv3 "$@" --output-format csv -d "$O/$out" -- python3 "$R/bench.py" ${BENCH_ARGS:-} --no-cpu > "$O/$out.json" 2>/dev/null; }
+prof() { out=$1; shift; rocprofv3 "$@" --output-format csv -d "$O/$out" -- python3 "$R/bench.py" ${BENCH_ARGS:-} --no-cpu --no-extra-legs > "$O/$out.json" 2>/dev/null; }
 BENCH_ARGS="" prof trace --kernel-trace --stats
 # ... and of the driver's own command (20-step regions)
 BENCH_ARGS="--gpus 1 --steps 20 --warmup 5" prof trace_driver --kernel-trace --stats

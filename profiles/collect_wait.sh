@@ -13,7 +13,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 cd /tmp; export TMPDIR=/tmp
-prof() { out=$1; shift; rocprofv3 "$@" --output-format csv -d "$O/$out" -- python3 "$R/bench.py" ${BENCH_ARGS:-} --no-cpu > "$O/$out.json" 2>"$O/$out.err"; }
+prof() { out=$1; shift; rocprofv3 "$@" --output-format csv -d "$O/$out" -- python3 "$R/bench.py" ${BENCH_ARGS:-} --no-cpu --no-extra-legs > "$O/$out.json" 2>"$O/$out.err"; }
 G_WAIT="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM"
 G_FETCH="SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC"
 G_ICACHE="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE"

@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "multi-purpose-mpc_amd")
-for p in (PKG, os.path.join(ROOT, "oracle"), ROOT):
+for p in (PKG, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "bench_support"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -204,117 +204,9 @@ def farkas_batch(qp, N, y, eps=1e-6):
     return ok, support, aty
 
 
-class Emul:
-    """ctypes view of tests/_build/libmpmpc_emul.so (CPU lock-step emulation of the kernels)."""
-
-    def __init__(self):
-        so = os.path.join(ROOT, "tests", "_build", "libmpmpc_emul.so")
-        subprocess.run(["make", "-s", "-j4", "-C", os.path.join(ROOT, "tests", "emul")], check=True)
-        self.lib = C.CDLL(so)
-        self._wide = {}
-
-    def wide(self, width):
-        """the general solver on an emulated WORKGROUP of 128 / 256 lanes (horizons 64 .. 255: tests/emul/emul_wide.cpp)"""
-        if width not in self._wide:
-            self._wide[width] = C.CDLL(os.path.join(ROOT, "tests", "_build", "libmpmpc_emul_w%d.so" % width))
-            assert self._wide[width].emuw_width() == width
-        return self._wide[width]
-
-    def assemble(self, cfg, track, inputs, use_table=False, obstacles=False):
-        wp, x0, cc, lb, ub = inputs
-        B = wp.size
-        N = cfg.N
-        ld = mpmpc.stage_ld(N)
-        qp = np.zeros((mpmpc.NUM_FIELDS, B, ld))
-        k, v, d = (np.ascontiguousarray(a, float) for a in (track.kappa, track.v_ref, track.ds_next))
-        ubT = np.ascontiguousarray(track.ub_obstacles if obstacles else track.ub_free)
-        lbT = np.ascontiguousarray(track.lb_obstacles if obstacles else track.lb_free)
-        wp = np.ascontiguousarray(wp, np.int32)
-        x0 = np.ascontiguousarray(x0, float)
-        cc = np.ascontiguousarray(cc, float)
-        lbp = None if use_table else np.ascontiguousarray(lb, float)
-        ubp = None if use_table else np.ascontiguousarray(ub, float)
-        rc = self.lib.emu_assemble(C.byref(cfg), C.c_int(k.size), _d(k), _d(v), _d(d), C.c_int(ubT.shape[1]),
-                                   _d(ubT), _d(lbT), C.c_int(B), _i(wp), _d(x0), _d(cc), _d(lbp), _d(ubp), _d(qp))
-        assert rc == 0
-        return qp
-
-    def solve(self, cfg, settings, qp, G=64, want_y=True):
-        B = qp.shape[1]
-        N = cfg.N
-        n, m = 5 * N + 3, 8 * N + 6
-        z, u0 = np.zeros((B, n)), np.zeros((B, 2))
-        st, it, rs = np.zeros(B, np.int32), np.zeros((B, 2), np.int32), np.zeros((B, 2))
-        y = np.zeros((B, m)) if want_y else None
-        qp = np.ascontiguousarray(qp)
-        if 64 < N + 1 <= 128 and G != 128 and self.lib.emu_reduced_native(C.byref(cfg), C.byref(settings)):
-            # the launcher's sequence at horizons 64 .. 127: the reduced-native kernel with TWO stages per lane in one
-            # wavefront, then the workgroup kernel (mode 2) on what it lists (G = 128: the workgroup kernels alone, as
-            # mpmpc_set_packing(h, 128))
-            yy = y if want_y else np.zeros((B, m))
-            nt = C.c_int(0)
-            rc = self.lib.emu_solve_rn(C.byref(cfg), C.byref(settings), C.c_int(64), _d(qp), C.c_int(B), _d(z), _d(u0), _i(st), _i(it),
-                                       _d(rs), _d(yy), C.byref(nt))
-            assert rc == 0
-            ids = np.ascontiguousarray(np.flatnonzero(st == -10), np.int32)          # MPMPC_UNSOLVED
-            assert ids.size == nt.value
-            rc = self.wide(128).emuw_solve_tail(C.byref(cfg), C.byref(settings), _d(qp), C.c_int(B), _d(z), _d(u0), _i(st), _i(it),
-                                                _d(rs), _d(yy), _i(ids), C.c_int(ids.size))
-            assert rc == 0
-            return mpmpc.Solution(z, u0, st, it, rs, y)
-        if N + 1 > 64:        # one instance per workgroup of 2 / 4 wavefronts on the device: the wide emulation
-            yy = y if want_y else np.zeros((B, m))
-            rc = self.wide(mpmpc.stage_ld(N)).emuw_solve(C.byref(cfg), C.byref(settings), _d(qp), C.c_int(B), _d(z), _d(u0), _i(st), _i(it),
-                                                         _d(rs), _d(yy))
-            assert rc == 0
-            return mpmpc.Solution(z, u0, st, it, rs, y)
-        rc = self.lib.emu_solve(C.byref(cfg), C.byref(settings), C.c_int(G), _d(qp), C.c_int(B), _d(z), _d(u0),
-                                _i(st), _i(it), _d(rs), _d(y))
-        assert rc == 0
-        return mpmpc.Solution(z, u0, st, it, rs, y)
-
-    def solve_launch(self, cfg, settings, qp, G=64):
-        """what the launcher does: a packed batch (G < 64) runs its early pass packed and its tail one per wave.
-        -> (Solution, number of instances handed to the second launch)"""
-        B = qp.shape[1]
-        N = cfg.N
-        n, m = 5 * N + 3, 8 * N + 6
-        z, u0, y = np.zeros((B, n)), np.zeros((B, 2)), np.zeros((B, m))
-        st, it, rs = np.zeros(B, np.int32), np.zeros((B, 2), np.int32), np.zeros((B, 2))
-        nt = C.c_int(0)
-        rc = self.lib.emu_solve_launch(C.byref(cfg), C.byref(settings), C.c_int(G), _d(np.ascontiguousarray(qp)), C.c_int(B),
-                                       _d(z), _d(u0), _i(st), _i(it), _d(rs), _d(y), C.byref(nt))
-        assert rc == 0
-        return mpmpc.Solution(z, u0, st, it, rs, y), nt.value
-
-    def solve_rn(self, cfg, settings, qp, G=64, sequential=False):
-        """the reduced-native kernel alone (no tail launch); sequential = True: the same kernel with the chain-sequential
-        factorisation in place of the cyclic reduction (Solver<..., CR = false>).  -> (Solution, instances left unsolved)"""
-        B = qp.shape[1]
-        N = cfg.N
-        n, m = 5 * N + 3, 8 * N + 6
-        z, u0, y = np.zeros((B, n)), np.zeros((B, 2)), np.zeros((B, m))
-        st, it, rs = np.zeros(B, np.int32), np.zeros((B, 2), np.int32), np.zeros((B, 2))
-        nt = C.c_int(0)
-        fn = self.lib.emu_solve_rn_sequential if sequential else self.lib.emu_solve_rn
-        rc = fn(C.byref(cfg), C.byref(settings), C.c_int(G), _d(np.ascontiguousarray(qp)), C.c_int(B), _d(z), _d(u0), _i(st), _i(it),
-                _d(rs), _d(y), C.byref(nt))
-        assert rc == 0
-        return mpmpc.Solution(z, u0, st, it, rs, y), nt.value
-
-    def solve_warm(self, cfg, settings, qp, guess, G=64):
-        """closed-loop variant: start from the active sets `guess` [B, ld]; -> (Solution, act [B, ld])"""
-        B = qp.shape[1]
-        N = cfg.N
-        n, m = 5 * N + 3, 8 * N + 6
-        z, u0, y = np.zeros((B, n)), np.zeros((B, 2)), np.zeros((B, m))
-        st, it, rs = np.zeros(B, np.int32), np.zeros((B, 2), np.int32), np.zeros((B, 2))
-        act = np.zeros((B, mpmpc.stage_ld(N)), np.int32)
-        guess = np.ascontiguousarray(guess, np.int32)
-        rc = self.lib.emu_solve_warm(C.byref(cfg), C.byref(settings), C.c_int(G), _d(np.ascontiguousarray(qp)), C.c_int(B),
-                                     _i(guess), _d(z), _d(u0), _i(st), _i(it), _d(rs), _d(y), _i(act))
-        assert rc == 0
-        return mpmpc.Solution(z, u0, st, it, rs, y), act
+# (the ctypes view of the kernels' CPU emulation and the handle stand-ins built on it live in bench_support/emulation.py:
+#  bench.py --dry-run drives them too, and a benchmark script does not import from tests/)
+from emulation import Emul, EmuBackend, DryHandle  # noqa: E402,F401
 
 
 _WIDE_TRACKS = {}
@@ -362,71 +254,6 @@ def emu_speed_profile(li, kappa, limits, eps=1e-12, device=0):
                                           C.byref(it))
         iters[p] = it.value
     return v, status, iters
-
-
-class EmuBackend:
-    """Drop-in for mpmpc.Handle in host-logic tests: same set_path / solve surface, kernels run in
-    the CPU lock-step emulation.  Test infrastructure only."""
-
-    class _T:
-        pass
-
-    def __init__(self, cfg, settings, emu=None):
-        self.cfg, self.settings = cfg, settings
-        self.emu = emu or Emul()
-        self.t = EmuBackend._T()
-        z = np.zeros((2, max(cfg.N, 1)))
-        self.t.ub_free = self.t.lb_free = self.t.ub_obstacles = self.t.lb_obstacles = z
-
-    def set_path(self, kappa, v_ref, ds_next):
-        self.t.kappa, self.t.v_ref, self.t.ds_next = (np.ascontiguousarray(a, float) for a in (kappa, v_ref, ds_next))
-
-    def solve(self, wp_id, x0, cc_prev, lb=None, ub=None, want_y=False):
-        qp = self.emu.assemble(self.cfg, self.t, (np.asarray(wp_id, np.int32), x0, cc_prev, lb, ub))
-        return self.emu.solve(self.cfg, self.settings, qp, G=64, want_y=want_y)
-
-
-class DryHandle(EmuBackend):
-    """The RESIDENT surface of mpmpc.Handle (upload / solve_resident / sync / download, set_pipeline / set_outputs / set_packing)
-    on the CPU emulation: what `bench.py --dry-run` drives when it rehearses the multi-rank plumbing on a box without GPUs.
-    A resident launch is emulated when its results are asked for (download); the launches of a timed loop cost nothing."""
-
-    class _Lib:
-        @staticmethod
-        def mpmpc_version():
-            return b"mpmpc DRY RUN (CPU emulation of the kernels, tests/emul)"
-
-    def __init__(self, cfg, settings, emu=None):
-        super().__init__(cfg, settings, emu)
-        self.lib = DryHandle._Lib()
-        self.pipeline, self.uploaded, self.launches, self._sol = 3, None, 0, None
-
-    def set_packing(self, lanes_per_instance=0):
-        pass
-
-    def set_outputs(self, want_y=True):
-        pass
-
-    def set_pipeline(self, depth=3):
-        self.pipeline = int(depth)
-
-    def upload(self, wp_id, x0, cc_prev, lb=None, ub=None):
-        self.uploaded, self._sol = (np.asarray(wp_id, np.int32), x0, cc_prev, lb, ub), None
-
-    def solve_resident(self, B):
-        assert self.uploaded is not None and B <= self.uploaded[0].size
-        self.launches += 1
-
-    def sync(self):
-        pass
-
-    def download(self, B, want_y=False):
-        if self._sol is None:
-            self._sol = self.solve(*self.uploaded, want_y=want_y)
-        return self._sol
-
-    def close(self):
-        pass
 
 
 # ---- the independent leg (oracle/independent.py, golden G8): nothing below shares code with the device algorithm
@@ -485,3 +312,32 @@ def relaxed_plan_check(qp_i, N, z, y, viol):
     kkt = I.kkt_residuals(Pd, q, A, lr, ur, z, y)
     uq = I.uniqueness_certificate(Pd, A, lr, ur, z, y, keep)
     return dict(kkt=max(kkt), unique=bool(uq["unique"]), relaxation=relax, ratio=relax / viol if viol > 0 else np.inf)
+
+
+def branch_compare(cfgid, B, settings=None):
+    """Which branch of src/MPC.py:185-216 does get_control take - a fresh plan or the fallback - with the device's settings,
+    against the restated stock OSQP (the C oracle at OSQP's defaults: the arithmetic of the reference's own solver call,
+    src/MPC.py:159,183)?  Needs a device.  -> dict(agreement, rows, ...): rows = (instance, device status, device violation,
+    stock status, stock iterations, stock pri_res) of every instance on which the two disagree.  (profiles/branch_agreement.py
+    prints it; tests/test_gpu_parity.py pins size, direction and cause.)"""
+    import oracle_c as OC
+    track = scenarios.sim_track()
+    sc = scenarios.make(cfgid, track, B=B)
+    cfg = stock_config(sc.N, sc.weights, max_batch=B)
+    st = settings or mpmpc.default_settings()
+    h = mpmpc.Handle(cfg, st)
+    h.set_path(track.kappa, track.v_ref, track.ds_next)
+    sol = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    h.close()
+    ocfg = OC.mpc_cfg(sc.N, scenarios.WEIGHTS[sc.weights], scenarios.UMIN, scenarios.UMAX, scenarios.XMIN, scenarios.XMAX, 4.0, 0.12)
+    stock = OC.mpc_batch(ocfg, OC.settings(polish=0, early_polish=0, phase1=0), track.kappa, track.v_ref, track.ds_next, sc.wp_id,
+                         sc.x0, sc.cc_prev, sc.lb, sc.ub)
+
+    def usable(s):
+        return np.isin(s, (1, 2, -2))
+    dis = np.flatnonzero(usable(sol.status) != usable(stock["status"]))
+    rows = [(int(i), int(sol.status[i]), float(sol.resid[i, 0]), int(stock["status"][i]), int(stock["iters"][i, 0]), float(stock["resid"][i, 0]))
+            for i in dis]
+    return dict(agreement=1.0 - dis.size / B, rows=rows, device=dict(zip(*map(lambda a: a.tolist(), np.unique(sol.status, return_counts=True)))),
+                stock=dict(zip(*map(lambda a: a.tolist(), np.unique(stock["status"], return_counts=True)))), B=B,
+                threshold=1e-3 + 1e-3 * float(scenarios.UMAX[1]))

@@ -137,3 +137,22 @@ def test_bench_launcher_rehearsal_with_eight_ranks():
     assert sum(x["solved"] + x["solved_inaccurate"] + x["infeasible"] + x["other"] for x in d["ranks"]) == 24
     assert d["gather_check"]["instances"] == 24 and d["gather_check"]["status_equal"] is True and d["gather_check"]["max_abs_u_diff"] == 0.0
     assert len(d["ms_per_step_by_rank_emulated"]) == 8 and d["config"]["batch_per_gpu"] == 3
+
+
+@pytest.mark.skipif(mpmpc.device_count() > 0, reason="the rehearsal is for boxes without GPUs")
+def test_bench_single_process_rehearsal_with_eight_handles():
+    """the torch-free second path of the 8-GPU run - `bench.py --gpus 8 --single-process` - rehearsed with
+    eight emulation handles: the line has the torchrun line's schema (ranks with device ordinals and status counts, the
+    one-launch-in-flight point, the gather check) and every handle sits on a device of its own."""
+    import json
+    r = _run_bench(["--gpus", "8", "--single-process", "--dry-run", "--config", "5", "--batch", "5", "--steps", "2", "--warmup", "1",
+                    "--repeats", "1"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["value"] is None and d["n_gpus"] == 8 and d["rccl_world_size"] == 0
+    assert d["devices"] == list(range(8)) and [x["device"] for x in d["ranks"]] == list(range(8))
+    assert sum(x["solved"] + x["solved_inaccurate"] + x["infeasible"] + x["other"] for x in d["ranks"]) == 40
+    assert d["gather_check"] == {"same_status": True, "same_u0": True, "instances": 40}
+    assert "value_one_launch_in_flight" in d and "one_launch_in_flight" in d and d["config"]["batch_per_gpu"] == 5

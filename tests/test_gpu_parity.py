@@ -388,10 +388,7 @@ def test_default_branch_agreement_with_restated_stock_osqp_on_the_batch_configs(
     DIRECTION and CAUSE: at most 8 instances, every one refused by the device and accepted by OSQP, and every one either
     abandoned by OSQP at max_iter (it then returns its iterate, "solved inaccurate": nothing but its 4 000 iterations can know
     that) or within 0.5 % of OSQP's primal tolerance (OSQP stops an iterate short of its limit point).  Round 4: 28 / 24."""
-    import sys
-    sys.path.insert(0, T.ROOT + "/profiles")
-    import branch_agreement
-    r = branch_agreement.compare(cfgid, 8192)
+    r = T.branch_compare(cfgid, 8192)
     assert r["agreement"] >= 0.999 and len(r["rows"]) <= 8, r
     for i, dev_status, dev_viol, st_status, st_iters, st_pri in r["rows"]:
         assert dev_status == mpmpc.PRIMAL_INFEASIBLE and st_status in (1, 2), (i, dev_status, st_status)

@@ -69,6 +69,33 @@ def test_sharded_handles_on_one_device_match_one_handle(cfgid, B, world, track):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,weights", [(70, "stock"), (150, "stock"), (70, "time_optimal")])
+def test_sharded_handles_at_long_horizons(N, weights, track, emu):
+    """several handles of one process at horizons above 63 - the kernels there need a dynamic-LDS attribute that is
+    set once per function AND DEVICE (it used to be once per process).  Two handles on device 0 (the box has one GPU; the
+    per-device bookkeeping is what an 8-GPU node exercises) against one handle: the pair kernel (N = 70, stock weights), the
+    256-lane workgroup kernels (N = 150) and the general workgroup kernel (time-optimal weights)."""
+    B = 96
+    tw = T.wide_track(track, emu, N)
+    sc = scenarios.make(4, tw, B=B, N=N)
+    sc.weights = weights
+
+    def handle(n):
+        h = mpmpc.Handle(T.stock_config(N, weights, max_batch=n), mpmpc.default_settings())
+        h.set_path(track.kappa, track.v_ref, track.ds_next)
+        return h
+    one = handle(B)
+    ref = one.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    one.close()
+    sh = sharded.ShardedHandles([handle(B // 2), handle(B // 2)])
+    got = sh.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub)
+    sh.close()
+    assert np.array_equal(got.status, ref.status) and np.array_equal(got.iters, ref.iters)
+    ok = ref.status == 1
+    assert ok.sum() >= B // 2 and np.array_equal(got.u0[ok], ref.u0[ok]) and np.array_equal(got.z[ok], ref.z[ok])
+
+
+@pytest.mark.gpu
 def test_sharded_batch_mpc_is_batch_mpc():
     """the class with the reference's constructor arguments, two handles on device 0, against BatchMPC"""
     import test_host_mpc as H

@@ -124,6 +124,32 @@ def test_abandoned_stream_leaves_nothing_in_flight(emu, track):
     assert np.array_equal(sb.drain()[0].z, ref[3].z)
 
 
+def test_discard_drains_every_slot_when_one_of_them_fails(emu, track):
+    """a staged_end that raises inside discard() must not leave the other slots marked busy - all are drained, the
+    first error surfaces once, and the ring starts again at its first handle."""
+    B, depth = 4, 3
+    batches, sc = _batches(track, 6, B)
+    cfg = T.stock_config(sc.N, sc.weights, max_batch=B)
+    st = mpmpc.default_settings()
+    hs = [_EmuStagedHandle(emu, cfg, st, track) for _ in range(depth)]
+    sb = streamed.StreamedBatches(handles=hs)
+    for b in batches[:depth]:
+        assert sb.submit(*b) is None
+    good_end = hs[1].staged_end
+
+    def failing_end():
+        hs[1].pending = None
+        raise mpmpc.MpmpcError("device error (injected)")
+    hs[1].staged_end = failing_end
+    with pytest.raises(mpmpc.MpmpcError):
+        sb.discard()
+    assert not sb._order and all(b is None for b in sb._busy) and all(h.pending is None for h in hs) and sb._next == 0
+    hs[1].staged_end = good_end
+    ref = [emu.solve_launch(cfg, st, emu.assemble(cfg, track, b), G=64)[0] for b in batches]
+    got = list(sb.map(batches))
+    assert len(got) == len(batches) and all(np.array_equal(g.z, r.z) for g, r in zip(got, ref))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("depth", [1, 3])
 def test_streamed_batches_on_device_match_the_single_call(depth, track):
