@@ -74,10 +74,11 @@ class Emul:
         st, it, rs = np.zeros(B, np.int32), np.zeros((B, 2), np.int32), np.zeros((B, 2))
         y = np.zeros((B, m)) if want_y else None
         qp = np.ascontiguousarray(qp)
-        if 64 < N + 1 <= 128 and G != 128 and self.lib.emu_reduced_native(C.byref(cfg), C.byref(settings)):
-            # the launcher's sequence at horizons 64 .. 127: the reduced-native kernel with TWO stages per lane in one
-            # wavefront, then the workgroup kernel (mode 2) on what it lists (G = 128: the workgroup kernels alone, as
-            # mpmpc_set_packing(h, 128))
+        if 64 < N + 1 <= 128 and G != 128 and (self.lib.emu_reduced_native(C.byref(cfg), C.byref(settings)) or
+                                               self.lib.emu_reduced_native_tt(C.byref(cfg), C.byref(settings))):
+            # the launcher's sequence at horizons 64 .. 127: the reduced-native kernel (or its terminal-time twin) with TWO stages
+            # per lane in one wavefront, then the workgroup kernel (mode 2) on what it lists (G = 128: the workgroup kernels
+            # alone, as mpmpc_set_packing(h, 128))
             yy = y if want_y else np.zeros((B, m))
             nt = C.c_int(0)
             rc = self.lib.emu_solve_rn(C.byref(cfg), C.byref(settings), C.c_int(64), _d(qp), C.c_int(B), _d(z), _d(u0), _i(st), _i(it),

@@ -305,6 +305,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   }
 }
 
+// K2t2: K2t with two stages per lane, for horizons 64 .. 127 - ONE wavefront per instance where such weights used to run the
+// general 3-state solver on a workgroup of two (mpmpc_solve_block_kernel<128, 0>); 502 registers, no scratch.
+template <int GB>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void mpmpc_reduced_t_pair_kernel(mpmpc_config cfg, SolverParams st, int B, AssembleIn ain,
+                                                           double* __restrict__ z, double* __restrict__ u0,
+                                                           int* __restrict__ status, int* __restrict__ iters,
+                                                           double* __restrict__ resid, double* __restrict__ y,
+                                                           int* __restrict__ tail) {
+  using L = LanePair<LaneGpu<GB, GB, RN2_SLOTS>>;
+  const I2 inst = L::slot() + (int)(blockIdx.x * L::per_wave);
+  const I2 k = L::stage();
+  D2 fields[MPMPC_NUM_FIELDS];
+  assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
+  ReducedTSolver<L> s;
+  s.run(fields, B, inst, k, cfg.N, st, cfg.QN[2]);
+  const I2 inst_o = L::slot_again() + (int)(blockIdx.x * L::per_wave);
+  const I2 k_o = L::stage_again();
+  s.store(inst_o, k_o, cfg.wheelbase, z, u0, status, iters, resid, y);
+  if (k_o.v[0] == 0 && inst_o.v[0] < B && s.status.v[0] == MPMPC_UNSOLVED) tail[1 + atomicAdd(tail, 1)] = inst_o.v[0];
+}
+
 // K2t: the reduced-native kernel of the weightings with a TERMINAL cost on the time state (mpmpc_reduced_t.hpp; BASELINE
 // config 3): the (e_y, e_psi, kappa) problem plus the speeds plus one rank-one term, Sherman-Morrison on the 2 x 2-block
 // solves.  Same launch contract as K2r (cold starts only: a warm-started closed loop of such weights starts cold here).
@@ -1463,6 +1484,13 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
                            h->iters, h->resid, y_out, h->tail, spare, h->tail_flag, h->seq, spare + ((size_t)h->cfg.max_batch + 1));
       } else if (N + 1 <= 128) LAUNCH_RBLOCK(128);
       else LAUNCH_RBLOCK(256);
+      tail_blk = h->tail;
+    } else if (!fullqn && reduced_native_tt(h->cfg, h->st) && N + 1 <= 128 && h->force_lanes != 128) {
+      // a terminal cost on the time state at 65 .. 128 stages: K2t with two stages per lane (one wavefront per instance), the
+      // general workgroup kernel on what it lists
+      HIP_TRY(hipMemsetAsync(h->tail, 0, sizeof(int), h->stream));
+      hipLaunchKernelGGL(mpmpc_reduced_t_pair_kernel<64>, dim3(B), dim3(64), 0, h->stream, h->cfg, prm, B, ain, h->z, h->u0, h->status,
+                         h->iters, h->resid, y_out, h->tail);
       tail_blk = h->tail;
     }
     if (N + 1 <= 128) { if (fullqn) LAUNCH_BLOCK(128, 1); else if (redb) LAUNCH_BLOCK(128, 2); else LAUNCH_BLOCK(128, 0); }

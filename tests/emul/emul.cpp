@@ -125,6 +125,24 @@ static void solve_rnt(const mpmpc_config* cfg, const mpmpc_settings* st, const d
       if (k.v[i] == 0 && inst.v[i] < B && s.status.v[i] == MPMPC_UNSOLVED) tail[1 + tail[0]++] = inst.v[i];
   }
 }
+// ... with two stages per lane: horizons 64 .. 127 in one emulated wavefront (mpmpc_reduced_t_pair_kernel<64>)
+template <int GB>
+static void solve_rnt2(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
+                       int* status, int* iters, double* resid, double* y, int* tail) {
+  using L = LanePair<LaneEmu<GB, GB>>;
+  const int ld = stage_ld(cfg->N);
+  for (int w = 0; w < B; ++w) {
+    const I2 inst = L::slot() + w;
+    const I2 k = L::stage();
+    ReducedTSolver<L> s;
+    typename L::real fields[MPMPC_NUM_FIELDS];
+    ReducedTSolver<L>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    s.run(fields, B, inst, k, cfg->N, make_params(*st), cfg->QN[2]);
+    s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y);
+    for (int i = 0; i < EMU_W; ++i)
+      if (k.v[0].v[i] == 0 && inst.v[0].v[i] < B && s.status.v[0].v[i] == MPMPC_UNSOLVED) tail[1 + tail[0]++] = inst.v[0].v[i];
+  }
+}
 // mpmpc_reduced_tail_kernel: the reduced-native tail solver on the instances listed in tail; what it leaves UNSOLVED is
 // appended to tail2[1..]
 static int g_emu_lean_tail = 1;          // emu_set_lean_tail, like mpmpc_set_tail_kernel: 0 = the general kernel takes the whole
@@ -164,6 +182,7 @@ static int solve_rnt_g(int G, const mpmpc_config* cfg, const mpmpc_settings* st,
   const int C = lane_split(64, cfg->N);
   // (one instance per wave whatever packing the caller asked for: the launcher does the same)
   (void)G;
+  if (cfg->N + 1 > 64) { if (cfg->N + 1 > 128) return -1; solve_rnt2<64>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail); return 0; }
   if (C == 16 && lane_split(64, cfg->N) == 16) solve_rnt<64, 16>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
   else solve_rnt<64, 32>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail);
   return 0;
@@ -246,7 +265,7 @@ extern "C" int emu_solve_launch(const mpmpc_config* cfg, const mpmpc_settings* s
 // the reduced-native kernel alone: what it cannot certify stays UNSOLVED and is counted in *n_tail
 extern "C" int emu_solve_rn(const mpmpc_config* cfg, const mpmpc_settings* st, int G, const double* qp, int B,
                             double* z, double* u0, int* status, int* iters, double* resid, double* y, int* n_tail) {
-  if (cfg->N + 1 > G && !((G == 16 || G == 64) && cfg->N + 1 <= 2 * G && reducible(*cfg, *st))) return -1;
+  if (cfg->N + 1 > G && !((G == 16 || G == 64) && cfg->N + 1 <= 2 * G && (reducible(*cfg, *st) || (G == 64 && reducible_tt(*cfg, *st))))) return -1;
   std::vector<int> tail(B + 1, 0);
   if (reducible_tt(*cfg, *st)) {
     if (solve_rnt_g(G, cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data())) return -1;

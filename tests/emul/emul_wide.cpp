@@ -71,11 +71,11 @@ static void solve_wide_native(const mpmpc_config* cfg, const mpmpc_settings* st,
   }
 }
 
-// the tail alone: mpmpc_solve_block_kernel<G, 2> on the listed instances (mode 2: phase 1 and the full iteration) - what follows
-// the reduced-native kernel with two stages per lane (horizons 64 .. 127 in one wavefront: emul.cpp, solve_rn2<64>)
-extern "C" int emuw_solve_tail(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
-                               int* status, int* iters, double* resid, double* y, const int* ids, int n_ids) {
-  if (stage_ld(cfg->N) != EMU_W || !reducible(*cfg, *st)) return -1;
+// the tail alone: mpmpc_solve_block_kernel<G, VAR> on the listed instances (mode 2: phase 1 and the full iteration) - what follows
+// the reduced-native kernels with two stages per lane (horizons 64 .. 127 in one wavefront: emul.cpp, solve_rn2<64> / solve_rnt2<64>)
+template <int VAR>
+static void solve_wide_tail(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
+                            int* status, int* iters, double* resid, double* y, const int* ids, int n_ids) {
   constexpr int G = EMU_W, C = EMU_W / 2;
   using L = LaneEmu<G, C>;
   const int ld = stage_ld(cfg->N);
@@ -83,13 +83,19 @@ extern "C" int emuw_solve_tail(const mpmpc_config* cfg, const mpmpc_settings* st
     const int id = ids[j];
     VI inst = L::slot() + id;
     VI k = L::stage() - lane_offset(G, C, cfg->N);
-    using S = Solver<L, false, true, false, true>;
+    using S = Solver<L, false, VAR == 2, false, VAR == 2>;
     S s;
     typename L::real fields[MPMPC_NUM_FIELDS];
     S::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
     s.template run<false, true>(fields, B, inst, k, cfg->N, make_params(*st), 2, VI(0), VI(iters[id * 2 + 1]), nullptr);
     s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y, nullptr, ld);
   }
+}
+extern "C" int emuw_solve_tail(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
+                               int* status, int* iters, double* resid, double* y, const int* ids, int n_ids) {
+  if (stage_ld(cfg->N) != EMU_W || full_weights(*cfg)) return -1;
+  if (reducible(*cfg, *st)) solve_wide_tail<2>(cfg, st, qp, B, z, u0, status, iters, resid, y, ids, n_ids);
+  else solve_wide_tail<0>(cfg, st, qp, B, z, u0, status, iters, resid, y, ids, n_ids);      // (the terminal-time kernel's tail: the full problem)
   return 0;
 }
 

@@ -202,6 +202,30 @@ def test_two_stages_per_lane_in_one_wavefront_against_the_workgroup_emulation(N,
     assert max(prim.max(), stat.max(), comp.max()) <= 1e-8
 
 
+@pytest.mark.parametrize("N,B", [(64, 8), (70, 12), (96, 6), (100, 8), (127, 8)])
+def test_terminal_time_kernel_with_two_stages_per_lane_at_long_horizons(N, B, emu, track):
+    """Time-optimal weights (a terminal cost on the time state, README.md:56 of the reference) at horizons 64 .. 127: the
+    terminal-time reduced-native solver (2 x 2 blocks + Sherman-Morrison) on the pair layout, one wavefront per instance,
+    instead of the general 3-state solver on a workgroup - against that solver's emulation and the C oracle (statuses,
+    controls to 1e-6, measured 2e-10), KKT with plain numpy on the FULL problem."""
+    tw = T.wide_track(track, emu, N)
+    sc = scenarios.make(3, tw, B=B, N=N)
+    cfg = T.stock_config(N, "time_optimal")
+    st = mpmpc.default_settings(phase1_accept=0)
+    qp = emu.assemble(cfg, tw, (sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub))
+    pair = emu.solve(cfg, st, qp)                  # the launcher's sequence
+    wg = emu.solve(cfg, st, qp, G=128)             # the general workgroup kernel (mpmpc_set_packing(h, 128))
+    assert np.array_equal(pair.status, wg.status)
+    ok = pair.status == 1
+    assert ok.sum() >= B // 2 and np.max(np.abs(pair.u0[ok] - wg.u0[ok])) <= 1e-8
+    # (fewer iterations than the general kernel: its own Ruiz pass and start, as at N = 50)
+    assert pair.iters[ok, 1].mean() < wg.iters[ok, 1].mean()
+    ref = _oracle(track, sc, scenarios.WEIGHTS["time_optimal"])
+    assert np.array_equal(pair.status, ref["status"]) and np.max(np.abs(pair.u0[ok] - ref["u0"][ok])) <= 1e-6
+    prim, stat, comp = T.kkt_batch(qp[:, ok, :], N, pair.z[ok], pair.y[ok])
+    assert max(prim.max(), stat.max(), comp.max()) <= 1e-8
+
+
 def test_horizon_limits_are_checked():
     with pytest.raises(ValueError):
         T.stock_config(256)
