@@ -86,6 +86,13 @@ class Emul:
             assert rc == 0
             ids = np.ascontiguousarray(np.flatnonzero(st == -10), np.int32)          # MPMPC_UNSOLVED
             assert ids.size == nt.value
+            if ids.size and self.lib.emu_reduced_native_tail(C.byref(cfg), C.byref(settings)):
+                # ... the reduced-native TAIL solver on the same layout first (mpmpc_reduced_tail_pair_kernel<64>)
+                ids2, n2 = np.zeros(ids.size, np.int32), C.c_int(0)
+                rc = self.lib.emu_solve_rn_tail_pair(C.byref(cfg), C.byref(settings), _d(qp), C.c_int(B), _d(z), _d(u0), _i(st), _i(it),
+                                                     _d(rs), _d(yy), _i(ids), C.c_int(ids.size), _i(ids2), C.byref(n2))
+                assert rc == 0
+                ids = np.ascontiguousarray(ids2[:n2.value])
             rc = self.wide(128).emuw_solve_tail(C.byref(cfg), C.byref(settings), _d(qp), C.c_int(B), _d(z), _d(u0), _i(st), _i(it),
                                                 _d(rs), _d(yy), _i(ids), C.c_int(ids.size))
             assert rc == 0

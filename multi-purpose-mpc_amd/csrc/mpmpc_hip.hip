@@ -305,6 +305,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   }
 }
 
+// K2p2: the reduced-native TAIL solver (mpmpc_reduced_tail.hpp: phase 1 / Farkas ray / relaxed plan, one more attempt) with two
+// stages per lane - the tail of K2r2<64> at horizons 64 .. 127, one instance per wavefront, where the general solver on a workgroup
+// used to take all of it (40 % of an obstacle-course step at N = 100); what it leaves is listed in tail2 for that kernel.
+template <int GB>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void mpmpc_reduced_tail_pair_kernel(mpmpc_config cfg, SolverParams st, int B, AssembleIn ain,
+                                                           double* __restrict__ z, double* __restrict__ u0,
+                                                           int* __restrict__ status, int* __restrict__ iters,
+                                                           double* __restrict__ resid, double* __restrict__ y,
+                                                           const int* __restrict__ tail, int* __restrict__ tail2) {
+  using L = LanePair<LaneGpu<GB, GB, RN2_SLOTS>>;
+  static_assert(L::per_wave == 1, "one instance per wavefront");
+  if ((int)blockIdx.x >= tail[0]) return;
+  const int in0 = tail[1 + blockIdx.x];
+  const I2 inst(in0, in0);
+  const I2 k = L::stage();
+  D2 fields[MPMPC_NUM_FIELDS];
+  assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
+  ReducedTailSolver<L> s;
+  const int base = iters ? iters[in0 * 2 + 1] : 0;
+  s.run(fields, B, inst, k, cfg.N, st, I2(base));
+  const I2 k_o = L::stage_again();
+  s.store(inst, k_o, cfg.wheelbase, z, u0, status, iters, resid, y);
+  if (k_o.v[0] == 0 && s.status.v[0] == MPMPC_UNSOLVED) tail2[1 + atomicAdd(tail2, 1)] = in0;
+}
+
 // K2t2: K2t with two stages per lane, for horizons 64 .. 127 - ONE wavefront per instance where such weights used to run the
 // general 3-state solver on a workgroup of two (mpmpc_solve_block_kernel<128, 0>); 502 registers, no scratch.
 template <int GB>
@@ -1482,9 +1507,18 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
         int* spare = h->tail + ((size_t)h->cfg.max_batch + 1);
         hipLaunchKernelGGL(mpmpc_reduced_pair_kernel<64>, dim3(B), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, ain, h->z, h->u0, h->status,
                            h->iters, h->resid, y_out, h->tail, spare, h->tail_flag, h->seq, spare + ((size_t)h->cfg.max_batch + 1));
-      } else if (N + 1 <= 128) LAUNCH_RBLOCK(128);
-      else LAUNCH_RBLOCK(256);
-      tail_blk = h->tail;
+        tail_blk = h->tail;
+        if (h->lean_tail && reduced_native_tail(h->cfg, h->st)) {
+          // ... its tail to the reduced-native tail solver on the same layout (K2p2; the list it fills was emptied by the kernel above)
+          hipLaunchKernelGGL(mpmpc_reduced_tail_pair_kernel<64>, dim3(B), dim3(64), 0, h->stream, h->cfg, prm, B, ain, h->z, h->u0, h->status,
+                             h->iters, h->resid, y_out, h->tail, spare);
+          tail_blk = spare;
+        }
+      } else {
+        if (N + 1 <= 128) LAUNCH_RBLOCK(128);
+        else LAUNCH_RBLOCK(256);
+        tail_blk = h->tail;
+      }
     } else if (!fullqn && reduced_native_tt(h->cfg, h->st) && N + 1 <= 128 && h->force_lanes != 128) {
       // a terminal cost on the time state at 65 .. 128 stages: K2t with two stages per lane (one wavefront per instance), the
       // general workgroup kernel on what it lists

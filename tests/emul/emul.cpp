@@ -172,6 +172,38 @@ static void solve_rn_tail(const mpmpc_config* cfg, const mpmpc_settings* st, con
       if (k.v[i] == 0 && inst.v[i] < B && s.status.v[i] == MPMPC_UNSOLVED) tail2[1 + tail2[0]++] = inst.v[i];
   }
 }
+// ... with two stages per lane (mpmpc_reduced_tail_pair_kernel<64>: horizons 64 .. 127, one instance per emulated wavefront)
+template <int GB>
+static void solve_rn_tail2(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
+                           int* status, int* iters, double* resid, double* y, const int* tail, int* tail2) {
+  using L = LanePair<LaneEmu<GB, GB>>;
+  static_assert(L::per_wave == 1, "one instance per wavefront");
+  const int ld = stage_ld(cfg->N);
+  for (int w = 0; w < tail[0]; ++w) {
+    const int id = tail[1 + w];
+    const I2 inst = I2(id), base = I2(iters[id * 2 + 1]);
+    const I2 k = L::stage();
+    ReducedTailSolver<L> s;
+    typename L::real fields[MPMPC_NUM_FIELDS];
+    ReducedTailSolver<L>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    s.run(fields, B, inst, k, cfg->N, make_params(*st), base);
+    s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y);
+    for (int i = 0; i < EMU_W; ++i)
+      if (k.v[0].v[i] == 0 && s.status.v[0].v[i] == MPMPC_UNSOLVED) tail2[1 + tail2[0]++] = id;
+  }
+}
+// the reduced-native tail solver (pair layout) on a list of instances; ids2 <- what it leaves (n2 of them)
+extern "C" int emu_solve_rn_tail_pair(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
+                                      int* status, int* iters, double* resid, double* y, const int* ids, int n_ids, int* ids2, int* n2) {
+  if (cfg->N + 1 <= 64 || cfg->N + 1 > 128 || !reduced_native_tail(*cfg, *st)) return -1;
+  std::vector<int> tail(n_ids + 1), tail2(n_ids + 1, 0);
+  tail[0] = n_ids;
+  for (int i = 0; i < n_ids; ++i) tail[1 + i] = ids[i];
+  solve_rn_tail2<64>(cfg, st, qp, B, z, u0, status, iters, resid, y, tail.data(), tail2.data());
+  *n2 = tail2[0];
+  for (int i = 0; i < tail2[0]; ++i) ids2[i] = tail2[1 + i];
+  return 0;
+}
 extern "C" void emu_set_lean_tail(int on) { g_emu_lean_tail = on; }
 extern "C" int emu_reduced_native_tail(const mpmpc_config* cfg, const mpmpc_settings* st) { return reduced_native_tail(*cfg, *st) ? 1 : 0; }
 static int g_emu_tail2 = 0;              // instances the last emu_solve_launch's reduced-native tail solver left to the general kernel

@@ -200,6 +200,16 @@ def test_two_stages_per_lane_in_one_wavefront_against_the_workgroup_emulation(N,
     assert np.array_equal(pair.status, ref["status"]) and np.max(np.abs(pair.u0[ok] - ref["u0"][ok])) <= 1e-6
     prim, stat, comp = T.kkt_batch(qp[:, ok, :], N, pair.z[ok], pair.y[ok])
     assert max(prim.max(), stat.max(), comp.max()) <= 1e-8
+    if (~ok).any():
+        good, _, _ = T.farkas_batch(qp[:, ~ok, :], N, pair.y[~ok])
+        assert good.all()
+    # ... and with the DEFAULT verdict semantics (marginally infeasible instances come back as plans over relaxed boxes, status 2):
+    # the tail solver on the pair layout (mpmpc_reduced_tail_pair_kernel<64>) against the general workgroup kernel's phase 1
+    dflt = mpmpc.default_settings()
+    pair2, wg2 = emu.solve(cfg, dflt, qp), emu.solve(cfg, dflt, qp, G=128)
+    assert np.array_equal(pair2.status, wg2.status)
+    u = pair2.status > 0
+    assert np.max(np.abs(pair2.u0[u] - wg2.u0[u])) <= 1e-6 and np.max(np.abs(pair2.resid[:, 0] - wg2.resid[:, 0])) <= 1e-7
 
 
 @pytest.mark.parametrize("N,B", [(64, 8), (70, 12), (96, 6), (100, 8), (127, 8)])
