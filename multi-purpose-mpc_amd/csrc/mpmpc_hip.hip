@@ -1447,95 +1447,183 @@ static int launch_assemble(mpmpc_handle h, int B) {
   return MPMPC_OK;
 }
 
+}  // extern "C"  (the dispatch functions below are templates)
+
+// ---------------------------------------------------------------------------------------------------- launch dispatch
+// What a solve launch hands to its kernels, and ONE small function per kernel family that turns it into the launch of an
+// instantiation.  launch_solve below decides WHICH kernels run (policy: packing, warm start, tail deferral); the tables after
+// the families map that decision - (lanes per instance, chain split, variant, warm) - to the instantiation (VERDICT r5 item 8:
+// the six nested launch macros this replaces multiplied with every new layout).
+struct SolveLaunch {
+  mpmpc_handle h;
+  SolverParams prm;
+  AssembleIn ain;
+  int B;
+  double* y_out;
+  int *tail_cur, *tail_next, *tail2;      // the list this launch fills / the next launch's (emptied here) / what the tail kernel leaves
+  int* warm_act;
+  const int* warm_shift;
+};
+// general kernel, one instance per wave: the whole solve (mode 0) or the tail of a reduced-native launch (mode 2, list `tail`)
+template <int C, bool WARM, int VAR>
+static void go_general(const SolveLaunch& a, int mode, int blocks, int* tail) {
+  mpmpc_handle h = a.h;
+  hipLaunchKernelGGL((mpmpc_solve_kernel<64, C, WARM, VAR>), dim3(blocks), dim3(64), 0, h->stream, h->cfg, a.prm, a.B, h->ld, a.ain, h->z, h->u0,
+                     h->status, h->iters, h->resid, a.y_out, mode, tail, WARM ? a.warm_act : nullptr, WARM ? a.warm_shift : nullptr, a.tail_next);
+}
+using GeneralFn = void (*)(const SolveLaunch&, int, int, int*);
+// [C == 32][warm][VAR: 0 full problem, 1 full weights, 2 reduced polish, 3 free e_psi / t]
+#define MPMPC_GENERAL_ROW(C, W) {go_general<C, W, 0>, go_general<C, W, 1>, go_general<C, W, 2>, go_general<C, W, 3>}
+static const GeneralFn kGeneral[2][2][4] = {{MPMPC_GENERAL_ROW(16, false), MPMPC_GENERAL_ROW(16, true)},
+                                            {MPMPC_GENERAL_ROW(32, false), MPMPC_GENERAL_ROW(32, true)}};
+#undef MPMPC_GENERAL_ROW
+// (knob of the occupancy experiment, profiles/r3/occupancy.txt: MPMPC_RN_OCC=1 pads every block of the one-stage reduced-native
+//  kernels with 20 KB of unused dynamic LDS - 40 KB per wave, four waves per CU, ONE per SIMD - so that the same code object can
+//  be timed at one and at two waves per SIMD)
+static int rn_pad() {
+  static const int pad = (std::getenv("MPMPC_RN_OCC") && std::atoi(std::getenv("MPMPC_RN_OCC")) == 1) ? 20 * 1024 : 0;
+  return pad;
+}
+// K2r: the reduced-native batch kernel, 1 / 2 / 4 instances per wave
+template <int G, int C, bool WARM>
+static void go_reduced(const SolveLaunch& a, int blocks) {
+  mpmpc_handle h = a.h;
+  hipLaunchKernelGGL((mpmpc_reduced_kernel<G, C, WARM>), dim3(blocks), dim3(64), rn_pad(), h->stream, h->cfg, a.prm, a.B, h->ld, a.ain, h->z, h->u0,
+                     h->status, h->iters, h->resid, a.y_out, a.tail_cur, a.warm_act, a.warm_shift, a.tail_next, h->tail_flag, h->seq, a.tail2);
+}
+using ReducedFn = void (*)(const SolveLaunch&, int);
+// [layout: <64,16>, <64,32>, <32,16>, <16,16>][warm]
+static const ReducedFn kReduced[4][2] = {{go_reduced<64, 16, false>, go_reduced<64, 16, true>}, {go_reduced<64, 32, false>, go_reduced<64, 32, true>},
+                                         {go_reduced<32, 16, false>, go_reduced<32, 16, true>}, {go_reduced<16, 16, false>, go_reduced<16, 16, true>}};
+static int reduced_layout(int G, int C) { return G == 64 ? (C == 16 ? 0 : 1) : (G == 32 ? 2 : 3); }
+// K2t: its twin for a terminal cost on the time state (one instance per wave)
+template <int C>
+static void go_reduced_t(const SolveLaunch& a, int blocks) {
+  mpmpc_handle h = a.h;
+  hipLaunchKernelGGL((mpmpc_reduced_t_kernel<64, C>), dim3(blocks), dim3(64), rn_pad(), h->stream, h->cfg, a.prm, a.B, a.ain, h->z, h->u0, h->status,
+                     h->iters, h->resid, a.y_out, a.tail_cur, a.tail_next, h->tail_flag, h->seq);
+}
+// K2p: the reduced-native tail kernel on the list `tail_cur`; what it leaves goes to tail2
+template <int G, int C>
+static void go_reduced_tail(const SolveLaunch& a, int blocks) {
+  mpmpc_handle h = a.h;
+  hipLaunchKernelGGL((mpmpc_reduced_tail_kernel<G, C>), dim3(blocks), dim3(64), rn_pad(), h->stream, h->cfg, a.prm, a.B, a.ain, h->z, h->u0, h->status,
+                     h->iters, h->resid, a.y_out, a.tail_cur, a.tail_next, a.tail2, h->tail_flag + 1, h->seq);
+}
+// K2r2 / K2t2 / K2p2: two stages per lane (lane_pair.hpp) - GB lanes per instance
+template <int GB>
+static void go_pair(const SolveLaunch& a, int blocks) {
+  mpmpc_handle h = a.h;
+  hipLaunchKernelGGL(mpmpc_reduced_pair_kernel<GB>, dim3(blocks), dim3(64), 0, h->stream, h->cfg, a.prm, a.B, h->ld, a.ain, h->z, h->u0, h->status,
+                     h->iters, h->resid, a.y_out, a.tail_cur, a.tail_next, h->tail_flag, h->seq, a.tail2);
+}
+template <int GB>
+static void go_pair_t(const SolveLaunch& a) {
+  mpmpc_handle h = a.h;
+  hipLaunchKernelGGL(mpmpc_reduced_t_pair_kernel<GB>, dim3(a.B), dim3(64), 0, h->stream, h->cfg, a.prm, a.B, a.ain, h->z, h->u0, h->status, h->iters,
+                     h->resid, a.y_out, a.tail_cur);
+}
+template <int GB>
+static void go_pair_tail(const SolveLaunch& a) {
+  mpmpc_handle h = a.h;
+  hipLaunchKernelGGL(mpmpc_reduced_tail_pair_kernel<GB>, dim3(a.B), dim3(64), 0, h->stream, h->cfg, a.prm, a.B, a.ain, h->z, h->u0, h->status, h->iters,
+                     h->resid, a.y_out, a.tail_cur, a.tail_next);
+}
+// K2b / K2rb: one instance per WORKGROUP of G = 128 / 256 lanes.  The kernels need more dynamic LDS than the default limit: the
+// attribute is set once per function AND DEVICE (one process may drive several - sharded.py, bench.py --single-process - and the
+// attribute belongs to the function on the device that is current; two threads may both set it once: the call is idempotent)
+constexpr int MAX_DEVICES = 64;
+static int device_slot(mpmpc_handle h) { return h->cfg.device >= 0 && h->cfg.device < MAX_DEVICES ? h->cfg.device : 0; }
+template <int G, int VAR>
+static int go_block(const SolveLaunch& a, const int* tail) {
+  mpmpc_handle h = a.h;
+  static std::atomic<bool> attr_set[MAX_DEVICES];
+  if (!attr_set[device_slot(h)]) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpmpc_solve_block_kernel<G, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)LaneBlock<G>::lds_bytes));
+    attr_set[device_slot(h)] = true;
+  }
+  hipLaunchKernelGGL((mpmpc_solve_block_kernel<G, VAR>), dim3(a.B), dim3(G), LaneBlock<G>::lds_bytes, h->stream, h->cfg, a.prm, a.B, a.ain, h->z, h->u0,
+                     h->status, h->iters, h->resid, a.y_out, tail);
+  return MPMPC_OK;
+}
+using BlockFn = int (*)(const SolveLaunch&, const int*);
+static const BlockFn kBlock[2][3] = {{go_block<128, 0>, go_block<128, 1>, go_block<128, 2>}, {go_block<256, 0>, go_block<256, 1>, go_block<256, 2>}};
+template <int G>
+static int go_rblock(const SolveLaunch& a) {
+  mpmpc_handle h = a.h;
+  using LB = LaneBlock<G, RNB_SLOTS>;
+  static std::atomic<bool> attr_set[MAX_DEVICES];
+  if (!attr_set[device_slot(h)]) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpmpc_reduced_block_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LB::lds_bytes));
+    attr_set[device_slot(h)] = true;
+  }
+  hipLaunchKernelGGL((mpmpc_reduced_block_kernel<G>), dim3(a.B), dim3(G), LB::lds_bytes, h->stream, h->cfg, a.prm, a.B, a.ain, h->z, h->u0, h->status, h->iters,
+                     h->resid, a.y_out, a.tail_cur);
+  return MPMPC_OK;
+}
+
+// Horizons above 63.  65 .. 128 stages of the reference's own weights (or of a terminal cost on the time state): TWO stages per
+// lane, the whole instance in ONE wavefront (K2r2<64> / K2t2<64>), its tail to K2p2<64>, what that leaves to the general solver on
+// a workgroup; mpmpc_set_packing(h, 128) keeps round 5's workgroup kernels.  Everything else - longer horizons, full weights,
+// bounded e_psi / t - one instance per workgroup of 2 / 4 wavefronts (K2rb in front where the reduction applies).  No packing, no
+// deferred tail, cold starts in the closed loop too.
+static int launch_long_horizon(mpmpc_handle h, SolveLaunch& a, int tail_only) {
+  if (tail_only) return MPMPC_OK;
+  const int N = h->cfg.N;
+  h->pend = h->pend2 = false;
+  const bool fullqn = full_weights(h->cfg);
+  const int var = fullqn ? 1 : (reducible(h->cfg, h->st) ? 2 : 0);
+  const bool one_wave = N + 1 <= 128 && h->force_lanes != 128;
+  int* list1 = h->tail;
+  int* list2 = h->tail + ((size_t)h->cfg.max_batch + 1);
+  int* list3 = list2 + ((size_t)h->cfg.max_batch + 1);
+  const int* tail_blk = nullptr;          // the list the general workgroup kernel works on (null: every instance, the whole solve)
+  a.tail_cur = list1;
+  if (!fullqn && reduced_native(h->cfg, h->st)) {
+    HIP_TRY(hipMemsetAsync(list1, 0, sizeof(int), h->stream));
+    tail_blk = list1;
+    if (one_wave) {
+      // (the kernel empties "the lists of the next launch" - here the two lists behind the one it fills; the tail kernels below
+      //  always run, so the host-side flag it stamps is not consulted)
+      a.tail_next = list2; a.tail2 = list3;
+      go_pair<64>(a, a.B);
+      if (h->lean_tail && reduced_native_tail(h->cfg, h->st)) {
+        a.tail_next = list2;          // K2p2 reads list 1, fills list 2
+        go_pair_tail<64>(a);
+        tail_blk = list2;
+      }
+    } else if (int rc = (N + 1 <= 128 ? go_rblock<128>(a) : go_rblock<256>(a))) return rc;
+  } else if (!fullqn && reduced_native_tt(h->cfg, h->st) && one_wave) {
+    HIP_TRY(hipMemsetAsync(list1, 0, sizeof(int), h->stream));
+    go_pair_t<64>(a);
+    tail_blk = list1;
+  }
+  if (int rc = kBlock[N + 1 <= 128 ? 0 : 1][var](a, tail_blk)) return rc;
+  HIP_TRY(hipGetLastError());
+  return MPMPC_OK;
+}
+
 // tail_only: 1 = the deferred tail launches of the last reduced-native launch (observe_tail), nothing else; 2 = of those,
 // only the general kernel on what the reduced-native tail kernel left
 static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, int tail_only, LaunchKind kind) {
   const int N = h->cfg.N;
-  double* y_out = want_y ? h->y : nullptr;        // nobody wants the multipliers: the kernel skips their stores
   h->y_valid = want_y;
-  AssembleIn ain;
-  ain.tab = PathTables{h->kappa, h->v_ref, h->ds_next, h->n_wp, h->ub_tab, h->lb_tab, h->n_cols};
-  ain.wp_id = h->wp_id; ain.x0 = h->x0; ain.cc = h->cc;
-  ain.lb = h->have_rows ? h->lb : nullptr; ain.ub = h->have_rows ? h->ub : nullptr;
+  SolveLaunch a{};
+  a.h = h;
+  a.B = B;
+  a.prm = make_params(h->st);
+  a.y_out = want_y ? h->y : nullptr;        // nobody wants the multipliers: the kernel skips their stores
+  a.ain.tab = PathTables{h->kappa, h->v_ref, h->ds_next, h->n_wp, h->ub_tab, h->lb_tab, h->n_cols};
+  a.ain.wp_id = h->wp_id; a.ain.x0 = h->x0; a.ain.cc = h->cc;
+  a.ain.lb = h->have_rows ? h->lb : nullptr; a.ain.ub = h->have_rows ? h->ub : nullptr;
+  if (N + 1 > 64) return launch_long_horizon(h, a, tail_only);
   // Full weights (Q, R or QN with off-diagonal entries), bounds on e_psi / t or a cost on t rule the reduction out:
   // such configurations run the general kernels, one instance per wave.
   const bool fullqn = full_weights(h->cfg);
-  if (N + 1 > 64) {
-    // Horizons above 63: one instance per workgroup of 2 / 4 wavefronts, the general solver, the whole solve in one launch
-    // (no packing, no tail lists, cold starts in the closed loop too); 77 / 154 KB of dynamic LDS per workgroup.
-    if (tail_only) return MPMPC_OK;
-    h->pend = h->pend2 = false;
-    const SolverParams prm = make_params(h->st);
-    constexpr int MAX_DEVICES = 64;
-    const int dev_slot = h->cfg.device >= 0 && h->cfg.device < MAX_DEVICES ? h->cfg.device : 0;
-#define LAUNCH_BLOCK(GG, VV)                                                                                                          \
-  do {                                                                                                                                \
-    /* (per DEVICE: one process may drive several - sharded.py, bench.py --single-process - and the attribute belongs to the   \
-       function on the device that is current; two threads may both set it once - the call is idempotent) */                                                                          \
-    static std::atomic<bool> attr_set[MAX_DEVICES];                                                                                           \
-    if (!attr_set[dev_slot]) {                                                                                                        \
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpmpc_solve_block_kernel<GG, VV>),                                  \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LaneBlock<GG>::lds_bytes));                        \
-      attr_set[dev_slot] = true;                                                                                                      \
-    }                                                                                                                                 \
-    hipLaunchKernelGGL((mpmpc_solve_block_kernel<GG, VV>), dim3(B), dim3(GG), LaneBlock<GG>::lds_bytes, h->stream, h->cfg, prm, B, \
-                       ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, tail_blk);                                             \
-  } while (0)
-#define LAUNCH_RBLOCK(GG)                                                                                                             \
-  do {                                                                                                                                \
-    using LB_ = LaneBlock<GG, RNB_SLOTS>;                                                                                             \
-    static std::atomic<bool> attr_set[MAX_DEVICES];                                                                                           \
-    if (!attr_set[dev_slot]) {                                                                                                        \
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpmpc_reduced_block_kernel<GG>),                                    \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LB_::lds_bytes));                                 \
-      attr_set[dev_slot] = true;                                                                                                      \
-    }                                                                                                                                 \
-    hipLaunchKernelGGL((mpmpc_reduced_block_kernel<GG>), dim3(B), dim3(GG), LB_::lds_bytes, h->stream, h->cfg, prm, B,             \
-                       ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, h->tail);                                              \
-  } while (0)
-    const bool redb = !fullqn && reducible(h->cfg, h->st);
-    // the reference's own weights at the default settings: the reduced-native solver first (K2rb), the general one on what
-    // it lists (the same split as below 64 stages, without packing and without the deferred tail: the list is cleared here)
-    const bool rnb = !fullqn && reduced_native(h->cfg, h->st);
-    const int* tail_blk = nullptr;
-    if (rnb) {
-      HIP_TRY(hipMemsetAsync(h->tail, 0, sizeof(int), h->stream));
-      // 65 .. 128 stages: TWO stages per lane, the whole instance in ONE wavefront (K2r2<64>; mpmpc_set_packing(h, 128) keeps the
-      // workgroup kernel K2rb).  Its "lists of the next launch" are two words behind the list it fills; the tail kernel below
-      // always runs, so the host-side flag it stamps is not consulted.
-      if (N + 1 <= 128 && h->force_lanes != 128) {
-        int* spare = h->tail + ((size_t)h->cfg.max_batch + 1);
-        hipLaunchKernelGGL(mpmpc_reduced_pair_kernel<64>, dim3(B), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, ain, h->z, h->u0, h->status,
-                           h->iters, h->resid, y_out, h->tail, spare, h->tail_flag, h->seq, spare + ((size_t)h->cfg.max_batch + 1));
-        tail_blk = h->tail;
-        if (h->lean_tail && reduced_native_tail(h->cfg, h->st)) {
-          // ... its tail to the reduced-native tail solver on the same layout (K2p2; the list it fills was emptied by the kernel above)
-          hipLaunchKernelGGL(mpmpc_reduced_tail_pair_kernel<64>, dim3(B), dim3(64), 0, h->stream, h->cfg, prm, B, ain, h->z, h->u0, h->status,
-                             h->iters, h->resid, y_out, h->tail, spare);
-          tail_blk = spare;
-        }
-      } else {
-        if (N + 1 <= 128) LAUNCH_RBLOCK(128);
-        else LAUNCH_RBLOCK(256);
-        tail_blk = h->tail;
-      }
-    } else if (!fullqn && reduced_native_tt(h->cfg, h->st) && N + 1 <= 128 && h->force_lanes != 128) {
-      // a terminal cost on the time state at 65 .. 128 stages: K2t with two stages per lane (one wavefront per instance), the
-      // general workgroup kernel on what it lists
-      HIP_TRY(hipMemsetAsync(h->tail, 0, sizeof(int), h->stream));
-      hipLaunchKernelGGL(mpmpc_reduced_t_pair_kernel<64>, dim3(B), dim3(64), 0, h->stream, h->cfg, prm, B, ain, h->z, h->u0, h->status,
-                         h->iters, h->resid, y_out, h->tail);
-      tail_blk = h->tail;
-    }
-    if (N + 1 <= 128) { if (fullqn) LAUNCH_BLOCK(128, 1); else if (redb) LAUNCH_BLOCK(128, 2); else LAUNCH_BLOCK(128, 0); }
-    else { if (fullqn) LAUNCH_BLOCK(256, 1); else if (redb) LAUNCH_BLOCK(256, 2); else LAUNCH_BLOCK(256, 0); }
-#undef LAUNCH_RBLOCK
-#undef LAUNCH_BLOCK
-    HIP_TRY(hipGetLastError());
-    return MPMPC_OK;
-  }
   const bool red = reducible(h->cfg, h->st);      // the polish may work on the (e_y, e_psi, kappa) problem
   const bool freex = !fullqn && !red && free_states(h->cfg);
+  const int var = fullqn ? 1 : (red ? 2 : (freex ? 3 : 0));
   // The reduced-native kernels (mpmpc_reduced.hpp) take the batch path of every configuration they apply to - cold and
   // warm-started - and only they pack several instances into a wave; the general kernel then sees their tail.
   const bool rnt = reduced_native_tt(h->cfg, h->st);      // ... or their twin for a terminal cost on the time state
@@ -1560,7 +1648,8 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
     if (N + 1 <= 32 && B > (throughput ? 128 : 1024)) G = 32;
     if (N + 1 <= 16 && B > (throughput ? 256 : 2048)) G = 16;
     if (h->force_lanes && N + 1 <= h->force_lanes) G = h->force_lanes;      // mpmpc_set_packing
-    // TWO stages per lane (K2r2): 17 .. 32 stages in 16 lanes, four instances per wavefront; cold starts only
+    // TWO stages per lane (K2r2<16>): 17 .. 32 stages in 16 lanes, four instances per wavefront; cold starts only.  Measured
+    // slower than <32,16> at two waves per SIMD: never the automatic choice.
     if (h->force_lanes == 16 && N + 1 > 16 && N + 1 <= 32 && !closed_loop) { G = 32; two = true; }
   }
   // closed loop: the previous step's active sets as a first guess.  A launch with one instance per wave ends with
@@ -1568,115 +1657,63 @@ static int launch_solve(mpmpc_handle h, int B, bool closed_loop, bool want_y, in
   // per car and step: the miss pays for the attempt AND the normal path, 1024 cars -7 %), so "auto" warm-starts the
   // packed launches (x1.5 at 8192 cars) and the very small fleets (x1.7 at 8 cars) only.
   const bool warm = closed_loop && !rnt && (h->ro_warm == 1 || (h->ro_warm == 2 && (G < 64 || B <= 16)));
-  int* warm_act = warm ? h->ro_act : nullptr;
-  const int* warm_shift = warm ? h->ro_shift : nullptr;
+  a.warm_act = warm ? h->ro_act : nullptr;
+  a.warm_shift = warm ? h->ro_shift : nullptr;
   const int per = two ? 4 : 64 / G;
   const int blocks = (B + per - 1) / per;
-  const SolverParams prm = make_params(h->st);
   const int C = lane_split(G, N);        // where the two elimination chains of the factorisation meet
+  const int C64 = lane_split(64, N);     // ... of the one-instance-per-wave kernels that take a tail
   // tail lists ([0] = count, [1..] = instance ids), two of them used in turn: the tail launch of this step empties the
   // list of the next one, so that no memset has to sit between the launches of consecutive steps
-  int* tail_cur = h->tail + (size_t)h->tail_flip * (h->cfg.max_batch + 1);
-  int* tail_next = h->tail + (size_t)(1 - h->tail_flip) * (h->cfg.max_batch + 1);
-  int* tail2 = h->tail + 2 * ((size_t)h->cfg.max_batch + 1);      // what the reduced-native tail kernel leaves to the general one
-  if (tail_only) { tail_cur = h->pend_cur; tail_next = h->pend_next; }
+  a.tail_cur = h->tail + (size_t)h->tail_flip * (h->cfg.max_batch + 1);
+  a.tail_next = h->tail + (size_t)(1 - h->tail_flip) * (h->cfg.max_batch + 1);
+  a.tail2 = h->tail + 2 * ((size_t)h->cfg.max_batch + 1);      // what the reduced-native tail kernel leaves to the general one
+  if (tail_only) { a.tail_cur = h->pend_cur; a.tail_next = h->pend_next; }
   else if (rn) { h->tail_flip = 1 - h->tail_flip; h->seq += 1; }
+  if (!rn) {
+    // the general kernel, one instance per wave, the whole solve
+    kGeneral[C == 32][warm][var](a, 0, blocks, a.tail_cur);
+    HIP_TRY(hipGetLastError());
+    return MPMPC_OK;
+  }
   // The tail of a batch launch goes to the reduced-native tail kernel first (K2p: two waves per SIMD instead of one).  The
   // closed loop keeps the general kernel for the whole tail: its step would pay for a third launch every time.
-  const bool lean = rn && !rnt && !closed_loop && h->lean_tail && reduced_native_tail(h->cfg, h->st);
-#define LAUNCH_W(CC, WW, FF, MODE, BLOCKS)                                                                                \
-  hipLaunchKernelGGL((mpmpc_solve_kernel<64, CC, WW, FF>), dim3(BLOCKS), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, \
-                     ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, MODE, tail_cur, WW ? warm_act : nullptr,   \
-                     WW ? warm_shift : nullptr, tail_next)
-#define LAUNCH_V(CC, WW, MODE, BLOCKS)                  \
-  do {                                                  \
-    if (fullqn) LAUNCH_W(CC, WW, 1, MODE, BLOCKS);      \
-    else if (red) LAUNCH_W(CC, WW, 2, MODE, BLOCKS);    \
-    else if (freex) LAUNCH_W(CC, WW, 3, MODE, BLOCKS);  \
-    else LAUNCH_W(CC, WW, 0, MODE, BLOCKS);             \
-  } while (0)
-  // the general kernel, one instance per wave: the whole solve (mode 0), or the tail of a reduced-native launch (mode 2)
-#define LAUNCH(CC, WW, MODE, BLOCKS)                    \
-  do {                                                  \
-    if (WW) LAUNCH_V(CC, true, MODE, BLOCKS);           \
-    else LAUNCH_V(CC, false, MODE, BLOCKS);             \
-  } while (0)
-  // (knob of the occupancy experiment, profiles/r3/occupancy.txt: MPMPC_RN_OCC=1 pads every block with 20 KB of unused
-  //  dynamic LDS - 40 KB per wave, four waves per CU, ONE per SIMD - so that the same code object can be timed at one
-  //  and at two waves per SIMD)
-  static const int rn_pad = (std::getenv("MPMPC_RN_OCC") && std::atoi(std::getenv("MPMPC_RN_OCC")) == 1) ? 20 * 1024 : 0;
-#define LAUNCH_RN_W(GG, CC, WW)                                                                                             \
-  hipLaunchKernelGGL((mpmpc_reduced_kernel<GG, CC, WW>), dim3(blocks), dim3(64), rn_pad, h->stream, h->cfg, prm, B, h->ld, \
-                     ain, h->z, h->u0, h->status, h->iters, h->resid, y_out, tail_cur, warm_act, warm_shift, tail_next,      \
-                     h->tail_flag, h->seq, tail2)
-#define LAUNCH_RN(GG, CC)                       \
-  do {                                          \
-    if (warm) LAUNCH_RN_W(GG, CC, true);        \
-    else LAUNCH_RN_W(GG, CC, false);            \
-  } while (0)
-#define LAUNCH_RNT(GG, CC)                                                                                               \
-  hipLaunchKernelGGL((mpmpc_reduced_t_kernel<GG, CC>), dim3(blocks), dim3(64), rn_pad, h->stream, h->cfg, prm, B, ain, \
-                     h->z, h->u0, h->status, h->iters, h->resid, y_out, tail_cur, tail_next, h->tail_flag, h->seq)
-  if (rn) {
-    if (!tail_only && rnt) {
-      if (C == 16) LAUNCH_RNT(64, 16);
-      else LAUNCH_RNT(64, 32);
-    } else if (!tail_only && two) {
-      hipLaunchKernelGGL(mpmpc_reduced_pair_kernel<16>, dim3(blocks), dim3(64), 0, h->stream, h->cfg, prm, B, h->ld, ain, h->z, h->u0, h->status,
-                         h->iters, h->resid, y_out, tail_cur, tail_next, h->tail_flag, h->seq, tail2);
-    } else if (!tail_only) {
-      if (G == 64 && C == 16) LAUNCH_RN(64, 16);
-      else if (G == 64) LAUNCH_RN(64, 32);
-      else if (G == 32) LAUNCH_RN(32, 16);
-      else LAUNCH_RN(16, 16);
+  const bool lean = !rnt && !closed_loop && h->lean_tail && reduced_native_tail(h->cfg, h->st);
+  if (!tail_only) {
+    if (rnt) (C == 16 ? go_reduced_t<16> : go_reduced_t<32>)(a, blocks);
+    else if (two) go_pair<16>(a, blocks);
+    else kReduced[reduced_layout(G, C)][warm](a, blocks);
+  }
+  // The tail is short (infeasible / very hard instances).  One block per instance of the batch: blocks beyond the
+  // list's length return at once (an all-empty launch takes 4.8 us at 1 024 blocks, 15 us at 65 536: rocprofv3 kernel
+  // trace - which is why it is not enqueued when no tail is expected, below; a grid-stride loop over the list around the solver costs
+  // the general kernels 70 registers and puts 148-544 B of scratch into kernels that have none: measured on the code
+  // object, not kept).  Its instances carry no guess for the next closed-loop step (act stays 0 from the first launch).
+  // Deferred (see the handle): no tail launch is enqueued while the launches the host has seen leave none; the closed
+  // loop consumes its results on the device and always launches it.
+  h->pend = !tail_only && !closed_loop && h->tail_expect_empty;
+  h->pend2 = false;
+  if (h->pend) {
+    h->pend_B = B; h->pend_y = want_y; h->pend_cur = a.tail_cur; h->pend_next = a.tail_next;
+  } else if (lean) {
+    if (tail_only != 2) {
+      // (the list's order differs from run to run - atomic appends - and with it the two instances that share a wave of the
+      //  packed form: the solver's arithmetic does not depend on the partner, Solver::active_set)
+      if (C64 == 32) go_reduced_tail<64, 32>(a, B);          // horizons 32 .. 63: one lane per stage, one instance per wave
+      else if (!h->lean_tail_single) go_reduced_tail<32, 16>(a, (B + 1) / 2);
+      else go_reduced_tail<64, 16>(a, B);
     }
-    // The tail is short (infeasible / very hard instances).  One block per instance of the batch: blocks beyond the
-    // list's length return at once (an all-empty launch takes 4.8 us at 1 024 blocks, 15 us at 65 536: rocprofv3 kernel
-    // trace - which is why it is not enqueued when no tail is expected, below; a grid-stride loop over the list around the solver costs
-    // the general kernels 70 registers and puts 148-544 B of scratch into kernels that have none: measured on the code
-    // object, not kept).  Its instances carry no guess for the next closed-loop step (act stays 0 from the first launch).
-    // Deferred (see the handle): no tail launch is enqueued while the launches the host has seen leave none; the closed
-    // loop consumes its results on the device and always launches it.
-    h->pend = !tail_only && !closed_loop && h->tail_expect_empty;
-    h->pend2 = false;
-    if (h->pend) {
-      h->pend_B = B; h->pend_y = want_y; h->pend_cur = tail_cur; h->pend_next = tail_next;
-    } else if (lean) {
-      if (tail_only != 2) {
-        // (the list's order differs from run to run - atomic appends - and with it the two instances that share a wave of the
-        //  packed form: the solver's arithmetic does not depend on the partner, Solver::active_set)
-        if (lane_split(64, N) == 32)          // horizons 32 .. 63: one lane per stage, one instance per wave
-          hipLaunchKernelGGL((mpmpc_reduced_tail_kernel<64, 32>), dim3(B), dim3(64), rn_pad, h->stream, h->cfg, prm, B, ain, h->z, h->u0,
-                             h->status, h->iters, h->resid, y_out, tail_cur, tail_next, tail2, h->tail_flag + 1, h->seq);
-        else if (!h->lean_tail_single) {
-          hipLaunchKernelGGL((mpmpc_reduced_tail_kernel<32, 16>), dim3((B + 1) / 2), dim3(64), rn_pad, h->stream, h->cfg, prm, B, ain, h->z,
-                             h->u0, h->status, h->iters, h->resid, y_out, tail_cur, tail_next, tail2, h->tail_flag + 1, h->seq);
-        } else
-          hipLaunchKernelGGL((mpmpc_reduced_tail_kernel<64, 16>), dim3(B), dim3(64), rn_pad, h->stream, h->cfg, prm, B, ain, h->z, h->u0,
-                             h->status, h->iters, h->resid, y_out, tail_cur, tail_next, tail2, h->tail_flag + 1, h->seq);
-      }
-      // ... and the general kernel on what that left: deferred like the tail itself while the launches seen leave nothing
-      h->pend2 = tail_only != 2 && h->tail2_expect_empty;
-      if (h->pend2) {
-        h->pend_B = B; h->pend_y = want_y; h->pend_cur = tail_cur; h->pend_next = tail_next;
-      } else {
-        tail_cur = tail2;
-        if (lane_split(64, N) == 16) LAUNCH(16, false, 2, B);
-        else LAUNCH(32, false, 2, B);
-      }
-    } else if (lane_split(64, N) == 16) LAUNCH(16, false, 2, B);
-    else LAUNCH(32, false, 2, B);
-  } else if (C == 16) LAUNCH(16, warm, 0, blocks);
-  else LAUNCH(32, warm, 0, blocks);
-#undef LAUNCH_RNT
-#undef LAUNCH_RN
-#undef LAUNCH_RN_W
-#undef LAUNCH_V
-#undef LAUNCH_W
-#undef LAUNCH
+    // ... and the general kernel on what that left: deferred like the tail itself while the launches seen leave nothing
+    h->pend2 = tail_only != 2 && h->tail2_expect_empty;
+    if (h->pend2) {
+      h->pend_B = B; h->pend_y = want_y; h->pend_cur = a.tail_cur; h->pend_next = a.tail_next;
+    } else kGeneral[C64 == 32][0][var](a, 2, B, a.tail2);
+  } else kGeneral[C64 == 32][0][var](a, 2, B, a.tail_cur);
   HIP_TRY(hipGetLastError());
   return MPMPC_OK;
 }
+
+extern "C" {
 
 // Drain the stream, see whether the last reduced-native launch left a tail, run it if its launch was deferred.
 static int observe_tail(mpmpc_handle h) {
