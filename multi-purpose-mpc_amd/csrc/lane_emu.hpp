@@ -115,7 +115,8 @@ inline VB selb(const VB& m, const VB& a, const VB& b) { VB r; for (int i = 0; i 
 // G = lanes per instance (16, 32 or 64; 128 / 256 in the wide builds); one emulated wave carries EMU_W / G instances.
 // C = split of the twisted factorisation (mpmpc_core.hpp, factor): lanes [C, 2C) of an instance are
 // reversed in chain layout; C == G means no second chain.
-template <int G, int C = G / 2>
+// SLOTS: cold slots (the device backends' LDS budget: 66 the general solver, 2 x 40 the pair layout, 2 x 37 its lean form)
+template <int G, int C = G / 2, int SLOTS = 80>
 struct LaneEmu {
   static constexpr int split = C;
   using real = VD;
@@ -235,7 +236,7 @@ struct LaneEmu {
 
   // "cold" per-lane storage (LDS on the GPU) for values that are only needed at termination checks
   // and in the certificate, so that they do not occupy registers inside the iteration loops
-  static constexpr int cold_slots = 80;          // (66: the general solver; 2 x 40: the reduced-native one with two stages per lane)
+  static constexpr int cold_slots = SLOTS;
   static VD* cold() { static VD buf[cold_slots]; return buf; }
   static void cold_put(int slot, const VD& a) { cold()[slot] = a; }
   static VD cold_get(int slot) { return cold()[slot]; }

@@ -392,10 +392,14 @@ struct LaneGpu {
 // price of a horizon the reference allows (src/MPC.py:73-74 has no limit) and a 64-lane wavefront does not hold.
 // LDS per workgroup: SLOTS cold slots of G doubles (also the staging of the output rows) + nine exchange rows + the
 // reduction scratch: 77 KB at G = 128 (two workgroups per CU), 154 KB at G = 256, passed as DYNAMIC shared memory (above the 64 KB static limit).
-template <int G, int SLOTS = 66>
+// CH: lanes of a chain of the reduced solvers' cyclic reduction - G / 2 (two chains that meet in the middle: the twisted
+// factorisation of the one-stage layout) or G (ONE chain in stage order: the lanes underneath the two-stages-per-lane layout of
+// horizons 128 .. 255, lane_pair.hpp).  XR: exchange rows - the widest batch of values one pass through LDS carries.
+template <int G, int SLOTS = 66, int CH = G / 2, int XR = 9>
 struct LaneBlock {
   static_assert(G == 128 || G == 256, "a workgroup of 2 or 4 wavefronts");
-  static constexpr int split = G / 2;
+  static_assert(CH == G / 2 || CH == G, "two chains that meet in the middle, or one");
+  static constexpr int split = CH;
   static constexpr int C = G / 2;
   using real = double;
   using mask = bool;
@@ -408,7 +412,7 @@ struct LaneBlock {
   static constexpr int stages_per_lane = 1;
   static constexpr bool junction_moves = false;
   static constexpr bool staged_sweeps = (G == 256);   // a chain spans two wavefronts: Solver::staged_sweep
-  static constexpr int xrows = 9;             // exchange rows: the widest batch is the 3 x 3 block of a factorisation step
+  static constexpr int xrows = XR;            // exchange rows: the widest batch is the 3 x 3 block of a factorisation step (general solver)
   // ... + 8 doubles of reduction scratch + the edge values of a staged sweep (xrows per chain)
   static constexpr size_t lds_bytes = sizeof(double) * ((size_t)(SLOTS + xrows) * G + 8 + 2 * xrows);
 
@@ -548,12 +552,13 @@ struct LaneBlock {
   template <int D> static __device__ __forceinline__ bool cr_elim() { return (((threadIdx.x & 15) + D + 1) & (2 * D - 1)) == 0; }
   // position of a lane in its chain = lane % C; step r works on the survivor X of row r (position 15), the survivor Y of row
   // r + 1 and that row's lanes 0, 1, 3, 7.  At G = 256 (chains of eight rows over two wavefronts) step 3 crosses the wavefronts.
-  static __device__ __forceinline__ bool cr64_x(int r) { return (int)(threadIdx.x & (C - 1)) == 16 * r + 15; }
+  static __device__ __forceinline__ bool cr64_x(int r) { return (int)(threadIdx.x & (CH - 1)) == 16 * r + 15; }
   static __device__ __forceinline__ bool cr64_special(int r) {
     const int p = threadIdx.x & 15;
-    return (int)((threadIdx.x & (C - 1)) >> 4) == r + 1 && ((p & (p + 1)) == 0) && p != 15;
+    return (int)((threadIdx.x & (CH - 1)) >> 4) == r + 1 && ((p & (p + 1)) == 0) && p != 15;
   }
-  static __device__ __forceinline__ bool cr_crosses(int r) { return G == 256 && r == 3; }
+  // (a chain of more than four rows spans wavefronts: the step from the last row of one to the first row of the next crosses)
+  static __device__ __forceinline__ bool cr_crosses(int r) { return CH > 64 && (r & 3) == 3; }
   // pull: every lane gets v of the same position one row up the chain (lane + 16); push: one row down (lane - 16); down: of
   // the next lane; bcast: of position 15 of the row below.  Inside a wavefront a lane permutation / DPP move per value; the
   // crossing step batches its values through the exchange rows (what a lane without such a source gets is not used).

@@ -92,7 +92,9 @@ MPMPC_HD B2 bit_(const I2& v, int b) { return B2(bit_(v.v[0], b), bit_(v.v[1], b
 // no LDS exchange, no workgroup barrier - where the one-stage layout needs a workgroup of two)
 template <class Base>
 struct LanePair {
-  static_assert(Base::split == Base::group && (Base::group == 16 || Base::group == 64), "two stages per lane: one chain of 16 or 64 lanes per instance");
+  // (... or a workgroup of two wavefronts, G = C = 128: horizons 128 .. 255, the lanes' exchanges through LDS - LaneBlock)
+  static_assert(Base::split == Base::group && (Base::group == 16 || Base::group == 64 || Base::group == 128),
+                "two stages per lane: one chain of 16, 64 or 128 lanes per instance");
   using L1 = Base;                    // the lanes underneath: what the cross-lane levels of the cyclic reduction run on
   using real = D2;
   using mask = B2;
@@ -101,7 +103,7 @@ struct LanePair {
   static constexpr int group = 2 * Base::group;        // STAGES per instance
   static constexpr int split = group;                  // one chain, no twist: stage 0 on lane 0, component 0
   static constexpr int per_wave = Base::per_wave;
-  static constexpr bool batched = false;
+  static constexpr bool batched = Base::batched;       // (a workgroup base: the values of a step share one pass through LDS)
   static constexpr bool junction_moves = false;
   static constexpr bool staged_sweeps = false;
   static constexpr int cold_slots = Base::cold_slots / 2;
@@ -123,6 +125,30 @@ struct LanePair {
   static MPMPC_HD R1 down1(const R1& a) { if constexpr (Base::group == 16) return Base::template rshl<1>(a); else return Base::down(a); }
   static MPMPC_HD D2 up(const D2& a) { return D2(up1(a.v[1]), a.v[0]); }
   static MPMPC_HD D2 down(const D2& a) { return D2(a.v[1], down1(a.v[0])); }
+  // ... NV values at once (where the base batches its exchanges, they share ONE pass)
+  template <int NV> static MPMPC_HD void up1n(const R1* v, R1* o) {
+    if constexpr (Base::batched) Base::template upv<NV>(v, o);
+    else { for (int i = 0; i < NV; ++i) o[i] = up1(v[i]); }
+  }
+  template <int NV> static MPMPC_HD void down1n(const R1* v, R1* o) {
+    if constexpr (Base::batched) Base::template downv<NV>(v, o);
+    else { for (int i = 0; i < NV; ++i) o[i] = down1(v[i]); }
+  }
+  template <int NV> static MPMPC_HD void upv(const D2* v, D2* o) {
+    R1 t[NV], u[NV];
+    for (int i = 0; i < NV; ++i) t[i] = v[i].v[1];
+    up1n<NV>(t, u);
+    for (int i = 0; i < NV; ++i) o[i] = D2(u[i], v[i].v[0]);
+  }
+  template <int NV> static MPMPC_HD void downv(const D2* v, D2* o) {
+    R1 t[NV], u[NV];
+    for (int i = 0; i < NV; ++i) t[i] = v[i].v[0];
+    down1n<NV>(t, u);
+    for (int i = 0; i < NV; ++i) o[i] = D2(v[i].v[1], u[i]);
+  }
+  template <int NV> static MPMPC_HD void cupv(const D2* v, D2* o) { upv<NV>(v, o); }
+  template <int NV> static MPMPC_HD void cdownv(const D2* v, D2* o) { downv<NV>(v, o); }
+  template <int NV> static MPMPC_HD void mirrorv(const D2* v, D2* o) { for (int i = 0; i < NV; ++i) o[i] = v[i]; }
   // (one chain in stage order: the chain layout is the stage layout)
   static MPMPC_HD D2 mirror(const D2& a) { return a; }
   static MPMPC_HD D2 cup(const D2& a) { return up(a); }

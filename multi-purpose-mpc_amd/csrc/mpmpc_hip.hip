@@ -305,6 +305,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   }
 }
 
+// K2rb2: horizons 128 .. 255 with two stages per lane - the instance on a workgroup of TWO wavefronts (128 lanes, one chain of
+// eight rows; the lanes of the two wavefronts talk through LDS: LaneBlock<128, ., 128>) instead of four with one stage per lane.
+// Lean LDS - 37 pair slots (ReducedSolver::kLean) + 4 exchange rows = 80 000 B - so that TWO workgroups share a CU: four
+// wavefronts per CU, one per SIMD, and two instances per CU in flight where K2rb<256> (100 KB, 298 registers) holds one.
+constexpr int RNB2_SLOTS = 74, RNB2_XR = 4;
+using LanePairBlock = LanePair<LaneBlock<128, RNB2_SLOTS, 128, RNB2_XR>>;
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void mpmpc_reduced_pair_block_kernel(mpmpc_config cfg, SolverParams st, int B, AssembleIn ain,
+                                                           double* __restrict__ z, double* __restrict__ u0,
+                                                           int* __restrict__ status, int* __restrict__ iters,
+                                                           double* __restrict__ resid, double* __restrict__ y,
+                                                           int* __restrict__ tail) {
+  using L = LanePairBlock;
+  const I2 inst((int)blockIdx.x);
+  const I2 k = L::stage();
+  D2 fields[MPMPC_NUM_FIELDS];
+  assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
+  ReducedSolver<L> s;
+  static_assert(ReducedSolver<L>::kLean, "37 pair slots: the lean cold storage");
+  s.template run<false>(fields, B, inst, k, cfg.N, st);
+  s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y, nullptr, 0);
+  if (k.v[0] == 0 && inst.v[0] < B && s.status.v[0] == MPMPC_UNSOLVED) tail[1 + atomicAdd(tail, 1)] = inst.v[0];
+}
+
 // K2p2: the reduced-native TAIL solver (mpmpc_reduced_tail.hpp: phase 1 / Farkas ray / relaxed plan, one more attempt) with two
 // stages per lane - the tail of K2r2<64> at horizons 64 .. 127, one instance per wavefront, where the general solver on a workgroup
 // used to take all of it (40 % of an obstacle-course step at N = 100); what it leaves is listed in tail2 for that kernel.
@@ -1088,11 +1111,12 @@ int mpmpc_set_packing(mpmpc_handle h, int32_t lanes_per_instance) {
   if (!h) return fail(MPMPC_E_ARG, "handle is NULL");
   MPMPC_SETTLE(h);
   const int g = lanes_per_instance;
-  if (g != 0 && g != 16 && g != 32 && g != 64 && !(g == 128 && h->cfg.N + 1 > 64 && h->cfg.N + 1 <= 128))
-    return fail(MPMPC_E_ARG, "lanes_per_instance must be 0 (auto), 16, 32 or 64 (128: the workgroup kernel of horizons 64 .. 127)");
+  if (g != 0 && g != 16 && g != 32 && g != 64 && !(g == 128 && h->cfg.N + 1 > 64) && !(g == 256 && h->cfg.N + 1 > 128))
+    return fail(MPMPC_E_ARG, "lanes_per_instance must be 0 (auto), 16, 32 or 64 (128 / 256: the one-stage workgroup kernels of horizons 64 .. 127 / 128 .. 255)");
   // (16 lanes for 17 .. 32 stages: TWO stages per lane, four instances per wavefront - the reduced-native batch kernel only)
   // (64 / 128 at 65 .. 128 stages: two stages per lane in one wavefront - the default there - or the workgroup kernel)
-  const bool two = (g == 16 && h->cfg.N + 1 > 16 && h->cfg.N + 1 <= 32) || ((g == 64 || g == 128) && h->cfg.N + 1 > 64 && h->cfg.N + 1 <= 128);
+  const bool two = (g == 16 && h->cfg.N + 1 > 16 && h->cfg.N + 1 <= 32) || ((g == 64 || g == 128) && h->cfg.N + 1 > 64 && h->cfg.N + 1 <= 128) ||
+                   ((g == 128 || g == 256) && h->cfg.N + 1 > 128);
   if (g != 0 && h->cfg.N + 1 > g && !two) return fail(MPMPC_E_ARG, "lanes_per_instance must hold the N + 1 stages of an instance, or half of them at 16 (horizons above 63 take a workgroup: only 0)");
   h->force_lanes = g;
   return MPMPC_OK;
@@ -1563,6 +1587,19 @@ static int go_rblock(const SolveLaunch& a) {
   return MPMPC_OK;
 }
 
+static int go_pair_block(const SolveLaunch& a) {
+  mpmpc_handle h = a.h;
+  using LB = LaneBlock<128, RNB2_SLOTS, 128, RNB2_XR>;
+  static std::atomic<bool> attr_set[MAX_DEVICES];
+  if (!attr_set[device_slot(h)]) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpmpc_reduced_pair_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LB::lds_bytes));
+    attr_set[device_slot(h)] = true;
+  }
+  hipLaunchKernelGGL(mpmpc_reduced_pair_block_kernel, dim3(a.B), dim3(128), LB::lds_bytes, h->stream, h->cfg, a.prm, a.B, a.ain, h->z, h->u0, h->status, h->iters,
+                     h->resid, a.y_out, a.tail_cur);
+  return MPMPC_OK;
+}
+
 // Horizons above 63.  65 .. 128 stages of the reference's own weights (or of a terminal cost on the time state): TWO stages per
 // lane, the whole instance in ONE wavefront (K2r2<64> / K2t2<64>), its tail to K2p2<64>, what that leaves to the general solver on
 // a workgroup; mpmpc_set_packing(h, 128) keeps round 5's workgroup kernels.  Everything else - longer horizons, full weights,
@@ -1593,6 +1630,9 @@ static int launch_long_horizon(mpmpc_handle h, SolveLaunch& a, int tail_only) {
         go_pair_tail<64>(a);
         tail_blk = list2;
       }
+    } else if (N + 1 > 128 && h->force_lanes != 256) {
+      // 129 .. 256 stages: two stages per lane on a workgroup of two wavefronts (K2rb2; mpmpc_set_packing(h, 256): K2rb<256>)
+      if (int rc = go_pair_block(a)) return rc;
     } else if (int rc = (N + 1 <= 128 ? go_rblock<128>(a) : go_rblock<256>(a))) return rc;
   } else if (!fullqn && reduced_native_tt(h->cfg, h->st) && one_wave) {
     HIP_TRY(hipMemsetAsync(list1, 0, sizeof(int), h->stream));

@@ -61,7 +61,13 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
   enum { C_D = 0, C_E = 3, C_C = 5, K_LO0 = 6, K_HI0 = 7, K_LO2 = 8, K_HI2 = 9, C_V = 10, C_LAMV = 11, C_A20 = 12, C_BV = 13, C_BEQ2 = 14,
          C_G = 15, C_PI = 18, C_XS = 15, C_LAM = 18, C_NUS = 21, C_GAP = 23,
          K_PP = 24, K_QQ = 27, K_LEQ = 30, K_RD = 32, K_RP = 35, K_PARK = 32, COLD_USED = 40 };
-  static_assert(COLD_USED <= L::cold_slots, "lane backend has too few cold slots");
+  // LEAN cold storage (a backend with 37 .. 39 slots: the 128-lane workgroup of the pair layout, whose LDS must leave room for a
+  // second workgroup on the CU): the last three of the eight parked values go to the slots of the start's box-row scalings
+  // (C_G: read before the first interior-point iteration only) instead of three slots of their own, and a point that is not
+  // certified is not written over them (commit) - one instance per execution group only
+  static constexpr bool kLean = L::cold_slots < COLD_USED;
+  static_assert(L::cold_slots >= (kLean ? 37 : COLD_USED) && (!kLean || L::per_wave == 1), "lane backend has too few cold slots");
+  MPMPC_HD static constexpr int park_slot(int i) { return (!kLean || i < 5) ? K_PARK + i : C_G + (i - 5); }
   // a scaled bound beyond this is "infinite" (raw infinities are +-1e30, the Ruiz factors stay within [1e-4, 1e4] per pass)
   static constexpr double BOX_INF = 1e20;
   // Attempts: interior point to native_ipm_tol, active-set rounds, certificate; what the rounds cannot settle is taken up
@@ -558,8 +564,8 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
     MPMPC_UNROLL
     for (int b = 0; b < 2; ++b) {
       const int j = kSplit ? b : (b == 0 ? 0 : 2);
-      L::cold_put(K_PARK + 4 * b + 0, s.sl[j]); L::cold_put(K_PARK + 4 * b + 1, s.su[j]);
-      L::cold_put(K_PARK + 4 * b + 2, s.zl[j]); L::cold_put(K_PARK + 4 * b + 3, s.zu[j]);
+      L::cold_put(park_slot(4 * b + 0), s.sl[j]); L::cold_put(park_slot(4 * b + 1), s.su[j]);
+      L::cold_put(park_slot(4 * b + 2), s.zl[j]); L::cold_put(park_slot(4 * b + 3), s.zu[j]);
       L::cold_put(K_QQ + b, s.pi[j]);
     }
     // (the packed interior point's copies of cost and offsets are in registers again by now: their slots take the iterate)
@@ -573,8 +579,8 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
     MPMPC_UNROLL
     for (int b = 0; b < 2; ++b) {
       const int j = kSplit ? b : (b == 0 ? 0 : 2);
-      s.sl[j] = L::cold_get(K_PARK + 4 * b + 0); s.su[j] = L::cold_get(K_PARK + 4 * b + 1);
-      s.zl[j] = L::cold_get(K_PARK + 4 * b + 2); s.zu[j] = L::cold_get(K_PARK + 4 * b + 3);
+      s.sl[j] = L::cold_get(park_slot(4 * b + 0)); s.su[j] = L::cold_get(park_slot(4 * b + 1));
+      s.zl[j] = L::cold_get(park_slot(4 * b + 2)); s.zu[j] = L::cold_get(park_slot(4 * b + 3));
       s.pi[j] = L::cold_get(K_QQ + b);
     }
     MPMPC_UNROLL
@@ -594,7 +600,10 @@ struct ReducedSolver : Solver<L, false, true, false, CR> {
   // the certified point goes to cold storage (the slots of the start's G and pin multipliers, which are done with); with
   // `merge` a packed wave's later commit does not disturb what its partner instance has committed before
   MPMPC_HD void commit(const Mk& good, bool merge, const R xa[3], const R na[2], const R la[3], const R& prim, const R& stat) {
-    if (!merge) {
+    bool skip = false;
+    if constexpr (kLean) skip = !L::wany(good);          // (nothing certified: the slots still hold what a further attempt unparks)
+    if (skip) {
+    } else if (!merge) {
       MPMPC_UNROLL
       for (int e = 0; e < 3; ++e) { L::cold_put(C_XS + e, xa[e]); L::cold_put(C_LAM + e, la[e]); }
       L::cold_put(C_NUS, na[0]); L::cold_put(C_NUS + 1, na[1]);

@@ -174,8 +174,10 @@
       const T i11 = rsqrt_(fma_(-l10, l10, Dg[2].v[0]));
       const T i10 = -(l10 * i00) * i11;
       T Cm[4], Ua[4], Ub[4];
-      MPMPC_UNROLL
-      for (int i = 0; i < 4; ++i) Cm[i] = L::up1(Tc[i].v[1]);       // S_{e, a}: what the odd stage below hands up
+      {
+        const T t1[4] = {Tc[0].v[1], Tc[1].v[1], Tc[2].v[1], Tc[3].v[1]};
+        L::template up1n<4>(t1, Cm);                                 // S_{e, a}: what the odd stage below hands up
+      }
       Ub[0] = i00 * Tc[0].v[0]; Ub[1] = i00 * Tc[2].v[0];                         // inv(L_e) S_be'
       Ub[2] = fma_(i11, Tc[1].v[0], i10 * Tc[0].v[0]); Ub[3] = fma_(i11, Tc[3].v[0], i10 * Tc[2].v[0]);
       Ua[0] = i00 * Cm[0]; Ua[1] = i00 * Cm[1];
@@ -184,7 +186,12 @@
       D1[1] = fma_(-Ub[3], Ub[2], fma_(-Ub[1], Ub[0], Dg[1].v[1]));
       D1[2] = fma_(-Ub[3], Ub[3], fma_(-Ub[1], Ub[1], Dg[2].v[1]));
       const T w0 = fma_(Ua[2], Ua[2], Ua[0] * Ua[0]), w1 = fma_(Ua[3], Ua[2], Ua[1] * Ua[0]), w2 = fma_(Ua[3], Ua[3], Ua[1] * Ua[1]);
-      D1[0] = D1[0] - L::down1(w0); D1[1] = D1[1] - L::down1(w1); D1[2] = D1[2] - L::down1(w2);
+      {
+        const T wv[3] = {w0, w1, w2};
+        T wd[3];
+        L::template down1n<3>(wv, wd);
+        D1[0] = D1[0] - wd[0]; D1[1] = D1[1] - wd[1]; D1[2] = D1[2] - wd[2];
+      }
       C1[0] = -fma_(Ub[2], Ua[2], Ub[0] * Ua[0]);
       C1[1] = -fma_(Ub[2], Ua[3], Ub[0] * Ua[1]);
       C1[2] = -fma_(Ub[3], Ua[2], Ub[1] * Ua[0]);
@@ -281,8 +288,11 @@
       t0 = Li[0].v[0] * b0.v[0]; t1 = fma_(Li[2].v[0], b1.v[0], Li[1].v[0] * b0.v[0]);
       const T pb0 = fma_(Gout[2].v[0], t1, Gout[0].v[0] * t0), pb1 = fma_(Gout[3].v[0], t1, Gout[1].v[0] * t0);
       const T pa0 = fma_(Gin[2].v[0], t1, Gin[0].v[0] * t0), pa1 = fma_(Gin[3].v[0], t1, Gin[1].v[0] * t0);
-      c0 = b0.v[1] - pb0 - L::down1(pa0);
-      c1 = b1.v[1] - pb1 - L::down1(pa1);
+      const T pv[2] = {pa0, pa1};
+      T pd[2];
+      L::template down1n<2>(pv, pd);
+      c0 = b0.v[1] - pb0 - pd[0];
+      c1 = b1.v[1] - pb1 - pd[1];
       MPMPC_SERIAL_END(1);
     }
     T y0(0.0), y1(0.0);
@@ -325,7 +335,10 @@
     {
       // ---- level H backward: nu_e = inv(L_e)' (y_e - Ua nu_a - Ub nu_b),  nu_a from the lane below, nu_b in the lane
       MPMPC_SERIAL_BEGIN();
-      const T a0 = L::up1(n0), a1 = L::up1(n1);
+      const T nv[2] = {n0, n1};
+      T na[2];
+      L::template up1n<2>(nv, na);
+      const T a0 = na[0], a1 = na[1];
       const T r0 = fma_(-Gout[1].v[0], n1, fma_(-Gout[0].v[0], n0, fma_(-Gin[1].v[0], a1, fma_(-Gin[0].v[0], a0, t0))));
       const T r1 = fma_(-Gout[3].v[0], n1, fma_(-Gout[2].v[0], n0, fma_(-Gin[3].v[0], a1, fma_(-Gin[2].v[0], a0, t1))));
       nu[0] = R(fma_(Li[1].v[0], r1, Li[0].v[0] * r0), n0);

@@ -9,6 +9,7 @@
 #define MPMPC_TICK_END(i) ((void)0)
 #define MPMPC_TICK_COUNT(i) ((void)0)
 #include "lane_emu.hpp"
+#include "lane_pair.hpp"
 #include "mpmpc_core.hpp"
 #include "mpmpc_reduced.hpp"
 
@@ -97,6 +98,36 @@ extern "C" int emuw_solve_tail(const mpmpc_config* cfg, const mpmpc_settings* st
   if (reducible(*cfg, *st)) solve_wide_tail<2>(cfg, st, qp, B, z, u0, status, iters, resid, y, ids, n_ids);
   else solve_wide_tail<0>(cfg, st, qp, B, z, u0, status, iters, resid, y, ids, n_ids);      // (the terminal-time kernel's tail: the full problem)
   return 0;
+}
+
+// Horizons 128 .. 255 with TWO stages per lane: the instance on an emulated workgroup of 128 lanes - one chain of eight rows over
+// two wavefronts (mpmpc_reduced_pair_block_kernel; the 128-lane build only).  ids <- the instances it leaves UNSOLVED (*n of them):
+// they go to the general solver on 256 lanes (the 256-lane build's emuw_solve_tail).
+extern "C" int emuw_solve_rn_pair(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
+                                  int* status, int* iters, double* resid, double* y, int* ids, int* n) {
+#if MPMPC_EMU_W != 128
+  (void)cfg; (void)st; (void)qp; (void)B; (void)z; (void)u0; (void)status; (void)iters; (void)resid; (void)y; (void)ids; (void)n;
+  return -1;
+#else
+  {
+    if (stage_ld(cfg->N) != 256 || full_weights(*cfg) || !reduced_native(*cfg, *st)) return -1;
+    using L = LanePair<LaneEmu<128, 128, 74>>;          // (37 pair slots: the lean cold storage of the device kernel, ReducedSolver::kLean)
+    static_assert(ReducedSolver<L>::kLean, "lean cold storage");
+    const int ld = stage_ld(cfg->N);
+    *n = 0;
+    for (int w = 0; w < B; ++w) {
+      const I2 inst = L::slot() + w;
+      const I2 k = L::stage();
+      ReducedSolver<L> s;
+      typename L::real fields[MPMPC_NUM_FIELDS];
+      ReducedSolver<L>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+      s.template run<false>(fields, B, inst, k, cfg->N, make_params(*st));
+      s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y, nullptr, ld);
+      if (s.status.v[0].v[0] == MPMPC_UNSOLVED) ids[(*n)++] = w;
+    }
+    return 0;
+  }
+#endif
 }
 
 // the kernel the launcher picks for a horizon above 63: the general solver, one instance per workgroup; full weights

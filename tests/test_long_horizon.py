@@ -212,6 +212,32 @@ def test_two_stages_per_lane_in_one_wavefront_against_the_workgroup_emulation(N,
     assert np.max(np.abs(pair2.u0[u] - wg2.u0[u])) <= 1e-6 and np.max(np.abs(pair2.resid[:, 0] - wg2.resid[:, 0])) <= 1e-7
 
 
+@pytest.mark.parametrize("N,cfgid,B", [(128, 2, 6), (128, 4, 8), (129, 2, 4), (150, 4, 8), (191, 4, 6), (192, 2, 4), (200, 2, 6), (254, 2, 4), (255, 4, 8)])
+def test_two_stages_per_lane_on_a_workgroup_of_128_lanes(N, cfgid, B, emu, track):
+    """Horizons 128 .. 255 (round 6): the pair layout on a workgroup of TWO wavefronts - one chain of eight rows, the step from
+    row 3 to row 4 crossing the wavefronts through LDS - with the LEAN cold storage of the device kernel (37 pair slots:
+    ReducedSolver::kLean), against the 256-lane workgroup emulation of the same solver and the C oracle.  The loose first
+    tolerance of the second run forces repeated attempts: the parked iterate comes back from the slots it shares."""
+    tw = T.wide_track(track, emu, N)
+    sc = scenarios.make(cfgid, tw, B=B, N=N)
+    cfg = T.stock_config(N, sc.weights)
+    qp = emu.assemble(cfg, tw, (sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub))
+    ref = _oracle(track, sc, scenarios.WEIGHTS[sc.weights])
+    for kw in (dict(), dict(native_ipm_tol=3e-5), dict(native_ipm_tol=1e-2)):
+        st = mpmpc.default_settings(phase1_accept=0, **kw)
+        pair = emu.solve(cfg, st, qp)                  # the launcher's sequence: K2rb2, then the 256-lane workgroup kernel on its list
+        wg = emu.solve(cfg, st, qp, G=256)             # mpmpc_set_packing(h, 256): round 5's kernels alone
+        assert np.array_equal(pair.status, wg.status) and np.array_equal(pair.iters, wg.iters)
+        ok = pair.status == 1
+        assert ok.sum() >= B // 2 and np.max(np.abs(pair.u0[ok] - wg.u0[ok])) <= 1e-13 and np.max(np.abs(pair.z[ok] - wg.z[ok])) <= 1e-10
+        assert np.array_equal(pair.status, ref["status"]) and np.max(np.abs(pair.u0[ok] - ref["u0"][ok])) <= 1e-6
+        prim, stat, comp = T.kkt_batch(qp[:, ok, :], N, pair.z[ok], pair.y[ok])
+        assert max(prim.max(), stat.max(), comp.max()) <= 1e-8
+    # (at 1e-2 the first attempt of an obstacle-course instance stops too early for its active-set rounds and is taken up again at
+    #  1e-4 from the iterate the lean storage parked - measured: 6 - 7 iterations where 3e-5 takes 5; the lean and the full storage
+    #  give the same iterates bit for bit, which is what the equality above checks)
+
+
 @pytest.mark.parametrize("N,B", [(64, 8), (70, 12), (96, 6), (100, 8), (127, 8)])
 def test_terminal_time_kernel_with_two_stages_per_lane_at_long_horizons(N, B, emu, track):
     """Time-optimal weights (a terminal cost on the time state, README.md:56 of the reference) at horizons 64 .. 127: the
@@ -290,22 +316,23 @@ def test_long_horizons_on_device(N, cfgid, track, emu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,cfgid", [(64, 4), (100, 2), (127, 4)])
+@pytest.mark.parametrize("N,cfgid", [(64, 4), (100, 2), (127, 4), (128, 4), (200, 2), (255, 4)])
 def test_pair_kernel_and_workgroup_kernel_agree_on_device(N, cfgid, track, emu):
-    """Horizons 64 .. 127: the default (two stages per lane, one wavefront per instance) against mpmpc_set_packing(h, 128) (the
-    workgroup kernels of round 5) on 512 instances: statuses, iteration counts of the certified instances, controls to 1e-12."""
+    """Horizons 64 .. 255: the default (two stages per lane: one wavefront per instance up to 127, a workgroup of two above)
+    against mpmpc_set_packing(h, 128 / 256) (the one-stage workgroup kernels of round 5) on 512 instances: statuses, iteration
+    counts of the certified instances, controls to 1e-12."""
     B = 512
     tw = T.wide_track(track, emu, N)
     sc = scenarios.make(cfgid, tw, B=B, N=N)
     cfg = T.stock_config(N, sc.weights, max_batch=B)
     sols = {}
-    for lanes in (0, 128):
+    for lanes in (0, 128 if N < 128 else 256):
         h = mpmpc.Handle(cfg, mpmpc.default_settings())
         h.set_path(track.kappa, track.v_ref, track.ds_next)
         h.set_packing(lanes)
         sols[lanes] = h.solve(sc.wp_id, sc.x0, sc.cc_prev, sc.lb, sc.ub, want_y=True)
         h.close()
-    a, b = sols[0], sols[128]
+    a, b = sols[0], sols[128 if N < 128 else 256]
     assert np.array_equal(a.status, b.status)
     ok = a.status == 1
     assert ok.mean() > 0.5 and np.max(np.abs(a.iters[ok, 1] - b.iters[ok, 1])) <= 1 and (a.iters[ok, 1] != b.iters[ok, 1]).sum() <= 2
