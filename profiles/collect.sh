@@ -4,7 +4,7 @@
 # Raw output lands in gpurun_out/<round>/ (scratch); profiles/summarize.py turns it into the
 # committed summaries under profiles/<round>/.
 set -u
-ROUND=${1:-r5}
+ROUND=${1:-r6}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$ROUND
 mkdir -p "$O"

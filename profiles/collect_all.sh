@@ -2,7 +2,7 @@
 # everything profiles/<round> is made of, on one box, for the library in the tree:
 #   /usr/local/graft/bin/gpurun --timeout 2700 -- 'bash profiles/collect_all.sh r5'
 # then here:  python profiles/finish_collect.py r5
-R=${1:-r5}
+R=${1:-r6}
 bash profiles/collect.sh $R > /dev/null 2>&1
 bash profiles/collect_wait.sh ${R}w > /dev/null 2>&1
 bash profiles/phases.sh $R > /dev/null 2>&1

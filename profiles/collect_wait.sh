@@ -8,7 +8,7 @@
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash profiles/collect_wait.sh r3a'
 # profiles/summarize_wait.py condenses gpurun_out/<tag>/ into profiles/r3/pmc_wait_<tag>.json
 set -u
-TAG=${1:-r5w}
+TAG=${1:-r6w}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"

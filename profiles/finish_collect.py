@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r5"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r6"
 os.chdir(ROOT)
 for cmd in (["profiles/summarize.py", RND], ["profiles/summarize_wait.py", RND + "w", RND], ["profiles/kernel_resources.py", RND]):
     subprocess.run([sys.executable] + cmd, check=True, stdout=subprocess.DEVNULL)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-wave phase clocks of K2 (profiling build of the library, -DMPMPC_PHASE_CLOCK) for the configurations of a round:
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash profiles/phases.sh r2'
-R=${1:-r5}
+R=${1:-r6}
 mkdir -p profiles/_ab gpurun_out/$R
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -DMPMPC_PHASE_CLOCK \
     -Iinclude -o profiles/_ab/P.so multi-purpose-mpc_amd/csrc/mpmpc_hip.hip || exit 1

@@ -8,7 +8,7 @@ import os
 import shutil
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r5"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r6"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O, P = os.path.join(root, "gpurun_out", rnd), os.path.join(root, "profiles", rnd)
 os.makedirs(P, exist_ok=True)
