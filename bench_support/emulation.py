@@ -97,16 +97,25 @@ class Emul:
                                                 _d(rs), _d(yy), _i(ids), C.c_int(ids.size))
             assert rc == 0
             return mpmpc.Solution(z, u0, st, it, rs, y)
-        if 128 < N + 1 <= 256 and G != 256 and self.lib.emu_reduced_native(C.byref(cfg), C.byref(settings)):
+        if 128 < N + 1 <= 256 and G != 256 and (self.lib.emu_reduced_native(C.byref(cfg), C.byref(settings)) or
+                                                self.lib.emu_reduced_native_tt(C.byref(cfg), C.byref(settings))):
             # horizons 128 .. 255: the reduced-native solver with two stages per lane on a workgroup of 128 lanes, then the
             # general solver on 256 lanes (mode 2) on what it lists (G = 256: the 256-lane workgroup kernels alone, as
             # mpmpc_set_packing(h, 256))
             yy = y if want_y else np.zeros((B, m))
             ids, n = np.zeros(B, np.int32), C.c_int(0)
-            rc = self.wide(128).emuw_solve_rn_pair(C.byref(cfg), C.byref(settings), _d(qp), C.c_int(B), _d(z), _d(u0), _i(st), _i(it),
-                                                   _d(rs), _d(yy), _i(ids), C.byref(n))
+            tt = bool(self.lib.emu_reduced_native_tt(C.byref(cfg), C.byref(settings)))
+            fn = self.wide(128).emuw_solve_rnt_pair if tt else self.wide(128).emuw_solve_rn_pair
+            rc = fn(C.byref(cfg), C.byref(settings), _d(qp), C.c_int(B), _d(z), _d(u0), _i(st), _i(it), _d(rs), _d(yy), _i(ids), C.byref(n))
             assert rc == 0
             ids = np.ascontiguousarray(ids[:n.value])
+            if ids.size and not tt and self.lib.emu_reduced_native_tail(C.byref(cfg), C.byref(settings)):
+                # ... the tail solver on the same workgroup layout first (mpmpc_reduced_tail_pair_block_kernel)
+                ids2, n2 = np.zeros(ids.size, np.int32), C.c_int(0)
+                rc = self.wide(128).emuw_solve_rn_tail_pair(C.byref(cfg), C.byref(settings), _d(qp), C.c_int(B), _d(z), _d(u0), _i(st), _i(it),
+                                                            _d(rs), _d(yy), _i(ids), C.c_int(ids.size), _i(ids2), C.byref(n2))
+                assert rc == 0
+                ids = np.ascontiguousarray(ids2[:n2.value])
             rc = self.wide(256).emuw_solve_tail(C.byref(cfg), C.byref(settings), _d(qp), C.c_int(B), _d(z), _d(u0), _i(st), _i(it),
                                                 _d(rs), _d(yy), _i(ids), C.c_int(ids.size))
             assert rc == 0

@@ -328,6 +328,44 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (k.v[0] == 0 && inst.v[0] < B && s.status.v[0] == MPMPC_UNSOLVED) tail[1 + atomicAdd(tail, 1)] = inst.v[0];
 }
 
+// ... its tail (K2p's solver) and its twin for a terminal cost on the time state (K2t's solver) on the same workgroup layout, with
+// the FULL cold storage (80 slots + 4 exchange rows = 86 KB: one workgroup per CU - the tail is a tenth of a batch, and the
+// terminal-time weights ran the general 3-state solver on FOUR wavefronts before: 0.19 M solves/s at N = 150)
+using LanePairBlockFull = LanePair<LaneBlock<128, RN2_SLOTS, 128, RNB2_XR>>;
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void mpmpc_reduced_tail_pair_block_kernel(mpmpc_config cfg, SolverParams st, int B, AssembleIn ain,
+                                                           double* __restrict__ z, double* __restrict__ u0,
+                                                           int* __restrict__ status, int* __restrict__ iters,
+                                                           double* __restrict__ resid, double* __restrict__ y,
+                                                           const int* __restrict__ tail, int* __restrict__ tail2) {
+  using L = LanePairBlockFull;
+  if ((int)blockIdx.x >= tail[0]) return;
+  const int in0 = tail[1 + blockIdx.x];
+  const I2 inst(in0);
+  const I2 k = L::stage();
+  D2 fields[MPMPC_NUM_FIELDS];
+  assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
+  ReducedTailSolver<L> s;
+  const int base = iters ? iters[in0 * 2 + 1] : 0;
+  s.run(fields, B, inst, k, cfg.N, st, I2(base));
+  s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y);
+  if (k.v[0] == 0 && s.status.v[0] == MPMPC_UNSOLVED) tail2[1 + atomicAdd(tail2, 1)] = in0;
+}
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void mpmpc_reduced_t_pair_block_kernel(mpmpc_config cfg, SolverParams st, int B, AssembleIn ain,
+                                                           double* __restrict__ z, double* __restrict__ u0,
+                                                           int* __restrict__ status, int* __restrict__ iters,
+                                                           double* __restrict__ resid, double* __restrict__ y,
+                                                           int* __restrict__ tail) {
+  using L = LanePairBlockFull;
+  const I2 inst((int)blockIdx.x);
+  const I2 k = L::stage();
+  D2 fields[MPMPC_NUM_FIELDS];
+  assemble_fields<L>(cfg, ain.tab, B, inst, k, ain.wp_id, ain.x0, ain.cc, ain.lb, ain.ub, fields);
+  ReducedTSolver<L> s;
+  s.run(fields, B, inst, k, cfg.N, st, cfg.QN[2]);
+  s.store(inst, k, cfg.wheelbase, z, u0, status, iters, resid, y);
+  if (k.v[0] == 0 && inst.v[0] < B && s.status.v[0] == MPMPC_UNSOLVED) tail[1 + atomicAdd(tail, 1)] = inst.v[0];
+}
+
 // K2p2: the reduced-native TAIL solver (mpmpc_reduced_tail.hpp: phase 1 / Farkas ray / relaxed plan, one more attempt) with two
 // stages per lane - the tail of K2r2<64> at horizons 64 .. 127, one instance per wavefront, where the general solver on a workgroup
 // used to take all of it (40 % of an obstacle-course step at N = 100); what it leaves is listed in tail2 for that kernel.
@@ -1600,6 +1638,31 @@ static int go_pair_block(const SolveLaunch& a) {
   return MPMPC_OK;
 }
 
+static int go_pair_block_tail(const SolveLaunch& a) {
+  mpmpc_handle h = a.h;
+  using LB = LaneBlock<128, RN2_SLOTS, 128, RNB2_XR>;
+  static std::atomic<bool> attr_set[MAX_DEVICES];
+  if (!attr_set[device_slot(h)]) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpmpc_reduced_tail_pair_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LB::lds_bytes));
+    attr_set[device_slot(h)] = true;
+  }
+  hipLaunchKernelGGL(mpmpc_reduced_tail_pair_block_kernel, dim3(a.B), dim3(128), LB::lds_bytes, h->stream, h->cfg, a.prm, a.B, a.ain, h->z, h->u0, h->status,
+                     h->iters, h->resid, a.y_out, a.tail_cur, a.tail_next);
+  return MPMPC_OK;
+}
+static int go_pair_block_t(const SolveLaunch& a) {
+  mpmpc_handle h = a.h;
+  using LB = LaneBlock<128, RN2_SLOTS, 128, RNB2_XR>;
+  static std::atomic<bool> attr_set[MAX_DEVICES];
+  if (!attr_set[device_slot(h)]) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpmpc_reduced_t_pair_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LB::lds_bytes));
+    attr_set[device_slot(h)] = true;
+  }
+  hipLaunchKernelGGL(mpmpc_reduced_t_pair_block_kernel, dim3(a.B), dim3(128), LB::lds_bytes, h->stream, h->cfg, a.prm, a.B, a.ain, h->z, h->u0, h->status,
+                     h->iters, h->resid, a.y_out, a.tail_cur);
+  return MPMPC_OK;
+}
+
 // Horizons above 63.  65 .. 128 stages of the reference's own weights (or of a terminal cost on the time state): TWO stages per
 // lane, the whole instance in ONE wavefront (K2r2<64> / K2t2<64>), its tail to K2p2<64>, what that leaves to the general solver on
 // a workgroup; mpmpc_set_packing(h, 128) keeps round 5's workgroup kernels.  Everything else - longer horizons, full weights,
@@ -1631,12 +1694,22 @@ static int launch_long_horizon(mpmpc_handle h, SolveLaunch& a, int tail_only) {
         tail_blk = list2;
       }
     } else if (N + 1 > 128 && h->force_lanes != 256) {
-      // 129 .. 256 stages: two stages per lane on a workgroup of two wavefronts (K2rb2; mpmpc_set_packing(h, 256): K2rb<256>)
+      // 129 .. 256 stages: two stages per lane on a workgroup of two wavefronts (K2rb2; mpmpc_set_packing(h, 256): K2rb<256>), its
+      // tail to the tail solver on the same layout (the list it fills is emptied first: no kernel of this sequence does it)
       if (int rc = go_pair_block(a)) return rc;
+      if (h->lean_tail && reduced_native_tail(h->cfg, h->st)) {
+        HIP_TRY(hipMemsetAsync(list2, 0, sizeof(int), h->stream));
+        a.tail_next = list2;
+        if (int rc = go_pair_block_tail(a)) return rc;
+        tail_blk = list2;
+      }
     } else if (int rc = (N + 1 <= 128 ? go_rblock<128>(a) : go_rblock<256>(a))) return rc;
-  } else if (!fullqn && reduced_native_tt(h->cfg, h->st) && one_wave) {
+  } else if (!fullqn && reduced_native_tt(h->cfg, h->st) && (one_wave || (N + 1 > 128 && h->force_lanes != 256))) {
+    // a terminal cost on the time state: K2t's solver with two stages per lane - one wavefront per instance up to 128 stages, a
+    // workgroup of two above - and the general workgroup kernel on what it lists
     HIP_TRY(hipMemsetAsync(list1, 0, sizeof(int), h->stream));
-    go_pair_t<64>(a);
+    if (one_wave) go_pair_t<64>(a);
+    else if (int rc = go_pair_block_t(a)) return rc;
     tail_blk = list1;
   }
   if (int rc = kBlock[N + 1 <= 128 ? 0 : 1][var](a, tail_blk)) return rc;

@@ -12,6 +12,8 @@
 #include "lane_pair.hpp"
 #include "mpmpc_core.hpp"
 #include "mpmpc_reduced.hpp"
+#include "mpmpc_reduced_t.hpp"
+#include "mpmpc_reduced_tail.hpp"
 
 using namespace mpmpc;
 static_assert(EMU_W == 128 || EMU_W == 256, "build with -DMPMPC_EMU_W=128 or 256");
@@ -127,6 +129,57 @@ extern "C" int emuw_solve_rn_pair(const mpmpc_config* cfg, const mpmpc_settings*
     }
     return 0;
   }
+#endif
+}
+
+// ... its twin for a terminal cost on the time state (mpmpc_reduced_t_pair_block_kernel; full cold storage: one workgroup per CU)
+extern "C" int emuw_solve_rnt_pair(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
+                                   int* status, int* iters, double* resid, double* y, int* ids, int* n) {
+#if MPMPC_EMU_W != 128
+  (void)cfg; (void)st; (void)qp; (void)B; (void)z; (void)u0; (void)status; (void)iters; (void)resid; (void)y; (void)ids; (void)n;
+  return -1;
+#else
+  if (stage_ld(cfg->N) != 256 || full_weights(*cfg) || !reduced_native_tt(*cfg, *st)) return -1;
+  using L = LanePair<LaneEmu<128, 128>>;
+  const int ld = stage_ld(cfg->N);
+  *n = 0;
+  for (int w = 0; w < B; ++w) {
+    const I2 inst = L::slot() + w;
+    const I2 k = L::stage();
+    ReducedTSolver<L> s;
+    typename L::real fields[MPMPC_NUM_FIELDS];
+    ReducedTSolver<L>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    s.run(fields, B, inst, k, cfg->N, make_params(*st), cfg->QN[2]);
+    s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y);
+    if (s.status.v[0].v[0] == MPMPC_UNSOLVED) ids[(*n)++] = w;
+  }
+  return 0;
+#endif
+}
+// ... and the reduced-native TAIL solver on the same workgroup, on a list of instances (mpmpc_reduced_tail_pair_block_kernel);
+// ids2 <- what it leaves
+extern "C" int emuw_solve_rn_tail_pair(const mpmpc_config* cfg, const mpmpc_settings* st, const double* qp, int B, double* z, double* u0,
+                                       int* status, int* iters, double* resid, double* y, const int* ids, int n_ids, int* ids2, int* n2) {
+#if MPMPC_EMU_W != 128
+  (void)cfg; (void)st; (void)qp; (void)B; (void)z; (void)u0; (void)status; (void)iters; (void)resid; (void)y; (void)ids; (void)n_ids; (void)ids2; (void)n2;
+  return -1;
+#else
+  if (stage_ld(cfg->N) != 256 || !reduced_native_tail(*cfg, *st)) return -1;
+  using L = LanePair<LaneEmu<128, 128>>;
+  const int ld = stage_ld(cfg->N);
+  *n2 = 0;
+  for (int j = 0; j < n_ids; ++j) {
+    const int id = ids[j];
+    const I2 inst = I2(id), base = I2(iters[id * 2 + 1]);
+    const I2 k = L::stage();
+    ReducedTailSolver<L> s;
+    typename L::real fields[MPMPC_NUM_FIELDS];
+    ReducedTailSolver<L>::fetch_fields(qp, B, ld, inst, k, cfg->N, fields);
+    s.run(fields, B, inst, k, cfg->N, make_params(*st), base);
+    s.store(inst, k, cfg->wheelbase, z, u0, status, iters, resid, y);
+    if (s.status.v[0].v[0] == MPMPC_UNSOLVED) ids2[(*n2)++] = id;
+  }
+  return 0;
 #endif
 }
 

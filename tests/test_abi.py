@@ -111,14 +111,18 @@ def test_pair_layout_kernel_fits_one_wave_per_simd(lib):
     """mpmpc_reduced_pair_kernel (two stages per lane, csrc/lane_pair.hpp): twice the per-lane state of the one-stage kernels -
     one wavefront per SIMD, four per CU: at most 512 registers, 40 KB of LDS (80 slots), and the three dwords of scratch it
     was measured with (a regression fails)."""
-    rows = {r["name"]: r for r in _kernel_rows(lib) if r["name"].startswith(("mpmpc_reduced_pair_kernel", "mpmpc_reduced_t_pair_kernel", "mpmpc_reduced_tail_pair_kernel", "mpmpc_reduced_pair_block_kernel"))}
-    assert sorted(rows) == ["mpmpc_reduced_pair_block_kernel", "mpmpc_reduced_pair_kernel<16>", "mpmpc_reduced_pair_kernel<64>", "mpmpc_reduced_t_pair_kernel<64>",
-                            "mpmpc_reduced_tail_pair_kernel<64>"], rows
+    rows = {r["name"]: r for r in _kernel_rows(lib) if r["name"].startswith(("mpmpc_reduced_pair_kernel", "mpmpc_reduced_t_pair_kernel", "mpmpc_reduced_tail_pair_kernel", "mpmpc_reduced_pair_block_kernel",
+                                                                            "mpmpc_reduced_t_pair_block_kernel", "mpmpc_reduced_tail_pair_block_kernel"))}
+    assert sorted(rows) == sorted(["mpmpc_reduced_pair_kernel<16>", "mpmpc_reduced_pair_kernel<64>", "mpmpc_reduced_t_pair_kernel<64>",
+                                   "mpmpc_reduced_tail_pair_kernel<64>", "mpmpc_reduced_pair_block_kernel", "mpmpc_reduced_t_pair_block_kernel",
+                                   "mpmpc_reduced_tail_pair_block_kernel"]), rows
     for name, r in rows.items():
         # <16>: four instances per wavefront (horizons 16 .. 31, behind set_packing(16)); <64>: one instance of 65 .. 128 stages per
         # wavefront (the default at horizons 64 .. 127, and its twin for a terminal cost on the time state) - no scratch there
         # (the workgroup kernel of horizons 128 .. 255: its cold slots are dynamic LDS - 80 000 B, two workgroups per CU)
-        assert r["vgpr"] <= 512 and r["lds"] <= 40 * 1024 and r["scratch"] <= (12 if name.endswith("<16>") else 0), r
+        # (... and the terminal-time solver on that workgroup, the one kernel of the family that spills: 164 B, measured when listed)
+        known = {"mpmpc_reduced_pair_kernel<16>": 12, "mpmpc_reduced_t_pair_block_kernel": 164}
+        assert r["vgpr"] <= 512 and r["lds"] <= 40 * 1024 and r["scratch"] <= known.get(name, 0), r
 
 
 def test_no_batch_path_solve_kernel_has_scratch(lib):
