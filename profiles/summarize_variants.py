@@ -37,6 +37,10 @@ CO = {re.sub(r"\s+", " ", r["name"]).replace("mpmpc::", ""): {"vgpr": r["vgpr"],
       for r in kernel_resources.kernel_table()}
 # dynamic LDS of the workgroup kernels (lane_gpu.hpp: LaneBlock::lds_bytes; mpmpc_hip.hip: RNB_SLOTS = 40, general 66 slots)
 def dyn_lds(k):
+    if k.startswith("mpmpc_reduced_pair_block_kernel"):          # LaneBlock<128, 74, 128, 4>: 37 pair slots + 4 exchange rows
+        return 8 * ((74 + 4) * 128 + 8 + 8)
+    if k.startswith(("mpmpc_reduced_t_pair_block_kernel", "mpmpc_reduced_tail_pair_block_kernel")):      # <128, 80, 128, 4>
+        return 8 * ((80 + 4) * 128 + 8 + 8)
     m = re.match(r"mpmpc_(reduced|solve)_block_kernel<(\d+)", k)
     if not m:
         return 0
@@ -85,6 +89,10 @@ for name in names:
             d["valu_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
             wg = d.get("resources", {}).get("workgroup", 64)
             inst_per_launch = c["SQ_WAVES"] * 64 / max(wg, 64) if wg > 64 else None      # workgroup kernels: one instance per workgroup
+            if inst_per_launch is None and (k.startswith("mpmpc_reduced_pair_kernel<64>") or k.startswith("mpmpc_reduced_t_pair_kernel<64>")):
+                inst_per_launch = c["SQ_WAVES"]          # one instance per wavefront
+            if inst_per_launch is None and k.startswith("mpmpc_reduced_pair_kernel<16>"):
+                inst_per_launch = 4 * c["SQ_WAVES"]
             if inst_per_launch:
                 d["valu_per_instance"] = c["SQ_INSTS_VALU"] / inst_per_launch
             elif k.startswith("mpmpc_solve_kernel<64"):          # the general wavefront kernels: one instance per wave
@@ -103,7 +111,7 @@ for name in names:
     out[name] = v
 json.dump(out, open(os.path.join(P, "variants.json"), "w"), indent=1, sort_keys=True)
 
-lines = ["# Kernel variants round 5 added, measured (profiles/collect_variants.sh -> profiles/summarize_variants.py)", "",
+lines = ["# Kernel variants beside the BASELINE configurations, measured (profiles/collect_variants.sh -> profiles/summarize_variants.py)", "",
          "Library: %s.  One resident batch, HIP-timed regions of 20 launches (median of 5); per kernel: rocprofv3 `--kernel-trace --stats`" % next(iter(out.values()))["library"],
          "average of the same command, registers / scratch / static LDS from the code object (profiles/kernel_resources.py), SQ counters from two `--pmc` passes.", "",
          "| variant | N | B | lanes / instance | solves/s, 1 launch in flight | 4 in flight | interior-point iterations mean (max) | statuses |",
