@@ -605,7 +605,7 @@ def _main(real_stdout):
     # launches in flight - the chip holds fewer kernels at its two ends - which a long-running caller does not.  Reported
     # beside `value` (value_200_step_regions, ramp_drain_share), never as it.
     dt200 = None
-    if not args.dry_run and args.steps < 200:
+    if not args.dry_run and args.steps < 200 and not args.no_extra_legs:          # (not under the profiler: 1 000 more launches per pass)
         d2 = []
         for _ in range(5):
             barrier()
