@@ -243,7 +243,9 @@ class Handle:
         self._check(self.lib.mpmpc_set_settings(self._h, C.byref(settings)))
 
     def set_packing(self, lanes_per_instance: int = 0):
-        """0 = automatic; 64 / 32 / 16 force that many lanes of a wavefront per instance (tests, tuning)."""
+        """0 = automatic; 64 / 32 / 16 force that many lanes of a wavefront per instance (tests, tuning).  16 at horizons
+        16 .. 31: two stages per lane, four instances per wavefront (measured slower than 32: never automatic).  Horizons above
+        63: 128 (N <= 127) / 256 (N >= 128) select the one-stage workgroup kernels instead of the two-stages-per-lane default."""
         self._check(self.lib.mpmpc_set_packing(self._h, int(lanes_per_instance)))
 
     def set_tail_kernel(self, reduced_native: bool = True):

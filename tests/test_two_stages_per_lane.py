@@ -66,6 +66,30 @@ def test_two_stages_per_lane_reach_the_g5_optima_of_the_reference_qps(emu, track
     assert np.max(np.abs(sol.z[ok][:, -2 * N:-2 * N + 2] - g5["x"][ok][:, -2 * N:-2 * N + 2])) < 1e-8
 
 
+def test_census_of_the_pair_layout(track):
+    """Step A of VERDICT r5 item 1, kept as a test: the counting build of the emulation executes at least 25 % fewer wave-level
+    operations PER INSTANCE in the pair layout than in the shipped <32,16> packing on config 2 (profiles/census_s2.py prints the
+    classes; 32.7 % at B = 1 024).  What the device makes of it - AGPR moves, one wave per SIMD - is DESIGN.md section 4 K2r2."""
+    import ctypes as C
+    import os
+    e = T.Emul()
+    e.lib = C.CDLL(os.path.join(T.ROOT, "tests", "_build", "libmpmpc_emul_count.so"))
+    B = 128
+    sc = scenarios.make(2, track, B=B)
+    cfg = T.stock_config(sc.N, sc.weights)
+    qp = e.assemble(cfg, track, _inputs(sc))
+    out = (C.c_longlong * 7)()
+    w = dict(fma=1, addmul=1, rcp=4, rsqrt=6, cmpsel=1.6, shift=2)          # VALU instructions per operation class (lane_gpu.hpp)
+    per_instance = {}
+    for G, per_wave, red in ((32, 2, 15), (16, 4, 12)):
+        e.lib.emu_op_count(out, 1)
+        e.solve_rn(cfg, mpmpc.default_settings(), qp, G=G)
+        e.lib.emu_op_count(out, 1)
+        c = dict(zip(("fma", "addmul", "rcp", "rsqrt", "cmpsel", "shift", "reduce"), out))
+        per_instance[G] = (sum(w[k] * c[k] for k in w) + red * c["reduce"]) / B
+    assert per_instance[16] <= 0.75 * per_instance[32], per_instance
+
+
 def test_the_pair_layout_is_refused_where_it_does_not_apply(emu, track):
     """16 lanes hold at most 32 stages, and only the reduced-native batch kernel has the layout (time-optimal weights: no)."""
     sc = scenarios.make(3, track, B=4, N=30)
