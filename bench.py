@@ -12,6 +12,13 @@ instances are independent) and `value` is the whole-job rate.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5] [--batch B]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --single-process        # ONE process drives the N devices (no torch, no process group): same line schema
+  python bench.py --gpus N [--single-process] --dry-run   # rehearsal of either multi-GPU path on a box without GPUs (value: null)
+  ... --no-extra-legs                               # under a profiler: the timed loop's kernels only
+
+Beside `value` (median of >= 25 regions of exactly K steps, four resident launches in flight) the line carries `value_200_step_regions`
+/ `ramp_drain_share` (the same loop in long regions), `value_one_launch_in_flight` (a caller whose step k + 1 needs step k),
+`admm_stock_mode` (the restated OSQP alone), `roofline` (HBM; + `roofline_fp64`, `roofline_assembly`), `cpu_baseline` (+ `_stock`).
 
 `--gpus N` with N > 1 and no launcher environment (RANK / WORLD_SIZE unset) starts the N ranks itself: this
 process, which has not touched a GPU yet, runs `python -m torch.distributed.run --nproc-per-node N bench.py ...`
