@@ -153,3 +153,25 @@ def test_two_stages_per_lane_on_device_against_the_c_oracle(cfgid, B, N, track, 
     solved = e.status == 1
     assert np.array_equal(two.status[:nn][solved], e.status[solved]) and np.array_equal(two.iters[:nn][solved], e.iters[solved])
     assert np.max(np.abs(two.z[:nn][solved] - e.z[solved])) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_pair_kernel_reaches_the_g5_optima_of_the_reference_qps_on_device(track):
+    """The reference's own captured inputs at N = 30 (golden G4: what it handed to osqp.setup) through libmpmpc.so with
+    mpmpc_set_packing(h, 16): the statuses of G5 (certified optimum or certified infeasible for every capture) and its optima to
+    1e-6 - the bar the one-stage kernels are held to (tests/test_gpu_parity.py)."""
+    import mpc_np as M
+    N = 30
+    g4 = np.load(M.GOLDEN + "/g4_assembly_N%d.npz" % N)
+    g5 = np.load(M.GOLDEN + "/g5_solutions_N%d.npz" % N)
+    B = g4["wp_id"].size
+    cfg = T.stock_config(N, str(g4["weights"][0]), max_batch=B)
+    h = mpmpc.Handle(cfg, mpmpc.default_settings(phase1_accept=0))
+    h.set_path(track.kappa, track.v_ref, track.ds_next)
+    h.set_packing(16)
+    sol = h.solve(g4["wp_id"].astype(np.int32), g4["x0"], g4["cc_prev"], g4["lb"], g4["ub"], want_y=True)
+    h.close()
+    assert np.array_equal(sol.status, g5["status"])
+    ok = g5["status"] == 1
+    assert np.max(np.abs(sol.z[ok] - g5["x"][ok])) < 1e-6
+    assert np.max(np.abs(sol.z[ok][:, -2 * N:-2 * N + 2] - g5["x"][ok][:, -2 * N:-2 * N + 2])) < 1e-8
